@@ -1,0 +1,154 @@
+"""ctypes binding of libabcsmc_hip.so -- exactly the symbols include/abcsmc_hip.h declares."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libabcsmc_hip.so")
+
+PRIOR_GAUSS, PRIOR_UNIF_INT, PRIOR_UNIF_REAL = 0, 1, 2
+RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
+
+
+class LibraryMissing(ImportError):
+    pass
+
+
+class AbcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("abcsmc_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Prior(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
+
+
+class Rng(C.Structure):
+    _fields_ = [("s1", C.c_uint32), ("s2", C.c_uint32), ("s3", C.c_uint32)]
+
+
+class GenerationCfg(C.Structure):
+    _fields_ = [("N", C.c_size_t), ("M", C.c_size_t), ("P", C.c_size_t),
+                ("K", C.c_size_t), ("Kp", C.c_size_t), ("Nnext", C.c_size_t),
+                ("train_frac", C.c_double),
+                ("max_comp", C.c_int32), ("rule", C.c_int32), ("multivariate", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class GenerationIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "X", "Y", "obs", "priors", "theta_prev", "w_prev", "dv_prev", "idx", "dist", "theta", "w",
+        "dv", "L", "next", "parent", "seeds")]
+
+
+def make_priors(spec):
+    arr = (Prior * len(spec))()
+    for i, (k, a, b) in enumerate(spec):
+        arr[i].kind, arr[i].a, arr[i].b = int(k), float(a), float(b)
+    return arr
+
+
+# symbol -> (restype, argtypes); MUST list every function declared in include/abcsmc_hip.h
+_vp, _sz, _u64, _i, _d = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_double
+SIGNATURES = {
+    "abc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "abc_ctx_destroy": (None, [_vp]),
+    "abc_last_error": (C.c_char_p, [_vp]),
+    "abc_ctx_set_stream": (_i, [_vp, _vp]),
+    "abc_ctx_synchronize": (_i, [_vp]),
+    "abc_version": (_i, []),
+    "abc_rng_set": (None, [_vp, C.c_ulong]),
+    "abc_rng_get": (C.c_uint32, [_vp]),
+    "abc_rng_jump": (None, [_vp, _u64]),
+    "abc_particle_ranking_pls": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _d, _i, _i, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "abc_particle_ranking_simple": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "abc_calculate_doubled_variance": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "abc_weight_predictive_prior_uniform": (_i, [_vp, _sz, _vp]),
+    "abc_weight_predictive_prior": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "abc_setup_mvn_sampler": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "abc_sample_posterior": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "abc_sample_mvn_predictive_priors": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "abc_sample_predictive_priors": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "abc_generation_dev": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "abc_stats_len": (_sz, [_sz, _sz]),
+    "abc_stats_shift_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "abc_stats_accumulate_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _u64, _u64, _vp]),
+    "abc_model_len": (_sz, [_sz, _sz, _sz]),
+    "abc_pls_model_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _i, _vp]),
+    "abc_model_ncomp": (_i, [_vp, _vp, _sz, _sz, _sz, _vp]),
+    "abc_simple_model_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "abc_project_distance_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _i, _vp]),
+    "abc_select_smallest_dev": (_i, [_vp, _vp, _sz, _sz, _u64, _vp, _vp]),
+    "abc_sort_pairs_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "abc_gather_rows_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _sz, _u64, _vp, _sz]),
+    "abc_doubled_variance_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "abc_weights_raw_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "abc_normalize_l2_dev": (_i, [_vp, _vp, _sz]),
+    "abc_setup_mvn_sampler_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "abc_resample_dev": (_i, [_vp, _vp, _vp, _sz, _u64, _sz, _vp]),
+    "abc_perturb_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _u64, _sz, _i, _vp, _vp, _vp, _u64]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load the HIP library; fail loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise LibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C abcsmc_amd/csrc` (there is no CPU fallback)" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+class Context:
+    """One abc_ctx per GPU (include/abcsmc_hip.h: abc_ctx_create)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().abc_ctx_create(int(device), C.byref(self._h))
+        if rc:
+            raise AbcError(rc, "abc_ctx_create(device=%d) failed: no usable GPU (HIP path is mandatory)" % device)
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self, rc):
+        if rc:
+            raise AbcError(rc, lib().abc_last_error(self._h).decode())
+
+    def set_stream(self, stream_ptr):
+        self.check(lib().abc_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(lib().abc_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().abc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device=0):
+    if device not in _DEFAULT_CTX:
+        _DEFAULT_CTX[device] = Context(device)
+    return _DEFAULT_CTX[device]

@@ -1,0 +1,144 @@
+// Internal declarations shared by the HIP translation units of libabcsmc_hip.so.
+// gfx950 (MI355X, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/abcsmc_hip.h"
+
+#define ABC_WAVE 64
+
+struct abc_ctx {
+    int device;
+    hipStream_t stream;
+    hipStream_t own_stream;
+    char err[512];
+    // device workspace arena (bump allocator, reset per API call)
+    char* ws;
+    size_t ws_bytes;
+    size_t ws_off;
+    // pinned host scratch
+    char* pin;
+    size_t pin_bytes;
+    // cached alias table (device) for the last weights vector handed to abc_resample_dev
+    double* alias_F;
+    uint32_t* alias_A;
+    size_t alias_K;
+    uint64_t alias_tag;
+    bool alias_valid;
+    // jump-ahead matrices for taus2 (device), built once
+    uint32_t* jump_tab;
+};
+
+#define ABC_FAIL(ctx, code, ...)                                   \
+    do {                                                           \
+        snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__);     \
+        return (code);                                             \
+    } while (0)
+
+#define ABC_HIP(ctx, call)                                                            \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            ABC_FAIL(ctx, ABC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,   \
+                     hipGetErrorString(e_));                                          \
+    } while (0)
+
+#define ABC_TRY(expr)                  \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != ABC_OK) return rc_; \
+    } while (0)
+
+// ---- workspace ------------------------------------------------------------------------
+int abc_ws_reserve(abc_ctx* ctx, size_t bytes);           // may reallocate; resets the arena
+void* abc_ws_alloc(abc_ctx* ctx, size_t bytes);           // 256-B aligned bump; NULL if exhausted
+int abc_pin_reserve(abc_ctx* ctx, size_t bytes);
+
+static inline size_t abc_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- stats record layout (see abc_stats_len in the public header) ----------------------
+struct StatsLayout {
+    size_t C16;        // padded column count (multiple of 16)
+    size_t off_n;      // 2 doubles: n_train, n_test
+    size_t off_shift;  // C16
+    size_t off_sum[2]; // C16 each
+    size_t off_G[2];   // C16*C16 each, column-major, symmetric
+    size_t len;
+};
+__host__ __device__ static inline StatsLayout stats_layout(size_t M, size_t P) {
+    StatsLayout s;
+    s.C16 = (M + P + 15) / 16 * 16;
+    s.off_n = 0;
+    s.off_shift = 2;
+    s.off_sum[0] = s.off_shift + s.C16;
+    s.off_sum[1] = s.off_sum[0] + s.C16;
+    s.off_G[0] = s.off_sum[1] + s.C16;
+    s.off_G[1] = s.off_G[0] + s.C16 * s.C16;
+    s.len = s.off_G[1] + s.C16 * s.C16;
+    return s;
+}
+
+// ---- model record layout ---------------------------------------------------------------
+// [ ncomp, A, n_total, pad, mean[M+P], sd[M+P], zobs[M], obs_scores[A], R[M*A], Q[P*A], W[M*A],
+//   Pl[M*A], press[A*P], per_response[P] ]
+struct ModelLayout {
+    size_t off_hdr, off_mean, off_sd, off_zobs, off_oscore, off_R, off_Q, off_W, off_P, off_press,
+        off_per, len;
+};
+__host__ __device__ static inline ModelLayout model_layout(size_t M, size_t P, size_t A) {
+    ModelLayout m;
+    m.off_hdr = 0;
+    m.off_mean = 4;
+    m.off_sd = m.off_mean + M + P;
+    m.off_zobs = m.off_sd + M + P;
+    m.off_oscore = m.off_zobs + M;
+    m.off_R = m.off_oscore + A;
+    m.off_Q = m.off_R + M * A;
+    m.off_W = m.off_Q + P * A;
+    m.off_P = m.off_W + M * A;
+    m.off_press = m.off_P + M * A;
+    m.off_per = m.off_press + A * P;
+    m.len = m.off_per + P;
+    return m;
+}
+
+// ---- stage launchers (each in its own .hip file) ---------------------------------------
+int launch_stats_shift(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
+                       size_t M, size_t P, double* stats);
+int launch_stats_accumulate(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx,
+                            size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
+                            double* stats);
+int launch_pls_model(abc_ctx*, const double* stats, const double* obs, size_t M, size_t P, size_t A,
+                     int rule, double* model);
+int launch_simple_model(abc_ctx*, const double* stats, const double* obs, size_t M, size_t P,
+                        double* model);
+int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P,
+                            size_t A, const double* model, int simple, double* dist);
+int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
+                           uint64_t* idx, double* dist_out);
+int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
+int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, size_t P,
+                       const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt);
+int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
+int launch_weights_raw(abc_ctx*, const abc_prior* priors, const double* theta, size_t K, size_t P,
+                       size_t k0, size_t kn, const double* theta_prev, size_t Kp,
+                       const double* w_prev, const double* dv_prev, double* w_raw);
+int launch_fill(abc_ctx*, double* w, size_t K, double v);
+int launch_normalize_l2(abc_ctx*, double* w, size_t K);
+int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* L, int* status_host,
+                     int* status_dev);
+int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
+                    uint64_t* parent);
+int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P,
+                   const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
+                   int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
+                   uint64_t seed_stream_offset);
+
+// taus2 helpers shared by host code
+void taus2_set(abc_rng* r, unsigned long seed);
+uint32_t taus2_get(abc_rng* r);
+void taus2_jump(abc_rng* r, uint64_t n);

@@ -1,0 +1,495 @@
+// C ABI of libabcsmc_hip.so (see include/abcsmc_hip.h for the contract and reference citations).
+#include <math.h>
+#include <stdlib.h>
+
+#include <new>
+
+#include "abc_internal.h"
+
+// ---- workspace -------------------------------------------------------------------------------
+int abc_ws_reserve(abc_ctx* ctx, size_t bytes) {
+    bytes = abc_align(bytes, 1 << 20);
+    if (bytes > ctx->ws_bytes) {
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ws) { ABC_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->ws, bytes));
+        ctx->ws_bytes = bytes;
+    }
+    ctx->ws_off = 0;
+    return ABC_OK;
+}
+void* abc_ws_alloc(abc_ctx* ctx, size_t bytes) {
+    const size_t off = abc_align(ctx->ws_off, 256);
+    if (off + bytes > ctx->ws_bytes) return nullptr;
+    ctx->ws_off = off + bytes;
+    return ctx->ws + off;
+}
+int abc_pin_reserve(abc_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pin_bytes) return ABC_OK;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pin) { ABC_HIP(ctx, hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_bytes = 0; }
+    bytes = abc_align(bytes, 1 << 16);
+    ABC_HIP(ctx, hipHostMalloc((void**)&ctx->pin, bytes, hipHostMallocDefault));
+    ctx->pin_bytes = bytes;
+    return ABC_OK;
+}
+
+// generous upper bound of the arena needed by any single API call on these sizes
+static size_t ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext) {
+    const size_t C = (M + P + 15) / 16;
+    const size_t psz = (C * (C + 1) / 2) * 256 + 16 * C;
+    size_t b = 0;
+    b += 2 * 384 * psz * 8 * 2;                                   // gram partials (PLS stats + covariance)
+    b += 4 * (stats_layout(M, P).len + model_layout(M, P, A ? A : 1).len) * 8;
+    b += (2 * M * P + 2 * M * M + P + A * M + A * A + P * A + M * 40) * 8;
+    b += N * 8;                                                   // distances
+    b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort
+    b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
+    b += K * P * 8;                                               // theta
+    b += (K + Kp) * 32 * 8 + 1024 * 8 + 8 * ((K < 2048 ? 1024 * K : 8 * K) + 1024);   // weights
+    b += K * 8 + P * P * 8 + P * 8;
+    b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
+    b += 64 * 256;                                                // alignment slack
+    return b + (4u << 20);
+}
+
+// ---- context ---------------------------------------------------------------------------------
+extern "C" int abc_version(void) { return 100; }
+
+extern "C" int abc_ctx_create(int device, abc_ctx** out) {
+    if (!out) return ABC_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return ABC_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return ABC_ERR_HIP;
+    abc_ctx* ctx = new (std::nothrow) abc_ctx();
+    if (!ctx) return ABC_ERR_NOMEM;
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ABC_ERR_HIP; }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return ABC_OK;
+}
+
+extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->alias_F) (void)hipFree(ctx->alias_F);
+    if (ctx->alias_A) (void)hipFree(ctx->alias_A);
+    if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* abc_last_error(const abc_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int abc_ctx_set_stream(abc_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ABC_ERR_INVALID;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ABC_OK;
+}
+
+extern "C" int abc_ctx_synchronize(abc_ctx* ctx) {
+    if (!ctx) return ABC_ERR_INVALID;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABC_OK;
+}
+
+extern "C" void abc_rng_set(abc_rng* r, unsigned long seed) { taus2_set(r, seed); }
+extern "C" uint32_t abc_rng_get(abc_rng* r) { return taus2_get(r); }
+extern "C" void abc_rng_jump(abc_rng* r, uint64_t n) { taus2_jump(r, n); }
+
+#define CHECK_CTX(ctx)                         \
+    do {                                       \
+        if (!(ctx)) return ABC_ERR_INVALID;    \
+        (ctx)->err[0] = 0;                     \
+        if (hipSetDevice((ctx)->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed"); \
+    } while (0)
+
+static size_t default_A(size_t M, size_t P, int max_comp) {
+    return (max_comp > 0) ? (size_t)max_comp : (M < P ? M : P);
+}
+
+// ---- stage-level device entry points -----------------------------------------------------------
+extern "C" size_t abc_stats_len(size_t M, size_t P) { return stats_layout(M, P).len; }
+extern "C" size_t abc_model_len(size_t M, size_t P, size_t A) { return model_layout(M, P, A).len; }
+
+extern "C" int abc_stats_shift_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
+                                   size_t M, size_t P, double* stats) {
+    CHECK_CTX(ctx);
+    return launch_stats_shift(ctx, X, Y, n, ldx, ldy, M, P, stats);
+}
+
+extern "C" int abc_stats_accumulate_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx,
+                                        size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
+                                        double* stats) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, 1, 0, 0, 0)));
+    return launch_stats_accumulate(ctx, X, Y, n, ldx, ldy, M, P, row0, n_train_global, stats);
+}
+
+extern "C" int abc_pls_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A,
+                                 int rule, double* model) {
+    CHECK_CTX(ctx);
+    if (rule != ABC_RULE_MIN_PRESS) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "component rule %d not available on the device", rule);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0)));
+    return launch_pls_model(ctx, stats, obs, M, P, A, rule, model);
+}
+
+extern "C" int abc_simple_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P,
+                                    double* model) {
+    CHECK_CTX(ctx);
+    return launch_simple_model(ctx, stats, obs, M, P, model);
+}
+
+extern "C" int abc_model_ncomp(abc_ctx* ctx, const double* model, size_t M, size_t P, size_t A, int32_t* ncomp) {
+    CHECK_CTX(ctx);
+    double hdr[4];
+    ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ncomp) *ncomp = (int32_t)hdr[0];
+    return ABC_OK;
+}
+
+extern "C" int abc_project_distance_dev(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P,
+                                        size_t A, const double* model, int simple, double* dist) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0)));
+    return launch_project_distance(ctx, X, n, ldx, M, P, A, model, simple, dist);
+}
+
+extern "C" int abc_select_smallest_dev(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base,
+                                       uint64_t* idx, double* dist_out) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, K, 0, 0)));
+    return launch_select_smallest(ctx, dist, n, K, idx_base, idx, dist_out);
+}
+
+extern "C" int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size_t n) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, n, 0, 0)));
+    return launch_sort_pairs(ctx, key, idx, n);
+}
+
+extern "C" int abc_gather_rows_dev(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P,
+                                   const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt) {
+    CHECK_CTX(ctx);
+    return launch_gather_rows(ctx, Y, n_local, ldy, P, idx, K, idx_base, theta, ldt);
+}
+
+extern "C" int abc_doubled_variance_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
+    CHECK_CTX(ctx);
+    return launch_doubled_variance(ctx, theta, K, P, dv);
+}
+
+extern "C" int abc_weights_raw_dev(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P,
+                                   size_t k0, size_t kn, const double* theta_prev, size_t Kp, const double* w_prev,
+                                   const double* dv_prev, double* w_raw) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, kn, Kp, 0)));
+    return launch_weights_raw(ctx, priors, theta, K, P, k0, kn, theta_prev, Kp, w_prev, dv_prev, w_raw);
+}
+
+extern "C" int abc_normalize_l2_dev(abc_ctx* ctx, double* w, size_t K) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, 1 << 20));
+    return launch_normalize_l2(ctx, w, K);
+}
+
+extern "C" int abc_setup_mvn_sampler_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, P, 0, 1, 0, 0, 0)));
+    int st = 0;
+    ABC_TRY(launch_mvn_setup(ctx, theta, K, P, L, &st, nullptr));
+    if (st) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
+    return ABC_OK;
+}
+
+extern "C" int abc_resample_dev(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
+                                uint64_t* parent) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, 1, 1, 0, 0, n)));
+    return launch_resample(ctx, rng, w, K, i0, n, parent);
+}
+
+extern "C" int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P,
+                               const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
+                               int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
+                               uint64_t seed_stream_offset) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, 1, 1, 0, 0, n)));
+    return launch_perturb(ctx, rng, theta, K, P, priors, parent, i0, n, multivariate, L_or_dv, out, seeds,
+                          seed_stream_offset);
+}
+
+// ---- fused generation (device-resident) ----------------------------------------------------------
+// does NOT reserve/reset the arena: the caller has done so (lets host wrappers keep their staging
+// buffers in the same arena)
+static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
+                           int32_t* ncomp_host, int simple, const double** model_out = nullptr) {
+    const size_t N = cfg->N, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->Nnext;
+    if (!N || !M || K > N) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: bad sizes N=%zu M=%zu K=%zu", N, M, K);
+    if (!simple && !(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))      // AbcUtil.cpp:428
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "training fraction %g outside (0,1]", cfg->train_frac);
+    if (!simple && cfg->rule != ABC_RULE_MIN_PRESS)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "component rule %d not available on the device", cfg->rule);
+    const size_t A = simple ? 0 : default_A(M, P, cfg->max_comp);
+    const StatsLayout SL = stats_layout(M, P);
+    const ModelLayout ML = model_layout(M, P, A);
+    double* stats = (double*)abc_ws_alloc(ctx, SL.len * 8);
+    double* model = (double*)abc_ws_alloc(ctx, ML.len * 8);
+    double* dist = (double*)abc_ws_alloc(ctx, N * 8);
+    int* spd_dev = (int*)abc_ws_alloc(ctx, sizeof(int));
+    if (!stats || !model || !dist || !spd_dev) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+    if (model_out) *model_out = model;
+    const uint64_t ntrain = simple ? N : (uint64_t)llround((double)N * cfg->train_frac);   // AbcUtil.cpp:438
+    const double* Yp = io->Y ? io->Y : io->X;
+    const size_t Pstat = io->Y ? P : 0;
+    ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
+    ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
+    if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
+    else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
+    ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
+    if (K == 0) return ABC_OK;
+    ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist));
+    if (!simple && ncomp_host && !io->w) {
+        double hdr[4];
+        ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *ncomp_host = (int32_t)hdr[0];
+    }
+    if (!io->w) return ABC_OK;   // ranking only
+
+    double* theta = io->theta ? io->theta : (double*)abc_ws_alloc(ctx, K * P * 8);
+    if (!theta) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+    ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K));
+    double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
+    ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
+    if (Kp == 0 || !io->theta_prev) {
+        ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
+    } else {
+        ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
+                                   io->w));
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K));                          // AbcUtil.cpp:583
+    }
+    int spd = 0;
+    bool have_spd = false;
+    if (Nn) {
+        uint64_t* parent = io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8);
+        if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+        double* L = nullptr;
+        if (cfg->multivariate) {
+            L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
+            ABC_TRY(launch_mvn_setup(ctx, theta, K, P, L, nullptr, spd_dev));
+            have_spd = true;
+        }
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent));   // contains the alias-table host round trip
+        ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, 0, Nn, cfg->multivariate,
+                               cfg->multivariate ? L : dv, io->next, io->seeds, Nn));
+        taus2_jump(rng, 2 * (uint64_t)Nn);   // Nnext resampling draws + Nnext seeds
+    }
+    {
+        double hdr[4] = {0, 0, 0, 0};
+        if (!simple) ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(&spd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
+    }
+    if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
+    return ABC_OK;
+}
+
+extern "C" int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
+                                  int32_t* ncomp_host) {
+    CHECK_CTX(ctx);
+    if (!cfg || !io || !io->X || !io->obs || !io->idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: null argument");
+    const size_t A = default_A(cfg->M, cfg->P, cfg->max_comp);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext)));
+    return generation_core(ctx, cfg, io, rng, ncomp_host, 0);
+}
+
+// ---- host-pointer entry points ---------------------------------------------------------------------
+namespace {
+struct Stage {   // host<->device staging inside the arena
+    abc_ctx* ctx;
+    template <typename T>
+    T* up(const T* h, size_t n) {
+        T* d = (T*)abc_ws_alloc(ctx, n * sizeof(T));
+        if (d && h && n) (void)hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        return d;
+    }
+    template <typename T>
+    T* dev(size_t n) { return (T*)abc_ws_alloc(ctx, n * sizeof(T)); }
+    template <typename T>
+    void down(T* h, const T* d, size_t n) {
+        if (h && d && n) (void)hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
+    }
+};
+}  // namespace
+
+static int ranking_host(abc_ctx* ctx, const double* X, const double* Y, const double* obs, size_t N, size_t M,
+                        size_t P, double train_frac, int max_comp, int rule, size_t K, uint64_t* idx, double* dist,
+                        int32_t* ncomp, double* R, double* mean, double* sd, int simple) {
+    if (!X || !obs || !idx || (!simple && !Y)) ABC_FAIL(ctx, ABC_ERR_INVALID, "ranking: null argument");
+    const size_t A = simple ? 0 : default_A(M, P, max_comp);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(N, M, P, A, K, 0, 0) + (N * (M + P) + M + 2 * K) * 8));
+    Stage s{ctx};
+    abc_generation_io io;
+    memset(&io, 0, sizeof(io));
+    io.X = s.up(X, N * M);
+    io.Y = simple ? nullptr : s.up(Y, N * P);
+    io.obs = s.up(obs, M);
+    io.idx = s.dev<uint64_t>(K);
+    io.dist = s.dev<double>(K);
+    if (!io.X || !io.obs || !io.idx || !io.dist) ABC_FAIL(ctx, ABC_ERR_NOMEM, "ranking: workspace exhausted");
+    abc_generation_cfg cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.N = N; cfg.M = M; cfg.P = simple ? 0 : P; cfg.K = K; cfg.train_frac = train_frac;
+    cfg.max_comp = max_comp; cfg.rule = rule;
+    const double* model = nullptr;
+    ABC_TRY(generation_core(ctx, &cfg, &io, nullptr, ncomp, simple, &model));
+    s.down(idx, io.idx, K);
+    s.down(dist, io.dist, K);
+    if (R || mean || sd) {
+        const ModelLayout ML = model_layout(M, simple ? 0 : P, A);
+        if (R && !simple) s.down(R, model + ML.off_R, M * A);
+        s.down(mean, model + ML.off_mean, M);
+        s.down(sd, model + ML.off_sd, M);
+    }
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+extern "C" int abc_particle_ranking_pls(abc_ctx* ctx, const double* X, const double* Y, const double* obs, size_t N,
+                                        size_t M, size_t P, double train_frac, int max_comp, int rule, size_t K,
+                                        uint64_t* idx, double* dist, int32_t* ncomp, double* R, double* mean,
+                                        double* sd) {
+    CHECK_CTX(ctx);
+    return ranking_host(ctx, X, Y, obs, N, M, P, train_frac, max_comp, rule, K, idx, dist, ncomp, R, mean, sd, 0);
+}
+
+extern "C" int abc_particle_ranking_simple(abc_ctx* ctx, const double* X, const double* obs, size_t N, size_t M,
+                                           size_t K, uint64_t* idx, double* dist) {
+    CHECK_CTX(ctx);
+    return ranking_host(ctx, X, nullptr, obs, N, M, 0, 1.0, 0, 0, K, idx, dist, nullptr, nullptr, nullptr, nullptr, 1);
+}
+
+extern "C" int abc_calculate_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
+    CHECK_CTX(ctx);
+    if (!theta || !dv) ABC_FAIL(ctx, ABC_ERR_INVALID, "doubled_variance: null argument");
+    ABC_TRY(abc_ws_reserve(ctx, (K * P + P) * 8 + (1 << 20)));
+    Stage s{ctx};
+    double* dth = s.up(theta, K * P);
+    double* ddv = s.dev<double>(P);
+    ABC_TRY(launch_doubled_variance(ctx, dth, K, P, ddv));
+    s.down(dv, ddv, P);
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABC_OK;
+}
+
+extern "C" int abc_weight_predictive_prior_uniform(abc_ctx* ctx, size_t K, double* w) {
+    CHECK_CTX(ctx);
+    if (!w || !K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: null argument");
+    ABC_TRY(abc_ws_reserve(ctx, K * 8 + (1 << 20)));
+    Stage s{ctx};
+    double* dw = s.dev<double>(K);
+    ABC_TRY(launch_fill(ctx, dw, K, 1.0 / (double)K));
+    s.down(w, dw, K);
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABC_OK;
+}
+
+extern "C" int abc_weight_predictive_prior(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K,
+                                           size_t P, const double* theta_prev, size_t Kp, const double* w_prev,
+                                           const double* dv_prev, double* w) {
+    CHECK_CTX(ctx);
+    if (!priors || !theta || !theta_prev || !w_prev || !dv_prev || !w)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: null argument");
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, K, Kp, 0) + ((K + Kp) * (P + 1) + 2 * P) * 8 + P * sizeof(abc_prior)));
+    Stage s{ctx};
+    abc_prior* dpr = s.up(priors, P);
+    double* dth = s.up(theta, K * P);
+    double* dtp = s.up(theta_prev, Kp * P);
+    double* dwp = s.up(w_prev, Kp);
+    double* ddv = s.up(dv_prev, P);
+    double* dw = s.dev<double>(K);
+    if (!dpr || !dth || !dtp || !dwp || !ddv || !dw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    ABC_TRY(launch_weights_raw(ctx, dpr, dth, K, P, 0, K, dtp, Kp, dwp, ddv, dw));
+    ABC_TRY(launch_normalize_l2(ctx, dw, K));
+    s.down(w, dw, K);
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABC_OK;
+}
+
+extern "C" int abc_setup_mvn_sampler(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L) {
+    CHECK_CTX(ctx);
+    if (!theta || !L) ABC_FAIL(ctx, ABC_ERR_INVALID, "mvn: null argument");
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, P, 0, 1, 0, 0, 0) + (K * P + P * P) * 8));
+    Stage s{ctx};
+    double* dth = s.up(theta, K * P);
+    double* dL = s.dev<double>(P * P);
+    int st = 0;
+    ABC_TRY(launch_mvn_setup(ctx, dth, K, P, dL, &st, nullptr));
+    if (st) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
+    s.down(L, dL, P * P);
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ABC_OK;
+}
+
+extern "C" int abc_sample_posterior(abc_ctx* ctx, abc_rng* rng, const double* w, size_t K, size_t n, uint64_t* idx) {
+    CHECK_CTX(ctx);
+    if (!rng || !w || !idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "sample_posterior: null argument");
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, 1, 1, 0, 0, n) + K * 8 + n * 8));
+    Stage s{ctx};
+    double* dw = s.up(w, K);
+    uint64_t* dp = s.dev<uint64_t>(n);
+    ABC_TRY(launch_resample(ctx, rng, dw, K, 0, n, dp));
+    s.down(idx, dp, n);
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    taus2_jump(rng, n);
+    return ABC_OK;
+}
+
+static int sample_host(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w, const double* theta, size_t K, size_t P,
+                       const abc_prior* priors, const double* L_or_dv, int multivariate, double* out, uint64_t* parent,
+                       uint64_t* seeds) {
+    if (!rng || !w || !theta || !priors || !L_or_dv || !out) ABC_FAIL(ctx, ABC_ERR_INVALID, "sample: null argument");
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, K, 0, n) + (K * (P + 1) + P * P + n * (P + 2)) * 8 + P * sizeof(abc_prior)));
+    Stage s{ctx};
+    double* dw = s.up(w, K);
+    double* dth = s.up(theta, K * P);
+    abc_prior* dpr = s.up(priors, P);
+    double* dl = s.up(L_or_dv, multivariate ? P * P : P);
+    double* dout = s.dev<double>(n * P);
+    uint64_t* dpar = s.dev<uint64_t>(n);
+    uint64_t* dseed = seeds ? s.dev<uint64_t>(n) : nullptr;
+    if (!dw || !dth || !dpr || !dl || !dout || !dpar) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sample: workspace exhausted");
+    ABC_TRY(launch_resample(ctx, rng, dw, K, 0, n, dpar));
+    ABC_TRY(launch_perturb(ctx, rng, dth, K, P, dpr, dpar, 0, n, multivariate, dl, dout, dseed, n));
+    s.down(out, dout, n * P);
+    s.down(parent, dpar, n);
+    s.down(seeds, dseed, n);
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    taus2_jump(rng, seeds ? 2 * (uint64_t)n : (uint64_t)n);
+    return ABC_OK;
+}
+
+extern "C" int abc_sample_mvn_predictive_priors(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w,
+                                                const double* theta, size_t K, size_t P, const abc_prior* priors,
+                                                const double* L, double* out, uint64_t* parent, uint64_t* seeds) {
+    CHECK_CTX(ctx);
+    return sample_host(ctx, rng, n, w, theta, K, P, priors, L, 1, out, parent, seeds);
+}
+
+extern "C" int abc_sample_predictive_priors(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w, const double* theta,
+                                            size_t K, size_t P, const abc_prior* priors, const double* dv, double* out,
+                                            uint64_t* parent, uint64_t* seeds) {
+    CHECK_CTX(ctx);
+    return sample_host(ctx, rng, n, w, theta, K, P, priors, dv, 0, out, parent, seeds);
+}

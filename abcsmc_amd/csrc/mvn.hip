@@ -1,0 +1,66 @@
+// Proposal covariance of the selected particles and its Cholesky factor.
+// Replaces ABC::setup_mvn_sampler (AbcUtil.cpp:462-488): [GSL] gsl_ran_multivariate_gaussian_vcov
+// (n-1 covariance), diagonal doubled (:475-479), [GSL] gsl_linalg_cholesky_decomp1 (lower factor in
+// place, strict upper triangle keeps the covariance entries).
+// The K x P cross-products come from the same one-pass MFMA Gram kernel as the PLS statistics
+// (gram.hip, theta treated as a P-column matrix); the P x P factorisation is one wavefront in LDS.
+#include "abc_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stats, int P, double* __restrict__ Lout,
+                                                 int* __restrict__ status) {
+    extern __shared__ double A[];   // P x P column-major
+    __shared__ double delta[64];
+    const StatsLayout SL = stats_layout(P, 0);
+    const int lane = threadIdx.x;
+    const double n = stats[SL.off_n] + stats[SL.off_n + 1];
+    for (int c = lane; c < P; c += 64) delta[c] = (stats[SL.off_sum[0] + c] + stats[SL.off_sum[1] + c]) / n;
+    __syncthreads();
+    for (int e = lane; e < P * P; e += 64) {
+        const int a = e % P, b = e / P;
+        const double g = stats[SL.off_G[0] + a + SL.C16 * b] + stats[SL.off_G[1] + a + SL.C16 * b];
+        double c = (g - n * delta[a] * delta[b]) / (n - 1.0);
+        if (a == b) c = 2.0 * c;                       // AbcUtil.cpp:475-479
+        A[e] = c;
+    }
+    __syncthreads();
+    int ok = 1;
+    for (int j = 0; j < P; j++) {
+        for (int i = j + lane; i < P; i += 64) {
+            double temp = 0.0;
+            for (int k = 0; k < j; k++) temp += A[j + P * k] * A[i + P * k];
+            A[i + P * j] += -1.0 * temp;
+        }
+        __syncthreads();
+        const double ajj = A[j + P * j];
+        if (!(ajj > 0.0)) { ok = 0; break; }           // GSL_EDOM in the reference (process abort)
+        const double inv = 1.0 / sqrt(ajj);
+        __syncthreads();
+        for (int i = j + lane; i < P; i += 64) A[i + P * j] *= inv;
+        __syncthreads();
+    }
+    for (int e = lane; e < P * P; e += 64) Lout[e] = A[e];
+    if (lane == 0) *status = ok ? 0 : -1;
+}
+
+}  // namespace
+
+int launch_mvn_setup(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L, int* status_host,
+                     int* status_dev) {
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "mvn: P = %zu > 64", P);
+    if (K < 2) ABC_FAIL(ctx, ABC_ERR_INVALID, "mvn: need at least 2 particles (K=%zu)", K);
+    const StatsLayout SL = stats_layout(P, 0);
+    double* stats = (double*)abc_ws_alloc(ctx, SL.len * sizeof(double));
+    int* status = status_dev ? status_dev : (int*)abc_ws_alloc(ctx, sizeof(int));
+    if (!stats || !status) ABC_FAIL(ctx, ABC_ERR_NOMEM, "mvn: workspace exhausted");
+    ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
+    ABC_TRY(launch_stats_accumulate(ctx, theta, theta, K, K, K, P, 0, 0, K, stats));
+    hipLaunchKernelGGL(k_cov_chol, dim3(1), dim3(64), P * P * sizeof(double), ctx->stream, stats, (int)P, L, status);
+    ABC_HIP(ctx, hipGetLastError());
+    if (status_host) {
+        ABC_HIP(ctx, hipMemcpyAsync(status_host, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ABC_OK;
+}

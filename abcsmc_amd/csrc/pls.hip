@@ -1,0 +1,351 @@
+// PLS model from sufficient statistics: z-score moments, improved-kernel PLS2 deflation loop
+// (Dayal & MacGregor "type 2": everything in M x M / M x P space, no further pass over the particles),
+// PRESS on the validation statistics, component choice and observed scores.
+// Replaces PLS::Model ctor, cv_NEW_DATA, optimal_num_components (reference call sites
+// AbcUtil.cpp:432-449, 453).
+//
+// Latency-bound, tiny matrices: k_zstats is one 256-thread work-group; k_pls_fit is ONE wavefront
+// (no inter-wave barriers): XY and the Jacobi work matrices live in LDS, XX stays in L2.
+#include "abc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// zwork layout: [ XYtr M*P | XXtr M*M | XYte M*P | XXte M*M | YYte P ]
+struct ZLayout {
+    size_t off_XY[2], off_XX[2], off_YY, len;
+};
+__host__ __device__ static inline ZLayout z_layout(size_t M, size_t P) {
+    ZLayout z;
+    z.off_XY[0] = 0;
+    z.off_XX[0] = M * P;
+    z.off_XY[1] = z.off_XX[0] + M * M;
+    z.off_XX[1] = z.off_XY[1] + M * P;
+    z.off_YY = z.off_XX[1] + M * M;
+    z.len = z.off_YY + P;
+    return z;
+}
+
+// mean / n-1 stdev of every column, then the z-scored cross-products of both partitions.
+__global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats, int M, int P, int A,
+                                                double* __restrict__ model, double* __restrict__ zwork) {
+    const StatsLayout L = stats_layout(M, P);
+    const ModelLayout ML = model_layout(M, P, A);
+    const ZLayout Z = z_layout(M, P);
+    __shared__ double delta[160], sd[160];
+    const int t = threadIdx.x;
+    const int C = M + P;
+    const double n0 = stats[L.off_n], n1 = stats[L.off_n + 1];
+    const double n = n0 + n1;
+    for (int c = t; c < C; c += 256) {
+        const double s = stats[L.off_sum[0] + c] + stats[L.off_sum[1] + c];
+        const double d = (n > 0) ? s / n : 0.0;  // mean - shift
+        const double g = stats[L.off_G[0] + c + L.C16 * c] + stats[L.off_G[1] + c + L.C16 * c];
+        double ss = g - n * d * d;               // centred sum of squares
+        if (ss < 0.0) ss = 0.0;
+        const double sdv = (n >= 2) ? sqrt(ss / (n - 1.0)) : 0.0;
+        delta[c] = d;
+        sd[c] = sdv;
+        model[ML.off_mean + c] = stats[L.off_shift + c] + d;
+        model[ML.off_sd + c] = sdv;
+    }
+    if (t == 0) { model[ML.off_hdr + 1] = (double)A; model[ML.off_hdr + 2] = n; model[ML.off_hdr + 3] = 0.0; }
+    __syncthreads();
+    if (zwork == nullptr) return;
+    for (int part = 0; part < 2; part++) {
+        const double np = part ? n1 : n0;
+        const double* G = stats + L.off_G[part];
+        const double* S = stats + L.off_sum[part];
+        // XX (M x M) and XY (M x P) in one sweep over columns b of [X|Y]
+        for (int e = t; e < M * C; e += 256) {
+            const int a = e % M, b = e / M;
+            const double cross = G[a + L.C16 * b] - delta[a] * S[b] - delta[b] * S[a] + np * delta[a] * delta[b];
+            const double den = sd[a] * sd[b];
+            const double zv = (den > 0.0) ? cross / den : 0.0;
+            if (b < M) zwork[Z.off_XX[part] + a + (size_t)M * b] = zv;
+            else zwork[Z.off_XY[part] + a + (size_t)M * (b - M)] = zv;
+        }
+    }
+    for (int j = t; j < P; j += 256) {
+        const int c = M + j;
+        const double cross = stats[L.off_G[1] + c + L.C16 * c] - 2.0 * delta[c] * stats[L.off_sum[1] + c] +
+                             n1 * delta[c] * delta[c];
+        const double den = sd[c] * sd[c];
+        zwork[Z.off_YY + j] = (den > 0.0) ? cross / den : 0.0;
+    }
+}
+
+// ONE wavefront.  LDS: XY (M*P), S and V (np*np each), vectors.
+__global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
+                                                int M, int P, int A, double* __restrict__ model,
+                                                double* __restrict__ scratch /* A*M + A*A + P*A */) {
+    extern __shared__ double lds[];
+    const ModelLayout ML = model_layout(M, P, A);
+    const ZLayout Z = z_layout(M, P);
+    const int lane = threadIdx.x;
+    const int np = (P + 1) & ~1;  // Jacobi works on an even order (pad with a zero row/column)
+    double* XY = lds;                   // M*P
+    double* S = XY + (size_t)M * P;     // np*np
+    double* V = S + np * np;            // np*np
+    double* qv = V + np * np;           // np
+    double* wv = qv + np;               // M
+    double* rv = wv + M;                // M
+    double* pv = rv + M;                // M
+    double* xr = pv + M;                // M
+    double* rot = xr + M;               // 2*(np/2): c, s
+    int* rpq = (int*)(rot + np);        // 2*(np/2): p, q
+
+    const double* XXtr = zwork + Z.off_XX[0];
+    double* Rm = model + ML.off_R;
+    double* Qm = model + ML.off_Q;
+    double* Wm = model + ML.off_W;
+    double* Pm = model + ML.off_P;
+
+    for (int e = lane; e < M * P; e += 64) XY[e] = zwork[Z.off_XY[0] + e];
+    __syncthreads();
+
+    for (int comp = 0; comp < A; comp++) {
+        if (P == 1) {
+            for (int m = lane; m < M; m += 64) wv[m] = XY[m];
+        } else {
+            // S = XY' XY (symmetric), V = I
+            for (int e = lane; e < np * np; e += 64) {
+                const int a = e % np, b = e / np;
+                double s = 0.0;
+                if (a < P && b < P)
+                    for (int m = 0; m < M; m++) s = fma(XY[m + M * a], XY[m + M * b], s);
+                S[e] = s;
+                V[e] = (a == b) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            // parallel-order (round-robin) Jacobi sweeps
+            for (int sweep = 0; sweep < 40; sweep++) {
+                double off = 0.0, dg = 0.0;
+                for (int e = lane; e < np * np; e += 64) {
+                    const double x = S[e];
+                    if (e % np == e / np) dg += x * x; else off += x * x;
+                }
+                off = wave_sum(off);
+                dg = wave_sum(dg);
+                if (off <= 1e-32 * dg || off == 0.0) break;
+                for (int round = 0; round < np - 1; round++) {
+                    const int half = np / 2;
+                    if (lane < half) {
+                        int a, b;
+                        if (lane == 0) { a = np - 1; b = round; }
+                        else { a = (round + lane) % (np - 1); b = (round - lane + (np - 1)) % (np - 1); }
+                        const int p = a < b ? a : b, q = a < b ? b : a;
+                        const double apq = S[p + np * q];
+                        double c = 1.0, s = 0.0;
+                        if (apq != 0.0) {
+                            const double tau = (S[q + np * q] - S[p + np * p]) / (2.0 * apq);
+                            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                            c = 1.0 / sqrt(1.0 + tt * tt);
+                            s = tt * c;
+                        }
+                        rot[2 * lane] = c; rot[2 * lane + 1] = s;
+                        rpq[2 * lane] = p; rpq[2 * lane + 1] = q;
+                    }
+                    __syncthreads();
+                    for (int e = lane; e < half * np; e += 64) {   // columns of S and V
+                        const int k = e / np, i = e % np;
+                        const int p = rpq[2 * k], q = rpq[2 * k + 1];
+                        const double c = rot[2 * k], s = rot[2 * k + 1];
+                        const double sp = S[i + np * p], sq = S[i + np * q];
+                        S[i + np * p] = c * sp - s * sq;
+                        S[i + np * q] = s * sp + c * sq;
+                        const double vp = V[i + np * p], vq = V[i + np * q];
+                        V[i + np * p] = c * vp - s * vq;
+                        V[i + np * q] = s * vp + c * vq;
+                    }
+                    __syncthreads();
+                    for (int e = lane; e < half * np; e += 64) {   // rows of S
+                        const int k = e / np, i = e % np;
+                        const int p = rpq[2 * k], q = rpq[2 * k + 1];
+                        const double c = rot[2 * k], s = rot[2 * k + 1];
+                        const double sp = S[p + np * i], sq = S[q + np * i];
+                        S[p + np * i] = c * sp - s * sq;
+                        S[q + np * i] = s * sp + c * sq;
+                    }
+                    __syncthreads();
+                }
+            }
+            // dominant eigenvector: largest diagonal entry; unit norm; largest |component| positive
+            int best = 0;
+            for (int i = 1; i < P; i++) if (S[i + np * i] > S[best + np * best]) best = i;
+            double nrm = 0.0; int big = 0;
+            for (int i = 0; i < P; i++) {
+                const double x = V[i + np * best];
+                nrm += x * x;
+                if (fabs(x) > fabs(V[big + np * best])) big = i;
+            }
+            nrm = sqrt(nrm);
+            const double sgn = (V[big + np * best] < 0.0) ? -1.0 : 1.0;
+            for (int i = lane; i < P; i += 64) qv[i] = sgn * V[i + np * best] / nrm;
+            __syncthreads();
+            for (int m = lane; m < M; m += 64) {
+                double s = 0.0;
+                for (int j = 0; j < P; j++) s = fma(XY[m + M * j], qv[j], s);
+                wv[m] = s;
+            }
+        }
+        __syncthreads();
+        double ww = 0.0;
+        for (int m = lane; m < M; m += 64) ww = fma(wv[m], wv[m], ww);
+        ww = sqrt(wave_sum(ww));
+        for (int m = lane; m < M; m += 64) { const double x = wv[m] / ww; wv[m] = x; rv[m] = x; }
+        __syncthreads();
+        for (int j = 0; j < comp; j++) {
+            double pw = 0.0;
+            for (int m = lane; m < M; m += 64) pw = fma(Pm[m + (size_t)M * j], wv[m], pw);
+            pw = wave_sum(pw);
+            for (int m = lane; m < M; m += 64) rv[m] -= pw * Rm[m + (size_t)M * j];
+        }
+        __syncthreads();
+        // type 2: xr = XX r ; tt = r' xr ; p = xr / tt
+        double tt = 0.0;
+        for (int a = lane; a < M; a += 64) {
+            double s = 0.0;
+            for (int b = 0; b < M; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
+            xr[a] = s;
+            tt = fma(rv[a], s, tt);
+        }
+        tt = wave_sum(tt);
+        for (int m = lane; m < M; m += 64) {
+            const double pm = xr[m] / tt;
+            pv[m] = pm;
+            Pm[m + (size_t)M * comp] = pm;
+            Wm[m + (size_t)M * comp] = wv[m];
+            Rm[m + (size_t)M * comp] = rv[m];
+        }
+        __syncthreads();
+        for (int j = lane; j < P; j += 64) {
+            double s = 0.0;
+            for (int m = 0; m < M; m++) s = fma(XY[m + M * j], rv[m], s);
+            s /= tt;
+            qv[j] = s;
+            Qm[j + (size_t)P * comp] = s;
+        }
+        __syncthreads();
+        for (int e = lane; e < M * P; e += 64) {
+            const int m = e % M, j = e / M;
+            XY[e] -= tt * (pv[m] * qv[j]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // ---- PRESS on the validation statistics -------------------------------------------------
+    // c_jk = r_k' XYte[:,j]; v_k = XXte r_k; H_kl = r_k' v_l;
+    // PRESS_j(a) = YY_jj - 2 sum_{k<a} q_jk c_jk + sum_{k,l<a} q_jk q_jl H_kl
+    const double* XYte = zwork + Z.off_XY[1];
+    const double* XXte = zwork + Z.off_XX[1];
+    const double* YYte = zwork + Z.off_YY;
+    double* vk = scratch;               // A*M
+    double* H = vk + (size_t)A * M;     // A*A
+    double* cm = H + (size_t)A * A;     // P*A
+    for (int e = lane; e < A * M; e += 64) {
+        const int m = e % M, k = e / M;
+        double s = 0.0;
+        for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
+        vk[e] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int e = lane; e < A * A; e += 64) {
+        const int k = e % A, l = e / A;
+        double s = 0.0;
+        for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], vk[m + (size_t)M * l], s);
+        H[e] = s;
+    }
+    for (int e = lane; e < P * A; e += 64) {
+        const int j = e % P, k = e / P;
+        double s = 0.0;
+        for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
+        cm[e] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    double* press = model + ML.off_press;   // A x P, column-major
+    for (int j = lane; j < P; j += 64) {
+        double lin = 0.0, quad = 0.0;
+        double best = 0.0; int besta = 0;
+        for (int a = 0; a < A; a++) {
+            const double qa = Qm[j + (size_t)P * a];
+            lin = fma(qa, cm[j + (size_t)P * a], lin);
+            // add row/column a of the quadratic form
+            double add = 0.0;
+            for (int l = 0; l < a; l++) add = fma(Qm[j + (size_t)P * l], H[a + (size_t)A * l], add);
+            quad += 2.0 * qa * add + qa * qa * H[a + (size_t)A * a];
+            const double pr = YYte[j] - 2.0 * lin + quad;
+            press[a + (size_t)A * j] = pr;
+            if (a == 0 || pr < best) { best = pr; besta = a; }
+        }
+        model[ML.off_per + j] = (double)(besta + 1);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ncomp = max over responses; observed z-scores and scores (m-ascending fma chain per component)
+    int ncomp = 1;
+    for (int j = 0; j < P; j++) { const int v = (int)model[ML.off_per + j]; if (v > ncomp) ncomp = v; }
+    if (lane == 0) model[ML.off_hdr] = (double)ncomp;
+    for (int m = lane; m < M; m += 64) {
+        const double sdv = model[ML.off_sd + m];
+        model[ML.off_zobs + m] = (sdv == 0.0) ? 0.0 : (obs[m] - model[ML.off_mean + m]) / sdv;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = lane; k < A; k += 64) {
+        double s = 0.0;
+        for (int m = 0; m < M; m++) s = fma(model[ML.off_zobs + m], Rm[m + (size_t)M * k], s);
+        model[ML.off_oscore + k] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_simple_obs(const double* __restrict__ obs, int M, int P,
+                                                   double* __restrict__ model) {
+    const ModelLayout ML = model_layout(M, P, 0);
+    for (int m = threadIdx.x; m < M; m += 64) {
+        const double sdv = model[ML.off_sd + m];
+        model[ML.off_zobs + m] = (sdv == 0.0) ? 0.0 : (obs[m] - model[ML.off_mean + m]) / sdv;
+    }
+    if (threadIdx.x == 0) model[ML.off_hdr] = 0.0;
+}
+
+}  // namespace
+
+int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
+                     double* model) {
+    if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M+P = %zu > 160", M + P);
+    if (A < 1 || A > M) ABC_FAIL(ctx, ABC_ERR_INVALID, "pls: components A=%zu must be in [1, M=%zu]", A, M);
+    const ZLayout Z = z_layout(M, P);
+    double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
+    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A) * sizeof(double));
+    if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
+    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
+    ABC_HIP(ctx, hipGetLastError());
+    const size_t np = (P + 1) & ~(size_t)1;
+    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + np + np /* ints */ + 8;
+    const size_t lds_bytes = lds_d * sizeof(double);
+    if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k_pls_fit, dim3(1), dim3(64), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
+                       scratch);
+    ABC_HIP(ctx, hipGetLastError());
+    (void)rule;
+    return ABC_OK;
+}
+
+int launch_simple_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, double* model) {
+    if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "simple: M+P = %zu > 160", M + P);
+    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, 0, model, (double*)nullptr);
+    ABC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_simple_obs, dim3(1), dim3(64), 0, ctx->stream, obs, (int)M, (int)P, model);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}

@@ -1,0 +1,118 @@
+// Per-particle projection onto the PLS components and Euclidean distance to the observed scores:
+// dist_i = || z(x_i) R[:, :a] - obs_scores ||_2   (AbcUtil.cpp:434, 453-455; euclidean :320-324),
+// or, for FILTER::SIMPLE, || z(x_i) - z(obs) ||_2 (AbcUtil.cpp:412-419).
+//
+// One particle per lane, metrics streamed column by column (each wave-instruction reads 64
+// consecutive particles of one metric = 512 contiguous bytes); the z-score is applied on the fly
+// (no materialised copy); R / mean / sd are wave-uniform and come through the scalar cache.
+// The operation order is FIXED and shared with the oracle (orc_project_distance): for each
+// metric m ascending, z = (x - mean)/sd (true division), s_k = fma(z, R[m,k], s_k); then
+// d2 = fma(s_k - o_k, s_k - o_k, d2) for k ascending; dist = sqrt(d2).  HBM-bound: 8*M B/particle.
+#include "abc_internal.h"
+
+namespace {
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_project_dist(const double* __restrict__ X, size_t n, size_t ldx, int M,
+                                                      const double* __restrict__ mean,
+                                                      const double* __restrict__ sd,
+                                                      const double* __restrict__ Rpad /* M x KC, row-major */,
+                                                      const double* __restrict__ opad /* KC */,
+                                                      double* __restrict__ dist) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double s[KC];
+#pragma unroll
+        for (int k = 0; k < KC; k++) s[k] = 0.0;
+        const double* xp = X + i;
+#pragma unroll 4
+        for (int m = 0; m < M; m++) {
+            const double x = xp[(size_t)m * ldx];
+            const double sdm = sd[m];
+            const double z = (sdm == 0.0) ? 0.0 : (x - mean[m]) / sdm;
+#pragma unroll
+            for (int k = 0; k < KC; k++) s[k] = fma(z, Rpad[m * KC + k], s[k]);
+        }
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const double t = s[k] - opad[k];
+            d2 = fma(t, t, d2);
+        }
+        dist[i] = sqrt(d2);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_simple_dist(const double* __restrict__ X, size_t n, size_t ldx, int M,
+                                                     const double* __restrict__ mean,
+                                                     const double* __restrict__ sd,
+                                                     const double* __restrict__ zobs,
+                                                     double* __restrict__ dist) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double d2 = 0.0;
+        const double* xp = X + i;
+#pragma unroll 4
+        for (int m = 0; m < M; m++) {
+            const double sdm = sd[m];
+            const double z = (sdm == 0.0) ? 0.0 : (xp[(size_t)m * ldx] - mean[m]) / sdm;
+            const double t = z - zobs[m];
+            d2 = fma(t, t, d2);
+        }
+        dist[i] = sqrt(d2);
+    }
+}
+
+// Rpad[m*KC + k] = k < ncomp ? R[m + M*k] : 0 ; opad[k] = k < ncomp ? obs_scores[k] : 0.
+// Zero padding is exact: fma(z, 0, s) == s and fma(0, 0, d2) == d2.
+__global__ void k_pad_model(const double* __restrict__ model, int M, int P, int A, int KC,
+                            double* __restrict__ Rpad, double* __restrict__ opad) {
+    const ModelLayout ML = model_layout(M, P, A);
+    const int ncomp = (int)model[ML.off_hdr];
+    for (int e = threadIdx.x; e < M * KC; e += blockDim.x) {
+        const int m = e / KC, k = e % KC;
+        Rpad[e] = (k < ncomp) ? model[ML.off_R + m + (size_t)M * k] : 0.0;
+    }
+    for (int k = threadIdx.x; k < KC; k += blockDim.x) opad[k] = (k < ncomp) ? model[ML.off_oscore + k] : 0.0;
+}
+
+}  // namespace
+
+int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A,
+                            const double* model, int simple, double* dist) {
+    if (n == 0) return ABC_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (simple) {
+        const ModelLayout ML = model_layout(M, P, 0);
+        hipLaunchKernelGGL(k_simple_dist, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n, ldx, (int)M,
+                           model + ML.off_mean, model + ML.off_sd, model + ML.off_zobs, dist);
+        ABC_HIP(ctx, hipGetLastError());
+        return ABC_OK;
+    }
+    const ModelLayout ML = model_layout(M, P, A);
+    // ncomp lives on the device; the kernel is compiled for the next power-of-two >= A and the
+    // unused components are zero-padded (exact, see k_pad_model).
+    int KC = 1;
+    while (KC < (int)A) KC *= 2;
+    if (KC > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "project: A = %zu > 32 components", A);
+    double* Rpad = (double*)abc_ws_alloc(ctx, (M * KC + KC) * sizeof(double));
+    if (!Rpad) ABC_FAIL(ctx, ABC_ERR_NOMEM, "project: workspace exhausted");
+    double* opad = Rpad + M * KC;
+    hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
+    ABC_HIP(ctx, hipGetLastError());
+#define LAUNCH_PD(KCV)                                                                                               \
+    hipLaunchKernelGGL(k_project_dist<KCV>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n, ldx, (int)M,   \
+                       model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist)
+    switch (KC) {
+        case 1: LAUNCH_PD(1); break;
+        case 2: LAUNCH_PD(2); break;
+        case 4: LAUNCH_PD(4); break;
+        case 8: LAUNCH_PD(8); break;
+        case 16: LAUNCH_PD(16); break;
+        default: LAUNCH_PD(32); break;
+    }
+#undef LAUNCH_PD
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}

@@ -1,0 +1,364 @@
+// Resampling of parent particles and perturbation into the next set.
+// Replaces ABC::gsl_rng_nonuniform_int / sample_posterior (AbcUtil.cpp:111-120, 366-375),
+// sample_mvn_predictive_priors + gsl_ran_trunc_mv_normal (AbcUtil.cpp:391-404, 122-143),
+// sample_predictive_priors + gsl_ran_trunc_normal + Prior::noise (AbcUtil.cpp:377-389, 145-158;
+// Priors.h:19-43) and the per-particle seed draw (AbcSmc.cpp:535).
+//
+// Parent indices are BIT-EXACT with the reference stream: the reference consumes exactly one
+// gsl_rng_taus2 output per draw (gsl_ran_discrete), and taus2 is linear over GF(2), so draw i's
+// output is obtained by an O(log i) jump-ahead (32x32 bit-matrix powers); every lane regenerates a
+// 64-output run of the sequential stream.  The Walker alias table is built on the host exactly as
+// gsl_ran_discrete_preproc does (a data-dependent LIFO-stack algorithm, inherently serial).
+// The Gaussian noise uses a counter-based Philox4x32-10 stream keyed by (rng state, draw index,
+// attempt): same distribution as the reference's polar Box-Muller on taus2, not the same numbers
+// (the reference's rejection loops consume a data-dependent number of outputs per particle).
+#include <vector>
+
+#include "abc_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// taus2 (host): [GSL] rng/taus.c
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t taus_c1(uint32_t s) { return ((s & 4294967294u) << 12) ^ (((s << 13) ^ s) >> 19); }
+static inline uint32_t taus_c2(uint32_t s) { return ((s & 4294967288u) << 4) ^ (((s << 2) ^ s) >> 25); }
+static inline uint32_t taus_c3(uint32_t s) { return ((s & 4294967280u) << 17) ^ (((s << 3) ^ s) >> 11); }
+
+uint32_t taus2_get(abc_rng* r) {
+    r->s1 = taus_c1(r->s1); r->s2 = taus_c2(r->s2); r->s3 = taus_c3(r->s3);
+    return r->s1 ^ r->s2 ^ r->s3;
+}
+void taus2_set(abc_rng* r, unsigned long seed) {
+    uint32_t s = (uint32_t)(seed & 0xffffffffUL);
+    if (s == 0) s = 1;
+    r->s1 = 69069u * s;     if (r->s1 < 2) r->s1 += 2;
+    r->s2 = 69069u * r->s1; if (r->s2 < 8) r->s2 += 8;
+    r->s3 = 69069u * r->s2; if (r->s3 < 16) r->s3 += 16;
+    for (int i = 0; i < 6; i++) taus2_get(r);
+}
+
+// 32x32 bit matrices over GF(2), stored as 32 column words: M * e_i = col[i]
+struct BitMat { uint32_t col[32]; };
+static inline uint32_t bm_apply(const BitMat& m, uint32_t v) {
+    uint32_t y = 0;
+    for (int i = 0; i < 32; i++) y ^= (uint32_t)(-(int32_t)((v >> i) & 1u)) & m.col[i];
+    return y;
+}
+static inline BitMat bm_mul(const BitMat& a, const BitMat& b) {   // a*b
+    BitMat c;
+    for (int i = 0; i < 32; i++) c.col[i] = bm_apply(a, b.col[i]);
+    return c;
+}
+static void taus_step_mats(BitMat m[3]) {
+    for (int i = 0; i < 32; i++) {
+        m[0].col[i] = taus_c1(1u << i); m[1].col[i] = taus_c2(1u << i); m[2].col[i] = taus_c3(1u << i);
+    }
+}
+// pow2[k][c] = T_c^(2^k), k = 0..63
+static const BitMat (*taus_pow2())[3] {
+    static BitMat tab[64][3];
+    static bool init = false;
+    if (!init) {
+        taus_step_mats(tab[0]);
+        for (int k = 1; k < 64; k++)
+            for (int c = 0; c < 3; c++) tab[k][c] = bm_mul(tab[k - 1][c], tab[k - 1][c]);
+        init = true;
+    }
+    return tab;
+}
+void taus2_jump(abc_rng* r, uint64_t n) {
+    const BitMat(*tab)[3] = taus_pow2();
+    for (int k = 0; k < 64; k++)
+        if ((n >> k) & 1ull) {
+            r->s1 = bm_apply(tab[k][0], r->s1); r->s2 = bm_apply(tab[k][1], r->s2); r->s3 = bm_apply(tab[k][2], r->s3);
+        }
+}
+
+namespace {
+
+constexpr int RUN = 64;        // consecutive stream outputs regenerated per lane
+constexpr int RUN_LOG2 = 6;
+
+// device table: jt[k][c][32] = T_c^(RUN * 2^k), k = 0..31
+__device__ __forceinline__ uint32_t d_apply(const uint32_t* __restrict__ col, uint32_t v) {
+    uint32_t y = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) y ^= (uint32_t)(-(int32_t)((v >> i) & 1u)) & col[i];
+    return y;
+}
+
+// out[i] = output #(i) of the taus2 stream starting at state `base` (i.e. the value the (i+1)-th
+// gsl_rng_get would return), for i in [0, n)
+__global__ __launch_bounds__(256) void k_taus_stream(abc_rng base, size_t n, const uint32_t* __restrict__ jt,
+                                                     uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t first = t * RUN;
+    if (first >= n) return;
+    uint32_t s1 = base.s1, s2 = base.s2, s3 = base.s3;
+    for (int k = 0; k < 32; k++)
+        if ((t >> k) & 1) {
+            const uint32_t* m = jt + (size_t)k * 96;
+            s1 = d_apply(m, s1); s2 = d_apply(m + 32, s2); s3 = d_apply(m + 64, s3);
+        }
+    const size_t last = (first + RUN < n) ? first + RUN : n;
+    for (size_t i = first; i < last; i++) {
+        s1 = ((s1 & 4294967294u) << 12) ^ (((s1 << 13) ^ s1) >> 19);
+        s2 = ((s2 & 4294967288u) << 4) ^ (((s2 << 2) ^ s2) >> 25);
+        s3 = ((s3 & 4294967280u) << 17) ^ (((s3 << 3) ^ s3) >> 11);
+        out[i] = s1 ^ s2 ^ s3;
+    }
+}
+
+// [GSL] gsl_ran_discrete (KNUTH_CONVENTION): u = get/2^32; c = floor(u*K); F[c]==1 ? c : (u<F[c] ? c : A[c])
+__global__ __launch_bounds__(256) void k_alias_draw(const uint32_t* __restrict__ raw, size_t n,
+                                                    const double* __restrict__ F, const uint32_t* __restrict__ A,
+                                                    size_t K, unsigned long long* __restrict__ parent) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double u = (double)raw[i] / 4294967296.0;
+    const size_t c = (size_t)(u * (double)K);
+    const double f = F[c];
+    parent[i] = (f == 1.0) ? c : ((u < f) ? c : (size_t)A[c]);
+}
+
+__global__ __launch_bounds__(256) void k_widen(const uint32_t* __restrict__ raw, size_t n,
+                                               unsigned long long* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = raw[i];
+}
+
+// ---- Philox4x32-10 --------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // (0,1), 53 bits
+    return ((double)(((unsigned long long)(hi >> 5) << 26) | (lo >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
+}
+// two independent N(0,1) from one Philox block
+__device__ __forceinline__ void normal2(U4 r, double& z0, double& z1) {
+    const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(6.283185307179586476925 * u2, &s, &c);
+    z0 = rad * c; z1 = rad * s;
+}
+
+__device__ __forceinline__ double d_recast(const abc_prior& pr, double v) {          // Priors.h:58,80,106
+    return (pr.kind == ABC_PRIOR_UNIF_INT) ? round(v) : v;
+}
+__device__ __forceinline__ bool d_valid(const abc_prior& pr, double v) {             // Parameter.h:77
+    if (pr.kind == ABC_PRIOR_GAUSS) {
+        const double u = (v - pr.a) / fabs(pr.b);
+        return (1.0 / (sqrt(2.0 * M_PI) * fabs(pr.b))) * exp(-u * u / 2.0) != 0.0;
+    }
+    if (pr.kind == ABC_PRIOR_UNIF_INT) return (v == round(v)) && (pr.a <= v) && (v <= pr.b);
+    return (pr.a <= v) && (v <= pr.b);
+}
+__device__ __forceinline__ double d_prior_mean(const abc_prior& pr) {                 // Priors.h:35
+    return (pr.kind == ABC_PRIOR_GAUSS) ? pr.a : (pr.b + pr.a) / 2.0;
+}
+
+constexpr unsigned MVN_MAX_TRIES = 1u << 20;
+
+// one new particle per lane
+template <int PP>
+__global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __restrict__ theta, size_t K, int P,
+                                                 const abc_prior* __restrict__ priors,
+                                                 const unsigned long long* __restrict__ parent,
+                                                 unsigned long long i0, size_t n, int multivariate,
+                                                 const double* __restrict__ L_or_dv, double* __restrict__ out) {
+    __shared__ double sL[PP * PP];
+    __shared__ abc_prior sp[PP];
+    for (int e = threadIdx.x; e < PP * PP; e += 256) {
+        const int a = e % PP, b = e / PP;
+        double v = 0.0;
+        if (multivariate) { if (a < P && b < P && b <= a) v = L_or_dv[a + (size_t)P * b]; }
+        else if (a == b && a < P) v = sqrt(L_or_dv[a]);                    // AbcUtil.cpp:150
+        sL[e] = v;
+    }
+    for (int p = threadIdx.x; p < PP; p += 256) {
+        abc_prior q; q.kind = ABC_PRIOR_UNIF_REAL; q.pad_ = 0; q.a = -1e300; q.b = 1e300;
+        sp[p] = (p < P) ? priors[p] : q;
+    }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long gi = i0 + i;
+    const size_t par = (size_t)parent[i];
+    double mu[PP], val[PP];
+#pragma unroll
+    for (int p = 0; p < PP; p++) { mu[p] = (p < P) ? theta[par + K * (size_t)p] : 0.0; val[p] = mu[p]; }
+    const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
+    if (multivariate) {
+        // AbcUtil.cpp:132-139: draw the whole vector, accept iff every coordinate is valid
+        for (unsigned attempt = 0; attempt < MVN_MAX_TRIES; attempt++) {
+            double z[PP];
+#pragma unroll
+            for (int p = 0; p < PP; p += 2) {
+                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)(p >> 1);
+                normal2(philox(c, k0, k1), z[p], z[p + 1]);
+            }
+            bool ok = true;
+#pragma unroll
+            for (int a = 0; a < PP; a++) {
+                double x = 0.0;
+#pragma unroll
+                for (int b = 0; b <= a; b++) x = fma(sL[a + PP * b], z[b], x);   // x = L z (lower triangular)
+                const double v = d_recast(sp[a], x + mu[a]);
+                val[a] = v;
+                ok = ok && d_valid(sp[a], v);
+            }
+            if (ok) break;
+            if (attempt + 1 == MVN_MAX_TRIES) {
+#pragma unroll
+                for (int p = 0; p < PP; p++) val[p] = mu[p];   // give up: keep the (valid) parent
+            }
+        }
+    } else {
+        // Priors.h:19-33: per coordinate, up to 1000 tries, then the prior mean
+#pragma unroll
+        for (int p = 0; p < PP; p++) {
+            if (p < P) {
+                double v = 0.0; bool ok = false;
+                for (unsigned attempt = 0; attempt < 1000 && !ok; attempt++) {
+                    U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0x80000000u | (uint32_t)p;
+                    double z0, z1;
+                    normal2(philox(c, k0, k1), z0, z1);
+                    v = d_recast(sp[p], sL[p + PP * p] * z0 + mu[p]);
+                    ok = d_valid(sp[p], v);
+                }
+                val[p] = ok ? v : d_prior_mean(sp[p]);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PP; p++)
+        if (p < P) out[i + n * (size_t)p] = val[p];
+}
+
+int ensure_jump_tab(abc_ctx* ctx) {
+    if (ctx->jump_tab) return ABC_OK;
+    const BitMat(*tab)[3] = taus_pow2();
+    std::vector<uint32_t> h(32 * 96);
+    for (int k = 0; k < 32; k++)
+        for (int c = 0; c < 3; c++)
+            for (int i = 0; i < 32; i++) h[(size_t)k * 96 + c * 32 + i] = tab[k + RUN_LOG2][c].col[i];
+    ABC_HIP(ctx, hipMalloc((void**)&ctx->jump_tab, h.size() * sizeof(uint32_t)));
+    ABC_HIP(ctx, hipMemcpy(ctx->jump_tab, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return ABC_OK;
+}
+
+int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
+    ABC_TRY(ensure_jump_tab(ctx));
+    const size_t threads = (n + RUN - 1) / RUN;
+    hipLaunchKernelGGL(k_taus_stream, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, base, n,
+                       ctx->jump_tab, out);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+// [GSL] gsl_ran_discrete_preproc (randist/discrete.c): Walker alias with two LIFO stacks
+void alias_preproc(size_t K, const double* w, double* F, uint32_t* A) {
+    double total = 0.0;
+    for (size_t k = 0; k < K; k++) total += w[k];
+    std::vector<double> E(K);
+    for (size_t k = 0; k < K; k++) E[k] = w[k] / total;
+    const double mean = 1.0 / (double)K;
+    std::vector<uint32_t> bigs, smalls;
+    bigs.reserve(K); smalls.reserve(K);
+    for (size_t k = 0; k < K; k++) (E[k] < mean ? smalls : bigs).push_back((uint32_t)k);
+    while (!smalls.empty()) {
+        const uint32_t s = smalls.back(); smalls.pop_back();
+        if (bigs.empty()) { A[s] = s; F[s] = 1.0; continue; }
+        const uint32_t b = bigs.back(); bigs.pop_back();
+        A[s] = b;
+        F[s] = (double)K * E[s];
+        const double d = mean - E[s];
+        E[s] += d;
+        E[b] -= d;
+        if (E[b] < mean) smalls.push_back(b);
+        else if (E[b] > mean) bigs.push_back(b);
+        else { A[b] = b; F[b] = 1.0; }
+    }
+    while (!bigs.empty()) { const uint32_t b = bigs.back(); bigs.pop_back(); A[b] = b; F[b] = 1.0; }
+    for (size_t k = 0; k < K; k++) { F[k] += (double)k; F[k] /= (double)K; }
+}
+
+}  // namespace
+
+int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
+                    uint64_t* parent) {
+    if (n == 0) return ABC_OK;
+    if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
+    // alias table: weights to the host, serial Walker build, tables back to HBM
+    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 2 + sizeof(uint32_t))));
+    double* hw = (double*)ctx->pin;
+    double* hF = hw + K;
+    uint32_t* hA = (uint32_t*)(hF + K);
+    ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    alias_preproc(K, hw, hF, hA);
+    if (ctx->alias_K < K) {
+        if (ctx->alias_F) { (void)hipFree(ctx->alias_F); (void)hipFree(ctx->alias_A); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * sizeof(double)));
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_A, K * sizeof(uint32_t)));
+        ctx->alias_K = K;
+    }
+    ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_F, hF, K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_A, hA, K * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
+    abc_rng base = *rng;
+    taus2_jump(&base, i0);
+    ABC_TRY(taus_stream(ctx, base, n, raw));
+    hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
+                       ctx->alias_A, K, (unsigned long long*)parent);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P, const abc_prior* priors,
+                   const uint64_t* parent, uint64_t i0, size_t n, int multivariate, const double* L_or_dv, double* out,
+                   uint64_t* seeds, uint64_t seed_stream_offset) {
+    if (n == 0) return ABC_OK;
+    if (P > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 32", P);
+    int PP = 2;
+    while (PP < (int)P) PP *= 2;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+#define LAUNCH_PT(PPV)                                                                                          \
+    hipLaunchKernelGGL(k_perturb<PPV>, dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, priors, \
+                       (const unsigned long long*)parent, (unsigned long long)i0, n, multivariate, L_or_dv, out)
+    switch (PP) {
+        case 2: LAUNCH_PT(2); break;
+        case 4: LAUNCH_PT(4); break;
+        case 8: LAUNCH_PT(8); break;
+        case 16: LAUNCH_PT(16); break;
+        default: LAUNCH_PT(32); break;
+    }
+#undef LAUNCH_PT
+    ABC_HIP(ctx, hipGetLastError());
+    if (seeds) {
+        // AbcSmc.cpp:535: one gsl_rng_get per new particle; here taken from the taus2 stream at
+        // position seed_stream_offset + i0 + i (after the resampling draws)
+        uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+        if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+        abc_rng base = *rng;
+        taus2_jump(&base, seed_stream_offset + i0);
+        ABC_TRY(taus_stream(ctx, base, n, raw));
+        hipLaunchKernelGGL(k_widen, dim3(blocks), dim3(256), 0, ctx->stream, raw, n, (unsigned long long*)seeds);
+        ABC_HIP(ctx, hipGetLastError());
+    }
+    return ABC_OK;
+}

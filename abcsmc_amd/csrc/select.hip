@@ -1,0 +1,380 @@
+// Selection of the K particles closest to the observation, in ascending (distance, index) order.
+// Replaces [PLS] ordered() = ranker.h order() (AbcUtil.cpp:420,457; lib/ranker.h:46-53) followed by
+// the caller's truncation to the predictive-prior size (AbcSmc.cpp:645-646): only the first K
+// entries of the argsort are ever consumed, so this is an exact radix SELECT of the K-th smallest
+// key + a stable compaction of the winners + a stable LSD radix SORT of those K (key, index) pairs.
+// Integer/byte work, HBM-bound, bit-exact: keys are the IEEE-754 bit patterns of the distances
+// mapped to an order-preserving uint64; ties are broken by particle index (declared).
+#include "abc_internal.h"
+
+namespace {
+
+struct SelState {
+    unsigned long long prefix;  // bits decided so far (high bits)
+    unsigned long long mask;    // which bits are decided
+    unsigned long long krem;    // 1-based rank still to find inside the current prefix bucket
+    unsigned long long n_less;  // #keys strictly below the threshold (valid after the last pass)
+    unsigned long long ties;    // #keys equal to the threshold to take (lowest indices first)
+};
+
+__device__ __forceinline__ unsigned long long key_of(double d) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dist_of(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+constexpr int SEL_BITS = 11;
+constexpr int SEL_BINS = 1 << SEL_BITS;
+
+__global__ void k_sel_init(SelState* st, unsigned long long K, unsigned int* hist) {
+    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) { st->prefix = 0; st->mask = 0; st->krem = K; st->n_less = 0; st->ties = 0; }
+}
+
+// histogram of the digit [shift, shift+nbits) over keys matching the decided prefix
+__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ dist, size_t n,
+                                                  const SelState* __restrict__ st, int shift, int nbits,
+                                                  unsigned int* __restrict__ hist) {
+    __shared__ unsigned int lh[SEL_BINS];
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = st->prefix, mask = st->mask;
+    const unsigned int dm = (1u << nbits) - 1u;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned long long k = key_of(dist[i]);
+        if ((k & mask) == prefix) atomicAdd(&lh[(unsigned int)(k >> shift) & dm], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) {
+        const unsigned int c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// one work-group: find the digit whose cumulative count reaches krem; update state; clear hist
+__global__ __launch_bounds__(256) void k_sel_pick(SelState* st, int shift, int nbits, unsigned int* hist,
+                                                  int last, unsigned long long K) {
+    __shared__ unsigned long long csum[256];
+    __shared__ int found_digit;
+    __shared__ unsigned long long found_below;
+    const int t = threadIdx.x;
+    const int bins = 1 << nbits;
+    const int per = (bins + 255) / 256;
+    unsigned long long loc = 0;
+    for (int j = 0; j < per; j++) { const int b = t * per + j; if (b < bins) loc += hist[b]; }
+    csum[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 256; i++) { const unsigned long long v = csum[i]; csum[i] = run; run += v; }
+    }
+    __syncthreads();
+    const unsigned long long krem = st->krem;
+    unsigned long long run = csum[t];
+    for (int j = 0; j < per; j++) {
+        const int b = t * per + j;
+        if (b < bins) {
+            const unsigned long long c = hist[b];
+            if (run < krem && krem <= run + c) { found_digit = b; found_below = run; }
+            run += c;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long dm = ((1ull << nbits) - 1ull) << shift;
+        st->prefix |= ((unsigned long long)found_digit) << shift;
+        st->mask |= dm;
+        st->krem = krem - found_below;
+        if (last) { st->ties = st->krem; st->n_less = K - st->krem; }
+    }
+    for (int i = t; i < SEL_BINS; i += 256) hist[i] = 0;
+}
+
+constexpr int CP_ITEMS = 8;
+constexpr int CP_CHUNK = 256 * CP_ITEMS;
+
+// per-chunk counts of (key < T) and (key == T)
+__global__ __launch_bounds__(256) void k_cp_count(const double* __restrict__ dist, size_t n,
+                                                  const SelState* __restrict__ st,
+                                                  unsigned int* __restrict__ cnt /* [2][nb] */, int nb) {
+    __shared__ unsigned int sl[4], se[4];
+    const unsigned long long T = st->prefix;
+    const size_t base = (size_t)blockIdx.x * CP_CHUNK + (size_t)threadIdx.x * CP_ITEMS;
+    unsigned int l = 0, e = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) {
+        const size_t i = base + j;
+        if (i < n) { const unsigned long long k = key_of(dist[i]); l += (k < T); e += (k == T); }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { l += __shfl_xor(l, o, 64); e += __shfl_xor(e, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = l; se[threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt[blockIdx.x] = sl[0] + sl[1] + sl[2] + sl[3];
+        cnt[nb + blockIdx.x] = se[0] + se[1] + se[2] + se[3];
+    }
+}
+
+// exclusive scan of m unsigned counters in place, one work-group (sequential over 256-wide slabs)
+__global__ __launch_bounds__(256) void k_scan_u32(unsigned int* __restrict__ a, int m0, int m1) {
+    __shared__ unsigned int s[256];
+    __shared__ unsigned int carry;
+    for (int seg = 0; seg < 2; seg++) {
+        unsigned int* p = seg ? a + m0 : a;
+        const int m = seg ? m1 : m0;
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < m; b0 += 256) {
+            const int i = b0 + threadIdx.x;
+            const unsigned int v = (i < m) ? p[i] : 0u;
+            s[threadIdx.x] = v;
+            __syncthreads();
+            for (int o = 1; o < 256; o <<= 1) {
+                const unsigned int add = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0u;
+                __syncthreads();
+                s[threadIdx.x] += add;
+                __syncthreads();
+            }
+            const unsigned int incl = s[threadIdx.x];
+            const unsigned int c = carry;
+            if (i < m) p[i] = c + incl - v;
+            __syncthreads();
+            if (threadIdx.x == 255) carry = c + incl;
+            __syncthreads();
+        }
+    }
+}
+
+// stable compaction: winners with key < T to [0, n_less) and the first `ties` keys == T to
+// [n_less, K), both in particle-index order
+__global__ __launch_bounds__(256) void k_cp_write(const double* __restrict__ dist, size_t n,
+                                                  const SelState* __restrict__ st,
+                                                  const unsigned int* __restrict__ off /* [2][nb] scanned */,
+                                                  int nb, unsigned long long idx_base,
+                                                  unsigned long long* __restrict__ okey,
+                                                  unsigned long long* __restrict__ oidx) {
+    __shared__ unsigned int wl[4], we[4];
+    const unsigned long long T = st->prefix, n_less = st->n_less, ties = st->ties;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t base = (size_t)blockIdx.x * CP_CHUNK + (size_t)t * CP_ITEMS;
+    unsigned long long k[CP_ITEMS];
+    unsigned int l = 0, e = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) {
+        const size_t i = base + j;
+        k[j] = (i < n) ? key_of(dist[i]) : ~0ull;
+        if (i < n) { l += (k[j] < T); e += (k[j] == T); }
+    }
+    // exclusive scan over threads (wave scan + cross-wave)
+    unsigned int il = l, ie = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int al = __shfl_up(il, o, 64), ae = __shfl_up(ie, o, 64);
+        if (lane >= o) { il += al; ie += ae; }
+    }
+    if (lane == 63) { wl[wave] = il; we[wave] = ie; }
+    __syncthreads();
+    unsigned int pl = il - l, pe = ie - e;
+    for (int w = 0; w < wave; w++) { pl += wl[w]; pe += we[w]; }
+    unsigned long long posl = (unsigned long long)off[blockIdx.x] + pl;
+    unsigned long long pose = (unsigned long long)off[nb + blockIdx.x] + pe;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) {
+        const size_t i = base + j;
+        if (i >= n) break;
+        if (k[j] < T) { okey[posl] = k[j]; oidx[posl] = idx_base + i; posl++; }
+        else if (k[j] == T) {
+            if (pose < ties) { okey[n_less + pose] = k[j]; oidx[n_less + pose] = idx_base + i; }
+            pose++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_init_pairs(const double* __restrict__ dist, size_t n,
+                                                    unsigned long long idx_base,
+                                                    unsigned long long* __restrict__ okey,
+                                                    unsigned long long* __restrict__ oidx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { okey[i] = key_of(dist[i]); if (oidx) oidx[i] = idx_base + i; }
+}
+
+__global__ __launch_bounds__(256) void k_keys_to_dist(const unsigned long long* __restrict__ key, size_t n,
+                                                      double* __restrict__ dist) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dist[i] = dist_of(key[i]);
+}
+
+// ---- stable LSD radix sort of (key, idx) pairs, 8 bits per pass ---------------------------------
+constexpr int ST_ITEMS = 8;
+constexpr int ST_CHUNK = 256 * ST_ITEMS;   // items per work-group; each wave owns ST_CHUNK/4 in order
+
+__global__ __launch_bounds__(256) void k_sort_hist(const unsigned long long* __restrict__ key, size_t n, int shift,
+                                                   unsigned int* __restrict__ bh /* [256][nb] */, int nb) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * ST_CHUNK;
+#pragma unroll
+    for (int j = 0; j < ST_ITEMS; j++) {
+        const size_t i = base + (size_t)j * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&lh[(unsigned int)(key[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    bh[(size_t)threadIdx.x * nb + blockIdx.x] = lh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(const unsigned long long* __restrict__ key,
+                                                      const unsigned long long* __restrict__ idx, size_t n,
+                                                      int shift, const unsigned int* __restrict__ bh, int nb,
+                                                      unsigned long long* __restrict__ okey,
+                                                      unsigned long long* __restrict__ oidx) {
+    __shared__ unsigned int whist[4][256];
+    __shared__ volatile unsigned int woff[4][256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) whist[w][t] = 0;
+    __syncthreads();
+    const size_t seg = (size_t)blockIdx.x * ST_CHUNK + (size_t)wave * (ST_CHUNK / 4);
+    unsigned long long k[ST_ITEMS];
+#pragma unroll
+    for (int j = 0; j < ST_ITEMS; j++) {
+        const size_t i = seg + (size_t)j * 64 + lane;
+        k[j] = (i < n) ? key[i] : 0ull;
+        if (i < n) atomicAdd(&whist[wave][(unsigned int)(k[j] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {
+        unsigned int run = bh[(size_t)t * nb + blockIdx.x];   // scanned: global base of (digit t, this block)
+#pragma unroll
+        for (int w = 0; w < 4; w++) { woff[w][t] = run; run += whist[w][t]; }
+    }
+    __syncthreads();
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < ST_ITEMS; j++) {
+        const size_t i = seg + (size_t)j * 64 + lane;
+        const bool valid = i < n;
+        const unsigned int d = (unsigned int)(k[j] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        if (valid) {
+            const unsigned int rank = __popcll(peers & lt_mask);
+            const unsigned int pos = woff[wave][d] + rank;
+            okey[pos] = k[j];
+            oidx[pos] = idx[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0) woff[wave][d] += (unsigned int)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// exclusive scan of the digit-major [256][nb] block histogram, one work-group
+__global__ __launch_bounds__(256) void k_sort_scan(unsigned int* __restrict__ bh, int nb) {
+    __shared__ unsigned int tot[256];
+    const int t = threadIdx.x;
+    unsigned int s = 0;
+    for (int b = 0; b < nb; b++) s += bh[(size_t)t * nb + b];
+    tot[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        unsigned int run = 0;
+        for (int d = 0; d < 256; d++) { const unsigned int v = tot[d]; tot[d] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned int run = tot[t];
+    for (int b = 0; b < nb; b++) {
+        const unsigned int v = bh[(size_t)t * nb + b];
+        bh[(size_t)t * nb + b] = run;
+        run += v;
+    }
+}
+
+// sorts n pairs; result ends in (key0, idx0); (key1, idx1) is scratch of the same size
+int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* idx0, unsigned long long* key1,
+                   unsigned long long* idx1, size_t n) {
+    if (n <= 1) return ABC_OK;
+    const int nb = (int)((n + ST_CHUNK - 1) / ST_CHUNK);
+    unsigned int* bh = (unsigned int*)abc_ws_alloc(ctx, (size_t)256 * nb * sizeof(unsigned int));
+    if (!bh) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sort: workspace exhausted");
+    unsigned long long *ka = key0, *ia = idx0, *kb = key1, *ib = idx1;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, ctx->stream, ka, n, shift, bh, nb);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(256), 0, ctx->stream, bh, nb);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, ctx->stream, ka, ia, n, shift, bh, nb, kb, ib);
+        unsigned long long* tk = ka; ka = kb; kb = tk;
+        unsigned long long* ti = ia; ia = ib; ib = ti;
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;   // 8 passes: even number of swaps -> result back in (key0, idx0)
+}
+
+}  // namespace
+
+int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx,
+                           double* dist_out) {
+    if (K == 0) return ABC_OK;
+    if (K > n) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: K = %zu > n = %zu", K, n);
+    unsigned long long* key0 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
+    unsigned long long* key1 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
+    unsigned long long* idx1 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
+    if (!key0 || !key1 || !idx1) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
+    unsigned long long* idx0 = (unsigned long long*)idx;
+    if (K == n) {
+        hipLaunchKernelGGL(k_init_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dist, n,
+                           (unsigned long long)idx_base, key0, idx0);
+    } else {
+        SelState* st = (SelState*)abc_ws_alloc(ctx, sizeof(SelState));
+        unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, SEL_BINS * sizeof(unsigned int));
+        const int nb = (int)((n + CP_CHUNK - 1) / CP_CHUNK);
+        unsigned int* cnt = (unsigned int*)abc_ws_alloc(ctx, (size_t)2 * nb * sizeof(unsigned int));
+        if (!st || !hist || !cnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
+        hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, st, (unsigned long long)K, hist);
+        size_t hb = (n + 255) / 256;
+        if (hb > 2048) hb = 2048;
+        static const int shifts[6] = {53, 42, 31, 20, 9, 0};
+        static const int widths[6] = {11, 11, 11, 11, 11, 9};
+        for (int p = 0; p < 6; p++) {
+            hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)hb), dim3(256), 0, ctx->stream, dist, n, st, shifts[p],
+                               widths[p], hist);
+            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, st, shifts[p], widths[p], hist,
+                               (int)(p == 5), (unsigned long long)K);
+        }
+        hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb);
+        hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb,
+                           (unsigned long long)idx_base, key0, idx0);
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    ABC_TRY(sort_pairs_u64(ctx, key0, idx0, key1, idx1, K));
+    if (dist_out) {
+        hipLaunchKernelGGL(k_keys_to_dist, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, key0, K,
+                           dist_out);
+        ABC_HIP(ctx, hipGetLastError());
+    }
+    return ABC_OK;
+}
+
+int launch_sort_pairs(abc_ctx* ctx, double* key, uint64_t* idx, size_t n) {
+    if (n <= 1) return ABC_OK;
+    unsigned long long* key0 = (unsigned long long*)abc_ws_alloc(ctx, n * 8);
+    unsigned long long* key1 = (unsigned long long*)abc_ws_alloc(ctx, n * 8);
+    unsigned long long* idx1 = (unsigned long long*)abc_ws_alloc(ctx, n * 8);
+    if (!key0 || !key1 || !idx1) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sort: workspace exhausted");
+    hipLaunchKernelGGL(k_init_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key, n, 0ull, key0,
+                       (unsigned long long*)nullptr);
+    ABC_TRY(sort_pairs_u64(ctx, key0, (unsigned long long*)idx, key1, idx1, n));
+    hipLaunchKernelGGL(k_keys_to_dist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key0, n, key);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}

@@ -1,0 +1,247 @@
+// Posterior bookkeeping of one SMC set: gather of the K selected parameter rows, doubled variance,
+// Gaussian-kernel importance weights and their L2 normalisation.
+// Replaces ABC::calculate_doubled_variance (AbcUtil.cpp:528-537, RunningStat.h:16-46),
+// ABC::weight_predictive_prior (AbcUtil.cpp:539-586), Parameter::likelihood (Priors.h:54-56, 76-78,
+// 102-104) and the Eigen row gathers of AbcSmc.cpp:1045-1060.
+//
+// The weight kernel is the compute-bound stage of a generation, O(K * K' * P): per pair the P
+// per-parameter Gaussian factors of the reference are fused into ONE exponential,
+//   prod_p pdf(t_ip - t'_jp; sqrt(dv_p)) = C * exp(-1/2 sum_p ((t_ip - t'_jp)/sigma_p)^2),
+// with both parameter sets pre-scaled by 1/sigma_p.  One new particle per lane; previous-set rows
+// are wave-uniform and stream through the scalar cache.  fp64 VALU throughout.
+#include "abc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* sm /* >= 4 */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ Y, size_t n_local, size_t ldy,
+                                                     int P, const unsigned long long* __restrict__ idx, size_t K,
+                                                     unsigned long long idx_base, double* __restrict__ theta,
+                                                     size_t ldt) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * (size_t)P) return;
+    const size_t i = e % K, p = e / K;
+    const unsigned long long g = idx[i];
+    if (g >= idx_base && g - idx_base < n_local) theta[i + ldt * p] = Y[(g - idx_base) + ldy * p];
+}
+
+// one work-group per parameter: dv_p = 2 * sum (x - mean)^2 / (K - 1)
+__global__ __launch_bounds__(256) void k_doubled_variance(const double* __restrict__ theta, size_t K,
+                                                          double* __restrict__ dv) {
+    __shared__ double sm[4];
+    const double* col = theta + K * (size_t)blockIdx.x;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < K; i += 256) s += col[i];
+    const double mean = block_sum_256(s, sm) / (double)K;
+    double ss = 0.0;
+    for (size_t i = threadIdx.x; i < K; i += 256) { const double d = col[i] - mean; ss = fma(d, d, ss); }
+    ss = block_sum_256(ss, sm);
+    if (threadIdx.x == 0) dv[blockIdx.x] = (K > 1) ? 2.0 * (ss / (double)(K - 1)) : 0.0;
+}
+
+// ---- weights --------------------------------------------------------------------------------------
+struct WConst {           // per-parameter constants, built on the device by k_wprep
+    double scale[32];     // 1/sqrt(dv_p), or 0 when dv_p == 0
+    double logC;          // unused
+    double C;             // prod over dv_p != 0 of 1/(sqrt(2 pi) sqrt(dv_p))
+    int nzero;            // number of parameters with dv_p == 0
+    int zero_idx[32];
+};
+
+__global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc) {
+    if (threadIdx.x != 0) return;
+    double C = 1.0; int nz = 0;
+    for (int p = 0; p < 32; p++) {
+        double sc = 0.0;
+        if (p < P) {
+            const double dv = dv_prev[p];
+            if (dv != 0.0) { const double sg = sqrt(dv); sc = 1.0 / sg; C *= 1.0 / (sqrt(2.0 * M_PI) * sg); }
+            else wc->zero_idx[nz++] = p;
+        }
+        wc->scale[p] = sc;
+    }
+    wc->C = C; wc->nzero = nz; wc->logC = 0.0;
+}
+
+// scaled copies: out[row*PP + p] = in[row + ld*p] * scale[p]   (row-major, zero padded to PP)
+__global__ __launch_bounds__(256) void k_wscale(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP,
+                                                const WConst* __restrict__ wc, double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * (size_t)PP) return;
+    const size_t r = e / PP; const int p = (int)(e % PP);
+    out[e] = (p < P) ? in[r + ld * p] * wc->scale[p] : 0.0;
+}
+
+// partial denominators: part[slice*kn + i] = sum_{j in slice} w'_j * exp(-1/2 |a_i - b_j|^2) [* zero-dv mask]
+template <int PP>
+__global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn x PP scaled rows */, size_t kn,
+                                             const double* __restrict__ b /* Kp x PP scaled rows */, size_t Kp,
+                                             const double* __restrict__ w_prev, const WConst* __restrict__ wc,
+                                             const double* __restrict__ theta_raw, size_t K, size_t k0,
+                                             const double* __restrict__ prev_raw, double* __restrict__ part) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t slices = gridDim.y, sl = blockIdx.y;
+    const size_t j0 = Kp * sl / slices, j1 = Kp * (sl + 1) / slices;
+    const bool active = i < kn;
+    double ai[PP];
+#pragma unroll
+    for (int p = 0; p < PP; p++) ai[p] = active ? a[i * PP + p] : 0.0;
+    const int nzero = wc->nzero;
+    double acc = 0.0;
+    for (size_t j = j0; j < j1; j++) {
+        const double* bj = b + j * PP;
+        double e = 0.0;
+#pragma unroll
+        for (int p = 0; p < PP; p++) { const double d = ai[p] - bj[p]; e = fma(d, d, e); }
+        double term = w_prev[j] * exp(-0.5 * e);
+        if (nzero) {   // converged parameters: factor 1 if equal (AbcUtil.cpp:573), else 0 (declared)
+            for (int z = 0; z < nzero; z++) {
+                const int p = wc->zero_idx[z];
+                if (active && theta_raw[(k0 + i) + K * (size_t)p] != prev_raw[j + Kp * (size_t)p]) term = 0.0;
+            }
+        }
+        acc += term;
+    }
+    if (active) part[sl * kn + i] = acc;
+}
+
+__device__ __forceinline__ double gaussian_pdf(double x, double sigma) {   // [GSL] gsl_ran_gaussian_pdf
+    const double u = x / fabs(sigma);
+    return (1.0 / (sqrt(2.0 * M_PI) * fabs(sigma))) * exp(-u * u / 2.0);
+}
+
+__device__ __forceinline__ double prior_likelihood(const abc_prior& pr, double v) {
+    if (pr.kind == ABC_PRIOR_GAUSS) return gaussian_pdf(v - pr.a, pr.b);
+    if (pr.kind == ABC_PRIOR_UNIF_INT)
+        return ((v == round(v)) && (pr.a <= v) && (v <= pr.b)) ? 1.0 / (pr.b - pr.a + 1.0) : 0.0;
+    return ((pr.a <= v) && (v <= pr.b)) ? 1.0 / (pr.b - pr.a) : 0.0;
+}
+
+// w_raw[i] = prod_p likelihood_p(theta_ip) / (C * sum over slices)   (AbcUtil.cpp:557-580)
+__global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ priors, const double* __restrict__ theta,
+                                                 size_t K, int P, size_t k0, size_t kn,
+                                                 const double* __restrict__ part, int slices,
+                                                 const WConst* __restrict__ wc, double* __restrict__ w_raw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= kn) return;
+    double num = 1.0;
+    for (int p = 0; p < P; p++) num *= prior_likelihood(priors[p], theta[(k0 + i) + K * (size_t)p]);
+    double den = 0.0;
+    for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
+    w_raw[i] = num / (wc->C * den);
+}
+
+__global__ __launch_bounds__(256) void k_fill(double* __restrict__ w, size_t K, double v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < K) w[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict__ w, size_t K,
+                                                       double* __restrict__ part) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < K; i += (size_t)gridDim.x * 256) s = fma(w[i], w[i], s);
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t K, const double* __restrict__ part,
+                                                  int nparts) {
+    double sq = 0.0;
+    for (int b = 0; b < nparts; b++) sq += part[b];
+    if (!(sq > 0.0)) return;                     // Eigen normalize(): only if squaredNorm > 0
+    const double nrm = sqrt(sq);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < K) w[i] = w[i] / nrm;
+}
+
+}  // namespace
+
+int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P, const uint64_t* idx,
+                       size_t K, uint64_t idx_base, double* theta, size_t ldt) {
+    const size_t tot = K * P;
+    if (!tot) return ABC_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Y, n_local, ldy,
+                       (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
+    if (!P) return ABC_OK;
+    hipLaunchKernelGGL(k_doubled_variance, dim3((unsigned)P), dim3(256), 0, ctx->stream, theta, K, dv);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P, size_t k0,
+                       size_t kn, const double* theta_prev, size_t Kp, const double* w_prev, const double* dv_prev,
+                       double* w_raw) {
+    if (P > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 32 parameters", P);
+    if (kn == 0) return ABC_OK;
+    if (k0 + kn > K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: row range [%zu,%zu) outside K=%zu", k0, k0 + kn, K);
+    int PP = 2;
+    while (PP < (int)P) PP *= 2;
+    const size_t rb = (kn + 255) / 256;
+    size_t slices = (2048 + rb - 1) / rb;
+    if (slices > Kp / 64) slices = Kp / 64;
+    if (slices < 1) slices = 1;
+    if (slices > 1024) slices = 1024;
+    WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
+    double* a = (double*)abc_ws_alloc(ctx, kn * PP * sizeof(double));
+    double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
+    double* part = (double*)abc_ws_alloc(ctx, slices * kn * sizeof(double));
+    if (!wc || !a || !b || !part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc);
+    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn * PP + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
+                       (int)P, PP, wc, a);
+    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp * PP + 255) / 256)), dim3(256), 0, ctx->stream, theta_prev, Kp, Kp,
+                       (int)P, PP, wc, b);
+#define LAUNCH_KDE(PPV)                                                                                        \
+    hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
+                       Kp, w_prev, wc, theta, K, k0, theta_prev, part)
+    switch (PP) {
+        case 2: LAUNCH_KDE(2); break;
+        case 4: LAUNCH_KDE(4); break;
+        case 8: LAUNCH_KDE(8); break;
+        case 16: LAUNCH_KDE(16); break;
+        default: LAUNCH_KDE(32); break;
+    }
+#undef LAUNCH_KDE
+    hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
+                       (int)slices, wc, w_raw);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_fill(abc_ctx* ctx, double* w, size_t K, double v) {
+    if (!K) return ABC_OK;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, v);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K) {
+    if (!K) return ABC_OK;
+    int nparts = (int)((K + 255) / 256);
+    if (nparts > 256) nparts = 256;
+    double* part = (double*)abc_ws_alloc(ctx, nparts * sizeof(double));
+    if (!part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "normalize: workspace exhausted");
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(nparts), dim3(256), 0, ctx->stream, w, K, part);
+    hipLaunchKernelGGL(k_div_norm, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, part, nparts);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}

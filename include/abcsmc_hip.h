@@ -1,0 +1,220 @@
+/*
+ * abcsmc_hip.h -- C ABI of the MI355X (gfx950) implementation of AbcSmc's per-generation
+ * numerical hot path.  Plain pointers and sizes only; no C++/torch types cross this line.
+ *
+ * The reference has no FFI for its numerics: the boundary this library replaces is the set of
+ * C++ free functions in namespace ABC declared in /root/reference/include/AbcSmc/AbcUtil.h:78-172
+ * and called from /root/reference/src/AbcSmc.cpp:490-518, 634-640, 1041-1066.  Each entry point
+ * below names the declaration it stands in for.  A C++ facade with the reference's own
+ * signatures sits on top (abcsmc_amd/cxx/AbcUtilHip.hpp); INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - all matrices are double, COLUMN-MAJOR with leading dimension = number of rows (Eigen's
+ *     default layout for the reference's Mat2D): each metric / parameter is one contiguous
+ *     particle-major vector.
+ *   - functions WITHOUT the _dev suffix take HOST pointers (drop-in for the reference call
+ *     sites); functions WITH _dev take DEVICE pointers (HBM-resident data, used by bench.py and
+ *     the multi-GPU driver) and run asynchronously on the context's stream.
+ *   - every function returns ABC_OK (0) or a negative abc_status; abc_last_error() gives text.
+ *     Nothing here calls exit() or throws (the reference exits/aborts).
+ *   - one context per GPU and per host thread; calls on one context are serialised.
+ */
+#ifndef ABCSMC_HIP_H
+#define ABCSMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct abc_ctx abc_ctx;
+
+typedef enum {
+    ABC_OK = 0,
+    ABC_ERR_INVALID = -1,       /* bad argument (reference: assert / exit)                   */
+    ABC_ERR_HIP = -2,           /* HIP runtime failure                                        */
+    ABC_ERR_NOT_SPD = -3,       /* covariance not positive definite (reference: GSL abort)    */
+    ABC_ERR_UNSUPPORTED = -4,   /* size outside what the kernels are built for                */
+    ABC_ERR_NOMEM = -5
+} abc_status;
+
+/* POD form of the concrete priors in Priors.h:46-110 (likelihood / recast / valid / mean). */
+enum { ABC_PRIOR_GAUSS = 0, ABC_PRIOR_UNIF_INT = 1, ABC_PRIOR_UNIF_REAL = 2 };
+typedef struct {
+    int32_t kind;     /* ABC_PRIOR_*                               */
+    int32_t pad_;
+    double  a;        /* GAUSS: mean ; UNIF_*: min                 */
+    double  b;        /* GAUSS: sd   ; UNIF_*: max                 */
+} abc_prior;
+
+/* gsl_rng_taus2 state (examples/include/examples.h:10); abc_rng_set == gsl_rng_set. */
+typedef struct { uint32_t s1, s2, s3; } abc_rng;
+
+/* PLS component-selection rule ([PLS] optimal_num_components, AbcUtil.cpp:447-449). */
+enum { ABC_RULE_MIN_PRESS = 0, ABC_RULE_WILCOXON = 1 };
+
+/* ---- context ----------------------------------------------------------------------- */
+int  abc_ctx_create(int device, abc_ctx** out);
+void abc_ctx_destroy(abc_ctx* ctx);
+const char* abc_last_error(const abc_ctx* ctx);
+/* Run on an existing hipStream_t (e.g. torch's current stream); NULL -> context's own. */
+int  abc_ctx_set_stream(abc_ctx* ctx, void* hip_stream);
+int  abc_ctx_synchronize(abc_ctx* ctx);
+int  abc_version(void);
+
+/* ---- RNG (gsl_rng_set / gsl_rng_get on taus2) ------------------------------------------- */
+void     abc_rng_set(abc_rng* r, unsigned long seed);
+uint32_t abc_rng_get(abc_rng* r);
+/* advance the state by n outputs in O(log n) (taus2 is GF(2)-linear) */
+void     abc_rng_jump(abc_rng* r, uint64_t n);
+
+/* ======================================================================================== */
+/* HOST-pointer entry points (drop-in for the AbcUtil.h free functions)                     */
+/* ======================================================================================== */
+
+/* ABC::particle_ranking_PLS (AbcUtil.h:149-153, AbcUtil.cpp:423-458).
+ * X: N x M metrics, Y: N x P parameters, obs: M observed metrics.  Returns the first K entries
+ * of the ascending-distance ordering (the caller keeps only those: AbcSmc.cpp:645-646); K = N
+ * gives the whole vector the reference returns.  max_comp <= 0 -> min(M,P).
+ * Optional outputs (NULL to skip): dist[K], ncomp, R[M*A], mean[M], sd[M]. */
+int abc_particle_ranking_pls(abc_ctx* ctx, const double* X, const double* Y, const double* obs,
+                             size_t N, size_t M, size_t P, double train_frac, int max_comp,
+                             int rule, size_t K, uint64_t* idx, double* dist, int32_t* ncomp,
+                             double* R, double* mean, double* sd);
+
+/* ABC::particle_ranking_simple (AbcUtil.h:144-147, AbcUtil.cpp:408-421) */
+int abc_particle_ranking_simple(abc_ctx* ctx, const double* X, const double* obs, size_t N,
+                                size_t M, size_t K, uint64_t* idx, double* dist);
+
+/* ABC::calculate_doubled_variance (AbcUtil.h:168-170, AbcUtil.cpp:528-537); theta K x P */
+int abc_calculate_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv);
+
+/* ABC::weight_predictive_prior, set 0 (AbcUtil.h:155-158, AbcUtil.cpp:539-545) */
+int abc_weight_predictive_prior_uniform(abc_ctx* ctx, size_t K, double* w);
+
+/* ABC::weight_predictive_prior, set > 0 (AbcUtil.h:160-166, AbcUtil.cpp:547-586): Gaussian-kernel
+ * importance weights, L2-normalised.  theta K x P, theta_prev Kp x P, w_prev[Kp], dv_prev[P]. */
+int abc_weight_predictive_prior(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K,
+                                size_t P, const double* theta_prev, size_t Kp, const double* w_prev,
+                                const double* dv_prev, double* w);
+
+/* ABC::setup_mvn_sampler (AbcUtil.h:128-130, AbcUtil.cpp:462-488): L is P x P column-major, lower
+ * triangle + diagonal = Cholesky factor of the doubled-diagonal covariance, strict upper triangle =
+ * covariance entries (as gsl_linalg_cholesky_decomp1 leaves them). */
+int abc_setup_mvn_sampler(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L);
+
+/* ABC::gsl_rng_nonuniform_int / sample_posterior (AbcUtil.h:78, 110-114; AbcUtil.cpp:111-120,
+ * 366-375): n weighted draws of parent rows; consumes exactly n outputs of rng (bit-exact with
+ * gsl_ran_discrete on taus2) and advances it. */
+int abc_sample_posterior(abc_ctx* ctx, abc_rng* rng, const double* w, size_t K, size_t n, uint64_t* idx);
+
+/* ABC::sample_mvn_predictive_priors (AbcUtil.h:132-137, AbcUtil.cpp:391-404, 122-143) and
+ * ABC::sample_predictive_priors (AbcUtil.h:121-126, AbcUtil.cpp:377-389, 145-158).
+ * out: n x P proposals; parent (optional): n parent rows; seeds (optional): n simulator seeds
+ * (AbcSmc.cpp:535).  Parent indices are bit-exact with the reference stream; the Gaussian noise
+ * comes from a counter-based generator keyed by (rng state, particle), i.e. it is distributed as
+ * the reference's but is not the same stream (DESIGN.md "Declared deviations"). */
+int abc_sample_mvn_predictive_priors(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w,
+                                     const double* theta, size_t K, size_t P, const abc_prior* priors,
+                                     const double* L, double* out, uint64_t* parent, uint64_t* seeds);
+int abc_sample_predictive_priors(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w,
+                                 const double* theta, size_t K, size_t P, const abc_prior* priors,
+                                 const double* dv, double* out, uint64_t* parent, uint64_t* seeds);
+
+/* ======================================================================================== */
+/* DEVICE-pointer entry points                                                               */
+/* ======================================================================================== */
+
+/* One SMC generation turn-over with everything resident in HBM
+ * (AbcSmc.cpp:634-664 rank+truncate, :1041-1066 dv+weights, :490-518 proposals, :535 seeds). */
+typedef struct {
+    size_t N, M, P;            /* this set: particles, metrics, parameters                   */
+    size_t K, Kp, Nnext;       /* pred-prior size, previous pred-prior size (0 = set 0), next */
+    double train_frac;
+    int32_t max_comp, rule, multivariate, reserved;
+} abc_generation_cfg;
+
+typedef struct {               /* all DEVICE pointers; optional ones may be NULL              */
+    const double* X;           /* N x M                                                       */
+    const double* Y;           /* N x P                                                       */
+    const double* obs;         /* M                                                           */
+    const abc_prior* priors;   /* P                                                           */
+    const double* theta_prev;  /* Kp x P  (NULL for set 0)                                    */
+    const double* w_prev;      /* Kp                                                          */
+    const double* dv_prev;     /* P                                                           */
+    uint64_t* idx;             /* K   selected particle rows, ascending distance              */
+    double*   dist;            /* K   their distances (optional)                              */
+    double*   theta;           /* K x P gathered posterior (optional)                         */
+    double*   w;               /* K   weights                                                 */
+    double*   dv;              /* P   doubled variance                                        */
+    double*   L;               /* P x P Cholesky factor (multivariate; optional)              */
+    double*   next;            /* Nnext x P proposals                                         */
+    uint64_t* parent;          /* Nnext parent rows (optional)                                */
+    uint64_t* seeds;           /* Nnext simulator seeds (optional)                            */
+} abc_generation_io;
+
+int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, const abc_generation_io* io,
+                       abc_rng* rng, int32_t* ncomp_host);
+
+/* ---- stage-level device entry points (used by the sharded multi-GPU driver) -- */
+
+/* Doubles needed for one sufficient-statistics record for (M,P):
+ *   [ n_train, n_test, shift[C16], sum_train[C16], sum_test[C16], G_train[C16*C16], G_test[C16*C16] ]
+ * with C16 = 16*ceil((M+P)/16).  Records from different row shards that used the same shift are
+ * combined by plain addition of everything after shift[] (that is the packed all-reduce). */
+size_t abc_stats_len(size_t M, size_t P);
+/* pilot shift (mean of the first min(n,256) local rows) -> stats record's shift[]; rank 0's
+ * record is broadcast before abc_stats_accumulate_dev in the sharded driver. */
+int abc_stats_shift_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx,
+                        size_t ldy, size_t M, size_t P, double* stats);
+/* one pass over the local rows: column sums + Gram of the shifted [X|Y], train rows =
+ * global rows < n_train_global.  row0 = global index of local row 0. */
+int abc_stats_accumulate_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx,
+                             size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
+                             double* stats);
+/* model record length in doubles, and the fit: z-score moments, kernel-PLS deflation (type 2),
+ * PRESS on the test statistics, component choice, observed scores. */
+size_t abc_model_len(size_t M, size_t P, size_t A);
+int abc_pls_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P,
+                      size_t A, int rule, double* model);
+int abc_model_ncomp(abc_ctx* ctx, const double* model, size_t M, size_t P, size_t A, int32_t* ncomp);
+/* "simple" model: only means / sds / z-scored obs (AbcUtil.cpp:412-416) */
+int abc_simple_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P,
+                         double* model);
+/* per-row distance to the observed scores (AbcUtil.cpp:453-455, or :419 when simple != 0) */
+int abc_project_distance_dev(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P,
+                             size_t A, const double* model, int simple, double* dist);
+/* K smallest of dist[n] in ascending (dist, index) order: idx[K] (local row + idx_base), dist[K] */
+int abc_select_smallest_dev(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base,
+                            uint64_t* idx, double* dist_out);
+/* sort n (key, idx) pairs by (key, idx); used to merge per-shard winners */
+int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size_t n);
+/* theta[i, :] = Y[idx[i] - idx_base, :] for idx in [idx_base, idx_base + n_local), else untouched */
+int abc_gather_rows_dev(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P,
+                        const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt);
+int abc_doubled_variance_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv);
+/* un-normalised importance weights for rows [k0, k0+kn) of theta (sharded KDE); w_raw[kn] */
+int abc_weights_raw_dev(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P,
+                        size_t k0, size_t kn, const double* theta_prev, size_t Kp, const double* w_prev,
+                        const double* dv_prev, double* w_raw);
+/* w /= ||w||_2 (AbcUtil.cpp:583) */
+int abc_normalize_l2_dev(abc_ctx* ctx, double* w, size_t K);
+int abc_setup_mvn_sampler_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L);
+/* draws [i0, i0+n) of the reference's resampling stream: parent[i] for those draws; rng is the
+ * state at draw 0 and is NOT advanced. w is a device pointer (the alias table is built on the
+ * host exactly as gsl_ran_discrete_preproc, then cached in the context). */
+int abc_resample_dev(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0,
+                     size_t n, uint64_t* parent);
+/* proposals for draws [i0, i0+n): out is n x P (ld = n) */
+int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P,
+                    const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
+                    int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
+                    uint64_t seed_stream_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABCSMC_HIP_H */
