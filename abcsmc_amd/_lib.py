@@ -57,6 +57,8 @@ SIGNATURES = {
     "abc_ctx_set_stream": (_i, [_vp, _vp]),
     "abc_ctx_synchronize": (_i, [_vp]),
     "abc_version": (_i, []),
+    "abc_timing_enable": (_i, [_vp, _i]),
+    "abc_timing_read": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
     "abc_rng_set": (None, [_vp, C.c_ulong]),
     "abc_rng_get": (C.c_uint32, [_vp]),
     "abc_rng_jump": (None, [_vp, _u64]),
@@ -128,7 +130,22 @@ class Context:
             raise AbcError(rc, lib().abc_last_error(self._h).decode())
 
     def set_stream(self, stream_ptr):
-        self.check(lib().abc_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+        if getattr(self, "_stream", None) != stream_ptr:      # abc_ctx_set_stream synchronises: only on change
+            self.check(lib().abc_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+            self._stream = stream_ptr
+
+    def timing_enable(self, on=True):
+        self.check(lib().abc_timing_enable(self._h, int(on)))
+
+    def timing_read(self, reset=True):
+        """-> {stage: (device_ms, host_ms, launches)} accumulated since the last reset"""
+        n = 32
+        names = (C.c_char_p * n)()
+        ms, hms, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        k = lib().abc_timing_read(self._h, names, ms, hms, cnt, n, int(reset))
+        if k < 0:
+            self.check(k)
+        return {names[i].decode(): (ms[i], hms[i], cnt[i]) for i in range(k)}
 
     def synchronize(self):
         self.check(lib().abc_ctx_synchronize(self._h))

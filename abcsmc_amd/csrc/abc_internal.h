@@ -11,6 +11,10 @@
 
 #define ABC_WAVE 64
 
+// timed stages (abc_timing_names in api.hip must match)
+enum { ST_GRAM = 0, ST_STATS_REDUCE, ST_PLS_MODEL, ST_PROJECT, ST_SELECT, ST_SORT, ST_GATHER_DV, ST_KDE,
+       ST_WEIGHTS_MISC, ST_MVN, ST_ALIAS_HOST, ST_RESAMPLE, ST_PERTURB, ABC_NSTAGE };
+
 struct abc_ctx {
     int device;
     hipStream_t stream;
@@ -31,6 +35,26 @@ struct abc_ctx {
     bool alias_valid;
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
+    // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
+    bool timing;
+    int nev;
+    struct { hipEvent_t a, b; int stage; } ev[256];
+    double stage_ms[ABC_NSTAGE];
+    double stage_host_ms[ABC_NSTAGE];
+    long long stage_cnt[ABC_NSTAGE];
+};
+
+// RAII marker: records an event pair around a stage when timing is on
+struct StageTimer {
+    abc_ctx* ctx; int slot;
+    StageTimer(abc_ctx* c, int stage) : ctx(c), slot(-1) {
+        if (!c->timing || c->nev >= 256) return;
+        slot = c->nev++;
+        if (!c->ev[slot].a) { (void)hipEventCreate(&c->ev[slot].a); (void)hipEventCreate(&c->ev[slot].b); }
+        c->ev[slot].stage = stage;
+        (void)hipEventRecord(c->ev[slot].a, c->stream);
+    }
+    ~StageTimer() { if (slot >= 0) (void)hipEventRecord(ctx->ev[slot].b, ctx->stream); }
 };
 
 #define ABC_FAIL(ctx, code, ...)                                   \

@@ -81,6 +81,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->alias_F) (void)hipFree(ctx->alias_F);
     if (ctx->alias_A) (void)hipFree(ctx->alias_A);
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
+    for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -98,6 +99,46 @@ extern "C" int abc_ctx_synchronize(abc_ctx* ctx) {
     if (!ctx) return ABC_ERR_INVALID;
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ABC_OK;
+}
+
+static const char* const kStageNames[ABC_NSTAGE] = {
+    "k_gram", "stats_reduce", "pls_model", "project_distance", "select", "sort_winners", "gather_dv", "k_kde",
+    "weights_misc", "mvn_setup", "alias_host", "resample", "perturb"};
+
+extern "C" int abc_timing_enable(abc_ctx* ctx, int on) {
+    if (!ctx) return ABC_ERR_INVALID;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timing = on != 0;
+    ctx->nev = 0;
+    return ABC_OK;
+}
+
+static int timing_flush(abc_ctx* ctx) {
+    if (!ctx->nev) return ABC_OK;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->nev; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[i].a, ctx->ev[i].b) == hipSuccess) {
+            ctx->stage_ms[ctx->ev[i].stage] += ms;
+            ctx->stage_cnt[ctx->ev[i].stage] += 1;
+        }
+    }
+    ctx->nev = 0;
+    return ABC_OK;
+}
+
+extern "C" int abc_timing_read(abc_ctx* ctx, const char** names, double* ms, double* host_ms, long long* count,
+                               int max_stages, int reset) {
+    if (!ctx) return ABC_ERR_INVALID;
+    ABC_TRY(timing_flush(ctx));
+    for (int i = 0; i < ABC_NSTAGE && i < max_stages; i++) {
+        if (names) names[i] = kStageNames[i];
+        if (ms) ms[i] = ctx->stage_ms[i];
+        if (host_ms) host_ms[i] = ctx->stage_host_ms[i];
+        if (count) count[i] = ctx->stage_cnt[i];
+    }
+    if (reset) for (int i = 0; i < ABC_NSTAGE; i++) { ctx->stage_ms[i] = 0; ctx->stage_host_ms[i] = 0; ctx->stage_cnt[i] = 0; }
+    return ABC_NSTAGE;
 }
 
 extern "C" void abc_rng_set(abc_rng* r, unsigned long seed) { taus2_set(r, seed); }
@@ -300,6 +341,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
     }
+    if (ctx->timing && ctx->nev > 128) ABC_TRY(timing_flush(ctx));
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
     return ABC_OK;
 }

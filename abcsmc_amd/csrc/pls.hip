@@ -323,6 +323,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
                      double* model) {
     if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M+P = %zu > 160", M + P);
     if (A < 1 || A > M) ABC_FAIL(ctx, ABC_ERR_INVALID, "pls: components A=%zu must be in [1, M=%zu]", A, M);
+    StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
     double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
     double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A) * sizeof(double));

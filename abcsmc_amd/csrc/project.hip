@@ -81,6 +81,7 @@ __global__ void k_pad_model(const double* __restrict__ model, int M, int P, int 
 int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A,
                             const double* model, int simple, double* dist) {
     if (n == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_PROJECT);
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (simple) {

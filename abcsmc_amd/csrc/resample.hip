@@ -12,6 +12,7 @@
 // The Gaussian noise uses a counter-based Philox4x32-10 stream keyed by (rng state, draw index,
 // attempt): same distribution as the reference's polar Box-Muller on taus2, not the same numbers
 // (the reference's rejection loops consume a data-dependent number of outputs per particle).
+#include <chrono>
 #include <vector>
 
 #include "abc_internal.h"
@@ -309,7 +310,15 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     uint32_t* hA = (uint32_t*)(hF + K);
     ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    alias_preproc(K, hw, hF, hA);
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        alias_preproc(K, hw, hF, hA);
+        if (ctx->timing) {
+            ctx->stage_host_ms[ST_ALIAS_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            ctx->stage_cnt[ST_ALIAS_HOST] += 1;
+        }
+    }
+    StageTimer tm(ctx, ST_RESAMPLE);
     if (ctx->alias_K < K) {
         if (ctx->alias_F) { (void)hipFree(ctx->alias_F); (void)hipFree(ctx->alias_A); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
         ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * sizeof(double)));
@@ -336,6 +345,7 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     if (P > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 32", P);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
+    StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);
 #define LAUNCH_PT(PPV)                                                                                          \
     hipLaunchKernelGGL(k_perturb<PPV>, dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, priors, \

@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void k_sort_scan(unsigned int* __restrict__ bh
 int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* idx0, unsigned long long* key1,
                    unsigned long long* idx1, size_t n) {
     if (n <= 1) return ABC_OK;
+    StageTimer tm(ctx, ST_SORT);
     const int nb = (int)((n + ST_CHUNK - 1) / ST_CHUNK);
     unsigned int* bh = (unsigned int*)abc_ws_alloc(ctx, (size_t)256 * nb * sizeof(unsigned int));
     if (!bh) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sort: workspace exhausted");
@@ -330,6 +331,8 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
     unsigned long long* idx1 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
     if (!key0 || !key1 || !idx1) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
     unsigned long long* idx0 = (unsigned long long*)idx;
+    {
+    StageTimer tm(ctx, ST_SELECT);
     if (K == n) {
         hipLaunchKernelGGL(k_init_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dist, n,
                            (unsigned long long)idx_base, key0, idx0);
@@ -354,6 +357,7 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
         hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb);
         hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb,
                            (unsigned long long)idx_base, key0, idx0);
+    }
     }
     ABC_HIP(ctx, hipGetLastError());
     ABC_TRY(sort_pairs_u64(ctx, key0, idx0, key1, idx1, K));

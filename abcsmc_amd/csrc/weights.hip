@@ -174,6 +174,7 @@ int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy
                        size_t K, uint64_t idx_base, double* theta, size_t ldt) {
     const size_t tot = K * P;
     if (!tot) return ABC_OK;
+    StageTimer tm(ctx, ST_GATHER_DV);
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Y, n_local, ldy,
                        (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt);
     ABC_HIP(ctx, hipGetLastError());
@@ -182,6 +183,7 @@ int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy
 
 int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
     if (!P) return ABC_OK;
+    StageTimer tm(ctx, ST_GATHER_DV);
     hipLaunchKernelGGL(k_doubled_variance, dim3((unsigned)P), dim3(256), 0, ctx->stream, theta, K, dv);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -205,6 +207,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* part = (double*)abc_ws_alloc(ctx, slices * kn * sizeof(double));
     if (!wc || !a || !b || !part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    StageTimer tm(ctx, ST_WEIGHTS_MISC);
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn * PP + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
                        (int)P, PP, wc, a);
@@ -213,12 +216,15 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #define LAUNCH_KDE(PPV)                                                                                        \
     hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
                        Kp, w_prev, wc, theta, K, k0, theta_prev, part)
-    switch (PP) {
-        case 2: LAUNCH_KDE(2); break;
-        case 4: LAUNCH_KDE(4); break;
-        case 8: LAUNCH_KDE(8); break;
-        case 16: LAUNCH_KDE(16); break;
-        default: LAUNCH_KDE(32); break;
+    {
+        StageTimer tk(ctx, ST_KDE);
+        switch (PP) {
+            case 2: LAUNCH_KDE(2); break;
+            case 4: LAUNCH_KDE(4); break;
+            case 8: LAUNCH_KDE(8); break;
+            case 16: LAUNCH_KDE(16); break;
+            default: LAUNCH_KDE(32); break;
+        }
     }
 #undef LAUNCH_KDE
     hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
@@ -240,6 +246,7 @@ int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K) {
     if (nparts > 256) nparts = 256;
     double* part = (double*)abc_ws_alloc(ctx, nparts * sizeof(double));
     if (!part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "normalize: workspace exhausted");
+    StageTimer tm(ctx, ST_WEIGHTS_MISC);
     hipLaunchKernelGGL(k_sumsq_partial, dim3(nparts), dim3(256), 0, ctx->stream, w, K, part);
     hipLaunchKernelGGL(k_div_norm, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, part, nparts);
     ABC_HIP(ctx, hipGetLastError());

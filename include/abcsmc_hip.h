@@ -64,6 +64,13 @@ const char* abc_last_error(const abc_ctx* ctx);
 int  abc_ctx_set_stream(abc_ctx* ctx, void* hip_stream);
 int  abc_ctx_synchronize(abc_ctx* ctx);
 int  abc_version(void);
+/* Optional per-stage timing: HIP events recorded on the context's stream around each stage
+ * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
+ * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]
+ * accumulated host-side time (alias-table build), count[i] the number of launches; reset != 0 clears. */
+int  abc_timing_enable(abc_ctx* ctx, int on);
+int  abc_timing_read(abc_ctx* ctx, const char** names, double* ms, double* host_ms, long long* count,
+                     int max_stages, int reset);
 
 /* ---- RNG (gsl_rng_set / gsl_rng_get on taus2) ------------------------------------------- */
 void     abc_rng_set(abc_rng* r, unsigned long seed);

@@ -1,0 +1,388 @@
+"""GPU parity tests proper: every stage of the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Bar: bit-exact for selection indices, resampled parents and
+seeds; <= 1e-6 relative for floating point (tolerances written per assertion; most are far tighter)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # BASELINE.json north_star: "float within 1e-6 rel"
+
+
+def _wl(M, P, N, seed=12345):
+    from abcsmc_amd import synthetic
+    wl = synthetic.Workload(M, P, seed)
+    X, Y = wl.rows(0, N)
+    return wl, X, Y, wl.observed()
+
+
+def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
+    """two orderings agree except where the oracle's distances are within tol (relative)"""
+    bad = np.nonzero(idx_a != idx_b)[0]
+    for k in bad:
+        da, db = dist_full[int(idx_a[k])], dist_full[int(idx_b[k])]
+        if abs(da - db) > tol * max(abs(da), abs(db), 1e-300):
+            return False
+    return True
+
+
+# ---------------------------------------------------------------------------------------------------
+# ranking (AbcUtil.cpp:408-458)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,M,P,A,f", [
+    (1000, 7, 5, 0, 0.5),        # ragged small
+    (5000, 32, 16, 8, 0.5),      # BASELINE config shape
+    (1001, 12, 3, 3, 0.37),      # odd leading dimension -> scalar-load path, odd split
+    (300, 2, 2, 0, 0.5),         # dice-sized (config 1)
+    (4097, 20, 1, 4, 0.9),       # single response (P == 1 branch of the PLS loop)
+    (777, 40, 24, 10, 1.0),      # f = 1: empty validation set
+])
+def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
+    from abcsmc_amd import abcutil
+    wl, X, Y, obs = _wl(M, P, N)
+    g = abcutil.particle_ranking_PLS(X, Y, obs, f, max_comp=A, details=True, ctx=gpu_ctx)
+    o = oracle.particle_ranking_pls(X, Y, obs, f, A)
+    assert g["ncomp"] == o["ncomp"]
+    assert np.allclose(g["mean"], o["mean"], rtol=1e-12)
+    assert np.allclose(g["sd"], o["sd"], rtol=1e-11)
+    nc = o["ncomp"]
+    # loadings: 1e-6 relative to the column norm (same sign convention on both sides)
+    for k in range(nc):
+        assert np.linalg.norm(g["R"][:, k] - o["R"][:, k]) <= RTOL * np.linalg.norm(o["R"][:, k]), k
+    # staged bit-exactness: oracle projection fed the GPU's model == GPU distances, and so the order
+    with np.errstate(invalid="ignore", divide="ignore"):
+        zobs = np.where(g["sd"] == 0, 0.0, (obs - g["mean"]) / g["sd"])
+    so = np.array([_fma_dot(zobs, g["R"][:, k]) for k in range(nc)])
+    d_staged = oracle.project_distance(X, g["mean"], g["sd"], g["R"], nc, so)
+    order_staged = oracle.ordered(d_staged)
+    assert np.array_equal(g["idx"], order_staged), "selection indices not bit-exact given the same model"
+    assert np.array_equal(g["dist"], d_staged[order_staged.astype(int)]), "distances not bit-exact"
+    # end-to-end against the independent oracle model: equal up to near-ties, distances to 1e-6
+    assert np.allclose(g["dist"], o["dist"][g["idx"].astype(int)], rtol=RTOL)
+    assert _near_tie_ok(g["idx"], o["idx"], o["dist"])
+
+
+def _fma_dot(a, b):
+    """m-ascending fma chain in float64 (matches orc_* and the kernels) using exact arithmetic"""
+    from fractions import Fraction
+    s = 0.0
+    for x, y in zip(a, b):
+        s = float(Fraction(float(x)) * Fraction(float(y)) + Fraction(s))
+    return s
+
+
+@pytest.mark.parametrize("N,M", [(1000, 7), (4099, 32), (50, 3)])
+def test_particle_ranking_simple(gpu_ctx, oracle, N, M):
+    from abcsmc_amd import abcutil
+    wl, X, Y, obs = _wl(M, 4, N)
+    g = abcutil.particle_ranking_simple(X, Y, obs, details=True, ctx=gpu_ctx)
+    oi, od = oracle.particle_ranking_simple(X, obs)
+    assert np.allclose(g["dist"], od[g["idx"].astype(int)], rtol=1e-11)
+    assert _near_tie_ok(g["idx"], oi, od)
+    assert sorted(g["idx"].tolist()) == list(range(N))
+
+
+def test_ranking_top_k_is_prefix_of_full_order(gpu_ctx):
+    from abcsmc_amd import abcutil
+    wl, X, Y, obs = _wl(16, 8, 6000)
+    full = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, ctx=gpu_ctx)
+    for K in (1, 7, 600, 5999):
+        top = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=K, ctx=gpu_ctx)
+        assert np.array_equal(top, full[:K])
+
+
+def test_ranking_zero_variance_metric(gpu_ctx, oracle):
+    from abcsmc_amd import abcutil
+    wl, X, Y, obs = _wl(6, 3, 500)
+    X[:, 2] = 3.25                     # constant column: declared z = 0 (reference divides by 0)
+    g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, details=True, ctx=gpu_ctx)
+    o = oracle.particle_ranking_pls(X, Y, obs, 0.5, 0)
+    assert g["sd"][2] == 0.0 and g["ncomp"] == o["ncomp"]
+    assert np.allclose(g["dist"], o["dist"][g["idx"].astype(int)], rtol=RTOL)
+
+
+def test_ranking_rejects_bad_arguments(gpu_ctx):
+    from abcsmc_amd import abcutil, _lib
+    wl, X, Y, obs = _wl(6, 3, 100)
+    with pytest.raises(ValueError):
+        abcutil.particle_ranking_PLS(X, Y, obs, 0.0, ctx=gpu_ctx)          # assert at AbcUtil.cpp:428
+    with pytest.raises(_lib.AbcError):
+        abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=101, ctx=gpu_ctx)
+    with pytest.raises(_lib.AbcError):
+        abcutil.particle_ranking_PLS(X, Y, obs, 0.5, max_comp=7, ctx=gpu_ctx)   # more components than metrics
+
+
+# ---------------------------------------------------------------------------------------------------
+# selection / sort (ranker.h order semantics)
+# ---------------------------------------------------------------------------------------------------
+def _select(gpu_ctx, d, K, base=0):
+    import torch
+    from abcsmc_amd._lib import lib
+    dd = torch.from_numpy(d).cuda()
+    idx = torch.empty(K, dtype=torch.int64, device="cuda")
+    out = torch.empty(K, dtype=torch.float64, device="cuda")
+    gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    gpu_ctx.check(lib().abc_select_smallest_dev(gpu_ctx.handle, dd.data_ptr(), d.size, K, base, idx.data_ptr(),
+                                                out.data_ptr()))
+    torch.cuda.synchronize()
+    return idx.cpu().numpy().astype(np.uint64), out.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,K", [(1, 1), (5, 5), (5, 2), (2048, 100), (2049, 2049), (100000, 10000),
+                                 (100000, 99999), (65537, 1)])
+def test_select_smallest_random(gpu_ctx, oracle, n, K):
+    rng = np.random.default_rng(n * 31 + K)
+    d = np.abs(rng.normal(size=n)) * 10.0 ** rng.integers(-3, 4, size=n)
+    idx, out = _select(gpu_ctx, d, K)
+    ref = oracle.ordered(d)[:K]
+    assert np.array_equal(idx, ref)
+    assert np.array_equal(out, d[ref.astype(int)])
+
+
+def test_select_smallest_ties_and_offsets(gpu_ctx, oracle):
+    rng = np.random.default_rng(4)
+    d = rng.integers(0, 50, size=30000).astype(np.float64)      # massive ties: index tie-break decides
+    for K in (1, 599, 600, 601, 15000, 30000):
+        idx, out = _select(gpu_ctx, d, K, base=7_000_000_000)
+        ref = oracle.ordered(d)[:K]
+        assert np.array_equal(idx, ref + np.uint64(7_000_000_000))
+    d[:] = 2.5                                                    # all equal
+    idx, _ = _select(gpu_ctx, d, 1234)
+    assert np.array_equal(idx, np.arange(1234, dtype=np.uint64))
+    d = np.array([0.0, 1e-310, 5e-324, 1e308, np.inf, 3.0])       # zero, subnormals, huge, inf
+    idx, _ = _select(gpu_ctx, d, 6)
+    assert np.array_equal(idx, oracle.ordered(d))
+
+
+def test_sort_pairs(gpu_ctx, oracle):
+    import torch
+    from abcsmc_amd._lib import lib
+    rng = np.random.default_rng(8)
+    key = np.round(np.abs(rng.normal(size=50000)), 2)
+    val = rng.permutation(50000).astype(np.int64)
+    k, v = torch.from_numpy(key.copy()).cuda(), torch.from_numpy(val.copy()).cuda()
+    gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    gpu_ctx.check(lib().abc_sort_pairs_dev(gpu_ctx.handle, k.data_ptr(), v.data_ptr(), key.size))
+    torch.cuda.synchronize()
+    o = np.argsort(key, kind="stable")
+    assert np.array_equal(k.cpu().numpy(), key[o]) and np.array_equal(v.cpu().numpy(), val[o])
+
+
+# ---------------------------------------------------------------------------------------------------
+# doubled variance, weights, MVN setup
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,P", [(2, 1), (1000, 16), (4097, 5)])
+def test_doubled_variance(gpu_ctx, oracle, K, P):
+    from abcsmc_amd import abcutil
+    th = np.random.default_rng(K).normal(size=(K, P)) * 50 + 1000
+    assert np.allclose(abcutil.calculate_doubled_variance(th, ctx=gpu_ctx), oracle.doubled_variance(th), rtol=1e-10)
+
+
+def _weights_case(P, K, Kp, seed):
+    from abcsmc_amd import synthetic
+    wl = synthetic.Workload(8, P, seed)
+    _, th = wl.rows(0, K)
+    th = np.asfortranarray(wl.mu_y + 0.4 * (th - wl.mu_y))
+    tp, wp, dv = wl.previous_set(Kp)
+    wp = np.random.default_rng(seed).random(Kp)
+    wp /= np.linalg.norm(wp)
+    return wl, th, tp, wp, dv
+
+
+@pytest.mark.parametrize("P,K,Kp", [(16, 700, 900), (2, 100, 64), (5, 1, 130), (32, 300, 257), (3, 2500, 70)])
+def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp):
+    from abcsmc_amd import abcutil, _lib
+    wl, th, tp, wp, dv = _weights_case(P, K, Kp, 77 + P)
+    spec = wl.prior_spec()
+    w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    ref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv)
+    assert np.all(ref > 0)
+    assert np.allclose(w, ref, rtol=RTOL, atol=0)
+    assert np.max(np.abs(w - ref) / ref) < 1e-9
+    assert np.linalg.norm(w) == pytest.approx(1.0, rel=1e-12)          # L2, not L1 (AbcUtil.cpp:583)
+
+
+def test_weight_uniform_first_set(gpu_ctx):
+    from abcsmc_amd import abcutil
+    w = abcutil.weight_predictive_prior(None, np.zeros((123, 4)), ctx=gpu_ctx)
+    assert np.array_equal(w, np.full(123, 1.0 / 123))
+
+
+def test_weight_converged_parameter_and_prior_support(gpu_ctx, oracle):
+    from abcsmc_amd import abcutil, _lib
+    wl, th, tp, wp, dv = _weights_case(4, 200, 150, 5)
+    th[:, 1] = 7.0
+    tp[:, 1] = 7.0
+    tp[::7, 1] = 8.0                     # some previous particles differ: factor 0 (declared deviation)
+    dv[1] = 0.0
+    spec = wl.prior_spec()
+    spec[1] = (_lib.PRIOR_UNIF_INT, 1, 10)
+    spec[2] = (_lib.PRIOR_UNIF_REAL, float(np.median(th[:, 2])), float(th[:, 2].max() + 1))   # half outside support
+    w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    ref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv, 0)
+    assert (ref == 0).sum() > 10 and np.array_equal(w == 0, ref == 0)
+    assert np.allclose(w, ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("K,P", [(400, 6), (50, 16), (5000, 32), (33, 1)])
+def test_setup_mvn_sampler(gpu_ctx, oracle, K, P):
+    from abcsmc_amd import abcutil
+    rng = np.random.default_rng(K + P)
+    th = rng.normal(size=(K, P)) @ rng.normal(size=(P, P)) + rng.normal(size=P) * 100
+    L = abcutil.setup_mvn_sampler(th, ctx=gpu_ctx)
+    rc, Lo, cov = oracle.mvn_setup(th)
+    assert rc == 0
+    assert np.allclose(L, Lo, rtol=1e-7, atol=1e-9 * np.abs(Lo).max())
+    assert np.allclose(np.tril(L) @ np.tril(L).T, cov, rtol=1e-8, atol=1e-9 * np.abs(cov).max())
+
+
+def test_setup_mvn_sampler_not_spd(gpu_ctx):
+    from abcsmc_amd import abcutil, _lib
+    th = np.ones((20, 3))
+    th[:, 0] = np.arange(20)
+    with pytest.raises(_lib.AbcError) as e:
+        abcutil.setup_mvn_sampler(th, ctx=gpu_ctx)        # reference: GSL_EDOM abort; here an error code
+    assert e.value.code == -3
+
+
+# ---------------------------------------------------------------------------------------------------
+# resampling (bit-exact) and perturbation (distributional)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,n,seed", [(1, 10, 1), (37, 5000, 2), (1000, 100000, 3), (4096, 64, 4), (513, 65, 5)])
+def test_resample_bit_exact(gpu_ctx, oracle, K, n, seed):
+    from abcsmc_amd import abcutil
+    w = np.random.default_rng(seed).random(K) ** 3
+    if K > 5:
+        w[3] = 0.0
+    r, o = abcutil.rng(seed), oracle.rng(seed)
+    for _ in range(seed):                 # start somewhere inside the stream
+        abcutil.rng_get(r)
+        oracle.rng_get(o)
+    idx = abcutil.gsl_rng_nonuniform_int(r, n, w, ctx=gpu_ctx)
+    ref = oracle.resample(o, w, n)
+    assert np.array_equal(idx, ref)
+    assert (r.s1, r.s2, r.s3) == (o.s1, o.s2, o.s3)      # both consumed exactly n outputs
+    assert np.array_equal(np.bincount(idx.astype(int), minlength=K), np.bincount(ref.astype(int), minlength=K))
+
+
+def test_sample_mvn_predictive_priors(gpu_ctx, oracle):
+    from abcsmc_amd import abcutil, _lib
+    rng = np.random.default_rng(21)
+    K, P, n = 300, 4, 200000
+    th = np.column_stack([rng.normal(5, 1, K), np.round(rng.uniform(3, 18, K)), rng.uniform(0.2, 0.8, K),
+                          rng.normal(0, 2, K)])
+    spec = [(_lib.PRIOR_GAUSS, 5.0, 3.0), (_lib.PRIOR_UNIF_INT, 1, 20), (_lib.PRIOR_UNIF_REAL, 0.0, 1.0),
+            (_lib.PRIOR_GAUSS, 0.0, 10.0)]
+    w = rng.random(K)
+    L = abcutil.setup_mvn_sampler(th, ctx=gpu_ctx)
+    r, o = abcutil.rng(99), oracle.rng(99)
+    out, parent, seeds = abcutil.sample_mvn_predictive_priors(r, n, w, th, _lib.make_priors(spec), L, seeds=True,
+                                                              ctx=gpu_ctx)
+    oout, opar, _ = oracle.sample_mvn_predictive_priors(o, n, w, th, oracle.make_priors(spec), L)
+    assert np.array_equal(parent, opar)                                  # bit-exact parents
+    # seeds: the taus2 outputs right after the n resampling draws
+    o2 = oracle.rng(99)
+    for _ in range(n):
+        oracle.rng_get(o2)
+    assert np.array_equal(seeds[:1000], np.array([oracle.rng_get(o2) for _ in range(1000)], dtype=np.uint64))
+    # support / recast
+    assert np.all(out[:, 1] == np.round(out[:, 1])) and out[:, 1].min() >= 1 and out[:, 1].max() <= 20
+    assert out[:, 2].min() >= 0.0 and out[:, 2].max() <= 1.0
+    # distribution: same moments as the reference stream's proposals (both truncated the same way)
+    for p in range(P):
+        sd = oout[:, p].std()
+        assert abs(out[:, p].mean() - oout[:, p].mean()) < 5 * sd / np.sqrt(n) * 2
+        assert abs(out[:, p].std() / sd - 1) < 0.02
+    dg, do = out - th[parent.astype(int)], oout - th[opar.astype(int)]
+    assert np.allclose(np.corrcoef(dg[:, [0, 3]].T), np.corrcoef(do[:, [0, 3]].T), atol=0.02)
+
+
+def test_sample_predictive_priors_independent(gpu_ctx, oracle):
+    from abcsmc_amd import abcutil, _lib
+    rng = np.random.default_rng(22)
+    K, P, n = 200, 3, 100000
+    th = np.column_stack([rng.normal(5, 1, K), np.round(rng.uniform(3, 18, K)), rng.uniform(0.45, 0.55, K)])
+    spec = [(_lib.PRIOR_GAUSS, 5.0, 3.0), (_lib.PRIOR_UNIF_INT, 1, 20), (_lib.PRIOR_UNIF_REAL, 0.4, 0.6)]
+    w = np.full(K, 1.0 / K)
+    dv = abcutil.calculate_doubled_variance(th, ctx=gpu_ctx)
+    r, o = abcutil.rng(5), oracle.rng(5)
+    out, parent = abcutil.sample_predictive_priors(r, n, w, th, _lib.make_priors(spec), dv, ctx=gpu_ctx)
+    oout, opar, _ = oracle.sample_predictive_priors(o, n, w, th, oracle.make_priors(spec), dv)
+    assert np.array_equal(parent, opar)
+    assert out[:, 2].min() >= 0.4 and out[:, 2].max() <= 0.6
+    assert np.all(out[:, 1] == np.round(out[:, 1]))
+    for p in range(P):
+        assert abs(out[:, p].mean() - oout[:, p].mean()) < 0.02 * oout[:, p].std() + 1e-3
+        assert abs(out[:, p].std() / oout[:, p].std() - 1) < 0.02
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole generation, device resident (AbcSmc.cpp:634-664, 1041-1066, 490-518)
+# ---------------------------------------------------------------------------------------------------
+def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890):
+    import torch
+    from abcsmc_amd import abcutil, device, _lib
+    wl, X, Y, obs = _wl(M, P, N)
+    spec = wl.prior_spec()
+    prev = wl.previous_set(Kp) if Kp else (None, None, None)
+    dev = "cuda:0"
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, multivariate=multivariate, device=dev)
+    r = abcutil.rng(seed)
+    gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev),
+            device.priors_to_device(_lib.make_priors(spec), dev), r,
+            *(device.colmajor(a, dev) if a is not None else None for a in prev))
+    torch.cuda.synchronize()
+    return wl, X, Y, obs, spec, prev, gen, r
+
+
+@pytest.mark.parametrize("multivariate,Kp", [(True, 400), (False, 400), (True, 0)])
+def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp):
+    from abcsmc_amd import device
+    N, M, P, K, Nn, A = 3000, 32, 16, 400, 3000, 8
+    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, multivariate)
+    o = oracle.rng(67890)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A,
+                            multivariate=multivariate)
+    assert gen.ncomp.value == ref["ncomp"]
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
+    assert np.allclose(gen.dv.cpu().numpy(), ref["dv"], rtol=1e-9)
+    assert np.array_equal(device.to_numpy(gen.theta), Y[ref["idx"].astype(int)])
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    if multivariate:
+        L = device.to_numpy(gen.L)
+        assert np.allclose(np.tril(L), np.tril(ref["L"]), rtol=1e-7, atol=1e-12)
+    nxt = device.to_numpy(gen.next)
+    assert nxt.shape == (Nn, P) and np.isfinite(nxt).all()
+    for p in range(P):                                       # proposals respect the prior support
+        k, a, b = spec[p]
+        if k == 2:
+            assert nxt[:, p].min() >= a and nxt[:, p].max() <= b
+
+
+def test_generation_full_size_properties(gpu_ctx):
+    """BASELINE config 2 size (N = 1e5, M = 32, P = 16, A = 8): size-independent invariants."""
+    from abcsmc_amd import device
+    N, M, P, K, Kp, Nn, A = 100000, 32, 16, 10000, 10000, 100000, 8
+    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    idx = gen.idx.cpu().numpy()
+    dist = gen.dist.cpu().numpy()
+    assert len(set(idx.tolist())) == K and idx.min() >= 0 and idx.max() < N
+    assert np.all(np.diff(dist) >= 0)                                         # sortedness
+    w = gen.w.cpu().numpy()
+    assert np.all(w >= 0) and np.linalg.norm(w) == pytest.approx(1.0, rel=1e-10)
+    parent = gen.parent.cpu().numpy()
+    counts = np.bincount(parent, minlength=K)
+    assert counts.sum() == Nn and parent.min() >= 0 and parent.max() < K      # checksum of resample counts
+    # resample counts follow the weights (chi-square-ish sanity on the heaviest particles)
+    top = np.argsort(-w)[:50]
+    exp = Nn * w[top] / w.sum()
+    assert np.all(np.abs(counts[top] - exp) < 6 * np.sqrt(exp) + 6)
+    # idempotence: the same inputs and rng state give the same bits
+    wl2, X2, Y2, obs2, spec2, prev2, gen2, r2 = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    assert np.array_equal(gen2.idx.cpu().numpy(), idx) and np.array_equal(gen2.w.cpu().numpy(), w)
+    assert np.array_equal(gen2.parent.cpu().numpy(), parent)
+    assert np.array_equal(device.to_numpy(gen2.next), device.to_numpy(gen.next))
+    assert (r.s1, r.s2, r.s3) == (r2.s1, r2.s2, r2.s3)
