@@ -37,6 +37,7 @@ struct abc_ctx {
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
     bool timing;
+    bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
     int nev;
     struct { hipEvent_t a, b; int stage; } ev[256];
     double stage_ms[ABC_NSTAGE];
@@ -48,7 +49,7 @@ struct abc_ctx {
 struct StageTimer {
     abc_ctx* ctx; int slot;
     StageTimer(abc_ctx* c, int stage) : ctx(c), slot(-1) {
-        if (!c->timing || c->nev >= 256) return;
+        if (!c->timing || c->nev >= 256 || stage < 0) return;
         slot = c->nev++;
         if (!c->ev[slot].a) { (void)hipEventCreate(&c->ev[slot].a); (void)hipEventCreate(&c->ev[slot].b); }
         c->ev[slot].stage = stage;

@@ -210,12 +210,12 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
         attr_set = true;
     }
     {
-        StageTimer tm(ctx, ST_GRAM);
+        StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL(k_gram<C>, dim3((unsigned)G, 2), dim3(256), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
                            (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
     }
     ABC_HIP(ctx, hipGetLastError());
-    StageTimer tm2(ctx, ST_STATS_REDUCE);
+    StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
     hipLaunchKernelGGL(k_stats_reduce<C>, dim3((D::PSZ + 255) / 256, 2), dim3(256), 0, ctx->stream, partial, (int)G,
                        stats, ntr, nte);
     ABC_HIP(ctx, hipGetLastError());

@@ -56,7 +56,10 @@ int launch_mvn_setup(abc_ctx* ctx, const double* theta, size_t K, size_t P, doub
     if (!stats || !status) ABC_FAIL(ctx, ABC_ERR_NOMEM, "mvn: workspace exhausted");
     StageTimer tm(ctx, ST_MVN);
     ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
-    ABC_TRY(launch_stats_accumulate(ctx, theta, theta, K, K, K, P, 0, 0, K, stats));
+    ctx->in_mvn = true;
+    const int rc_acc = launch_stats_accumulate(ctx, theta, theta, K, K, K, P, 0, 0, K, stats);
+    ctx->in_mvn = false;
+    ABC_TRY(rc_acc);
     hipLaunchKernelGGL(k_cov_chol, dim3(1), dim3(64), P * P * sizeof(double), ctx->stream, stats, (int)P, L, status);
     ABC_HIP(ctx, hipGetLastError());
     if (status_host) {

@@ -1,0 +1,221 @@
+"""Row-sharded SMC generation: one process per GPU, particles split in contiguous row blocks,
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) for the
+few real exchange steps of the path:
+
+  1. broadcast of the pilot shift                       (16*ceil((M+P)/16) doubles)
+  2. ONE packed all-reduce of the sufficient statistics  (counts, column sums, Gram blocks; <= 0.35 MB)
+     -> the PLS deflation loop is then replicated on every rank (deterministic, identical model)
+  3. all-gather of each rank's local winners (dist, global row), replicated merge-sort -> global top K
+  4. all-reduce of the K x P gathered posterior (each row is owned by exactly one rank)
+  5. all-gather of the raw importance weights (KDE rows are sharded K/G per rank)
+  6. resampling/perturbation need no exchange: every rank regenerates its own slice of the
+     reference's sequential taus2 stream by jump-ahead and perturbs locally.
+
+The numerical stages are behind a small backend interface: `HipBackend` (the product: C ABI ->
+HIP kernels on device tensors).  tests/ provide a numpy backend so the orchestration, offsets and
+collectives are covered at world_size 2 on CPU with gloo.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import Rng, lib
+
+
+class HipBackend:
+    """Stage calls on device-resident torch tensors through include/abcsmc_hip.h (*_dev entry points)."""
+
+    def __init__(self, device, ctx=None):
+        self.device = torch.device(device)
+        self.ctx = ctx if ctx is not None else _lib.default_context(self.device.index or 0)
+
+    def _s(self):
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        return self.ctx.handle
+
+    def empty(self, shape, dtype=torch.float64):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype=torch.float64):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def stats_len(self, M, P):
+        return lib().abc_stats_len(M, P)
+
+    def model_len(self, M, P, A):
+        return lib().abc_model_len(M, P, A)
+
+    def stats_shift(self, X, Y, stats):
+        M, n = X.shape
+        P = Y.shape[0]
+        self.ctx.check(lib().abc_stats_shift_dev(self._s(), X.data_ptr(), Y.data_ptr(), n, n, n, M, P, stats.data_ptr()))
+
+    def stats_accumulate(self, X, Y, row0, n_train_global, stats):
+        M, n = X.shape
+        P = Y.shape[0]
+        self.ctx.check(lib().abc_stats_accumulate_dev(self._s(), X.data_ptr(), Y.data_ptr(), n, n, n, M, P, row0,
+                                                      n_train_global, stats.data_ptr()))
+
+    def pls_model(self, stats, obs, M, P, A, rule, model):
+        self.ctx.check(lib().abc_pls_model_dev(self._s(), stats.data_ptr(), obs.data_ptr(), M, P, A, rule, model.data_ptr()))
+
+    def model_ncomp(self, model, M, P, A):
+        nc = C.c_int32(0)
+        self.ctx.check(lib().abc_model_ncomp(self._s(), model.data_ptr(), M, P, A, C.addressof(nc)))
+        return nc.value
+
+    def project_distance(self, X, P, A, model, out):
+        M, n = X.shape
+        self.ctx.check(lib().abc_project_distance_dev(self._s(), X.data_ptr(), n, n, M, P, A, model.data_ptr(), 0,
+                                                      out.data_ptr()))
+
+    def select_smallest(self, d, K, idx_base, idx_out, dist_out):
+        self.ctx.check(lib().abc_select_smallest_dev(self._s(), d.data_ptr(), d.numel(), K, idx_base, idx_out.data_ptr(),
+                                                     dist_out.data_ptr()))
+
+    def sort_pairs(self, key, idx):
+        self.ctx.check(lib().abc_sort_pairs_dev(self._s(), key.data_ptr(), idx.data_ptr(), key.numel()))
+
+    def gather_rows(self, Y, idx, idx_base, theta):
+        P, n = Y.shape
+        K = idx.numel()
+        self.ctx.check(lib().abc_gather_rows_dev(self._s(), Y.data_ptr(), n, n, P, idx.data_ptr(), K, idx_base,
+                                                 theta.data_ptr(), K))
+
+    def doubled_variance(self, theta, dv):
+        P, K = theta.shape
+        self.ctx.check(lib().abc_doubled_variance_dev(self._s(), theta.data_ptr(), K, P, dv.data_ptr()))
+
+    def weights_raw(self, priors, theta, k0, kn, theta_prev, w_prev, dv_prev, out):
+        P, K = theta.shape
+        Kp = theta_prev.shape[1]
+        self.ctx.check(lib().abc_weights_raw_dev(self._s(), priors.data_ptr(), theta.data_ptr(), K, P, k0, kn,
+                                                 theta_prev.data_ptr(), Kp, w_prev.data_ptr(), dv_prev.data_ptr(),
+                                                 out.data_ptr()))
+
+    def normalize_l2(self, w):
+        self.ctx.check(lib().abc_normalize_l2_dev(self._s(), w.data_ptr(), w.numel()))
+
+    def setup_mvn(self, theta, L):
+        P, K = theta.shape
+        self.ctx.check(lib().abc_setup_mvn_sampler_dev(self._s(), theta.data_ptr(), K, P, L.data_ptr()))
+
+    def resample(self, rng, w, i0, n, parent):
+        self.ctx.check(lib().abc_resample_dev(self._s(), C.addressof(rng), w.data_ptr(), w.numel(), i0, n, parent.data_ptr()))
+
+    def perturb(self, rng, theta, priors, parent, i0, n, multivariate, L_or_dv, out, seeds, seed_offset):
+        P, K = theta.shape
+        self.ctx.check(lib().abc_perturb_dev(self._s(), C.addressof(rng), theta.data_ptr(), K, P, priors.data_ptr(),
+                                             parent.data_ptr(), i0, n, int(multivariate), L_or_dv.data_ptr(),
+                                             out.data_ptr(), seeds.data_ptr() if seeds is not None else None, seed_offset))
+
+
+class ShardedGeneration:
+    """One generation turn-over over `world` ranks; every rank holds n_local rows of the set."""
+
+    def __init__(self, backend, n_local, M, P, K, Kp, nnext_local, train_frac=0.5, max_comp=0,
+                 rule=_lib.RULE_MIN_PRESS, multivariate=True, group=None):
+        self.be = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_local, self.M, self.P, self.K, self.Kp = n_local, M, P, K, Kp
+        self.N = n_local * self.world
+        self.nnext_local = nnext_local
+        self.Nnext = nnext_local * self.world
+        self.A = max_comp if max_comp > 0 else min(M, P)
+        self.train_frac, self.rule, self.multivariate = train_frac, rule, multivariate
+        be = backend
+        self.k_local = min(K, n_local)
+        self.stats = be.zeros(be.stats_len(M, P))
+        self.model = be.empty(be.model_len(M, P, self.A))
+        self.dist_local = be.empty(n_local)
+        self.cand_idx = be.empty(self.k_local * self.world, torch.int64)
+        self.cand_dist = be.empty(self.k_local * self.world)
+        self.loc_idx = be.empty(self.k_local, torch.int64)
+        self.loc_dist = be.empty(self.k_local)
+        self.idx = be.empty(K, torch.int64)
+        self.dist = be.empty(K)
+        self.theta = be.zeros((P, K))
+        self.dv = be.empty(P)
+        self.w = be.empty(K)
+        self.L = be.empty((P, P))
+        # KDE row ranges per rank (contiguous, as even as possible)
+        base, rem = divmod(K, self.world)
+        self.k_counts = [base + (1 if r < rem else 0) for r in range(self.world)]
+        self.k_offsets = [sum(self.k_counts[:r]) for r in range(self.world)]
+        self.kmax = max(self.k_counts)
+        self.w_slices = be.zeros(self.kmax * self.world)
+        self.w_mine = be.zeros(self.kmax)
+        self.next = be.empty((P, max(nnext_local, 1)))
+        self.parent = be.empty(max(nnext_local, 1), torch.int64)
+        self.seeds = be.empty(max(nnext_local, 1), torch.int64)
+        self.ncomp = 0
+        self.shift_len = 16 * ((M + P + 15) // 16)
+
+    def _ar(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def run(self, X, Y, obs, priors, rng, theta_prev=None, w_prev=None, dv_prev=None):
+        be, W, r = self.be, self.world, self.rank
+        M, P, K, A = self.M, self.P, self.K, self.A
+        row0 = r * self.n_local
+        ntrain = int(math.floor(self.N * self.train_frac + 0.5))   # AbcUtil.cpp:438 (std::round, half away from zero)
+        # 1-2: sufficient statistics
+        be.stats_shift(X, Y, self.stats)
+        shift = self.stats[2:2 + self.shift_len]
+        if W > 1:
+            dist.broadcast(shift, src=0, group=self.group)
+        be.stats_accumulate(X, Y, row0, ntrain, self.stats)
+        if W > 1:
+            if r != 0:
+                shift.zero_()
+            self._ar(self.stats)
+        # replicated model fit
+        be.pls_model(self.stats, obs, M, P, A, self.rule, self.model)
+        # 3: distances, local winners, global merge
+        be.project_distance(X, P, A, self.model, self.dist_local)
+        be.select_smallest(self.dist_local, self.k_local, row0, self.loc_idx, self.loc_dist)
+        if W > 1:
+            dist.all_gather_into_tensor(self.cand_idx, self.loc_idx, group=self.group)
+            dist.all_gather_into_tensor(self.cand_dist, self.loc_dist, group=self.group)
+            be.sort_pairs(self.cand_dist, self.cand_idx)
+            self.idx.copy_(self.cand_idx[:K])
+            self.dist.copy_(self.cand_dist[:K])
+        else:
+            self.idx.copy_(self.loc_idx[:K])
+            self.dist.copy_(self.loc_dist[:K])
+        # 4: posterior rows
+        self.theta.zero_()
+        be.gather_rows(Y, self.idx, row0, self.theta)
+        self._ar(self.theta)
+        be.doubled_variance(self.theta, self.dv)
+        # 5: weights
+        if theta_prev is None or self.Kp == 0:
+            self.w.fill_(1.0 / K)                                                      # AbcUtil.cpp:543-544
+        else:
+            k0, kn = self.k_offsets[r], self.k_counts[r]
+            be.weights_raw(priors, self.theta, k0, kn, theta_prev, w_prev, dv_prev, self.w_mine)
+            if W > 1:
+                dist.all_gather_into_tensor(self.w_slices, self.w_mine, group=self.group)
+                for q in range(W):
+                    self.w[self.k_offsets[q]:self.k_offsets[q] + self.k_counts[q]].copy_(
+                        self.w_slices[q * self.kmax:q * self.kmax + self.k_counts[q]])
+            else:
+                self.w.copy_(self.w_mine[:K])
+            be.normalize_l2(self.w)                                                    # AbcUtil.cpp:583
+        # 6: proposals for this rank's slice of the next set
+        if self.nnext_local:
+            i0 = r * self.nnext_local
+            if self.multivariate:
+                be.setup_mvn(self.theta, self.L)
+            be.resample(rng, self.w, i0, self.nnext_local, self.parent)
+            be.perturb(rng, self.theta, priors, self.parent, i0, self.nnext_local, self.multivariate,
+                       self.L if self.multivariate else self.dv, self.next, self.seeds, self.Nnext)
+            lib().abc_rng_jump(C.addressof(rng), 2 * self.Nnext)   # Nnext resampling draws + Nnext seeds (host-only call)
+        self.ncomp = be.model_ncomp(self.model, M, P, A)
+        return self

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- particles/s of one whole SMC generation turn-over (PLS rank + weights + resample/perturb)
+on synthetic particle x (parameter | metric) matrices, with the inputs resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one generation: abc_generation_dev on one GPU, or the row-sharded driver
+(abcsmc_amd/sharded.py, RCCL collectives) on N GPUs with the per-GPU particle count fixed (weak).
+Prints ONE JSON line on rank 0 carrying the driver contract plus `roofline` (the dominant HBM kernel,
+k_gram: algorithmic bytes / HIP-event time measured live in this run) and `cpu_baseline` (the
+single-threaded CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs (per-GPU sizes; K = K' = 0.1 N, N_next = N, train fraction 0.5, MULTIVARIATE)
+CONFIGS = {
+    2: dict(name="configs[1]: synthetic 100k particles x 16 params x 32 metrics, PLS 8 components, full generation",
+            N=100_000, M=32, P=16, A=8),
+    3: dict(name="configs[2]: synthetic 1M particles x 16 params x 32 metrics, PLS 8 components, full generation",
+            N=1_000_000, M=32, P=16, A=8),
+    4: dict(name="configs[3]: synthetic 10M/8 particles per GPU x 32 params x 64 metrics, PLS 8 components",
+            N=1_250_000, M=64, P=32, A=8),
+}
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from abcsmc_amd import _lib, abcutil, device, sharded, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    cfg = CONFIGS[args.config]
+    n_loc, M, P, A = cfg["N"], cfg["M"], cfg["P"], cfg["A"]
+    N = n_loc * world
+    K = N // 10
+    Kp = K
+    nn_loc = n_loc
+
+    # ---- synthetic inputs, generated on the host once, then resident in HBM ---------------------------
+    wl = synthetic.Workload(M, P, seed=12345)
+    X, Y = wl.rows(rank * n_loc, (rank + 1) * n_loc)
+    obs = wl.observed()
+    spec = wl.prior_spec()
+    th_prev, w_prev, dv_prev = wl.previous_set(Kp)
+    dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev)
+    dpri = device.priors_to_device(_lib.make_priors(spec), dev)
+    dtp, dwp, ddvp = device.colmajor(th_prev, dev), device.colmajor(w_prev, dev), device.colmajor(dv_prev, dev)
+    rng = abcutil.rng(67890)
+
+    ctx = _lib.default_context(local_rank)
+    if world == 1:
+        gen = device.Generation(N, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
+
+        def step():
+            gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
+    else:
+        be = sharded.HipBackend(dev, ctx)
+        gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+
+        def step():
+            gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_enable(True)          # HIP events on the stream the kernels are launched on
+    ctx.timing_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stages = ctx.timing_read(reset=True)
+    ctx.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N / (elapsed / args.steps)
+
+    # ---- roofline of the dominant HBM kernel (k_gram): algorithmic bytes = 8 (M+P) per particle ------
+    g_ms, _, g_cnt = stages["k_gram"]
+    gram_launches_per_step = g_cnt / max(args.steps, 1)
+    # one launch per step: reads X and Y (local rows) exactly once -> 8 (M+P) bytes per particle
+    alg_bytes = 8.0 * n_loc * (M + P)
+    gram_ms_per_step = g_ms / max(args.steps, 1)
+    achieved = alg_bytes / (gram_ms_per_step * 1e-3) / 1e9 if gram_ms_per_step > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_k_gram.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            if pj.get("config") == args.config and pj.get("n_gpus", 1) == 1:
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "k_gram", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": round(gram_ms_per_step, 5),
+                "launches_per_step": gram_launches_per_step}
+    stage_ms = {k: round((v[0] + v[1]) / max(args.steps, 1), 5) for k, v in stages.items()}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, wl, X, Y, obs, spec, th_prev, w_prev, dv_prev, K, A, args.cpu_budget_s)
+
+    if rank == 0:
+        out = {
+            "metric": "particles/sec per SMC generation (PLS+weight+resample), 1/2/4/8 GPU",
+            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "particles_per_gpu": n_loc, "particles_total": N, "metrics": M,
+                       "params": P, "pls_components": A, "pred_prior_size": K, "prev_pred_prior_size": Kp,
+                       "next_set_size": nn_loc * world, "noise": "MULTIVARIATE", "train_fraction": 0.5,
+                       "ncomp_chosen": int(gen.ncomp.value if world == 1 else gen.ncomp),
+                       "parallelism": "row-sharded x%d" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "stage_ms_per_step": stage_ms,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, wl, X, Y, obs, spec, th_prev, w_prev, dv_prev, K, A, budget_s):
+    """Single-threaded CPU oracle (oracle/, a restatement of the reference path: the reference itself
+    cannot be built here) timed on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import pyoracle as O
+    N = X.shape[0]
+    pri = O.make_priors(spec)
+    # the O(K K' P) weight stage dominates on the CPU: cap K, K' so the whole sample takes ~budget
+    # (~1.3e8 pdf evaluations/s/core measured on this class of host)
+    cap = int(min(K, max(1000, (budget_s * 0.6 * 1.0e8 / max(1, X.shape[1] // 2)) ** 0.5)))
+    Ks, Kps = min(K, cap), min(th_prev.shape[0], cap)
+    t0 = time.perf_counter()
+    r = O.particle_ranking_pls(X, Y, obs, 0.5, A)
+    t_rank = time.perf_counter() - t0
+    idx = r["idx"][:Ks].astype(np.int64)
+    theta = np.asfortranarray(Y[idx])
+    t0 = time.perf_counter()
+    O.doubled_variance(theta)
+    w = O.weights_importance(pri, theta, th_prev[:Kps], w_prev[:Kps], dv_prev)
+    t_w = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rc, L, _ = O.mvn_setup(theta)
+    rng = O.rng(67890)
+    O.sample_mvn_predictive_priors(rng, N, w, theta, pri, L)
+    t_s = time.perf_counter() - t0
+    # scale the weight stage to the full K x K' pair count (labelled extrapolation when capped)
+    scale = (K / Ks) * (th_prev.shape[0] / Kps)
+    total = t_rank + t_w * scale + t_s
+    return {"value": N / total, "unit": "particles/s", "cores": 1, "kind": "port",
+            "sample": ("full ranking (N=%d) and resample+perturb (N_next=%d) timed in full; weight stage timed at "
+                       "K=%d x K'=%d of %d x %d pairs and scaled by %.1fx (extrapolated)" if scale > 1.0 else
+                       "whole workload: ranking N=%d, resample+perturb N_next=%d, weights K=%d x K'=%d (of %d x %d, x%.1f)")
+                      % (N, N, Ks, Kps, K, th_prev.shape[0], scale),
+            "seconds": {"rank_pls": round(t_rank, 3), "weights_sampled": round(t_w, 3),
+                        "weights_scaled": round(t_w * scale, 3), "resample_perturb": round(t_s, 3)},
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

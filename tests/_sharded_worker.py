@@ -1,0 +1,87 @@
+"""Worker for the world_size-2 tests of the row-sharded generation (launched by torch.distributed.run).
+argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, both ranks on one GPU),
+out_json."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    backend, out_path = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from abcsmc_amd import _lib, sharded, synthetic
+    from oracle import pyoracle as O
+    n_loc, M, P, A, K, Kp, nn_loc = 1500, 12, 5, 4, 500, 300, 1000
+    N = n_loc * world
+    wl = synthetic.Workload(M, P, 777)
+    X, Y = wl.rows(rank * n_loc, (rank + 1) * n_loc)
+    obs, spec = wl.observed(), wl.prior_spec()
+    thp, wp, dvp = wl.previous_set(Kp)
+    if backend == "numpy":
+        from _numpy_backend import NumpyBackend
+        be, dev = NumpyBackend(), "cpu"
+        priors = O.make_priors(spec)
+    else:
+        be, dev = sharded.HipBackend("cuda:0"), "cuda:0"
+        from abcsmc_amd import device
+        priors = device.priors_to_device(_lib.make_priors(spec), dev)
+
+    def cm(a):
+        a = np.asarray(a, dtype=np.float64)
+        return torch.from_numpy(np.ascontiguousarray(a.T if a.ndim == 2 else a)).to(dev)
+
+    gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+    rng = _lib.Rng()
+    _lib.lib().abc_rng_set(__import__("ctypes").byref(rng), 4242)
+    gen.run(cm(X), cm(Y), cm(obs), priors, rng, cm(thp), cm(wp), cm(dvp))
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    # gather the sharded outputs on rank 0
+    parents = [torch.zeros(nn_loc, dtype=torch.int64) for _ in range(world)]
+    seeds = [torch.zeros(nn_loc, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(parents, gen.parent[:nn_loc].cpu())
+    dist.all_gather(seeds, gen.seeds[:nn_loc].cpu())
+    res = {"ok": True}
+    if rank == 0:
+        Xa, Ya = wl.rows(0, N)
+        o = O.rng(4242)
+        ref = O.generation(Xa, Ya, obs, O.make_priors(spec), K, nn_loc * world, o, thp, wp, dvp, train_frac=0.5,
+                           max_comp=A, multivariate=True)
+        # declared deviation: seeds are the taus2 outputs right after the Nnext resampling draws
+        # (the reference draws them after its data-dependent noise consumption)
+        o2 = O.rng(4242)
+        for _ in range(nn_loc * world):
+            O.rng_get(o2)
+        exp_seeds = np.array([O.rng_get(o2) for _ in range(nn_loc * world)], dtype=np.uint64)
+        idx = gen.idx.cpu().numpy().astype(np.uint64)
+        w = gen.w.cpu().numpy()
+        par = torch.cat(parents).numpy().astype(np.uint64)
+        sd = torch.cat(seeds).numpy().astype(np.uint64)
+        res = {
+            "ncomp": [int(gen.ncomp), int(ref["ncomp"])],
+            "idx_equal": bool(np.array_equal(idx, ref["idx"])),
+            "w_maxrel": float(np.max(np.abs(w - ref["w"]) / ref["w"])),
+            "dv_maxrel": float(np.max(np.abs(gen.dv.cpu().numpy() - ref["dv"]) / ref["dv"])),
+            "theta_equal": bool(np.array_equal(gen.theta.cpu().numpy().T, Ya[ref["idx"].astype(int)])),
+            "parent_equal": bool(np.array_equal(par, ref["parent"])),
+            "seeds_equal": bool(np.array_equal(sd, exp_seeds)),
+            "rng_equal": [rng.s1, rng.s2, rng.s3] == [o2.s1, o2.s2, o2.s3],
+            "next_finite": bool(torch.isfinite(gen.next).all().item()),
+        }
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
