@@ -55,6 +55,7 @@ SIGNATURES = {
     "abc_ctx_destroy": (None, [_vp]),
     "abc_last_error": (C.c_char_p, [_vp]),
     "abc_ctx_set_stream": (_i, [_vp, _vp]),
+    "abc_ctx_use_own_stream": (_i, [_vp]),
     "abc_ctx_synchronize": (_i, [_vp]),
     "abc_version": (_i, []),
     "abc_timing_enable": (_i, [_vp, _i]),
@@ -130,7 +131,7 @@ class Context:
             raise AbcError(rc, lib().abc_last_error(self._h).decode())
 
     def set_stream(self, stream_ptr):
-        if getattr(self, "_stream", None) != stream_ptr:      # abc_ctx_set_stream synchronises: only on change
+        if getattr(self, "_stream", -1) != stream_ptr:      # abc_ctx_set_stream synchronises: only on change
             self.check(lib().abc_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
             self._stream = stream_ptr
 

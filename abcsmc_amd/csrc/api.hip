@@ -91,7 +91,14 @@ extern "C" const char* abc_last_error(const abc_ctx* ctx) { return ctx ? ctx->er
 extern "C" int abc_ctx_set_stream(abc_ctx* ctx, void* hip_stream) {
     if (!ctx) return ABC_ERR_INVALID;
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return ABC_OK;
+}
+
+extern "C" int abc_ctx_use_own_stream(abc_ctx* ctx) {
+    if (!ctx) return ABC_ERR_INVALID;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return ABC_OK;
 }
 

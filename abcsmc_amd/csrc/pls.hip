@@ -5,7 +5,7 @@
 // AbcUtil.cpp:432-449, 453).
 //
 // Latency-bound, tiny matrices: k_zstats is one 256-thread work-group; k_pls_fit is ONE wavefront
-// (no inter-wave barriers): XY and the Jacobi work matrices live in LDS, XX stays in L2.
+// (no inter-wave barriers): XY and the P x P eigen work matrices live in LDS, XX stays in L2.
 #include "abc_internal.h"
 
 namespace {
@@ -13,6 +13,11 @@ namespace {
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
 }
 
@@ -88,17 +93,15 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     const ModelLayout ML = model_layout(M, P, A);
     const ZLayout Z = z_layout(M, P);
     const int lane = threadIdx.x;
-    const int np = (P + 1) & ~1;  // Jacobi works on an even order (pad with a zero row/column)
+    const int np = P;
     double* XY = lds;                   // M*P
     double* S = XY + (size_t)M * P;     // np*np
-    double* V = S + np * np;            // np*np
-    double* qv = V + np * np;           // np
+    double* V = S + np * np;            // 2*np*np: ping-pong powers of S
+    double* qv = V + 2 * np * np;       // np
     double* wv = qv + np;               // M
     double* rv = wv + M;                // M
     double* pv = rv + M;                // M
     double* xr = pv + M;                // M
-    double* rot = xr + M;               // 2*(np/2): c, s
-    int* rpq = (int*)(rot + np);        // 2*(np/2): p, q
 
     const double* XXtr = zwork + Z.off_XX[0];
     double* Rm = model + ML.off_R;
@@ -113,80 +116,83 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
         if (P == 1) {
             for (int m = lane; m < M; m += 64) wv[m] = XY[m];
         } else {
-            // S = XY' XY (symmetric), V = I
-            for (int e = lane; e < np * np; e += 64) {
-                const int a = e % np, b = e / np;
+            // S = XY' XY (symmetric PSD, P x P)
+            const int n = P;
+            for (int e = lane; e < n * n; e += 64) {
+                const int a = e % n, b = e / n;
                 double s = 0.0;
-                if (a < P && b < P)
-                    for (int m = 0; m < M; m++) s = fma(XY[m + M * a], XY[m + M * b], s);
+                for (int m = 0; m < M; m++) s = fma(XY[m + M * a], XY[m + M * b], s);
                 S[e] = s;
-                V[e] = (a == b) ? 1.0 : 0.0;
             }
             __syncthreads();
-            // parallel-order (round-robin) Jacobi sweeps
-            for (int sweep = 0; sweep < 40; sweep++) {
-                double off = 0.0, dg = 0.0;
-                for (int e = lane; e < np * np; e += 64) {
-                    const double x = S[e];
-                    if (e % np == e / np) dg += x * x; else off += x * x;
+            // Dominant eigenvector by repeated squaring of B = S / trace(S): B^(2^k) -> q q' (trace 1).
+            // The error is squared every step once the gap opens, so "changed by < 1e-9" + one more
+            // squaring is converged to rounding.  (The oracle uses a full Jacobi eigen-solve; both
+            // deliver the dominant eigenvector of the same symmetric matrix.)
+            double tr = 0.0;
+            for (int i = lane; i < n; i += 64) tr += S[i + n * i];
+            tr = wave_sum(tr);
+            double* Bc = V;            // current power
+            double* Bn = V + n * n;    // next power
+            if (tr > 0.0) {
+                for (int e = lane; e < n * n; e += 64) Bc[e] = S[e] / tr;
+                __syncthreads();
+                bool last = false;
+                for (int it = 0; it < 60; it++) {
+                    double dtr = 0.0;
+                    for (int e = lane; e < n * n; e += 64) {
+                        const int a = e % n, b = e / n;
+                        double c = 0.0;
+                        for (int k = 0; k < n; k++) c = fma(Bc[k + n * a], Bc[k + n * b], c);
+                        Bn[e] = c;
+                        if (a == b) dtr += c;
+                    }
+                    dtr = wave_sum(dtr);
+                    double diff = 0.0;
+                    for (int e = lane; e < n * n; e += 64) {
+                        const double c = Bn[e] / dtr;
+                        Bn[e] = c;
+                        diff = fmax(diff, fabs(c - Bc[e]));
+                    }
+                    diff = wave_max(diff);
+                    __syncthreads();
+                    double* tsw = Bc; Bc = Bn; Bn = tsw;
+                    if (last) break;
+                    if (diff < 1e-9) last = true;
                 }
-                off = wave_sum(off);
-                dg = wave_sum(dg);
-                if (off <= 1e-32 * dg || off == 0.0) break;
-                for (int round = 0; round < np - 1; round++) {
-                    const int half = np / 2;
-                    if (lane < half) {
-                        int a, b;
-                        if (lane == 0) { a = np - 1; b = round; }
-                        else { a = (round + lane) % (np - 1); b = (round - lane + (np - 1)) % (np - 1); }
-                        const int p = a < b ? a : b, q = a < b ? b : a;
-                        const double apq = S[p + np * q];
-                        double c = 1.0, s = 0.0;
-                        if (apq != 0.0) {
-                            const double tau = (S[q + np * q] - S[p + np * p]) / (2.0 * apq);
-                            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                            c = 1.0 / sqrt(1.0 + tt * tt);
-                            s = tt * c;
-                        }
-                        rot[2 * lane] = c; rot[2 * lane + 1] = s;
-                        rpq[2 * lane] = p; rpq[2 * lane + 1] = q;
-                    }
-                    __syncthreads();
-                    for (int e = lane; e < half * np; e += 64) {   // columns of S and V
-                        const int k = e / np, i = e % np;
-                        const int p = rpq[2 * k], q = rpq[2 * k + 1];
-                        const double c = rot[2 * k], s = rot[2 * k + 1];
-                        const double sp = S[i + np * p], sq = S[i + np * q];
-                        S[i + np * p] = c * sp - s * sq;
-                        S[i + np * q] = s * sp + c * sq;
-                        const double vp = V[i + np * p], vq = V[i + np * q];
-                        V[i + np * p] = c * vp - s * vq;
-                        V[i + np * q] = s * vp + c * vq;
-                    }
-                    __syncthreads();
-                    for (int e = lane; e < half * np; e += 64) {   // rows of S
-                        const int k = e / np, i = e % np;
-                        const int p = rpq[2 * k], q = rpq[2 * k + 1];
-                        const double c = rot[2 * k], s = rot[2 * k + 1];
-                        const double sp = S[p + np * i], sq = S[q + np * i];
-                        S[p + np * i] = c * sp - s * sq;
-                        S[q + np * i] = s * sp + c * sq;
-                    }
-                    __syncthreads();
-                }
+            } else {
+                for (int e = lane; e < n * n; e += 64) Bc[e] = (e == 0) ? 1.0 : 0.0;
+                __syncthreads();
             }
-            // dominant eigenvector: largest diagonal entry; unit norm; largest |component| positive
             int best = 0;
-            for (int i = 1; i < P; i++) if (S[i + np * i] > S[best + np * best]) best = i;
+            for (int i = 1; i < n; i++) if (Bc[i + n * i] > Bc[best + n * best]) best = i;
+            for (int i = lane; i < n; i += 64) qv[i] = Bc[i + n * best];
+            __syncthreads();
+            // two power steps with S itself wash out the rounding of the squarings
+            for (int rep = 0; rep < 2 && tr > 0.0; rep++) {
+                double v = 0.0;
+                if (lane < n) for (int k = 0; k < n; k++) v = fma(S[lane + n * k], qv[k], v);
+                __syncthreads();
+                if (lane < n) qv[lane] = v;
+                __syncthreads();
+                double nn = 0.0;
+                for (int k = 0; k < n; k++) nn = fma(qv[k], qv[k], nn);
+                nn = sqrt(nn);
+                __syncthreads();
+                if (lane < n) qv[lane] = v / nn;
+                __syncthreads();
+            }
+            // unit norm; largest |component| positive (same convention as the oracle)
             double nrm = 0.0; int big = 0;
-            for (int i = 0; i < P; i++) {
-                const double x = V[i + np * best];
-                nrm += x * x;
-                if (fabs(x) > fabs(V[big + np * best])) big = i;
+            for (int i = 0; i < n; i++) {
+                const double x = qv[i];
+                nrm = fma(x, x, nrm);
+                if (fabs(x) > fabs(qv[big])) big = i;
             }
             nrm = sqrt(nrm);
-            const double sgn = (V[big + np * best] < 0.0) ? -1.0 : 1.0;
-            for (int i = lane; i < P; i += 64) qv[i] = sgn * V[i + np * best] / nrm;
+            const double sgn = (qv[big] < 0.0) ? -1.0 : 1.0;
+            __syncthreads();
+            if (lane < n) qv[lane] = sgn * qv[lane] / nrm;
             __syncthreads();
             for (int m = lane; m < M; m += 64) {
                 double s = 0.0;
@@ -330,8 +336,8 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
     hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
-    const size_t np = (P + 1) & ~(size_t)1;
-    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + np + np /* ints */ + 8;
+    const size_t np = P;
+    const size_t lds_d = M * P + 3 * np * np + np + 4 * M + 8;
     const size_t lds_bytes = lds_d * sizeof(double);
     if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -60,8 +60,11 @@ enum { ABC_RULE_MIN_PRESS = 0, ABC_RULE_WILCOXON = 1 };
 int  abc_ctx_create(int device, abc_ctx** out);
 void abc_ctx_destroy(abc_ctx* ctx);
 const char* abc_last_error(const abc_ctx* ctx);
-/* Run on an existing hipStream_t (e.g. torch's current stream); NULL -> context's own. */
+/* Run on an existing hipStream_t (e.g. torch's current stream; NULL = HIP's default stream).
+ * A new context runs on a private non-blocking stream until this is called;
+ * abc_ctx_use_own_stream switches back to it. Both synchronise the stream being left. */
 int  abc_ctx_set_stream(abc_ctx* ctx, void* hip_stream);
+int  abc_ctx_use_own_stream(abc_ctx* ctx);
 int  abc_ctx_synchronize(abc_ctx* ctx);
 int  abc_version(void);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
