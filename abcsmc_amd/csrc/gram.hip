@@ -25,22 +25,25 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int C>
+// C = 16-column blocks of [X|Y]; the trailing CY blocks hold only parameter (Y) / padding columns.
+// Y'Y is needed on its diagonal only (PRESS, z-scores), so the CY(CY+1)/2 pure-Y blocks are skipped and
+// the diagonal comes from a per-column sum of squares taken while the tile is staged.
+template <int C, int CY>
 struct GramDims {
     static constexpr int C16 = 16 * C;
-    static constexpr int NBLK = C * (C + 1) / 2;
-    static constexpr int NI = 4 * C;               // 16-byte vectors per thread per tile
-    static constexpr int PSZ = NBLK * 256 + C16;   // doubles per work-group partial record
+    static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
+    static constexpr int NI = 4 * C;                   // 16-byte vectors per thread per tile
+    static constexpr int PSZ = NBLK * 256 + 2 * C16;   // doubles per work-group partial record
     static constexpr int LDS_D = (C16 * TRP > PSZ) ? C16 * TRP : PSZ;
 };
 
 // grid = (G, 2): blockIdx.y = partition (0: rows [0,split) training, 1: rows [split,n) validation)
-template <int C>
+template <int C, int CY>
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, const double* __restrict__ Y,
                                               size_t ldx, size_t ldy, int M, int P, long long n,
                                               long long split, const double* __restrict__ shift,
                                               double* __restrict__ partial, int vec_ok) {
-    using D = GramDims<C>;
+    using D = GramDims<C, CY>;
     extern __shared__ double lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: column pointers live in SGPRs
@@ -52,16 +55,17 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
     d4 acc[D::NBLK];
 #pragma unroll
     for (int b = 0; b < D::NBLK; b++) acc[b] = (d4){0.0, 0.0, 0.0, 0.0};
-    double colsum[D::NI];
-    double sh[D::NI];
+    double colsum[D::NI], colsq[D::NI];
+    double sh[D::NI], keep[D::NI];
     const double* cptr[D::NI];
 #pragma unroll
     for (int i = 0; i < D::NI; i++) {
-        const int c = wave + 4 * i;  // one column per wave-instruction
+        const int c = wave + 4 * i;  // one column per wave-instruction; padding columns re-read column 0, zeroed
         colsum[i] = 0.0;
-        if (c < M) { cptr[i] = X + (size_t)c * ldx; sh[i] = shift[c]; }
-        else if (c < M + P) { cptr[i] = Y + (size_t)(c - M) * ldy; sh[i] = shift[c]; }
-        else { cptr[i] = nullptr; sh[i] = 0.0; }
+        colsq[i] = 0.0;
+        keep[i] = (c < M + P) ? 1.0 : 0.0;
+        cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+        sh[i] = (c < M + P) ? shift[c] : 0.0;
     }
 
     d2 v[D::NI];
@@ -71,17 +75,15 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
         const bool full = (row0 >= r_begin) && (row0 + TR <= r_end);
         if (full && vec_ok) {
 #pragma unroll
-            for (int i = 0; i < D::NI; i++)
-                v[i] = cptr[i] ? *reinterpret_cast<const d2*>(cptr[i] + r) : (d2){0.0, 0.0};
-        } else {
+            for (int i = 0; i < D::NI; i++) v[i] = *reinterpret_cast<const d2*>(cptr[i] + r);
+        } else {   // edge tile / unaligned columns: clamp the address, mask the value (no divergence)
+            const long long ra = r < r_begin ? r_begin : (r >= r_end ? r_end - 1 : r);
+            const long long rb = r + 1 < r_begin ? r_begin : (r + 1 >= r_end ? r_end - 1 : r + 1);
+            const bool oka = (r >= r_begin) && (r < r_end), okb = (r + 1 >= r_begin) && (r + 1 < r_end);
 #pragma unroll
             for (int i = 0; i < D::NI; i++) {
-                d2 x = (d2){sh[i], sh[i]};  // masked rows contribute (x - shift) = 0
-                if (cptr[i]) {
-                    if (r >= r_begin && r < r_end) x.x = cptr[i][r];
-                    if (r + 1 >= r_begin && r + 1 < r_end) x.y = cptr[i][r + 1];
-                }
-                v[i] = x;
+                const double xa = cptr[i][ra], xb = cptr[i][rb];
+                v[i] = (d2){oka ? xa : sh[i], okb ? xb : sh[i]};   // masked rows contribute (x - shift) = 0
             }
         }
     };
@@ -93,8 +95,10 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
 #pragma unroll
         for (int i = 0; i < D::NI; i++) {
             const int c = wave + 4 * i;
-            d2 z = (d2){v[i].x - sh[i], v[i].y - sh[i]};
+            d2 z = (d2){(v[i].x - sh[i]) * keep[i], (v[i].y - sh[i]) * keep[i]};
             colsum[i] += z.x + z.y;
+            colsq[i] = fma(z.x, z.x, colsq[i]);
+            colsq[i] = fma(z.y, z.y, colsq[i]);
             *reinterpret_cast<d2*>(&lds[c * TRP + 2 * lane]) = z;
         }
         __syncthreads();
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
             for (int b = 0; b < C; b++) a[b] = lds[(16 * b + cl) * TRP + rb];
             int blk = 0;
 #pragma unroll
-            for (int bi = 0; bi < C; bi++)
+            for (int bi = 0; bi < C - CY; bi++)
 #pragma unroll
                 for (int bj = bi; bj < C; bj++) {
                     acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[blk], 0, 0, 0);
@@ -117,47 +121,81 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
         }
     }
 
-    // cross-wave reduction in a fixed order (deterministic), through LDS
-    __syncthreads();
-    for (int w = 0; w < 4; w++) {
-        if (wave == w) {
-#pragma unroll
-            for (int b = 0; b < D::NBLK; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int e = b * 256 + r * 64 + lane;
-                    lds[e] = (w == 0 ? 0.0 : lds[e]) + acc[b][r];
-                }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < D::NI; i++) {
-        const double s = wave_sum(colsum[i]);
-        if (lane == 0) lds[D::NBLK * 256 + wave + 4 * i] = s;
-    }
-    __syncthreads();
+    // ---- epilogue: fixed-order (deterministic) reductions through the now idle tile buffer ------------
     double* out = partial + ((size_t)part * G + g) * D::PSZ;
-    for (int e = t; e < D::PSZ; e += 256) out[e] = lds[e];
+    __syncthreads();
+    if constexpr (4 * D::NBLK * 256 <= D::LDS_D) {
+        // every wave parks its accumulators in its own slab, then all threads add the four slabs
+#pragma unroll
+        for (int b = 0; b < D::NBLK; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) lds[wave * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
+        __syncthreads();
+        for (int e = t; e < D::NBLK * 256; e += 256)
+            out[e] = ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+    } else {
+        for (int w = 0; w < 4; w++) {
+            if (wave == w) {
+#pragma unroll
+                for (int b = 0; b < D::NBLK; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int e = b * 256 + r * 64 + lane;
+                        lds[e] = (w == 0 ? 0.0 : lds[e]) + acc[b][r];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int e = t; e < D::NBLK * 256; e += 256) out[e] = lds[e];
+    }
+    // column sums / sums of squares: lane-major park, then one thread per column adds its 64 lanes in order
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < D::NI; i++) lds[i * 256 + t] = half ? colsq[i] : colsum[i];
+        __syncthreads();
+        if (t < D::C16) {
+            const int i = t >> 2, w = t & 3;     // column t was staged by wave w as its i-th column
+            double s = 0.0;
+            for (int l = 0; l < 64; l++) s += lds[i * 256 + w * 64 + l];
+            out[D::NBLK * 256 + half * D::C16 + t] = s;
+        }
+    }
 }
 
 // Sum the per-work-group partial records in a fixed order and scatter into the stats record.
-template <int C>
+template <int C, int CY>
 __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__ partial, int G,
                                                       double* __restrict__ stats, long long n_train,
                                                       long long n_test) {
-    using D = GramDims<C>;
+    using D = GramDims<C, CY>;
     const StatsLayout L = stats_layout(D::C16, 0);
     const int part = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e == 0 && part == 0) { stats[L.off_n] = (double)n_train; stats[L.off_n + 1] = (double)n_test; }
-    if (e >= D::PSZ) return;
-    const double* p = partial + (size_t)part * G * D::PSZ + e;
+    // 16 record elements x 16 slices of the G partial records per block; slices are combined in a fixed order
+    __shared__ double red[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && part == 0) { stats[L.off_n] = (double)n_train; stats[L.off_n + 1] = (double)n_test; }
+    double ps = 0.0;
+    if (e < D::PSZ) {
+        const double* p = partial + (size_t)part * G * D::PSZ + e;
+        const int g0 = (int)((long long)G * sl / 16), g1 = (int)((long long)G * (sl + 1) / 16);
+#pragma unroll 4
+        for (int g = g0; g < g1; g++) ps += p[(size_t)g * D::PSZ];
+    }
+    red[sl][el] = ps;
+    __syncthreads();
+    if (sl != 0 || e >= D::PSZ) return;
     double s = 0.0;
-#pragma unroll 8
-    for (int g = 0; g < G; g++) s += p[(size_t)g * D::PSZ];
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += red[q][el];
     if (e >= D::NBLK * 256) {
-        stats[L.off_sum[part] + (e - D::NBLK * 256)] = s;
+        const int c = e - D::NBLK * 256;
+        if (c < D::C16) stats[L.off_sum[part] + c] = s;
+        else if (c - D::C16 >= 16 * (C - CY)) {     // diagonal of the skipped pure-Y blocks (rest stays 0)
+            const int cc = c - D::C16;
+            stats[L.off_G[part] + cc + (size_t)D::C16 * cc] = s;
+        }
         return;
     }
     int blk = e >> 8;
@@ -188,35 +226,36 @@ __global__ void k_pilot_shift(const double* __restrict__ X, const double* __rest
     if (lane == 0) shift[c] = (c < M + P && m > 0) ? s / (double)m : 0.0;
 }
 
-template <int C>
+template <int C, int CY>
 int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
              size_t P, long long split, double* stats) {
-    using D = GramDims<C>;
+    using D = GramDims<C, CY>;
     const StatsLayout L = stats_layout(M, P);
     const long long ntr = split, nte = (long long)n - split;
     const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
-    long long G = tiles / 4;
+    long long G = tiles / 2;           // >= 2 tiles per work-group amortise its prologue / epilogue
     if (G < 1) G = 1;
-    if (G > 384) G = 384;
+    if (G > 384) G = 384;              // 2 partitions x 384 = three resident work-groups per CU
     const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
+    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
     const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
         attr_set = true;
     }
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
-        hipLaunchKernelGGL(k_gram<C>, dim3((unsigned)G, 2), dim3(256), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
+        hipLaunchKernelGGL((k_gram<C, CY>), dim3((unsigned)G, 2), dim3(256), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
                            (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
-    hipLaunchKernelGGL(k_stats_reduce<C>, dim3((D::PSZ + 255) / 256, 2), dim3(256), 0, ctx->stream, partial, (int)G,
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 15) / 16, 2), dim3(256), 0, ctx->stream, partial, (int)G,
                        stats, ntr, nte);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -238,13 +277,14 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     long long split = 0;
     if (n_train_global > row0) split = (long long)((n_train_global - row0) < n ? (n_train_global - row0) : n);
     const size_t C = (M + P + 15) / 16;
+    size_t CY = C - (M + 15) / 16;      // trailing blocks without any metric column
+    if (CY > 2) CY = 2;
+#define GRAM_CASE(c, cy) if (C == c && CY == cy) return run_gram<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+    GRAM_CASE(1, 0); GRAM_CASE(2, 0); GRAM_CASE(2, 1); GRAM_CASE(3, 0); GRAM_CASE(3, 1); GRAM_CASE(3, 2);
+    GRAM_CASE(4, 0); GRAM_CASE(4, 1); GRAM_CASE(4, 2); GRAM_CASE(5, 0); GRAM_CASE(5, 1); GRAM_CASE(5, 2);
+    GRAM_CASE(6, 0); GRAM_CASE(6, 1); GRAM_CASE(6, 2);
+#undef GRAM_CASE
     switch (C) {
-        case 1: return run_gram<1>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
-        case 2: return run_gram<2>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
-        case 3: return run_gram<3>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
-        case 4: return run_gram<4>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
-        case 5: return run_gram<5>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
-        case 6: return run_gram<6>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
         default:
             ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "gram: M+P = %zu exceeds 96 columns", M + P);
     }

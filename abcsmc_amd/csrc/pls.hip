@@ -85,6 +85,89 @@ __global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats
     }
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Dominant-eigenvector helper: repeated squaring of B = S / trace(S) (S symmetric PSD, n <= 16*NB)
+// entirely in registers with v_mfma_f64_16x16x4_f64.  A 16x16 block of a SYMMETRIC matrix held in
+// the MFMA C/D layout (lane l, reg r <-> [l&15][(l>>4) + 4r], using symmetry) is bit-for-bit the
+// A-operand layout of k-step r AND (again by symmetry) the B-operand layout, so
+//   C_IJ = sum_K sum_r mfma(D_IK[r], D_JK[r])        needs no data movement between squarings.
+// The error is squared every step once the spectral gap opens: "changed by < 1e-9", then one more.
+template <int NB>
+__device__ void eig_square(const double* __restrict__ S, int n, double tr, double* __restrict__ Bout) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    d4 D[NB][NB];
+#pragma unroll
+    for (int I = 0; I < NB; I++)
+#pragma unroll
+        for (int J = 0; J < NB; J++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * I + c, j = 16 * J + q + 4 * r;
+                D[I][J][r] = (i < n && j < n) ? S[i + n * j] / tr : 0.0;
+            }
+    // Groups of 4 un-normalised squarings (trace 1 -> entries >= n^-16, no underflow), then ONE
+    // trace normalisation + convergence check per group (the cross-lane reductions dominate).
+    bool last = false;
+    for (int grp = 0; grp < 16; grp++) {
+        d4 Dn[NB][NB];
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+#pragma unroll
+            for (int J = 0; J < NB; J++) Dn[I][J] = D[I][J];
+#pragma unroll 1
+        for (int sq = 0; sq < 4; sq++) {
+            d4 T[NB][NB];
+#pragma unroll
+            for (int I = 0; I < NB; I++)
+#pragma unroll
+                for (int J = 0; J < NB; J++) {
+                    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int K = 0; K < NB; K++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)   // operands (J,K),(I,K): MFMA output row/col map gives block (I,J)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dn[J][K][r], Dn[I][K][r], acc, 0, 0, 0);
+                    T[I][J] = acc;
+                }
+#pragma unroll
+            for (int I = 0; I < NB; I++)
+#pragma unroll
+                for (int J = 0; J < NB; J++) Dn[I][J] = T[I][J];
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) t += (q + 4 * r == c) ? Dn[I][I][r] : 0.0;
+        t = wave_sum(t);
+        const double inv = 1.0 / t;
+        double diff = 0.0;
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+#pragma unroll
+            for (int J = 0; J < NB; J++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double v = Dn[I][J][r] * inv;
+                    diff = fmax(diff, fabs(v - D[I][J][r]));
+                    D[I][J][r] = v;
+                }
+        diff = wave_max(diff);
+        if (last) break;
+        if (diff < 1e-7) last = true;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; I++)
+#pragma unroll
+        for (int J = 0; J < NB; J++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * I + c, j = 16 * J + q + 4 * r;
+                if (i < n && j < n) Bout[i + n * j] = D[I][J][r];
+            }
+}
+
 // ONE wavefront.  LDS: XY (M*P), S and V (np*np each), vectors.
 __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
                                                 int M, int P, int A, double* __restrict__ model,
@@ -96,8 +179,8 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     const int np = P;
     double* XY = lds;                   // M*P
     double* S = XY + (size_t)M * P;     // np*np
-    double* V = S + np * np;            // 2*np*np: ping-pong powers of S
-    double* qv = V + 2 * np * np;       // np
+    double* V = S + np * np;            // np*np: converged power of S
+    double* qv = V + np * np;           // np
     double* wv = qv + np;               // M
     double* rv = wv + M;                // M
     double* pv = rv + M;                // M
@@ -125,45 +208,21 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
                 S[e] = s;
             }
             __syncthreads();
-            // Dominant eigenvector by repeated squaring of B = S / trace(S): B^(2^k) -> q q' (trace 1).
-            // The error is squared every step once the gap opens, so "changed by < 1e-9" + one more
-            // squaring is converged to rounding.  (The oracle uses a full Jacobi eigen-solve; both
-            // deliver the dominant eigenvector of the same symmetric matrix.)
+            // dominant eigenvector of S: repeated squaring in registers (eig_square), then two
+            // power steps with S itself.  (The oracle uses a full Jacobi eigen-solve; both deliver
+            // the dominant eigenvector of the same symmetric matrix.)
             double tr = 0.0;
             for (int i = lane; i < n; i += 64) tr += S[i + n * i];
             tr = wave_sum(tr);
-            double* Bc = V;            // current power
-            double* Bn = V + n * n;    // next power
+            double* Bc = V;
             if (tr > 0.0) {
-                for (int e = lane; e < n * n; e += 64) Bc[e] = S[e] / tr;
-                __syncthreads();
-                bool last = false;
-                for (int it = 0; it < 60; it++) {
-                    double dtr = 0.0;
-                    for (int e = lane; e < n * n; e += 64) {
-                        const int a = e % n, b = e / n;
-                        double c = 0.0;
-                        for (int k = 0; k < n; k++) c = fma(Bc[k + n * a], Bc[k + n * b], c);
-                        Bn[e] = c;
-                        if (a == b) dtr += c;
-                    }
-                    dtr = wave_sum(dtr);
-                    double diff = 0.0;
-                    for (int e = lane; e < n * n; e += 64) {
-                        const double c = Bn[e] / dtr;
-                        Bn[e] = c;
-                        diff = fmax(diff, fabs(c - Bc[e]));
-                    }
-                    diff = wave_max(diff);
-                    __syncthreads();
-                    double* tsw = Bc; Bc = Bn; Bn = tsw;
-                    if (last) break;
-                    if (diff < 1e-9) last = true;
-                }
+                if (n <= 16) eig_square<1>(S, n, tr, Bc);
+                else if (n <= 32) eig_square<2>(S, n, tr, Bc);
+                else eig_square<4>(S, n, tr, Bc);
             } else {
                 for (int e = lane; e < n * n; e += 64) Bc[e] = (e == 0) ? 1.0 : 0.0;
-                __syncthreads();
             }
+            __syncthreads();
             int best = 0;
             for (int i = 1; i < n; i++) if (Bc[i + n * i] > Bc[best + n * best]) best = i;
             for (int i = lane; i < n; i += 64) qv[i] = Bc[i + n * best];
@@ -337,7 +396,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
-    const size_t lds_d = M * P + 3 * np * np + np + 4 * M + 8;
+    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 8;
     const size_t lds_bytes = lds_d * sizeof(double);
     if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

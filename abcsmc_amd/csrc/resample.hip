@@ -171,7 +171,7 @@ __device__ __forceinline__ double d_prior_mean(const abc_prior& pr) {           
     return (pr.kind == ABC_PRIOR_GAUSS) ? pr.a : (pr.b + pr.a) / 2.0;
 }
 
-constexpr unsigned MVN_MAX_TRIES = 1u << 20;
+constexpr unsigned MVN_MAX_TRIES = 1u << 14;   // the reference retries for ever (AbcUtil.cpp:132); bounded here
 
 // one new particle per lane
 template <int PP>

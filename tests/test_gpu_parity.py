@@ -386,3 +386,19 @@ def test_generation_full_size_properties(gpu_ctx):
     assert np.array_equal(gen2.parent.cpu().numpy(), parent)
     assert np.array_equal(device.to_numpy(gen2.next), device.to_numpy(gen.next))
     assert (r.s1, r.s2, r.s3) == (r2.s1, r2.s2, r2.s3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# C++ facade with the reference's signatures (abcsmc_amd/cxx/AbcUtilHip.hpp)
+# ---------------------------------------------------------------------------------------------------
+def test_cxx_facade_demo(gpu_ctx, tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(root, "abcsmc_amd", "cxx", "facade_demo.cpp"),
+                           "-L" + os.path.join(root, "abcsmc_amd"), "-labcsmc_hip",
+                           "-Wl,-rpath," + os.path.join(root, "abcsmc_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "facade ok" in out.stdout
