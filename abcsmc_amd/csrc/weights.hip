@@ -7,8 +7,12 @@
 // The weight kernel is the compute-bound stage of a generation, O(K * K' * P): per pair the P
 // per-parameter Gaussian factors of the reference are fused into ONE exponential,
 //   prod_p pdf(t_ip - t'_jp; sqrt(dv_p)) = C * exp(-1/2 sum_p ((t_ip - t'_jp)/sigma_p)^2),
-// with both parameter sets pre-scaled by 1/sigma_p.  One new particle per lane; previous-set rows
-// are wave-uniform and stream through the scalar cache.  fp64 VALU throughout.
+// with both parameter sets centred on one previous particle and pre-scaled by 1/sigma_p, and the squared
+// distance expanded as |a|^2 + |b|^2 - 2 a.b so a pair costs P FMAs + one exp:
+//   w'_j * exp(-1/2 |a_i - b_j|^2) = exp(a_i.b_j - 1/2|a_i|^2 - (1/2|b_j|^2 - ln w'_j)).
+// The exp is an inline range-reduced degree-10 polynomial (|rel err| < 3e-13, far inside the 1e-6
+// budget; ~17 instructions instead of ~40 for the library exp).  One new particle per lane;
+// previous-set rows are wave-uniform and stream through the scalar cache.  fp64 VALU throughout.
 #include "abc_internal.h"
 
 namespace {
@@ -76,20 +80,50 @@ __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __res
     wc->C = C; wc->nzero = nz; wc->logC = 0.0;
 }
 
-// scaled copies: out[row*PP + p] = in[row + ld*p] * scale[p]   (row-major, zero padded to PP)
+// scaled copies: out[row*PP + p] = (in[row + ld*p] - centre[p]) * scale[p]   (row-major, zero padded to PP);
+// centre = first previous particle (differences are unchanged, magnitudes stay O(few sigma)).
+// If hb != NULL also hb[row] = 1/2 |out[row,:]|^2 - ln(w[row])  (the per-column part of the exponent).
 __global__ __launch_bounds__(256) void k_wscale(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP,
-                                                const WConst* __restrict__ wc, double* __restrict__ out) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= rows * (size_t)PP) return;
-    const size_t r = e / PP; const int p = (int)(e % PP);
-    out[e] = (p < P) ? in[r + ld * p] * wc->scale[p] : 0.0;
+                                                const WConst* __restrict__ wc, const double* __restrict__ centre,
+                                                size_t ldc, const double* __restrict__ w, double* __restrict__ out,
+                                                double* __restrict__ hb) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    double nn = 0.0;
+    for (int p = 0; p < PP; p++) {
+        const double v = (p < P) ? (in[r + ld * p] - centre[ldc * p]) * wc->scale[p] : 0.0;
+        out[r * PP + p] = v;
+        nn = fma(v, v, nn);
+    }
+    if (hb) hb[r] = 0.5 * nn - log(w[r]);
 }
 
-// partial denominators: part[slice*kn + i] = sum_{j in slice} w'_j * exp(-1/2 |a_i - b_j|^2) [* zero-dv mask]
+// exp(x) for x <= 0 (clamped at -800 -> 0): Cody-Waite reduction x = n ln2 + r, degree-10 Taylor polynomial
+// on |r| <= ln2/2 (remainder < 2.2e-13), scaling by 2^n with v_ldexp_f64 (handles subnormal results).
+__device__ __forceinline__ double exp_neg(double x) {
+    x = fmax(x, -800.0);
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 2.7557319223985890653e-07;            // 1/10!
+    p = fma(p, r, 2.7557319223985892511e-06);        // 1/9!
+    p = fma(p, r, 2.4801587301587301566e-05);        // 1/8!
+    p = fma(p, r, 1.9841269841269841253e-04);        // 1/7!
+    p = fma(p, r, 1.3888888888888889419e-03);        // 1/6!
+    p = fma(p, r, 8.3333333333333332177e-03);        // 1/5!
+    p = fma(p, r, 4.1666666666666664354e-02);        // 1/4!
+    p = fma(p, r, 1.6666666666666665741e-01);        // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// partial denominators: part[slice*kn + i] = sum_{j in slice} exp(a_i.b_j - 1/2|a_i|^2 - hb_j) [* zero-dv mask]
 template <int PP>
 __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn x PP scaled rows */, size_t kn,
                                              const double* __restrict__ b /* Kp x PP scaled rows */, size_t Kp,
-                                             const double* __restrict__ w_prev, const WConst* __restrict__ wc,
+                                             const double* __restrict__ hb /* Kp */, const WConst* __restrict__ wc,
                                              const double* __restrict__ theta_raw, size_t K, size_t k0,
                                              const double* __restrict__ prev_raw, double* __restrict__ part) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -97,16 +131,18 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
     const size_t j0 = Kp * sl / slices, j1 = Kp * (sl + 1) / slices;
     const bool active = i < kn;
     double ai[PP];
+    double ha = 0.0;
 #pragma unroll
-    for (int p = 0; p < PP; p++) ai[p] = active ? a[i * PP + p] : 0.0;
+    for (int p = 0; p < PP; p++) { ai[p] = active ? a[i * PP + p] : 0.0; ha = fma(ai[p], ai[p], ha); }
+    ha *= 0.5;
     const int nzero = wc->nzero;
     double acc = 0.0;
     for (size_t j = j0; j < j1; j++) {
         const double* bj = b + j * PP;
-        double e = 0.0;
+        double e = -(ha + hb[j]);
 #pragma unroll
-        for (int p = 0; p < PP; p++) { const double d = ai[p] - bj[p]; e = fma(d, d, e); }
-        double term = w_prev[j] * exp(-0.5 * e);
+        for (int p = 0; p < PP; p++) e = fma(ai[p], bj[p], e);
+        double term = exp_neg(e);
         if (nzero) {   // converged parameters: factor 1 if equal (AbcUtil.cpp:573), else 0 (declared)
             for (int z = 0; z < nzero; z++) {
                 const int p = wc->zero_idx[z];
@@ -206,16 +242,17 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     double* a = (double*)abc_ws_alloc(ctx, kn * PP * sizeof(double));
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* part = (double*)abc_ws_alloc(ctx, slices * kn * sizeof(double));
-    if (!wc || !a || !b || !part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
+    if (!wc || !a || !b || !part || !hb) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc);
-    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn * PP + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
-                       (int)P, PP, wc, a);
-    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp * PP + 255) / 256)), dim3(256), 0, ctx->stream, theta_prev, Kp, Kp,
-                       (int)P, PP, wc, b);
+    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
+                       (int)P, PP, wc, theta_prev, Kp, (const double*)nullptr, a, (double*)nullptr);
+    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, ctx->stream, theta_prev, Kp, Kp,
+                       (int)P, PP, wc, theta_prev, Kp, w_prev, b, hb);
 #define LAUNCH_KDE(PPV)                                                                                        \
     hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
-                       Kp, w_prev, wc, theta, K, k0, theta_prev, part)
+                       Kp, hb, wc, theta, K, k0, theta_prev, part)
     {
         StageTimer tk(ctx, ST_KDE);
         switch (PP) {
