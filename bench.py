@@ -124,13 +124,16 @@ def main():
     alg_bytes = 8.0 * n_loc * (M + P)
     gram_ms_per_step = g_ms / max(args.steps, 1)
     achieved = alg_bytes / (gram_ms_per_step * 1e-3) / 1e9 if gram_ms_per_step > 0 else 0.0
+    # HBM traffic of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 correction
+    # applied by the script that wrote the file); only valid for the exact single-GPU configuration profiled
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "pmc_k_gram.json")
-    if os.path.exists(prof):
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if os.path.exists(prof) and world == 1:
         try:
-            pj = json.load(open(prof))
-            if pj.get("config") == args.config and pj.get("n_gpus", 1) == 1:
-                traffic = pj.get("hbm_bytes_per_launch")
+            ent = json.load(open(prof))["configs"].get(str(args.config), {})
+            for k, v in ent.items():
+                if k.startswith("k_gram<3"):
+                    traffic = v["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
     roofline = {"kernel": "k_gram", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
