@@ -78,6 +78,7 @@ SIGNATURES = {
     "abc_stats_accumulate_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _u64, _u64, _vp]),
     "abc_model_len": (_sz, [_sz, _sz, _sz]),
     "abc_pls_model_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _i, _vp]),
+    "abc_pls_wilcoxon_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp]),
     "abc_model_ncomp": (_i, [_vp, _vp, _sz, _sz, _sz, _vp]),
     "abc_simple_model_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "abc_project_distance_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _i, _vp]),

@@ -146,6 +146,11 @@ int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, siz
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
+int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
+                       unsigned long long* val1, size_t n, int byte_lo, int byte_hi);
+// Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n)
+int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
+                    size_t A, size_t row_test, double* model);
 int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, size_t P,
                        const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt);
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);

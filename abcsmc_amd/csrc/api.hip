@@ -34,6 +34,12 @@ int abc_pin_reserve(abc_ctx* ctx, size_t bytes) {
     return ABC_OK;
 }
 
+// arena needed by the Wilcoxon reduction: scores + 4 key/value buffers over (segments x validation rows)
+static size_t wx_need(size_t nt, size_t P, size_t A) {
+    const size_t seg = P * (A > 0 ? A - 1 : 0);
+    return nt * A * 8 + 4 * seg * nt * 8 + 256 * ((seg * nt) / 2048 + 2) * 4 + (1u << 20);
+}
+
 // generous upper bound of the arena needed by any single API call on these sizes
 static size_t ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext) {
     const size_t C = (M + P + 15) / 16;
@@ -184,9 +190,19 @@ extern "C" int abc_stats_accumulate_dev(abc_ctx* ctx, const double* X, const dou
 extern "C" int abc_pls_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A,
                                  int rule, double* model) {
     CHECK_CTX(ctx);
-    if (rule != ABC_RULE_MIN_PRESS) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "component rule %d not available on the device", rule);
+    if (rule != ABC_RULE_MIN_PRESS)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "abc_pls_model_dev fits from statistics only: call abc_pls_wilcoxon_dev "
+                 "afterwards for rule %d (needs the validation rows)", rule);
     ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0)));
     return launch_pls_model(ctx, stats, obs, M, P, A, rule, model);
+}
+
+extern "C" int abc_pls_wilcoxon_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
+                                    size_t M, size_t P, size_t A, size_t row_test, double* model) {
+    CHECK_CTX(ctx);
+    const size_t nt = row_test < n ? n - row_test : 0;
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0) + wx_need(nt, P, A)));
+    return launch_wilcoxon(ctx, X, Y, n, ldx, ldy, M, P, A, row_test, model);
 }
 
 extern "C" int abc_simple_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P,
@@ -284,8 +300,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (!N || !M || K > N) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: bad sizes N=%zu M=%zu K=%zu", N, M, K);
     if (!simple && !(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))      // AbcUtil.cpp:428
         ABC_FAIL(ctx, ABC_ERR_INVALID, "training fraction %g outside (0,1]", cfg->train_frac);
-    if (!simple && cfg->rule != ABC_RULE_MIN_PRESS)
-        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "component rule %d not available on the device", cfg->rule);
+    if (!simple && cfg->rule != ABC_RULE_MIN_PRESS && cfg->rule != ABC_RULE_WILCOXON)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "unknown component rule %d", cfg->rule);
     const size_t A = simple ? 0 : default_A(M, P, cfg->max_comp);
     const StatsLayout SL = stats_layout(M, P);
     const ModelLayout ML = model_layout(M, P, A);
@@ -302,6 +318,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
     if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
     else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
+    if (!simple && cfg->rule == ABC_RULE_WILCOXON)
+        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist));
@@ -358,7 +376,9 @@ extern "C" int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, c
     CHECK_CTX(ctx);
     if (!cfg || !io || !io->X || !io->obs || !io->idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: null argument");
     const size_t A = default_A(cfg->M, cfg->P, cfg->max_comp);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext)));
+    size_t need = ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext);
+    if (cfg->rule == ABC_RULE_WILCOXON) need += wx_need(cfg->N, cfg->P, A);
+    ABC_TRY(abc_ws_reserve(ctx, need));
     return generation_core(ctx, cfg, io, rng, ncomp_host, 0);
 }
 
@@ -386,7 +406,8 @@ static int ranking_host(abc_ctx* ctx, const double* X, const double* Y, const do
                         int32_t* ncomp, double* R, double* mean, double* sd, int simple) {
     if (!X || !obs || !idx || (!simple && !Y)) ABC_FAIL(ctx, ABC_ERR_INVALID, "ranking: null argument");
     const size_t A = simple ? 0 : default_A(M, P, max_comp);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(N, M, P, A, K, 0, 0) + (N * (M + P) + M + 2 * K) * 8));
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(N, M, P, A, K, 0, 0) + (N * (M + P) + M + 2 * K) * 8 +
+                                    ((!simple && rule == ABC_RULE_WILCOXON) ? wx_need(N, P, A) : 0)));
     Stage s{ctx};
     abc_generation_io io;
     memset(&io, 0, sizeof(io));

@@ -301,14 +301,14 @@ __global__ __launch_bounds__(256) void k_sort_scan(unsigned int* __restrict__ bh
 
 // sorts n pairs; result ends in (key0, idx0); (key1, idx1) is scratch of the same size
 int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* idx0, unsigned long long* key1,
-                   unsigned long long* idx1, size_t n) {
+                   unsigned long long* idx1, size_t n, int byte_lo = 0, int byte_hi = 8) {
     if (n <= 1) return ABC_OK;
     StageTimer tm(ctx, ST_SORT);
     const int nb = (int)((n + ST_CHUNK - 1) / ST_CHUNK);
     unsigned int* bh = (unsigned int*)abc_ws_alloc(ctx, (size_t)256 * nb * sizeof(unsigned int));
     if (!bh) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sort: workspace exhausted");
     unsigned long long *ka = key0, *ia = idx0, *kb = key1, *ib = idx1;
-    for (int pass = 0; pass < 8; pass++) {
+    for (int pass = byte_lo; pass < byte_hi; pass++) {   // an even number of passes ends in (key0, idx0)
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, ctx->stream, ka, n, shift, bh, nb);
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(256), 0, ctx->stream, bh, nb);
@@ -321,6 +321,14 @@ int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* i
 }
 
 }  // namespace
+
+// stable LSD radix sort of n (key, value) pairs on key bytes [byte_lo, byte_hi) (an even number of passes);
+// the result is left in (key0, val0); (key1, val1) are scratch.  Used by the Wilcoxon rank sums.
+int abc_sort_u64_bytes(abc_ctx* ctx, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
+                       unsigned long long* val1, size_t n, int byte_lo, int byte_hi) {
+    if ((byte_hi - byte_lo) % 2 != 0) ABC_FAIL(ctx, ABC_ERR_INVALID, "sort: odd number of radix passes");
+    return sort_pairs_u64(ctx, key0, val0, key1, val1, n, byte_lo, byte_hi);
+}
 
 int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx,
                            double* dist_out) {

@@ -190,6 +190,10 @@ int abc_stats_accumulate_dev(abc_ctx* ctx, const double* X, const double* Y, siz
 size_t abc_model_len(size_t M, size_t P, size_t A);
 int abc_pls_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P,
                       size_t A, int rule, double* model);
+/* optional second step of the fit for rule ABC_RULE_WILCOXON: reduces the per-response PRESS optima using the
+ * validation rows [row_test, n) of THIS device (single-GPU sets only) and rewrites ncomp in the model record */
+int abc_pls_wilcoxon_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
+                         size_t M, size_t P, size_t A, size_t row_test, double* model);
 int abc_model_ncomp(abc_ctx* ctx, const double* model, size_t M, size_t P, size_t A, int32_t* ncomp);
 /* "simple" model: only means / sds / z-scored obs (AbcUtil.cpp:412-416) */
 int abc_simple_model_dev(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P,

@@ -402,3 +402,36 @@ def test_cxx_facade_demo(gpu_ctx, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "facade ok" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------------
+# Wilcoxon-reduced component count ([PLS] optimal_num_components)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,M,P,A,f,seed", [(400, 10, 4, 0, 0.5, 1), (1000, 32, 16, 8, 0.5, 2), (250, 12, 3, 3, 0.6, 3),
+                                             (3000, 20, 6, 6, 0.5, 4), (120, 8, 5, 5, 0.5, 5), (5000, 32, 16, 8, 0.5, 6)])
+def test_particle_ranking_pls_wilcoxon_rule(gpu_ctx, oracle, N, M, P, A, f, seed):
+    from abcsmc_amd import abcutil, _lib
+    wl, X, Y, obs = _wl(M, P, N, seed)
+    # noisier responses make later components insignificant, so the reduction actually bites
+    rng = np.random.default_rng(seed)
+    Y = np.asfortranarray(Y + rng.normal(size=Y.shape) * Y.std(0) * 1.5)
+    g = abcutil.particle_ranking_PLS(X, Y, obs, f, max_comp=A, rule=_lib.RULE_WILCOXON, details=True, ctx=gpu_ctx)
+    o = oracle.particle_ranking_pls(X, Y, obs, f, A, rule=oracle.RULE_WILCOXON)
+    o0 = oracle.particle_ranking_pls(X, Y, obs, f, A, rule=oracle.RULE_MIN_PRESS)
+    assert g["ncomp"] == o["ncomp"], (g["ncomp"], o["ncomp"], o0["ncomp"])
+    assert np.allclose(g["dist"], o["dist"][g["idx"].astype(int)], rtol=RTOL)
+    assert _near_tie_ok(g["idx"], o["idx"], o["dist"])
+
+
+def test_wilcoxon_rule_reduces_somewhere(oracle):
+    """sanity of the test design: at least one of the cases above is a genuine reduction"""
+    hit = 0
+    for (N, M, P, A, f, seed) in [(400, 10, 4, 0, 0.5, 1), (250, 12, 3, 3, 0.6, 3), (120, 8, 5, 5, 0.5, 5)]:
+        wl, X, Y, obs = _wl(M, P, N, seed)
+        rng = np.random.default_rng(seed)
+        Y = np.asfortranarray(Y + rng.normal(size=Y.shape) * Y.std(0) * 1.5)
+        a = oracle.particle_ranking_pls(X, Y, obs, f, A, rule=oracle.RULE_WILCOXON)["ncomp"]
+        b = oracle.particle_ranking_pls(X, Y, obs, f, A, rule=oracle.RULE_MIN_PRESS)["ncomp"]
+        assert a <= b
+        hit += a < b
+    assert hit >= 1
