@@ -38,7 +38,10 @@ struct GramDims {
 };
 
 // grid = (G, 2): blockIdx.y = partition (0: rows [0,split) training, 1: rows [split,n) validation)
-template <int C, int CY>
+// TABLE = true: the columns come from a device table of column pointers (X reinterpreted as
+// `const double* const*`, NULL = padding) instead of the two dense arrays; used to cover wide sets
+// (M+P > 96) with several launches over column-group pairs.
+template <int C, int CY, bool TABLE = false>
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, const double* __restrict__ Y,
                                               size_t ldx, size_t ldy, int M, int P, long long n,
                                               long long split, const double* __restrict__ shift,
@@ -63,9 +66,17 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
         const int c = wave + 4 * i;  // one column per wave-instruction; padding columns re-read column 0, zeroed
         colsum[i] = 0.0;
         colsq[i] = 0.0;
-        keep[i] = (c < M + P) ? 1.0 : 0.0;
-        cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
-        sh[i] = (c < M + P) ? shift[c] : 0.0;
+        if constexpr (TABLE) {
+            const double* const* tab = reinterpret_cast<const double* const*>(X);
+            const double* q = tab[c];
+            keep[i] = q ? 1.0 : 0.0;
+            cptr[i] = q ? q : tab[0];
+            sh[i] = q ? shift[c] : 0.0;
+        } else {
+            keep[i] = (c < M + P) ? 1.0 : 0.0;
+            cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+            sh[i] = (c < M + P) ? shift[c] : 0.0;
+        }
     }
 
     d2 v[D::NI];
@@ -261,6 +272,84 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     return ABC_OK;
 }
 
+// ---- wide sets (M+P > 96): column groups of <= 48, one k_gram<.,0,TABLE> launch per pair of groups ------------
+__global__ void k_group_table(const double* X, const double* Y, size_t ldx, size_t ldy, int M, int P, int ga0, int gan,
+                              int gb0, int gbn, const double* __restrict__ shift_big, const double** __restrict__ tab,
+                              double* __restrict__ shift_loc, int* __restrict__ gmap, int C16loc) {
+    const int a = threadIdx.x;
+    if (a >= C16loc) return;
+    int gc = -1;                                   // global column of local column a
+    if (a < 48) { if (a < gan) gc = ga0 + a; }
+    else if (a - 48 < gbn) gc = gb0 + (a - 48);
+    gmap[a] = gc;
+    tab[a] = (gc < 0) ? nullptr : (gc < M ? X + (size_t)gc * ldx : Y + (size_t)(gc - M) * ldy);
+    shift_loc[a] = (gc < 0) ? 0.0 : shift_big[gc];
+}
+
+__global__ __launch_bounds__(256) void k_group_scatter(const double* __restrict__ loc, int C16loc, const int* __restrict__ gmap,
+                                                       double* __restrict__ big, int C16big) {
+    const StatsLayout LL = stats_layout(C16loc, 0), LB = stats_layout(C16big, 0);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) { big[LB.off_n] = loc[LL.off_n]; big[LB.off_n + 1] = loc[LL.off_n + 1]; }
+    if (e >= C16loc * C16loc) return;
+    const int a = e % C16loc, b = e / C16loc;
+    const int ga = gmap[a], gb = gmap[b];
+    if (ga < 0 || gb < 0) return;
+    for (int part = 0; part < 2; part++) {
+        big[LB.off_G[part] + ga + (size_t)C16big * gb] = loc[LL.off_G[part] + a + (size_t)C16loc * b];
+        if (b == 0) big[LB.off_sum[part] + ga] = loc[LL.off_sum[part] + a];
+    }
+}
+
+int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
+                     size_t P, long long split, double* stats) {
+    const StatsLayout LB = stats_layout(M, P);
+    const int ncol = (int)(M + P);
+    const int ng = (ncol + 47) / 48;
+    const StatsLayout LL = stats_layout(96, 0);
+    double* loc = (double*)abc_ws_alloc(ctx, LL.len * sizeof(double));
+    const double** tab = (const double**)abc_ws_alloc(ctx, 96 * sizeof(double*));
+    int* gmap = (int*)abc_ws_alloc(ctx, 96 * sizeof(int));
+    if (!loc || !tab || !gmap) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted");
+    const size_t ws_mark = ctx->ws_off;
+    for (int ga = 0; ga < ng; ga++)
+        for (int gb = ga + 1; gb < ng; gb++) {
+            ctx->ws_off = ws_mark;                       // the per-launch partial records reuse the same arena space
+            const int ga0 = 48 * ga, gan = ncol - ga0 < 48 ? ncol - ga0 : 48;
+            const int gb0 = 48 * gb, gbn = ncol - gb0 < 48 ? ncol - gb0 : 48;
+            hipLaunchKernelGGL(k_group_table, dim3(1), dim3(128), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P, ga0, gan,
+                               gb0, gbn, stats + LB.off_shift, tab, loc + LL.off_shift, gmap, 96);
+            using D = GramDims<6, 0>;
+            const long long ntr = split, nte = (long long)n - split;
+            const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
+            long long G = tiles / 2;
+            if (G < 1) G = 1;
+            if (G > 128) G = 128;                        // 100 KB of LDS: one work-group per CU
+            double* partial = (double*)abc_ws_alloc(ctx, (size_t)2 * G * D::PSZ * sizeof(double));
+            if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted");
+            const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
+            const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
+            static bool attr_set = false;
+            if (!attr_set) {
+                ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<6, 0, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                attr_set = true;
+            }
+            {
+                StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
+                hipLaunchKernelGGL((k_gram<6, 0, true>), dim3((unsigned)G, 2), dim3(256), lds_bytes, ctx->stream,
+                                   (const double*)tab, (const double*)nullptr, ldx, ldy, 96, 0, (long long)n, split,
+                                   loc + LL.off_shift, partial, vec_ok);
+            }
+            hipLaunchKernelGGL((k_stats_reduce<6, 0>), dim3((D::PSZ + 15) / 16, 2), dim3(256), 0, ctx->stream, partial,
+                               (int)G, loc, ntr, nte);
+            hipLaunchKernelGGL(k_group_scatter, dim3((96 * 96 + 255) / 256), dim3(256), 0, ctx->stream, loc, 96, gmap, stats,
+                               (int)LB.C16);
+            ABC_HIP(ctx, hipGetLastError());
+        }
+    return ABC_OK;
+}
+
 }  // namespace
 
 int launch_stats_shift(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
@@ -284,8 +373,9 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     GRAM_CASE(4, 0); GRAM_CASE(4, 1); GRAM_CASE(4, 2); GRAM_CASE(5, 0); GRAM_CASE(5, 1); GRAM_CASE(5, 2);
     GRAM_CASE(6, 0); GRAM_CASE(6, 1); GRAM_CASE(6, 2);
 #undef GRAM_CASE
+    if (C > 6 && M + P <= 480) return run_gram_grouped(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
     switch (C) {
         default:
-            ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "gram: M+P = %zu exceeds 96 columns", M + P);
+            ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "gram: M+P = %zu exceeds 480 columns", M + P);
     }
 }

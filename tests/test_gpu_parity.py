@@ -38,6 +38,9 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (300, 2, 2, 0, 0.5),         # dice-sized (config 1)
     (4097, 20, 1, 4, 0.9),       # single response (P == 1 branch of the PLS loop)
     (777, 40, 24, 10, 1.0),      # f = 1: empty validation set
+    (4000, 64, 32, 8, 0.5),      # BASELINE configs[3] shape (6 column blocks, Y'Y blocks skipped)
+    (3000, 128, 16, 32, 0.5),    # BASELINE configs[4] shape: 144 columns -> grouped Gram launches, 32 components
+    (1500, 100, 28, 12, 0.5),    # ragged wide set
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
