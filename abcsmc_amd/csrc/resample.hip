@@ -91,13 +91,16 @@ __device__ __forceinline__ uint32_t d_apply(const uint32_t* __restrict__ col, ui
 // gsl_rng_get would return), for i in [0, n)
 __global__ __launch_bounds__(256) void k_taus_stream(abc_rng base, size_t n, const uint32_t* __restrict__ jt,
                                                      uint32_t* __restrict__ out) {
+    __shared__ uint32_t sjt[24 * 96];          // T^(RUN*2^k), k < 24 (16 M lanes x 64 outputs = 2^30 draws)
+    for (int e = threadIdx.x; e < 24 * 96; e += 256) sjt[e] = jt[e];
+    __syncthreads();
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t first = t * RUN;
     if (first >= n) return;
     uint32_t s1 = base.s1, s2 = base.s2, s3 = base.s3;
     for (int k = 0; k < 32; k++)
         if ((t >> k) & 1) {
-            const uint32_t* m = jt + (size_t)k * 96;
+            const uint32_t* m = (k < 24) ? sjt + k * 96 : jt + (size_t)k * 96;
             s1 = d_apply(m, s1); s2 = d_apply(m + 32, s2); s3 = d_apply(m + 64, s3);
         }
     const size_t last = (first + RUN < n) ? first + RUN : n;
@@ -152,7 +155,7 @@ __device__ __forceinline__ void normal2(U4 r, double& z0, double& z1) {
     const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
     const double rad = sqrt(-2.0 * log(u1));
     double s, c;
-    sincos(6.283185307179586476925 * u2, &s, &c);
+    sincospi(2.0 * u2, &s, &c);        // exact argument reduction in units of pi: no large-argument slow path
     z0 = rad * c; z1 = rad * s;
 }
 
@@ -174,19 +177,20 @@ __device__ __forceinline__ double d_prior_mean(const abc_prior& pr) {           
 constexpr unsigned MVN_MAX_TRIES = 1u << 14;   // the reference retries for ever (AbcUtil.cpp:132); bounded here
 
 // one new particle per lane
-template <int PP>
+template <int PP, bool MV>
 __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __restrict__ theta, size_t K, int P,
                                                  const abc_prior* __restrict__ priors,
                                                  const unsigned long long* __restrict__ parent,
-                                                 unsigned long long i0, size_t n, int multivariate,
+                                                 unsigned long long i0, size_t n,
                                                  const double* __restrict__ L_or_dv, double* __restrict__ out) {
-    __shared__ double sL[PP * PP];
+    __shared__ double sL[PP * PP];     // MV: lower-triangular factor (column-major, zero above the diagonal);
+                                       // otherwise sqrt(dv) on the diagonal (AbcUtil.cpp:150)
     __shared__ abc_prior sp[PP];
     for (int e = threadIdx.x; e < PP * PP; e += 256) {
         const int a = e % PP, b = e / PP;
         double v = 0.0;
-        if (multivariate) { if (a < P && b < P && b <= a) v = L_or_dv[a + (size_t)P * b]; }
-        else if (a == b && a < P) v = sqrt(L_or_dv[a]);                    // AbcUtil.cpp:150
+        if (MV) { if (a < P && b < P && b <= a) v = L_or_dv[a + (size_t)P * b]; }
+        else if (a == b && a < P) v = sqrt(L_or_dv[a]);
         sL[e] = v;
     }
     for (int p = threadIdx.x; p < PP; p += 256) {
@@ -202,22 +206,26 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
 #pragma unroll
     for (int p = 0; p < PP; p++) { mu[p] = (p < P) ? theta[par + K * (size_t)p] : 0.0; val[p] = mu[p]; }
     const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
-    if (multivariate) {
-        // AbcUtil.cpp:132-139: draw the whole vector, accept iff every coordinate is valid
+    if (MV) {
+        // AbcUtil.cpp:132-139: draw the whole vector x = mu + L z, accept iff every coordinate is valid
         for (unsigned attempt = 0; attempt < MVN_MAX_TRIES; attempt++) {
-            double z[PP];
+            double x[PP];
 #pragma unroll
-            for (int p = 0; p < PP; p += 2) {
-                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)(p >> 1);
-                normal2(philox(c, k0, k1), z[p], z[p + 1]);
+            for (int a = 0; a < PP; a++) x[a] = 0.0;
+#pragma unroll 1
+            for (int pr = 0; pr < PP / 2; pr++) {      // one Philox block -> two normals -> two columns of L
+                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
+                double z0, z1;
+                normal2(philox(c, k0, k1), z0, z1);
+                const double* l0 = sL + PP * (2 * pr);
+                const double* l1 = l0 + PP;
+#pragma unroll
+                for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
             }
             bool ok = true;
 #pragma unroll
             for (int a = 0; a < PP; a++) {
-                double x = 0.0;
-#pragma unroll
-                for (int b = 0; b <= a; b++) x = fma(sL[a + PP * b], z[b], x);   // x = L z (lower triangular)
-                const double v = d_recast(sp[a], x + mu[a]);
+                const double v = d_recast(sp[a], x[a] + mu[a]);
                 val[a] = v;
                 ok = ok && d_valid(sp[a], v);
             }
@@ -347,9 +355,15 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     while (PP < (int)P) PP *= 2;
     StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-#define LAUNCH_PT(PPV)                                                                                          \
-    hipLaunchKernelGGL(k_perturb<PPV>, dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, priors, \
-                       (const unsigned long long*)parent, (unsigned long long)i0, n, multivariate, L_or_dv, out)
+#define LAUNCH_PT(PPV)                                                                                                 \
+    do {                                                                                                               \
+        if (multivariate)                                                                                              \
+            hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_perturb<PPV, false>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);   \
+    } while (0)
     switch (PP) {
         case 2: LAUNCH_PT(2); break;
         case 4: LAUNCH_PT(4); break;
