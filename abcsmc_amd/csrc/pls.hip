@@ -185,6 +185,8 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     double* rv = wv + M;                // M
     double* pv = rv + M;                // M
     double* xr = pv + M;                // M
+    double* Pl = xr + M;                // M*A: loadings P (LDS copy, read by the deflation of later components)
+    double* Rl = Pl + (size_t)M * A;    // M*A: rotations R
 
     const double* XXtr = zwork + Z.off_XX[0];
     double* Rm = model + ML.off_R;
@@ -223,35 +225,42 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
                 for (int e = lane; e < n * n; e += 64) Bc[e] = (e == 0) ? 1.0 : 0.0;
             }
             __syncthreads();
-            int best = 0;
-            for (int i = 1; i < n; i++) if (Bc[i + n * i] > Bc[best + n * best]) best = i;
-            for (int i = lane; i < n; i += 64) qv[i] = Bc[i + n * best];
-            __syncthreads();
-            // two power steps with S itself wash out the rounding of the squarings
-            for (int rep = 0; rep < 2 && tr > 0.0; rep++) {
+            // column of the converged power with the largest diagonal entry (wave arg-max, ties -> lowest index)
+            double dg = (lane < n) ? Bc[lane + n * lane] : -1.0;
+            int bi = lane;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double od = __shfl_xor(dg, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (od > dg || (od == dg && oi < bi)) { dg = od; bi = oi; }
+            }
+            const int best = bi;
+            // one power step with S itself washes out the rounding of the squarings; then unit norm and
+            // the sign convention (largest |component| positive; ties -> lowest index), all in registers
+            double qi = (lane < n) ? Bc[lane + n * best] : 0.0;
+            if (tr > 0.0) {
+                if (lane < n) qv[lane] = qi;
+                __syncthreads();
                 double v = 0.0;
-                if (lane < n) for (int k = 0; k < n; k++) v = fma(S[lane + n * k], qv[k], v);
-                __syncthreads();
-                if (lane < n) qv[lane] = v;
-                __syncthreads();
-                double nn = 0.0;
-                for (int k = 0; k < n; k++) nn = fma(qv[k], qv[k], nn);
-                nn = sqrt(nn);
-                __syncthreads();
-                if (lane < n) qv[lane] = v / nn;
+                if (lane < n) {
+#pragma unroll 8
+                    for (int k = 0; k < n; k++) v = fma(S[lane + n * k], qv[k], v);
+                }
+                qi = v;
                 __syncthreads();
             }
-            // unit norm; largest |component| positive (same convention as the oracle)
-            double nrm = 0.0; int big = 0;
-            for (int i = 0; i < n; i++) {
-                const double x = qv[i];
-                nrm = fma(x, x, nrm);
-                if (fabs(x) > fabs(qv[big])) big = i;
+            const double nrm = sqrt(wave_sum(qi * qi));
+            double am = fabs(qi);
+            int ai = lane;
+            double sv = qi;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double om = __shfl_xor(am, o, 64), os = __shfl_xor(sv, o, 64);
+                const int oi = __shfl_xor(ai, o, 64);
+                if (om > am || (om == am && oi < ai)) { am = om; ai = oi; sv = os; }
             }
-            nrm = sqrt(nrm);
-            const double sgn = (qv[big] < 0.0) ? -1.0 : 1.0;
-            __syncthreads();
-            if (lane < n) qv[lane] = sgn * qv[lane] / nrm;
+            const double sgn = (sv < 0.0) ? -1.0 : 1.0;
+            if (lane < n) qv[lane] = sgn * qi / nrm;
             __syncthreads();
             for (int m = lane; m < M; m += 64) {
                 double s = 0.0;
@@ -267,9 +276,9 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
         __syncthreads();
         for (int j = 0; j < comp; j++) {
             double pw = 0.0;
-            for (int m = lane; m < M; m += 64) pw = fma(Pm[m + (size_t)M * j], wv[m], pw);
+            for (int m = lane; m < M; m += 64) pw = fma(Pl[m + (size_t)M * j], wv[m], pw);
             pw = wave_sum(pw);
-            for (int m = lane; m < M; m += 64) rv[m] -= pw * Rm[m + (size_t)M * j];
+            for (int m = lane; m < M; m += 64) rv[m] -= pw * Rl[m + (size_t)M * j];
         }
         __syncthreads();
         // type 2: xr = XX r ; tt = r' xr ; p = xr / tt
@@ -285,8 +294,10 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             const double pm = xr[m] / tt;
             pv[m] = pm;
             Pm[m + (size_t)M * comp] = pm;
+            Pl[m + (size_t)M * comp] = pm;
             Wm[m + (size_t)M * comp] = wv[m];
             Rm[m + (size_t)M * comp] = rv[m];
+            Rl[m + (size_t)M * comp] = rv[m];
         }
         __syncthreads();
         for (int j = lane; j < P; j += 64) {
@@ -396,7 +407,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
-    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 8;
+    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + 8;
     const size_t lds_bytes = lds_d * sizeof(double);
     if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -27,6 +27,8 @@ CONFIGS = {
             N=1_000_000, M=32, P=16, A=8),
     4: dict(name="configs[3]: synthetic 10M/8 particles per GPU x 32 params x 64 metrics, PLS 8 components",
             N=1_250_000, M=64, P=32, A=8),
+    5: dict(name="configs[4]: synthetic 1M/8 particles per GPU x 16 params x 128 metrics, PLS 32 components",
+            N=125_000, M=128, P=16, A=32),
 }
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
