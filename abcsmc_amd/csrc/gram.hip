@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
         __syncthreads();
         if (tile + G < ntiles) fetch(tile + G);  // next tile's HBM latency hides under the MFMAs
         const int cl = lane & 15, q = lane >> 4;
-#pragma unroll 2
+#pragma unroll
         for (int s = 0; s < TR / 16; s++) {
             const int rb = wave * (TR / 4) + 4 * s + q;
             double a[C];

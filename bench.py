@@ -38,7 +38,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json config: 3 = configs[2] (1M particles, the full weight+resample generation the metric "
+                         "is quoted on; default), 2 = configs[1] (100k), 4/5 = per-GPU shards of configs[3]/[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     args = ap.parse_args()
@@ -143,6 +145,20 @@ def main():
                 "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": round(gram_ms_per_step, 5),
                 "launches_per_step": gram_launches_per_step}
     stage_ms = {k: round((v[0] + v[1]) / max(args.steps, 1), 5) for k, v in stages.items()}
+    # the compute-bound kernel of the path (informational): pairs x flops per pair / HIP-event time.
+    # Per pair: P FMAs (dot product) + 1 add + inline exp (2 mul/round + 13 FMA + ldexp) + 1 accumulate.
+    k_ms, _, _ = stages["k_kde"]
+    pairs = float(K // world + (1 if rank < K % world else 0)) * Kp if world > 1 else float(K) * Kp
+    PPad = 2
+    while PPad < P:
+        PPad *= 2
+    flop_pair = 2 * PPad + 1 + 2 * 13 + 4 + 1
+    kde_ms_per_step = k_ms / max(args.steps, 1)
+    kde_tflops = pairs * flop_pair / (kde_ms_per_step * 1e-3) / 1e12 if kde_ms_per_step > 0 else 0.0
+    roofline_compute = {"kernel": "k_kde", "bound": "fp64_valu", "achieved": round(kde_tflops, 2), "peak": 78.6,
+                        "unit": "TFLOP/s", "frac": round(kde_tflops / 78.6, 4),
+                        "note": "peak = MI355X fp64 vector spec; scripts/ubench.hip measures 56 TFLOP/s sustained v_fma_f64",
+                        "pairs_per_step": pairs, "flop_per_pair": flop_pair, "kernel_ms_per_step": round(kde_ms_per_step, 5)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -160,6 +176,7 @@ def main():
                        "ncomp_chosen": int(gen.ncomp.value if world == 1 else gen.ncomp),
                        "parallelism": "row-sharded x%d" % world},
             "roofline": roofline,
+            "roofline_compute": roofline_compute,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,
         }
