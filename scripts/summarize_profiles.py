@@ -1,0 +1,42 @@
+"""Copies the rocprofv3 summaries a gpurun call left under gpurun_out/ into profiles/ (tracked) and derives the
+per-kernel HBM traffic from the separate FETCH_SIZE / WRITE_SIZE PMC passes, with the gfx950 correction of
+/opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of a wide coalesced read; WRITE_SIZE exact).
+usage: python scripts/summarize_profiles.py <round-tag> <stats-prefix> <pmc-prefix>"""
+import csv, glob, json, re, shutil, sys
+
+tag, sp, pp = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def short(k):
+    m = re.search(r'(k_[a-z0-9_]+(<[^>]*>)?)', k)
+    return m.group(1) if m else k.split('(')[0].strip()
+
+
+def pmc(d, counter):
+    out = {}
+    for r in csv.DictReader(open(glob.glob(d + '/runc/*_counter_collection.csv')[0])):
+        if r['Counter_Name'] == counter:
+            out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `python3 bench.py --config N --steps 2 "
+                "--warmup 1 --no-cpu-baseline`; per-dispatch averages in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                "(gfx950: FETCH_SIZE counts 64 B per 128-B request).", "configs": {}}
+rows = []
+for cfg in (2, 3):
+    shutil.copy(glob.glob('gpurun_out/%s_c%d/runc/*_kernel_stats.csv' % (sp, cfg))[0],
+                'profiles/%s_kernel_stats_config%d.csv' % (tag, cfg))
+    fe, wr = pmc('gpurun_out/%s_fetch_c%d' % (pp, cfg), 'FETCH_SIZE'), pmc('gpurun_out/%s_write_c%d' % (pp, cfg), 'WRITE_SIZE')
+    ent = {}
+    for k in fe:
+        hbm = (2 * fe[k] + wr.get(k, 0)) * 1024
+        rows.append((cfg, short(k), fe[k], wr.get(k, 0), hbm))
+        ent[short(k)] = {"FETCH_SIZE_KiB_raw": fe[k], "WRITE_SIZE_KiB": wr.get(k, 0), "hbm_bytes_per_launch": hbm}
+    res["configs"][str(cfg)] = ent
+json.dump(res, open('profiles/%s_pmc_hbm_traffic.json' % tag, 'w'), indent=1)
+with open('profiles/%s_pmc_hbm_traffic.csv' % tag, 'w') as f:
+    f.write("config,kernel,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB,hbm_bytes_corrected\n")
+    for r in rows:
+        f.write('%d,"%s",%.1f,%.1f,%.0f\n' % r)
+print("k_gram traffic:", {c: [v["hbm_bytes_per_launch"] for k, v in e.items() if k.startswith("k_gram<3")] for c, e in res["configs"].items()})
