@@ -9,6 +9,8 @@
 // 2 doubles so the 16-column x 4-row MFMA operand fetch is bank-conflict free), then every wave
 // runs v_mfma_f64_16x16x4_f64 over its 32 rows of the tile for all C(C+1)/2 upper-triangular
 // 16x16 blocks (fp64 in, fp64 accumulate).  HBM-bound: 8*(M+P) bytes per particle, read once.
+#include <stdlib.h>
+
 #include "abc_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -28,13 +30,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 // C = 16-column blocks of [X|Y]; the trailing CY blocks hold only parameter (Y) / padding columns.
 // Y'Y is needed on its diagonal only (PRESS, z-scores), so the CY(CY+1)/2 pure-Y blocks are skipped and
 // the diagonal comes from a per-column sum of squares taken while the tile is staged.
+// NW = waves per work-group: 8 for narrow sets (C <= 3).  fp64 MFMA only reaches its rate with several
+// waves per SIMD issuing (scripts/ubench.hip: 33 TFLOP/s at 1 wave/SIMD, 44 at 2, 46-49 at 4-8), and the
+// 50 KB LDS tile admits three work-groups per CU, so each work-group brings two waves per SIMD.
 template <int C, int CY>
 struct GramDims {
     static constexpr int C16 = 16 * C;
     static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
-    static constexpr int NI = 4 * C;                   // 16-byte vectors per thread per tile
+    static constexpr int NW = (C <= 3) ? 8 : 4;
+    static constexpr int NT = 64 * NW;
+    static constexpr int NI = 16 * C / NW;             // 16-byte vectors per thread per tile
     static constexpr int PSZ = NBLK * 256 + 2 * C16;   // doubles per work-group partial record
     static constexpr int LDS_D = (C16 * TRP > PSZ) ? C16 * TRP : PSZ;
+    static constexpr int EPT = (NBLK * 256 + NT - 1) / NT;   // partial-record elements per thread
+    static constexpr int IQ = 16 * (C - CY) / NW;            // staged columns i >= IQ may lie in a skipped Y'Y block
 };
 
 // grid = (G, 2): blockIdx.y = partition (0: rows [0,split) training, 1: rows [split,n) validation)
@@ -42,12 +51,13 @@ struct GramDims {
 // `const double* const*`, NULL = padding) instead of the two dense arrays; used to cover wide sets
 // (M+P > 96) with several launches over column-group pairs.
 template <int C, int CY, bool TABLE = false>
-__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, const double* __restrict__ Y,
+__global__ __launch_bounds__((GramDims<C, CY>::NT)) void k_gram(const double* __restrict__ X, const double* __restrict__ Y,
                                               size_t ldx, size_t ldy, int M, int P, long long n,
                                               long long split, const double* __restrict__ shift,
                                               double* __restrict__ partial, int vec_ok) {
     using D = GramDims<C, CY>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NW = D::NW, NT = D::NT;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: column pointers live in SGPRs
     const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
     const double* cptr[D::NI];
 #pragma unroll
     for (int i = 0; i < D::NI; i++) {
-        const int c = wave + 4 * i;  // one column per wave-instruction; padding columns re-read column 0, zeroed
+        const int c = wave + NW * i;  // one column per wave-instruction; padding columns re-read column 0, zeroed
         colsum[i] = 0.0;
         colsq[i] = 0.0;
         if constexpr (TABLE) {
@@ -105,19 +115,21 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
         __syncthreads();  // previous tile's operand reads are done
 #pragma unroll
         for (int i = 0; i < D::NI; i++) {
-            const int c = wave + 4 * i;
+            const int c = wave + NW * i;
             d2 z = (d2){(v[i].x - sh[i]) * keep[i], (v[i].y - sh[i]) * keep[i]};
             colsum[i] += z.x + z.y;
-            colsq[i] = fma(z.x, z.x, colsq[i]);
-            colsq[i] = fma(z.y, z.y, colsq[i]);
+            if (i >= D::IQ) {          // sums of squares are only needed where the Gram block is skipped
+                colsq[i] = fma(z.x, z.x, colsq[i]);
+                colsq[i] = fma(z.y, z.y, colsq[i]);
+            }
             *reinterpret_cast<d2*>(&lds[c * TRP + 2 * lane]) = z;
         }
         __syncthreads();
         if (tile + G < ntiles) fetch(tile + G);  // next tile's HBM latency hides under the MFMAs
         const int cl = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int s = 0; s < TR / 16; s++) {
-            const int rb = wave * (TR / 4) + 4 * s + q;
+        for (int s = 0; s < TR / (4 * NW); s++) {
+            const int rb = wave * (TR / NW) + 4 * s + q;
             double a[C];
 #pragma unroll
             for (int b = 0; b < C; b++) a[b] = lds[(16 * b + cl) * TRP + rb];
@@ -136,16 +148,33 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
     double* out = partial + ((size_t)part * G + g) * D::PSZ;
     __syncthreads();
     if constexpr (4 * D::NBLK * 256 <= D::LDS_D) {
-        // every wave parks its accumulators in its own slab, then all threads add the four slabs
+        // four waves at a time park their accumulators in slabs; every thread adds the slabs of "its" elements
+        double tot[D::EPT];
 #pragma unroll
-        for (int b = 0; b < D::NBLK; b++)
+        for (int k = 0; k < D::EPT; k++) tot[k] = 0.0;
+        for (int round = 0; round < NW / 4; round++) {
+            if ((wave >> 2) == round) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) lds[wave * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
-        __syncthreads();
-        for (int e = t; e < D::NBLK * 256; e += 256)
-            out[e] = ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+                for (int b = 0; b < D::NBLK; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lds[(wave & 3) * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < D::EPT; k++) {
+                const int e = t + k * NT;
+                if (e < D::NBLK * 256)
+                    tot[k] += ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < D::EPT; k++) {
+            const int e = t + k * NT;
+            if (e < D::NBLK * 256) out[e] = tot[k];
+        }
     } else {
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < NW; w++) {
             if (wave == w) {
 #pragma unroll
                 for (int b = 0; b < D::NBLK; b++)
@@ -157,18 +186,18 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, cons
             }
             __syncthreads();
         }
-        for (int e = t; e < D::NBLK * 256; e += 256) out[e] = lds[e];
+        for (int e = t; e < D::NBLK * 256; e += NT) out[e] = lds[e];
     }
     // column sums / sums of squares: lane-major park, then one thread per column adds its 64 lanes in order
     for (int half = 0; half < 2; half++) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < D::NI; i++) lds[i * 256 + t] = half ? colsq[i] : colsum[i];
+        for (int i = 0; i < D::NI; i++) lds[i * NT + t] = half ? colsq[i] : colsum[i];
         __syncthreads();
         if (t < D::C16) {
-            const int i = t >> 2, w = t & 3;     // column t was staged by wave w as its i-th column
+            const int i = t / NW, w = t % NW;     // column t was staged by wave w as its i-th column
             double s = 0.0;
-            for (int l = 0; l < 64; l++) s += lds[i * 256 + w * 64 + l];
+            for (int l = 0; l < 64; l++) s += lds[i * NT + w * 64 + l];
             out[D::NBLK * 256 + half * D::C16 + t] = s;
         }
     }
@@ -246,7 +275,8 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
     long long G = tiles / 2;           // >= 2 tiles per work-group amortise its prologue / epilogue
     if (G < 1) G = 1;
-    if (G > 384) G = 384;              // 2 partitions x 384 = three resident work-groups per CU
+    const long long gmax = (D::NW == 8) ? 256 : 384;   // resident work-groups: 2 x 8 waves or 3 x 4 waves per CU
+    if (G > gmax) G = gmax;
     const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
@@ -261,7 +291,7 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     }
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
-        hipLaunchKernelGGL((k_gram<C, CY>), dim3((unsigned)G, 2), dim3(256), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
+        hipLaunchKernelGGL((k_gram<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
                            (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
     }
     ABC_HIP(ctx, hipGetLastError());
@@ -337,7 +367,7 @@ int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, s
             }
             {
                 StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
-                hipLaunchKernelGGL((k_gram<6, 0, true>), dim3((unsigned)G, 2), dim3(256), lds_bytes, ctx->stream,
+                hipLaunchKernelGGL((k_gram<6, 0, true>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream,
                                    (const double*)tab, (const double*)nullptr, ldx, ldy, 96, 0, (long long)n, split,
                                    loc + LL.off_shift, partial, vec_ok);
             }

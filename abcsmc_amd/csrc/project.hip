@@ -10,7 +10,48 @@
 // d2 = fma(s_k - o_k, s_k - o_k, d2) for k ascending; dist = sqrt(d2).  HBM-bound: 8*M B/particle.
 #include "abc_internal.h"
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 namespace {
+
+// two particles per lane (16-B loads: a wave-instruction reads 1 KiB of one metric column); needs 16-B aligned
+// columns.  Per-particle arithmetic is identical to k_project_dist (same operation order -> same bits).
+template <int KC>
+__global__ __launch_bounds__(256) void k_project_dist2(const double* __restrict__ X, size_t npairs, size_t ldx, int M,
+                                                       const double* __restrict__ mean,
+                                                       const double* __restrict__ sd,
+                                                       const double* __restrict__ Rpad,
+                                                       const double* __restrict__ opad,
+                                                       double* __restrict__ dist) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
+        double s0[KC], s1[KC];
+#pragma unroll
+        for (int k = 0; k < KC; k++) { s0[k] = 0.0; s1[k] = 0.0; }
+        const double* xp = X + 2 * i;
+#pragma unroll 4
+        for (int m = 0; m < M; m++) {
+            const d2 x = *reinterpret_cast<const d2*>(xp + (size_t)m * ldx);
+            const double sdm = sd[m], mu = mean[m];
+            const double z0 = (sdm == 0.0) ? 0.0 : (x.x - mu) / sdm;
+            const double z1 = (sdm == 0.0) ? 0.0 : (x.y - mu) / sdm;
+#pragma unroll
+            for (int k = 0; k < KC; k++) {
+                const double r = Rpad[m * KC + k];
+                s0[k] = fma(z0, r, s0[k]);
+                s1[k] = fma(z1, r, s1[k]);
+            }
+        }
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const double t0 = s0[k] - opad[k], t1 = s1[k] - opad[k];
+            d0 = fma(t0, t0, d0);
+            d1 = fma(t1, t1, d1);
+        }
+        *reinterpret_cast<d2*>(dist + 2 * i) = (d2){sqrt(d0), sqrt(d1)};
+    }
+}
 
 template <int KC>
 __global__ __launch_bounds__(256) void k_project_dist(const double* __restrict__ X, size_t n, size_t ldx, int M,
@@ -102,9 +143,24 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     double* opad = Rpad + M * KC;
     hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
     ABC_HIP(ctx, hipGetLastError());
-#define LAUNCH_PD(KCV)                                                                                               \
-    hipLaunchKernelGGL(k_project_dist<KCV>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n, ldx, (int)M,   \
-                       model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist)
+    // fast path: row pairs with 16-B loads/stores; the odd last row (if any) goes through the scalar kernel
+    const bool vec_ok = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)dist & 15) == 0) && n >= 2;
+    const size_t npairs = vec_ok ? n / 2 : 0;
+    const size_t ntail = n - 2 * npairs;
+    size_t pblocks = (npairs + 255) / 256;
+    if (pblocks > 256 * 16) pblocks = 256 * 16;
+    blocks = (ntail + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define LAUNCH_PD(KCV)                                                                                                 \
+    do {                                                                                                               \
+        if (npairs)                                                                                                    \
+            hipLaunchKernelGGL(k_project_dist2<KCV>, dim3((unsigned)pblocks), dim3(256), 0, ctx->stream, X, npairs,    \
+                               ldx, (int)M, model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist);                 \
+        if (ntail)                                                                                                     \
+            hipLaunchKernelGGL(k_project_dist<KCV>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,                 \
+                               X + 2 * npairs, ntail, ldx, (int)M, model + ML.off_mean, model + ML.off_sd, Rpad, opad, \
+                               dist + 2 * npairs);                                                                     \
+    } while (0)
     switch (KC) {
         case 1: LAUNCH_PD(1); break;
         case 2: LAUNCH_PD(2); break;

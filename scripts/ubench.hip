@@ -121,6 +121,16 @@ int main() {
         printf("mfma_f64_16x16x4 nacc=%d: %.1f us -> %.1f ns per MFMA per SIMD (= %.0f cycles @2.4GHz), %.1f TFLOP/s\n", nacc,
                ms * 1e3, ms * 1e6 / nm, ms * 1e6 / nm * 2.4, nm * 1024 * 2048 / ms / 1e9);
     }
+    // MFMA rate vs waves per SIMD (independent accumulators, 6 per wave)
+    for (int wg : {256, 512, 1024, 2048}) {
+        const int iters = 1000;
+        auto f = [&] { hipLaunchKernelGGL(k_mfma_rate<6>, dim3(wg), dim3(256), 0, 0, iters, out); };
+        for (int i = 0; i < 2; i++) f();
+        hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        const double fl = (double)wg * 4 * iters * 6 * 2048;
+        printf("mfma_f64_16x16x4, %d waves/SIMD: %.1f us -> %.1f TFLOP/s\n", wg / 256, ms * 1e3, fl / ms / 1e9);
+    }
     for (int wg : {256, 512, 1024}) {   // 1, 2, 4 waves per SIMD
         const int iters = 4000;
         auto f = [&] { hipLaunchKernelGGL(k_fma_rate, dim3(wg), dim3(256), 0, 0, iters, out); };
