@@ -438,3 +438,37 @@ def test_wilcoxon_rule_reduces_somewhere(oracle):
         assert a <= b
         hit += a < b
     assert hit >= 1
+
+
+def test_generation_config3_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[2] size (N = 1e6, M = 32, P = 16, A = 8, K = K' = 1e5): invariants that do not need
+    the O(K K' P) oracle: sortedness, K-th order statistic, selection = oracle's given the device's own
+    distances, L2 norm, resample-count checksum, spot-checked weights on a few rows, bit reproducibility."""
+    from abcsmc_amd import device
+    N, M, P, K, Kp, Nn, A = 1_000_000, 32, 16, 100_000, 100_000, 1_000_000, 8
+    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    idx, dist = gen.idx.cpu().numpy(), gen.dist.cpu().numpy()
+    assert np.all(np.diff(dist) >= 0) and len(np.unique(idx)) == K
+    # full distance vector through the staged entry point, then the oracle's argsort on those exact values
+    from abcsmc_amd import abcutil
+    g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=N, max_comp=A, details=True, ctx=gpu_ctx)
+    full = np.empty(N)
+    full[g["idx"].astype(np.int64)] = g["dist"]
+    ref = oracle.ordered(full)[:K]
+    assert np.array_equal(idx.astype(np.uint64), ref)                       # bit-exact selection at full size
+    assert np.array_equal(dist, full[ref.astype(np.int64)])
+    w = gen.w.cpu().numpy()
+    assert np.all(w >= 0) and abs(np.linalg.norm(w) - 1.0) < 1e-10
+    # weights of a few selected particles against the oracle formula restricted to those rows
+    theta = Y[idx]
+    rows = np.array([0, 1, 777, K // 2, K - 1])
+    raw = oracle.weights_importance(oracle.make_priors(spec), theta[rows], prev[0], prev[1], prev[2])
+    ratio = (w[rows] / w[rows[0]]) / (raw / raw[0])                          # normalisation cancels in ratios
+    assert np.allclose(ratio, 1.0, rtol=1e-9)
+    parent = gen.parent.cpu().numpy()
+    assert np.bincount(parent, minlength=K).sum() == Nn and parent.max() < K
+    # the resampled parents are exactly the oracle's for the device's own weights
+    o = oracle.rng(67890)
+    assert np.array_equal(parent.astype(np.uint64), oracle.resample(o, w, Nn))
+    nxt = device.to_numpy(gen.next)
+    assert np.isfinite(nxt).all()
