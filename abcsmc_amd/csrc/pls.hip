@@ -87,6 +87,25 @@ __global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {     // wave-uniform broadcast, no LDS crossbar
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+    return u.d;
+}
+// trace of a matrix held as NB x NB blocks in the C/D layout: diagonal element 16 I + c sits in register c>>2 of
+// lane c + 16 (c & 3)
+template <int NB>
+__device__ __forceinline__ double trace_cd(const d4 (&D)[NB][NB]) {
+    double t = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; I++)
+#pragma unroll
+        for (int c = 0; c < 16; c++) t += readlane_f64(D[I][I][c >> 2], c + 16 * (c & 3));
+    return t;
+}
+
 // Dominant-eigenvector helper: repeated squaring of B = S / trace(S) (S symmetric PSD, n <= 16*NB)
 // entirely in registers with v_mfma_f64_16x16x4_f64.  A 16x16 block of a SYMMETRIC matrix held in
 // the MFMA C/D layout (lane l, reg r <-> [l&15][(l>>4) + 4r], using symmetry) is bit-for-bit the
@@ -94,9 +113,29 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //   C_IJ = sum_K sum_r mfma(D_IK[r], D_JK[r])        needs no data movement between squarings.
 // The error is squared every step once the spectral gap opens: "changed by < 1e-9", then one more.
 template <int NB>
-__device__ void eig_square(const double* __restrict__ S, int n, double tr, double* __restrict__ Bout) {
+__device__ double eig_square(const double* __restrict__ XY, int M, int n, double* __restrict__ S,
+                             double* __restrict__ Bout) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    // S = XY' XY straight into the C/D register layout with MFMA: block (I,J) = sum over 4-row slabs of
+    // mfma(a_J, a_I), a_I(lane) = XY[4s + q][16 I + c]  (zero beyond M rows / n columns)
     d4 D[NB][NB];
+#pragma unroll
+    for (int I = 0; I < NB; I++)
+#pragma unroll
+        for (int J = 0; J < NB; J++) D[I][J] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        double a[NB];
+#pragma unroll
+        for (int I = 0; I < NB; I++) {
+            const int m = m0 + q, col = 16 * I + c;
+            a[I] = (m < M && col < n) ? XY[m + M * col] : 0.0;
+        }
+#pragma unroll
+        for (int I = 0; I < NB; I++)
+#pragma unroll
+            for (int J = 0; J < NB; J++) D[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], a[I], D[I][J], 0, 0, 0);
+    }
+    const double tr = trace_cd<NB>(D);
 #pragma unroll
     for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -104,58 +143,45 @@ __device__ void eig_square(const double* __restrict__ S, int n, double tr, doubl
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = 16 * I + c, j = 16 * J + q + 4 * r;
-                D[I][J][r] = (i < n && j < n) ? S[i + n * j] / tr : 0.0;
+                if (i < n && j < n) S[i + n * j] = D[I][J][r];          // kept in LDS for the power step
+                D[I][J][r] = (tr > 0.0) ? D[I][J][r] / tr : ((i == 0 && j == 0) ? 1.0 : 0.0);
             }
-    // Groups of 4 un-normalised squarings (trace 1 -> entries >= n^-16, no underflow), then ONE
-    // trace normalisation + convergence check per group (the cross-lane reductions dominate).
-    bool last = false;
-    for (int grp = 0; grp < 16; grp++) {
-        d4 Dn[NB][NB];
-#pragma unroll
-        for (int I = 0; I < NB; I++)
-#pragma unroll
-            for (int J = 0; J < NB; J++) Dn[I][J] = D[I][J];
+    // Groups of 3 un-normalised squarings of the trace-1 matrix (B -> B^8, entries >= n^-8), then one trace
+    // normalisation.  With eigenvalues lambda_i (sum 1), t = trace(B^8) = sum lambda_i^8.  t > 0.95 forces
+    // lambda_1 > 0.9936, i.e. every other eigenvalue of the group's INPUT was < 6.4e-3 of it, so its OUTPUT has
+    // them below (6.4e-3)^8 = 3e-18: converged to rounding, stop.
+    for (int grp = 0; grp < 24; grp++) {
 #pragma unroll 1
-        for (int sq = 0; sq < 4; sq++) {
+        for (int sq = 0; sq < 3; sq++) {
             d4 T[NB][NB];
 #pragma unroll
             for (int I = 0; I < NB; I++)
 #pragma unroll
                 for (int J = 0; J < NB; J++) {
-                    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                    d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int K = 0; K < NB; K++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++)   // operands (J,K),(I,K): MFMA output row/col map gives block (I,J)
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dn[J][K][r], Dn[I][K][r], acc, 0, 0, 0);
-                    T[I][J] = acc;
+                    for (int K = 0; K < NB; K++) {   // operands (J,K),(I,K): the MFMA output row/col map gives block (I,J)
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[J][K][0], D[I][K][0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[J][K][1], D[I][K][1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[J][K][2], D[I][K][2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[J][K][3], D[I][K][3], acc1, 0, 0, 0);
+                    }
+                    T[I][J] = acc0 + acc1;
                 }
 #pragma unroll
             for (int I = 0; I < NB; I++)
 #pragma unroll
-                for (int J = 0; J < NB; J++) Dn[I][J] = T[I][J];
+                for (int J = 0; J < NB; J++) D[I][J] = T[I][J];
         }
-        double t = 0.0;
-#pragma unroll
-        for (int I = 0; I < NB; I++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) t += (q + 4 * r == c) ? Dn[I][I][r] : 0.0;
-        t = wave_sum(t);
+        const double t = trace_cd<NB>(D);
         const double inv = 1.0 / t;
-        double diff = 0.0;
 #pragma unroll
         for (int I = 0; I < NB; I++)
 #pragma unroll
             for (int J = 0; J < NB; J++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double v = Dn[I][J][r] * inv;
-                    diff = fmax(diff, fabs(v - D[I][J][r]));
-                    D[I][J][r] = v;
-                }
-        diff = wave_max(diff);
-        if (last) break;
-        if (diff < 1e-7) last = true;
+                for (int r = 0; r < 4; r++) D[I][J][r] *= inv;
+        if (t > 0.95) break;
     }
 #pragma unroll
     for (int I = 0; I < NB; I++)
@@ -166,13 +192,22 @@ __device__ void eig_square(const double* __restrict__ S, int n, double tr, doubl
                 const int i = 16 * I + c, j = 16 * J + q + 4 * r;
                 if (i < n && j < n) Bout[i + n * j] = D[I][J][r];
             }
+    return tr;
 }
 
 // ONE wavefront.  LDS: XY (M*P), S and V (np*np each), vectors.
 __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
                                                 int M, int P, int A, double* __restrict__ model,
-                                                double* __restrict__ scratch /* A*M + A*A + P*A */) {
+                                                double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds) {
     extern __shared__ double lds[];
+#ifdef PLS_STAMPS
+    long long st_last = __builtin_readcyclecounter();
+    double* st_out = scratch + (size_t)A * M + (size_t)A * A + (size_t)P * A;     // 16 doubles of diagnostics
+    if (threadIdx.x < 16) st_out[threadIdx.x] = 0.0;
+#define STAMP(id) do { const long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) st_out[id] += (double)(now_ - st_last); st_last = now_; } while (0)
+#else
+#define STAMP(id)
+#endif
     const ModelLayout ML = model_layout(M, P, A);
     const ZLayout Z = z_layout(M, P);
     const int lane = threadIdx.x;
@@ -187,8 +222,13 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     double* xr = pv + M;                // M
     double* Pl = xr + M;                // M*A: loadings P (LDS copy, read by the deflation of later components)
     double* Rl = Pl + (size_t)M * A;    // M*A: rotations R
+    double* XXl = Rl + (size_t)M * A;   // M*M copy of X'X (training) when it fits (xx_in_lds)
 
     const double* XXtr = zwork + Z.off_XX[0];
+    if (xx_in_lds) {
+        for (int e = lane; e < M * M; e += 64) XXl[e] = XXtr[e];
+        XXtr = XXl;
+    }
     double* Rm = model + ML.off_R;
     double* Qm = model + ML.off_Q;
     double* Wm = model + ML.off_W;
@@ -197,34 +237,23 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     for (int e = lane; e < M * P; e += 64) XY[e] = zwork[Z.off_XY[0] + e];
     __syncthreads();
 
+    STAMP(9);
     for (int comp = 0; comp < A; comp++) {
         if (P == 1) {
             for (int m = lane; m < M; m += 64) wv[m] = XY[m];
         } else {
-            // S = XY' XY (symmetric PSD, P x P)
+            // S = XY' XY (symmetric PSD, P x P) and its dominant eigenvector: MFMA cross-product into registers,
+            // repeated squaring there (eig_square), one power step with S itself.  (The oracle uses a full
+            // Jacobi eigen-solve; both deliver the dominant eigenvector of the same symmetric matrix.)
             const int n = P;
-            for (int e = lane; e < n * n; e += 64) {
-                const int a = e % n, b = e / n;
-                double s = 0.0;
-                for (int m = 0; m < M; m++) s = fma(XY[m + M * a], XY[m + M * b], s);
-                S[e] = s;
-            }
-            __syncthreads();
-            // dominant eigenvector of S: repeated squaring in registers (eig_square), then two
-            // power steps with S itself.  (The oracle uses a full Jacobi eigen-solve; both deliver
-            // the dominant eigenvector of the same symmetric matrix.)
-            double tr = 0.0;
-            for (int i = lane; i < n; i += 64) tr += S[i + n * i];
-            tr = wave_sum(tr);
             double* Bc = V;
-            if (tr > 0.0) {
-                if (n <= 16) eig_square<1>(S, n, tr, Bc);
-                else if (n <= 32) eig_square<2>(S, n, tr, Bc);
-                else eig_square<4>(S, n, tr, Bc);
-            } else {
-                for (int e = lane; e < n * n; e += 64) Bc[e] = (e == 0) ? 1.0 : 0.0;
-            }
+            STAMP(1);
+            double tr;
+            if (n <= 16) tr = eig_square<1>(XY, M, n, S, Bc);
+            else if (n <= 32) tr = eig_square<2>(XY, M, n, S, Bc);
+            else tr = eig_square<4>(XY, M, n, S, Bc);
             __syncthreads();
+            STAMP(2);
             // column of the converged power with the largest diagonal entry (wave arg-max, ties -> lowest index)
             double dg = (lane < n) ? Bc[lane + n * lane] : -1.0;
             int bi = lane;
@@ -264,11 +293,12 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             __syncthreads();
             for (int m = lane; m < M; m += 64) {
                 double s = 0.0;
-                for (int j = 0; j < P; j++) s = fma(XY[m + M * j], qv[j], s);
+                _Pragma("unroll 8") for (int j = 0; j < P; j++) s = fma(XY[m + M * j], qv[j], s);
                 wv[m] = s;
             }
         }
         __syncthreads();
+        STAMP(3);
         double ww = 0.0;
         for (int m = lane; m < M; m += 64) ww = fma(wv[m], wv[m], ww);
         ww = sqrt(wave_sum(ww));
@@ -281,11 +311,12 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             for (int m = lane; m < M; m += 64) rv[m] -= pw * Rl[m + (size_t)M * j];
         }
         __syncthreads();
+        STAMP(4);
         // type 2: xr = XX r ; tt = r' xr ; p = xr / tt
         double tt = 0.0;
         for (int a = lane; a < M; a += 64) {
             double s = 0.0;
-            for (int b = 0; b < M; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
+            _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
             xr[a] = s;
             tt = fma(rv[a], s, tt);
         }
@@ -300,9 +331,10 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             Rl[m + (size_t)M * comp] = rv[m];
         }
         __syncthreads();
+        STAMP(5);
         for (int j = lane; j < P; j += 64) {
             double s = 0.0;
-            for (int m = 0; m < M; m++) s = fma(XY[m + M * j], rv[m], s);
+            _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(XY[m + M * j], rv[m], s);
             s /= tt;
             qv[j] = s;
             Qm[j + (size_t)P * comp] = s;
@@ -314,8 +346,10 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
         }
         __threadfence_block();
         __syncthreads();
+        STAMP(6);
     }
 
+    STAMP(7);
     // ---- PRESS on the validation statistics -------------------------------------------------
     // c_jk = r_k' XYte[:,j]; v_k = XXte r_k; H_kl = r_k' v_l;
     // PRESS_j(a) = YY_jj - 2 sum_{k<a} q_jk c_jk + sum_{k,l<a} q_jk q_jl H_kl
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     for (int e = lane; e < A * M; e += 64) {
         const int m = e % M, k = e / M;
         double s = 0.0;
-        for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
+        _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
         vk[e] = s;
     }
     __threadfence_block();
@@ -336,13 +370,13 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     for (int e = lane; e < A * A; e += 64) {
         const int k = e % A, l = e / A;
         double s = 0.0;
-        for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], vk[m + (size_t)M * l], s);
+        _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], vk[m + (size_t)M * l], s);
         H[e] = s;
     }
     for (int e = lane; e < P * A; e += 64) {
         const int j = e % P, k = e / P;
         double s = 0.0;
-        for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
+        _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
         cm[e] = s;
     }
     __threadfence_block();
@@ -356,7 +390,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             lin = fma(qa, cm[j + (size_t)P * a], lin);
             // add row/column a of the quadratic form
             double add = 0.0;
-            for (int l = 0; l < a; l++) add = fma(Qm[j + (size_t)P * l], H[a + (size_t)A * l], add);
+            _Pragma("unroll 8") for (int l = 0; l < a; l++) add = fma(Qm[j + (size_t)P * l], H[a + (size_t)A * l], add);
             quad += 2.0 * qa * add + qa * qa * H[a + (size_t)A * a];
             const double pr = YYte[j] - 2.0 * lin + quad;
             press[a + (size_t)A * j] = pr;
@@ -366,6 +400,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     }
     __threadfence_block();
     __syncthreads();
+    STAMP(8);
     // ncomp = max over responses; observed z-scores and scores (m-ascending fma chain per component)
     int ncomp = 1;
     for (int j = 0; j < P; j++) { const int v = (int)model[ML.off_per + j]; if (v > ncomp) ncomp = v; }
@@ -378,7 +413,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     __syncthreads();
     for (int k = lane; k < A; k += 64) {
         double s = 0.0;
-        for (int m = 0; m < M; m++) s = fma(model[ML.off_zobs + m], Rm[m + (size_t)M * k], s);
+        _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(model[ML.off_zobs + m], Rm[m + (size_t)M * k], s);
         model[ML.off_oscore + k] = s;
     }
 }
@@ -395,6 +430,10 @@ __global__ __launch_bounds__(64) void k_simple_obs(const double* __restrict__ ob
 
 }  // namespace
 
+#ifdef PLS_STAMPS
+static double g_pls_stamps[16];
+#endif
+
 int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
                      double* model) {
     if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M+P = %zu > 160", M + P);
@@ -402,21 +441,30 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
     double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
-    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A) * sizeof(double));
+    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A + 16) * sizeof(double));
     if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
     hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
-    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + 8;
+    const int xx_in_lds = M <= 64;
+    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8;
     const size_t lds_bytes = lds_d * sizeof(double);
     if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(k_pls_fit, dim3(1), dim3(64), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                       scratch);
+                       scratch, xx_in_lds);
     ABC_HIP(ctx, hipGetLastError());
+#ifdef PLS_STAMPS
+    ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + P * A, 16 * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#endif
     (void)rule;
     return ABC_OK;
 }
+#ifdef PLS_STAMPS
+extern "C" void abc_debug_pls_stamps(double* out16) { for (int i = 0; i < 16; i++) out16[i] = g_pls_stamps[i]; }
+#endif
 
 int launch_simple_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, double* model) {
     if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "simple: M+P = %zu > 160", M + P);

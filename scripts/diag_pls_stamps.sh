@@ -1,0 +1,24 @@
+#!/bin/bash
+# Diagnostic (not the product): rebuild the library with -DPLS_STAMPS in a scratch dir and print where k_pls_fit
+# spends its cycles (phase ids in abcsmc_amd/csrc/pls.hip).  Run on the GPU box from the repo root.
+set -e
+D=/tmp/abc_stamps; rm -rf $D; mkdir -p $D; cp -r abcsmc_amd include scripts $D/; cd $D/abcsmc_amd/csrc
+make clean >/dev/null; make -j8 HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -DPLS_STAMPS" >/dev/null 2>&1
+cd $D; python3 - <<'PY'
+import sys, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np, torch
+from abcsmc_amd import _lib, device, synthetic, sharded
+L = _lib.lib(); dev = "cuda:0"; ctx = _lib.default_context(0); be = sharded.HipBackend(dev, ctx)
+for (M, P, A) in [(32, 16, 8), (32, 16, 1), (64, 32, 8)]:
+    wl = synthetic.Workload(M, P); X, Y = wl.rows(0, 20000)
+    dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(wl.observed(), dev)
+    stats = be.zeros(be.stats_len(M, P)); model = be.empty(be.model_len(M, P, A))
+    be.stats_shift(dX, dY, stats); be.stats_accumulate(dX, dY, 0, 10000, stats)
+    for _ in range(3): be.pls_model(stats, dobs, M, P, A, 0, model)
+    out = (C.c_double * 16)(); C.CDLL(_lib.SO_PATH).abc_debug_pls_stamps(out)
+    names = {9: "prologue", 1: "S=XY'XY", 2: "eig squaring", 3: "eigvec post + w", 4: "normalise w, r-update", 5: "XX r, p",
+             6: "q, deflate", 7: "(loop exit)", 8: "PRESS", 0: ""}
+    tot = sum(out)
+    print("M=%d P=%d A=%d total %.0f kcycles" % (M, P, A, tot / 1e3), {names.get(i, i): round(out[i] / 1e3, 1) for i in range(10) if out[i]})
+PY
