@@ -154,6 +154,10 @@ int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t
 int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, size_t P,
                        const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt);
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
+// K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor
+int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);
+int launch_dv_from_stats(abc_ctx*, const double* stats, size_t P, double* dv);
+int launch_mvn_from_stats(abc_ctx*, const double* stats, size_t P, double* L, int* status_dev);
 int launch_weights_raw(abc_ctx*, const abc_prior* priors, const double* theta, size_t K, size_t P,
                        size_t k0, size_t kn, const double* theta_prev, size_t Kp,
                        const double* w_prev, const double* dv_prev, double* w_raw);

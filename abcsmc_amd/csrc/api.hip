@@ -335,7 +335,14 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (!theta) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
     ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K));
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
-    ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
+    double* theta_stats = nullptr;        // moments of the posterior: shared by dv and the MVN factor
+    if (P <= 64 && K >= 2) {
+        StageTimer tm(ctx, ST_GATHER_DV);
+        ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats));
+        ABC_TRY(launch_dv_from_stats(ctx, theta_stats, P, dv));
+    } else {
+        ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
+    }
     if (Kp == 0 || !io->theta_prev) {
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
     } else {
@@ -351,7 +358,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         double* L = nullptr;
         if (cfg->multivariate) {
             L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
-            ABC_TRY(launch_mvn_setup(ctx, theta, K, P, L, nullptr, spd_dev));
+            if (theta_stats) {
+                StageTimer tm(ctx, ST_MVN);
+                ABC_TRY(launch_mvn_from_stats(ctx, theta_stats, P, L, spd_dev));
+            } else {
+                ABC_TRY(launch_mvn_setup(ctx, theta, K, P, L, nullptr, spd_dev));
+            }
             have_spd = true;
         }
         ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent));   // contains the alias-table host round trip

@@ -44,24 +44,56 @@ __global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stat
     if (lane == 0) *status = ok ? 0 : -1;
 }
 
+// dv_p = 2 * Var_p (n-1 denominator) from the same statistics record (AbcUtil.cpp:528-537)
+__global__ void k_dv_from_stats(const double* __restrict__ stats, int P, double* __restrict__ dv) {
+    const StatsLayout SL = stats_layout(P, 0);
+    const int p = threadIdx.x;
+    if (p >= P) return;
+    const double n = stats[SL.off_n] + stats[SL.off_n + 1];
+    const double d = (stats[SL.off_sum[0] + p] + stats[SL.off_sum[1] + p]) / n;
+    double ss = stats[SL.off_G[0] + p + SL.C16 * p] + stats[SL.off_G[1] + p + SL.C16 * p] - n * d * d;
+    if (ss < 0.0) ss = 0.0;
+    dv[p] = (n > 1.0) ? 2.0 * (ss / (n - 1.0)) : 0.0;
+}
+
 }  // namespace
 
-int launch_mvn_setup(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L, int* status_host,
-                     int* status_dev) {
-    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "mvn: P = %zu > 64", P);
-    if (K < 2) ABC_FAIL(ctx, ABC_ERR_INVALID, "mvn: need at least 2 particles (K=%zu)", K);
+// one pass over the K x P posterior: pilot shift + Gram (k_gram<.,0>) -> statistics record in the arena
+int launch_theta_stats(abc_ctx* ctx, const double* theta, size_t K, size_t P, double** stats_out) {
     const StatsLayout SL = stats_layout(P, 0);
     double* stats = (double*)abc_ws_alloc(ctx, SL.len * sizeof(double));
-    int* status = status_dev ? status_dev : (int*)abc_ws_alloc(ctx, sizeof(int));
-    if (!stats || !status) ABC_FAIL(ctx, ABC_ERR_NOMEM, "mvn: workspace exhausted");
-    StageTimer tm(ctx, ST_MVN);
+    if (!stats) ABC_FAIL(ctx, ABC_ERR_NOMEM, "theta stats: workspace exhausted");
     ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
     ctx->in_mvn = true;
     const int rc_acc = launch_stats_accumulate(ctx, theta, theta, K, K, K, P, 0, 0, K, stats);
     ctx->in_mvn = false;
     ABC_TRY(rc_acc);
-    hipLaunchKernelGGL(k_cov_chol, dim3(1), dim3(64), P * P * sizeof(double), ctx->stream, stats, (int)P, L, status);
+    *stats_out = stats;
+    return ABC_OK;
+}
+
+int launch_dv_from_stats(abc_ctx* ctx, const double* stats, size_t P, double* dv) {
+    hipLaunchKernelGGL(k_dv_from_stats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)P, dv);
     ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_mvn_from_stats(abc_ctx* ctx, const double* stats, size_t P, double* L, int* status_dev) {
+    hipLaunchKernelGGL(k_cov_chol, dim3(1), dim3(64), P * P * sizeof(double), ctx->stream, stats, (int)P, L, status_dev);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+int launch_mvn_setup(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L, int* status_host,
+                     int* status_dev) {
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "mvn: P = %zu > 64", P);
+    if (K < 2) ABC_FAIL(ctx, ABC_ERR_INVALID, "mvn: need at least 2 particles (K=%zu)", K);
+    int* status = status_dev ? status_dev : (int*)abc_ws_alloc(ctx, sizeof(int));
+    if (!status) ABC_FAIL(ctx, ABC_ERR_NOMEM, "mvn: workspace exhausted");
+    StageTimer tm(ctx, ST_MVN);
+    double* stats = nullptr;
+    ABC_TRY(launch_theta_stats(ctx, theta, K, P, &stats));
+    ABC_TRY(launch_mvn_from_stats(ctx, stats, P, L, status));
     if (status_host) {
         ABC_HIP(ctx, hipMemcpyAsync(status_host, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -44,9 +44,21 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ dis
     const unsigned long long prefix = st->prefix, mask = st->mask;
     const unsigned int dm = (1u << nbits) - 1u;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const unsigned long long k = key_of(dist[i]);
-        if ((k & mask) == prefix) atomicAdd(&lh[(unsigned int)(k >> shift) & dm], 1u);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const size_t nround = (n + stride - 1) / stride;      // uniform trip count: the ballots need every lane
+    for (size_t it = 0; it < nround; it++) {
+        const size_t i = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const unsigned long long k = (i < n) ? key_of(dist[i]) : 0ull;
+        const bool in = (i < n) && ((k & mask) == prefix);
+        const unsigned int d = (unsigned int)(k >> shift) & dm;
+        // distances cluster in a few digits: aggregate equal digits inside the wave, one LDS add per group
+        unsigned long long peers = __ballot(in);
+        for (int b = 0; b < nbits; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        if (in && (peers & lt_mask) == 0) atomicAdd(&lh[d], (unsigned int)__popcll(peers));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SEL_BINS; i += 256) {
@@ -278,23 +290,40 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned long long* 
     }
 }
 
-// exclusive scan of the digit-major [256][nb] block histogram, one work-group
-__global__ __launch_bounds__(256) void k_sort_scan(unsigned int* __restrict__ bh, int nb) {
+// exclusive scan of the digit-major [256][nb] block histogram, one work-group of 1024 threads:
+// 4 threads per digit, each owning a quarter of the blocks
+__global__ __launch_bounds__(1024) void k_sort_scan(unsigned int* __restrict__ bh, int nb) {
+    __shared__ unsigned int part[4][256];
     __shared__ unsigned int tot[256];
-    const int t = threadIdx.x;
+    const int d = threadIdx.x & 255, p = threadIdx.x >> 8;
+    const int b0 = (int)((long long)nb * p / 4), b1 = (int)((long long)nb * (p + 1) / 4);
     unsigned int s = 0;
-    for (int b = 0; b < nb; b++) s += bh[(size_t)t * nb + b];
-    tot[t] = s;
+#pragma unroll 4
+    for (int b = b0; b < b1; b++) s += bh[(size_t)d * nb + b];
+    part[p][d] = s;
     __syncthreads();
-    if (t == 0) {
-        unsigned int run = 0;
-        for (int d = 0; d < 256; d++) { const unsigned int v = tot[d]; tot[d] = run; run += v; }
+    if (threadIdx.x < 64) {       // exclusive scan of the 256 digit totals: 4 per lane + wave scan
+        const int lane = threadIdx.x;
+        unsigned int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int dd = 4 * lane + q;
+            v[q] = part[0][dd] + part[1][dd] + part[2][dd] + part[3][dd];
+            sum += v[q];
+        }
+        unsigned int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int a = __shfl_up(inc, o, 64); if (lane >= o) inc += a; }
+        unsigned int run = inc - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { tot[4 * lane + q] = run; run += v[q]; }
     }
     __syncthreads();
-    unsigned int run = tot[t];
-    for (int b = 0; b < nb; b++) {
-        const unsigned int v = bh[(size_t)t * nb + b];
-        bh[(size_t)t * nb + b] = run;
+    unsigned int run = tot[d];
+    for (int q = 0; q < p; q++) run += part[q][d];
+    for (int b = b0; b < b1; b++) {
+        const unsigned int v = bh[(size_t)d * nb + b];
+        bh[(size_t)d * nb + b] = run;
         run += v;
     }
 }
@@ -311,7 +340,7 @@ int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* i
     for (int pass = byte_lo; pass < byte_hi; pass++) {   // an even number of passes ends in (key0, idx0)
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, ctx->stream, ka, n, shift, bh, nb);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(256), 0, ctx->stream, bh, nb);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ctx->stream, bh, nb);
         hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, ctx->stream, ka, ia, n, shift, bh, nb, kb, ib);
         unsigned long long* tk = ka; ka = kb; kb = tk;
         unsigned long long* ti = ia; ia = ib; ib = ti;
@@ -352,7 +381,7 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
         if (!st || !hist || !cnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
         hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, st, (unsigned long long)K, hist);
         size_t hb = (n + 255) / 256;
-        if (hb > 2048) hb = 2048;
+        if (hb > 512) hb = 512;      // every block flushes up to 2048 bins with global atomics: keep the count low
         static const int shifts[6] = {53, 42, 31, 20, 9, 0};
         static const int widths[6] = {11, 11, 11, 11, 11, 9};
         for (int p = 0; p < 6; p++) {

@@ -220,9 +220,14 @@ int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy
 int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
     if (!P) return ABC_OK;
     StageTimer tm(ctx, ST_GATHER_DV);
-    hipLaunchKernelGGL(k_doubled_variance, dim3((unsigned)P), dim3(256), 0, ctx->stream, theta, K, dv);
-    ABC_HIP(ctx, hipGetLastError());
-    return ABC_OK;
+    if (P > 64 || K < 2) {       // outside the Gram path: direct two-pass kernel, one work-group per parameter
+        hipLaunchKernelGGL(k_doubled_variance, dim3((unsigned)P), dim3(256), 0, ctx->stream, theta, K, dv);
+        ABC_HIP(ctx, hipGetLastError());
+        return ABC_OK;
+    }
+    double* stats = nullptr;
+    ABC_TRY(launch_theta_stats(ctx, theta, K, P, &stats));
+    return launch_dv_from_stats(ctx, stats, P, dv);
 }
 
 int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P, size_t k0,
