@@ -5,7 +5,9 @@ on synthetic particle x (parameter | metric) matrices, with the inputs resident 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 A "step" is one generation: abc_generation_dev on one GPU, or the row-sharded driver
-(abcsmc_amd/sharded.py, RCCL collectives) on N GPUs with the per-GPU particle count fixed (weak).
+(abcsmc_amd/sharded.py, RCCL collectives) on N GPUs with the per-GPU particle count fixed (weak scaling:
+the current set has N x n_local particles and K = 0.1 N x n_local retained; the previous set's posterior keeps
+the single-GPU size, so the O(K K'/N_gpus) weight work per GPU stays fixed as well).
 Prints ONE JSON line on rank 0 carrying the driver contract plus `roofline` (the dominant HBM kernel,
 k_gram: algorithmic bytes / HIP-event time measured live in this run) and `cpu_baseline` (the
 single-threaded CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only).
@@ -67,8 +69,9 @@ def main():
     cfg = CONFIGS[args.config]
     n_loc, M, P, A = cfg["N"], cfg["M"], cfg["P"], cfg["A"]
     N = n_loc * world
-    K = N // 10
-    Kp = K
+    K = N // 10                   # predictive-prior fraction 0.1 of the (sharded) current set
+    Kp = n_loc // 10              # previous predictive prior: the single-GPU set's (AbcSmc sets may grow between
+                                  # generations, reference.json num_samples); keeps the O(K K'/G) weight work per GPU fixed
     nn_loc = n_loc
 
     # ---- synthetic inputs, generated on the host once, then resident in HBM ---------------------------
