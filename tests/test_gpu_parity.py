@@ -472,3 +472,35 @@ def test_generation_config3_size_properties(gpu_ctx, oracle):
     assert np.array_equal(parent.astype(np.uint64), oracle.resample(o, w, Nn))
     nxt = device.to_numpy(gen.next)
     assert np.isfinite(nxt).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# degenerate sizes: must neither hang nor fault, and agree with the oracle where the oracle is finite
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,M,P", [(2, 1, 1), (3, 1, 1), (5, 2, 1), (4, 3, 2), (17, 1, 3), (64, 5, 5), (129, 16, 16)])
+def test_ranking_tiny_sets(gpu_ctx, oracle, N, M, P):
+    from abcsmc_amd import abcutil
+    rng = np.random.default_rng(N * 100 + M * 10 + P)
+    Y = np.asfortranarray(rng.normal(size=(N, P)))
+    X = np.asfortranarray(Y[:, :1] @ rng.normal(size=(1, M)) + 0.1 * rng.normal(size=(N, M)))
+    obs = X[0] * 0.9
+    A = min(M, P)
+    g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, details=True, ctx=gpu_ctx)
+    o = oracle.particle_ranking_pls(X, Y, obs, 0.5, 0)
+    assert sorted(g["idx"].tolist()) == list(range(N))
+    if np.isfinite(o["dist"]).all() and np.isfinite(g["dist"]).all():
+        assert g["ncomp"] == o["ncomp"]
+        assert np.allclose(g["dist"], o["dist"][g["idx"].astype(int)], rtol=1e-6, atol=1e-12)
+    s = abcutil.particle_ranking_simple(X, Y, obs, details=True, ctx=gpu_ctx)
+    oi, od = oracle.particle_ranking_simple(X, obs)
+    assert np.allclose(s["dist"], od[s["idx"].astype(int)], rtol=1e-9, atol=1e-12)
+
+
+def test_generation_tiny(gpu_ctx, oracle):
+    N, M, P, K, Kp, Nn, A = 40, 3, 2, 10, 8, 25, 2
+    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    o = oracle.rng(67890)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A)
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
+    assert np.array_equal(gen.parent.cpu().numpy()[:Nn].astype(np.uint64), ref["parent"])
