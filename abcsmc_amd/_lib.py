@@ -83,6 +83,11 @@ SIGNATURES = {
     "abc_simple_model_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "abc_project_distance_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _i, _vp]),
     "abc_select_smallest_dev": (_i, [_vp, _vp, _sz, _sz, _u64, _vp, _vp]),
+    "abc_select_begin_dev": (_i, [_vp, _u64, _vp, _vp]),
+    "abc_select_hist_dev": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
+    "abc_select_pick_dev": (_i, [_vp, _vp, _i, _vp, _u64]),
+    "abc_select_count_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "abc_select_compact_dev": (_i, [_vp, _vp, _sz, _vp, _u64, _u64, _u64, _vp, _vp]),
     "abc_sort_pairs_dev": (_i, [_vp, _vp, _vp, _sz]),
     "abc_gather_rows_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _sz, _u64, _vp, _sz]),
     "abc_doubled_variance_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),

@@ -146,6 +146,13 @@ int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, siz
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
+// distributed radix select stages (state: 8 x int64, hist: 2048 x int32, all-reduced by the caller between hist and pick)
+int launch_select_begin(abc_ctx*, uint64_t K, long long* state, int* hist);
+int launch_select_hist(abc_ctx*, const double* dist, size_t n, const long long* state, int pass, int* hist);
+int launch_select_pick(abc_ctx*, long long* state, int pass, int* hist, uint64_t K);
+int launch_select_count(abc_ctx*, const double* dist, size_t n, const long long* state, long long* counts);
+int launch_select_compact(abc_ctx*, const double* dist, size_t n, const long long* state, uint64_t n_less,
+                          uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out);
 int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
                        unsigned long long* val1, size_t n, int byte_lo, int byte_hi);
 // Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n)

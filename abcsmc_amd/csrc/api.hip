@@ -234,6 +234,31 @@ extern "C" int abc_select_smallest_dev(abc_ctx* ctx, const double* dist, size_t 
     return launch_select_smallest(ctx, dist, n, K, idx_base, idx, dist_out);
 }
 
+extern "C" int abc_select_begin_dev(abc_ctx* ctx, uint64_t K, int64_t* state, int32_t* hist) {
+    CHECK_CTX(ctx);
+    return launch_select_begin(ctx, K, (long long*)state, (int*)hist);
+}
+extern "C" int abc_select_hist_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, int pass,
+                                   int32_t* hist) {
+    CHECK_CTX(ctx);
+    return launch_select_hist(ctx, dist, n, (const long long*)state, pass, (int*)hist);
+}
+extern "C" int abc_select_pick_dev(abc_ctx* ctx, int64_t* state, int pass, int32_t* hist, uint64_t K) {
+    CHECK_CTX(ctx);
+    return launch_select_pick(ctx, (long long*)state, pass, (int*)hist, K);
+}
+extern "C" int abc_select_count_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, int64_t* counts) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, 0, 0, 0)));
+    return launch_select_count(ctx, dist, n, (const long long*)state, (long long*)counts);
+}
+extern "C" int abc_select_compact_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, uint64_t n_less,
+                                      uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out) {
+    CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, n_less + ties_take, 0, 0)));
+    return launch_select_compact(ctx, dist, n, (const long long*)state, n_less, ties_take, idx_base, idx_out, dist_out);
+}
+
 extern "C" int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size_t n) {
     CHECK_CTX(ctx);
     ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, n, 0, 0)));

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void k_cp_count(const double* __restrict__ dis
 }
 
 // exclusive scan of m unsigned counters in place, one work-group (sequential over 256-wide slabs)
-__global__ __launch_bounds__(256) void k_scan_u32(unsigned int* __restrict__ a, int m0, int m1) {
+__global__ __launch_bounds__(256) void k_scan_u32(unsigned int* __restrict__ a, int m0, int m1,
+                                                  unsigned long long* __restrict__ totals = nullptr) {
     __shared__ unsigned int s[256];
     __shared__ unsigned int carry;
     for (int seg = 0; seg < 2; seg++) {
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(256) void k_scan_u32(unsigned int* __restrict__ a, 
             if (threadIdx.x == 255) carry = c + incl;
             __syncthreads();
         }
+        if (totals && threadIdx.x == 0) totals[seg] = carry;
+        __syncthreads();
     }
 }
 
@@ -169,9 +172,11 @@ __global__ __launch_bounds__(256) void k_cp_write(const double* __restrict__ dis
                                                   const unsigned int* __restrict__ off /* [2][nb] scanned */,
                                                   int nb, unsigned long long idx_base,
                                                   unsigned long long* __restrict__ okey,
-                                                  unsigned long long* __restrict__ oidx) {
+                                                  unsigned long long* __restrict__ oidx,
+                                                  const unsigned long long* __restrict__ lim = nullptr) {
     __shared__ unsigned int wl[4], we[4];
-    const unsigned long long T = st->prefix, n_less = st->n_less, ties = st->ties;
+    // lim (distributed select): {local count of keys below the threshold, ties this shard may take}
+    const unsigned long long T = st->prefix, n_less = lim ? lim[0] : st->n_less, ties = lim ? lim[1] : st->ties;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t base = (size_t)blockIdx.x * CP_CHUNK + (size_t)t * CP_ITEMS;
     unsigned long long k[CP_ITEMS];
@@ -359,6 +364,69 @@ int abc_sort_u64_bytes(abc_ctx* ctx, unsigned long long* key0, unsigned long lon
     return sort_pairs_u64(ctx, key0, val0, key1, val1, n, byte_lo, byte_hi);
 }
 
+// ---- distributed radix select (sharded driver): the histogram of every pass is all-reduced between
+// launch_select_hist and launch_select_pick, so all shards walk to the same global K-th key ----------------
+static const int kSelShift[6] = {53, 42, 31, 20, 9, 0};
+static const int kSelWidth[6] = {11, 11, 11, 11, 11, 9};
+
+int launch_select_begin(abc_ctx* ctx, uint64_t K, long long* state, int* hist) {
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, (SelState*)state, (unsigned long long)K,
+                       (unsigned int*)hist);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+int launch_select_hist(abc_ctx* ctx, const double* dist, size_t n, const long long* state, int pass, int* hist) {
+    if (pass < 0 || pass > 5) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: pass %d", pass);
+    if (n == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_SELECT);
+    size_t hb = (n + 255) / 256;
+    if (hb > 512) hb = 512;
+    hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)hb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state,
+                       kSelShift[pass], kSelWidth[pass], (unsigned int*)hist);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+int launch_select_pick(abc_ctx* ctx, long long* state, int pass, int* hist, uint64_t K) {
+    if (pass < 0 || pass > 5) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: pass %d", pass);
+    StageTimer tm(ctx, ST_SELECT);
+    hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, (SelState*)state, kSelShift[pass], kSelWidth[pass],
+                       (unsigned int*)hist, (int)(pass == 5), (unsigned long long)K);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+// counts[0] = local #keys below the global threshold, counts[1] = local #keys equal to it
+int launch_select_count(abc_ctx* ctx, const double* dist, size_t n, const long long* state, long long* counts) {
+    StageTimer tm(ctx, ST_SELECT);
+    const int nb = (int)((n + CP_CHUNK - 1) / CP_CHUNK);
+    unsigned int* cnt = (unsigned int*)abc_ws_alloc(ctx, (size_t)2 * (nb + 1) * sizeof(unsigned int));
+    if (!cnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
+    if (nb) hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, (unsigned long long*)counts);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+// local winners in particle-index order: the n_less keys below the threshold, then the first ties_take ties
+int launch_select_compact(abc_ctx* ctx, const double* dist, size_t n, const long long* state, uint64_t n_less,
+                          uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out) {
+    StageTimer tm(ctx, ST_SELECT);
+    const size_t nw = n_less + ties_take;
+    if (nw == 0 || n == 0) return ABC_OK;
+    const int nb = (int)((n + CP_CHUNK - 1) / CP_CHUNK);
+    unsigned int* cnt = (unsigned int*)abc_ws_alloc(ctx, (size_t)2 * nb * sizeof(unsigned int));
+    unsigned long long* lim = (unsigned long long*)abc_ws_alloc(ctx, 2 * sizeof(unsigned long long));
+    unsigned long long* key = (unsigned long long*)abc_ws_alloc(ctx, nw * 8);
+    if (!cnt || !lim || !key) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
+    const unsigned long long hl[2] = {n_less, ties_take};
+    ABC_HIP(ctx, hipMemcpyAsync(lim, hl, sizeof(hl), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb,
+                       (unsigned long long)idx_base, key, (unsigned long long*)idx_out, lim);
+    hipLaunchKernelGGL(k_keys_to_dist, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, key, nw, dist_out);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
 int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx,
                            double* dist_out) {
     if (K == 0) return ABC_OK;
@@ -391,9 +459,9 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
                                (int)(p == 5), (unsigned long long)K);
         }
         hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb,
-                           (unsigned long long)idx_base, key0, idx0);
+                           (unsigned long long)idx_base, key0, idx0, (const unsigned long long*)nullptr);
     }
     }
     ABC_HIP(ctx, hipGetLastError());

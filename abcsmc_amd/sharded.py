@@ -5,7 +5,8 @@ few real exchange steps of the path:
   1. broadcast of the pilot shift                       (16*ceil((M+P)/16) doubles)
   2. ONE packed all-reduce of the sufficient statistics  (counts, column sums, Gram blocks; <= 0.35 MB)
      -> the PLS deflation loop is then replicated on every rank (deterministic, identical model)
-  3. all-gather of each rank's local winners (dist, global row), replicated merge-sort -> global top K
+  3. exact distributed radix select: 6 all-reduces of a 2048-bin histogram (8 KB) find the global K-th key,
+     then an all-gather of the K winners (dist, global row) padded to the largest shard + a replicated sort
   4. all-reduce of the K x P gathered posterior (each row is owned by exactly one rank)
   5. all-gather of the raw importance weights (KDE rows are sharded K/G per rank)
   6. resampling/perturbation need no exchange: every rank regenerates its own slice of the
@@ -79,6 +80,23 @@ class HipBackend:
     def sort_pairs(self, key, idx):
         self.ctx.check(lib().abc_sort_pairs_dev(self._s(), key.data_ptr(), idx.data_ptr(), key.numel()))
 
+    # distributed radix select (histograms are all-reduced by the driver between hist and pick)
+    def select_begin(self, K, state, hist):
+        self.ctx.check(lib().abc_select_begin_dev(self._s(), K, state.data_ptr(), hist.data_ptr()))
+
+    def select_hist(self, d, state, p, hist):
+        self.ctx.check(lib().abc_select_hist_dev(self._s(), d.data_ptr(), d.numel(), state.data_ptr(), p, hist.data_ptr()))
+
+    def select_pick(self, state, p, hist, K):
+        self.ctx.check(lib().abc_select_pick_dev(self._s(), state.data_ptr(), p, hist.data_ptr(), K))
+
+    def select_count(self, d, state, counts):
+        self.ctx.check(lib().abc_select_count_dev(self._s(), d.data_ptr(), d.numel(), state.data_ptr(), counts.data_ptr()))
+
+    def select_compact(self, d, state, n_less, ties_take, idx_base, idx_out, dist_out):
+        self.ctx.check(lib().abc_select_compact_dev(self._s(), d.data_ptr(), d.numel(), state.data_ptr(), n_less, ties_take,
+                                                    idx_base, idx_out.data_ptr(), dist_out.data_ptr()))
+
     def gather_rows(self, Y, idx, idx_base, theta):
         P, n = Y.shape
         K = idx.numel()
@@ -137,6 +155,10 @@ class ShardedGeneration:
         self.cand_dist = be.empty(self.k_local * self.world)
         self.loc_idx = be.empty(self.k_local, torch.int64)
         self.loc_dist = be.empty(self.k_local)
+        self.sel_state = be.zeros(8, torch.int64)
+        self.sel_hist = be.zeros(2048, torch.int32)
+        self.sel_counts = be.zeros(2, torch.int64)
+        self.sel_all_counts = be.zeros(2 * self.world, torch.int64)
         self.idx = be.empty(K, torch.int64)
         self.dist = be.empty(K)
         self.theta = be.zeros((P, K))
@@ -179,14 +201,38 @@ class ShardedGeneration:
         be.pls_model(self.stats, obs, M, P, A, self.rule, self.model)
         # 3: distances, local winners, global merge
         be.project_distance(X, P, A, self.model, self.dist_local)
-        be.select_smallest(self.dist_local, self.k_local, row0, self.loc_idx, self.loc_dist)
         if W > 1:
-            dist.all_gather_into_tensor(self.cand_idx, self.loc_idx, group=self.group)
-            dist.all_gather_into_tensor(self.cand_dist, self.loc_dist, group=self.group)
-            be.sort_pairs(self.cand_dist, self.cand_idx)
-            self.idx.copy_(self.cand_idx[:K])
-            self.dist.copy_(self.cand_dist[:K])
+            # exact distributed selection: 6 all-reduced radix histograms -> global K-th key on every rank
+            be.select_begin(K, self.sel_state, self.sel_hist)
+            for p in range(6):
+                be.select_hist(self.dist_local, self.sel_state, p, self.sel_hist)
+                self._ar(self.sel_hist)
+                be.select_pick(self.sel_state, p, self.sel_hist, K)
+            be.select_count(self.dist_local, self.sel_state, self.sel_counts)
+            dist.all_gather_into_tensor(self.sel_all_counts, self.sel_counts, group=self.group)
+            ac = self.sel_all_counts.cpu().tolist()
+            less = [ac[2 * q] for q in range(W)]
+            eq = [ac[2 * q + 1] for q in range(W)]
+            remaining = K - sum(less)                 # ties at the threshold go to the lowest global rows first
+            take = []
+            for q in range(W):
+                tq = min(eq[q], max(remaining, 0))
+                take.append(tq)
+                remaining -= tq
+            nw = [less[q] + take[q] for q in range(W)]
+            maxw = max(nw)
+            be.select_compact(self.dist_local, self.sel_state, less[r], take[r], row0, self.loc_idx, self.loc_dist)
+            if nw[r] < maxw:                          # pad to the common length with sentinels that sort last
+                self.loc_idx[nw[r]:maxw].fill_(1 << 62)
+                self.loc_dist[nw[r]:maxw].fill_(float("inf"))
+            cidx, cdist = self.cand_idx[:W * maxw], self.cand_dist[:W * maxw]
+            dist.all_gather_into_tensor(cidx, self.loc_idx[:maxw], group=self.group)
+            dist.all_gather_into_tensor(cdist, self.loc_dist[:maxw], group=self.group)
+            be.sort_pairs(cdist, cidx)                # stable: equal distances stay in global row order
+            self.idx.copy_(cidx[:K])
+            self.dist.copy_(cdist[:K])
         else:
+            be.select_smallest(self.dist_local, self.k_local, row0, self.loc_idx, self.loc_dist)
             self.idx.copy_(self.loc_idx[:K])
             self.dist.copy_(self.loc_dist[:K])
         # 4: posterior rows

@@ -204,6 +204,17 @@ int abc_project_distance_dev(abc_ctx* ctx, const double* X, size_t n, size_t ldx
 /* K smallest of dist[n] in ascending (dist, index) order: idx[K] (local row + idx_base), dist[K] */
 int abc_select_smallest_dev(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base,
                             uint64_t* idx, double* dist_out);
+/* Distributed exact selection: every shard histograms its keys for pass p = 0..5 (digits of the
+ * IEEE bit pattern, high to low), the caller all-reduces hist (2048 x int32) over the shards, then every shard
+ * picks the same digit; after pass 5 `state` holds the global K-th smallest key.  count -> {#below, #equal} per
+ * shard (the caller decides how many ties each shard takes, lowest global rows first); compact -> that shard's
+ * winners (dist, row + idx_base) in row order.  state: 8 x int64, hist: 2048 x int32 (zeroed by begin / pick). */
+int abc_select_begin_dev(abc_ctx* ctx, uint64_t K, int64_t* state, int32_t* hist);
+int abc_select_hist_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, int pass, int32_t* hist);
+int abc_select_pick_dev(abc_ctx* ctx, int64_t* state, int pass, int32_t* hist, uint64_t K);
+int abc_select_count_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, int64_t* counts);
+int abc_select_compact_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, uint64_t n_less,
+                           uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out);
 /* sort n (key, idx) pairs by (key, idx); used to merge per-shard winners */
 int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size_t n);
 /* theta[i, :] = Y[idx[i] - idx_base, :] for idx in [idx_base, idx_base + n_local), else untouched */

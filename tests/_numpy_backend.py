@@ -144,6 +144,59 @@ class NumpyBackend:
         idx_out.copy_(torch.from_numpy(o + idx_base))
         dist_out.copy_(torch.from_numpy(dn[o]))
 
+    # ---- distributed radix select, mirroring k_sel_* (state = [prefix, mask, krem, n_less, ties, ...]) ----
+    _SHIFT = [53, 42, 31, 20, 9, 0]
+    _WIDTH = [11, 11, 11, 11, 11, 9]
+
+    @staticmethod
+    def _keys(d):
+        b = _np(d).view(np.uint64)
+        neg = (b >> np.uint64(63)).astype(bool)
+        return np.where(neg, ~b, b | np.uint64(1 << 63))
+
+    def select_begin(self, K, state, hist):
+        state.zero_()
+        state[2] = K
+        hist.zero_()
+
+    def select_hist(self, d, state, p, hist):
+        k = self._keys(d)
+        st = _np(state).view(np.uint64)
+        m = (k & st[1]) == st[0]
+        dig = ((k[m] >> np.uint64(self._SHIFT[p])) & np.uint64((1 << self._WIDTH[p]) - 1)).astype(np.int64)
+        hist += torch.from_numpy(np.bincount(dig, minlength=2048).astype(np.int32))
+
+    def select_pick(self, state, p, hist, K):
+        st = _np(state).view(np.uint64)
+        h = _np(hist).astype(np.int64)
+        cum = np.cumsum(h)
+        krem = int(st[2])
+        dsel = int(np.searchsorted(cum, krem, side="left"))
+        below = int(cum[dsel - 1]) if dsel > 0 else 0
+        st[0] |= np.uint64(dsel) << np.uint64(self._SHIFT[p])
+        st[1] |= np.uint64(((1 << self._WIDTH[p]) - 1) << self._SHIFT[p])
+        st[2] = np.uint64(krem - below)
+        if p == 5:
+            st[4] = st[2]
+            st[3] = np.uint64(K - int(st[2]))
+        hist.zero_()
+
+    def select_count(self, d, state, counts):
+        k = self._keys(d)
+        T = _np(state).view(np.uint64)[0]
+        counts[0] = int((k < T).sum())
+        counts[1] = int((k == T).sum())
+
+    def select_compact(self, d, state, n_less, ties_take, idx_base, idx_out, dist_out):
+        k = self._keys(d)
+        T = _np(state).view(np.uint64)[0]
+        lo = np.nonzero(k < T)[0]
+        eq = np.nonzero(k == T)[0][:ties_take]
+        sel = np.concatenate([lo, eq]).astype(np.int64)
+        assert lo.size == n_less
+        idx_out[:sel.size] = torch.from_numpy(sel + idx_base)
+        dist_out[:sel.size] = torch.from_numpy(_np(d)[sel])
+
     def sort_pairs(self, key, idx):
         o = np.argsort(_np(key), kind="stable")
         k, i = _np(key)[o].copy(), _np(idx)[o].copy()

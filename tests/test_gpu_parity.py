@@ -504,3 +504,54 @@ def test_generation_tiny(gpu_ctx, oracle):
     assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
     assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
     assert np.array_equal(gen.parent.cpu().numpy()[:Nn].astype(np.uint64), ref["parent"])
+
+
+def test_distributed_select_protocol_with_ties(gpu_ctx, oracle):
+    """The sharded driver's exact selection (6 all-reduced radix histograms, tie hand-out by global row, padded
+    gather, stable merge sort) replayed in one process over 3 emulated shards, on tie-heavy keys."""
+    import torch
+    from abcsmc_amd import sharded
+    be = sharded.HipBackend("cuda:0", gpu_ctx)
+    rng = np.random.default_rng(12)
+    n_loc, W = 5000, 3
+    d = np.round(np.abs(rng.normal(size=n_loc * W)) * 20) / 20.0          # ~80 distinct values: massive ties
+    shards = [torch.from_numpy(d[q * n_loc:(q + 1) * n_loc].copy()).cuda() for q in range(W)]
+    for K in (1, 37, 4999, 5000, 7501, 14999):
+        st = [be.zeros(8, torch.int64) for _ in range(W)]
+        hs = [be.zeros(2048, torch.int32) for _ in range(W)]
+        for q in range(W):
+            be.select_begin(K, st[q], hs[q])
+        for p in range(6):
+            for q in range(W):
+                be.select_hist(shards[q], st[q], p, hs[q])
+            tot = sum(hs)                                                  # the all-reduce
+            for q in range(W):
+                hs[q].copy_(tot)
+                be.select_pick(st[q], p, hs[q], K)
+        assert all(torch.equal(st[0], s) for s in st)
+        cnt = []
+        for q in range(W):
+            c = be.zeros(2, torch.int64)
+            be.select_count(shards[q], st[q], c)
+            cnt.append(c.cpu().tolist())
+        remaining = K - sum(c[0] for c in cnt)
+        take = []
+        for q in range(W):
+            tq = min(cnt[q][1], max(remaining, 0))
+            take.append(tq)
+            remaining -= tq
+        assert remaining == 0
+        idxs, dists = [], []
+        for q in range(W):
+            nw = cnt[q][0] + take[q]
+            io, do = be.zeros(max(nw, 1), torch.int64), be.zeros(max(nw, 1))
+            be.select_compact(shards[q], st[q], cnt[q][0], take[q], q * n_loc, io, do)
+            idxs.append(io[:nw])
+            dists.append(do[:nw])
+        ci, cd = torch.cat(idxs).contiguous(), torch.cat(dists).contiguous()
+        assert ci.numel() == K
+        be.sort_pairs(cd, ci)
+        torch.cuda.synchronize()
+        ref = oracle.ordered(d)[:K]
+        assert np.array_equal(ci.cpu().numpy().astype(np.uint64), ref), K
+        assert np.array_equal(cd.cpu().numpy(), d[ref.astype(np.int64)])
