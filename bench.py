@@ -163,6 +163,22 @@ def main():
                         "note": "peak = MI355X fp64 vector spec; scripts/ubench.hip measures 56 TFLOP/s sustained v_fma_f64",
                         "pairs_per_step": pairs, "flop_per_pair": flop_pair, "kernel_ms_per_step": round(kde_ms_per_step, 5)}
 
+    # set 0 (uniform weights, AbcUtil.cpp:539-545) has no O(K K') stage: reported separately, outside the timed region
+    set0 = None
+    if world == 1:
+        rng0 = abcutil.rng(67890)
+        gen0 = device.Generation(N, M, P, K, 0, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
+        for _ in range(2):
+            gen0.run(dX, dY, dobs, dpri, rng0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            gen0.run(dX, dY, dobs, dpri, rng0)
+        barrier()
+        dt0 = (time.perf_counter() - t1) / 5
+        set0 = {"value": N / dt0, "unit": "particles/s", "ms_per_step": 1e3 * dt0,
+                "note": "first SMC set: rank + uniform weights + resample/perturb (no importance-weight stage)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, wl, X, Y, obs, spec, th_prev, w_prev, dv_prev, K, A, args.cpu_budget_s)
@@ -180,6 +196,7 @@ def main():
                        "parallelism": "row-sharded x%d" % world},
             "roofline": roofline,
             "roofline_compute": roofline_compute,
+            "set0": set0,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,
         }

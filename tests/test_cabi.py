@@ -90,3 +90,29 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "pyoracle" not in txt and "abc_oracle" not in txt and "liboracle" not in txt, fn
+
+
+def test_header_is_plain_c_and_links(tmp_path, L):
+    """include/abcsmc_hip.h must be consumable from C (no C++ types): compile and link a C99 translation unit
+    against the shared library, call only host-side entry points."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include "abcsmc_hip.h"
+#include <stdio.h>
+int main(void) {
+    abc_rng r; abc_rng_set(&r, 123);
+    unsigned v = abc_rng_get(&r);
+    abc_prior p = {ABC_PRIOR_GAUSS, 0, 0.0, 1.0};
+    abc_generation_cfg cfg = {0};
+    (void)p; (void)cfg;
+    printf("%u %d %zu\n", v, abc_version(), abc_stats_len(32, 16));
+    return v == 2720986350u ? 0 : 1;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-L" + os.path.join(ROOT, "abcsmc_amd"), "-labcsmc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "abcsmc_amd"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
