@@ -203,6 +203,155 @@ __global__ __launch_bounds__((GramDims<C, CY>::NT)) void k_gram(const double* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant for narrow sets (C <= 3) with 16-B aligned columns: tiles go HBM -> LDS directly
+// (global_load_lds_dwordx4, no VGPR round trip, no LDS write phase), a ring of three tile buffers (two DMAs in
+// flight behind the tile being read, counted s_waitcnt vmcnt), ONE barrier per tile.
+// The shift is subtracted when the MFMA operand is read (3 VALU ops per 5 MFMAs: free next to the matrix
+// pipe), which is also where the column sums / sums of squares are taken and edge rows are masked.
+template <int C, int CY, int NW>
+struct GramDimsDma {
+    static constexpr int C16 = 16 * C;
+    static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
+    static constexpr int NT = 64 * NW;
+    static constexpr int NI = C16 / NW;                 // DMA instructions (one column x 128 rows) per wave per tile
+    static constexpr int PSZ = NBLK * 256 + 2 * C16;    // same partial record as k_gram
+    static constexpr int BUF = C16 * TRP;
+    static constexpr int EPT = (NBLK * 256 + NT - 1) / NT;
+    static constexpr int LDS_D = 3 * BUF;               // ring of three tiles: two DMAs in flight behind the one being read
+};
+
+template <int C, int CY, int NW>
+__global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
+    const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M, int P, long long n,
+    long long split, const double* __restrict__ shift, double* __restrict__ partial) {
+    using D = GramDimsDma<C, CY, NW>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NT = D::NT;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
+    const long long r_begin = part ? split : 0, r_end = part ? n : split;
+    const long long t0 = r_begin & ~1LL;
+    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + TR - 1) / TR : 0;
+    const long long rmax = (n - 2) & ~1LL;             // last in-bounds 16-B row pair (n is even on this path)
+
+    const double* cptr[D::NI];
+#pragma unroll
+    for (int i = 0; i < D::NI; i++) {
+        const int c = wave + NW * i;                    // padding columns re-read column 0, masked at operand read
+        cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+    }
+    auto stage = [&](long long tile, double* buf) {
+        long long r = t0 + tile * TR + 2 * lane;
+        r = r > rmax ? rmax : r;                        // rows past the end are masked later; keep the address legal
+#pragma unroll
+        for (int i = 0; i < D::NI; i++) {
+            const int c = wave + NW * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cptr[i] + r),
+                                             (__attribute__((address_space(3))) void*)(buf + c * TRP), 16, 0, 0);
+        }
+    };
+
+    const int cl = lane & 15, q = lane >> 4;
+    double sh[C], keep[C];
+#pragma unroll
+    for (int b = 0; b < C; b++) {
+        const int c = 16 * b + cl;
+        keep[b] = (c < M + P) ? 1.0 : 0.0;
+        sh[b] = (c < M + P) ? shift[c] : 0.0;
+    }
+    d4 acc[D::NBLK];
+#pragma unroll
+    for (int b = 0; b < D::NBLK; b++) acc[b] = (d4){0.0, 0.0, 0.0, 0.0};
+    double cs[C], cq[C];
+#pragma unroll
+    for (int b = 0; b < C; b++) { cs[b] = 0.0; cq[b] = 0.0; }
+
+    int cur = 0;
+    long long tile = g;
+    if (tile < ntiles) stage(tile, lds);
+    if (tile + G < ntiles) stage(tile + G, lds + D::BUF);
+    for (; tile < ntiles; tile += G) {
+        const double* buf = lds + cur * D::BUF;
+        // The DMA of THIS tile must have landed; the next tile's (issued later by the same wave, NI instructions)
+        // may stay in flight.  hipcc does not reliably place these waits for LDS-DMA issued in an earlier loop
+        // iteration (seen in the ISA), so they are explicit.
+        if (tile + G < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();           // every wave's share of this tile is in LDS; the buffer refilled below is idle
+        if (tile + 2 * G < ntiles) stage(tile + 2 * G, lds + ((cur + 2) % 3) * D::BUF);
+        const long long row0 = t0 + tile * TR;
+        const bool full = (row0 >= r_begin) && (row0 + TR <= r_end);
+#pragma unroll
+        for (int s = 0; s < TR / (4 * NW); s++) {
+            const int rb = wave * (TR / NW) + 4 * s + q;
+            const long long grow = row0 + rb;
+            const bool ok = full || (grow >= r_begin && grow < r_end);
+            double a[C];
+#pragma unroll
+            for (int b = 0; b < C; b++) {
+                const double z = (buf[(16 * b + cl) * TRP + rb] - sh[b]) * keep[b];
+                a[b] = ok ? z : 0.0;
+                cs[b] += a[b];
+                if (b >= C - CY) cq[b] = fma(a[b], a[b], cq[b]);
+            }
+            int blk = 0;
+#pragma unroll
+            for (int bi = 0; bi < C - CY; bi++)
+#pragma unroll
+                for (int bj = bi; bj < C; bj++) {
+                    acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[blk], 0, 0, 0);
+                    blk++;
+                }
+        }
+        cur = (cur + 1) % 3;
+    }
+
+    // ---- epilogue (same partial record as k_gram) -------------------------------------------------------
+    double* out = partial + ((size_t)part * G + g) * D::PSZ;
+    __syncthreads();
+    double tot[D::EPT];
+#pragma unroll
+    for (int k = 0; k < D::EPT; k++) tot[k] = 0.0;
+    for (int round = 0; round < NW / 4; round++) {
+        if ((wave >> 2) == round) {
+#pragma unroll
+            for (int b = 0; b < D::NBLK; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) lds[(wave & 3) * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < D::EPT; k++) {
+            const int e = t + k * NT;
+            if (e < D::NBLK * 256)
+                tot[k] += ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < D::EPT; k++) {
+        const int e = t + k * NT;
+        if (e < D::NBLK * 256) out[e] = tot[k];
+    }
+    // column sums: lane (cl, q) of every wave holds the partial sum of column 16 b + cl over its rows
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < C; b++) lds[b * NT + t] = half ? cq[b] : cs[b];
+        __syncthreads();
+        if (t < D::C16) {
+            const int b = t >> 4, c = t & 15;
+            double sacc = 0.0;
+            for (int w = 0; w < NW; w++)
+                for (int qq = 0; qq < 4; qq++) sacc += lds[b * NT + w * 64 + qq * 16 + c];
+            out[D::NBLK * 256 + half * D::C16 + t] = sacc;
+        }
+    }
+}
+
+
 // Sum the per-work-group partial records in a fixed order and scatter into the stats record.
 template <int C, int CY>
 __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__ partial, int G,
@@ -293,6 +442,40 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
                            (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 15) / 16, 2), dim3(256), 0, ctx->stream, partial, (int)G,
+                       stats, ntr, nte);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+template <int C, int CY, int NW>
+int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
+                 size_t P, long long split, double* stats) {
+    using D = GramDimsDma<C, CY, NW>;
+    const StatsLayout L = stats_layout(M, P);
+    const long long ntr = split, nte = (long long)n - split;
+    const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
+    long long G = tiles / 2;
+    if (G < 1) G = 1;
+    if (G > 128) G = 128;              // 150 KB of LDS: one work-group per CU, 2 partitions x 128
+    const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
+    double* partial = (double*)abc_ws_alloc(ctx, pbytes);
+    if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
+    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
+    const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+        attr_set = true;
+    }
+    {
+        StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
+        hipLaunchKernelGGL((k_gram_dma<C, CY, NW>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
+                           ldy, (int)M, (int)P, (long long)n, split, stats + L.off_shift, partial);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
@@ -398,6 +581,17 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     const size_t C = (M + P + 15) / 16;
     size_t CY = C - (M + 15) / 16;      // trailing blocks without any metric column
     if (CY > 2) CY = 2;
+    // LDS-DMA staging needs 16-B aligned columns and an even row count (row pairs never straddle the array end)
+    static const int dma_mode = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : 8;     // 0 = off (A/B), 8 / 16 waves
+    const bool dma_ok = dma_mode && (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
+                        (((uintptr_t)Y & 15) == 0) && n >= 2;
+#define GRAM_DMA_CASE(c, cy)                                                                              \
+    if (C == c && CY == cy && dma_ok) {                                                                   \
+        if (dma_mode == 16) return run_gram_dma<c, cy, 16>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);   \
+        return run_gram_dma<c, cy, 8>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);                        \
+    }
+    GRAM_DMA_CASE(1, 0); GRAM_DMA_CASE(2, 0); GRAM_DMA_CASE(2, 1); GRAM_DMA_CASE(3, 0); GRAM_DMA_CASE(3, 1); GRAM_DMA_CASE(3, 2);
+#undef GRAM_DMA_CASE
 #define GRAM_CASE(c, cy) if (C == c && CY == cy) return run_gram<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_CASE(1, 0); GRAM_CASE(2, 0); GRAM_CASE(2, 1); GRAM_CASE(3, 0); GRAM_CASE(3, 1); GRAM_CASE(3, 2);
     GRAM_CASE(4, 0); GRAM_CASE(4, 1); GRAM_CASE(4, 2); GRAM_CASE(5, 0); GRAM_CASE(5, 1); GRAM_CASE(5, 2);
