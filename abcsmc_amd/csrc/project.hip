@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_project_dist2(const double* __restrict_
 #pragma unroll
         for (int k = 0; k < KC; k++) { s0[k] = 0.0; s1[k] = 0.0; }
         const double* xp = X + 2 * i;
-#pragma unroll 4
+#pragma unroll 8
         for (int m = 0; m < M; m++) {
             const d2 x = *reinterpret_cast<const d2*>(xp + (size_t)m * ldx);
             const double sdm = sd[m], mu = mean[m];

@@ -278,30 +278,32 @@ int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
     return ABC_OK;
 }
 
-// [GSL] gsl_ran_discrete_preproc (randist/discrete.c): Walker alias with two LIFO stacks
-void alias_preproc(size_t K, const double* w, double* F, uint32_t* A) {
+// [GSL] gsl_ran_discrete_preproc (randist/discrete.c): Walker alias with two LIFO stacks.
+// scratch: K doubles (E) + 2 K uint32 (the stacks), caller-provided so the hot loop never allocates.
+void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs) {
     double total = 0.0;
     for (size_t k = 0; k < K; k++) total += w[k];
-    std::vector<double> E(K);
-    for (size_t k = 0; k < K; k++) E[k] = w[k] / total;
     const double mean = 1.0 / (double)K;
-    std::vector<uint32_t> bigs, smalls;
-    bigs.reserve(K); smalls.reserve(K);
-    for (size_t k = 0; k < K; k++) (E[k] < mean ? smalls : bigs).push_back((uint32_t)k);
-    while (!smalls.empty()) {
-        const uint32_t s = smalls.back(); smalls.pop_back();
-        if (bigs.empty()) { A[s] = s; F[s] = 1.0; continue; }
-        const uint32_t b = bigs.back(); bigs.pop_back();
+    size_t ns = 0, nb = 0;
+    for (size_t k = 0; k < K; k++) {
+        const double e = w[k] / total;
+        E[k] = e;
+        if (e < mean) smalls[ns++] = (uint32_t)k; else bigs[nb++] = (uint32_t)k;
+    }
+    while (ns) {
+        const uint32_t s = smalls[--ns];
+        if (!nb) { A[s] = s; F[s] = 1.0; continue; }
+        const uint32_t b = bigs[--nb];
         A[s] = b;
         F[s] = (double)K * E[s];
         const double d = mean - E[s];
         E[s] += d;
         E[b] -= d;
-        if (E[b] < mean) smalls.push_back(b);
-        else if (E[b] > mean) bigs.push_back(b);
+        if (E[b] < mean) smalls[ns++] = b;
+        else if (E[b] > mean) bigs[nb++] = b;
         else { A[b] = b; F[b] = 1.0; }
     }
-    while (!bigs.empty()) { const uint32_t b = bigs.back(); bigs.pop_back(); A[b] = b; F[b] = 1.0; }
+    while (nb) { const uint32_t b = bigs[--nb]; A[b] = b; F[b] = 1.0; }
     for (size_t k = 0; k < K; k++) { F[k] += (double)k; F[k] /= (double)K; }
 }
 
@@ -312,15 +314,18 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     // alias table: weights to the host, serial Walker build, tables back to HBM
-    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 2 + sizeof(uint32_t))));
+    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3)));
     double* hw = (double*)ctx->pin;
     double* hF = hw + K;
-    uint32_t* hA = (uint32_t*)(hF + K);
+    double* hE = hF + K;
+    uint32_t* hA = (uint32_t*)(hE + K);
+    uint32_t* hS = hA + K;
+    uint32_t* hB = hS + K;
     ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     {
         const auto t0 = std::chrono::steady_clock::now();
-        alias_preproc(K, hw, hF, hA);
+        alias_preproc(K, hw, hF, hA, hE, hS, hB);
         if (ctx->timing) {
             ctx->stage_host_ms[ST_ALIAS_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             ctx->stage_cnt[ST_ALIAS_HOST] += 1;
