@@ -555,3 +555,31 @@ def test_distributed_select_protocol_with_ties(gpu_ctx, oracle):
         ref = oracle.ordered(d)[:K]
         assert np.array_equal(ci.cpu().numpy().astype(np.uint64), ref), K
         assert np.array_equal(cd.cpu().numpy(), d[ref.astype(np.int64)])
+
+
+# ---------------------------------------------------------------------------------------------------
+# error conventions of the C ABI (int status + message, never exit/abort)
+# ---------------------------------------------------------------------------------------------------
+def test_error_codes_and_messages(gpu_ctx):
+    import ctypes as C
+    from abcsmc_amd import _lib, abcutil
+    L = _lib.lib()
+    h = gpu_ctx.handle
+    X = np.asfortranarray(np.random.default_rng(0).normal(size=(50, 4)))
+    Y = np.asfortranarray(np.random.default_rng(1).normal(size=(50, 2)))
+    idx = np.zeros(50, dtype=np.uint64)
+    # null argument -> ABC_ERR_INVALID (-1)
+    assert L.abc_particle_ranking_pls(h, None, None, None, 50, 4, 2, 0.5, 0, 0, 10, None, None, None, None, None, None) == -1
+    assert b"null" in L.abc_last_error(h)
+    # unknown component rule
+    rc = L.abc_particle_ranking_pls(h, X.ctypes.data, Y.ctypes.data, X[0].copy().ctypes.data, 50, 4, 2, 0.5, 0, 7, 10,
+                                    idx.ctypes.data, None, None, None, None, None)
+    assert rc == -1 and b"rule" in L.abc_last_error(h)
+    # more than 32 parameters in the weight kernel -> ABC_ERR_UNSUPPORTED (-4), not a crash
+    th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 40)))
+    pri = _lib.make_priors([(_lib.PRIOR_GAUSS, 0.0, 1.0)] * 40)
+    with pytest.raises(_lib.AbcError) as e:
+        abcutil.weight_predictive_prior(pri, th, th, np.full(20, 0.05), np.ones(40), ctx=gpu_ctx)
+    assert e.value.code == -4
+    # a later valid call on the same context still works
+    assert abcutil.calculate_doubled_variance(th[:, :3], ctx=gpu_ctx).shape == (3,)
