@@ -58,17 +58,17 @@ __global__ __launch_bounds__(256) void k_doubled_variance(const double* __restri
 
 // ---- weights --------------------------------------------------------------------------------------
 struct WConst {           // per-parameter constants, built on the device by k_wprep
-    double scale[32];     // 1/sqrt(dv_p), or 0 when dv_p == 0
+    double scale[64];     // 1/sqrt(dv_p), or 0 when dv_p == 0
     double logC;          // unused
     double C;             // prod over dv_p != 0 of 1/(sqrt(2 pi) sqrt(dv_p))
     int nzero;            // number of parameters with dv_p == 0
-    int zero_idx[32];
+    int zero_idx[64];
 };
 
 __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc) {
     if (threadIdx.x != 0) return;
     double C = 1.0; int nz = 0;
-    for (int p = 0; p < 32; p++) {
+    for (int p = 0; p < 64; p++) {
         double sc = 0.0;
         if (p < P) {
             const double dv = dv_prev[p];
@@ -233,7 +233,7 @@ int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t 
 int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P, size_t k0,
                        size_t kn, const double* theta_prev, size_t Kp, const double* w_prev, const double* dv_prev,
                        double* w_raw) {
-    if (P > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 32 parameters", P);
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
     if (kn == 0) return ABC_OK;
     if (k0 + kn > K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: row range [%zu,%zu) outside K=%zu", k0, k0 + kn, K);
     int PP = 2;
@@ -265,7 +265,8 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             case 4: LAUNCH_KDE(4); break;
             case 8: LAUNCH_KDE(8); break;
             case 16: LAUNCH_KDE(16); break;
-            default: LAUNCH_KDE(32); break;
+            case 32: LAUNCH_KDE(32); break;
+            default: LAUNCH_KDE(64); break;
         }
     }
 #undef LAUNCH_KDE

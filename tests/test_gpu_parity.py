@@ -194,7 +194,7 @@ def _weights_case(P, K, Kp, seed):
     return wl, th, tp, wp, dv
 
 
-@pytest.mark.parametrize("P,K,Kp", [(16, 700, 900), (2, 100, 64), (5, 1, 130), (32, 300, 257), (3, 2500, 70)])
+@pytest.mark.parametrize("P,K,Kp", [(16, 700, 900), (2, 100, 64), (5, 1, 130), (32, 300, 257), (3, 2500, 70), (48, 200, 150)])
 def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp):
     from abcsmc_amd import abcutil, _lib
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 77 + P)
@@ -575,11 +575,11 @@ def test_error_codes_and_messages(gpu_ctx):
     rc = L.abc_particle_ranking_pls(h, X.ctypes.data, Y.ctypes.data, X[0].copy().ctypes.data, 50, 4, 2, 0.5, 0, 7, 10,
                                     idx.ctypes.data, None, None, None, None, None)
     assert rc == -1 and b"rule" in L.abc_last_error(h)
-    # more than 32 parameters in the weight kernel -> ABC_ERR_UNSUPPORTED (-4), not a crash
-    th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 40)))
-    pri = _lib.make_priors([(_lib.PRIOR_GAUSS, 0.0, 1.0)] * 40)
+    # more than 64 parameters in the weight kernel -> ABC_ERR_UNSUPPORTED (-4), not a crash
+    th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 70)))
+    pri = _lib.make_priors([(_lib.PRIOR_GAUSS, 0.0, 1.0)] * 70)
     with pytest.raises(_lib.AbcError) as e:
-        abcutil.weight_predictive_prior(pri, th, th, np.full(20, 0.05), np.ones(40), ctx=gpu_ctx)
+        abcutil.weight_predictive_prior(pri, th, th, np.full(20, 0.05), np.ones(70), ctx=gpu_ctx)
     assert e.value.code == -4
     # a later valid call on the same context still works
     assert abcutil.calculate_doubled_variance(th[:, :3], ctx=gpu_ctx).shape == (3,)
