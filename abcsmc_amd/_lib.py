@@ -60,6 +60,7 @@ SIGNATURES = {
     "abc_version": (_i, []),
     "abc_timing_enable": (_i, [_vp, _i]),
     "abc_timing_read": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
+    "abc_timing_overhead": (_i, [_vp, _i, _vp]),
     "abc_rng_set": (None, [_vp, C.c_ulong]),
     "abc_rng_get": (C.c_uint32, [_vp]),
     "abc_rng_jump": (None, [_vp, _u64]),
@@ -153,6 +154,12 @@ class Context:
         if k < 0:
             self.check(k)
         return {names[i].decode(): (ms[i], hms[i], cnt[i]) for i in range(k)}
+
+    def timing_overhead(self, reps=50):
+        """ms an event pair around one kernel reports beyond the kernel's execution (abc_timing_overhead)"""
+        ov = C.c_double(0.0)
+        self.check(lib().abc_timing_overhead(self._h, int(reps), C.byref(ov)))
+        return ov.value
 
     def synchronize(self):
         self.check(lib().abc_ctx_synchronize(self._h))

@@ -51,7 +51,7 @@ static size_t ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t K
     b += N * 8;                                                   // distances
     b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
-    b += K * P * 8;                                               // theta
+    b += K * P * 8 + K * 32 * 8;                                  // theta, and its row-major copy for the perturb gather
     b += (K + Kp) * 64 * 8 + 1024 * 8 + 8 * ((K < 2048 ? 1024 * K : 8 * K) + 1024);   // weights
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
@@ -152,6 +152,37 @@ extern "C" int abc_timing_read(abc_ctx* ctx, const char** names, double* ms, dou
     }
     if (reset) for (int i = 0; i < ABC_NSTAGE; i++) { ctx->stage_ms[i] = 0; ctx->stage_host_ms[i] = 0; ctx->stage_cnt[i] = 0; }
     return ABC_NSTAGE;
+}
+
+// Event-bracket overhead: what an event pair around ONE kernel reports beyond that kernel's execution (packet
+// processing before the dispatch, the end-of-kernel release before the closing marker).  b1 = bracket around one
+// empty kernel, b2 = around two; b2 - b1 is the marginal cost of an empty kernel, so overhead = b1 - (b2 - b1).
+__global__ void k_noop() {}
+extern "C" int abc_timing_overhead(abc_ctx* ctx, int reps, double* overhead_ms) {
+    if (!ctx || !overhead_ms || reps < 1) return ABC_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed");
+    hipEvent_t a, b;
+    ABC_HIP(ctx, hipEventCreate(&a));
+    ABC_HIP(ctx, hipEventCreate(&b));
+    double acc[2] = {0, 0};
+    for (int k = 0; k < 2; k++)
+        for (int r = 0; r < reps + 2; r++) {
+            hipLaunchKernelGGL(k_noop, dim3(256), dim3(256), 0, ctx->stream);      // the stream is busy, as in a step
+            ABC_HIP(ctx, hipEventRecord(a, ctx->stream));
+            for (int j = 0; j <= k; j++) hipLaunchKernelGGL(k_noop, dim3(256), dim3(256), 0, ctx->stream);
+            ABC_HIP(ctx, hipEventRecord(b, ctx->stream));
+            ABC_HIP(ctx, hipEventSynchronize(b));
+            float ms = 0;
+            ABC_HIP(ctx, hipEventElapsedTime(&ms, a, b));
+            if (r >= 2) acc[k] += ms;                                              // two warm-up rounds
+        }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    const double b1 = acc[0] / reps, b2 = acc[1] / reps;
+    double ov = b1 - (b2 - b1);
+    if (ov < 0) ov = 0;
+    *overhead_ms = ov;
+    return ABC_OK;
 }
 
 extern "C" void abc_rng_set(abc_rng* r, unsigned long seed) { taus2_set(r, seed); }
@@ -311,7 +342,7 @@ extern "C" int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* t
                                int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
                                uint64_t seed_stream_offset) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, 1, 1, 0, 0, n)));
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, K, 0, n)));
     return launch_perturb(ctx, rng, theta, K, P, priors, parent, i0, n, multivariate, L_or_dv, out, seeds,
                           seed_stream_offset);
 }

@@ -10,10 +10,13 @@
 #ifndef ABCSMC_AMD_ABCUTILHIP_HPP
 #define ABCSMC_AMD_ABCUTILHIP_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/abcsmc_hip.h"
@@ -42,27 +45,6 @@ struct HipError : std::runtime_error {
     HipError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 
-// ---- parameters (Parameter.h:36-87, Priors.h:46-110): only what the hot path evaluates -------------------
-struct Parameter {
-    virtual ~Parameter() {}
-    virtual abc_prior pod() const = 0;
-};
-struct GaussianPrior : Parameter {
-    float_type mean, sd;
-    GaussianPrior(float_type mn, float_type s) : mean(mn), sd(s) {}
-    abc_prior pod() const override { return abc_prior{ABC_PRIOR_GAUSS, 0, mean, sd}; }
-};
-struct DiscreteUniformPrior : Parameter {
-    long minval, maxval;
-    DiscreteUniformPrior(long mn, long mx) : minval(mn), maxval(mx) {}
-    abc_prior pod() const override { return abc_prior{ABC_PRIOR_UNIF_INT, 0, (double)minval, (double)maxval}; }
-};
-struct ContinuousUniformPrior : Parameter {
-    float_type minval, maxval;
-    ContinuousUniformPrior(float_type mn, float_type mx) : minval(mn), maxval(mx) {}
-    abc_prior pod() const override { return abc_prior{ABC_PRIOR_UNIF_REAL, 0, minval, maxval}; }
-};
-
 // ---- RNG: stands in for `const gsl_rng*` of type gsl_rng_taus2 (examples/include/examples.h:10) ----------
 struct RNG {
     mutable abc_rng state;
@@ -70,6 +52,153 @@ struct RNG {
 };
 inline void rng_set(const RNG* r, unsigned long seed) { abc_rng_set(&r->state, seed); }     // gsl_rng_set
 inline unsigned long rng_get(const RNG* r) { return abc_rng_get(&r->state); }                // gsl_rng_get
+// the three GSL draws Priors.h uses for set 0 (host side, one-off per fit): gsl_rng_uniform = get / 2^32;
+// gsl_rng_uniform_int rejects above n * (0xffffffff / n); gsl_ran_gaussian is the polar Box-Muller on
+// uniforms in (-1, 1) [published GSL 2.x algorithms; GSL itself is not in this image]
+inline double rng_uniform(const RNG* r) { return abc_rng_get(&r->state) / 4294967296.0; }
+inline unsigned long rng_uniform_int(const RNG* r, unsigned long n) {
+    const unsigned long scale = 0xffffffffUL / n;
+    unsigned long k;
+    do { k = abc_rng_get(&r->state) / scale; } while (k >= n);
+    return k;
+}
+inline double ran_gaussian(const RNG* r, double sigma) {
+    double x, y, r2;
+    do {
+        x = -1.0 + 2.0 * rng_uniform(r);
+        y = -1.0 + 2.0 * rng_uniform(r);
+        r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    return sigma * y * std::sqrt(-2.0 * std::log(r2) / r2);
+}
+
+// ---- ParRNG (ParRNG.h:19-81): the RNG handed to Parameter::sample, plus the odometer over PSEUDO states and
+// the cursor over POSTERIOR rows.  One pseudo parameter advances per unlock(); a parameter at its last state
+// wraps to 0 and lets the next one advance.
+struct Parameter;
+struct ParRNG {
+    ParRNG(const RNG* rng, const std::vector<const Parameter*>& mpars, size_t posterior_size);
+    const RNG* rng() const { return rng_; }
+    void unlock() { lock_ = false; }
+    size_t pseudo(const Parameter* p) {
+        std::pair<size_t, size_t>* st = nullptr;
+        for (auto& e : pseudo_) if (e.first == p) st = &e.second;
+        if (!st) throw std::logic_error("ParRNG::pseudo: parameter was not registered");
+        const size_t ret = st->first;
+        if (!lock_) {
+            if (st->first < st->second) { st->first++; lock_ = true; } else { st->first = 0; }
+        }
+        return ret;
+    }
+    size_t posterior() {
+        const size_t ret = post_idx_;
+        if (!lock_) post_idx_ = (post_idx_ < post_max_) ? post_idx_ + 1 : 0;
+        return ret;
+    }
+
+   private:
+    const RNG* rng_;
+    std::vector<std::pair<const Parameter*, std::pair<size_t, size_t>>> pseudo_;   // (state, last state)
+    bool lock_ = false;
+    size_t post_idx_ = 0, post_max_;
+};
+typedef ParRNG PRNG;
+
+// ---- parameters (Parameter.h:36-87, Priors.h:9-110, IndexedPars.h:9-55) ------------------------------------
+// The device evaluates likelihood / recast / valid / noise from the POD (`pod()`); the host keeps the names and
+// the set-0 `sample`.  The two-argument constructors (no names) are a convenience the reference does not have.
+struct Parameter {
+    Parameter(const std::string& s = "", const std::string& ss = "", size_t states = 0)
+        : name(s), short_name(ss), state_size_(states) {}
+    virtual ~Parameter() {}
+    std::string get_name() const { return name; }
+    std::string get_short_name() const { return short_name; }
+    virtual abc_prior pod() const = 0;
+    virtual float_type sample(PRNG& prng) const = 0;
+    virtual float_type likelihood(float_type pval) const = 0;
+    virtual float_type recast(float_type pval) const = 0;
+    virtual float_type get_mean() const { return std::nan(""); }
+    virtual float_type get_sd() const { return std::nan(""); }
+    virtual bool isPosterior() const { return false; }
+    bool valid(float_type pval) const { return likelihood(pval) != 0.0; }
+    size_t state_size() const { return state_size_; }
+
+   private:
+    std::string name, short_name;
+    size_t state_size_;
+};
+inline ParRNG::ParRNG(const RNG* rng, const std::vector<const Parameter*>& mpars, size_t posterior_size)
+    : rng_(rng), post_max_(posterior_size - 1) {
+    for (const Parameter* p : mpars)
+        if (!p->isPosterior() && p->state_size() != 0) pseudo_.push_back({p, {0, p->state_size() - 1}});
+}
+
+struct GaussianPrior : Parameter {
+    float_type mean, sd;
+    GaussianPrior(const std::string& nm, const std::string& snm, float_type mn, float_type s)
+        : Parameter(nm, snm), mean(mn), sd(s) {}
+    GaussianPrior(float_type mn, float_type s) : mean(mn), sd(s) {}
+    abc_prior pod() const override { return abc_prior{ABC_PRIOR_GAUSS, 0, mean, sd}; }
+    float_type sample(PRNG& prng) const override { return ran_gaussian(prng.rng(), sd) + mean; }
+    float_type likelihood(float_type pval) const override {
+        const float_type u = (pval - mean) / std::fabs(sd);
+        return (1.0 / (std::sqrt(2.0 * M_PI) * std::fabs(sd))) * std::exp(-u * u / 2.0);
+    }
+    float_type recast(float_type pval) const override { return pval; }
+    float_type get_mean() const override { return mean; }
+    float_type get_sd() const override { return sd; }
+};
+struct DiscreteUniformPrior : Parameter {
+    long minval, maxval;
+    DiscreteUniformPrior(const std::string& nm, const std::string& snm, long mn, long mx)
+        : Parameter(nm, snm), minval(mn), maxval(mx) {}
+    DiscreteUniformPrior(long mn, long mx) : minval(mn), maxval(mx) {}
+    abc_prior pod() const override { return abc_prior{ABC_PRIOR_UNIF_INT, 0, (double)minval, (double)maxval}; }
+    float_type sample(PRNG& prng) const override {
+        return (float_type)((long)rng_uniform_int(prng.rng(), (unsigned long)(maxval - minval + 1)) + minval);
+    }
+    float_type likelihood(float_type pval) const override {
+        return (pval == recast(pval) && minval <= pval && pval <= maxval) ? 1.0 / (maxval - minval + 1) : 0.0;
+    }
+    float_type recast(float_type pval) const override { return std::round(pval); }
+    float_type get_mean() const override { return (float_type)(maxval + minval) / 2.0; }
+    float_type get_sd() const override { return (float_type)(maxval - minval) / std::sqrt(12.0); }
+};
+struct ContinuousUniformPrior : Parameter {
+    float_type minval, maxval;
+    ContinuousUniformPrior(const std::string& nm, const std::string& snm, float_type mn, float_type mx)
+        : Parameter(nm, snm), minval(mn), maxval(mx) {}
+    ContinuousUniformPrior(float_type mn, float_type mx) : minval(mn), maxval(mx) {}
+    abc_prior pod() const override { return abc_prior{ABC_PRIOR_UNIF_REAL, 0, minval, maxval}; }
+    float_type sample(PRNG& prng) const override { return rng_uniform(prng.rng()) * (maxval - minval) + minval; }
+    float_type likelihood(float_type pval) const override {
+        return (minval <= pval && pval <= maxval) ? 1.0 / (maxval - minval) : 0.0;
+    }
+    float_type recast(float_type pval) const override { return pval; }
+    float_type get_mean() const override { return (maxval + minval) / 2.0; }
+    float_type get_sd() const override { return (maxval - minval) / std::sqrt(12.0); }
+};
+// PSEUDO / POSTERIOR parameters only occur in projection mode (one set, no weights, no perturbation): asking them
+// for a density is an error upstream too (IndexedPars.h:20-28)
+struct IndexedPar : Parameter {
+    IndexedPar(const std::string& s, const std::string& ss, size_t size) : Parameter(s, ss, size) {
+        if (size == 0) throw std::invalid_argument("IndexedPar: empty state set");
+    }
+    abc_prior pod() const override { throw std::logic_error("IndexedPar " + get_name() + " has no prior density"); }
+    float_type likelihood(float_type) const override { throw std::logic_error("likelihood asked of IndexedPar " + get_name()); }
+    float_type recast(float_type) const override { throw std::logic_error("recast asked of IndexedPar " + get_name()); }
+};
+struct PseudoPar : IndexedPar {
+    std::vector<float_type> states;
+    PseudoPar(const std::string& s, const std::string& ss, const std::vector<float_type>& vals)
+        : IndexedPar(s, ss, vals.size()), states(vals) {}
+    float_type sample(PRNG& prng) const override { return states[prng.pseudo(this)]; }
+};
+struct PosteriorPar : IndexedPar {
+    PosteriorPar(const std::string& s, const std::string& ss, size_t size) : IndexedPar(s, ss, size) {}
+    float_type sample(PRNG& prng) const override { return (float_type)prng.posterior(); }
+    bool isPosterior() const override { return true; }
+};
 
 // ---- context (one per host thread, device 0 unless set before first use) -------------------------------
 inline int& default_device() { static int d = 0; return d; }
@@ -150,24 +279,31 @@ inline Mat2D sample_posterior(const RNG* rng, const size_t num_samples, const Co
         for (size_t i = 0; i < num_samples; i++) out(i, j) = posterior(rows[i], j);
     return out;
 }
+// `seeds` (optional, not in the reference signature): the per-particle simulator seeds AbcSmc.cpp:535 draws with
+// gsl_rng_get after the proposals; when asked for they are produced by the same call and the stream advances
+// past them (DESIGN.md "Declared deviations": the Gaussian noise does not consume the taus2 stream).
 inline Mat2D sample_mvn_predictive_priors(const RNG* rng, const size_t num_samples, const Col& weights,
                                           const Mat2D& parameter_prior, const std::vector<const Parameter*>& pars,
-                                          const Mat2D& L) {
+                                          const Mat2D& L, std::vector<unsigned long>* seeds = nullptr) {
     Mat2D out(num_samples, parameter_prior.cols());
     const std::vector<abc_prior> pr = to_pod(pars);
+    std::vector<uint64_t> sd(seeds ? num_samples : 0);
     check(abc_sample_mvn_predictive_priors(context(), &rng->state, num_samples, weights.data(), parameter_prior.data(),
                                            parameter_prior.rows(), parameter_prior.cols(), pr.data(), L.data(),
-                                           out.data(), nullptr, nullptr));
+                                           out.data(), nullptr, seeds ? sd.data() : nullptr));
+    if (seeds) seeds->assign(sd.begin(), sd.end());
     return out;
 }
 inline Mat2D sample_predictive_priors(const RNG* rng, const size_t num_samples, const Col& weights,
                                       const Mat2D& parameter_prior, const std::vector<const Parameter*>& pars,
-                                      const Row& doubled_variance) {
+                                      const Row& doubled_variance, std::vector<unsigned long>* seeds = nullptr) {
     Mat2D out(num_samples, parameter_prior.cols());
     const std::vector<abc_prior> pr = to_pod(pars);
+    std::vector<uint64_t> sd(seeds ? num_samples : 0);
     check(abc_sample_predictive_priors(context(), &rng->state, num_samples, weights.data(), parameter_prior.data(),
                                        parameter_prior.rows(), parameter_prior.cols(), pr.data(),
-                                       doubled_variance.data(), out.data(), nullptr, nullptr));
+                                       doubled_variance.data(), out.data(), nullptr, seeds ? sd.data() : nullptr));
+    if (seeds) seeds->assign(sd.begin(), sd.end());
     return out;
 }
 
@@ -181,6 +317,60 @@ inline Col euclidean(const Mat2D& sims, const Row& ref) {
     }
     return d;
 }
+
+// ---- host-side helpers of the shell (one-off or O(K) work; not on the per-generation device path) --------
+// AbcUtil.cpp:490-526: set 0 (and projection mode): every non-posterior parameter is sampled in order, then the
+// posterior cursor; the posterior columns are filled from the looked-up rows afterwards.
+inline Mat2D sample_priors(const RNG* rng, const size_t num_samples, const Mat2D& posterior,
+                           const std::vector<const Parameter*>& mpars, std::vector<size_t>& post_ranks) {
+    ParRNG par_rng(rng, mpars, posterior.rows());
+    Mat2D par_samples(num_samples, mpars.size());
+    std::vector<size_t> nonpost, post;
+    for (size_t j = 0; j < mpars.size(); j++) (mpars[j]->isPosterior() ? post : nonpost).push_back(j);
+    if (post.size() != posterior.cols()) throw std::invalid_argument("sample_priors: posterior columns != POSTERIOR parameters");
+    if (!post.empty()) post_ranks.resize(num_samples);
+    for (size_t i = 0; i < num_samples; i++) {
+        par_rng.unlock();
+        for (size_t j : nonpost) par_samples(i, j) = mpars[j]->sample(par_rng);
+        if (!post.empty()) post_ranks[i] = (size_t)mpars[post[0]]->sample(par_rng);
+    }
+    for (size_t c = 0; c < post.size(); c++)
+        for (size_t i = 0; i < num_samples; i++) par_samples(i, post[c]) = posterior(post_ranks[i], c);
+    return par_samples;
+}
+inline Mat2D select_rows(const Mat2D& m, const std::vector<size_t>& rows) {     // Eigen's m(rows, all)
+    Mat2D out(rows.size(), m.cols());
+    for (size_t j = 0; j < m.cols(); j++)
+        for (size_t i = 0; i < rows.size(); i++) out(i, j) = m(rows[i], j);
+    return out;
+}
+inline Row col_means(const Mat2D& m) {
+    Row mu(m.cols(), 0.0);
+    for (size_t j = 0; j < m.cols(); j++) {
+        double s = 0;
+        for (size_t i = 0; i < m.rows(); i++) s += m(i, j);
+        mu[j] = m.rows() ? s / (double)m.rows() : 0.0;
+    }
+    return mu;
+}
+inline float_type median(Col data) {                                            // AbcUtil.cpp:46-62
+    if (data.empty()) throw std::invalid_argument("median of an empty column");
+    std::sort(data.begin(), data.end());
+    const size_t n = data.size();
+    return (n % 2 == 0) ? (data[n / 2 - 1] + data[n / 2]) / 2 : data[n / 2];
+}
+inline float_type calculate_nrmse(const Mat2D& posterior_mets, const Row& observed) {   // AbcUtil.cpp:326-345
+    const Row sim = col_means(posterior_mets);
+    double acc = 0;
+    for (size_t i = 0; i < sim.size(); i++) {
+        double expected = (std::fabs(observed[i]) + std::fabs(sim[i])) / 2.0;
+        if (sim[i] == observed[i]) expected = 1;
+        const double d = (sim[i] - observed[i]) / expected;
+        acc += d * d;
+    }
+    return std::sqrt(acc / (double)sim.size());
+}
+inline float_type logistic(float_type t) { return 1.0 / (1.0 + std::exp(-t)); }
 
 }  // namespace ABC
 #endif

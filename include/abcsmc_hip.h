@@ -74,6 +74,10 @@ int  abc_version(void);
 int  abc_timing_enable(abc_ctx* ctx, int on);
 int  abc_timing_read(abc_ctx* ctx, const char** names, double* ms, double* host_ms, long long* count,
                      int max_stages, int reset);
+/* What an event pair around a single kernel reports beyond the kernel's own execution time (dispatch and
+ * end-of-kernel release latencies), measured with empty kernels on the context's stream.  bench.py reports the
+ * k_gram duration both raw and with this subtracted; rocprofv3's kernel duration is the arbiter. */
+int  abc_timing_overhead(abc_ctx* ctx, int reps, double* overhead_ms);
 
 /* ---- RNG (gsl_rng_set / gsl_rng_get on taus2) ------------------------------------------- */
 void     abc_rng_set(abc_rng* r, unsigned long seed);

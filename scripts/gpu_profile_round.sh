@@ -1,0 +1,31 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the bench lines and the rocprofv3 passes profiles/ is regenerated from.
+#   gpurun --timeout 1500 -- 'bash scripts/gpu_profile_round.sh'
+#   python scripts/summarize_profiles.py r01 prof_final pmcf        (back in the container)
+# Kernel stats and each PMC counter are collected in SEPARATE rocprofv3 runs (no trace domains next to --pmc), and the
+# program itself follows `--` (no env/bash hop after the profiler has initialised the GPU).
+set -u
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+python3 bench.py --config 2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+for c in 2 3; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_final_c$c" -o runc --output-format csv -- \
+      python3 "$ROOT/bench.py" --config $c --steps 5 --warmup 2 --no-cpu-baseline) > "$OUT/prof_final_c$c.log" 2>&1
+  (cd /tmp && rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmcf_fetch_c$c" -o runc --output-format csv -- \
+      python3 "$ROOT/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmcf_fetch_c$c.log" 2>&1
+  (cd /tmp && rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmcf_write_c$c" -o runc --output-format csv -- \
+      python3 "$ROOT/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmcf_write_c$c.log" 2>&1
+done
+(cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES \
+    -d "$OUT/pmcf_sq_c3" -o runc --output-format csv -- \
+    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmcf_sq_c3.log" 2>&1
+(cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+    -d "$OUT/pmcf_sq2_c3" -o runc --output-format csv -- \
+    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmcf_sq2_c3.log" 2>&1
+# trim what travels back: only the stats / counter CSVs are needed
+find "$OUT" -name '*_kernel_trace.csv' -size +8M -delete
+ls -la "$OUT"/prof_final_c3/runc* "$OUT"/pmcf_fetch_c3/runc* 2>/dev/null | head
+cat "$OUT/bench_default.json" "$OUT/bench_c2.json"

@@ -7,6 +7,10 @@ import csv, glob, json, re, shutil, sys
 tag, sp, pp = sys.argv[1], sys.argv[2], sys.argv[3]
 
 
+def find(d, suffix):
+    return sorted(glob.glob(d + '/**/*' + suffix, recursive=True))[0]
+
+
 def short(k):
     m = re.search(r'(k_[a-z0-9_]+(<[^>]*>)?)', k)
     return m.group(1) if m else k.split('(')[0].strip()
@@ -14,7 +18,7 @@ def short(k):
 
 def pmc(d, counter):
     out = {}
-    for r in csv.DictReader(open(glob.glob(d + '/runc/*_counter_collection.csv')[0])):
+    for r in csv.DictReader(open(find(d, 'counter_collection.csv'))):
         if r['Counter_Name'] == counter:
             out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in out.items()}
@@ -25,7 +29,7 @@ res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE pas
                 "(gfx950: FETCH_SIZE counts 64 B per 128-B request).", "configs": {}}
 rows = []
 for cfg in (2, 3):
-    shutil.copy(glob.glob('gpurun_out/%s_c%d/runc/*_kernel_stats.csv' % (sp, cfg))[0],
+    shutil.copy(find('gpurun_out/%s_c%d' % (sp, cfg), 'kernel_stats.csv'),
                 'profiles/%s_kernel_stats_config%d.csv' % (tag, cfg))
     fe, wr = pmc('gpurun_out/%s_fetch_c%d' % (pp, cfg), 'FETCH_SIZE'), pmc('gpurun_out/%s_write_c%d' % (pp, cfg), 'WRITE_SIZE')
     ent = {}
@@ -39,4 +43,28 @@ with open('profiles/%s_pmc_hbm_traffic.csv' % tag, 'w') as f:
     f.write("config,kernel,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB,hbm_bytes_corrected\n")
     for r in rows:
         f.write('%d,"%s",%.1f,%.1f,%.0f\n' % r)
-print("k_gram traffic:", {c: [v["hbm_bytes_per_launch"] for k, v in e.items() if k.startswith("k_gram<3")] for c, e in res["configs"].items()})
+print("k_gram traffic:", {c: [v["hbm_bytes_per_launch"] for k, v in e.items() if k.startswith(("k_gram<3", "k_gram_dma<3"))] for c, e in res["configs"].items()})
+
+# SQ counters of the Gram kernel (two passes: pmcf_sq_c3, pmcf_sq2_c3)
+sq = {}
+for d in ('gpurun_out/%s_sq_c3' % pp, 'gpurun_out/%s_sq2_c3' % pp):
+    try:
+        fs = [find(d, 'counter_collection.csv')]
+    except IndexError:
+        continue
+    acc = {}
+    for r in csv.DictReader(open(fs[0])):
+        if 'k_gram_dma<3' in r['Kernel_Name'] or 'k_gram<3' in r['Kernel_Name']:
+            acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+            sq['_kernel'] = short(r['Kernel_Name'])
+    for k, v in acc.items():
+        sq[k] = sum(v) / len(v)
+if sq:
+    sq['_note'] = ("rocprofv3 --pmc (two passes) on `python3 bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline`, per-dispatch "
+                   "averages; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)")
+    if 'GRBM_GUI_ACTIVE' in sq and 'SQ_VALU_MFMA_BUSY_CYCLES' in sq:
+        sq['MfmaUtil_percent'] = 100 * sq['SQ_VALU_MFMA_BUSY_CYCLES'] / (sq['GRBM_GUI_ACTIVE'] / 8 * 1024)
+    if 'SQ_WAIT_INST_ANY' in sq and 'SQ_WAVE_CYCLES' in sq:
+        sq['wait_fraction_of_wave_cycles'] = sq['SQ_WAIT_INST_ANY'] / sq['SQ_WAVE_CYCLES']
+    json.dump(sq, open('profiles/%s_pmc_sq_k_gram_config3.json' % tag, 'w'), indent=1, sort_keys=True)
+    print("sq:", sq)
