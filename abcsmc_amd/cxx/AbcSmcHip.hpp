@@ -21,7 +21,6 @@
 #include <cstdlib>
 #include <ctime>
 #include <fstream>
-#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -167,7 +166,7 @@ class AbcSmc {
         return (set_num < _smc_set_sizes.size()) ? _smc_set_sizes[set_num] : _smc_set_sizes.back();
     }
     size_t get_pred_prior_size_at(const size_t set_num) {
-        if (set_num >= _num_smc_sets) throw std::out_of_range("set_num out of range");
+        if (set_num >= _num_smc_sets || _predictive_prior_sizes.empty()) throw std::out_of_range("set_num out of range");
         return (set_num < _predictive_prior_sizes.size()) ? _predictive_prior_sizes[set_num] : _predictive_prior_sizes.back();
     }
     void set_smc_iterations(const size_t n) { _num_smc_sets = n; }
@@ -813,20 +812,21 @@ inline void AbcLog::filtering_report(AbcSmc* abc, const size_t t, const Mat2D& p
     for (auto m : abc->_model_mets) os << std::setw(WIDTH) << m->get_obs_val();
     os << std::endl;
     os << "Normalized RMSE for metric means (lower is better):  " << ABC::calculate_nrmse(pmets, abc->_met_vals) << std::endl;
-    auto row_of = [&](const char* title, const std::function<double(const Mat2D&, size_t)>& f) {
+    auto medians = [](const Mat2D& m) {
+        Row out(m.cols());
+        for (size_t j = 0; j < m.cols(); j++) out[j] = ABC::median(Col(m.data() + j * m.rows(), m.data() + (j + 1) * m.rows()));
+        return out;
+    };
+    auto row_of = [&](const char* title, const Row& a, const Row& b) {
         os << title << std::endl;
         table_header(abc, os);
-        for (size_t j = 0; j < ppars.cols(); j++) os << std::setw(WIDTH) << f(ppars, j);
+        for (double v : a) os << std::setw(WIDTH) << v;
         os << " | ";
-        for (size_t j = 0; j < pmets.cols(); j++) os << std::setw(WIDTH) << f(pmets, j);
+        for (double v : b) os << std::setw(WIDTH) << v;
         os << std::endl;
     };
-    row_of("Posterior means:", [](const Mat2D& m, size_t j) { return ABC::col_means(m)[j]; });
-    row_of("Posterior medians:", [](const Mat2D& m, size_t j) {
-        Col c(m.rows());
-        for (size_t i = 0; i < m.rows(); i++) c[i] = m(i, j);
-        return ABC::median(c);
-    });
+    row_of("Posterior means:", ABC::col_means(ppars), ABC::col_means(pmets));
+    row_of("Posterior medians:", medians(ppars), medians(pmets));
     auto rows = [&](const char* title, size_t first, size_t count) {
         os << title << std::endl;
         table_header(abc, os);

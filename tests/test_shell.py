@@ -1,0 +1,363 @@
+"""AbcSmc shell: JSON configuration, SQLite storage, set-0 sampling, the simulate step and
+the job status machine of abcsmc_amd/cxx/AbcSmcHip.hpp, driven through examples/abc_dice.cpp.
+
+CPU tests cover everything up to the first --process of a finished set (that step ranks on the GPU and must fail
+loudly here); the GPU test runs a whole four-set fit and re-derives every stored posterior rank with the oracle.
+Expected values are restated from the reference's sources: schema AbcSmc.cpp:819-834, set-0 order AbcUtil.cpp:515-521
+and AbcSmc.cpp:843-871, odometer ParRNG.h:54-66, status machine AbcSmc.cpp:948-1037, exit codes as cited inline."""
+import json
+import math
+import os
+import sqlite3
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "abcsmc_amd")
+
+
+def _compile(src, exe):
+    subprocess.check_call(["g++", "-std=c++17", "-O1", src, "-o", exe, "-L" + LIBDIR, "-labcsmc_hip", "-ldl",
+                           "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def dice(tmp_path_factory):
+    if not os.path.exists(os.path.join(LIBDIR, "libabcsmc_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    d = tmp_path_factory.mktemp("shellbin")
+    return _compile(os.path.join(ROOT, "examples", "abc_dice.cpp"), str(d / "abc_dice"))
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory, dice):
+    d = tmp_path_factory.mktemp("probebin")
+    return _compile(os.path.join(ROOT, "tests", "cxx", "shell_probe.cpp"), str(d / "shell_probe"))
+
+
+DICE = {
+    "smc_iterations": 4,
+    "num_samples": [300, 400],
+    "predictive_prior_fraction": 0.25,
+    "pls_training_fraction": 0.5,
+    "noise": "MULTIVARIATE",
+    "parameters": [
+        {"name": "number of dice", "short_name": "ndice", "dist_type": "UNIFORM", "num_type": "INT", "par1": 1, "par2": 1000},
+        {"name": "number of sides", "short_name": "sides", "dist_type": "UNIFORM", "num_type": "INT", "par1": 1, "par2": 1000},
+    ],
+    "metrics": [
+        {"name": "sum", "num_type": "INT", "value": 44},
+        {"name": "sd", "num_type": "FLOAT", "value": 2.39925},
+    ],
+}
+
+
+def write_cfg(tmp_path, cfg, name="config.json", **over):
+    c = json.loads(json.dumps(cfg))
+    c.update(over)
+    c.setdefault("database_filename", str(tmp_path / "abc.sqlite"))
+    p = tmp_path / name
+    # the reference's configuration files carry comments (jsoncpp accepts them)
+    p.write_text("// fit configuration\n" + json.dumps(c, indent=2) + "\n/* end */\n")
+    return str(p), c["database_filename"]
+
+
+def run(exe, *args, check=True):
+    r = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=600)
+    if check:
+        assert r.returncode == 0, r.stderr[-2000:]
+    return r
+
+
+def six(v):
+    """the shell stores doubles through a default-formatted ostream: 6 significant digits"""
+    return float("%.6g" % v)
+
+
+def dice_metrics(ndice, sides, seed):
+    r = orc.rng(seed)
+    rolls = np.array([orc.rng_uniform_int(r, sides) + 1 for _ in range(ndice)], dtype=np.float64)
+    sd = float(np.sqrt(((rolls - rolls.mean()) ** 2).sum() / (ndice - 1))) if ndice > 1 else 0.0
+    return float(rolls.sum()), sd
+
+
+def test_first_set_schema_and_stream(dice, tmp_path):
+    cfg, db = write_cfg(tmp_path, DICE)
+    run(dice, cfg, "--process", "--seed", "7")
+    c = sqlite3.connect(db)
+    sql = {r[0]: " ".join(r[1].split()) for r in c.execute("select name, sql from sqlite_master where sql is not null")}
+    assert sql["job"] == ("CREATE TABLE job ( serial int primary key asc, smcSet int, particleIdx int, startTime int, "
+                          "duration real, status text, posterior int, attempts int )")
+    assert sql["idx1"] == "CREATE INDEX idx1 on job (status, attempts)"
+    assert sql["par"] == "CREATE TABLE par ( serial int primary key, seed blob, ndice real, sides real )"
+    assert sql["met"] == "CREATE TABLE met ( serial int primary key, sum real, sd real )"
+    assert "upar" not in sql
+    # set 0: for each particle every parameter in order, THEN one seed per particle
+    r = orc.rng(7)
+    want = [(orc.rng_uniform_int(r, 1000) + 1, orc.rng_uniform_int(r, 1000) + 1) for _ in range(300)]
+    seeds = [orc.rng_get(r) for _ in range(300)]
+    rows = c.execute("select serial, seed, ndice, sides from par order by serial").fetchall()
+    assert [(int(a), int(b)) for _, _, a, b in rows] == want
+    assert [int(s) for _, s, _, _ in rows] == seeds
+    assert [r[0] for r in rows] == list(range(300))
+    jobs = c.execute("select serial, smcSet, particleIdx, duration, status, posterior, attempts from job order by serial").fetchall()
+    assert jobs == [(i, 0, i, None, "Q", -1, 0) for i in range(300)]
+    assert c.execute("select count(*) from met where sum is null and sd is null").fetchone()[0] == 300
+    # a second --process on an unfinished set must refuse (AbcSmc.cpp:579-582) and leave the database alone
+    out = run(dice, cfg, "--process", "--seed", "8")
+    assert "not all particles are complete in set 0" in out.stderr
+    assert c.execute("select count(*) from job").fetchone()[0] == 300
+
+
+def test_simulate_status_machine(dice, tmp_path):
+    cfg, db = write_cfg(tmp_path, DICE)
+    run(dice, cfg, "--process", "--seed", "3")
+    c = sqlite3.connect(db)
+    run(dice, cfg, "--simulate", "-n", "120")
+    assert dict(c.execute("select status, count(*) from job group by status")) == {"D": 120, "Q": 180}
+    assert c.execute("select max(serial) from job where status = 'D'").fetchone()[0] == 119      # queue order
+    # a paused job is skipped by the queue but still takes results when asked for by serial (AbcSmc.cpp:966-972, 1006-1008)
+    c.execute("update job set status = 'P' where serial = 200")
+    c.commit()
+    run(dice, cfg, "--simulate", "-n", "1000")
+    assert dict(c.execute("select status, count(*) from job group by status")) == {"D": 299, "P": 1}
+    for serial, seed, nd, sd_, s, m in c.execute("select P.serial, P.seed, ndice, sides, sum, sd from par P, met M where "
+                                                  "P.serial = M.serial and P.serial != 200"):
+        es, esd = dice_metrics(int(nd), int(sd_), int(seed))
+        assert s == six(es) and m == pytest.approx(six(esd), rel=1e-12), serial
+    assert c.execute("select min(attempts), max(attempts) from job where serial != 200").fetchone() == (1, 1)
+    assert c.execute("select count(*) from job where duration is null").fetchone()[0] == 1
+    # nothing left: another call is a no-op
+    run(dice, cfg, "--simulate", "-n", "10")
+    assert c.execute("select max(attempts) from job").fetchone()[0] == 1
+
+
+def test_process_needs_the_gpu(dice, tmp_path):
+    """ranking a finished set is the HIP path: on a machine without the device the shell reports and exits non-zero,
+    it never computes on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg, db = write_cfg(tmp_path, DICE)
+    run(dice, cfg, "--process", "--seed", "3")
+    run(dice, cfg, "--simulate", "-n", "300")
+    r = run(dice, cfg, "--process", "--seed", "4", check=False)
+    assert r.returncode == 3 and "HIP path failed" in r.stderr
+    c = sqlite3.connect(db)
+    assert c.execute("select count(*) from job where posterior > -1").fetchone()[0] == 0
+
+
+def test_iteration_rules(probe, tmp_path):
+    def sizes(**over):
+        base = {k: v for k, v in DICE.items() if k not in ("predictive_prior_fraction", "smc_iterations", "num_samples")}
+        cfg, _ = write_cfg(tmp_path, base, **over)
+        r = run(probe, cfg, "x", check=False)
+        out = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines()) if r.returncode == 0 else {}
+        return r, out
+
+    # fractions: both lists extended by their last entry, sizes rounded (AbcSmc.cpp:100-111); iterations default to
+    # the longer list (:128)
+    r, o = sizes(num_samples=[300, 500, 750], predictive_prior_fraction=[0.5, 0.1])
+    assert o["iterations"] == "3" and o["set_sizes"] == "300 500 750" and o["pred_prior_sizes"] == "150 50 75"
+    r, o = sizes(num_samples=101, predictive_prior_fraction=0.5, smc_iterations=3)
+    assert o["set_sizes"] == "101 101 101" and o["pred_prior_sizes"] == "51 51 51"     # round half away from zero
+    r, o = sizes(num_samples=[200, 100], predictive_prior_size=[50, 40, 30], smc_iterations=5)
+    assert o["pred_prior_sizes"] == "50 40 30 30 30" and o["set_sizes"] == "200 100 100 100 100"
+    # errors: both / neither size option, predictive prior larger than its set, fraction outside (0,1], training
+    # fraction outside (0,1): exit(1) (AbcSmc.cpp:84-98, 112-126)
+    for over in (dict(num_samples=100), dict(num_samples=100, predictive_prior_fraction=0.5, predictive_prior_size=10),
+                 dict(num_samples=[100, 20], predictive_prior_size=[10, 30]),
+                 dict(num_samples=100, predictive_prior_fraction=1.5),
+                 dict(num_samples=100, predictive_prior_fraction=0.5, pls_training_fraction=1.0)):
+        r, _ = sizes(**over)
+        assert r.returncode == 1, over
+    r, _ = sizes(num_samples=100, predictive_prior_fraction=0.5, noise="CORRELATED")
+    assert r.returncode == (-210) % 256                                               # AbcSmc.cpp:424-427
+    bad = json.loads(json.dumps(DICE))
+    bad["parameters"][0]["dist_type"] = "CAUCHY"
+    cfg, _ = write_cfg(tmp_path, bad, name="bad.json")
+    assert run(probe, cfg, check=False).returncode == (-205) % 256                    # :270-272
+    bad = json.loads(json.dumps(DICE))
+    bad["metrics"][0]["num_type"] = "COMPLEX"
+    cfg, _ = write_cfg(tmp_path, bad, name="bad2.json")
+    assert run(probe, cfg, check=False).returncode == (-209) % 256                    # :147-150
+    (tmp_path / "broken.json").write_text('{"parameters": [ {"name": ] }')
+    assert run(probe, str(tmp_path / "broken.json"), check=False).returncode == 1     # :284-288
+    assert run(probe, str(tmp_path / "missing.json"), check=False).returncode == 1    # :277-280
+
+
+def test_pseudo_grid_and_transforms(dice, probe, tmp_path):
+    """projection mode: PSEUDO parameters enumerate their grid with the FIRST parameter fastest (ParRNG.h:54-66,
+    tests/ParRNG.test.cpp), one set, no predictive prior; `untransform` creates the upar table the simulator reads"""
+    cfg = {
+        "parameters": [
+            {"name": "number of dice", "short_name": "ndice", "dist_type": "PSEUDO", "num_type": "INT", "par1": 1, "par2": 5},
+            {"name": "number of sides", "short_name": "sides", "dist_type": "PSEUDO", "num_type": "INT", "vals": [2, 4, 6, 8, 10]},
+            {"name": "unused", "dist_type": "PSEUDO", "num_type": "FLOAT", "par1": 0.5, "par2": 1.0, "step": 0.25},
+        ],
+        "metrics": DICE["metrics"],
+    }
+    path, db = write_cfg(tmp_path, cfg)
+    out = run(probe, path).stdout
+    assert "iterations 1" in out and "set_sizes 75" in out
+    run(dice, path, "--process", "--seed", "5")
+    c = sqlite3.connect(db)
+    rows = c.execute("select ndice, sides, unused from par order by serial").fetchall()
+    want = [(float(a), float(b), u) for u in (0.5, 0.75, 1.0) for b in (2, 4, 6, 8, 10) for a in (1, 2, 3, 4, 5)]
+    assert rows == want
+    r = run(probe, write_cfg(tmp_path, cfg, name="c2.json", num_samples=74)[0], check=False)
+    assert r.returncode == (-201) % 256                                               # AbcSmc.cpp:69-73
+    r = run(probe, write_cfg(tmp_path, cfg, name="c3.json", smc_iterations=2)[0], check=False)
+    assert r.returncode == (-202) % 256                                               # :63-66
+
+    # transforms (AbcSmc.cpp:154-210, ParXform.h:25-37): POW_10 as a string; a LOGISTIC object with bounds and an
+    # untransformed factor
+    tcfg = json.loads(json.dumps(DICE))
+    tcfg["parameters"] = [
+        {"name": "log dice", "short_name": "ldice", "dist_type": "UNIFORM", "num_type": "FLOAT", "par1": 0, "par2": 2, "untransform": "POW_10"},
+        {"name": "sides", "dist_type": "UNIFORM", "num_type": "INT", "par1": 2, "par2": 12},
+        {"name": "frac", "dist_type": "NORMAL", "num_type": "FLOAT", "par1": 0, "par2": 1,
+         "untransform": {"type": "LOGISTIC", "min": 1, "max": 3, "untransformed_factor": ["sides"]}},
+    ]
+    path, db = write_cfg(tmp_path, tcfg, name="t.json", database_filename=str(tmp_path / "t.sqlite"))
+    run(dice, path, "--process", "--seed", "9")
+    c = sqlite3.connect(db)
+    assert c.execute("select count(*) from upar").fetchone()[0] == 300
+    r = orc.rng(9)
+    for (s1, ld, sides, fr), (s2, u0, u1, u2) in zip(c.execute("select serial, ldice, sides, frac from par order by serial"),
+                                                   c.execute("select serial, ldice, sides, frac from upar order by serial")):
+        e0 = orc.rng_uniform(r) * 2.0
+        e1 = orc.rng_uniform_int(r, 11) + 2
+        e2 = orc.ran_gaussian(r, 1.0) + 0.0
+        assert (ld, sides, fr) == (six(e0), float(e1), six(e2)) and s1 == s2
+        assert u0 == six(10.0 ** e0) and u1 == float(e1)
+        assert u2 == six((3 - 1) * ((1.0 / (1.0 + math.exp(-e2))) * e1) + 1)
+
+
+def test_configured_simulators(dice, tmp_path):
+    """`shared` (dlopen + the `simulator` symbol, AbcSim.h:62-76, 106-117) and `executable` (parameters as arguments,
+    metrics on stdout, AbcSim.h:122-157); an unset simulator exits 100 (AbcSim.h:45-52), a missing object 101, a
+    missing symbol 102, a wrong metric count -211 (AbcSmc.cpp:998)"""
+    src = tmp_path / "sim.cpp"
+    src.write_text('#include <vector>\nextern "C" std::vector<double> simulator(std::vector<double> p, const unsigned long seed, '
+                   'const unsigned long serial) { return {p[0] + p[1], (double)(seed % 1000) + 0.5}; }\n'
+                   'extern "C" int unrelated() { return 0; }\n')
+    so = str(tmp_path / "libsim.so")
+    subprocess.check_call(["g++", "-std=c++17", "-shared", "-fPIC", str(src), "-o", so])
+    cfg, db = write_cfg(tmp_path, DICE, name="so.json", shared=so, database_filename=str(tmp_path / "so.sqlite"))
+    run(dice, cfg, "--process", "--seed", "2", "--configured-simulator")
+    run(dice, cfg, "--simulate", "-n", "50", "--configured-simulator")
+    c = sqlite3.connect(db)
+    rows = c.execute("select seed, ndice, sides, sum, sd from par P, met M where P.serial = M.serial and sum is not null").fetchall()
+    assert len(rows) == 50
+    for seed, a, b, s_, d in rows:
+        assert s_ == a + b and d == int(seed) % 1000 + 0.5
+
+    script = tmp_path / "sim.sh"
+    script.write_text("#!/bin/sh\necho $(( $1 * 2 )) $2.25\n")
+    script.chmod(0o755)
+    cfg, db = write_cfg(tmp_path, DICE, name="ex.json", executable=str(script), database_filename=str(tmp_path / "ex.sqlite"))
+    run(dice, cfg, "--process", "--seed", "2", "--configured-simulator")
+    run(dice, cfg, "--simulate", "-n", "20", "--configured-simulator")
+    c = sqlite3.connect(db)
+    rows = c.execute("select ndice, sides, sum, sd from par P, met M where P.serial = M.serial and sum is not null").fetchall()
+    assert len(rows) == 20
+    for a, b, s_, d in rows:
+        assert s_ == 2 * a and d == b + 0.25
+
+    cfg, db = write_cfg(tmp_path, DICE, name="unset.json", database_filename=str(tmp_path / "unset.sqlite"))
+    run(dice, cfg, "--process", "--seed", "2", "--configured-simulator")
+    assert run(dice, cfg, "--simulate", "--configured-simulator", check=False).returncode == 100
+    cfg, _ = write_cfg(tmp_path, DICE, name="noso.json", shared=str(tmp_path / "nope.so"))
+    assert run(dice, cfg, "--process", "--configured-simulator", check=False).returncode == 101
+    src.write_text('extern "C" int unrelated() { return 0; }\n')
+    subprocess.check_call(["g++", "-shared", "-fPIC", str(src), "-o", str(tmp_path / "libnosym.so")])
+    cfg, _ = write_cfg(tmp_path, DICE, name="nosym.json", shared=str(tmp_path / "libnosym.so"))
+    assert run(dice, cfg, "--process", "--configured-simulator", check=False).returncode == 102
+    script.write_text("#!/bin/sh\necho 1 2 3\n")
+    cfg, db = write_cfg(tmp_path, DICE, name="ex3.json", executable=str(script), database_filename=str(tmp_path / "ex3.sqlite"))
+    run(dice, cfg, "--process", "--seed", "2", "--configured-simulator")
+    assert run(dice, cfg, "--simulate", "--configured-simulator", check=False).returncode == (-211) % 256
+
+
+def test_posterior_projection(dice, tmp_path):
+    """POSTERIOR parameters replay the posterior rows of an earlier fit (AbcSmc.cpp:293-335, AbcUtil.cpp:515-523):
+    the PSEUDO odometer turns fastest, the posterior cursor advances when it wraps; retain_posterior_rank copies
+    the row index into job.posterior (AbcSmc.cpp:848-853)"""
+    src = str(tmp_path / "earlier.sqlite")
+    c = sqlite3.connect(src)
+    c.execute("create table job ( serial int primary key asc, smcSet int, particleIdx int, startTime int, duration real, status text, posterior int, attempts int )")
+    c.execute("create table par ( serial int primary key, seed blob, ndice real, sides real )")
+    post = {}
+    for serial in range(12):
+        rank = {2: 1, 5: 0, 7: 3, 11: 2}.get(serial, -1)
+        c.execute("insert into job values (?, 0, ?, 0, NULL, 'D', ?, 1)", (serial, serial, rank))
+        c.execute("insert into par values (?, '1', ?, ?)", (serial, 10.0 + serial, 100.0 + serial))
+        if rank > -1:
+            post[serial] = (10.0 + serial, 100.0 + serial)
+    c.commit()
+    cfg = {
+        "posterior_database_filename": src,
+        "retain_posterior_rank": True,
+        "parameters": [
+            {"name": "ndice", "dist_type": "POSTERIOR", "num_type": "INT", "par1": 0, "par2": 3},
+            {"name": "scale", "dist_type": "PSEUDO", "num_type": "FLOAT", "vals": [0.5, 2.0]},
+            {"name": "sides", "dist_type": "POSTERIOR", "num_type": "INT", "par1": 0, "par2": 3},
+        ],
+        "metrics": DICE["metrics"],
+    }
+    path, db = write_cfg(tmp_path, cfg)
+    run(dice, path, "--process", "--seed", "1")
+    d = sqlite3.connect(db)
+    rows = d.execute("select J.posterior, ndice, scale, sides from job J, par P where J.serial = P.serial order by J.serial").fetchall()
+    order = [post[s] for s in sorted(post)]                 # rows come in storage order, not rank order
+    want = [(i, order[i][0], sc, order[i][1]) for i in range(4) for sc in (0.5, 2.0)]
+    assert rows == want
+    cfg.pop("posterior_database_filename")
+    path, _ = write_cfg(tmp_path, cfg, name="nopost.json")
+    assert run(dice, path, "--process", check=False).returncode == (-204) % 256      # AbcSmc.cpp:382-385
+
+
+# ---- whole fit on the GPU -----------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_dice_fit_end_to_end(dice, tmp_path):
+    cfg, db = write_cfg(tmp_path, DICE)
+    r = run(dice, cfg, "--process", "--simulate", "--all", "--seed", "11")
+    assert "Database already contains 4 complete sets." in r.stderr      # the closing --process of the loop
+    c = sqlite3.connect(db)
+    sizes = [300, 400, 400, 400]
+    K = [75, 100, 100, 100]
+    assert c.execute("select smcSet, count(*) from job group by smcSet order by smcSet").fetchall() == list(enumerate(sizes))
+    assert c.execute("select count(*) from job where status != 'D'").fetchone()[0] == 0
+    err = []
+    for t, n in enumerate(sizes):
+        rows = c.execute("select J.particleIdx, J.posterior, P.seed, ndice, sides, sum, sd from job J, par P, met M where J.serial = P.serial "
+                         "and J.serial = M.serial and smcSet = ? order by particleIdx", (t,)).fetchall()
+        pars = np.array([[r[3], r[4]] for r in rows])
+        mets = np.array([[r[5], r[6]] for r in rows])
+        # proposals are valid under the integer priors (recast + rejection on the device)
+        assert np.all(pars == np.round(pars)) and pars.min() >= 1 and pars.max() <= 1000
+        # the stored ranks are the oracle's ranking of exactly what is in the database (bit-exact indices)
+        want = orc.particle_ranking_pls(mets, pars, np.array([44.0, 2.39925]), 0.5)["idx"][:K[t]]
+        got = sorted((r[1], r[0]) for r in rows if r[1] > -1)
+        assert [g[0] for g in got] == list(range(K[t]))
+        assert [g[1] for g in got] == [int(i) for i in want], "set %d" % t
+        if t > 0:
+            # simulator seeds: taus2(seed + t) outputs n .. 2n-1, after the n resampling draws
+            g = orc.rng(11 + t)
+            for _ in range(n):
+                orc.rng_get(g)
+            assert [int(r[2]) for r in rows] == [orc.rng_get(g) for _ in range(n)]
+        post = mets[[g[1] for g in got]]
+        err.append(float(np.abs(post[:, 0] - 44).mean()))
+    assert err[-1] < 0.2 * err[0], err            # the posterior closes in on the observed sum
+    # a finished fit: --process reports and changes nothing
+    r = run(dice, cfg, "--process", "--seed", "1")
+    assert "Database already contains 4 complete sets." in r.stderr
+    assert c.execute("select count(*) from job").fetchone()[0] == sum(sizes)
