@@ -90,6 +90,7 @@ SIGNATURES = {
     "abc_select_count_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "abc_select_compact_dev": (_i, [_vp, _vp, _sz, _vp, _u64, _u64, _u64, _vp, _vp]),
     "abc_sort_pairs_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "abc_merge_sorted_runs_dev": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),
     "abc_gather_rows_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _sz, _u64, _vp, _sz]),
     "abc_doubled_variance_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "abc_weights_raw_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),

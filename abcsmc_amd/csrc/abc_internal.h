@@ -145,6 +145,7 @@ int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, siz
                             size_t A, const double* model, int simple, double* dist);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out);
+int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
 // distributed radix select stages (state: 8 x int64, hist: 2048 x int32, all-reduced by the caller between hist and pick)
 int launch_select_begin(abc_ctx*, uint64_t K, long long* state, int* hist);

@@ -296,6 +296,14 @@ extern "C" int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size
     return launch_sort_pairs(ctx, key, idx, n);
 }
 
+extern "C" int abc_merge_sorted_runs_dev(abc_ctx* ctx, const double* key, const uint64_t* idx, int n_runs, size_t run_len,
+                                        double* key_out, uint64_t* idx_out) {
+    CHECK_CTX(ctx);
+    if (!key || !idx || !key_out || !idx_out || key == key_out || idx == idx_out)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "merge: null or aliased buffers");
+    return launch_merge_runs(ctx, key, idx, n_runs, run_len, key_out, idx_out);
+}
+
 extern "C" int abc_gather_rows_dev(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P,
                                    const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt) {
     CHECK_CTX(ctx);

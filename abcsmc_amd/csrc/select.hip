@@ -474,6 +474,46 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
     return ABC_OK;
 }
 
+// ---- merge of W sorted runs (sharded winners): rank every element by binary searches in the other runs ----------
+// Run q occupies [q*len, (q+1)*len), sorted by (key, idx) with idx ascending in q: equal keys keep run order
+// (elements of a lower run first), i.e. the result equals a stable sort of the concatenation.
+__global__ __launch_bounds__(256) void k_merge_runs(const double* __restrict__ key, const unsigned long long* __restrict__ idx,
+                                                    int W, size_t len, double* __restrict__ okey,
+                                                    unsigned long long* __restrict__ oidx) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)W * len) return;
+    const int q = (int)(t / len);
+    const size_t i = t - (size_t)q * len;
+    const double d = key[t];
+    const unsigned long long x = key_of(d);
+    size_t pos = i;
+    for (int r = 0; r < W; r++) {
+        if (r == q) continue;
+        const double* run = key + (size_t)r * len;
+        size_t lo = 0, hi = len;                       // first element of run r that must come after x
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            const unsigned long long y = key_of(run[mid]);
+            const bool before = (r < q) ? (y <= x) : (y < x);
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        pos += lo;
+    }
+    okey[pos] = d;
+    oidx[pos] = idx[t];
+}
+
+int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx) {
+    if (W < 1) ABC_FAIL(ctx, ABC_ERR_INVALID, "merge: W = %d", W);
+    const size_t n = (size_t)W * len;
+    if (n == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_SORT);
+    hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key,
+                       (const unsigned long long*)idx, W, len, okey, (unsigned long long*)oidx);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
 int launch_sort_pairs(abc_ctx* ctx, double* key, uint64_t* idx, size_t n) {
     if (n <= 1) return ABC_OK;
     unsigned long long* key0 = (unsigned long long*)abc_ws_alloc(ctx, n * 8);

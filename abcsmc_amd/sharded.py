@@ -80,6 +80,10 @@ class HipBackend:
     def sort_pairs(self, key, idx):
         self.ctx.check(lib().abc_sort_pairs_dev(self._s(), key.data_ptr(), idx.data_ptr(), key.numel()))
 
+    def merge_runs(self, key, idx, n_runs, run_len, key_out, idx_out):
+        self.ctx.check(lib().abc_merge_sorted_runs_dev(self._s(), key.data_ptr(), idx.data_ptr(), n_runs, run_len,
+                                                       key_out.data_ptr(), idx_out.data_ptr()))
+
     # distributed radix select (histograms are all-reduced by the driver between hist and pick)
     def select_begin(self, K, state, hist):
         self.ctx.check(lib().abc_select_begin_dev(self._s(), K, state.data_ptr(), hist.data_ptr()))
@@ -153,6 +157,8 @@ class ShardedGeneration:
         self.dist_local = be.empty(n_local)
         self.cand_idx = be.empty(self.k_local * self.world, torch.int64)
         self.cand_dist = be.empty(self.k_local * self.world)
+        self.merged_idx = be.empty(self.k_local * self.world, torch.int64)
+        self.merged_dist = be.empty(self.k_local * self.world)
         self.loc_idx = be.empty(self.k_local, torch.int64)
         self.loc_dist = be.empty(self.k_local)
         self.sel_state = be.zeros(8, torch.int64)
@@ -222,15 +228,19 @@ class ShardedGeneration:
             nw = [less[q] + take[q] for q in range(W)]
             maxw = max(nw)
             be.select_compact(self.dist_local, self.sel_state, less[r], take[r], row0, self.loc_idx, self.loc_dist)
+            if nw[r] > 1:                             # every rank sorts its own winners (stable: ties stay in row order)
+                be.sort_pairs(self.loc_dist[:nw[r]], self.loc_idx[:nw[r]])
             if nw[r] < maxw:                          # pad to the common length with sentinels that sort last
                 self.loc_idx[nw[r]:maxw].fill_(1 << 62)
                 self.loc_dist[nw[r]:maxw].fill_(float("inf"))
             cidx, cdist = self.cand_idx[:W * maxw], self.cand_dist[:W * maxw]
             dist.all_gather_into_tensor(cidx, self.loc_idx[:maxw], group=self.group)
             dist.all_gather_into_tensor(cdist, self.loc_dist[:maxw], group=self.group)
-            be.sort_pairs(cdist, cidx)                # stable: equal distances stay in global row order
-            self.idx.copy_(cidx[:K])
-            self.dist.copy_(cdist[:K])
+            # W sorted runs -> one sequence; equal distances: lower rank (= lower global rows) first
+            midx, mdist = self.merged_idx[:W * maxw], self.merged_dist[:W * maxw]
+            be.merge_runs(cdist, cidx, W, maxw, mdist, midx)
+            self.idx.copy_(midx[:K])
+            self.dist.copy_(mdist[:K])
         else:
             be.select_smallest(self.dist_local, self.k_local, row0, self.loc_idx, self.loc_dist)
             self.idx.copy_(self.loc_idx[:K])

@@ -221,6 +221,10 @@ int abc_select_compact_dev(abc_ctx* ctx, const double* dist, size_t n, const int
                            uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out);
 /* sort n (key, idx) pairs by (key, idx); used to merge per-shard winners */
 int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size_t n);
+/* merge n_runs runs of run_len pairs, each sorted by (key, idx), laid out back to back, into one sorted
+ * sequence (ties: lower run first = a stable sort of the concatenation).  Out-of-place. */
+int abc_merge_sorted_runs_dev(abc_ctx* ctx, const double* key, const uint64_t* idx, int n_runs, size_t run_len,
+                              double* key_out, uint64_t* idx_out);
 /* theta[i, :] = Y[idx[i] - idx_base, :] for idx in [idx_base, idx_base + n_local), else untouched */
 int abc_gather_rows_dev(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P,
                         const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt);

@@ -203,6 +203,15 @@ class NumpyBackend:
         key.copy_(torch.from_numpy(k))
         idx.copy_(torch.from_numpy(i))
 
+    def merge_runs(self, key, idx, n_runs, run_len, key_out, idx_out):
+        k, i = _np(key)[:n_runs * run_len], _np(idx)[:n_runs * run_len]
+        for q in range(n_runs):      # precondition of the device kernel: every run sorted by (key, idx)
+            kk, ii = k[q * run_len:(q + 1) * run_len], i[q * run_len:(q + 1) * run_len]
+            assert np.all((kk[1:] > kk[:-1]) | ((kk[1:] == kk[:-1]) & (ii[1:] >= ii[:-1]))), "run %d not sorted" % q
+        o = np.argsort(k, kind="stable")
+        key_out.copy_(torch.from_numpy(k[o].copy()))
+        idx_out.copy_(torch.from_numpy(i[o].copy()))
+
     def gather_rows(self, Y, idx, idx_base, theta):
         P, n = Y.shape
         g = _np(idx) - idx_base

@@ -548,6 +548,20 @@ def test_distributed_select_protocol_with_ties(gpu_ctx, oracle):
             be.select_compact(shards[q], st[q], cnt[q][0], take[q], q * n_loc, io, do)
             idxs.append(io[:nw])
             dists.append(do[:nw])
+        # as the sharded driver does it: every shard sorts its own winners, pads to the longest run with sentinels,
+        # the runs are laid out back to back (the all-gather) and merged by ranking
+        maxw = max(max(i.numel() for i in idxs), 1)
+        ri, rd = be.zeros(W * maxw, torch.int64), be.zeros(W * maxw)
+        for q in range(W):
+            if idxs[q].numel() > 1:
+                be.sort_pairs(dists[q], idxs[q])
+            ri[q * maxw:(q + 1) * maxw].fill_(1 << 62)
+            rd[q * maxw:(q + 1) * maxw].fill_(float("inf"))
+            ri[q * maxw:q * maxw + idxs[q].numel()].copy_(idxs[q])
+            rd[q * maxw:q * maxw + idxs[q].numel()].copy_(dists[q])
+        mi, md = be.zeros(W * maxw, torch.int64), be.zeros(W * maxw)
+        be.merge_runs(rd, ri, W, maxw, md, mi)
+        # and the single stable sort of the concatenation it replaces
         ci, cd = torch.cat(idxs).contiguous(), torch.cat(dists).contiguous()
         assert ci.numel() == K
         be.sort_pairs(cd, ci)
@@ -555,6 +569,9 @@ def test_distributed_select_protocol_with_ties(gpu_ctx, oracle):
         ref = oracle.ordered(d)[:K]
         assert np.array_equal(ci.cpu().numpy().astype(np.uint64), ref), K
         assert np.array_equal(cd.cpu().numpy(), d[ref.astype(np.int64)])
+        assert np.array_equal(mi[:K].cpu().numpy().astype(np.uint64), ref), K
+        assert np.array_equal(md[:K].cpu().numpy(), d[ref.astype(np.int64)])
+        assert bool(torch.all(mi[K:] == (1 << 62))) and bool(torch.all(torch.isinf(md[K:])))
 
 
 # ---------------------------------------------------------------------------------------------------
