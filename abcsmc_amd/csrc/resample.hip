@@ -278,6 +278,80 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
         if (p < P) out[i + n * (size_t)p] = val[p];
 }
 
+// 32 < P <= 64: same draws and acceptance rule as k_perturb, but only the accumulators x[PP] live in registers;
+// the parent row is re-read (one cached line per 16 coordinates) and accepted coordinates are stored as they are
+// produced -- a rejected attempt is simply overwritten by the next one.
+template <int PP, bool MV>
+__global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const double* __restrict__ theta, size_t K, int P,
+                                                        const abc_prior* __restrict__ priors,
+                                                        const unsigned long long* __restrict__ parent,
+                                                        unsigned long long i0, size_t n,
+                                                        const double* __restrict__ L_or_dv, double* __restrict__ out) {
+    extern __shared__ double smem[];
+    double* sL = smem;                                  // MV: PP x PP, column-major, zero above the diagonal
+    abc_prior* sp = reinterpret_cast<abc_prior*>(smem + (MV ? PP * PP : PP));
+    if (MV) {
+        for (int e = threadIdx.x; e < PP * PP; e += 256) {
+            const int a = e % PP, b = e / PP;
+            sL[e] = (a < P && b < P && b <= a) ? L_or_dv[a + (size_t)P * b] : 0.0;
+        }
+    } else {
+        for (int e = threadIdx.x; e < PP; e += 256) sL[e] = (e < P) ? sqrt(L_or_dv[e]) : 0.0;
+    }
+    for (int p = threadIdx.x; p < PP; p += 256) {
+        abc_prior q; q.kind = ABC_PRIOR_UNIF_REAL; q.pad_ = 0; q.a = -1e300; q.b = 1e300;
+        sp[p] = (p < P) ? priors[p] : q;
+    }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long gi = i0 + i;
+    const double* mu = theta + (size_t)parent[i] * PP;
+    const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
+    if (MV) {
+        bool ok = false;
+        for (unsigned attempt = 0; attempt < MVN_MAX_TRIES && !ok; attempt++) {
+            double x[PP];
+#pragma unroll
+            for (int a = 0; a < PP; a++) x[a] = 0.0;
+#pragma unroll 1
+            for (int pr = 0; pr < PP / 2; pr++) {
+                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
+                double z0, z1;
+                normal2(philox(c, k0, k1), z0, z1);
+                const double* l0 = sL + PP * (2 * pr);
+                const double* l1 = l0 + PP;
+#pragma unroll
+                for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
+            }
+            ok = true;
+#pragma unroll
+            for (int a = 0; a < PP; a++) {
+                if (a < P) {
+                    const double v = d_recast(sp[a], x[a] + mu[a]);
+                    out[i + n * (size_t)a] = v;
+                    ok = ok && d_valid(sp[a], v);
+                }
+            }
+        }
+        if (!ok)
+            for (int p = 0; p < P; p++) out[i + n * (size_t)p] = mu[p];      // give up: keep the (valid) parent
+    } else {
+        for (int p = 0; p < P; p++) {
+            const double m = mu[p];
+            double v = 0.0; bool ok = false;
+            for (unsigned attempt = 0; attempt < 1000 && !ok; attempt++) {
+                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0x80000000u | (uint32_t)p;
+                double z0, z1;
+                normal2(philox(c, k0, k1), z0, z1);
+                v = d_recast(sp[p], sL[p] * z0 + m);
+                ok = d_valid(sp[p], v);
+            }
+            out[i + n * (size_t)p] = ok ? v : d_prior_mean(sp[p]);
+        }
+    }
+}
+
 int ensure_jump_tab(abc_ctx* ctx) {
     if (ctx->jump_tab) return ABC_OK;
     const BitMat(*tab)[3] = taus_pow2();
@@ -300,32 +374,44 @@ int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
 }
 
 // [GSL] gsl_ran_discrete_preproc (randist/discrete.c): Walker alias with two LIFO stacks.
-// scratch: K doubles (E) + 2 K uint32 (the stacks), caller-provided so the hot loop never allocates.
+// scratch: K doubles (E) + 2 (K + 1) uint32 (the stacks), caller-provided so the hot loop never allocates.
 void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs) {
+    // Same sequence of floating-point operations as GSL's loop (sequential total, E = w / total, one subtraction
+    // per small from the big on top of the stack); only the bookkeeping differs: a big that stays big after serving
+    // a small is pushed and popped again at once upstream, here it simply stays in registers.
     double total = 0.0;
     for (size_t k = 0; k < K; k++) total += w[k];
-    const double mean = 1.0 / (double)K;
+    const double mean = 1.0 / (double)K, dK = (double)K;
+    for (size_t k = 0; k < K; k++) E[k] = w[k] / total;
     size_t ns = 0, nb = 0;
-    for (size_t k = 0; k < K; k++) {
-        const double e = w[k] / total;
-        E[k] = e;
-        if (e < mean) smalls[ns++] = (uint32_t)k; else bigs[nb++] = (uint32_t)k;
+    for (size_t k = 0; k < K; k++) {          // both stacks in index order; scratch holds K + 1 entries each
+        const bool sm = E[k] < mean;
+        smalls[ns] = (uint32_t)k;
+        bigs[nb] = (uint32_t)k;
+        ns += sm;
+        nb += !sm;
     }
+    bool have = false;
+    uint32_t cb = 0;
+    double eb = 0.0;
     while (ns) {
         const uint32_t s = smalls[--ns];
-        if (!nb) { A[s] = s; F[s] = 1.0; continue; }
-        const uint32_t b = bigs[--nb];
-        A[s] = b;
-        F[s] = (double)K * E[s];
-        const double d = mean - E[s];
-        E[s] += d;
-        E[b] -= d;
-        if (E[b] < mean) smalls[ns++] = b;
-        else if (E[b] > mean) bigs[nb++] = b;
-        else { A[b] = b; F[b] = 1.0; }
+        if (!have) {
+            if (!nb) { A[s] = s; F[s] = 1.0; continue; }
+            cb = bigs[--nb];
+            eb = E[cb];
+            have = true;
+        }
+        const double es = E[s];
+        A[s] = cb;
+        F[s] = dK * es;
+        eb -= mean - es;
+        if (eb < mean) { E[cb] = eb; smalls[ns++] = cb; have = false; }       // demoted: it is served next
+        else if (!(eb > mean)) { A[cb] = cb; F[cb] = 1.0; have = false; }     // exactly full
     }
+    if (have) { A[cb] = cb; F[cb] = 1.0; }
     while (nb) { const uint32_t b = bigs[--nb]; A[b] = b; F[b] = 1.0; }
-    for (size_t k = 0; k < K; k++) { F[k] += (double)k; F[k] /= (double)K; }
+    for (size_t k = 0; k < K; k++) F[k] = (F[k] + (double)k) / dK;            // KNUTH_CONVENTION
 }
 
 }  // namespace
@@ -335,13 +421,13 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     // alias table: weights to the host, serial Walker build, tables back to HBM
-    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3)));
+    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
     double* hw = (double*)ctx->pin;
     double* hF = hw + K;
     double* hE = hF + K;
     uint32_t* hA = (uint32_t*)(hE + K);
     uint32_t* hS = hA + K;
-    uint32_t* hB = hS + K;
+    uint32_t* hB = hS + K + 1;
     ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     {
@@ -376,7 +462,7 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
                    const uint64_t* parent, uint64_t i0, size_t n, int multivariate, const double* L_or_dv, double* out,
                    uint64_t* seeds, uint64_t seed_stream_offset) {
     if (n == 0) return ABC_OK;
-    if (P > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 32", P);
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 64", P);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     StageTimer tm(ctx, ST_PERTURB);
@@ -401,7 +487,20 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
         case 4: LAUNCH_PT(4); break;
         case 8: LAUNCH_PT(8); break;
         case 16: LAUNCH_PT(16); break;
-        default: LAUNCH_PT(32); break;
+        case 32: LAUNCH_PT(32); break;
+        default: {
+            hipLaunchKernelGGL((k_theta_rows<64>), dim3((unsigned)((K + 63) / 64)), dim3(256), 0, ctx->stream, theta_cm, K,
+                               (int)P, rows);
+            if (multivariate) {
+                const size_t lds = (64 * 64) * sizeof(double) + 64 * sizeof(abc_prior);
+                hipLaunchKernelGGL((k_perturb_stream<64, true>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
+                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);
+            } else {
+                const size_t lds = 64 * sizeof(double) + 64 * sizeof(abc_prior);
+                hipLaunchKernelGGL((k_perturb_stream<64, false>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
+                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);
+            }
+        } break;
     }
 #undef LAUNCH_PT
     ABC_HIP(ctx, hipGetLastError());

@@ -321,6 +321,46 @@ def test_sample_predictive_priors_independent(gpu_ctx, oracle):
         assert abs(out[:, p].std() / oout[:, p].std() - 1) < 0.02
 
 
+@pytest.mark.parametrize("multivariate", [True, False])
+def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate):
+    """33..64 parameters take the streaming perturb kernel: same parents, same support rules, same spread"""
+    from abcsmc_amd import abcutil, _lib
+    rng = np.random.default_rng(23)
+    K, P, n = 500, 48, 30000
+    cols, spec = [], []
+    for p in range(P):
+        if p % 3 == 0:
+            cols.append(rng.normal(p, 1.0, K)); spec.append((_lib.PRIOR_GAUSS, float(p), 5.0))
+        elif p % 3 == 1:
+            cols.append(np.round(rng.uniform(40, 60, K))); spec.append((_lib.PRIOR_UNIF_INT, 0, 100))
+        else:
+            cols.append(rng.uniform(0.3, 0.7, K)); spec.append((_lib.PRIOR_UNIF_REAL, 0.0, 1.0))
+    th = np.column_stack(cols)
+    w = rng.random(K)
+    r, o = abcutil.rng(77), oracle.rng(77)
+    if multivariate:
+        L = abcutil.setup_mvn_sampler(th, ctx=gpu_ctx)
+        out, parent = abcutil.sample_mvn_predictive_priors(r, n, w, th, _lib.make_priors(spec), L, ctx=gpu_ctx)[:2]
+        oout, opar, _ = oracle.sample_mvn_predictive_priors(o, n, w, th, oracle.make_priors(spec), L)
+    else:
+        dv = abcutil.calculate_doubled_variance(th, ctx=gpu_ctx)
+        out, parent = abcutil.sample_predictive_priors(r, n, w, th, _lib.make_priors(spec), dv, ctx=gpu_ctx)[:2]
+        oout, opar, _ = oracle.sample_predictive_priors(o, n, w, th, oracle.make_priors(spec), dv)
+    assert np.array_equal(parent, opar)
+    assert out.shape == (n, P) and np.all(np.isfinite(out))
+    for p in range(P):
+        if p % 3 == 1:
+            assert np.all(out[:, p] == np.round(out[:, p])) and out[:, p].min() >= 0 and out[:, p].max() <= 100
+        if p % 3 == 2:
+            assert out[:, p].min() >= 0.0 and out[:, p].max() <= 1.0
+        dg, do = out[:, p] - th[parent.astype(int), p], oout[:, p] - th[opar.astype(int), p]
+        assert abs(dg.std() / do.std() - 1) < 0.04, p
+        assert abs(dg.mean() - do.mean()) < 6 * do.std() / np.sqrt(n) + 1e-9, p
+    if multivariate:      # the proposal keeps the posterior's correlations
+        dg, do = out - th[parent.astype(int)], oout - th[opar.astype(int)]
+        assert np.allclose(np.corrcoef(dg[:, [0, 3, 6, 45]].T), np.corrcoef(do[:, [0, 3, 6, 45]].T), atol=0.04)
+
+
 # ---------------------------------------------------------------------------------------------------
 # whole generation, device resident (AbcSmc.cpp:634-664, 1041-1066, 490-518)
 # ---------------------------------------------------------------------------------------------------
