@@ -432,12 +432,9 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
     const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
-        attr_set = true;
-    }
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
@@ -466,12 +463,9 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
     if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
-        attr_set = true;
-    }
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram_dma<C, CY, NW>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
@@ -542,12 +536,9 @@ int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, s
             if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted");
             const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
             const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
-            static bool attr_set = false;
-            if (!attr_set) {
-                ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<6, 0, true>,
+            // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
+            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram<6, 0, true>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                attr_set = true;
-            }
             {
                 StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
                 hipLaunchKernelGGL((k_gram<6, 0, true>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream,

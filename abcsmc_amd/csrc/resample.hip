@@ -54,17 +54,18 @@ static void taus_step_mats(BitMat m[3]) {
         m[0].col[i] = taus_c1(1u << i); m[1].col[i] = taus_c2(1u << i); m[2].col[i] = taus_c3(1u << i);
     }
 }
-// pow2[k][c] = T_c^(2^k), k = 0..63
-static const BitMat (*taus_pow2())[3] {
-    static BitMat tab[64][3];
-    static bool init = false;
-    if (!init) {
+// pow2[k][c] = T_c^(2^k), k = 0..63 (built once; initialisation of a function-local static is thread-safe)
+struct TausPow2 {
+    BitMat tab[64][3];
+    TausPow2() {
         taus_step_mats(tab[0]);
         for (int k = 1; k < 64; k++)
             for (int c = 0; c < 3; c++) tab[k][c] = bm_mul(tab[k - 1][c], tab[k - 1][c]);
-        init = true;
     }
-    return tab;
+};
+static const BitMat (*taus_pow2())[3] {
+    static const TausPow2 t;
+    return t.tab;
 }
 void taus2_jump(abc_rng* r, uint64_t n) {
     const BitMat(*tab)[3] = taus_pow2();

@@ -3,8 +3,9 @@
 // The reference wraps SQLite in lib/sqdb (Db / Statement / Convertor, /root/reference/lib/sqdb/include/sqdb.h:126-206)
 // and ships sqlite3.h without the amalgamation.  This image has the runtime library (libsqlite3.so.0) but no
 // header, so the handful of C entry points used here are declared locally and resolved with dlopen at first use.
-// Kept from sqdb: a statement's next() retries once a second while the database is locked by another process
-// (lib/sqdb/src/sqdb.cpp:271-290); any other failure throws.
+// Kept from sqdb: a statement's next() waits and retries while the database is locked by another process
+// (lib/sqdb/src/sqdb.cpp:271-290); here compiling a statement does the same (it needs the schema, which an
+// exclusive transaction of another worker also locks).  Any other failure throws.
 #ifndef ABCSMC_AMD_SQLITEDYN_HPP
 #define ABCSMC_AMD_SQLITEDYN_HPP
 
@@ -74,6 +75,7 @@ struct Api {
     }
 };
 
+constexpr unsigned kBusyWaitUs = 100000;   // the reference sleeps a whole second between tries
 enum { SQLITE_OK_ = 0, SQLITE_BUSY_ = 5, SQLITE_ROW_ = 100, SQLITE_DONE_ = 101, SQLITE_NULL_ = 5 };
 
 class Db;
@@ -96,7 +98,7 @@ class Stmt {
             const int rc = Api::get().step(st_);
             if (rc == SQLITE_ROW_) return true;
             if (rc == SQLITE_DONE_) return false;
-            if (rc == SQLITE_BUSY_) { sleep(1); continue; }
+            if (rc == SQLITE_BUSY_) { usleep(kBusyWaitUs); continue; }
             throw Error(rc, Api::get().errmsg(db_));
         }
     }
@@ -131,7 +133,9 @@ class Db {
 
     Stmt query(const std::string& sql) {
         sqlite3_stmt* st = nullptr;
-        const int rc = Api::get().prepare_v2(db_, sql.c_str(), -1, &st, nullptr);
+        int rc;
+        // compiling a statement reads the schema, which another worker's exclusive transaction also blocks
+        while ((rc = Api::get().prepare_v2(db_, sql.c_str(), -1, &st, nullptr)) == SQLITE_BUSY_) usleep(kBusyWaitUs);
         if (rc != SQLITE_OK_) throw Error(rc, std::string(Api::get().errmsg(db_)) + " in: " + sql);
         return Stmt(db_, st);
     }

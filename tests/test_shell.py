@@ -138,6 +138,21 @@ def test_simulate_status_machine(dice, tmp_path):
     assert c.execute("select max(attempts) from job").fetchone()[0] == 1
 
 
+def test_concurrent_workers_share_one_database(dice, tmp_path):
+    """the reference's farm model: many `--simulate` workers on one file; BEGIN EXCLUSIVE + busy-retry
+    (AbcSmc.cpp:886, sqdb.cpp:271-290) hand every queued particle to exactly one of them"""
+    cfg, db = write_cfg(tmp_path, DICE)
+    run(dice, cfg, "--process", "--seed", "3")
+    procs = [subprocess.Popen([dice, cfg, "--simulate", "-n", "60"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+             for _ in range(4)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    c = sqlite3.connect(db)
+    assert dict(c.execute("select status, count(*) from job group by status")) == {"D": 240, "Q": 60}
+    assert c.execute("select min(attempts), max(attempts) from job where status = 'D'").fetchone() == (1, 1)
+    assert c.execute("select count(*) from met where sum is not null").fetchone()[0] == 240
+
+
 def test_process_needs_the_gpu(dice, tmp_path):
     """ranking a finished set is the HIP path: on a machine without the device the shell reports and exits non-zero,
     it never computes on the host"""
