@@ -145,6 +145,23 @@ int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, siz
                             size_t A, const double* model, int simple, double* dist);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out);
+// column slices of the weight kernel (weights.hip) and the bytes of partial sums they need; shared with the
+// workspace sizing in api.hip
+inline size_t abc_kde_slices(size_t kn, size_t Kp, int PP) {
+    if (kn == 0 || Kp == 0) return 1;
+    size_t rows_per_slice = 24576 / (size_t)PP;            // ~190 KB of scaled previous-set rows per slice
+    if (rows_per_slice < 256) rows_per_slice = 256;
+    size_t s = (Kp + rows_per_slice - 1) / rows_per_slice;
+    const size_t rb = (kn + 255) / 256;
+    if (s * rb < 4096) s = (4096 + rb - 1) / rb;           // small sets: still a few work-groups per resident slot
+    size_t cap = ((size_t)64 << 20) / (8 * kn);            // partial sums: slices x kn doubles <= 64 MB ...
+    if (cap < 8) cap = 8;                                  // ... but at least 8 slices
+    if (s > cap) s = cap;
+    if (s > Kp / 64) s = Kp / 64;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return s;
+}
 int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
 // distributed radix select stages (state: 8 x int64, hist: 2048 x int32, all-reduced by the caller between hist and pick)

@@ -52,7 +52,8 @@ static size_t ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t K
     b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
     b += K * P * 8 + K * 64 * 8;                                  // theta, and its row-major copy for the perturb gather
-    b += (K + Kp) * 64 * 8 + 1024 * 8 + 8 * ((K < 2048 ? 1024 * K : 8 * K) + 1024);   // weights
+    b += (K + Kp) * 64 * 8 + 1024 * 8;                            // weights: scaled copies of both sets
+    if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
     b += 64 * 256;                                                // alignment slack

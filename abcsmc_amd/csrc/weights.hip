@@ -10,9 +10,12 @@
 // with both parameter sets centred on one previous particle and pre-scaled by 1/sigma_p, and the squared
 // distance expanded as |a|^2 + |b|^2 - 2 a.b so a pair costs P FMAs + one exp:
 //   w'_j * exp(-1/2 |a_i - b_j|^2) = exp(a_i.b_j - 1/2|a_i|^2 - (1/2|b_j|^2 - ln w'_j)).
-// The exp is an inline range-reduced degree-10 polynomial (|rel err| < 3e-13, far inside the 1e-6
-// budget; ~17 instructions instead of ~40 for the library exp).  One new particle per lane;
-// previous-set rows are wave-uniform and stream through the scalar cache.  fp64 VALU throughout.
+// Both sets are additionally scaled by sqrt(log2 e), so the exponent comes out in base 2 and the exponential is
+//   2^x = 2^n * 2^f,  n = round(x) by the 1.5*2^52 addition (its low dword IS n), f = x - n in [-1/2, 1/2],
+// 2^f a degree-8 minimax polynomial (|rel err| < 7.8e-13, scripts/exp2_minimax.py; far inside the 1e-6 budget):
+// 13 instructions for the exponential, 30 per pair at P = 16, instead of ~40 for the library exp alone.
+// One new particle per lane; previous-set rows are wave-uniform and stream through the scalar cache.
+// fp64 VALU throughout.
 #include "abc_internal.h"
 
 namespace {
@@ -58,12 +61,17 @@ __global__ __launch_bounds__(256) void k_doubled_variance(const double* __restri
 
 // ---- weights --------------------------------------------------------------------------------------
 struct WConst {           // per-parameter constants, built on the device by k_wprep
-    double scale[64];     // 1/sqrt(dv_p), or 0 when dv_p == 0
+    double scale[64];     // sqrt(log2 e)/sqrt(dv_p), or 0 when dv_p == 0
     double logC;          // unused
     double C;             // prod over dv_p != 0 of 1/(sqrt(2 pi) sqrt(dv_p))
     int nzero;            // number of parameters with dv_p == 0
     int zero_idx[64];
+    int far;              // set by k_wscale when a scaled coordinate is so large that exponents may leave int32
 };
+
+constexpr double W_SQRT_LOG2E = 1.2011224087864497825;     // sqrt(log2 e): a.b then comes out in base 2
+constexpr double W_COORD_BOUND = 2000.0;                   // |x| <= 2 PP B^2 + 1e8 < 2^31 for PP <= 64
+constexpr double W_HB_MAX = 1.0e8;                         // stands for "weight 0": 2^-1e8 == 0
 
 __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc) {
     if (threadIdx.x != 0) return;
@@ -75,48 +83,52 @@ __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __res
             if (dv != 0.0) { const double sg = sqrt(dv); sc = 1.0 / sg; C *= 1.0 / (sqrt(2.0 * M_PI) * sg); }
             else wc->zero_idx[nz++] = p;
         }
-        wc->scale[p] = sc;
+        wc->scale[p] = sc * W_SQRT_LOG2E;
     }
-    wc->C = C; wc->nzero = nz; wc->logC = 0.0;
+    wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0;
 }
 
 // scaled copies: out[row*PP + p] = (in[row + ld*p] - centre[p]) * scale[p]   (row-major, zero padded to PP);
 // centre = first previous particle (differences are unchanged, magnitudes stay O(few sigma)).
-// If hb != NULL also hb[row] = 1/2 |out[row,:]|^2 - ln(w[row])  (the per-column part of the exponent).
+// If hb != NULL also hb[row] = 1/2 |out[row,:]|^2 - log2(w[row])  (the per-column part of the base-2 exponent),
+// capped at W_HB_MAX (w = 0 -> the term vanishes).  Rows further than W_COORD_BOUND from the centre raise wc->far.
 __global__ __launch_bounds__(256) void k_wscale(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP,
-                                                const WConst* __restrict__ wc, const double* __restrict__ centre,
+                                                WConst* __restrict__ wc, const double* __restrict__ centre,
                                                 size_t ldc, const double* __restrict__ w, double* __restrict__ out,
                                                 double* __restrict__ hb) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     double nn = 0.0;
+    bool far = false;
     for (int p = 0; p < PP; p++) {
         const double v = (p < P) ? (in[r + ld * p] - centre[ldc * p]) * wc->scale[p] : 0.0;
         out[r * PP + p] = v;
         nn = fma(v, v, nn);
+        far = far || (fabs(v) > W_COORD_BOUND);
     }
-    if (hb) hb[r] = 0.5 * nn - log(w[r]);
+    if (hb) {
+        const double h = 0.5 * nn - log2(w[r]);
+        hb[r] = (h > W_HB_MAX) ? W_HB_MAX : h;          // NaN stays NaN
+    }
+    if (far) atomicOr(&wc->far, 1);
 }
 
-// exp(x) for x <= 0 (clamped at -800 -> 0): Cody-Waite reduction x = n ln2 + r, degree-10 Taylor polynomial
-// on |r| <= ln2/2 (remainder < 2.2e-13), scaling by 2^n with v_ldexp_f64 (handles subnormal results).
-__device__ __forceinline__ double exp_neg(double x) {
-    x = fmax(x, -800.0);
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 2.7557319223985890653e-07;            // 1/10!
-    p = fma(p, r, 2.7557319223985892511e-06);        // 1/9!
-    p = fma(p, r, 2.4801587301587301566e-05);        // 1/8!
-    p = fma(p, r, 1.9841269841269841253e-04);        // 1/7!
-    p = fma(p, r, 1.3888888888888889419e-03);        // 1/6!
-    p = fma(p, r, 8.3333333333333332177e-03);        // 1/5!
-    p = fma(p, r, 4.1666666666666664354e-02);        // 1/4!
-    p = fma(p, r, 1.6666666666666665741e-01);        // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+// 2^x for x <= ~0.  SAFE = false requires |x| < 2^31 (guaranteed when wc->far == 0); SAFE = true clamps first.
+template <bool SAFE>
+__device__ __forceinline__ double exp2_neg(double x) {
+    if (SAFE) x = fmax(x, -1100.0);                       // 2^-1100 == 0 in double
+    const double tm = x + 6755399441055744.0;             // 1.5 * 2^52: rounds x to an integer in the low mantissa bits
+    const double f = x - (tm - 6755399441055744.0);       // [-1/2, 1/2], exact
+    double p = 0x1.61afced541895p-20;                     // scripts/exp2_minimax.py 8
+    p = fma(p, f, 0x1.00dad250bededp-16);
+    p = fma(p, f, 0x1.430acca32fd76p-13);
+    p = fma(p, f, 0x1.5d87483855455p-10);
+    p = fma(p, f, 0x1.3b2ab5c529311p-7);
+    p = fma(p, f, 0x1.c6b08dd46d38fp-5);
+    p = fma(p, f, 0x1.ebfbdff9319e1p-3);
+    p = fma(p, f, 0x1.62e42fef8615ep-1);
+    p = fma(p, f, 0x1.ffffffffff7a3p-1);
+    return ldexp(p, __double2loint(tm));                  // v_ldexp_f64: subnormal / zero results handled
 }
 
 // partial denominators: part[slice*kn + i] = sum_{j in slice} exp(a_i.b_j - 1/2|a_i|^2 - hb_j) [* zero-dv mask]
@@ -128,7 +140,9 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
                                              const double* __restrict__ prev_raw, double* __restrict__ part) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t slices = gridDim.y, sl = blockIdx.y;
-    const size_t j0 = Kp * sl / slices, j1 = Kp * (sl + 1) / slices;
+    // wave-uniform bounds in SGPRs (Kp < 2^32, checked by the launcher): the loop test stays off the vector pipe
+    const unsigned j0 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * sl / slices));
+    const unsigned j1 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * (sl + 1) / slices));
     const bool active = i < kn;
     double ai[PP];
     double ha = 0.0;
@@ -137,19 +151,33 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
     ha *= 0.5;
     const int nzero = wc->nzero;
     double acc = 0.0;
-    for (size_t j = j0; j < j1; j++) {
-        const double* bj = b + j * PP;
-        double e = -(ha + hb[j]);
+    if (nzero == 0 && wc->far == 0) {          // the common case: nothing but the 30-instruction body
+        for (unsigned j = j0; j < j1; j++) {
+            const double* bj = b + (size_t)j * PP;
+            double bc[PP];
 #pragma unroll
-        for (int p = 0; p < PP; p++) e = fma(ai[p], bj[p], e);
-        double term = exp_neg(e);
-        if (nzero) {   // converged parameters: factor 1 if equal (AbcUtil.cpp:573), else 0 (declared)
+            for (int p = 0; p < PP; p++) bc[p] = bj[p];
+            const double hc = hb[j];
+            __builtin_amdgcn_sched_barrier(0);      // all scalar loads of the row are in flight before the first FMA waits
+            double e = -(ha + hc);
+#pragma unroll
+            for (int p = 0; p < PP; p++) e = fma(ai[p], bc[p], e);
+            acc += exp2_neg<false>(e);
+        }
+    } else {
+        for (unsigned j = j0; j < j1; j++) {
+            const double* bj = b + (size_t)j * PP;
+            double e = -(ha + hb[j]);
+#pragma unroll
+            for (int p = 0; p < PP; p++) e = fma(ai[p], bj[p], e);
+            double term = exp2_neg<true>(e);
+            // converged parameters: factor 1 if equal (AbcUtil.cpp:573), else 0 (declared)
             for (int z = 0; z < nzero; z++) {
                 const int p = wc->zero_idx[z];
                 if (active && theta_raw[(k0 + i) + K * (size_t)p] != prev_raw[j + Kp * (size_t)p]) term = 0.0;
             }
+            acc += term;
         }
-        acc += term;
     }
     if (active) part[sl * kn + i] = acc;
 }
@@ -235,11 +263,16 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
                        double* w_raw) {
     if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
     if (kn == 0) return ABC_OK;
+    if (Kp > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: K' = %zu >= 2^32", Kp);
     if (k0 + kn > K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: row range [%zu,%zu) outside K=%zu", k0, k0 + kn, K);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     const size_t rb = (kn + 255) / 256;
-    size_t slices = (2048 + rb - 1) / rb;
+    // Column slices: many short ones.  Work-groups are dispatched slice by slice, so the ~2000 resident groups all
+    // stream the same few hundred KB of the previous set through the scalar cache / L2; with 6 slices of 2 MB each
+    // (one residency) the same kernel was 25 % slower, waiting on scalar loads (measured: 6 -> 12.0 ms, 16 -> 10.0,
+    // 64 -> 9.1, 128 -> 9.05 at K = K' = 1e5).  Bounded by the partial-sum buffer (slices x kn doubles <= 64 MB).
+    size_t slices = abc_kde_slices(kn, Kp, PP);
     if (slices > Kp / 64) slices = Kp / 64;
     if (slices < 1) slices = 1;
     if (slices > 1024) slices = 1024;

@@ -157,19 +157,23 @@ def main():
                 "event_overhead_ms": round(event_overhead_ms, 5), "achieved_event_bracket": round(achieved_raw, 1)}
     stage_ms = {k: round((v[0] + v[1]) / max(args.steps, 1), 5) for k, v in stages.items()}
     # the compute-bound kernel of the path (informational): pairs x flops per pair / HIP-event time.
-    # Per pair: P FMAs (dot product) + 1 add + inline exp (2 mul/round + 13 FMA + ldexp) + 1 accumulate.
+    # Per pair (30 vector instructions at P = 16): 1 add, P FMAs (dot product), inline 2^x = 3 adds for the
+    # rounding split + 8 FMAs (minimax polynomial) + ldexp, 1 accumulate.  FMA = 2 flop, the rest 1.
     k_ms, _, _ = stages["k_kde"]
     pairs = float(K // world + (1 if rank < K % world else 0)) * Kp if world > 1 else float(K) * Kp
     PPad = 2
     while PPad < P:
         PPad *= 2
-    flop_pair = 2 * PPad + 1 + 2 * 13 + 4 + 1
+    flop_pair = 1 + 2 * PPad + 3 + 2 * 8 + 1 + 1
+    instr_pair = 1 + PPad + 3 + 8 + 1 + 1
     kde_ms_per_step = k_ms / max(args.steps, 1)
     kde_tflops = pairs * flop_pair / (kde_ms_per_step * 1e-3) / 1e12 if kde_ms_per_step > 0 else 0.0
     roofline_compute = {"kernel": "k_kde", "bound": "fp64_valu", "achieved": round(kde_tflops, 2), "peak": 78.6,
                         "unit": "TFLOP/s", "frac": round(kde_tflops / 78.6, 4),
                         "note": "peak = MI355X fp64 vector spec; scripts/ubench.hip measures 56 TFLOP/s sustained v_fma_f64",
-                        "pairs_per_step": pairs, "flop_per_pair": flop_pair, "kernel_ms_per_step": round(kde_ms_per_step, 5)}
+                        "pairs_per_step": pairs, "flop_per_pair": flop_pair, "valu_instr_per_pair": instr_pair,
+                        "valu_instr_rate_frac": round(pairs * instr_pair / (kde_ms_per_step * 1e-3) / (78.6e12 / 2), 4)
+                        if kde_ms_per_step > 0 else 0.0, "kernel_ms_per_step": round(kde_ms_per_step, 5)}
 
     # set 0 (uniform weights, AbcUtil.cpp:539-545) has no O(K K') stage: reported separately, outside the timed region
     set0 = None
