@@ -379,18 +379,17 @@ int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
 void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs) {
     // Same sequence of floating-point operations as GSL's loop (sequential total, E = w / total, one subtraction
     // per small from the big on top of the stack); only the bookkeeping differs: a big that stays big after serving
-    // a small is pushed and popped again at once upstream, here it simply stays in registers.
+    // a small is pushed and popped again at once upstream, here it simply stays in registers.  (Threading the
+    // order-free passes was measured on the GPU box, scripts/alias_bench.cpp: at K = 8e5 the serving loop and the
+    // sequential total are 60-75 % of the time and thread start-up eats the rest of the gain.)
     double total = 0.0;
     for (size_t k = 0; k < K; k++) total += w[k];
     const double mean = 1.0 / (double)K, dK = (double)K;
-    for (size_t k = 0; k < K; k++) E[k] = w[k] / total;
     size_t ns = 0, nb = 0;
-    for (size_t k = 0; k < K; k++) {          // both stacks in index order; scratch holds K + 1 entries each
-        const bool sm = E[k] < mean;
-        smalls[ns] = (uint32_t)k;
-        bigs[nb] = (uint32_t)k;
-        ns += sm;
-        nb += !sm;
+    for (size_t k = 0; k < K; k++) {
+        const double e = w[k] / total;
+        E[k] = e;
+        if (e < mean) smalls[ns++] = (uint32_t)k; else bigs[nb++] = (uint32_t)k;
     }
     bool have = false;
     uint32_t cb = 0;

@@ -253,7 +253,8 @@ def test_setup_mvn_sampler_not_spd(gpu_ctx):
 # ---------------------------------------------------------------------------------------------------
 # resampling (bit-exact) and perturbation (distributional)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("K,n,seed", [(1, 10, 1), (37, 5000, 2), (1000, 100000, 3), (4096, 64, 4), (513, 65, 5)])
+@pytest.mark.parametrize("K,n,seed", [(1, 10, 1), (37, 5000, 2), (1000, 100000, 3), (4096, 64, 4), (513, 65, 5),
+                                      (300001, 200000, 6)])       # >= 2e5: the threaded passes of the alias build
 def test_resample_bit_exact(gpu_ctx, oracle, K, n, seed):
     from abcsmc_amd import abcutil
     w = np.random.default_rng(seed).random(K) ** 3
