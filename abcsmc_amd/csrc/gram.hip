@@ -209,7 +209,7 @@ __global__ __launch_bounds__((GramDims<C, CY>::NT)) void k_gram(const double* __
 // flight behind the tile being read, counted s_waitcnt vmcnt), ONE barrier per tile.
 // The shift is subtracted when the MFMA operand is read (3 VALU ops per 5 MFMAs: free next to the matrix
 // pipe), which is also where the column sums / sums of squares are taken and edge rows are masked.
-template <int C, int CY, int NW>
+template <int C, int CY, int NW, int R = 3>
 struct GramDimsDma {
     static constexpr int C16 = 16 * C;
     static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
@@ -218,14 +218,29 @@ struct GramDimsDma {
     static constexpr int PSZ = NBLK * 256 + 2 * C16;    // same partial record as k_gram
     static constexpr int BUF = C16 * TRP;
     static constexpr int EPT = (NBLK * 256 + NT - 1) / NT;
-    static constexpr int LDS_D = 3 * BUF;               // ring of three tiles: two DMAs in flight behind the one being read
+    static constexpr int LDS_D = R * BUF;               // ring of R tiles: R - 1 DMAs in flight behind the one being read
 };
 
-template <int C, int CY, int NW>
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS at dst + 16 * lane (dst wave-uniform).
+// Issued as inline assembly ON PURPOSE: with __builtin_amdgcn_global_load_lds the compiler, which cannot tell the ring
+// buffer being refilled from the one being read, puts s_waitcnt vmcnt(0) in front of the next LDS operand read, i.e. it
+// waits for the prefetch it has just issued and nothing overlaps (seen in the ISA; the kernel then ran at the SUM of
+// its memory and MFMA times).  All waits for these loads are the explicit counted s_waitcnt in the loop.
+__device__ __forceinline__ void dma16(const double* gsrc, double* dst) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+}
+
+// PRIV = true (NW == 8): every wave stages and consumes its OWN 16 rows of each tile (8 columns x 16 rows per DMA
+// instruction, its own ring of three 6 KB chunks), so the main loop has no work-group barrier at all: a wave only
+// waits for its own DMAs and the eight waves drift apart instead of meeting once per tile.  Lane l of instruction i
+// fetches rows 2*((l>>3) ^ (i&1)) .. +1 of column 8 i + (l&7); the row-pair swizzle of odd instructions puts the two
+// 8-column halves of a 16-column MFMA operand on opposite halves of the LDS banks (conflict-free b64 reads, no padding).
+template <int C, int CY, int NW, bool PRIV, int R = 3>
 __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
     const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M, int P, long long n,
     long long split, const double* __restrict__ shift, double* __restrict__ partial) {
-    using D = GramDimsDma<C, CY, NW>;
+    using D = GramDimsDma<C, CY, NW, R>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NT = D::NT;
     const int t = threadIdx.x, lane = t & 63;
@@ -236,20 +251,33 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
     const long long ntiles = (r_end > r_begin) ? (r_end - t0 + TR - 1) / TR : 0;
     const long long rmax = (n - 2) & ~1LL;             // last in-bounds 16-B row pair (n is even on this path)
 
-    const double* cptr[D::NI];
+    constexpr int NIW = PRIV ? D::C16 / 8 : D::NI;     // DMA instructions per wave per tile
+    constexpr int CHB = D::C16 * 16;                   // PRIV: doubles per wave chunk (16 rows x C16 columns)
+    static_assert(!PRIV || (NW == 8 && TR == 128), "wave-private staging: 8 waves x 16 rows");
+    const double* cptr[NIW];
 #pragma unroll
-    for (int i = 0; i < D::NI; i++) {
-        const int c = wave + NW * i;                    // padding columns re-read column 0, masked at operand read
+    for (int i = 0; i < NIW; i++) {
+        const int c = PRIV ? 8 * i + (lane & 7) : wave + NW * i;   // padding columns re-read column 0, masked at operand read
         cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
     }
-    auto stage = [&](long long tile, double* buf) {
-        long long r = t0 + tile * TR + 2 * lane;
-        r = r > rmax ? rmax : r;                        // rows past the end are masked later; keep the address legal
+    double* const wring = lds + (PRIV ? wave * (R * CHB) : 0);
+    auto stage = [&](long long tile, int slot) {
+        if constexpr (PRIV) {
 #pragma unroll
-        for (int i = 0; i < D::NI; i++) {
-            const int c = wave + NW * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cptr[i] + r),
-                                             (__attribute__((address_space(3))) void*)(buf + c * TRP), 16, 0, 0);
+            for (int i = 0; i < NIW; i++) {
+                long long r = t0 + tile * TR + 16 * wave + 2 * ((lane >> 3) ^ (i & 1));
+                r = r > rmax ? rmax : r;                // rows past the end are masked later; keep the address legal
+                dma16(cptr[i] + r, wring + slot * CHB + i * 128);
+            }
+        } else {
+            double* buf = lds + slot * D::BUF;
+            long long r = t0 + tile * TR + 2 * lane;
+            r = r > rmax ? rmax : r;
+#pragma unroll
+            for (int i = 0; i < NIW; i++) {
+                const int c = wave + NW * i;
+                dma16(cptr[i] + r, buf + c * TRP);
+            }
         }
     };
 
@@ -268,19 +296,30 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
 #pragma unroll
     for (int b = 0; b < C; b++) { cs[b] = 0.0; cq[b] = 0.0; }
 
+    // PRIV operand address inside a chunk: region (2 b + cl/8) * 128 + 2 (cl & 7) + (q & 1) + 16 * (rowpair ^ (cl >> 3))
+    const int poff = PRIV ? (cl >> 3) * 128 + 2 * (cl & 7) + (q & 1) : 0;
+    const int pswz = cl >> 3;
     int cur = 0;
     long long tile = g;
-    if (tile < ntiles) stage(tile, lds);
-    if (tile + G < ntiles) stage(tile + G, lds + D::BUF);
+#pragma unroll
+    for (int d = 0; d < R - 1; d++)
+        if (tile + d * G < ntiles) stage(tile + d * G, d);
     for (; tile < ntiles; tile += G) {
-        const double* buf = lds + cur * D::BUF;
-        // The DMA of THIS tile must have landed; the next tile's (issued later by the same wave, NI instructions)
+        const double* buf = PRIV ? wring + cur * CHB : lds + cur * D::BUF;
+        // The DMA of THIS tile must have landed; the next tile's (issued later by the same wave, NIW instructions)
         // may stay in flight.  hipcc does not reliably place these waits for LDS-DMA issued in an earlier loop
         // iteration (seen in the ISA), so they are explicit.
-        if (tile + G < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();           // every wave's share of this tile is in LDS; the buffer refilled below is idle
-        if (tile + 2 * G < ntiles) stage(tile + 2 * G, lds + ((cur + 2) % 3) * D::BUF);
+        // tiles still to come after this one, capped at R - 2 (those may stay in flight)
+        {
+            const long long ahead = (ntiles - 1 - tile) / G;
+            if (R >= 6 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NIW) : "memory");
+            else if (R >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIW) : "memory");
+            else if (R >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (!PRIV) __syncthreads();   // every wave's share of this tile is in LDS; the buffer refilled below is idle
+        if (tile + (R - 1) * G < ntiles) stage(tile + (R - 1) * G, (cur + R - 1) % R);
         const long long row0 = t0 + tile * TR;
         const bool full = (row0 >= r_begin) && (row0 + TR <= r_end);
 #pragma unroll
@@ -291,7 +330,8 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
             double a[C];
 #pragma unroll
             for (int b = 0; b < C; b++) {
-                const double z = (buf[(16 * b + cl) * TRP + rb] - sh[b]) * keep[b];
+                const double v = PRIV ? buf[b * 256 + poff + 16 * ((2 * s + (q >> 1)) ^ pswz)] : buf[(16 * b + cl) * TRP + rb];
+                const double z = (v - sh[b]) * keep[b];
                 a[b] = ok ? z : 0.0;
                 cs[b] += a[b];
                 if (b >= C - CY) cq[b] = fma(a[b], a[b], cq[b]);
@@ -305,7 +345,7 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
                     blk++;
                 }
         }
-        cur = (cur + 1) % 3;
+        cur = (cur + 1) % R;
     }
 
     // ---- epilogue (same partial record as k_gram) -------------------------------------------------------
@@ -448,10 +488,10 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     return ABC_OK;
 }
 
-template <int C, int CY, int NW>
+template <int C, int CY, int NW, bool PRIV, int R = 3>
 int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
                  size_t P, long long split, double* stats) {
-    using D = GramDimsDma<C, CY, NW>;
+    using D = GramDimsDma<C, CY, NW, R>;
     const StatsLayout L = stats_layout(M, P);
     const long long ntr = split, nte = (long long)n - split;
     const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
@@ -464,11 +504,11 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
     // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
-    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW, PRIV, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
-        hipLaunchKernelGGL((k_gram_dma<C, CY, NW>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
+        hipLaunchKernelGGL((k_gram_dma<C, CY, NW, PRIV, R>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
                            ldy, (int)M, (int)P, (long long)n, split, stats + L.off_shift, partial);
     }
     ABC_HIP(ctx, hipGetLastError());
@@ -573,13 +613,17 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     size_t CY = C - (M + 15) / 16;      // trailing blocks without any metric column
     if (CY > 2) CY = 2;
     // LDS-DMA staging needs 16-B aligned columns and an even row count (row pairs never straddle the array end)
-    static const int dma_mode = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : 8;     // 0 = off (A/B), 8 / 16 waves
+    // A/B knob: 0 = VGPR-staged k_gram, 8 / 16 = shared tiles with 8 / 16 waves, 9 = wave-private chunks (default).
+    // Inside a generation all four land within a few % of each other (91-104 us at N = 1e6: the launch follows 128 MB
+    // of freshly written proposals whose dirty lines the streaming reads evict); stand-alone, 9 runs at 87 us.
+    static const int dma_mode = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : 9;
     const bool dma_ok = dma_mode && (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
                         (((uintptr_t)Y & 15) == 0) && n >= 2;
 #define GRAM_DMA_CASE(c, cy)                                                                              \
     if (C == c && CY == cy && dma_ok) {                                                                   \
-        if (dma_mode == 16) return run_gram_dma<c, cy, 16>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);   \
-        return run_gram_dma<c, cy, 8>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);                        \
+        if (dma_mode == 16) return run_gram_dma<c, cy, 16, false>(ctx, X, Y, n, ldx, ldy, M, P, split, stats); \
+        if (dma_mode == 9) return run_gram_dma<c, cy, 8, true>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);    \
+        return run_gram_dma<c, cy, 8, false>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);                      \
     }
     GRAM_DMA_CASE(1, 0); GRAM_DMA_CASE(2, 0); GRAM_DMA_CASE(2, 1); GRAM_DMA_CASE(3, 0); GRAM_DMA_CASE(3, 1); GRAM_DMA_CASE(3, 2);
 #undef GRAM_DMA_CASE
