@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
     }
 #pragma unroll
     for (int p = 0; p < PP; p++)
-        if (p < P) out[i + n * (size_t)p] = val[p];
+        if (p < P) __builtin_nontemporal_store(val[p], &out[i + n * (size_t)p]);   // read next by the host / simulators, not by a kernel:
+                                                                                    // keep the 8 P N bytes out of L2 / Infinity Cache
 }
 
 // 32 < P <= 64: same draws and acceptance rule as k_perturb, but only the accumulators x[PP] live in registers;

@@ -91,7 +91,7 @@ __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __res
 // scaled copies: out[row*PP + p] = (in[row + ld*p] - centre[p]) * scale[p]   (row-major, zero padded to PP);
 // centre = first previous particle (differences are unchanged, magnitudes stay O(few sigma)).
 // If hb != NULL also hb[row] = 1/2 |out[row,:]|^2 - log2(w[row])  (the per-column part of the base-2 exponent),
-// capped at W_HB_MAX (w = 0 -> the term vanishes).  Rows further than W_COORD_BOUND from the centre raise wc->far.
+// with -log2 w capped at W_HB_MAX (w = 0 -> the term vanishes).  Rows further than W_COORD_BOUND from the centre raise wc->far.
 __global__ __launch_bounds__(256) void k_wscale(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP,
                                                 WConst* __restrict__ wc, const double* __restrict__ centre,
                                                 size_t ldc, const double* __restrict__ w, double* __restrict__ out,
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void k_wscale(const double* __restrict__ in, s
         far = far || (fabs(v) > W_COORD_BOUND);
     }
     if (hb) {
-        const double h = 0.5 * nn - log2(w[r]);
-        hb[r] = (h > W_HB_MAX) ? W_HB_MAX : h;          // NaN stays NaN
+        const double lw = -log2(w[r]);                   // w = 0 -> +inf: capped so the term is 2^-1e8 == 0, not NaN
+        hb[r] = 0.5 * nn + ((lw > W_HB_MAX) ? W_HB_MAX : lw);      // (only the weight part: a far row keeps its |b|^2)
     }
     if (far) atomicOr(&wc->far, 1);
 }

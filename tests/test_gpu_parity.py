@@ -229,6 +229,32 @@ def test_weight_converged_parameter_and_prior_support(gpu_ctx, oracle):
     assert np.allclose(w, ref, rtol=RTOL)
 
 
+def test_weight_far_particles_and_zero_weights(gpu_ctx, oracle):
+    """the weight kernel's guarded loop: a previous particle 1e7 proposal-sigmas away (its exponent leaves the int32
+    range of the fast 2^x split), previous weights that are exactly 0, and a current particle so far from everything
+    that its denominator underflows -- same values as the per-factor reference formula"""
+    from abcsmc_amd import abcutil, _lib
+    wl, th, tp, wp, dv = _weights_case(6, 300, 200, 11)
+    spec = [(_lib.PRIOR_GAUSS, 0.0, 1e9)] * 6
+    tp = tp.copy(); wp = wp.copy(); th = th.copy()
+    tp[5, :] += 1e7 * np.sqrt(dv)            # contributes exactly 0 to every sum
+    wp[7] = 0.0
+    wp[8] = 0.0
+    ref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv)
+    w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    assert np.all(np.isfinite(ref)) and np.all(ref > 0)
+    assert np.max(np.abs(w - ref) / ref) < 1e-9
+    # the same set with the far / zero-weight particles REMOVED gives the same weights: they really contribute nothing
+    keep = np.ones(200, bool); keep[[5, 7, 8]] = False
+    w2 = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp[keep], wp[keep], dv, ctx=gpu_ctx)
+    assert np.max(np.abs(w2 - w) / w) < 1e-12
+    # one current particle 60 sigmas out in every coordinate: every term underflows to 0 in both implementations
+    th[3, :] += 60 * np.sqrt(dv)
+    raw = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    rref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv)
+    assert np.array_equal(np.isfinite(raw), np.isfinite(rref))
+
+
 @pytest.mark.parametrize("K,P", [(400, 6), (50, 16), (5000, 32), (33, 1)])
 def test_setup_mvn_sampler(gpu_ctx, oracle, K, P):
     from abcsmc_amd import abcutil
