@@ -3,10 +3,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libabcsmc_hip.so")
+# ABCSMC_HIP_SO: developer override for A/B runs of diagnostic builds (scripts/); default = the in-tree build
+SO_PATH = os.environ.get("ABCSMC_HIP_SO") or os.path.join(_HERE, "libabcsmc_hip.so")
 
 PRIOR_GAUSS, PRIOR_UNIF_INT, PRIOR_UNIF_REAL = 0, 1, 2
 RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
+KDE_AUTO, KDE_FP64 = 0, 1
+KDE_RAN_NONE, KDE_RAN_FP64, KDE_RAN_SPLIT = 0, 1, 2
 
 
 class LibraryMissing(ImportError):
@@ -56,6 +59,8 @@ SIGNATURES = {
     "abc_last_error": (C.c_char_p, [_vp]),
     "abc_ctx_set_stream": (_i, [_vp, _vp]),
     "abc_ctx_use_own_stream": (_i, [_vp]),
+    "abc_ctx_set_kde_mode": (_i, [_vp, _i]),
+    "abc_kde_last_kernel": (_i, [_vp, _vp]),
     "abc_ctx_synchronize": (_i, [_vp]),
     "abc_version": (_i, []),
     "abc_timing_enable": (_i, [_vp, _i]),
@@ -164,6 +169,16 @@ class Context:
 
     def synchronize(self):
         self.check(lib().abc_ctx_synchronize(self._h))
+
+    def kde_last_kernel(self):
+        """KDE_RAN_FP64 / KDE_RAN_SPLIT: which kernel summed the pairs of the last weight call (abc_kde_last_kernel)"""
+        w = C.c_int(0)
+        self.check(lib().abc_kde_last_kernel(self._h, C.byref(w)))
+        return w.value
+
+    def set_kde_mode(self, mode):
+        """KDE_AUTO (split-operand matrix-pipe kernel where it applies) or KDE_FP64 (abc_ctx_set_kde_mode)"""
+        self.check(lib().abc_ctx_set_kde_mode(self._h, int(mode)))
 
     def close(self):
         if self._h:

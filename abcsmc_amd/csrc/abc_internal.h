@@ -37,6 +37,8 @@ struct abc_ctx {
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
     bool timing;
+    int kde_mode;  // ABC_KDE_AUTO / ABC_KDE_FP64
+    int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish
     bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
     int nev;
     struct { hipEvent_t a, b; int stage; } ev[256];

@@ -53,6 +53,7 @@ static size_t ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t K
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
     b += K * P * 8 + K * 64 * 8;                                  // theta, and its row-major copy for the perturb gather
     b += (K + Kp) * 64 * 8 + 1024 * 8;                            // weights: scaled copies of both sets
+    b += (K + Kp + 512) * (9 * 32 + 8) + 8192;                    // ... and their bf16 limb tiles (<= 9 operands of 32 B a row)
     if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
@@ -88,6 +89,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->alias_F) (void)hipFree(ctx->alias_F);
     if (ctx->alias_A) (void)hipFree(ctx->alias_A);
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
+    if (ctx->kde_which) (void)hipFree(ctx->kde_which);
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -106,6 +108,22 @@ extern "C" int abc_ctx_use_own_stream(abc_ctx* ctx) {
     if (!ctx) return ABC_ERR_INVALID;
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = ctx->own_stream;
+    return ABC_OK;
+}
+
+extern "C" int abc_ctx_set_kde_mode(abc_ctx* ctx, int mode) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (mode != ABC_KDE_AUTO && mode != ABC_KDE_FP64) ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_kde_mode: unknown mode %d", mode);
+    ctx->kde_mode = mode;
+    return ABC_OK;
+}
+
+extern "C" int abc_kde_last_kernel(abc_ctx* ctx, int* which) {
+    if (!ctx || !which) return ABC_ERR_INVALID;
+    *which = ABC_KDE_RAN_NONE;
+    if (!ctx->kde_which) return ABC_OK;
+    ABC_HIP(ctx, hipMemcpyAsync(which, ctx->kde_which, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ABC_OK;
 }
 

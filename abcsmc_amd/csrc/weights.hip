@@ -16,6 +16,8 @@
 // 13 instructions for the exponential, 30 per pair at P = 16, instead of ~40 for the library exp alone.
 // One new particle per lane; previous-set rows are wave-uniform and stream through the scalar cache.
 // fp64 VALU throughout.
+#include <stdlib.h>
+
 #include "abc_internal.h"
 
 namespace {
@@ -67,6 +69,8 @@ struct WConst {           // per-parameter constants, built on the device by k_w
     int nzero;            // number of parameters with dv_p == 0
     int zero_idx[64];
     int far;              // set by k_wscale when a scaled coordinate is so large that exponents may leave int32
+    int far_split;        // set by k_wsplit when a row leaves the range the split-operand kernel is exact on
+    double centre[64];    // robust column centre of the previous set (k_wcentre): both sets are centred here
 };
 
 constexpr double W_SQRT_LOG2E = 1.2011224087864497825;     // sqrt(log2 e): a.b then comes out in base 2
@@ -85,11 +89,11 @@ __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __res
         }
         wc->scale[p] = sc * W_SQRT_LOG2E;
     }
-    wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0;
+    wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0; wc->far_split = 0;
 }
 
 // scaled copies: out[row*PP + p] = (in[row + ld*p] - centre[p]) * scale[p]   (row-major, zero padded to PP);
-// centre = first previous particle (differences are unchanged, magnitudes stay O(few sigma)).
+// centre = k_wcentre's robust column centre of the previous set: differences are unchanged, magnitudes stay O(few sigma).
 // If hb != NULL also hb[row] = 1/2 |out[row,:]|^2 - log2(w[row])  (the per-column part of the base-2 exponent),
 // with -log2 w capped at W_HB_MAX (w = 0 -> the term vanishes).  Rows further than W_COORD_BOUND from the centre raise wc->far.
 __global__ __launch_bounds__(256) void k_wscale(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP,
@@ -137,7 +141,10 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
                                              const double* __restrict__ b /* Kp x PP scaled rows */, size_t Kp,
                                              const double* __restrict__ hb /* Kp */, const WConst* __restrict__ wc,
                                              const double* __restrict__ theta_raw, size_t K, size_t k0,
-                                             const double* __restrict__ prev_raw, double* __restrict__ part) {
+                                             const double* __restrict__ prev_raw, double* __restrict__ part,
+                                             int fallback_of_split) {
+    // launched behind k_kde_split: runs only when that kernel declined (rows outside its exact range)
+    if (fallback_of_split && !(wc->far_split | wc->nzero | wc->far)) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t slices = gridDim.y, sl = blockIdx.y;
     // wave-uniform bounds in SGPRs (Kp < 2^32, checked by the launcher): the loop test stays off the vector pipe
@@ -182,6 +189,268 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
     if (active) part[sl * kn + i] = acc;
 }
 
+// ---- split-operand weight kernel: the pair dot products on the bf16 matrix pipe, exactly ---------------
+// The fp64 body above spends 17 of its 30 vector instructions per pair on the dot product a_i.b_j.  Here every
+// scaled coordinate is written as a sum of four bf16 "limbs",
+//   v = l0 + l1 + l2 + l3,   l0 = rint(4 v)/4 (|v| <= 10),  l1 = rint(U1 (v - l0))/U1 (U1 = 1024; 512 for P > 16),
+//   l2, l3 = bf16 roundings of what is left (|v - l0 - l1 - l2 - l3| <= 2^-29),
+// and the dot product as the sum of the limb cross-products, which v_mfma_f32_32x32x16_bf16 evaluates with the
+// parameter index as its K dimension (P <= 16: one K-step; P <= 32: two), 32 previous x 32 new particles per
+// instruction.  Two f32 accumulators keep the result at fp64-class accuracy:
+//   X = l0.l0' + l0.l1' + l1.l0' - hbTop_j - haTop_i   every term a multiple of 1/(4 U1), all partial sums below
+//                                                      2^24/(4 U1): EXACT in f32 whatever the order of accumulation
+//   Y = the ten smaller cross-products - hbLow_j - haLow_i      |Y| ~ 0.02, so its f32 rounding is ~1e-9 absolute
+// where hb_j = 1/2|b_j|^2 - log2 w'_j and ha_i = 1/2|a_i|^2 (each = Top, a multiple of 1/(4 U1), + Low) enter through
+// ONE more K-step whose operands hold the bf16 pieces of hb / ha against -1s / 1s on the other side.  X + Y is then
+// the whole base-2 exponent of the term (<= log2 w'_j), and the vector pipe only converts, adds and exponentiates:
+//   term = 2^(double(X) + double(Y))          14 instructions per pair instead of 30 (degree-6 polynomial).
+// Measured error of a weight against the oracle: 3.4e-9 max, 7e-10 rms (tests/test_gpu_parity.py), budget 1e-6.
+// Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400], converged parameters) raise
+// wc->far_split / use nzero and the fp64 kernel above runs instead: both kernels are always launched and the one
+// whose turn it is not returns at once, so no flag travels to the host.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int KS_NL = 4;                       // limbs per coordinate
+constexpr double KS_BOUND = 10.0;              // |scaled coordinate|: 16 NCH B^2 + 2 (8 NCH B^2) + 600 + ... < 2^24/(4 U1)
+constexpr double KS_LW_CAP = 600.0;            // -log2 w' of a non-zero weight (w' = 0 is an all-zero row with hb = KS_HB_ZERO)
+constexpr double KS_HB_ZERO = 1100.0;          // 2^-1100 == 0 in double
+__host__ __device__ constexpr double ks_u1(int nch) { return nch == 1 ? 1024.0 : 512.0; }
+
+// Centre of both sets -> wc->centre (one work-group per parameter): the first previous particle plus the mean offset
+// of the previous set from it, each offset clipped at +-16 proposal sigmas.  Without outliers this is the column
+// mean; a particle 1e7 sigmas away (tests) moves it by at most 16/K' sigmas, so the bulk keeps small coordinates --
+// which the expanded distance |a|^2 + |b|^2 - 2 a.b of both kernels needs (cancellation), and the split kernel's range.
+__global__ __launch_bounds__(256) void k_wcentre(const double* __restrict__ prev, size_t Kp, WConst* __restrict__ wc) {
+    __shared__ double sm[4];
+    const double* col = prev + Kp * (size_t)blockIdx.x;
+    const double c0 = col[0], sc = wc->scale[blockIdx.x];
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < Kp; i += 256) {
+        const double d = (col[i] - c0) * sc;
+        s += fmin(fmax(d, -16.0), 16.0);             // NaN -> -16: harmless, the NaN row poisons the weights anyway
+    }
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) wc->centre[blockIdx.x] = (sc != 0.0) ? c0 + (s / (double)Kp) / sc : c0;
+}
+
+__device__ __forceinline__ unsigned bf16_bits(double v, double* back) {      // round to nearest even, value returned too
+    unsigned u = __float_as_uint((float)v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    *back = (double)__uint_as_float(u);
+    return u >> 16;
+}
+// h = top (a multiple of 1/(4 U1), <= 24 significant bits: three bf16 pieces hold it exactly) + low (three more pieces)
+__device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc[6]) {
+    const double top = rint(h * unit_inv) / unit_inv;
+    double back, rem = top;
+    for (int k = 0; k < 3; k++) { pc[k] = bf16_bits(rem, &back); rem -= back; }
+    rem = h - top;
+    for (int k = 3; k < 6; k++) { pc[k] = bf16_bits(rem, &back); rem -= back; }
+}
+constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
+
+// Limb tiles of one set.  Input: the scaled row-major copy (rows x PPsrc) written by k_wscale.
+// Output, per tile of 32 rows: `ops` operands of 1 KiB in MFMA fragment order [half h][row r][8 bf16] (lane 32h + r
+// reads its 16 bytes at 16*(32h + r)): operand (c*KS_NL + k) = limb k of parameters 16c..16c+15, then the norm step:
+//   previous set (w != NULL), ONE operand:  K-slots 0..2 hbTop pieces, 3..5 hbLow pieces, 8..13 ones
+//   new set, TWO operands (for X and for Y): K-slots 0..2 (X) / 3..5 (Y) = -1, 8..10 (X) = -haTop pieces,
+//                                            11..13 (Y) = -haLow pieces
+// so that (previous operand) . (new X operand) = -hbTop - haTop and . (new Y operand) = -hbLow - haLow.
+// Rows >= rows are padding: zero limbs; a padded previous row has hb = KS_HB_ZERO (a term of exactly 0).
+template <int NCH>
+__global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, int PPsrc, size_t rows, size_t rows_pad,
+                                                const double* __restrict__ w, int is_prev, WConst* __restrict__ wc,
+                                                unsigned short* __restrict__ tiles, int ops) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows_pad) return;
+    bool valid = r < rows;
+    double lw = 0.0;
+    bool far = false;
+    if (is_prev) {
+        const double wr = valid ? w[r] : 0.0;
+        if (wr == 0.0) valid = false;                         // weight 0: contributes exactly nothing, like padding
+        else {
+            lw = -log2(wr);
+            if (!(lw >= -400.0 && lw <= KS_LW_CAP)) far = true;      // w' > 2^400, < 2^-600, negative or NaN
+        }
+    }
+    unsigned short* tb = tiles + (r >> 5) * (size_t)ops * 512;
+    const unsigned rr = (unsigned)(r & 31);
+    constexpr double U1 = ks_u1(NCH);
+    double nn = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned pk[KS_NL][4];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p = c * 16 + h * 8 + j;            // the copy is PPsrc wide (zero padded to a power of two)
+                double v = (valid && p < PPsrc) ? sc[r * (size_t)PPsrc + p] : 0.0;
+                if (!(fabs(v) <= KS_BOUND)) { far = true; v = 0.0; }
+                nn = fma(v, v, nn);
+                double back;
+                const double l0 = rint(v * 4.0) * 0.25;
+                const double r1 = v - l0;
+                const double l1 = rint(r1 * U1) * (1.0 / U1);
+                const double r2 = r1 - l1;
+                unsigned b[KS_NL];
+                b[0] = bf16_bits(l0, &back);
+                b[1] = bf16_bits(l1, &back);
+                b[2] = bf16_bits(r2, &back);
+                const double r3 = r2 - back;
+                b[3] = bf16_bits(r3, &back);
+#pragma unroll
+                for (int k = 0; k < KS_NL; k++) {
+                    if (j & 1) pk[k][j >> 1] |= b[k] << 16; else pk[k][j >> 1] = b[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KS_NL; k++)
+                *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + rr) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+        }
+    }
+    unsigned pc[6];
+    unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
+    if (is_prev) {
+        ks_pieces(valid && !far ? 0.5 * nn + lw : KS_HB_ZERO, 4.0 * U1, pc);
+        *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), 0u);
+        *(uint4*)(ob + (32 + rr) * 8) = make_uint4(KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), 0u);
+    } else {
+        ks_pieces(far ? 0.0 : -0.5 * nn, 4.0 * U1, pc);         // negated: the operand holds -ha
+        *(uint4*)(ob + rr * 8) = make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u);                       // X operand
+        *(uint4*)(ob + (32 + rr) * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2], 0u, 0u);
+        *(uint4*)(ob + 512 + rr * 8) = make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u);           // Y operand
+        *(uint4*)(ob + 512 + (32 + rr) * 8) = make_uint4(0u, pc[3] << 16, pc[4] | (pc[5] << 16), 0u);
+    }
+    if (far) atomicOr(&wc->far_split, 1);
+}
+
+// 2^x for the split kernel: same split as exp2_neg<false>, degree-6 minimax polynomial (1.9e-9 relative,
+// scripts/exp2_minimax.py 6 -- below what the operands are good to), 11 instructions with the running sum.
+__device__ __forceinline__ double exp2_d6(double x) {
+    const double tm = x + 6755399441055744.0;
+    const double f = x - (tm - 6755399441055744.0);
+    double p = 0x1.41d333a1fbff9p-13;
+    p = fma(p, f, 0x1.5f456a867c735p-10);
+    p = fma(p, f, 0x1.3b2dbbc0aa7a3p-7);
+    p = fma(p, f, 0x1.c6aed4b95c606p-5);
+    p = fma(p, f, 0x1.ebfbdadcb136fp-3);
+    p = fma(p, f, 0x1.62e430c7e91afp-1);
+    p = fma(p, f, 0x1.00000002614ffp+0);
+    return ldexp(p, __double2loint(tm));
+}
+
+// The 13 limb cross-products of one 16-parameter chunk, in issue order: which accumulator, which limb of the previous
+// (A operand) and of the new (B operand) particle.  X takes the three products that are multiples of 1/(4 U1); the two
+// chains alternate at the start so that no MFMA waits for the one just issued.
+constexpr signed char KS_LX[13] = {1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+constexpr signed char KS_LA[13] = {0, 3, 0, 1, 1, 2, 3, 0, 2, 1, 2, 0, 1};
+constexpr signed char KS_LB[13] = {0, 1, 1, 3, 0, 2, 0, 3, 1, 2, 0, 2, 1};
+__host__ __device__ constexpr int ks_nsteps(int nch) { return 13 * nch + 2; }
+
+// step S of a batch (one 32 x 32 block of pairs): 13 products per chunk, then the norm step into X and into Y
+template <int NCH, int S>
+__device__ __forceinline__ void ks_mfma(const bf16x8* A, const bf16x8* B, f32x16& X, f32x16& Y) {
+    constexpr int NS = 13 * NCH;
+    if constexpr (S < NS) {
+        constexpr int c = S / 13, l = S % 13;
+        const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bf16x8 a = A[c * KS_NL + KS_LA[l]], b = B[c * KS_NL + KS_LB[l]];
+        if constexpr (KS_LX[l] != 0) X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, (c == 0 && l == 0) ? Z : X, 0, 0, 0);
+        else Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, (c == 0 && l == 1) ? Z : Y, 0, 0, 0);
+    } else if constexpr (S == NS) {
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NCH * KS_NL], B[NCH * KS_NL], X, 0, 0, 0);
+    } else {
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NCH * KS_NL], B[NCH * KS_NL + 1], Y, 0, 0, 0);
+    }
+}
+template <int NCH, int S0, int S1>
+__device__ __forceinline__ void ks_mfma_range(const bf16x8* A, const bf16x8* B, f32x16& X, f32x16& Y) {
+    if constexpr (S0 < S1) {
+        ks_mfma<NCH, S0>(A, B, X, Y);
+        ks_mfma_range<NCH, S0 + 1, S1>(A, B, X, Y);
+    }
+}
+// One batch of vector work interleaved with the NEXT batch's matrix work: slot R issues its share of the next
+// batch's MFMAs (into Xn, Yn), then exponentiates G elements of the finished batch (Xc, Yc).  A wave issues in order
+// and an MFMA occupies the matrix pipe for 32 cycles, so 15 of them in a row would hold the wave's own exponentials
+// back for ~480 cycles; spread over the slots they keep both pipes of the SIMD fed from a single wave.
+template <int NCH, int G, int R>
+__device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32x16& Xn, f32x16& Yn,
+                                         const f32x16& Xc, const f32x16& Yc, double& s) {
+    if constexpr (R < 16 / G) {
+        // the MFMAs go into the first 14 / G slots, so the last results are ready when the next batch's first slot reads them
+        constexpr int NS = ks_nsteps(NCH), SL = 14 / G;
+        constexpr int s0 = (R < SL) ? (R * NS) / SL : NS, s1 = (R < SL) ? ((R + 1) * NS) / SL : NS;
+        // Empty asm "uses" of the accumulators written in EARLIER slots (X from step 0, Y from step 1 on) and of the
+        // running sum: without them the optimiser sinks matrix work whose results are only consumed in the next loop
+        // iteration, and the sums, to the end of the loop body.  A slot later the result has long been written: no wait.
+        if constexpr (s0 > 0 && s0 < NS) asm volatile("" : "+v"(Xn));
+        if constexpr (s0 > 1 && s0 < NS) asm volatile("" : "+v"(Yn));
+        ks_mfma_range<NCH, s0, s1>(An, Bn, Xn, Yn);
+        if constexpr (G == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; g++) s += exp2_d6((double)Xc[R * G + g] + (double)Yc[R * G + g]);
+        asm volatile("" : "+v"(s));
+        __builtin_amdgcn_sched_barrier(0);
+        ks_slots<NCH, G, R + 1>(An, Bn, Xn, Yn, Xc, Yc, s);
+    }
+}
+
+// part[slice*kn + i] = sum_{j in slice} 2^(a_i.b_j - 1/2|a_i|^2 - hb_j).  256 threads = 4 waves x 64 new particles
+// (two 32-column tiles per wave, resident as B operands); the previous set streams through as A operands, 32 rows a
+// tile, each lane loading its own 16-byte fragments one tile ahead (the four waves of a group and its neighbours
+// read the same tile at about the same time: L1 / L2 hits).  D = A.B puts the new particle on the lane and 16
+// previous particles in the registers, so a lane owns ONE running sum per column tile.
+template <int NCH, int G>
+__global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4* __restrict__ at, size_t kn,
+                                                      const uint4* __restrict__ bt, unsigned nbt,
+                                                      const WConst* __restrict__ wc, double* __restrict__ part) {
+    if (wc->far_split | wc->nzero | wc->far) return;          // the fp64 kernel's turn
+    constexpr int OPA = NCH * KS_NL + 2, OPB = NCH * KS_NL + 1;
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
+    const unsigned slices = gridDim.y, sl = blockIdx.y;
+    const unsigned t0 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * sl / slices));
+    const unsigned t1 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * (sl + 1) / slices));
+
+    bf16x8 B0[OPA], B1[OPA];
+#pragma unroll
+    for (int q = 0; q < OPA; q++) {
+        B0[q] = __builtin_bit_cast(bf16x8, at[((it0 + 0) * OPA + q) * 64 + lane]);
+        B1[q] = __builtin_bit_cast(bf16x8, at[((it0 + 1) * OPA + q) * 64 + lane]);
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    if (t0 < t1) {
+        bf16x8 A[OPB];
+#pragma unroll
+        for (int q = 0; q < OPB; q++) A[q] = __builtin_bit_cast(bf16x8, bt[((size_t)t0 * OPB + q) * 64 + lane]);
+        f32x16 X0, Y0, X1, Y1;
+        ks_mfma_range<NCH, 0, ks_nsteps(NCH)>(A, B0, X0, Y0);                    // (t0, columns 0)
+        for (unsigned t = t0; t < t1; t++) {
+            bf16x8 An[OPB];
+            const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass re-reads its own tile (no branch); unused
+#pragma unroll
+            for (int q = 0; q < OPB; q++) An[q] = __builtin_bit_cast(bf16x8, bt[((size_t)tn * OPB + q) * 64 + lane]);
+            __builtin_amdgcn_sched_barrier(0);
+            ks_slots<NCH, G, 0>(A, B1, X1, Y1, X0, Y0, acc0);       // matrix: (t, columns 1); vector: (t, columns 0)
+            ks_slots<NCH, G, 0>(An, B0, X0, Y0, X1, Y1, acc1);      // matrix: (t+1, columns 0); vector: (t, columns 1)
+#pragma unroll
+            for (int q = 0; q < OPB; q++) A[q] = An[q];
+        }
+    }
+    {
+        const double v0 = acc0 + __shfl_xor(acc0, 32, 64);          // the two halves hold different previous rows
+        const double v1 = acc1 + __shfl_xor(acc1, 32, 64);
+        const size_t i0 = (it0 + 0) * 32 + (lane & 31), i1 = (it0 + 1) * 32 + (lane & 31);
+        if (lane < 32 && i0 < kn) part[(size_t)sl * kn + i0] = v0;
+        if (lane < 32 && i1 < kn) part[(size_t)sl * kn + i1] = v1;
+    }
+}
+
 __device__ __forceinline__ double gaussian_pdf(double x, double sigma) {   // [GSL] gsl_ran_gaussian_pdf
     const double u = x / fabs(sigma);
     return (1.0 / (sqrt(2.0 * M_PI) * fabs(sigma))) * exp(-u * u / 2.0);
@@ -198,8 +467,11 @@ __device__ __forceinline__ double prior_likelihood(const abc_prior& pr, double v
 __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ priors, const double* __restrict__ theta,
                                                  size_t K, int P, size_t k0, size_t kn,
                                                  const double* __restrict__ part, int slices,
-                                                 const WConst* __restrict__ wc, double* __restrict__ w_raw) {
+                                                 const WConst* __restrict__ wc, double* __restrict__ w_raw,
+                                                 int split_launched, int* __restrict__ which) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0)       // which kernel's sums these are (abc_kde_last_kernel)
+        *which = (split_launched && !(wc->far_split | wc->nzero | wc->far)) ? ABC_KDE_RAN_SPLIT : ABC_KDE_RAN_FP64;
     if (i >= kn) return;
     double num = 1.0;
     for (int p = 0; p < P; p++) num *= prior_likelihood(priors[p], theta[(k0 + i) + K * (size_t)p]);
@@ -263,6 +535,10 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
                        double* w_raw) {
     if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
     if (kn == 0) return ABC_OK;
+    if (!ctx->kde_which) {
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->kde_which, sizeof(int)));
+        ABC_HIP(ctx, hipMemsetAsync(ctx->kde_which, 0, sizeof(int), ctx->stream));
+    }
     if (Kp > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: K' = %zu >= 2^32", Kp);
     if (k0 + kn > K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: row range [%zu,%zu) outside K=%zu", k0, k0 + kn, K);
     int PP = 2;
@@ -276,23 +552,59 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (slices > Kp / 64) slices = Kp / 64;
     if (slices < 1) slices = 1;
     if (slices > 1024) slices = 1024;
+    // split-operand kernel: 8 < P <= 32 parameters (below that the fp64 body is as short), unless the caller asked for fp64
+    const int NCH = (P <= 16) ? 1 : 2;
+    const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64);
+    const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
+    const int opa = NCH * KS_NL + 2, opb = NCH * KS_NL + 1;
     WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
     double* a = (double*)abc_ws_alloc(ctx, kn * PP * sizeof(double));
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* part = (double*)abc_ws_alloc(ctx, slices * kn * sizeof(double));
     double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
+    unsigned short *at = nullptr, *bt = nullptr;
+    if (split) {
+        at = (unsigned short*)abc_ws_alloc(ctx, nat * opa * 1024);
+        bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
+        if (!at || !bt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    }
     if (!wc || !a || !b || !part || !hb) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc);
+    hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P), dim3(256), 0, ctx->stream, theta_prev, Kp, wc);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
-                       (int)P, PP, wc, theta_prev, Kp, (const double*)nullptr, a, (double*)nullptr);
+                       (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, ctx->stream, theta_prev, Kp, Kp,
-                       (int)P, PP, wc, theta_prev, Kp, w_prev, b, hb);
+                       (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
+    if (split) {
+        const size_t ra = nat * 32, rbp = nbt * 32;
+        if (NCH == 1) {
+            hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
+                               (const double*)nullptr, 0, wc, at, opa);
+            hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
+                               w_prev, 1, wc, bt, opb);
+        } else {
+            hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
+                               (const double*)nullptr, 0, wc, at, opa);
+            hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
+                               w_prev, 1, wc, bt, opb);
+        }
+    }
 #define LAUNCH_KDE(PPV)                                                                                        \
     hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
-                       Kp, hb, wc, theta, K, k0, theta_prev, part)
+                       Kp, hb, wc, theta, K, k0, theta_prev, part, split ? 1 : 0)
     {
         StageTimer tk(ctx, ST_KDE);
+        if (split) {
+            static const int kg = getenv("ABC_KDE_G") ? atoi(getenv("ABC_KDE_G")) : 2;     // A/B: exponentials per slot
+#define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
+    hipLaunchKernelGGL((k_kde_split<NCHV, GV>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, \
+                       (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, part)
+            if (NCH == 1) { if (kg == 1) LAUNCH_SPLIT(1, 1); else LAUNCH_SPLIT(1, 2); }
+            else          { if (kg == 1) LAUNCH_SPLIT(2, 1); else LAUNCH_SPLIT(2, 2); }
+#undef LAUNCH_SPLIT
+        }
         switch (PP) {
             case 2: LAUNCH_KDE(2); break;
             case 4: LAUNCH_KDE(4); break;
@@ -304,7 +616,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     }
 #undef LAUNCH_KDE
     hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
-                       (int)slices, wc, w_raw);
+                       (int)slices, wc, w_raw, split ? 1 : 0, ctx->kde_which);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

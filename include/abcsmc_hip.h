@@ -67,6 +67,15 @@ int  abc_ctx_set_stream(abc_ctx* ctx, void* hip_stream);
 int  abc_ctx_use_own_stream(abc_ctx* ctx);
 int  abc_ctx_synchronize(abc_ctx* ctx);
 int  abc_version(void);
+/* Which kernel evaluates the O(K K' P) pair sums of weight_predictive_prior (AbcUtil.cpp:556-581).
+ * ABC_KDE_AUTO (default): 8 < P <= 32 parameters run the split-operand kernel (pair dot products on the bf16 matrix
+ * pipe from four exact limbs per coordinate, <= 2e-8 absolute error in the base-2 exponent of a term; sets it cannot
+ * represent exactly fall back by themselves); ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
+enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
+int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
+/* Which of the two kernels produced the pair sums of the most recent weight call on this context (synchronises). */
+enum { ABC_KDE_RAN_NONE = 0, ABC_KDE_RAN_FP64 = 1, ABC_KDE_RAN_SPLIT = 2 };
+int  abc_kde_last_kernel(abc_ctx* ctx, int* which);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
  * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]

@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-6          # BASELINE.json north_star: "float within 1e-6 rel"
 
 
+@pytest.fixture(autouse=True)
+def _default_kde_mode(request):
+    """tests that switch the weight kernel leave the shared context in its default mode, pass or fail"""
+    yield
+    if "gpu_ctx" in request.fixturenames:
+        from abcsmc_amd import _lib
+        request.getfixturevalue("gpu_ctx").set_kde_mode(_lib.KDE_AUTO)
+
+
 def _wl(M, P, N, seed=12345):
     from abcsmc_amd import synthetic
     wl = synthetic.Workload(M, P, seed)
@@ -194,17 +203,100 @@ def _weights_case(P, K, Kp, seed):
     return wl, th, tp, wp, dv
 
 
-@pytest.mark.parametrize("P,K,Kp", [(16, 700, 900), (2, 100, 64), (5, 1, 130), (32, 300, 257), (3, 2500, 70), (48, 200, 150)])
-def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp):
+# The pair sums run on one of two kernels (include/abcsmc_hip.h: abc_ctx_set_kde_mode).  Tolerances, relative, per weight:
+#   fp64 vector kernel                      1e-9  (measured ~1e-12)
+#   split-operand matrix-pipe kernel (auto)  2e-7  (<= 2e-8 absolute in the base-2 exponent of a term; north star: 1e-6)
+KDE_TOL = {"fp64": 1e-9, "auto": 2e-7}
+
+
+class _kde_mode:
+    def __init__(self, ctx, mode):
+        self.ctx, self.mode = ctx, mode
+
+    def __enter__(self):
+        from abcsmc_amd import _lib
+        self.ctx.set_kde_mode(_lib.KDE_FP64 if self.mode == "fp64" else _lib.KDE_AUTO)
+
+    def __exit__(self, *a):
+        from abcsmc_amd import _lib
+        self.ctx.set_kde_mode(_lib.KDE_AUTO)
+
+
+@pytest.mark.parametrize("mode", ["auto", "fp64"])
+@pytest.mark.parametrize("P,K,Kp", [(16, 700, 900), (2, 100, 64), (5, 1, 130), (32, 300, 257), (3, 2500, 70), (48, 200, 150),
+                                    (9, 513, 31), (20, 65, 1000), (13, 1, 40)])
+def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp, mode):
     from abcsmc_amd import abcutil, _lib
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 77 + P)
     spec = wl.prior_spec()
-    w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    with _kde_mode(gpu_ctx, mode):
+        w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+        # the split-operand kernel takes 5..32 parameters (padded to 8, 16 or 32 columns) unless fp64 was asked for
+        expect_split = mode == "auto" and 5 <= P <= 32
+        assert gpu_ctx.kde_last_kernel() == (_lib.KDE_RAN_SPLIT if expect_split else _lib.KDE_RAN_FP64)
     ref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv)
     assert np.all(ref > 0)
     assert np.allclose(w, ref, rtol=RTOL, atol=0)
-    assert np.max(np.abs(w - ref) / ref) < 1e-9
+    assert np.max(np.abs(w - ref) / ref) < KDE_TOL[mode]
     assert np.linalg.norm(w) == pytest.approx(1.0, rel=1e-12)          # L2, not L1 (AbcUtil.cpp:583)
+
+
+def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle):
+    """the split-operand kernel on a set large enough for many column slices and tiles: against the oracle and against
+    the fp64 kernel; previous particles of weight exactly 0 (inside the exact range) contribute exactly nothing"""
+    from abcsmc_amd import abcutil, _lib
+    P, K, Kp = 16, 3000, 5000
+    wl, th, tp, wp, dv = _weights_case(P, K, Kp, 4242)
+    wp = wp.copy()
+    wp[::97] = 0.0
+    pri = _lib.make_priors(wl.prior_spec())
+    ref = oracle.weights_importance(oracle.make_priors(wl.prior_spec()), th, tp, wp, dv)
+    w = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
+    with _kde_mode(gpu_ctx, "fp64"):
+        w64 = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+        assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64
+    err, err64 = np.abs(w - ref) / ref, np.abs(w64 - ref) / ref
+    print("split kernel: max rel err %.2e (rms %.2e); fp64 kernel: %.2e" % (err.max(), np.sqrt((err ** 2).mean()), err64.max()))
+    assert err64.max() < 1e-9 and err.max() < KDE_TOL["auto"]
+    keep = wp != 0.0
+    w2 = abcutil.weight_predictive_prior(pri, th, tp[keep], wp[keep], dv, ctx=gpu_ctx)
+    assert np.max(np.abs(w2 - w) / w) < KDE_TOL["auto"]
+
+
+def test_weight_split_kernel_range_edges(gpu_ctx, oracle):
+    """edges of the range the split-operand kernel is exact on: particles up to ~9.5 scaled units from the centre and
+    previous weights down to 1e-150 stay on it and still match the oracle; one coordinate past 10 units, or a weight of
+    1e-200, hands the whole call to the fp64 kernel (same answer, tighter tolerance)"""
+    from abcsmc_amd import abcutil, _lib
+    P, K, Kp = 16, 400, 600
+    wl, th, tp, wp, dv = _weights_case(P, K, Kp, 99)
+    spec = [(_lib.PRIOR_GAUSS, 0.0, 1e9)] * P
+    pri, opri = _lib.make_priors(spec), oracle.make_priors(spec)
+    unit = np.sqrt(dv) / np.sqrt(np.log2(np.e))          # one scaled unit of parameter p (weights.hip: k_wscale)
+    centre = tp.mean(axis=0)
+    th, tp, wp = th.copy(), tp.copy(), wp.copy()
+    th[5, :] = centre + 9.3 * unit * np.where(np.arange(P) % 2, 1.0, -1.0)      # every coordinate ~9.3 units out
+    th[6, 3] = centre[3] - 9.5 * unit[3]
+    tp[7, :] = centre + 9.0 * unit                                            # a previous particle equally far
+    tp[8, :] = th[5, :] + 0.3 * unit                                          # ... and one next to the far current one
+    wp[9], wp[10] = 1e-150, 0.0
+    ref = oracle.weights_importance(opri, th, tp, wp, dv)
+    w = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
+    assert np.all(ref > 0) and np.max(np.abs(w - ref) / ref) < KDE_TOL["auto"]
+    th2 = th.copy()
+    th2[6, 3] = centre[3] - 10.6 * unit[3]
+    ref2 = oracle.weights_importance(opri, th2, tp, wp, dv)
+    w2 = abcutil.weight_predictive_prior(pri, th2, tp, wp, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64
+    assert np.max(np.abs(w2 - ref2) / ref2) < KDE_TOL["fp64"]
+    wp3 = wp.copy()
+    wp3[9] = 1e-200
+    ref3 = oracle.weights_importance(opri, th, tp, wp3, dv)
+    w3 = abcutil.weight_predictive_prior(pri, th, tp, wp3, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64
+    assert np.max(np.abs(w3 - ref3) / ref3) < KDE_TOL["fp64"]
 
 
 def test_weight_uniform_first_set(gpu_ctx):
@@ -224,12 +316,14 @@ def test_weight_converged_parameter_and_prior_support(gpu_ctx, oracle):
     spec[1] = (_lib.PRIOR_UNIF_INT, 1, 10)
     spec[2] = (_lib.PRIOR_UNIF_REAL, float(np.median(th[:, 2])), float(th[:, 2].max() + 1))   # half outside support
     w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64            # a converged parameter: the guarded fp64 loop
     ref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv, 0)
     assert (ref == 0).sum() > 10 and np.array_equal(w == 0, ref == 0)
     assert np.allclose(w, ref, rtol=RTOL)
 
 
-def test_weight_far_particles_and_zero_weights(gpu_ctx, oracle):
+@pytest.mark.parametrize("mode", ["auto", "fp64"])
+def test_weight_far_particles_and_zero_weights(gpu_ctx, oracle, mode):
     """the weight kernel's guarded loop: a previous particle 1e7 proposal-sigmas away (its exponent leaves the int32
     range of the fast 2^x split), previous weights that are exactly 0, and a current particle so far from everything
     that its denominator underflows -- same values as the per-factor reference formula"""
@@ -241,16 +335,21 @@ def test_weight_far_particles_and_zero_weights(gpu_ctx, oracle):
     wp[7] = 0.0
     wp[8] = 0.0
     ref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv)
+    gpu_ctx.set_kde_mode(_lib.KDE_FP64 if mode == "fp64" else _lib.KDE_AUTO)
     w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
     assert np.all(np.isfinite(ref)) and np.all(ref > 0)
-    assert np.max(np.abs(w - ref) / ref) < 1e-9
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64
+    assert np.max(np.abs(w - ref) / ref) < 1e-9       # the far row sends BOTH modes through the guarded fp64 loop
     # the same set with the far / zero-weight particles REMOVED gives the same weights: they really contribute nothing
+    # (without the far row the auto mode runs the split-operand kernel: its tolerance applies)
     keep = np.ones(200, bool); keep[[5, 7, 8]] = False
     w2 = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp[keep], wp[keep], dv, ctx=gpu_ctx)
-    assert np.max(np.abs(w2 - w) / w) < 1e-12
+    assert gpu_ctx.kde_last_kernel() == (_lib.KDE_RAN_FP64 if mode == "fp64" else _lib.KDE_RAN_SPLIT)
+    assert np.max(np.abs(w2 - w) / w) < (1e-12 if mode == "fp64" else KDE_TOL["auto"])
     # one current particle 60 sigmas out in every coordinate: every term underflows to 0 in both implementations
     th[3, :] += 60 * np.sqrt(dv)
     raw = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    gpu_ctx.set_kde_mode(_lib.KDE_AUTO)
     rref = oracle.weights_importance(oracle.make_priors(spec), th, tp, wp, dv)
     assert np.array_equal(np.isfinite(raw), np.isfinite(rref))
 
@@ -531,7 +630,7 @@ def test_generation_config3_size_properties(gpu_ctx, oracle):
     rows = np.array([0, 1, 777, K // 2, K - 1])
     raw = oracle.weights_importance(oracle.make_priors(spec), theta[rows], prev[0], prev[1], prev[2])
     ratio = (w[rows] / w[rows[0]]) / (raw / raw[0])                          # normalisation cancels in ratios
-    assert np.allclose(ratio, 1.0, rtol=1e-9)
+    assert np.allclose(ratio, 1.0, rtol=2 * KDE_TOL["auto"])       # P = 16: the split-operand weight kernel
     parent = gen.parent.cpu().numpy()
     assert np.bincount(parent, minlength=K).sum() == Nn and parent.max() < K
     # the resampled parents are exactly the oracle's for the device's own weights
