@@ -33,6 +33,7 @@ struct abc_ctx {
     size_t alias_K;
     uint64_t alias_tag;
     bool alias_valid;
+    hipEvent_t ev_copy;    // marks the end of the weights' device-to-host copy (the host waits on it, not on the stream)
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)

@@ -90,6 +90,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->alias_A) (void)hipFree(ctx->alias_A);
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
     if (ctx->kde_which) (void)hipFree(ctx->kde_which);
+    if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -166,6 +166,9 @@ __device__ __forceinline__ double d_recast(const abc_prior& pr, double v) {     
 __device__ __forceinline__ bool d_valid(const abc_prior& pr, double v) {             // Parameter.h:77
     if (pr.kind == ABC_PRIOR_GAUSS) {
         const double u = (v - pr.a) / fabs(pr.b);
+        // likelihood != 0.  For u^2 < 1400 and |sigma| < 1e10 the product is >= 4e-11 * exp(-700) = 3.9e-315 > 0 for
+        // certain, so the exponential is only evaluated near the underflow edge (|u| > 37) and for NaN / huge sigma
+        if (u * u < 1400.0 && fabs(pr.b) < 1e10) return true;
         return (1.0 / (sqrt(2.0 * M_PI) * fabs(pr.b))) * exp(-u * u / 2.0) != 0.0;
     }
     if (pr.kind == ABC_PRIOR_UNIF_INT) return (v == round(v)) && (pr.a <= v) && (v <= pr.b);
@@ -234,8 +237,10 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
             double x[PP];
 #pragma unroll
             for (int a = 0; a < PP; a++) x[a] = 0.0;
+            // one Philox block -> two normals -> two columns of L.  L is lower triangular: the column pairs of its right
+            // half are zero in rows < PP/2, so the second loop only touches the lower half of x (a quarter of the FMAs)
 #pragma unroll 1
-            for (int pr = 0; pr < PP / 2; pr++) {      // one Philox block -> two normals -> two columns of L
+            for (int pr = 0; pr < (PP + 2) / 4; pr++) {      // ceil(PP/4) pairs = columns below PP/2 (all of them for PP = 2)
                 U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
                 double z0, z1;
                 normal2(philox(c, k0, k1), z0, z1);
@@ -243,6 +248,16 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
                 const double* l1 = l0 + PP;
 #pragma unroll
                 for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
+            }
+#pragma unroll 1
+            for (int pr = (PP + 2) / 4; pr < PP / 2; pr++) {
+                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
+                double z0, z1;
+                normal2(philox(c, k0, k1), z0, z1);
+                const double* l0 = sL + PP * (2 * pr);
+                const double* l1 = l0 + PP;
+#pragma unroll
+                for (int a = PP / 2; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
             }
             bool ok = true;
 #pragma unroll
@@ -433,7 +448,18 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     uint32_t* hS = hA + K;
     uint32_t* hB = hS + K + 1;
     ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->ev_copy) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
+    ABC_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream));
+    // the raw taus2 outputs of the draws do not depend on the table: queued behind the copy, generated while the host builds it
+    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
+    abc_rng base = *rng;
+    taus2_jump(&base, i0);
+    {
+        StageTimer tm(ctx, ST_RESAMPLE);
+        ABC_TRY(taus_stream(ctx, base, n, raw));
+    }
+    ABC_HIP(ctx, hipEventSynchronize(ctx->ev_copy));
     {
         const auto t0 = std::chrono::steady_clock::now();
         alias_preproc(K, hw, hF, hA, hE, hS, hB);
@@ -444,6 +470,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     }
     StageTimer tm(ctx, ST_RESAMPLE);
     if (ctx->alias_K < K) {
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->alias_F) { (void)hipFree(ctx->alias_F); (void)hipFree(ctx->alias_A); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
         ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * sizeof(double)));
         ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_A, K * sizeof(uint32_t)));
@@ -451,11 +478,6 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     }
     ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_F, hF, K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_A, hA, K * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
-    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
-    abc_rng base = *rng;
-    taus2_jump(&base, i0);
-    ABC_TRY(taus_stream(ctx, base, n, raw));
     hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
                        ctx->alias_A, K, (unsigned long long*)parent);
     ABC_HIP(ctx, hipGetLastError());

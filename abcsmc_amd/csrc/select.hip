@@ -333,11 +333,115 @@ __global__ __launch_bounds__(1024) void k_sort_scan(unsigned int* __restrict__ b
     }
 }
 
+// ---- small sets: LDS chunk sort + rank merge (2 launches instead of 24) -----------------------------------------
+// Up to SC_MAX_N pairs: every work-group bitonic-sorts SC_N pairs in LDS by (key, position in the chunk) -- the position
+// rides in the top 16 bits of the index word (row indices stay below 2^48), which makes the network's result the STABLE
+// order -- then k_merge_chunks ranks every element among the other chunks by binary search (equal keys: lower chunk
+// first), exactly the order the stable radix passes produce.
+constexpr int SC_N = 4096;
+constexpr size_t SC_MAX_N = (size_t)1 << 18;
+
+__global__ __launch_bounds__(1024) void k_sort_chunks(const unsigned long long* key, const unsigned long long* idx, size_t n,
+                                                      unsigned long long* okey, unsigned long long* oidx) {
+    __shared__ unsigned long long sk[SC_N];
+    __shared__ unsigned long long si[SC_N];
+    const size_t base = (size_t)blockIdx.x * SC_N;
+    const unsigned cnt = (unsigned)((n - base < (size_t)SC_N) ? n - base : (size_t)SC_N);
+    for (unsigned e = threadIdx.x; e < SC_N; e += 1024) {
+        sk[e] = (e < cnt) ? key[base + e] : ~0ull;                         // padding sorts last (larger position on ties)
+        si[e] = ((e < cnt) ? idx[base + e] : 0ull) | ((unsigned long long)e << 48);
+    }
+    // Compare-exchange pair p of phase (k, j) is elements i = 2j (p / j) + p % j and i + j.  A wave owns pairs
+    // 64w..64w+63 (and the same 1024 further on): for j <= 64 those are exactly elements 128w..128w+127, so the run of
+    // phases j = 64 .. 1 of every k stays inside the wave's own elements and needs no work-group barrier (a wave's LDS
+    // operations are issued and performed in order); only the 15 phases with j >= 128 are fenced on both sides.
+    __syncthreads();
+    unsigned prev_j = 1;
+    for (unsigned k = 2; k <= SC_N; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 128 || prev_j >= 128) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            prev_j = j;
+            unsigned ii[2];
+            unsigned long long ka[2], kb[2], ia[2], ib[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const unsigned p = threadIdx.x + 1024u * m;
+                ii[m] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                ka[m] = sk[ii[m]]; kb[m] = sk[ii[m] + j]; ia[m] = si[ii[m]]; ib[m] = si[ii[m] + j];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const bool gt = (ka[m] > kb[m]) || (ka[m] == kb[m] && (ia[m] >> 48) > (ib[m] >> 48));
+                if (gt == ((ii[m] & k) == 0)) { sk[ii[m]] = kb[m]; sk[ii[m] + j] = ka[m]; si[ii[m]] = ib[m]; si[ii[m] + j] = ia[m]; }
+            }
+        }
+    }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < cnt; e += 1024) {
+        okey[base + e] = sk[e];
+        oidx[base + e] = si[e] & 0x0000ffffffffffffull;
+    }
+}
+
+// Rank of x in chunk r = number of its elements that come before x: a fixed-trip branchless search (13 probes of a
+// 4096-element chunk).  Eight chunks are searched at once, so a thread has eight independent L2 load chains in flight
+// instead of one chain of 13 x (chunks - 1) dependent loads.
+__global__ __launch_bounds__(256) void k_merge_chunks(const unsigned long long* __restrict__ key,
+                                                      const unsigned long long* __restrict__ idx, size_t n,
+                                                      unsigned long long* __restrict__ okey, unsigned long long* __restrict__ oidx) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const unsigned q = (unsigned)(t / SC_N), W = (unsigned)((n + SC_N - 1) / SC_N);
+    const unsigned long long x = key[t];
+    size_t pos = t - (size_t)q * SC_N;
+    for (unsigned r0 = 0; r0 < W; r0 += 8) {
+        unsigned lo[8], len[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned r = r0 + u;
+            lo[u] = 0;
+            len[u] = (r < W && r != q) ? (unsigned)((n - (size_t)r * SC_N < (size_t)SC_N) ? n - (size_t)r * SC_N : (size_t)SC_N) : 0u;
+        }
+#pragma unroll 1
+        for (unsigned step = SC_N; step >= 1; step >>= 1) {
+            unsigned long long y[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {                               // unconditional (clamped) loads: all eight in flight
+                const unsigned c = lo[u] + step;                       // candidate count of elements before x
+                const unsigned r = (r0 + u < W) ? r0 + u : q;
+                y[u] = key[(size_t)r * SC_N + ((c <= len[u]) ? c - 1 : 0u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned c = lo[u] + step;
+                const bool before = (r0 + u < q) ? (y[u] <= x) : (y[u] < x);     // equal keys: lower chunks first (stable)
+                lo[u] = (c <= len[u] && before) ? c : lo[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) pos += lo[u];
+    }
+    okey[pos] = x;
+    oidx[pos] = idx[t];
+}
+
 // sorts n pairs; result ends in (key0, idx0); (key1, idx1) is scratch of the same size
 int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* idx0, unsigned long long* key1,
                    unsigned long long* idx1, size_t n, int byte_lo = 0, int byte_hi = 8) {
     if (n <= 1) return ABC_OK;
     StageTimer tm(ctx, ST_SORT);
+    if (byte_lo == 0 && byte_hi == 8 && n <= SC_MAX_N) {
+        const unsigned nc = (unsigned)((n + SC_N - 1) / SC_N);
+        if (nc == 1) {
+            hipLaunchKernelGGL(k_sort_chunks, dim3(1), dim3(1024), 0, ctx->stream, key0, idx0, n, key0, idx0);
+        } else {        // sorted chunks into the scratch pair, merged back into (key0, idx0)
+            hipLaunchKernelGGL(k_sort_chunks, dim3(nc), dim3(1024), 0, ctx->stream, key0, idx0, n, key1, idx1);
+            hipLaunchKernelGGL(k_merge_chunks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key1, idx1, n,
+                               key0, idx0);
+        }
+        ABC_HIP(ctx, hipGetLastError());
+        return ABC_OK;
+    }
     const int nb = (int)((n + ST_CHUNK - 1) / ST_CHUNK);
     unsigned int* bh = (unsigned int*)abc_ws_alloc(ctx, (size_t)256 * nb * sizeof(unsigned int));
     if (!bh) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sort: workspace exhausted");
@@ -356,7 +460,8 @@ int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* i
 
 }  // namespace
 
-// stable LSD radix sort of n (key, value) pairs on key bytes [byte_lo, byte_hi) (an even number of passes);
+// stable sort of n (key, value) pairs on key bytes [byte_lo, byte_hi) (an even number of passes; values below 2^48:
+// the full-key sort of small sets tags the value word, see k_sort_chunks);
 // the result is left in (key0, val0); (key1, val1) are scratch.  Used by the Wilcoxon rank sums.
 int abc_sort_u64_bytes(abc_ctx* ctx, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
                        unsigned long long* val1, size_t n, int byte_lo, int byte_hi) {

@@ -221,17 +221,30 @@ __host__ __device__ constexpr double ks_u1(int nch) { return nch == 1 ? 1024.0 :
 // of the previous set from it, each offset clipped at +-16 proposal sigmas.  Without outliers this is the column
 // mean; a particle 1e7 sigmas away (tests) moves it by at most 16/K' sigmas, so the bulk keeps small coordinates --
 // which the expanded distance |a|^2 + |b|^2 - 2 a.b of both kernels needs (cancellation), and the split kernel's range.
-__global__ __launch_bounds__(256) void k_wcentre(const double* __restrict__ prev, size_t Kp, WConst* __restrict__ wc) {
+// two stages, fixed summation order (bit-reproducible): WC_NB row blocks per parameter, then one thread per parameter
+constexpr int WC_NB = 64;
+__global__ __launch_bounds__(256) void k_wcentre(const double* __restrict__ prev, size_t Kp, const WConst* __restrict__ wc,
+                                                 double* __restrict__ partial /* P x WC_NB */) {
     __shared__ double sm[4];
     const double* col = prev + Kp * (size_t)blockIdx.x;
     const double c0 = col[0], sc = wc->scale[blockIdx.x];
+    const size_t i0 = Kp * blockIdx.y / WC_NB, i1 = Kp * (blockIdx.y + 1) / WC_NB;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < Kp; i += 256) {
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const double d = (col[i] - c0) * sc;
         s += fmin(fmax(d, -16.0), 16.0);             // NaN -> -16: harmless, the NaN row poisons the weights anyway
     }
     s = block_sum_256(s, sm);
-    if (threadIdx.x == 0) wc->centre[blockIdx.x] = (sc != 0.0) ? c0 + (s / (double)Kp) / sc : c0;
+    if (threadIdx.x == 0) partial[blockIdx.x * WC_NB + blockIdx.y] = s;
+}
+__global__ void k_wcentre_finish(const double* __restrict__ prev, size_t Kp, int P, const double* __restrict__ partial,
+                                 WConst* __restrict__ wc) {
+    const int p = threadIdx.x;
+    if (p >= P) return;
+    double s = 0.0;
+    for (int b = 0; b < WC_NB; b++) s += partial[p * WC_NB + b];
+    const double c0 = prev[Kp * (size_t)p], sc = wc->scale[p];
+    wc->centre[p] = (sc != 0.0) ? c0 + (s / (double)Kp) / sc : c0;
 }
 
 __device__ __forceinline__ unsigned bf16_bits(double v, double* back) {      // round to nearest even, value returned too
@@ -562,17 +575,19 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* part = (double*)abc_ws_alloc(ctx, slices * kn * sizeof(double));
     double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
+    double* cpart = (double*)abc_ws_alloc(ctx, 64 * WC_NB * sizeof(double));
     unsigned short *at = nullptr, *bt = nullptr;
     if (split) {
         at = (unsigned short*)abc_ws_alloc(ctx, nat * opa * 1024);
         bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
         if (!at || !bt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     }
-    if (!wc || !a || !b || !part || !hb) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    if (!wc || !a || !b || !part || !hb || !cpart) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc);
-    hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P), dim3(256), 0, ctx->stream, theta_prev, Kp, wc);
+    hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, ctx->stream, theta_prev, Kp, wc, cpart);
+    hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(64), 0, ctx->stream, theta_prev, Kp, (int)P, cpart, wc);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
                        (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, ctx->stream, theta_prev, Kp, Kp,

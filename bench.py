@@ -156,24 +156,36 @@ def main():
                 "launches_per_step": gram_launches_per_step, "event_bracket_ms": round(gram_bracket_ms, 5),
                 "event_overhead_ms": round(event_overhead_ms, 5), "achieved_event_bracket": round(achieved_raw, 1)}
     stage_ms = {k: round((v[0] + v[1]) / max(args.steps, 1), 5) for k, v in stages.items()}
-    # the compute-bound kernel of the path (informational): pairs x flops per pair / HIP-event time.
-    # Per pair (30 vector instructions at P = 16): 1 add, P FMAs (dot product), inline 2^x = 3 adds for the
-    # rounding split + 8 FMAs (minimax polynomial) + ldexp, 1 accumulate.  FMA = 2 flop, the rest 1.
+    # the compute-bound kernel of the path (informational): pairs x vector instructions per pair / HIP-event time.
+    # Two kernels can run it: the split-operand kernel (pair dot products on the bf16 matrix pipe,
+    # 14.5 fp64 vector instructions per pair: 2 converts, 5 adds, 6 FMAs, ldexp + loop share; 13 ceil(P/16) + 2 MFMAs
+    # per 32 x 32 pairs) and the fp64 vector kernel (1 add, PP FMAs, 13 for 2^x).  The chip is power-limited on both
+    # (measured 2.13 GHz on the fp64 kernel, 1.69 GHz with the matrix pipe active: profiles/r01_pmc_kde_clock.json), so
+    # the issue-rate fraction is quoted against the 2.4 GHz peak clock.
     k_ms, _, _ = stages["k_kde"]
     pairs = float(K // world + (1 if rank < K % world else 0)) * Kp if world > 1 else float(K) * Kp
     PPad = 2
     while PPad < P:
         PPad *= 2
-    flop_pair = 1 + 2 * PPad + 3 + 2 * 8 + 1 + 1
-    instr_pair = 1 + PPad + 3 + 8 + 1 + 1
+    which = ctx.kde_last_kernel()
     kde_ms_per_step = k_ms / max(args.steps, 1)
+    if which == _lib.KDE_RAN_SPLIT:
+        kname, instr_pair, flop_pair = "k_kde_split", 14.5, 2 + 5 + 2 * 6 + 1
+        mfma_per_1024 = 13 * ((P + 15) // 16) + 2
+    else:
+        kname, instr_pair, flop_pair = "k_kde", 1 + PPad + 3 + 8 + 1 + 1, 1 + 2 * PPad + 3 + 2 * 8 + 1 + 1
+        mfma_per_1024 = 0
     kde_tflops = pairs * flop_pair / (kde_ms_per_step * 1e-3) / 1e12 if kde_ms_per_step > 0 else 0.0
-    roofline_compute = {"kernel": "k_kde", "bound": "fp64_valu", "achieved": round(kde_tflops, 2), "peak": 78.6,
-                        "unit": "TFLOP/s", "frac": round(kde_tflops / 78.6, 4),
-                        "note": "peak = MI355X fp64 vector spec; scripts/ubench.hip measures 56 TFLOP/s sustained v_fma_f64",
-                        "pairs_per_step": pairs, "flop_per_pair": flop_pair, "valu_instr_per_pair": instr_pair,
-                        "valu_instr_rate_frac": round(pairs * instr_pair / (kde_ms_per_step * 1e-3) / (78.6e12 / 2), 4)
-                        if kde_ms_per_step > 0 else 0.0, "kernel_ms_per_step": round(kde_ms_per_step, 5)}
+    issue_peak = 256 * 4 * 2.4e9 / 4.0                # wave-instructions per second: 1024 SIMDs, 4 cycles each, 2.4 GHz
+    roofline_compute = {"kernel": kname, "bound": "fp64_valu_issue", "pairs_per_step": pairs,
+                        "pairs_per_s": pairs / (kde_ms_per_step * 1e-3) if kde_ms_per_step > 0 else 0.0,
+                        "valu_instr_per_pair": instr_pair, "mfma_32x32x16_per_1024_pairs": mfma_per_1024,
+                        "valu_issue_frac": round(pairs / 64.0 * (instr_pair + mfma_per_1024 * 2.0 / 16.0)
+                                                 / (kde_ms_per_step * 1e-3) / issue_peak, 4) if kde_ms_per_step > 0 else 0.0,
+                        "fp64_vector_tflops": round(kde_tflops, 2), "fp64_vector_peak_tflops": 78.6,
+                        "note": "valu_issue_frac = (vector instructions + 8 issue cycles per MFMA) / (1024 SIMDs x 2.4 GHz / 4); "
+                                "the fp64 kernel of the same stage (abc_ctx_set_kde_mode) runs 30 instructions per pair",
+                        "kernel_ms_per_step": round(kde_ms_per_step, 5)}
 
     # set 0 (uniform weights, AbcUtil.cpp:539-545) has no O(K K') stage: reported separately, outside the timed region
     set0 = None
