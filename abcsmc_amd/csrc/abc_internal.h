@@ -200,6 +200,10 @@ int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, 
                    int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
                    uint64_t seed_stream_offset);
 
+// [GSL] gsl_ran_discrete_preproc on the host (alias_host.cpp, a host-only translation unit built with the host compiler):
+// scratch E: K doubles, smalls / bigs: K + 1 uint32 each
+void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs);
+
 // taus2 helpers shared by host code
 void taus2_set(abc_rng* r, unsigned long seed);
 uint32_t taus2_get(abc_rng* r);

@@ -390,48 +390,7 @@ int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
     return ABC_OK;
 }
 
-// [GSL] gsl_ran_discrete_preproc (randist/discrete.c): Walker alias with two LIFO stacks.
-// scratch: K doubles (E) + 2 (K + 1) uint32 (the stacks), caller-provided so the hot loop never allocates.
-void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs) {
-    // Same sequence of floating-point operations as GSL's loop (sequential total, E = w / total, one subtraction
-    // per small from the big on top of the stack); only the bookkeeping differs: a big that stays big after serving
-    // a small is pushed and popped again at once upstream, here it simply stays in registers.  (Threading the
-    // order-free passes was measured on the GPU box, scripts/alias_bench.cpp: at K = 8e5 the serving loop and the
-    // sequential total are 60-75 % of the time and thread start-up eats the rest of the gain.)
-    double total = 0.0;
-    for (size_t k = 0; k < K; k++) total += w[k];
-    const double mean = 1.0 / (double)K, dK = (double)K;
-    for (size_t k = 0; k < K; k++) E[k] = w[k] / total;      // vectorised by the host compiler
-    size_t ns = 0, nb = 0;
-    for (size_t k = 0; k < K; k++) {          // branch-free: for random weights a conditional push mispredicts every
-        const bool sm = E[k] < mean;          // other element (2.8 -> 0.7 ms at K = 8e5); scratch holds K + 1 entries
-        smalls[ns] = (uint32_t)k;
-        bigs[nb] = (uint32_t)k;
-        ns += sm;
-        nb += !sm;
-    }
-    bool have = false;
-    uint32_t cb = 0;
-    double eb = 0.0;
-    while (ns) {
-        const uint32_t s = smalls[--ns];
-        if (!have) {
-            if (!nb) { A[s] = s; F[s] = 1.0; continue; }
-            cb = bigs[--nb];
-            eb = E[cb];
-            have = true;
-        }
-        const double es = E[s];
-        A[s] = cb;
-        F[s] = dK * es;
-        eb -= mean - es;
-        if (eb < mean) { E[cb] = eb; smalls[ns++] = cb; have = false; }       // demoted: it is served next
-        else if (!(eb > mean)) { A[cb] = cb; F[cb] = 1.0; have = false; }     // exactly full
-    }
-    if (have) { A[cb] = cb; F[cb] = 1.0; }
-    while (nb) { const uint32_t b = bigs[--nb]; A[b] = b; F[b] = 1.0; }
-    for (size_t k = 0; k < K; k++) F[k] = (F[k] + (double)k) / dK;            // KNUTH_CONVENTION
-}
+// the serial Walker build lives in alias_host.{h,cpp} (plain C++, also compiled and checked by tests/cxx/alias_probe.cpp)
 
 }  // namespace
 
@@ -462,7 +421,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     ABC_HIP(ctx, hipEventSynchronize(ctx->ev_copy));
     {
         const auto t0 = std::chrono::steady_clock::now();
-        alias_preproc(K, hw, hF, hA, hE, hS, hB);
+        abc_alias_preproc(K, hw, hF, hA, hE, hS, hB);
         if (ctx->timing) {
             ctx->stage_host_ms[ST_ALIAS_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             ctx->stage_cnt[ST_ALIAS_HOST] += 1;

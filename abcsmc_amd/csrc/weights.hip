@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
 // ONE more K-step whose operands hold the bf16 pieces of hb / ha against -1s / 1s on the other side.  X + Y is then
 // the whole base-2 exponent of the term (<= log2 w'_j), and the vector pipe only converts, adds and exponentiates:
 //   term = 2^(double(X) + double(Y))          14 instructions per pair instead of 30 (degree-6 polynomial).
-// Measured error of a weight against the oracle: 3.4e-9 max, 7e-10 rms (tests/test_gpu_parity.py), budget 1e-6.
+// Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32).  Measured error of a
+// weight against the oracle: 3.6e-9 max, 7e-10 rms (tests/test_gpu_parity.py), budget 1e-6.
 // Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400], converged parameters) raise
 // wc->far_split / use nzero and the fp64 kernel above runs instead: both kernels are always launched and the one
 // whose turn it is not returns at once, so no flag travels to the host.

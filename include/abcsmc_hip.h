@@ -69,7 +69,8 @@ int  abc_ctx_synchronize(abc_ctx* ctx);
 int  abc_version(void);
 /* Which kernel evaluates the O(K K' P) pair sums of weight_predictive_prior (AbcUtil.cpp:556-581).
  * ABC_KDE_AUTO (default): 8 < P <= 32 parameters run the split-operand kernel (pair dot products on the bf16 matrix
- * pipe from four exact limbs per coordinate, <= 2e-8 absolute error in the base-2 exponent of a term; sets it cannot
+ * pipe from four exact limbs per coordinate, <= 2e-8 (P <= 16) / 5e-8 (P <= 32) absolute error in the base-2 exponent of a
+ * term, measured <= 4e-9 relative on a weight; sets it cannot
  * represent exactly fall back by themselves); ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);

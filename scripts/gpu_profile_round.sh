@@ -25,6 +25,10 @@ done
 (cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     -d "$OUT/pmcf_sq2_c3" -o runc --output-format csv -- \
     python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmcf_sq2_c3.log" 2>&1
+# the weight kernel: cycles (clock = GRBM_GUI_ACTIVE / 8 XCDs / duration), matrix-pipe busy cycles, vector instructions
+(cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU \
+    -d "$OUT/pmcf_kde_c3" -o runc --output-format csv -- \
+    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmcf_kde_c3.log" 2>&1
 # trim what travels back: only the stats / counter CSVs are needed
 find "$OUT" -name '*_kernel_trace.csv' -size +8M -delete
 ls -la "$OUT"/prof_final_c3/runc* "$OUT"/pmcf_fetch_c3/runc* 2>/dev/null | head

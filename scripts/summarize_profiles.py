@@ -68,3 +68,33 @@ if sq:
         sq['wait_fraction_of_wave_cycles'] = sq['SQ_WAIT_INST_ANY'] / sq['SQ_WAVE_CYCLES']
     json.dump(sq, open('profiles/%s_pmc_sq_k_gram_config3.json' % tag, 'w'), indent=1, sort_keys=True)
     print("sq:", sq)
+
+# the weight kernel (k_kde_split / k_kde): clock and matrix-pipe utilisation from the pmcf_kde_c3 pass + the kernel stats
+try:
+    kd = {}
+    for r in csv.DictReader(open(find('gpurun_out/%s_kde_c3' % pp, 'counter_collection.csv'))):
+        if 'k_kde' in r['Kernel_Name']:
+            kd.setdefault(short(r['Kernel_Name']), {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+    dur = {}
+    for r in csv.DictReader(open(find('gpurun_out/%s_c3' % sp, 'kernel_stats.csv'))):
+        if 'k_kde' in r['Name']:
+            dur[short(r['Name'])] = float(r['AverageNs'])
+    out = {"_note": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU on `python3 bench.py "
+                    "--config 3 --steps 2 --warmup 1 --no-cpu-baseline` (per-dispatch averages) + the kernel duration of the "
+                    "--kernel-trace --stats pass; GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = cycles / 8 / duration; "
+                    "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles per XCD"}
+    for k, c in kd.items():
+        c = {n: sum(v) / len(v) for n, v in c.items()}
+        if c.get('GRBM_GUI_ACTIVE', 0) < 1e6:          # the kernel that was not its turn returns at once
+            continue
+        cyc = c['GRBM_GUI_ACTIVE'] / 8
+        ent = {"counters": {n: round(v) for n, v in c.items()}, "cycles_per_xcd": round(cyc),
+               "mfma_busy_frac": round(c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cyc, 3)}
+        if k in dur:
+            ent["kernel_avg_ms"] = round(dur[k] / 1e6, 4)
+            ent["clock_ghz"] = round(cyc / dur[k], 3)
+        out[k] = ent
+    json.dump(out, open('profiles/%s_pmc_kde_config3.json' % tag, 'w'), indent=1, sort_keys=True)
+    print("kde:", {k: v for k, v in out.items() if k != "_note"})
+except (IndexError, FileNotFoundError) as e:
+    print("no kde pmc pass:", e)

@@ -241,3 +241,17 @@ def test_samplers_respect_priors(oracle):
     assert out2[:, 2].min() >= 0 and out2[:, 2].max() <= 1
     d = out2[:, 0] - th[par2.astype(int), 0]
     assert abs(d.var() / dv[0] - 1) < 0.15
+
+
+def test_alias_host_build_is_bit_exact(tmp_path):
+    """abcsmc_amd/csrc/alias_host.h (host side of the resampling table, part of the product): its blocked exact sum and
+    the whole Walker table against the naive sequential loops / GSL's algorithm, bit for bit, on random and adversarial
+    weight vectors (exact ties, zeros, negatives, denormals, overflow, NaN) -- tests/cxx/alias_probe.cpp"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "alias_probe")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall",
+                           os.path.join(root, "tests", "cxx", "alias_probe.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
