@@ -69,7 +69,8 @@ struct WConst {           // per-parameter constants, built on the device by k_w
     int nzero;            // number of parameters with dv_p == 0
     int zero_idx[64];
     int far;              // set by k_wscale when a scaled coordinate is so large that exponents may leave int32
-    int far_split;        // set by k_wsplit when a row leaves the range the split-operand kernel is exact on
+    int nfar_i, nfar_j;   // rows of the new / previous set outside the range the split-operand kernel is exact on (k_wsplit)
+    int lim_i;            // more far new rows than this: the fp64 kernel takes the whole call
     double centre[64];    // robust column centre of the previous set (k_wcentre): both sets are centred here
 };
 
@@ -77,7 +78,13 @@ constexpr double W_SQRT_LOG2E = 1.2011224087864497825;     // sqrt(log2 e): a.b 
 constexpr double W_COORD_BOUND = 2000.0;                   // |x| <= 2 PP B^2 + 1e8 < 2^31 for PP <= 64
 constexpr double W_HB_MAX = 1.0e8;                         // stands for "weight 0": 2^-1e8 == 0
 
-__global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc) {
+constexpr int KS_MAX_FAR_J = 1024;     // far previous rows the column fix-up takes; more: the fp64 kernel takes the whole call
+// the split-operand kernel (+ its far-row fix-ups) handles this call; otherwise the fp64 kernel does
+__device__ __forceinline__ bool ks_split_on(const WConst* wc) {
+    return !(wc->nzero | wc->far) && wc->nfar_i <= wc->lim_i && wc->nfar_j <= KS_MAX_FAR_J;
+}
+
+__global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc, int lim_i) {
     if (threadIdx.x != 0) return;
     double C = 1.0; int nz = 0;
     for (int p = 0; p < 64; p++) {
@@ -89,7 +96,7 @@ __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __res
         }
         wc->scale[p] = sc * W_SQRT_LOG2E;
     }
-    wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0; wc->far_split = 0;
+    wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0; wc->nfar_i = 0; wc->nfar_j = 0; wc->lim_i = lim_i;
 }
 
 // scaled copies: out[row*PP + p] = (in[row + ld*p] - centre[p]) * scale[p]   (row-major, zero padded to PP);
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
                                              const double* __restrict__ theta_raw, size_t K, size_t k0,
                                              const double* __restrict__ prev_raw, double* __restrict__ part,
                                              int fallback_of_split) {
-    // launched behind k_kde_split: runs only when that kernel declined (rows outside its exact range)
-    if (fallback_of_split && !(wc->far_split | wc->nzero | wc->far)) return;
+    // launched behind k_kde_split: runs only when that kernel declined (converged parameters, too many far rows)
+    if (fallback_of_split && ks_split_on(wc)) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t slices = gridDim.y, sl = blockIdx.y;
     // wave-uniform bounds in SGPRs (Kp < 2^32, checked by the launcher): the loop test stays off the vector pipe
@@ -206,9 +213,12 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
 //   term = 2^(double(X) + double(Y))          14 instructions per pair instead of 30 (degree-6 polynomial).
 // Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32).  Measured error of a
 // weight against the oracle: 3.6e-9 max, 7e-10 rms (tests/test_gpu_parity.py), budget 1e-6.
-// Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400], converged parameters) raise
-// wc->far_split / use nzero and the fp64 kernel above runs instead: both kernels are always launched and the one
-// whose turn it is not returns at once, so no flag travels to the host.
+// Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400]) are "far": k_wsplit gives them
+// all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up kernels add
+// their pairs (k_kde_far_rows: a far new particle against the whole previous set; k_kde_far_cols: the far previous
+// particles against every new one), k_wfinish picking per row.  With converged parameters, coordinates beyond the int32
+// exponent range, or too many far rows (> K/16 + 32 new, > 1024 previous) the fp64 kernel above takes the whole call: every
+// kernel is always launched and those whose turn it is not return at once, so no flag travels to the host.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -276,7 +286,9 @@ constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
 template <int NCH>
 __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, int PPsrc, size_t rows, size_t rows_pad,
                                                 const double* __restrict__ w, int is_prev, WConst* __restrict__ wc,
-                                                unsigned short* __restrict__ tiles, int ops) {
+                                                unsigned short* __restrict__ tiles, int ops,
+                                                unsigned char* __restrict__ far_flag /* new set */,
+                                                unsigned* __restrict__ far_list /* previous set, KS_MAX_FAR_J */) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows_pad) return;
     bool valid = r < rows;
@@ -290,6 +302,18 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
             if (!(lw >= -400.0 && lw <= KS_LW_CAP)) far = true;      // w' > 2^400, < 2^-600, negative or NaN
         }
     }
+    constexpr int PPK = 16 * NCH;
+    if (valid) {
+        for (int p = 0; p < PPK && p < PPsrc; p++) far = far || !(fabs(sc[r * (size_t)PPsrc + p]) <= KS_BOUND);
+    }
+    // a far row takes no part in the matrix work (all-zero limbs, and hb = KS_HB_ZERO on the previous side): the fp64
+    // fix-up kernels (k_kde_far_rows / k_kde_far_cols) add its pairs
+    if (far) {
+        if (is_prev) { const int pos = atomicAdd(&wc->nfar_j, 1); if (pos < KS_MAX_FAR_J) far_list[pos] = (unsigned)r; }
+        else atomicAdd(&wc->nfar_i, 1);
+        valid = false;
+    }
+    if (!is_prev) far_flag[r] = far ? 1 : 0;
     unsigned short* tb = tiles + (r >> 5) * (size_t)ops * 512;
     const unsigned rr = (unsigned)(r & 31);
     constexpr double U1 = ks_u1(NCH);
@@ -302,8 +326,7 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int p = c * 16 + h * 8 + j;            // the copy is PPsrc wide (zero padded to a power of two)
-                double v = (valid && p < PPsrc) ? sc[r * (size_t)PPsrc + p] : 0.0;
-                if (!(fabs(v) <= KS_BOUND)) { far = true; v = 0.0; }
+                const double v = (valid && p < PPsrc) ? sc[r * (size_t)PPsrc + p] : 0.0;
                 nn = fma(v, v, nn);
                 double back;
                 const double l0 = rint(v * 4.0) * 0.25;
@@ -329,17 +352,92 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
     unsigned pc[6];
     unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
     if (is_prev) {
-        ks_pieces(valid && !far ? 0.5 * nn + lw : KS_HB_ZERO, 4.0 * U1, pc);
+        ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, 4.0 * U1, pc);
         *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), 0u);
         *(uint4*)(ob + (32 + rr) * 8) = make_uint4(KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), 0u);
     } else {
-        ks_pieces(far ? 0.0 : -0.5 * nn, 4.0 * U1, pc);         // negated: the operand holds -ha
+        ks_pieces(-0.5 * nn, 4.0 * U1, pc);                     // negated: the operand holds -ha  (0 for a far row)
         *(uint4*)(ob + rr * 8) = make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u);                       // X operand
         *(uint4*)(ob + (32 + rr) * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2], 0u, 0u);
         *(uint4*)(ob + 512 + rr * 8) = make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u);           // Y operand
         *(uint4*)(ob + 512 + (32 + rr) * 8) = make_uint4(0u, pc[3] << 16, pc[4] | (pc[5] << 16), 0u);
     }
-    if (far) atomicOr(&wc->far_split, 1);
+}
+
+// ---- far rows: pairs the split-operand kernel leaves out, in fp64 -----------------------------------------------------
+// ascending order of the (atomically appended, hence unordered) list of far previous rows: one work-group, bitonic in LDS;
+// a fixed order makes the column fix-up's sums bit-reproducible
+__global__ __launch_bounds__(1024) void k_wfarsort(const WConst* __restrict__ wc, unsigned* __restrict__ list) {
+    __shared__ unsigned sl[KS_MAX_FAR_J];
+    const int n = wc->nfar_j;
+    if (n <= 1 || n > KS_MAX_FAR_J || !ks_split_on(wc)) return;
+    const unsigned t = threadIdx.x;
+    sl[t] = ((int)t < n) ? list[t] : 0xffffffffu;
+    for (unsigned k = 2; k <= KS_MAX_FAR_J; k <<= 1)
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            const unsigned u = t ^ j;
+            if (u > t) {
+                const unsigned a = sl[t], b = sl[u];
+                if ((a > b) == ((t & k) == 0)) { sl[t] = b; sl[u] = a; }
+            }
+        }
+    __syncthreads();
+    if ((int)t < n) list[t] = sl[t];
+}
+
+// the base-2 exponent of one pair from the scaled fp64 rows, as k_kde's guarded loop computes it
+template <int PP>
+__device__ __forceinline__ double ks_pair_term(const double (&ai)[PP], double ha, const double* __restrict__ bj, double hbj) {
+    double e = -(ha + hbj);
+#pragma unroll
+    for (int p = 0; p < PP; p++) e = fma(ai[p], bj[p], e);
+    return exp2_neg<true>(e);
+}
+
+// far NEW particles: their whole sum over the previous set.  One work-group per tile of 32 new rows; tiles without a
+// far row (nearly all) return at once.
+template <int PP>
+__global__ __launch_bounds__(256) void k_kde_far_rows(const double* __restrict__ a, size_t kn, const double* __restrict__ b,
+                                                      size_t Kp, const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                                      const unsigned char* __restrict__ far_flag, double* __restrict__ fix_i) {
+    if (!ks_split_on(wc) || wc->nfar_i == 0) return;
+    __shared__ double sm[4];
+    const size_t i0 = (size_t)blockIdx.x * 32;
+    for (int r = 0; r < 32; r++) {
+        const size_t i = i0 + r;
+        if (i >= kn || !far_flag[i]) continue;               // work-group uniform
+        double ai[PP], ha = 0.0;
+#pragma unroll
+        for (int p = 0; p < PP; p++) { ai[p] = a[i * PP + p]; ha = fma(ai[p], ai[p], ha); }
+        ha *= 0.5;
+        double s = 0.0;
+        for (size_t j = threadIdx.x; j < Kp; j += 256) s += ks_pair_term<PP>(ai, ha, b + j * PP, hb[j]);
+        s = block_sum_256(s, sm);
+        if (threadIdx.x == 0) fix_i[i] = s;
+        __syncthreads();
+    }
+}
+
+// far PREVIOUS particles: their terms for every new particle (one per lane), in list order
+template <int PP>
+__global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__ a, size_t kn, const double* __restrict__ b,
+                                                      const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                                      const unsigned* __restrict__ list, double* __restrict__ fix_j) {
+    const int n = wc->nfar_j;
+    if (!ks_split_on(wc) || n == 0) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= kn) return;
+    double ai[PP], ha = 0.0;
+#pragma unroll
+    for (int p = 0; p < PP; p++) { ai[p] = a[i * PP + p]; ha = fma(ai[p], ai[p], ha); }
+    ha *= 0.5;
+    double s = 0.0;
+    for (int q = 0; q < n; q++) {
+        const size_t j = list[q];
+        s += ks_pair_term<PP>(ai, ha, b + j * PP, hb[j]);
+    }
+    fix_j[i] = s;
 }
 
 // 2^x for the split kernel: same split as exp2_neg<false>, degree-6 minimax polynomial (1.9e-9 relative,
@@ -423,7 +521,7 @@ template <int NCH, int G>
 __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4* __restrict__ at, size_t kn,
                                                       const uint4* __restrict__ bt, unsigned nbt,
                                                       const WConst* __restrict__ wc, double* __restrict__ part) {
-    if (wc->far_split | wc->nzero | wc->far) return;          // the fp64 kernel's turn
+    if (!ks_split_on(wc)) return;                             // the fp64 kernel's turn
     constexpr int OPA = NCH * KS_NL + 2, OPB = NCH * KS_NL + 1;
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
@@ -482,15 +580,22 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
                                                  size_t K, int P, size_t k0, size_t kn,
                                                  const double* __restrict__ part, int slices,
                                                  const WConst* __restrict__ wc, double* __restrict__ w_raw,
-                                                 int split_launched, int* __restrict__ which) {
+                                                 int split_launched, int* __restrict__ which,
+                                                 const unsigned char* __restrict__ far_flag, const double* __restrict__ fix_i,
+                                                 const double* __restrict__ fix_j) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0)       // which kernel's sums these are (abc_kde_last_kernel)
-        *which = (split_launched && !(wc->far_split | wc->nzero | wc->far)) ? ABC_KDE_RAN_SPLIT : ABC_KDE_RAN_FP64;
+    const bool split_on = split_launched && ks_split_on(wc);
+    if (i == 0) *which = split_on ? ABC_KDE_RAN_SPLIT : ABC_KDE_RAN_FP64;       // abc_kde_last_kernel
     if (i >= kn) return;
     double num = 1.0;
     for (int p = 0; p < P; p++) num *= prior_likelihood(priors[p], theta[(k0 + i) + K * (size_t)p]);
     double den = 0.0;
-    for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
+    if (split_on && far_flag[i]) {
+        den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far_rows
+    } else {
+        for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
+        if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far_cols)
+    }
     w_raw[i] = num / (wc->C * den);
 }
 
@@ -578,15 +683,22 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
     double* cpart = (double*)abc_ws_alloc(ctx, 64 * WC_NB * sizeof(double));
     unsigned short *at = nullptr, *bt = nullptr;
+    unsigned char* far_flag = nullptr;
+    unsigned* far_list = nullptr;
+    double *fix_i = nullptr, *fix_j = nullptr;
     if (split) {
         at = (unsigned short*)abc_ws_alloc(ctx, nat * opa * 1024);
         bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
-        if (!at || !bt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+        far_flag = (unsigned char*)abc_ws_alloc(ctx, nat * 32);
+        far_list = (unsigned*)abc_ws_alloc(ctx, KS_MAX_FAR_J * sizeof(unsigned));
+        fix_i = (double*)abc_ws_alloc(ctx, kn * sizeof(double));
+        fix_j = (double*)abc_ws_alloc(ctx, kn * sizeof(double));
+        if (!at || !bt || !far_flag || !far_list || !fix_i || !fix_j) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     }
     if (!wc || !a || !b || !part || !hb || !cpart) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
-    hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc);
+    hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc, (int)(kn / 16 + 32));
     hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, ctx->stream, theta_prev, Kp, wc, cpart);
     hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(64), 0, ctx->stream, theta_prev, Kp, (int)P, cpart, wc);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
@@ -597,14 +709,14 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         const size_t ra = nat * 32, rbp = nbt * 32;
         if (NCH == 1) {
             hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
-                               (const double*)nullptr, 0, wc, at, opa);
+                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list);
             hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb);
+                               w_prev, 1, wc, bt, opb, far_flag, far_list);
         } else {
             hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
-                               (const double*)nullptr, 0, wc, at, opa);
+                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list);
             hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb);
+                               w_prev, 1, wc, bt, opb, far_flag, far_list);
         }
     }
 #define LAUNCH_KDE(PPV)                                                                                        \
@@ -631,8 +743,24 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         }
     }
 #undef LAUNCH_KDE
+    if (split) {        // far rows (outside the split kernel's exact range): both kernels return at once when there are none
+        hipLaunchKernelGGL(k_wfarsort, dim3(1), dim3(1024), 0, ctx->stream, wc, far_list);
+#define LAUNCH_FAR(PPV)                                                                                                  \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL(k_kde_far_rows<PPV>, dim3((unsigned)nat), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc,    \
+                           far_flag, fix_i);                                                                             \
+        hipLaunchKernelGGL(k_kde_far_cols<PPV>, dim3((unsigned)rb), dim3(256), 0, ctx->stream, a, kn, b, hb, wc, far_list, \
+                           fix_j);                                                                                       \
+    } while (0)
+        switch (PP) {
+            case 8: LAUNCH_FAR(8); break;
+            case 16: LAUNCH_FAR(16); break;
+            default: LAUNCH_FAR(32); break;
+        }
+#undef LAUNCH_FAR
+    }
     hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
-                       (int)slices, wc, w_raw, split ? 1 : 0, ctx->kde_which);
+                       (int)slices, wc, w_raw, split ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

@@ -266,8 +266,9 @@ def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle):
 
 def test_weight_split_kernel_range_edges(gpu_ctx, oracle):
     """edges of the range the split-operand kernel is exact on: particles up to ~9.5 scaled units from the centre and
-    previous weights down to 1e-150 stay on it and still match the oracle; one coordinate past 10 units, or a weight of
-    1e-200, hands the whole call to the fp64 kernel (same answer, tighter tolerance)"""
+    previous weights down to 1e-150 are inside it; one coordinate past 10 units, or a weight of 1e-200, makes that ROW
+    'far': it leaves the matrix work and its pairs are added in fp64 by the fix-up kernels -- the call stays on the split
+    kernel and still matches the oracle"""
     from abcsmc_amd import abcutil, _lib
     P, K, Kp = 16, 400, 600
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 99)
@@ -286,17 +287,59 @@ def test_weight_split_kernel_range_edges(gpu_ctx, oracle):
     assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
     assert np.all(ref > 0) and np.max(np.abs(w - ref) / ref) < KDE_TOL["auto"]
     th2 = th.copy()
-    th2[6, 3] = centre[3] - 10.6 * unit[3]
+    th2[6, 3] = centre[3] - 10.6 * unit[3]                                    # a far new particle
     ref2 = oracle.weights_importance(opri, th2, tp, wp, dv)
     w2 = abcutil.weight_predictive_prior(pri, th2, tp, wp, dv, ctx=gpu_ctx)
-    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64
-    assert np.max(np.abs(w2 - ref2) / ref2) < KDE_TOL["fp64"]
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
+    assert np.max(np.abs(w2 - ref2) / ref2) < KDE_TOL["auto"]
+    assert abs(w2[6] - ref2[6]) / ref2[6] < KDE_TOL["fp64"]                  # the far row itself: summed in fp64
     wp3 = wp.copy()
-    wp3[9] = 1e-200
+    wp3[9] = 1e-200                                                           # a far previous particle
     ref3 = oracle.weights_importance(opri, th, tp, wp3, dv)
     w3 = abcutil.weight_predictive_prior(pri, th, tp, wp3, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
+    assert np.max(np.abs(w3 - ref3) / ref3) < KDE_TOL["auto"]
+
+
+def test_weight_far_rows_are_fixed_up_row_by_row(gpu_ctx, oracle):
+    """particles outside the split-operand kernel's exact range on BOTH sides, scattered over tiles and slices: far new
+    particles next to far previous ones (their mutual term dominates both sums), a far previous particle next to ordinary
+    new ones, previous particles of weight 0 among the far ones.  Everything stays on the split kernel + fix-ups and
+    matches the oracle; the result is bit-reproducible; with more far rows than the fix-ups take, the fp64 kernel runs."""
+    from abcsmc_amd import abcutil, _lib
+    P, K, Kp = 16, 1500, 2100
+    wl, th, tp, wp, dv = _weights_case(P, K, Kp, 1234)
+    spec = [(_lib.PRIOR_GAUSS, 0.0, 1e9)] * P
+    pri, opri = _lib.make_priors(spec), oracle.make_priors(spec)
+    unit = np.sqrt(dv) / np.sqrt(np.log2(np.e))
+    centre = tp.mean(axis=0)
+    th, tp, wp = th.copy(), tp.copy(), wp.copy()
+    rng = np.random.default_rng(7)
+    far_i = [3, 40, 41, 777, 1499]
+    far_j = [0, 65, 1000, 2099, 2098]
+    for n, (i, j) in enumerate(zip(far_i, far_j)):
+        d = rng.normal(size=P)
+        d *= (12.0 + 3 * n) / np.abs(d).max()             # largest coordinate 12..24 units out
+        th[i, :] = centre + d * unit
+        tp[j, :] = th[i, :] + 0.2 * unit * rng.normal(size=P)          # a far neighbour: the dominant term of row i
+    tp[500, 2] = centre[2] + 10.4 * unit[2]               # far in ONE coordinate, otherwise among the ordinary particles
+    wp[[65, 300, 301]] = 0.0
+    ref = oracle.weights_importance(opri, th, tp, wp, dv)
+    w = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
+    assert np.all(ref > 0) and np.max(np.abs(w - ref) / ref) < KDE_TOL["auto"]
+    w_again = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    assert np.array_equal(w, w_again)                      # fixed summation orders (sorted far list, block trees)
+    with _kde_mode(gpu_ctx, "fp64"):
+        w64 = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    assert np.max(np.abs(w64 - ref) / ref) < KDE_TOL["fp64"]
+    # too many far new particles (> K/16 + 32): the fp64 kernel takes the call
+    th_many = th.copy()
+    th_many[::8, 0] = centre[0] + 11.0 * unit[0]
+    refm = oracle.weights_importance(opri, th_many, tp, wp, dv)
+    wm = abcutil.weight_predictive_prior(pri, th_many, tp, wp, dv, ctx=gpu_ctx)
     assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_FP64
-    assert np.max(np.abs(w3 - ref3) / ref3) < KDE_TOL["fp64"]
+    assert np.max(np.abs(wm - refm) / refm) < KDE_TOL["fp64"]
 
 
 def test_weight_uniform_first_set(gpu_ctx):
