@@ -342,6 +342,44 @@ def test_weight_far_rows_are_fixed_up_row_by_row(gpu_ctx, oracle):
     assert np.max(np.abs(wm - refm) / refm) < KDE_TOL["fp64"]
 
 
+def test_weight_kernels_agree_on_random_shapes(gpu_ctx):
+    """randomised shapes (every padded width 8 / 16 / 32, row counts that are not multiples of the 32-row tiles, the 64-row
+    waves or the 256-row work-groups, several column slices) and row sub-ranges as the sharded driver uses them
+    (abc_weights_raw_dev with k0 > 0): the split-operand kernel against the fp64 kernel of the same library"""
+    import torch
+    from abcsmc_amd import _lib, device, sharded, synthetic
+    rng = np.random.default_rng(2024)
+    be = sharded.HipBackend("cuda:0", gpu_ctx)
+    for case in range(24):
+        P = int(rng.integers(5, 33))
+        K = int(rng.integers(1, 2500))
+        Kp = int(rng.integers(2, 6000))
+        wl = synthetic.Workload(4, P, seed=1000 + case)
+        _, th = wl.rows(0, K)
+        th = np.asfortranarray(wl.mu_y + 0.45 * (th - wl.mu_y))
+        tp, _, dv = wl.previous_set(Kp)
+        wp = rng.random(Kp) ** 4 + 1e-12
+        if case % 3 == 0:
+            wp[rng.integers(0, Kp, size=max(1, Kp // 50))] = 0.0
+        k0 = int(rng.integers(0, K))
+        kn = int(rng.integers(1, K - k0 + 1))
+        dth, dtp, dwp, ddv = (device.colmajor(a, "cuda:0") for a in (th, tp, wp, dv))
+        dpri = device.priors_to_device(_lib.make_priors(wl.prior_spec()), "cuda:0")
+        out = {}
+        for mode in ("auto", "fp64"):
+            with _kde_mode(gpu_ctx, mode):
+                o = torch.zeros(kn, dtype=torch.float64, device="cuda:0")
+                be.weights_raw(dpri, dth, k0, kn, dtp, dwp, ddv, o)
+                torch.cuda.synchronize()
+                assert gpu_ctx.kde_last_kernel() == (_lib.KDE_RAN_SPLIT if mode == "auto" else _lib.KDE_RAN_FP64)
+                out[mode] = o.cpu().numpy()
+        ok = out["fp64"] > 0
+        assert ok.any() and np.all(np.isfinite(out["auto"]))
+        err = np.abs(out["auto"][ok] - out["fp64"][ok]) / out["fp64"][ok]
+        assert err.max() < KDE_TOL["auto"], (case, P, K, Kp, k0, kn, err.max())
+        assert np.array_equal(out["auto"] == 0, out["fp64"] == 0)
+
+
 def test_weight_uniform_first_set(gpu_ctx):
     from abcsmc_amd import abcutil
     w = abcutil.weight_predictive_prior(None, np.zeros((123, 4)), ctx=gpu_ctx)
