@@ -44,6 +44,8 @@ def main():
                     help="BASELINE.json config: 3 = configs[2] (1M particles, the full weight+resample generation the metric "
                          "is quoted on; default), 2 = configs[1] (100k), 4/5 = per-GPU shards of configs[3]/[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kde-mode", choices=["auto", "fp64"], default="auto",
+                    help="weight kernel: auto = split-operand kernel where it applies (default), fp64 = the fp64 vector kernel (A/B runs)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     args = ap.parse_args()
 
@@ -86,6 +88,7 @@ def main():
     rng = abcutil.rng(67890)
 
     ctx = _lib.default_context(local_rank)
+    ctx.set_kde_mode(_lib.KDE_FP64 if args.kde_mode == "fp64" else _lib.KDE_AUTO)
     if world == 1:
         gen = device.Generation(N, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
 
