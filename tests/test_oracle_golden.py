@@ -255,3 +255,21 @@ def test_alias_host_build_is_bit_exact(tmp_path):
                            os.path.join(root, "tests", "cxx", "alias_probe.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("P,bound_rms,bound_max", [(16, 1e-8, 5e-8), (32, 3e-8, 1.5e-7)])
+def test_split_operand_arithmetic_emulation(P, bound_rms, bound_max):
+    """the operand split of the weight kernel k_kde_split, emulated in numpy (scripts/split_precision.py): the leading
+    accumulator X is exact in f32 (asserted inside the script for every case) and the exponent error of the shipped
+    split (4 limbs, 13 products per 16 parameters) stays inside the bound the header states"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "split_precision.py"), str(P), "250"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("shipped")][0]
+    rms, mx = (float(x) for x in re.findall(r"with the f32 accumulator: rms (\S+) max (\S+)", line)[0])
+    assert rms < bound_rms and mx < bound_max, line
