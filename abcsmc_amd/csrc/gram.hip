@@ -248,12 +248,15 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
     const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
     const long long r_begin = part ? split : 0, r_end = part ? n : split;
     const long long t0 = r_begin & ~1LL;
-    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + TR - 1) / TR : 0;
+    // rows per tile: the shared-tile variants use TR; wave-private staging gives every wave 16 rows, so 8 waves cover TR
+    // and the 4-wave variant for 4..6 column blocks (whose rings would not fit the LDS with 8 waves) covers 64
+    constexpr int TRK = PRIV ? 16 * NW : TR;
+    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + TRK - 1) / TRK : 0;
     const long long rmax = (n - 2) & ~1LL;             // last in-bounds 16-B row pair (n is even on this path)
 
     constexpr int NIW = PRIV ? D::C16 / 8 : D::NI;     // DMA instructions per wave per tile
     constexpr int CHB = D::C16 * 16;                   // PRIV: doubles per wave chunk (16 rows x C16 columns)
-    static_assert(!PRIV || (NW == 8 && TR == 128), "wave-private staging: 8 waves x 16 rows");
+    static_assert(!PRIV || ((NW == 8 && TR == 128) || NW == 4), "wave-private staging: 16 rows per wave, 8 or 4 waves");
     const double* cptr[NIW];
 #pragma unroll
     for (int i = 0; i < NIW; i++) {
@@ -265,13 +268,13 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
         if constexpr (PRIV) {
 #pragma unroll
             for (int i = 0; i < NIW; i++) {
-                long long r = t0 + tile * TR + 16 * wave + 2 * ((lane >> 3) ^ (i & 1));
+                long long r = t0 + tile * TRK + 16 * wave + 2 * ((lane >> 3) ^ (i & 1));
                 r = r > rmax ? rmax : r;                // rows past the end are masked later; keep the address legal
                 dma16(cptr[i] + r, wring + slot * CHB + i * 128);
             }
         } else {
             double* buf = lds + slot * D::BUF;
-            long long r = t0 + tile * TR + 2 * lane;
+            long long r = t0 + tile * TRK + 2 * lane;
             r = r > rmax ? rmax : r;
 #pragma unroll
             for (int i = 0; i < NIW; i++) {
@@ -320,11 +323,11 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
         }
         if constexpr (!PRIV) __syncthreads();   // every wave's share of this tile is in LDS; the buffer refilled below is idle
         if (tile + (R - 1) * G < ntiles) stage(tile + (R - 1) * G, (cur + R - 1) % R);
-        const long long row0 = t0 + tile * TR;
-        const bool full = (row0 >= r_begin) && (row0 + TR <= r_end);
+        const long long row0 = t0 + tile * TRK;
+        const bool full = (row0 >= r_begin) && (row0 + TRK <= r_end);
 #pragma unroll
-        for (int s = 0; s < TR / (4 * NW); s++) {
-            const int rb = wave * (TR / NW) + 4 * s + q;
+        for (int s = 0; s < TRK / (4 * NW); s++) {
+            const int rb = wave * (TRK / NW) + 4 * s + q;
             const long long grow = row0 + rb;
             const bool ok = full || (grow >= r_begin && grow < r_end);
             double a[C];
@@ -494,7 +497,8 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     using D = GramDimsDma<C, CY, NW, R>;
     const StatsLayout L = stats_layout(M, P);
     const long long ntr = split, nte = (long long)n - split;
-    const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
+    constexpr int TRK = PRIV ? 16 * NW : TR;          // rows per tile (k_gram_dma)
+    const long long tiles = ((ntr > nte ? ntr : nte) + TRK - 1) / TRK + 1;
     long long G = tiles / 2;
     if (G < 1) G = 1;
     if (G > 128) G = 128;              // 150 KB of LDS: one work-group per CU, 2 partitions x 128
@@ -502,7 +506,11 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
     if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
-    const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
+    // wave-private staging: NW rings of R chunks of 16 rows x C16 columns; the epilogue stages four waves' accumulators
+    constexpr size_t lds_priv = (size_t)NW * R * D::C16 * 16, lds_epi = (size_t)4 * D::NBLK * 256, lds_cs = (size_t)C * D::NT;
+    constexpr size_t lds_pmax = lds_priv > lds_epi ? (lds_priv > lds_cs ? lds_priv : lds_cs) : (lds_epi > lds_cs ? lds_epi : lds_cs);
+    const size_t lds_bytes = (PRIV ? lds_pmax : (size_t)D::LDS_D) * sizeof(double);
+    static_assert(!PRIV || lds_pmax * sizeof(double) <= 160 * 1024, "k_gram_dma: ring + epilogue exceed the 160 KB of LDS");
     // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW, PRIV, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
@@ -627,6 +635,13 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     }
     GRAM_DMA_CASE(1, 0); GRAM_DMA_CASE(2, 0); GRAM_DMA_CASE(2, 1); GRAM_DMA_CASE(3, 0); GRAM_DMA_CASE(3, 1); GRAM_DMA_CASE(3, 2);
 #undef GRAM_DMA_CASE
+    // 4..6 column blocks (49..96 columns, e.g. BASELINE configs[3]: 64 metrics + 32 parameters): the same kernel with FOUR
+    // waves of wave-private staging (64-row tiles; three-chunk rings of 8-12 KB per wave fit the LDS, eight would not).
+    // ABC_GRAM_DMA=0 keeps the VGPR-staged k_gram for A/B runs; (6, 0) needs 172 KB for its epilogue and stays there.
+#define GRAM_DMA4_CASE(c, cy) if (C == c && CY == cy && dma_ok) return run_gram_dma<c, cy, 4, true>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+    GRAM_DMA4_CASE(4, 0); GRAM_DMA4_CASE(4, 1); GRAM_DMA4_CASE(4, 2); GRAM_DMA4_CASE(5, 0); GRAM_DMA4_CASE(5, 1); GRAM_DMA4_CASE(5, 2);
+    GRAM_DMA4_CASE(6, 1); GRAM_DMA4_CASE(6, 2);
+#undef GRAM_DMA4_CASE
 #define GRAM_CASE(c, cy) if (C == c && CY == cy) return run_gram<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_CASE(1, 0); GRAM_CASE(2, 0); GRAM_CASE(2, 1); GRAM_CASE(3, 0); GRAM_CASE(3, 1); GRAM_CASE(3, 2);
     GRAM_CASE(4, 0); GRAM_CASE(4, 1); GRAM_CASE(4, 2); GRAM_CASE(5, 0); GRAM_CASE(5, 1); GRAM_CASE(5, 2);

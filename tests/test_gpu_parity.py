@@ -50,6 +50,10 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (4000, 64, 32, 8, 0.5),      # BASELINE configs[3] shape (6 column blocks, Y'Y blocks skipped)
     (3000, 128, 16, 32, 0.5),    # BASELINE configs[4] shape: 144 columns -> grouped Gram launches, 32 components
     (1500, 100, 28, 12, 0.5),    # ragged wide set
+    (4000, 40, 20, 6, 0.5),      # 4 column blocks: the four-wave LDS-DMA Gram kernel (one trailing parameter-only block)
+    (2002, 70, 9, 5, 0.45),      # 5 column blocks, parameters share the last block with metrics; split inside a tile
+    (3000, 50, 30, 6, 0.4),      # 5 column blocks, last one parameters only
+    (2001, 64, 32, 8, 0.5),      # 6 blocks, odd row count: the VGPR-staged kernel (LDS-DMA needs 16-byte row pairs)
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
