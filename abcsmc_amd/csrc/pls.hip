@@ -195,8 +195,26 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
     return tr;
 }
 
-// ONE wavefront.  LDS: XY (M*P), S and V (np*np each), vectors.
-__global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
+// sum over the work-group (NW waves); NW == 1: the wave sum
+template <int NW>
+__device__ __forceinline__ double pls_sum(double v, double* red) {
+    v = wave_sum(v);
+    if constexpr (NW == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) s += red[w];
+    return s;
+}
+
+// NW == 1: ONE wavefront (M <= 64: everything is tiny and latency-bound, no inter-wave barriers).  NW == 8 (M > 64, e.g.
+// BASELINE configs[4]: 128 metrics, 32 components): the eigenvector work stays on wave 0 (register-resident MFMA), every
+// vector phase is spread over the work-group -- X'X r with each row's dot product split four ways, the r-update with one
+// wave per earlier component, the PRESS contractions one entry per thread.  LDS: XY (M*P), S and V (np*np each), vectors.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
                                                 int M, int P, int A, double* __restrict__ model,
                                                 double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds) {
     extern __shared__ double lds[];
@@ -210,7 +228,9 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
 #endif
     const ModelLayout ML = model_layout(M, P, A);
     const ZLayout Z = z_layout(M, P);
-    const int lane = threadIdx.x;
+    constexpr int NT = 64 * NW;
+    const int lane = threadIdx.x;            // thread in the work-group (NW == 1: the lane)
+    const int wave = threadIdx.x >> 6;
     const int np = P;
     double* XY = lds;                   // M*P
     double* S = XY + (size_t)M * P;     // np*np
@@ -223,10 +243,13 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     double* Pl = xr + M;                // M*A: loadings P (LDS copy, read by the deflation of later components)
     double* Rl = Pl + (size_t)M * A;    // M*A: rotations R
     double* XXl = Rl + (size_t)M * A;   // M*M copy of X'X (training) when it fits (xx_in_lds)
+    double* red = XXl + (xx_in_lds ? (size_t)M * M : 0);   // 8: work-group sums
+    double* pwv = red + 8;              // A: projections of w on the earlier loadings (NW > 1)
+    double* xp = pwv + A;               // 4*M: partial dot products of X'X r (NW > 1)
 
     const double* XXtr = zwork + Z.off_XX[0];
     if (xx_in_lds) {
-        for (int e = lane; e < M * M; e += 64) XXl[e] = XXtr[e];
+        for (int e = lane; e < M * M; e += NT) XXl[e] = XXtr[e];
         XXtr = XXl;
     }
     double* Rm = model + ML.off_R;
@@ -234,13 +257,13 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     double* Wm = model + ML.off_W;
     double* Pm = model + ML.off_P;
 
-    for (int e = lane; e < M * P; e += 64) XY[e] = zwork[Z.off_XY[0] + e];
+    for (int e = lane; e < M * P; e += NT) XY[e] = zwork[Z.off_XY[0] + e];
     __syncthreads();
 
     STAMP(9);
     for (int comp = 0; comp < A; comp++) {
         if (P == 1) {
-            for (int m = lane; m < M; m += 64) wv[m] = XY[m];
+            for (int m = lane; m < M; m += NT) wv[m] = XY[m];
         } else {
             // S = XY' XY (symmetric PSD, P x P) and its dominant eigenvector: MFMA cross-product into registers,
             // repeated squaring there (eig_square), one power step with S itself.  (The oracle uses a full
@@ -248,11 +271,12 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             const int n = P;
             double* Bc = V;
             STAMP(1);
+            if (NW == 1 || wave == 0) {          // the whole eigenvector step is one wave's work (wave-uniform branch)
             double tr;
             if (n <= 16) tr = eig_square<1>(XY, M, n, S, Bc);
             else if (n <= 32) tr = eig_square<2>(XY, M, n, S, Bc);
             else tr = eig_square<4>(XY, M, n, S, Bc);
-            __syncthreads();
+            if constexpr (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
             STAMP(2);
             // column of the converged power with the largest diagonal entry (wave arg-max, ties -> lowest index)
             double dg = (lane < n) ? Bc[lane + n * lane] : -1.0;
@@ -269,14 +293,14 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             double qi = (lane < n) ? Bc[lane + n * best] : 0.0;
             if (tr > 0.0) {
                 if (lane < n) qv[lane] = qi;
-                __syncthreads();
+                if constexpr (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
                 double v = 0.0;
                 if (lane < n) {
 #pragma unroll 8
                     for (int k = 0; k < n; k++) v = fma(S[lane + n * k], qv[k], v);
                 }
                 qi = v;
-                __syncthreads();
+                if constexpr (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
             }
             const double nrm = sqrt(wave_sum(qi * qi));
             double am = fabs(qi);
@@ -290,8 +314,9 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             }
             const double sgn = (sv < 0.0) ? -1.0 : 1.0;
             if (lane < n) qv[lane] = sgn * qi / nrm;
+            }
             __syncthreads();
-            for (int m = lane; m < M; m += 64) {
+            for (int m = lane; m < M; m += NT) {
                 double s = 0.0;
                 _Pragma("unroll 8") for (int j = 0; j < P; j++) s = fma(XY[m + M * j], qv[j], s);
                 wv[m] = s;
@@ -300,28 +325,64 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
         __syncthreads();
         STAMP(3);
         double ww = 0.0;
-        for (int m = lane; m < M; m += 64) ww = fma(wv[m], wv[m], ww);
-        ww = sqrt(wave_sum(ww));
-        for (int m = lane; m < M; m += 64) { const double x = wv[m] / ww; wv[m] = x; rv[m] = x; }
+        for (int m = lane; m < M; m += NT) ww = fma(wv[m], wv[m], ww);
+        ww = sqrt(pls_sum<NW>(ww, red));
+        for (int m = lane; m < M; m += NT) { const double x = wv[m] / ww; wv[m] = x; rv[m] = x; }
         __syncthreads();
-        for (int j = 0; j < comp; j++) {
-            double pw = 0.0;
-            for (int m = lane; m < M; m += 64) pw = fma(Pl[m + (size_t)M * j], wv[m], pw);
-            pw = wave_sum(pw);
-            for (int m = lane; m < M; m += 64) rv[m] -= pw * Rl[m + (size_t)M * j];
+        if constexpr (NW == 1) {
+            for (int j = 0; j < comp; j++) {
+                double pw = 0.0;
+                for (int m = lane; m < M; m += NT) pw = fma(Pl[m + (size_t)M * j], wv[m], pw);
+                pw = wave_sum(pw);
+                for (int m = lane; m < M; m += NT) rv[m] -= pw * Rl[m + (size_t)M * j];
+            }
+        } else {
+            // the projections p_j'w only involve w: one wave per earlier component (same lane -> row map and wave sum as the
+            // one-wave code, so the same values), then every row subtracts them in component order
+            for (int j = wave; j < comp; j += NW) {
+                double pw = 0.0;
+                for (int m = lane & 63; m < M; m += 64) pw = fma(Pl[m + (size_t)M * j], wv[m], pw);
+                pw = wave_sum(pw);
+                if ((lane & 63) == 0) pwv[j] = pw;
+            }
+            __syncthreads();
+            for (int m = lane; m < M; m += NT) {
+                double r = rv[m];
+                for (int j = 0; j < comp; j++) r -= pwv[j] * Rl[m + (size_t)M * j];
+                rv[m] = r;
+            }
         }
         __syncthreads();
         STAMP(4);
         // type 2: xr = XX r ; tt = r' xr ; p = xr / tt
         double tt = 0.0;
-        for (int a = lane; a < M; a += 64) {
-            double s = 0.0;
-            _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
-            xr[a] = s;
-            tt = fma(rv[a], s, tt);
+        if constexpr (NW == 1) {
+            for (int a = lane; a < M; a += NT) {
+                double s = 0.0;
+                _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
+                xr[a] = s;
+                tt = fma(rv[a], s, tt);
+            }
+            tt = wave_sum(tt);
+        } else {
+            // four threads per row, a quarter of the columns each (four independent chains of M/4 instead of one of M)
+            const int qb = (M + 3) / 4;
+            for (int e = lane; e < 4 * M; e += NT) {
+                const int a = e % M, part = e / M;
+                const int b0 = part * qb, b1 = (b0 + qb < M) ? b0 + qb : M;
+                double s = 0.0;
+                _Pragma("unroll 8") for (int b = b0; b < b1; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
+                xp[e] = s;
+            }
+            __syncthreads();
+            for (int a = lane; a < M; a += NT) {
+                const double s = (xp[a] + xp[M + a]) + (xp[2 * M + a] + xp[3 * M + a]);
+                xr[a] = s;
+                tt = fma(rv[a], s, tt);
+            }
+            tt = pls_sum<NW>(tt, red);
         }
-        tt = wave_sum(tt);
-        for (int m = lane; m < M; m += 64) {
+        for (int m = lane; m < M; m += NT) {
             const double pm = xr[m] / tt;
             pv[m] = pm;
             Pm[m + (size_t)M * comp] = pm;
@@ -332,7 +393,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
         }
         __syncthreads();
         STAMP(5);
-        for (int j = lane; j < P; j += 64) {
+        for (int j = lane; j < P; j += NT) {
             double s = 0.0;
             _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(XY[m + M * j], rv[m], s);
             s /= tt;
@@ -340,7 +401,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
             Qm[j + (size_t)P * comp] = s;
         }
         __syncthreads();
-        for (int e = lane; e < M * P; e += 64) {
+        for (int e = lane; e < M * P; e += NT) {
             const int m = e % M, j = e / M;
             XY[e] -= tt * (pv[m] * qv[j]);
         }
@@ -359,7 +420,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     double* vk = scratch;               // A*M
     double* H = vk + (size_t)A * M;     // A*A
     double* cm = H + (size_t)A * A;     // P*A
-    for (int e = lane; e < A * M; e += 64) {
+    for (int e = lane; e < A * M; e += NT) {
         const int m = e % M, k = e / M;
         double s = 0.0;
         _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
@@ -367,13 +428,13 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     }
     __threadfence_block();
     __syncthreads();
-    for (int e = lane; e < A * A; e += 64) {
+    for (int e = lane; e < A * A; e += NT) {
         const int k = e % A, l = e / A;
         double s = 0.0;
         _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], vk[m + (size_t)M * l], s);
         H[e] = s;
     }
-    for (int e = lane; e < P * A; e += 64) {
+    for (int e = lane; e < P * A; e += NT) {
         const int j = e % P, k = e / P;
         double s = 0.0;
         _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
@@ -382,7 +443,7 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     __threadfence_block();
     __syncthreads();
     double* press = model + ML.off_press;   // A x P, column-major
-    for (int j = lane; j < P; j += 64) {
+    for (int j = lane; j < P; j += NT) {
         double lin = 0.0, quad = 0.0;
         double best = 0.0; int besta = 0;
         for (int a = 0; a < A; a++) {
@@ -405,13 +466,13 @@ __global__ __launch_bounds__(64) void k_pls_fit(const double* __restrict__ zwork
     int ncomp = 1;
     for (int j = 0; j < P; j++) { const int v = (int)model[ML.off_per + j]; if (v > ncomp) ncomp = v; }
     if (lane == 0) model[ML.off_hdr] = (double)ncomp;
-    for (int m = lane; m < M; m += 64) {
+    for (int m = lane; m < M; m += NT) {
         const double sdv = model[ML.off_sd + m];
         model[ML.off_zobs + m] = (sdv == 0.0) ? 0.0 : (obs[m] - model[ML.off_mean + m]) / sdv;
     }
     __threadfence_block();
     __syncthreads();
-    for (int k = lane; k < A; k += 64) {
+    for (int k = lane; k < A; k += NT) {
         double s = 0.0;
         _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(model[ML.off_zobs + m], Rm[m + (size_t)M * k], s);
         model[ML.off_oscore + k] = s;
@@ -447,12 +508,18 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
     const int xx_in_lds = M <= 64;
-    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8;
+    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8 + (8 + A + 4 * M);
     const size_t lds_bytes = lds_d * sizeof(double);
     if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
-    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(k_pls_fit, dim3(1), dim3(64), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                       scratch, xx_in_lds);
+    if (M <= 64) {      // one wavefront
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(k_pls_fit<1>, dim3(1), dim3(64), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
+                           scratch, xx_in_lds);
+    } else {            // eight waves for the vector phases
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(k_pls_fit<8>, dim3(1), dim3(512), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
+                           scratch, xx_in_lds);
+    }
     ABC_HIP(ctx, hipGetLastError());
 #ifdef PLS_STAMPS
     ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + P * A, 16 * sizeof(double), hipMemcpyDeviceToHost,

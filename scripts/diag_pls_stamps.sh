@@ -10,7 +10,7 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from abcsmc_amd import _lib, device, synthetic, sharded
 L = _lib.lib(); dev = "cuda:0"; ctx = _lib.default_context(0); be = sharded.HipBackend(dev, ctx)
-for (M, P, A) in [(32, 16, 8), (32, 16, 1), (64, 32, 8)]:
+for (M, P, A) in [(32, 16, 8), (64, 32, 8), (128, 16, 32)]:
     wl = synthetic.Workload(M, P); X, Y = wl.rows(0, 20000)
     dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(wl.observed(), dev)
     stats = be.zeros(be.stats_len(M, P)); model = be.empty(be.model_len(M, P, A))
