@@ -236,7 +236,8 @@ __device__ __forceinline__ void dma16(const double* gsrc, double* dst) {
 // waits for its own DMAs and the eight waves drift apart instead of meeting once per tile.  Lane l of instruction i
 // fetches rows 2*((l>>3) ^ (i&1)) .. +1 of column 8 i + (l&7); the row-pair swizzle of odd instructions puts the two
 // 8-column halves of a 16-column MFMA operand on opposite halves of the LDS banks (conflict-free b64 reads, no padding).
-template <int C, int CY, int NW, bool PRIV, int R = 3>
+// TABLE = true (wide sets, run_gram_grouped): X is a device table of C16 column pointers (NULL = padding column), Y unused
+template <int C, int CY, int NW, bool PRIV, int R = 3, bool TABLE = false>
 __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
     const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M, int P, long long n,
     long long split, const double* __restrict__ shift, double* __restrict__ partial) {
@@ -261,7 +262,13 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
 #pragma unroll
     for (int i = 0; i < NIW; i++) {
         const int c = PRIV ? 8 * i + (lane & 7) : wave + NW * i;   // padding columns re-read column 0, masked at operand read
-        cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+        if constexpr (TABLE) {
+            const double* const* tab = reinterpret_cast<const double* const*>(X);
+            const double* pc = tab[c];
+            cptr[i] = pc ? pc : tab[0];
+        } else {
+            cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+        }
     }
     double* const wring = lds + (PRIV ? wave * (R * CHB) : 0);
     auto stage = [&](long long tile, int slot) {
@@ -289,8 +296,10 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
 #pragma unroll
     for (int b = 0; b < C; b++) {
         const int c = 16 * b + cl;
-        keep[b] = (c < M + P) ? 1.0 : 0.0;
-        sh[b] = (c < M + P) ? shift[c] : 0.0;
+        bool real = c < M + P;
+        if constexpr (TABLE) real = real && reinterpret_cast<const double* const*>(X)[c] != nullptr;
+        keep[b] = real ? 1.0 : 0.0;
+        sh[b] = real ? shift[c] : 0.0;
     }
     d4 acc[D::NBLK];
 #pragma unroll
@@ -357,19 +366,25 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
     double tot[D::EPT];
 #pragma unroll
     for (int k = 0; k < D::EPT; k++) tot[k] = 0.0;
-    for (int round = 0; round < NW / 4; round++) {
-        if ((wave >> 2) == round) {
+    // accumulators of EW waves at a time go through LDS (four; two when four records of NBLK x 256 doubles exceed it)
+    constexpr int EW = ((size_t)4 * D::NBLK * 256 * sizeof(double) <= 160 * 1024) ? 4 : 2;
+    for (int round = 0; round < NW / EW; round++) {
+        if ((wave / EW) == round) {
 #pragma unroll
             for (int b = 0; b < D::NBLK; b++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) lds[(wave & 3) * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
+                for (int r = 0; r < 4; r++) lds[(wave % EW) * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < D::EPT; k++) {
             const int e = t + k * NT;
-            if (e < D::NBLK * 256)
-                tot[k] += ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+            if (e < D::NBLK * 256) {
+                if constexpr (EW == 4)
+                    tot[k] += ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+                else
+                    tot[k] += lds[e] + lds[D::NBLK * 256 + e];
+            }
         }
         __syncthreads();
     }
@@ -491,7 +506,7 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     return ABC_OK;
 }
 
-template <int C, int CY, int NW, bool PRIV, int R = 3>
+template <int C, int CY, int NW, bool PRIV, int R = 3, bool TABLE = false>
 int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
                  size_t P, long long split, double* stats) {
     using D = GramDimsDma<C, CY, NW, R>;
@@ -507,16 +522,18 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
     if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     // wave-private staging: NW rings of R chunks of 16 rows x C16 columns; the epilogue stages four waves' accumulators
-    constexpr size_t lds_priv = (size_t)NW * R * D::C16 * 16, lds_epi = (size_t)4 * D::NBLK * 256, lds_cs = (size_t)C * D::NT;
+    constexpr size_t epi4 = (size_t)4 * D::NBLK * 256;          // the epilogue stages four waves' accumulators (two if that is too much)
+    constexpr size_t lds_priv = (size_t)NW * R * D::C16 * 16, lds_epi = (epi4 * sizeof(double) <= 160 * 1024) ? epi4 : epi4 / 2,
+                     lds_cs = (size_t)C * D::NT;
     constexpr size_t lds_pmax = lds_priv > lds_epi ? (lds_priv > lds_cs ? lds_priv : lds_cs) : (lds_epi > lds_cs ? lds_epi : lds_cs);
     const size_t lds_bytes = (PRIV ? lds_pmax : (size_t)D::LDS_D) * sizeof(double);
     static_assert(!PRIV || lds_pmax * sizeof(double) <= 160 * 1024, "k_gram_dma: ring + epilogue exceed the 160 KB of LDS");
     // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
-    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW, PRIV, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma<C, CY, NW, PRIV, R, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
-        hipLaunchKernelGGL((k_gram_dma<C, CY, NW, PRIV, R>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
+        hipLaunchKernelGGL((k_gram_dma<C, CY, NW, PRIV, R, TABLE>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
                            ldy, (int)M, (int)P, (long long)n, split, stats + L.off_shift, partial);
     }
     ABC_HIP(ctx, hipGetLastError());
@@ -574,6 +591,13 @@ int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, s
             const int gb0 = 48 * gb, gbn = ncol - gb0 < 48 ? ncol - gb0 : 48;
             hipLaunchKernelGGL(k_group_table, dim3(1), dim3(128), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P, ga0, gan,
                                gb0, gbn, stats + LB.off_shift, tab, loc + LL.off_shift, gmap, 96);
+            static const int dma_mode = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : 9;
+            const bool dma_ok = dma_mode && (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
+                                (((uintptr_t)Y & 15) == 0) && n >= 2;
+            if (dma_ok) {
+                // the pair's 96 columns through the four-wave LDS-DMA kernel (column-pointer table instead of X / Y)
+                ABC_TRY((run_gram_dma<6, 0, 4, true, 3, true>(ctx, (const double*)tab, nullptr, n, ldx, ldy, 96, 0, split, loc)));
+            } else {
             using D = GramDims<6, 0>;
             const long long ntr = split, nte = (long long)n - split;
             const long long tiles = ((ntr > nte ? ntr : nte) + TR - 1) / TR + 1;
@@ -595,6 +619,7 @@ int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, s
             }
             hipLaunchKernelGGL((k_stats_reduce<6, 0>), dim3((D::PSZ + 15) / 16, 2), dim3(256), 0, ctx->stream, partial,
                                (int)G, loc, ntr, nte);
+            }
             hipLaunchKernelGGL(k_group_scatter, dim3((96 * 96 + 255) / 256), dim3(256), 0, ctx->stream, loc, 96, gmap, stats,
                                (int)LB.C16);
             ABC_HIP(ctx, hipGetLastError());
