@@ -54,6 +54,9 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (2002, 70, 9, 5, 0.45),      # 5 column blocks, parameters share the last block with metrics; split inside a tile
     (3000, 50, 30, 6, 0.4),      # 5 column blocks, last one parameters only
     (2001, 64, 32, 8, 0.5),      # 6 blocks, odd row count: the VGPR-staged kernel (LDS-DMA needs 16-byte row pairs)
+    (90, 50, 14, 4, 0.5),        # 4 blocks, fewer rows than one 64-row tile per partition
+    (1000, 80, 16, 6, 1.0),      # 6 blocks, f = 1: empty validation partition on the four-wave kernel
+    (600, 130, 20, 10, 0.5),     # 150 columns: grouped pairs through the pointer-table mode, 4 groups
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
