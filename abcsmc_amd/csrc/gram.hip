@@ -228,7 +228,10 @@ struct GramDimsDma {
 // its memory and MFMA times).  All waits for these loads are the explicit counted s_waitcnt in the loop.
 __device__ __forceinline__ void dma16(const double* gsrc, double* dst) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
+    // nt: every byte of X and Y is read exactly once -- streamed past L2 / Infinity Cache instead of allocated there.  Without
+    // it the kernel's time depended on what the previous kernels had left in the caches (1 GB flushed between launches:
+    // 134 us; behind a generation's 128 MB of freshly written proposals: 95 us); with it 84-86 us in every state.
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"(gsrc) : "memory");
 }
 
 // PRIV = true (NW == 8): every wave stages and consumes its OWN 16 rows of each tile (8 columns x 16 rows per DMA
