@@ -96,7 +96,8 @@ __global__ __launch_bounds__((GramDims<C, CY>::NT)) void k_gram(const double* __
         const bool full = (row0 >= r_begin) && (row0 + TR <= r_end);
         if (full && vec_ok) {
 #pragma unroll
-            for (int i = 0; i < D::NI; i++) v[i] = *reinterpret_cast<const d2*>(cptr[i] + r);
+            for (int i = 0; i < D::NI; i++)      // non-temporal: read once, streamed past L2 / Infinity Cache (see dma16)
+                v[i] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(cptr[i] + r));
         } else {   // edge tile / unaligned columns: clamp the address, mask the value (no divergence)
             const long long ra = r < r_begin ? r_begin : (r >= r_end ? r_end - 1 : r);
             const long long rb = r + 1 < r_begin ? r_begin : (r + 1 >= r_end ? r_end - 1 : r + 1);
@@ -648,15 +649,19 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     const size_t C = (M + P + 15) / 16;
     size_t CY = C - (M + 15) / 16;      // trailing blocks without any metric column
     if (CY > 2) CY = 2;
-    // LDS-DMA staging needs 16-B aligned columns and an even row count (row pairs never straddle the array end)
-    // A/B knob: 0 = VGPR-staged k_gram, 8 / 16 = shared tiles with 8 / 16 waves, 9 = wave-private chunks (default).
-    // Inside a generation all four land within a few % of each other (91-104 us at N = 1e6: the launch follows 128 MB
-    // of freshly written proposals whose dirty lines the streaming reads evict); stand-alone, 9 runs at 87 us.
-    static const int dma_mode = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : 9;
+    // Two kernels.  Up to 48 columns (C <= 3) the VGPR-staged k_gram is the default since its loads carry the non-temporal
+    // policy: 75 us against 84 us for the LDS-DMA kernel at N = 1e6, M = 32, P = 16 (0.68 against 0.60 of the HBM peak inside
+    // a generation); 49..96 columns run the four-wave LDS-DMA variant (0.35 against 0.68 ms on the configs[3] shape).
+    // LDS-DMA staging needs 16-B aligned columns and an even row count (row pairs never straddle the array end).
+    // ABC_GRAM_DMA (A/B runs): 0 = VGPR-staged k_gram everywhere, 8 / 16 = shared tiles with 8 / 16 waves, 9 = wave-private
+    // chunks (the DMA default) -- any non-zero value also selects the DMA kernel for C <= 3.
+    static const int dma_env = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : -1;
+    const int dma_mode = (dma_env >= 0) ? dma_env : 9;
     const bool dma_ok = dma_mode && (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
                         (((uintptr_t)Y & 15) == 0) && n >= 2;
+    const bool dma_small = dma_ok && dma_env > 0;       // C <= 3: only on request
 #define GRAM_DMA_CASE(c, cy)                                                                              \
-    if (C == c && CY == cy && dma_ok) {                                                                   \
+    if (C == c && CY == cy && dma_small) {                                                                \
         if (dma_mode == 16) return run_gram_dma<c, cy, 16, false>(ctx, X, Y, n, ldx, ldy, M, P, split, stats); \
         if (dma_mode == 9) return run_gram_dma<c, cy, 8, true>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);    \
         return run_gram_dma<c, cy, 8, false>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);                      \
