@@ -676,6 +676,14 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
     const int opa = NCH * KS_NL + 2, opb = NCH * KS_NL + 1;
+    if (split) {
+        // Every work-group of the split kernel loads its 48-96 KB of resident operands once per slice: with the 65 slices
+        // the fp64 kernel likes that was 1.2 GB of fabric traffic per launch at K = K' = 1e5 (PMC).  Its time is flat between
+        // 24 and 130 slices, so it gets about 12k work-groups (16 residencies of the chip) and no more.
+        size_t cap = 12288 / rb;
+        if (cap < 8) cap = 8;
+        if (slices > cap) slices = cap;
+    }
     WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
     double* a = (double*)abc_ws_alloc(ctx, kn * PP * sizeof(double));
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
