@@ -193,12 +193,17 @@ int launch_fill(abc_ctx*, double* w, size_t K, double v);
 int launch_normalize_l2(abc_ctx*, double* w, size_t K);
 int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* L, int* status_host,
                      int* status_dev);
+// while_host_builds (optional): called after the weights' copy to the host has been queued and before the host waits for it:
+// GPU work launched there runs while the host builds the alias table
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
-                    uint64_t* parent);
+                    uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr);
+struct abc_perturb_prep { double* rows; int seeds_done; };     // what launch_perturb_prepare has already done
+int launch_perturb_prepare(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
+                           uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep);
 int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P,
                    const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
                    int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
-                   uint64_t seed_stream_offset);
+                   uint64_t seed_stream_offset, const abc_perturb_prep* prep = nullptr);
 
 // [GSL] gsl_ran_discrete_preproc on the host (alias_host.cpp, a host-only translation unit built with the host compiler):
 // scratch E: K doubles, smalls / bigs: K + 1 uint32 each

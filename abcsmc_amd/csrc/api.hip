@@ -451,9 +451,18 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             }
             have_spd = true;
         }
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent));   // contains the alias-table host round trip
+        // the alias-table host round trip sits inside launch_resample; the row-major posterior copy and the seed stream of the
+        // perturbation do not depend on it and run on the GPU meanwhile
+        abc_perturb_prep prep = {nullptr, 0};
+        struct PrepArg { abc_ctx* ctx; const abc_rng* rng; const double* theta; size_t K, P, Nn; uint64_t* seeds; abc_perturb_prep* prep; };
+        PrepArg pa = {ctx, rng, theta, K, P, Nn, io->seeds, &prep};
+        auto hook = [](void* a) -> int {
+            PrepArg* q = (PrepArg*)a;
+            return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep);
+        };
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa));
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, 0, Nn, cfg->multivariate,
-                               cfg->multivariate ? L : dv, io->next, io->seeds, Nn));
+                               cfg->multivariate ? L : dv, io->next, io->seeds, Nn, &prep));
         taus2_jump(rng, 2 * (uint64_t)Nn);   // Nnext resampling draws + Nnext seeds
     }
     {

@@ -395,7 +395,7 @@ int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
 }  // namespace
 
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
-                    uint64_t* parent) {
+                    uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg) {
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     // alias table: weights to the host, serial Walker build, tables back to HBM
@@ -418,6 +418,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         StageTimer tm(ctx, ST_RESAMPLE);
         ABC_TRY(taus_stream(ctx, base, n, raw));
     }
+    if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));      // more table-independent GPU work of the caller
     ABC_HIP(ctx, hipEventSynchronize(ctx->ev_copy));
     {
         const auto t0 = std::chrono::steady_clock::now();
@@ -443,23 +444,65 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     return ABC_OK;
 }
 
+// The parts of the perturbation that need neither the parents nor the alias table: the row-major copy of the posterior the
+// kernel gathers parents from, and the simulator seeds (taus2 outputs seed_stream_offset + i0 + i).  launch_perturb does them
+// itself unless the caller already has (the fused driver runs them while the host builds the alias table).
+static int launch_theta_rows(abc_ctx* ctx, const double* theta, size_t K, size_t P, int PP, double* rows) {
+    const unsigned grid = (unsigned)((K + 63) / 64);
+    switch (PP) {
+        case 2: hipLaunchKernelGGL((k_theta_rows<2>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+        case 4: hipLaunchKernelGGL((k_theta_rows<4>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+        case 8: hipLaunchKernelGGL((k_theta_rows<8>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+        case 16: hipLaunchKernelGGL((k_theta_rows<16>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+        case 32: hipLaunchKernelGGL((k_theta_rows<32>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+        default: hipLaunchKernelGGL((k_theta_rows<64>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset) {
+    // AbcSmc.cpp:535: one gsl_rng_get per new particle; here taken from the taus2 stream at
+    // position seed_stream_offset + i0 + i (after the resampling draws)
+    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+    abc_rng base = *rng;
+    taus2_jump(&base, seed_stream_offset + i0);
+    ABC_TRY(taus_stream(ctx, base, n, raw));
+    hipLaunchKernelGGL(k_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, (unsigned long long*)seeds);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
+                           uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep) {
+    prep->rows = nullptr;
+    prep->seeds_done = 0;
+    if (n == 0 || P > 64) return ABC_OK;
+    int PP = 2;
+    while (PP < (int)P) PP *= 2;
+    StageTimer tm(ctx, ST_PERTURB);
+    double* rows = (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
+    if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+    ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows));
+    prep->rows = rows;
+    if (seeds) { ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset)); prep->seeds_done = 1; }
+    return ABC_OK;
+}
+
 int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P, const abc_prior* priors,
                    const uint64_t* parent, uint64_t i0, size_t n, int multivariate, const double* L_or_dv, double* out,
-                   uint64_t* seeds, uint64_t seed_stream_offset) {
+                   uint64_t* seeds, uint64_t seed_stream_offset, const abc_perturb_prep* prep) {
     if (n == 0) return ABC_OK;
     if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 64", P);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    double* rows = (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
+    double* rows = (prep && prep->rows) ? prep->rows : (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
     if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
-    const double* theta_cm = theta;
+    if (!(prep && prep->rows)) ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows));
     theta = rows;
 #define LAUNCH_PT(PPV)                                                                                                 \
     do {                                                                                                               \
-        hipLaunchKernelGGL((k_theta_rows<PPV>), dim3((unsigned)((K + 63) / 64)), dim3(256), 0, ctx->stream, theta_cm, \
-                           K, (int)P, rows);                                                                          \
         if (multivariate)                                                                                              \
             hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
                                priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);   \
@@ -474,8 +517,6 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
         case 16: LAUNCH_PT(16); break;
         case 32: LAUNCH_PT(32); break;
         default: {
-            hipLaunchKernelGGL((k_theta_rows<64>), dim3((unsigned)((K + 63) / 64)), dim3(256), 0, ctx->stream, theta_cm, K,
-                               (int)P, rows);
             if (multivariate) {
                 const size_t lds = (64 * 64) * sizeof(double) + 64 * sizeof(abc_prior);
                 hipLaunchKernelGGL((k_perturb_stream<64, true>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
@@ -489,16 +530,6 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     }
 #undef LAUNCH_PT
     ABC_HIP(ctx, hipGetLastError());
-    if (seeds) {
-        // AbcSmc.cpp:535: one gsl_rng_get per new particle; here taken from the taus2 stream at
-        // position seed_stream_offset + i0 + i (after the resampling draws)
-        uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
-        if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
-        abc_rng base = *rng;
-        taus2_jump(&base, seed_stream_offset + i0);
-        ABC_TRY(taus_stream(ctx, base, n, raw));
-        hipLaunchKernelGGL(k_widen, dim3(blocks), dim3(256), 0, ctx->stream, raw, n, (unsigned long long*)seeds);
-        ABC_HIP(ctx, hipGetLastError());
-    }
+    if (seeds && !(prep && prep->seeds_done)) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset));
     return ABC_OK;
 }
