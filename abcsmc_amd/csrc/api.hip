@@ -443,21 +443,27 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         double* L = nullptr;
         if (cfg->multivariate) {
             L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
-            if (theta_stats) {
-                StageTimer tm(ctx, ST_MVN);
-                ABC_TRY(launch_mvn_from_stats(ctx, theta_stats, P, L, spd_dev));
-            } else {
-                ABC_TRY(launch_mvn_setup(ctx, theta, K, P, L, nullptr, spd_dev));
-            }
             have_spd = true;
         }
-        // the alias-table host round trip sits inside launch_resample; the row-major posterior copy and the seed stream of the
-        // perturbation do not depend on it and run on the GPU meanwhile
+        // The alias-table host round trip sits inside launch_resample.  What does not depend on the weights runs on the GPU
+        // meanwhile: the MVN factor (covariance + Cholesky), the row-major posterior copy and the seed stream of the
+        // perturbation.
         abc_perturb_prep prep = {nullptr, 0};
-        struct PrepArg { abc_ctx* ctx; const abc_rng* rng; const double* theta; size_t K, P, Nn; uint64_t* seeds; abc_perturb_prep* prep; };
-        PrepArg pa = {ctx, rng, theta, K, P, Nn, io->seeds, &prep};
+        struct PrepArg {
+            abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
+            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev;
+        };
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev};
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
+            if (q->L) {
+                if (q->theta_stats) {
+                    StageTimer tm(q->ctx, ST_MVN);
+                    ABC_TRY(launch_mvn_from_stats(q->ctx, q->theta_stats, q->P, q->L, q->spd_dev));
+                } else {
+                    ABC_TRY(launch_mvn_setup(q->ctx, q->theta, q->K, q->P, q->L, nullptr, q->spd_dev));
+                }
+            }
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep);
         };
         ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa));
