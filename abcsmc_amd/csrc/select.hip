@@ -67,54 +67,133 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ dis
     }
 }
 
-// one work-group: find the digit whose cumulative count reaches krem; update state; clear hist
-__global__ __launch_bounds__(256) void k_sel_pick(SelState* st, int shift, int nbits, unsigned int* hist,
-                                                  int last, unsigned long long K) {
-    __shared__ unsigned long long csum[256];
-    __shared__ int found_digit;
-    __shared__ unsigned long long found_below;
+// find the digit whose cumulative count reaches krem and extend the decided prefix by it: the whole work-group cooperates
+// (parallel scan of the bin counts); every thread returns the new state
+__device__ __forceinline__ SelState sel_pick_block(const unsigned int* __restrict__ hist, SelState st, int shift, int nbits,
+                                                   int last, unsigned long long K, unsigned long long* csum /* 256 */,
+                                                   int* found_digit, unsigned long long* found_below) {
     const int t = threadIdx.x;
     const int bins = 1 << nbits;
     const int per = (bins + 255) / 256;
     unsigned long long loc = 0;
     for (int j = 0; j < per; j++) { const int b = t * per + j; if (b < bins) loc += hist[b]; }
-    csum[t] = loc;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 256; i++) { const unsigned long long v = csum[i]; csum[i] = run; run += v; }
+    // exclusive scan of the 256 per-thread counts: wave scan by shuffles, then the four wave totals
+    const int lane = t & 63, wave = t >> 6;
+    unsigned long long inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
+    if (lane == 63) csum[wave] = inc;
     __syncthreads();
-    const unsigned long long krem = st->krem;
-    unsigned long long run = csum[t];
+    unsigned long long run = inc - loc;
+    for (int w = 0; w < wave; w++) run += csum[w];
+    const unsigned long long krem = st.krem;
     for (int j = 0; j < per; j++) {
         const int b = t * per + j;
         if (b < bins) {
             const unsigned long long c = hist[b];
-            if (run < krem && krem <= run + c) { found_digit = b; found_below = run; }
+            if (run < krem && krem <= run + c) { *found_digit = b; *found_below = run; }
             run += c;
         }
     }
     __syncthreads();
-    if (t == 0) {
-        const unsigned long long dm = ((1ull << nbits) - 1ull) << shift;
-        st->prefix |= ((unsigned long long)found_digit) << shift;
-        st->mask |= dm;
-        st->krem = krem - found_below;
-        if (last) { st->ties = st->krem; st->n_less = K - st->krem; }
+    const unsigned long long dm = ((1ull << nbits) - 1ull) << shift;
+    st.prefix |= ((unsigned long long)*found_digit) << shift;
+    st.mask |= dm;
+    st.krem = krem - *found_below;
+    if (last) { st.ties = st.krem; st.n_less = K - st.krem; }
+    __syncthreads();                       // csum / found_* may be reused by the caller
+    return st;
+}
+
+// one work-group: the pick of the stage-wise (distributed) protocol; updates the state in place and clears the histogram
+__global__ __launch_bounds__(256) void k_sel_pick(SelState* st, int shift, int nbits, unsigned int* hist,
+                                                  int last, unsigned long long K) {
+    __shared__ unsigned long long csum[256];
+    __shared__ int found_digit;
+    __shared__ unsigned long long found_below;
+    const SelState nst = sel_pick_block(hist, *st, shift, nbits, last, K, csum, &found_digit, &found_below);
+    if (threadIdx.x == 0) *st = nst;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) hist[i] = 0;
+}
+
+// ---- single-GPU selection without the pick launches --------------------------------------------------------------
+// The six histogram passes each get their OWN histogram (zeroed once), and every work-group of pass p first repeats
+// pass p-1's pick on that finished histogram -- the same arithmetic in every block, hence the same state everywhere, no
+// synchronisation -- before it counts its keys.  The last pick moves into the first compaction kernel.  Saves the six
+// one-work-group k_sel_pick launches (and their gaps) of the stage-wise path, which the distributed driver keeps because
+// it all-reduces the histograms between hist and pick.
+__global__ void k_sel_init_fused(SelState* st_arr /* 7 */, unsigned long long K, unsigned int* hist_all /* 6 x SEL_BINS */) {
+    for (int i = threadIdx.x; i < 6 * SEL_BINS; i += blockDim.x) hist_all[i] = 0;
+    if (threadIdx.x == 0) { st_arr[0].prefix = 0; st_arr[0].mask = 0; st_arr[0].krem = K; st_arr[0].n_less = 0; st_arr[0].ties = 0; }
+}
+
+// pass p: st_arr[p] = state before this pass (= after the picks of passes 0..p-1); hist_all + p * SEL_BINS receives the counts
+__global__ __launch_bounds__(256) void k_sel_hist_fused(const double* __restrict__ dist, size_t n, SelState* __restrict__ st_arr,
+                                                        int p, int shift_prev, int nbits_prev, int shift, int nbits,
+                                                        unsigned int* __restrict__ hist_all, unsigned long long K) {
+    __shared__ unsigned int lh[SEL_BINS];
+    __shared__ unsigned long long csum[256];
+    __shared__ int found_digit;
+    __shared__ unsigned long long found_below;
+    SelState st = st_arr[p > 0 ? p - 1 : 0];
+    if (p > 0) {
+        st = sel_pick_block(hist_all + (size_t)(p - 1) * SEL_BINS, st, shift_prev, nbits_prev, 0, K, csum, &found_digit, &found_below);
+        if (threadIdx.x == 0) st_arr[p] = st;          // every block writes the same value
     }
-    for (int i = t; i < SEL_BINS; i += 256) hist[i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    unsigned int* hist = hist_all + (size_t)p * SEL_BINS;
+    const unsigned long long prefix = st.prefix, mask = st.mask;
+    const unsigned int dm = (1u << nbits) - 1u;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const size_t nround = (n + stride - 1) / stride;      // uniform trip count: the ballots need every lane
+    for (size_t it = 0; it < nround; it++) {
+        const size_t i = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const unsigned long long k = (i < n) ? key_of(dist[i]) : 0ull;
+        const bool in = (i < n) && ((k & mask) == prefix);
+        const unsigned int d = (unsigned int)(k >> shift) & dm;
+        unsigned long long peers = __ballot(in);
+        for (int b = 0; b < nbits; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        if (in && (peers & lt_mask) == 0) atomicAdd(&lh[d], (unsigned int)__popcll(peers));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) {
+        const unsigned int c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
 }
 
 constexpr int CP_ITEMS = 8;
 constexpr int CP_CHUNK = 256 * CP_ITEMS;
 
 // per-chunk counts of (key < T) and (key == T)
+// fused path (last_hist != NULL): st points at the state before the last pick, which every block repeats here; the result
+// goes to st[1] for k_cp_write
 __global__ __launch_bounds__(256) void k_cp_count(const double* __restrict__ dist, size_t n,
-                                                  const SelState* __restrict__ st,
-                                                  unsigned int* __restrict__ cnt /* [2][nb] */, int nb) {
+                                                  SelState* __restrict__ st,
+                                                  unsigned int* __restrict__ cnt /* [2][nb] */, int nb,
+                                                  const unsigned int* __restrict__ last_hist = nullptr, int shift = 0,
+                                                  int nbits = 0, unsigned long long K = 0) {
     __shared__ unsigned int sl[4], se[4];
-    const unsigned long long T = st->prefix;
+    __shared__ unsigned long long csum[256];
+    __shared__ int found_digit;
+    __shared__ unsigned long long found_below;
+    unsigned long long T;
+    if (last_hist) {
+        const SelState fin = sel_pick_block(last_hist, st[0], shift, nbits, 1, K, csum, &found_digit, &found_below);
+        if (threadIdx.x == 0) st[1] = fin;             // every block writes the same value
+        T = fin.prefix;
+    } else {
+        T = st->prefix;
+    }
     const size_t base = (size_t)blockIdx.x * CP_CHUNK + (size_t)threadIdx.x * CP_ITEMS;
     unsigned int l = 0, e = 0;
 #pragma unroll
@@ -505,7 +584,7 @@ int launch_select_count(abc_ctx* ctx, const double* dist, size_t n, const long l
     const int nb = (int)((n + CP_CHUNK - 1) / CP_CHUNK);
     unsigned int* cnt = (unsigned int*)abc_ws_alloc(ctx, (size_t)2 * (nb + 1) * sizeof(unsigned int));
     if (!cnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
-    if (nb) hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb);
+    if (nb) hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (SelState*)state, cnt, nb);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, (unsigned long long*)counts);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -523,7 +602,7 @@ int launch_select_compact(abc_ctx* ctx, const double* dist, size_t n, const long
     if (!cnt || !lim || !key) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
     const unsigned long long hl[2] = {n_less, ties_take};
     ABC_HIP(ctx, hipMemcpyAsync(lim, hl, sizeof(hl), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb);
+    hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (SelState*)state, cnt, nb);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb,
                        (unsigned long long)idx_base, key, (unsigned long long*)idx_out, lim);
@@ -547,25 +626,23 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
         hipLaunchKernelGGL(k_init_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dist, n,
                            (unsigned long long)idx_base, key0, idx0);
     } else {
-        SelState* st = (SelState*)abc_ws_alloc(ctx, sizeof(SelState));
-        unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, SEL_BINS * sizeof(unsigned int));
+        SelState* st = (SelState*)abc_ws_alloc(ctx, 7 * sizeof(SelState));           // st[p]: state before pass p; st[6]: final
+        unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, 6 * SEL_BINS * sizeof(unsigned int));
         const int nb = (int)((n + CP_CHUNK - 1) / CP_CHUNK);
         unsigned int* cnt = (unsigned int*)abc_ws_alloc(ctx, (size_t)2 * nb * sizeof(unsigned int));
         if (!st || !hist || !cnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
-        hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, ctx->stream, st, (unsigned long long)K, hist);
+        hipLaunchKernelGGL(k_sel_init_fused, dim3(1), dim3(256), 0, ctx->stream, st, (unsigned long long)K, hist);
         size_t hb = (n + 255) / 256;
         if (hb > 512) hb = 512;      // every block flushes up to 2048 bins with global atomics: keep the count low
         static const int shifts[6] = {53, 42, 31, 20, 9, 0};
         static const int widths[6] = {11, 11, 11, 11, 11, 9};
-        for (int p = 0; p < 6; p++) {
-            hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)hb), dim3(256), 0, ctx->stream, dist, n, st, shifts[p],
-                               widths[p], hist);
-            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, st, shifts[p], widths[p], hist,
-                               (int)(p == 5), (unsigned long long)K);
-        }
-        hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb);
+        for (int p = 0; p < 6; p++)
+            hipLaunchKernelGGL(k_sel_hist_fused, dim3((unsigned)hb), dim3(256), 0, ctx->stream, dist, n, st, p,
+                               p ? shifts[p - 1] : 0, p ? widths[p - 1] : 0, shifts[p], widths[p], hist, (unsigned long long)K);
+        hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st + 5, cnt, nb,
+                           (const unsigned int*)(hist + 5 * SEL_BINS), shifts[5], widths[5], (unsigned long long)K);
         hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, st, cnt, nb,
+        hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)(st + 6), cnt, nb,
                            (unsigned long long)idx_base, key0, idx0, (const unsigned long long*)nullptr);
     }
     }
