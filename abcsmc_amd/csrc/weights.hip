@@ -7,15 +7,18 @@
 // The weight kernel is the compute-bound stage of a generation, O(K * K' * P): per pair the P
 // per-parameter Gaussian factors of the reference are fused into ONE exponential,
 //   prod_p pdf(t_ip - t'_jp; sqrt(dv_p)) = C * exp(-1/2 sum_p ((t_ip - t'_jp)/sigma_p)^2),
-// with both parameter sets centred on one previous particle and pre-scaled by 1/sigma_p, and the squared
+// with both parameter sets centred on a robust centre of the previous set (k_wcentre) and pre-scaled by 1/sigma_p, and the squared
 // distance expanded as |a|^2 + |b|^2 - 2 a.b so a pair costs P FMAs + one exp:
 //   w'_j * exp(-1/2 |a_i - b_j|^2) = exp(a_i.b_j - 1/2|a_i|^2 - (1/2|b_j|^2 - ln w'_j)).
 // Both sets are additionally scaled by sqrt(log2 e), so the exponent comes out in base 2 and the exponential is
 //   2^x = 2^n * 2^f,  n = round(x) by the 1.5*2^52 addition (its low dword IS n), f = x - n in [-1/2, 1/2],
 // 2^f a degree-8 minimax polynomial (|rel err| < 7.8e-13, scripts/exp2_minimax.py; far inside the 1e-6 budget):
 // 13 instructions for the exponential, 30 per pair at P = 16, instead of ~40 for the library exp alone.
-// One new particle per lane; previous-set rows are wave-uniform and stream through the scalar cache.
-// fp64 VALU throughout.
+// Two kernels evaluate the pair sums (include/abcsmc_hip.h: abc_ctx_set_kde_mode):
+//   k_kde        fp64 vector kernel: one new particle per lane, previous-set rows wave-uniform through the scalar cache;
+//   k_kde_split  (default for 5..32 parameters) the dot products a_i.b_j on the bf16 matrix pipe from exact limb products,
+//                the vector pipe left with convert + add + 2^x: see the section "split-operand weight kernel" below,
+// plus two fp64 fix-up kernels for the rows the split kernel cannot represent exactly.
 #include <stdlib.h>
 
 #include "abc_internal.h"
