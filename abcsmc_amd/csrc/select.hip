@@ -668,18 +668,34 @@ __global__ __launch_bounds__(256) void k_merge_runs(const double* __restrict__ k
     const size_t i = t - (size_t)q * len;
     const double d = key[t];
     const unsigned long long x = key_of(d);
+    size_t top = 1;                                    // smallest power of two >= len: first probe distance
+    while (top < len) top <<= 1;
     size_t pos = i;
-    for (int r = 0; r < W; r++) {
-        if (r == q) continue;
-        const double* run = key + (size_t)r * len;
-        size_t lo = 0, hi = len;                       // first element of run r that must come after x
-        while (lo < hi) {
-            const size_t mid = (lo + hi) >> 1;
-            const unsigned long long y = key_of(run[mid]);
-            const bool before = (r < q) ? (y <= x) : (y < x);
-            if (before) lo = mid + 1; else hi = mid;
+    // rank of x in run r = number of its elements that come before x: fixed-trip branch-free searches, eight runs at a
+    // time (eight independent load chains instead of one), as in k_merge_chunks
+    for (int r0 = 0; r0 < W; r0 += 8) {
+        size_t lo[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) lo[u] = 0;
+#pragma unroll 1
+        for (size_t step = top; step >= 1; step >>= 1) {
+            unsigned long long y[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = (r0 + u < W) ? r0 + u : q;
+                const size_t c = lo[u] + step;
+                y[u] = key_of(key[(size_t)r * len + ((c <= len) ? c - 1 : 0)]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = r0 + u;
+                const size_t c = lo[u] + step;
+                const bool before = (r < q) ? (y[u] <= x) : (y[u] < x);       // equal keys: lower runs first (stable)
+                lo[u] = (r < W && r != q && c <= len && before) ? c : lo[u];
+            }
         }
-        pos += lo;
+#pragma unroll
+        for (int u = 0; u < 8; u++) pos += lo[u];
     }
     okey[pos] = d;
     oidx[pos] = idx[t];
