@@ -210,11 +210,15 @@ extern "C" void abc_rng_set(abc_rng* r, unsigned long seed) { taus2_set(r, seed)
 extern "C" uint32_t abc_rng_get(abc_rng* r) { return taus2_get(r); }
 extern "C" void abc_rng_jump(abc_rng* r, uint64_t n) { taus2_jump(r, n); }
 
+// Every public entry starts here.  With timing on, the event ring (256 pairs) is drained as soon as it is half full: no
+// stage timer is open at an entry point, so every recorded pair is complete, and a long run of stage-level calls (the
+// sharded driver opens ~30 timers per step and never reaches generation_core's flush) loses no sample.
 #define CHECK_CTX(ctx)                         \
     do {                                       \
         if (!(ctx)) return ABC_ERR_INVALID;    \
         (ctx)->err[0] = 0;                     \
         if (hipSetDevice((ctx)->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed"); \
+        if ((ctx)->timing && (ctx)->nev > 128) ABC_TRY(timing_flush(ctx)); \
     } while (0)
 
 static size_t default_A(size_t M, size_t P, int max_comp) {
@@ -333,6 +337,7 @@ extern "C" int abc_gather_rows_dev(abc_ctx* ctx, const double* Y, size_t n_local
 
 extern "C" int abc_doubled_variance_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
     CHECK_CTX(ctx);
+    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, P, 0, 1, 0, 0, 0)));     // the moments go through the Gram kernel's partial records
     return launch_doubled_variance(ctx, theta, K, P, dv);
 }
 

@@ -595,8 +595,7 @@ int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, s
             const int gb0 = 48 * gb, gbn = ncol - gb0 < 48 ? ncol - gb0 : 48;
             hipLaunchKernelGGL(k_group_table, dim3(1), dim3(128), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P, ga0, gan,
                                gb0, gbn, stats + LB.off_shift, tab, loc + LL.off_shift, gmap, 96);
-            static const int dma_mode = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : 9;
-            const bool dma_ok = dma_mode && (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
+            const bool dma_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
                                 (((uintptr_t)Y & 15) == 0) && n >= 2;
             if (dma_ok) {
                 // the pair's 96 columns through the four-wave LDS-DMA kernel (column-pointer table instead of X / Y)
@@ -653,24 +652,11 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // policy: 75 us against 84 us for the LDS-DMA kernel at N = 1e6, M = 32, P = 16 (0.68 against 0.60 of the HBM peak inside
     // a generation); 49..96 columns run the four-wave LDS-DMA variant (0.35 against 0.68 ms on the configs[3] shape).
     // LDS-DMA staging needs 16-B aligned columns and an even row count (row pairs never straddle the array end).
-    // ABC_GRAM_DMA (A/B runs): 0 = VGPR-staged k_gram everywhere, 8 / 16 = shared tiles with 8 / 16 waves, 9 = wave-private
-    // chunks (the DMA default) -- any non-zero value also selects the DMA kernel for C <= 3.
-    static const int dma_env = getenv("ABC_GRAM_DMA") ? atoi(getenv("ABC_GRAM_DMA")) : -1;
-    const int dma_mode = (dma_env >= 0) ? dma_env : 9;
-    const bool dma_ok = dma_mode && (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
+    const bool dma_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
                         (((uintptr_t)Y & 15) == 0) && n >= 2;
-    const bool dma_small = dma_ok && dma_env > 0;       // C <= 3: only on request
-#define GRAM_DMA_CASE(c, cy)                                                                              \
-    if (C == c && CY == cy && dma_small) {                                                                \
-        if (dma_mode == 16) return run_gram_dma<c, cy, 16, false>(ctx, X, Y, n, ldx, ldy, M, P, split, stats); \
-        if (dma_mode == 9) return run_gram_dma<c, cy, 8, true>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);    \
-        return run_gram_dma<c, cy, 8, false>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);                      \
-    }
-    GRAM_DMA_CASE(1, 0); GRAM_DMA_CASE(2, 0); GRAM_DMA_CASE(2, 1); GRAM_DMA_CASE(3, 0); GRAM_DMA_CASE(3, 1); GRAM_DMA_CASE(3, 2);
-#undef GRAM_DMA_CASE
     // 4..6 column blocks (49..96 columns, e.g. BASELINE configs[3]: 64 metrics + 32 parameters): the same kernel with FOUR
     // waves of wave-private staging (64-row tiles; three-chunk rings of 8-12 KB per wave fit the LDS, eight would not).
-    // ABC_GRAM_DMA=0 keeps the VGPR-staged k_gram for A/B runs; (6, 0) needs 172 KB for its epilogue and stays there.
+    // (6, 0) needs 172 KB for its epilogue and stays on the VGPR-staged kernel.
 #define GRAM_DMA4_CASE(c, cy) if (C == c && CY == cy && dma_ok) return run_gram_dma<c, cy, 4, true>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_DMA4_CASE(4, 0); GRAM_DMA4_CASE(4, 1); GRAM_DMA4_CASE(4, 2); GRAM_DMA4_CASE(5, 0); GRAM_DMA4_CASE(5, 1); GRAM_DMA4_CASE(5, 2);
     GRAM_DMA4_CASE(6, 1); GRAM_DMA4_CASE(6, 2);

@@ -514,9 +514,8 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     const size_t lds_bytes = lds_d * sizeof(double);
     if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
     // up to 16 metrics ONE wavefront (no work-group barriers at all), four up to 64 (measured: 0.119 -> 0.105 ms at M = 32,
-    // P = 16, A = 8; 0.308 -> 0.262 ms at M = 64, P = 32), eight beyond; ABC_PLS_NW=1 keeps one wavefront up to 64 (A/B runs)
-    static const int pls_nw = getenv("ABC_PLS_NW") ? atoi(getenv("ABC_PLS_NW")) : 4;
-    if (M > 16 && M <= 64 && pls_nw == 4) {
+    // P = 16, A = 8; 0.308 -> 0.262 ms at M = 64, P = 32), eight beyond
+    if (M > 16 && M <= 64) {
         ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(k_pls_fit<4>, dim3(1), dim3(256), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
                            scratch, xx_in_lds);

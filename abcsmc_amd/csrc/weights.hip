@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
     unsigned pc[6];
     unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
     if (is_prev) {
-        ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, 4.0 * U1, pc);
+        // minus one half: the vector side splits X = n + fract(X) by floor and evaluates 2^(fract + Y - 1/2) (ks_exp2_f32)
+        ks_pieces((valid ? 0.5 * nn + lw : KS_HB_ZERO) - 0.5, 4.0 * U1, pc);
         *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), 0u);
         *(uint4*)(ob + (32 + rr) * 8) = make_uint4(KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), 0u);
     } else {
@@ -443,19 +444,27 @@ __global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__
     fix_j[i] = s;
 }
 
-// 2^x for the split kernel: same split as exp2_neg<false>, degree-6 minimax polynomial (1.9e-9 relative,
-// scripts/exp2_minimax.py 6 -- below what the operands are good to), 11 instructions with the running sum.
-__device__ __forceinline__ double exp2_d6(double x) {
-    const double tm = x + 6755399441055744.0;
-    const double f = x - (tm - 6755399441055744.0);
-    double p = 0x1.41d333a1fbff9p-13;
-    p = fma(p, f, 0x1.5f456a867c735p-10);
-    p = fma(p, f, 0x1.3b2dbbc0aa7a3p-7);
-    p = fma(p, f, 0x1.c6aed4b95c606p-5);
-    p = fma(p, f, 0x1.ebfbdadcb136fp-3);
-    p = fma(p, f, 0x1.62e430c7e91afp-1);
-    p = fma(p, f, 0x1.00000002614ffp+0);
-    return ldexp(p, __double2loint(tm));
+// 2^(X + Y) for the split kernel, on the f32 side of the vector pipe.  X (exact: a multiple of 1/(4 U1) below 2^12) arrives with
+// one half added by the norm step (k_wsplit), so  X = n + fr  with n = floor(X) and fr = fract(X) both EXACT in f32, and
+//   2^(X - 1/2 + Y) = 2^n * 2^(g - 1/2),   g = fr + Y   (one f32 rounding, <= 2^-25 absolute),
+// 2^(g - 1/2) a degree-6 minimax polynomial in g fitted on [-0.2, 1.2] (|Y| is ~0.02, 0.25 at the very worst), float
+// coefficients and a float Horner chain: 1.1e-7 relative at most on that interval, 5e-7 on [-0.3, 1.3]
+// (scripts/exp2_minimax.py 6 f32 -0.2 1.2 0.5).  Only the last three instructions are fp64: convert, ldexp (exponents down
+// to 2^-1100 stay exact / flush to zero as before) and the running sum.  12 vector instructions per pair, 9 of them f32,
+// against 14.5 fp64 ones for the fp64 evaluation this replaces (2 converts, 3 adds for the split, 6 FMAs, ldexp, add):
+// scripts/ubench_valu.hip measures 0.70 of the issue time for the sequence on its own.
+__device__ __forceinline__ double ks_exp2_f32(float X, float Y) {
+    int n;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(n) : "v"(X));       // the compiler would emit v_floor_f32 + v_cvt_i32_f32
+    const float g = __builtin_amdgcn_fractf(X) + Y;
+    float p = 0x1.40aabap-13f;
+    p = fmaf(p, g, 0x1.d159p-11f);
+    p = fmaf(p, g, 0x1.bf6cb6p-8f);
+    p = fmaf(p, g, 0x1.417fb8p-5f);
+    p = fmaf(p, g, 0x1.5be1e4p-3f);
+    p = fmaf(p, g, 0x1.f5e46ep-2f);
+    p = fmaf(p, g, 0x1.6a09e6p-1f);
+    return ldexp((double)p, n);
 }
 
 // The 13 limb cross-products of one 16-parameter chunk, in issue order: which accumulator, which limb of the previous
@@ -508,7 +517,7 @@ __device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32
         ks_mfma_range<NCH, s0, s1>(An, Bn, Xn, Yn);
         if constexpr (G == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < G; g++) s += exp2_d6((double)Xc[R * G + g] + (double)Yc[R * G + g]);
+        for (int g = 0; g < G; g++) s += ks_exp2_f32(Xc[R * G + g], Yc[R * G + g]);
         asm volatile("" : "+v"(s));
         __builtin_amdgcn_sched_barrier(0);
         ks_slots<NCH, G, R + 1>(An, Bn, Xn, Yn, Xc, Yc, s);
@@ -674,7 +683,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (slices > Kp / 64) slices = Kp / 64;
     if (slices < 1) slices = 1;
     if (slices > 1024) slices = 1024;
-    // split-operand kernel: 8 < P <= 32 parameters (below that the fp64 body is as short), unless the caller asked for fp64
+    // split-operand kernel: 5 <= P <= 32 parameters (padded width 8, 16 or 32; below that the fp64 body is as short), unless the caller asked for fp64
     const int NCH = (P <= 16) ? 1 : 2;
     const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
@@ -736,12 +745,11 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     {
         StageTimer tk(ctx, ST_KDE);
         if (split) {
-            static const int kg = getenv("ABC_KDE_G") ? atoi(getenv("ABC_KDE_G")) : 2;     // A/B: exponentials per slot
 #define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
     hipLaunchKernelGGL((k_kde_split<NCHV, GV>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, \
                        (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, part)
-            if (NCH == 1) { if (kg == 1) LAUNCH_SPLIT(1, 1); else LAUNCH_SPLIT(1, 2); }
-            else          { if (kg == 1) LAUNCH_SPLIT(2, 1); else LAUNCH_SPLIT(2, 2); }
+            if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot (one: within 0.5 %)
+            else LAUNCH_SPLIT(2, 2);
 #undef LAUNCH_SPLIT
         }
         switch (PP) {

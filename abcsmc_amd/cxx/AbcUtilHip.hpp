@@ -53,9 +53,14 @@ struct RNG {
 inline void rng_set(const RNG* r, unsigned long seed) { abc_rng_set(&r->state, seed); }     // gsl_rng_set
 inline unsigned long rng_get(const RNG* r) { return abc_rng_get(&r->state); }                // gsl_rng_get
 // the three GSL draws Priors.h uses for set 0 (host side, one-off per fit): gsl_rng_uniform = get / 2^32;
-// gsl_rng_uniform_int rejects above n * (0xffffffff / n); gsl_ran_gaussian is the polar Box-Muller on
-// uniforms in (-1, 1) [published GSL 2.x algorithms; GSL itself is not in this image]
+// gsl_rng_uniform_pos redraws a zero; gsl_rng_uniform_int rejects above n * (0xffffffff / n); gsl_ran_gaussian is the
+// polar Box-Muller on uniform_pos draws mapped to (-1, 1) [published GSL 2.x algorithms; GSL itself is not in this image]
 inline double rng_uniform(const RNG* r) { return abc_rng_get(&r->state) / 4294967296.0; }
+inline double rng_uniform_pos(const RNG* r) {
+    double x;
+    do { x = rng_uniform(r); } while (x == 0.0);
+    return x;
+}
 inline unsigned long rng_uniform_int(const RNG* r, unsigned long n) {
     const unsigned long scale = 0xffffffffUL / n;
     unsigned long k;
@@ -65,8 +70,8 @@ inline unsigned long rng_uniform_int(const RNG* r, unsigned long n) {
 inline double ran_gaussian(const RNG* r, double sigma) {
     double x, y, r2;
     do {
-        x = -1.0 + 2.0 * rng_uniform(r);
-        y = -1.0 + 2.0 * rng_uniform(r);
+        x = -1.0 + 2.0 * rng_uniform_pos(r);      // gauss.c: gsl_rng_uniform_pos, a zero output is drawn again
+        y = -1.0 + 2.0 * rng_uniform_pos(r);
         r2 = x * x + y * y;
     } while (r2 > 1.0 || r2 == 0.0);
     return sigma * y * std::sqrt(-2.0 * std::log(r2) / r2);
