@@ -213,9 +213,10 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
 // where hb_j = 1/2|b_j|^2 - log2 w'_j and ha_i = 1/2|a_i|^2 (each = Top, a multiple of 1/(4 U1), + Low) enter through
 // ONE more K-step whose operands hold the bf16 pieces of hb / ha against -1s / 1s on the other side.  X + Y is then
 // the whole base-2 exponent of the term (<= log2 w'_j), and the vector pipe only converts, adds and exponentiates:
-//   term = 2^(double(X) + double(Y))          14 instructions per pair instead of 30 (degree-6 polynomial).
-// Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32).  Measured error of a
-// weight against the oracle: 3.6e-9 max, 7e-10 rms (tests/test_gpu_parity.py), budget 1e-6.
+//   term = 2^floor(X) * 2^(fract(X) + Y)      7 instructions per pair instead of 30 (ks_exp2: f32 split + v_exp_f32, fp64 sum).
+// Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32); error of a term
+// with the f32 evaluation: 3e-8 rms, 1e-7 max.  Measured error of a weight against the oracle: see
+// tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
 // Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400]) are "far": k_wsplit gives them
 // all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up kernels add
 // their pairs (k_kde_far_rows: a far new particle against the whole previous set; k_kde_far_cols: the far previous
@@ -355,8 +356,7 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
     unsigned pc[6];
     unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
     if (is_prev) {
-        // minus one half: the vector side splits X = n + fract(X) by floor and evaluates 2^(fract + Y - 1/2) (ks_exp2_f32)
-        ks_pieces((valid ? 0.5 * nn + lw : KS_HB_ZERO) - 0.5, 4.0 * U1, pc);
+        ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, 4.0 * U1, pc);
         *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), 0u);
         *(uint4*)(ob + (32 + rr) * 8) = make_uint4(KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), 0u);
     } else {
@@ -444,27 +444,22 @@ __global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__
     fix_j[i] = s;
 }
 
-// 2^(X + Y) for the split kernel, on the f32 side of the vector pipe.  X (exact: a multiple of 1/(4 U1) below 2^12) arrives with
-// one half added by the norm step (k_wsplit), so  X = n + fr  with n = floor(X) and fr = fract(X) both EXACT in f32, and
-//   2^(X - 1/2 + Y) = 2^n * 2^(g - 1/2),   g = fr + Y   (one f32 rounding, <= 2^-25 absolute),
-// 2^(g - 1/2) a degree-6 minimax polynomial in g fitted on [-0.2, 1.2] (|Y| is ~0.02, 0.25 at the very worst), float
-// coefficients and a float Horner chain: 1.1e-7 relative at most on that interval, 5e-7 on [-0.3, 1.3]
-// (scripts/exp2_minimax.py 6 f32 -0.2 1.2 0.5).  Only the last three instructions are fp64: convert, ldexp (exponents down
-// to 2^-1100 stay exact / flush to zero as before) and the running sum.  12 vector instructions per pair, 9 of them f32,
-// against 14.5 fp64 ones for the fp64 evaluation this replaces (2 converts, 3 adds for the split, 6 FMAs, ldexp, add):
-// scripts/ubench_valu.hip measures 0.70 of the issue time for the sequence on its own.
-__device__ __forceinline__ double ks_exp2_f32(float X, float Y) {
+// 2^(X + Y) for the split kernel.  X is exact in f32 (a multiple of 1/(4 U1) below 2^12), so n = floor(X) and fract(X) are
+// exact too, and
+//   2^(X + Y) = 2^n * 2^g,   g = fract(X) + Y   (one f32 rounding, <= 2^-24 absolute; |Y| is ~0.02, 0.25 at the very worst),
+// with 2^g from the hardware's v_exp_f32: measured on gfx950 over every float of [-0.3, 1.3] (scripts/exp2_hw_accuracy.hip)
+// max 8.2e-8, rms 2.6e-8, mean -2e-9 relative -- tighter than the degree-6 float polynomial it replaced (1.1e-7 / 3.8e-8).
+// Only the last three instructions are fp64: convert, ldexp (exponents down to 2^-1100 stay exact / flush to zero) and
+// the running sum.  7 vector instructions per pair (the transcendental issues in 8 cycles, the others in 4) against 14.5
+// fp64 ones for the all-fp64 evaluation of round 1 (2 converts, 3 adds for the split, 6 FMAs, ldexp, add).  Measured at
+// 1e10 pairs, P = 16: 5.7 ms (fp64) -> 4.4 ms (f32 polynomial) -> 3.6 ms (v_exp_f32); packed f32 FMAs for the polynomial
+// were slower than plain ones beside the MFMAs (4.6 ms), an f32 running sum flushed per batch would give another 4 %
+// and lose the range.
+__device__ __forceinline__ double ks_exp2(float X, float Y) {
     int n;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(n) : "v"(X));       // the compiler would emit v_floor_f32 + v_cvt_i32_f32
-    const float g = __builtin_amdgcn_fractf(X) + Y;
-    float p = 0x1.40aabap-13f;
-    p = fmaf(p, g, 0x1.d159p-11f);
-    p = fmaf(p, g, 0x1.bf6cb6p-8f);
-    p = fmaf(p, g, 0x1.417fb8p-5f);
-    p = fmaf(p, g, 0x1.5be1e4p-3f);
-    p = fmaf(p, g, 0x1.f5e46ep-2f);
-    p = fmaf(p, g, 0x1.6a09e6p-1f);
-    return ldexp((double)p, n);
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fractf(X) + Y);
+    return ldexp((double)e, n);
 }
 
 // The 13 limb cross-products of one 16-parameter chunk, in issue order: which accumulator, which limb of the previous
@@ -517,7 +512,7 @@ __device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32
         ks_mfma_range<NCH, s0, s1>(An, Bn, Xn, Yn);
         if constexpr (G == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < G; g++) s += ks_exp2_f32(Xc[R * G + g], Yc[R * G + g]);
+        for (int g = 0; g < G; g++) s += ks_exp2(Xc[R * G + g], Yc[R * G + g]);
         asm volatile("" : "+v"(s));
         __builtin_amdgcn_sched_barrier(0);
         ks_slots<NCH, G, R + 1>(An, Bn, Xn, Yn, Xc, Yc, s);
@@ -563,7 +558,7 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4
             ks_slots<NCH, G, 0>(A, B1, X1, Y1, X0, Y0, acc0);       // matrix: (t, columns 1); vector: (t, columns 0)
             ks_slots<NCH, G, 0>(An, B0, X0, Y0, X1, Y1, acc1);      // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
-            for (int q = 0; q < OPB; q++) A[q] = An[q];
+            for (int q = 0; q < OPB; q++) A[q] = An[q];       // (two tiles per trip with A / An trading places: no gain, measured)
         }
     }
     {
@@ -748,7 +743,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
     hipLaunchKernelGGL((k_kde_split<NCHV, GV>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, \
                        (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, part)
-            if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot (one: within 0.5 %)
+            if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot
             else LAUNCH_SPLIT(2, 2);
 #undef LAUNCH_SPLIT
         }
