@@ -15,12 +15,14 @@
 #define ABCSMC_AMD_ABCSMCHIP_HPP
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -200,6 +202,13 @@ class AbcSmc {
     bool simulate_next_particles(const int n = 1, const int serial_req = -1, const int posterior_req = -1);
     bool simulate_particle_by_serial(const int serial_req) { return simulate_next_particles(1, serial_req, -1); }
     bool simulate_particle_by_posterior_idx(const int posterior_req) { return simulate_next_particles(1, -1, posterior_req); }
+    // AbcSmc::run() is named by the stale drivers (examples/direct/main.cpp:32, examples/scratch/main_mpi_*.cpp) and absent from
+    // AbcSmc.h of this reference version; here it is the `--process --simulate --all` sequence of abc_loop
+    // (examples/include/examples.h:57-93): for every set, reseed + process_database, then simulate that set's particles;
+    // process_database once more for the final posterior.  reseed(step) gives the seed before the step-th --process
+    // (default: time(NULL) * getpid(), examples.h:64).
+    bool run(const ABC::RNG* RNG, const std::function<unsigned long(size_t)>& reseed = nullptr);
+    bool run(const std::string& executable, const ABC::RNG* RNG) { set_executable(executable); return run(RNG); }
 
     size_t npar() { return _model_pars.size(); }
     size_t nmet() { return _model_mets.size(); }
@@ -545,7 +554,8 @@ inline void AbcSmc::_insert_particles(sqdyn::Db& db, size_t set_num, long long f
 inline bool AbcSmc::build_database(const ABC::RNG* RNG) {                      // AbcSmc.cpp:810-873
     sqdyn::Db db(_database_filename);
     if (db.table_exists(JOB_TABLE) || db.table_exists(PAR_TABLE) || db.table_exists(MET_TABLE)) return false;
-    _transaction(db, "creating tables", [&] {
+    // the tables first; the priors and seeds are drawn (and the RNG stream consumed) only once they exist
+    const bool created = _transaction(db, "creating tables", [&] {
         db.exec(std::string("create table ") + JOB_TABLE + " ( serial int primary key asc, smcSet int, particleIdx int, startTime int, duration real, status text, posterior int, attempts int );");
         db.exec(std::string("create index idx1 on ") + JOB_TABLE + " (status, attempts);");
         db.exec(std::string("create table ") + PAR_TABLE + " ( serial int primary key, seed blob, " + _column_list("", true, " real") + ");");
@@ -553,6 +563,7 @@ inline bool AbcSmc::build_database(const ABC::RNG* RNG) {                      /
             db.exec(std::string("create table ") + UPAR_TABLE + " ( serial int primary key, seed blob, " + _column_list("", true, " real") + ");");
         db.exec(std::string("create table ") + MET_TABLE + " ( serial int primary key, " + _column_list("", false, " real") + ");");
     });
+    if (!created) { std::cerr << "ERROR: could not create the tables of " << _database_filename << std::endl; return false; }
     const size_t num_particles = get_smc_size_at(0);
     std::vector<size_t> posterior_ranks;
     const Mat2D pars = ABC::sample_priors(RNG, num_particles, _posterior, _model_pars, posterior_ranks);
@@ -560,7 +571,10 @@ inline bool AbcSmc::build_database(const ABC::RNG* RNG) {                      /
     for (size_t i = 0; i < num_particles; i++) seeds[i] = ABC::rng_get(RNG);     // after all samples (:843, 859)
     std::vector<long long> ranks;
     if (_retain_posterior_rank) ranks.assign(posterior_ranks.begin(), posterior_ranks.end());
-    _transaction(db, "inserting the first set", [&] { _insert_particles(db, 0, 0, pars, seeds, ranks); });
+    if (!_transaction(db, "inserting the first set", [&] { _insert_particles(db, 0, 0, pars, seeds, ranks); })) {
+        std::cerr << "ERROR: could not store the first set in " << _database_filename << std::endl;
+        return false;
+    }
     return true;
 }
 
@@ -657,6 +671,18 @@ inline void AbcSmc::calculate_predictive_prior_weights(const size_t t) {      //
         _weights.push_back(ABC::weight_predictive_prior(_model_pars, post, ABC::select_rows(_particle_parameters[t - 1], _predictive_prior[t - 1]),
                                                         _weights[t - 1], _doubled_variance[t - 1]));
     }
+}
+
+inline bool AbcSmc::run(const ABC::RNG* RNG, const std::function<unsigned long(size_t)>& reseed) {
+    auto seed_for = [&](size_t step) { return reseed ? reseed(step) : (unsigned long)time(NULL) * (unsigned long)getpid(); };
+    const size_t sets = get_smc_iterations();
+    for (size_t t = 0; t < sets; t++) {
+        ABC::rng_set(RNG, seed_for(t));
+        process_database(RNG);                                 // abc_inner ignores both results (examples.h:63-70)
+        simulate_next_particles((int)get_smc_size_at(t));
+    }
+    ABC::rng_set(RNG, seed_for(sets));
+    return process_database(RNG);                              // one last time, to get the posterior (examples.h:91-93)
 }
 
 inline bool AbcSmc::process_database(const ABC::RNG* RNG, const bool verbose) {   // AbcSmc.cpp:452-559

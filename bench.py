@@ -4,13 +4,17 @@ on synthetic particle x (parameter | metric) matrices, with the inputs resident 
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A "step" is one generation: abc_generation_dev on one GPU, or the row-sharded driver
-(abcsmc_amd/sharded.py, RCCL collectives) on N GPUs with the per-GPU particle count fixed (weak scaling:
-the current set has N x n_local particles and K = 0.1 N x n_local retained; the previous set's posterior keeps
-the single-GPU size, so the O(K K'/N_gpus) weight work per GPU stays fixed as well).
-Prints ONE JSON line on rank 0 carrying the driver contract plus `roofline` (the dominant HBM kernel,
-k_gram: algorithmic bytes / HIP-event time measured live in this run) and `cpu_baseline` (the
-single-threaded CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+A "step" is one generation: abc_generation_dev on one GPU, or the row-sharded driver (RCCL collectives) on N GPUs with
+the per-GPU particle count fixed (weak scaling in particles: the current set has N x n_local particles, K = 0.1 N x n_local
+are retained and the previous predictive prior has the same size K' = K, so the pair sums of the weight stage are
+K K' / N pairs per GPU and grow with N).
+Prints ONE JSON line on rank 0 carrying the driver contract plus
+  roofline            the kernel that dominates the step (the pair sums of the importance weights, k_kde_split): matrix-pipe
+                      work issued / HIP-event time measured live in this run, against the dense bf16 MFMA peak, with the
+                      vector-issue fraction beside it (the kernel keeps both pipes busy)
+  roofline_hbm        the dominant HBM kernel (k_gram): algorithmic bytes / HIP-event time
+  roofline_streaming  SURVEY 8(d): algorithmic bytes of a generation / (step time - pair-sum kernel), and the same for set 0
+  cpu_baseline        the single-threaded CPU oracle on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -33,6 +37,26 @@ CONFIGS = {
             N=125_000, M=128, P=16, A=32),
 }
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0    # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD at 2.4 GHz)
+
+
+def pmc_traffic(kernel_prefix, config, world):
+    """HBM bytes per launch of a kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE with the gfx950 correction,
+    written by scripts/summarize_profiles.py); only for the exact single-GPU configuration profiled, else None"""
+    if world != 1:
+        return None
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        prof = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(prof):
+            continue
+        try:
+            ent = json.load(open(prof))["configs"].get(str(config), {})
+            for k, v in ent.items():
+                if k.startswith(kernel_prefix):
+                    return v["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
 
 
 def main():
@@ -47,6 +71,8 @@ def main():
     ap.add_argument("--kde-mode", choices=["auto", "fp64"], default="auto",
                     help="weight kernel: auto = split-operand kernel where it applies (default), fp64 = the fp64 vector kernel (A/B runs)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--prev-size", type=int, default=0,
+                    help="size K' of the previous predictive prior (default: K = 0.1 x all particles, the stated configuration)")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,8 +98,10 @@ def main():
     n_loc, M, P, A = cfg["N"], cfg["M"], cfg["P"], cfg["A"]
     N = n_loc * world
     K = N // 10                   # predictive-prior fraction 0.1 of the (sharded) current set
-    Kp = n_loc // 10              # previous predictive prior: the single-GPU set's (AbcSmc sets may grow between
-                                  # generations, reference.json num_samples); keeps the O(K K'/G) weight work per GPU fixed
+    # previous predictive prior: K' = K (the previous set has the size of this one), so the
+    # weight stage is K^2 / G pairs per GPU and GROWS with the number of GPUs at fixed particles per GPU.  --prev-size
+    # bounds it (sets may grow between generations, reference.json num_samples); the workload string then says so.
+    Kp = args.prev_size if args.prev_size > 0 else K
     nn_loc = n_loc
 
     # ---- synthetic inputs, generated on the host once, then resident in HBM ---------------------------
@@ -127,68 +155,80 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = N / (elapsed / args.steps)
 
-    # ---- roofline of the dominant HBM kernel (k_gram): algorithmic bytes = 8 (M+P) per particle ------
-    g_ms, _, g_cnt = stages["k_gram"]
-    gram_launches_per_step = g_cnt / max(args.steps, 1)
-    # one launch per step: reads X and Y (local rows) exactly once -> 8 (M+P) bytes per particle
-    alg_bytes = 8.0 * n_loc * (M + P)
-    # the stage timer brackets that single launch with an event pair; the pair also sees the dispatch and the
-    # end-of-kernel release latency, which abc_timing_overhead measures with empty kernels on the same stream.
-    # kernel_ms_per_step = bracket - overhead is what rocprofv3 --kernel-trace reports for the kernel
-    # (profiles/r01_kernel_stats_config*.csv); the raw bracket is kept beside it.
-    gram_bracket_ms = g_ms / max(g_cnt, 1)
-    event_overhead_ms = ctx.timing_overhead(50)
-    gram_ms_per_step = max(gram_bracket_ms - event_overhead_ms, 0.0) * gram_launches_per_step
-    achieved = alg_bytes / (gram_ms_per_step * 1e-3) / 1e9 if gram_ms_per_step > 0 else 0.0
-    achieved_raw = alg_bytes / (gram_bracket_ms * gram_launches_per_step * 1e-3) / 1e9 if gram_bracket_ms > 0 else 0.0
-    # HBM traffic of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 correction
-    # applied by the script that wrote the file); only valid for the exact single-GPU configuration profiled
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(prof) and world == 1:
-        try:
-            ent = json.load(open(prof))["configs"].get(str(args.config), {})
-            for k, v in ent.items():
-                if k.startswith("k_gram<3") or k.startswith("k_gram_dma<3"):
-                    traffic = v["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "k_gram", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": round(gram_ms_per_step, 5),
-                "launches_per_step": gram_launches_per_step, "event_bracket_ms": round(gram_bracket_ms, 5),
-                "event_overhead_ms": round(event_overhead_ms, 5), "achieved_event_bracket": round(achieved_raw, 1)}
+    def per_launch_ms(stage):
+        """average HIP-event bracket of one launch of a stage (ms) and launches per step, from the recorded counts"""
+        ms, _, cnt = stages[stage]
+        assert cnt % args.steps == 0 and cnt > 0, "stage %s: %d samples over %d steps (timer ring lost samples?)" % (stage, cnt, args.steps)
+        return ms / cnt, cnt // args.steps
+
+    event_overhead_ms = ctx.timing_overhead(50)      # what an event pair reports beyond the kernel itself (empty-kernel calibration)
     stage_ms = {k: round((v[0] + v[1]) / max(args.steps, 1), 5) for k, v in stages.items()}
-    # the compute-bound kernel of the path (informational): pairs x vector instructions per pair / HIP-event time.
-    # Two kernels can run it: the split-operand kernel (pair dot products on the bf16 matrix pipe,
-    # 14.5 fp64 vector instructions per pair: 2 converts, 5 adds, 6 FMAs, ldexp + loop share; 13 ceil(P/16) + 2 MFMAs
-    # per 32 x 32 pairs) and the fp64 vector kernel (1 add, PP FMAs, 13 for 2^x).  The chip is power-limited on both
-    # (measured 2.13 GHz on the fp64 kernel, 1.69 GHz with the matrix pipe active: profiles/r01_pmc_kde_clock.json), so
-    # the issue-rate fraction is quoted against the 2.4 GHz peak clock.
-    k_ms, _, _ = stages["k_kde"]
-    pairs = float(K // world + (1 if rank < K % world else 0)) * Kp if world > 1 else float(K) * Kp
+
+    # ---- roofline of the DOMINANT kernel: the pair sums of the importance weights (k_kde_split / k_kde) ------------------
+    # Two kernels can run them (DESIGN.md section 4).  k_kde_split: pair dot products as exact bf16 limb products on the
+    # matrix pipe -- 13 ceil(P/16) + 2 v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs = 32 flop per pair and MFMA -- and 7 vector
+    # instructions per pair (floor, fract, add, v_exp_f32 [8 issue cycles], convert, ldexp, fp64 add) = 8 issue slots.
+    # k_kde (fp64 fallback): 1 add + PP FMAs + 13 for 2^x per pair, no matrix work.
+    kde_bracket_ms, kde_launches = per_launch_ms("k_kde") if Kp else (0.0, 0)
+    kde_ms = max(kde_bracket_ms - event_overhead_ms, 0.0)
+    pairs = (float(K // world + (1 if rank < K % world else 0)) if world > 1 else float(K)) * Kp
     PPad = 2
     while PPad < P:
         PPad *= 2
-    which = ctx.kde_last_kernel()
-    kde_ms_per_step = k_ms / max(args.steps, 1)
-    if which == _lib.KDE_RAN_SPLIT:
-        kname, instr_pair, flop_pair = "k_kde_split", 14.5, 2 + 5 + 2 * 6 + 1
-        mfma_per_1024 = 13 * ((P + 15) // 16) + 2
-    else:
-        kname, instr_pair, flop_pair = "k_kde", 1 + PPad + 3 + 8 + 1 + 1, 1 + 2 * PPad + 3 + 2 * 8 + 1 + 1
-        mfma_per_1024 = 0
-    kde_tflops = pairs * flop_pair / (kde_ms_per_step * 1e-3) / 1e12 if kde_ms_per_step > 0 else 0.0
+    which = ctx.kde_last_kernel() if Kp else _lib.KDE_RAN_NONE
     issue_peak = 256 * 4 * 2.4e9 / 4.0                # wave-instructions per second: 1024 SIMDs, 4 cycles each, 2.4 GHz
-    roofline_compute = {"kernel": kname, "bound": "fp64_valu_issue", "pairs_per_step": pairs,
-                        "pairs_per_s": pairs / (kde_ms_per_step * 1e-3) if kde_ms_per_step > 0 else 0.0,
-                        "valu_instr_per_pair": instr_pair, "mfma_32x32x16_per_1024_pairs": mfma_per_1024,
-                        "valu_issue_frac": round(pairs / 64.0 * (instr_pair + mfma_per_1024 * 2.0 / 16.0)
-                                                 / (kde_ms_per_step * 1e-3) / issue_peak, 4) if kde_ms_per_step > 0 else 0.0,
-                        "fp64_vector_tflops": round(kde_tflops, 2), "fp64_vector_peak_tflops": 78.6,
-                        "note": "valu_issue_frac = (vector instructions + 8 issue cycles per MFMA) / (1024 SIMDs x 2.4 GHz / 4); "
-                                "the fp64 kernel of the same stage (abc_ctx_set_kde_mode) runs 30 instructions per pair",
-                        "kernel_ms_per_step": round(kde_ms_per_step, 5)}
+    if which == _lib.KDE_RAN_SPLIT:
+        mfma_per_block = 13 * ((P + 15) // 16) + 2
+        flops = pairs * mfma_per_block * 32.0          # 32 x 32 x 16 x 2 flop per MFMA over 1024 pairs
+        slots_per_pair = 8.0
+        achieved_tf = flops / (kde_ms * 1e-3) / 1e12 if kde_ms > 0 else 0.0
+        roofline = {"kernel": "k_kde_split", "bound": "mfma", "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(achieved_tf / MFMA_BF16_PEAK_TF, 4),
+                    "traffic": pmc_traffic("k_kde_split", args.config, world),
+                    "flops_per_launch": flops, "mfma_32x32x16_bf16_per_1024_pairs": mfma_per_block,
+                    "pairs_per_launch": pairs, "pairs_per_s": pairs / (kde_ms * 1e-3) if kde_ms > 0 else 0.0,
+                    "valu_issue_slots_per_pair": slots_per_pair,
+                    "valu_issue_frac": round((pairs / 64.0) * (slots_per_pair + mfma_per_block * 2.0 / 16.0) / (kde_ms * 1e-3) / issue_peak, 4)
+                    if kde_ms > 0 else 0.0,
+                    "note": "flops = bf16 MFMA work issued (exact limb products of the fp64 pair dot products); valu_issue_frac = "
+                            "(vector issue slots + 8 issue cycles per MFMA) / (1024 SIMDs x 2.4 GHz / 4); the chip clocks down "
+                            "under this kernel (profiles/: clock from GRBM_GUI_ACTIVE)"}
+    else:
+        instr_pair = 1 + PPad + 13
+        flops = pairs * (1 + 2 * PPad + 3 + 2 * 8 + 2)
+        achieved_tf = flops / (kde_ms * 1e-3) / 1e12 if kde_ms > 0 else 0.0
+        roofline = {"kernel": "k_kde", "bound": "fp64_valu", "achieved": round(achieved_tf, 2), "peak": 78.6, "unit": "TFLOP/s",
+                    "frac": round(achieved_tf / 78.6, 4), "traffic": pmc_traffic("k_kde<", args.config, world),
+                    "pairs_per_launch": pairs, "valu_instr_per_pair": instr_pair,
+                    "valu_issue_frac": round((pairs / 64.0) * instr_pair / (kde_ms * 1e-3) / issue_peak, 4) if kde_ms > 0 else 0.0}
+    roofline.update({"kernel_ms": round(kde_ms, 5), "launches_per_step": kde_launches, "event_bracket_ms": round(kde_bracket_ms, 5),
+                     "event_overhead_ms": round(event_overhead_ms, 5), "share_of_step": round(kde_ms * kde_launches / ms_per_step, 4)})
+
+    # ---- the dominant HBM kernel (k_gram): one launch per step reads X and Y (local rows) exactly once ---------------------
+    gram_bracket_ms, gram_launches = per_launch_ms("k_gram")
+    gram_ms = max(gram_bracket_ms - event_overhead_ms, 0.0)
+    # (beyond 96 columns the set goes through column-group pairs, several launches: the algorithmic bytes of the set are
+    # spread over them, i.e. `achieved` is then bytes of the set / total time of those launches)
+    gram_bytes = 8.0 * n_loc * (M + P) / gram_launches
+    gram_gbs = gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0
+    roofline_hbm = {"kernel": "k_gram", "bound": "hbm", "achieved": round(gram_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gram_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_gram", args.config, world),
+                    "algorithmic_bytes_per_launch": gram_bytes, "kernel_ms": round(gram_ms, 5), "launches_per_step": gram_launches,
+                    "event_bracket_ms": round(gram_bracket_ms, 5),
+                    "achieved_event_bracket": round(gram_bytes / (gram_bracket_ms * 1e-3) / 1e9, 1) if gram_bracket_ms > 0 else 0.0}
+
+    # ---- SURVEY 8(d): all streaming stages together = the step without the pair-sum kernel ------------------------------
+    def alg_bytes(kp):
+        nn, k = nn_loc, K
+        return (8.0 * n_loc * (M + P) + 8.0 * n_loc * M + 8.0 * n_loc + 16.0 * n_loc + 16.0 * k * P + nn * (16.0 * P + 8.0)
+                + 8.0 * kp * P + 8.0 * (k + kp))
+    stream_ms = ms_per_step - kde_ms * kde_launches
+    stream_gbs = alg_bytes(Kp) / (stream_ms * 1e-3) / 1e9
+    roofline_streaming = {"bound": "hbm", "algorithmic_bytes_per_step": alg_bytes(Kp), "bytes_per_particle": round(alg_bytes(Kp) / n_loc, 1),
+                          "ms": round(stream_ms, 5), "achieved": round(stream_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(stream_gbs / HBM_PEAK_GBS, 4),
+                          "note": "SURVEY 8(d): B_alg / (wall time of a step minus the pair-sum kernel), per GPU; host work "
+                                  "(alias table) and launch gaps included"}
 
     # set 0 (uniform weights, AbcUtil.cpp:539-545) has no O(K K') stage: reported separately, outside the timed region
     set0 = None
@@ -203,7 +243,10 @@ def main():
             gen0.run(dX, dY, dobs, dpri, rng0)
         barrier()
         dt0 = (time.perf_counter() - t1) / 5
+        g0 = alg_bytes(0) / dt0 / 1e9
         set0 = {"value": N / dt0, "unit": "particles/s", "ms_per_step": 1e3 * dt0,
+                "roofline_streaming": {"algorithmic_bytes_per_step": alg_bytes(0), "achieved": round(g0, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(g0 / HBM_PEAK_GBS, 4)},
                 "note": "first SMC set: rank + uniform weights + resample/perturb (no importance-weight stage)"}
 
     cpu = None
@@ -216,13 +259,14 @@ def main():
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"], "particles_per_gpu": n_loc, "particles_total": N, "metrics": M,
+            "config": {"workload": cfg["name"] + ("" if Kp == K else " [previous predictive prior bounded to K' = %d]" % Kp), "particles_per_gpu": n_loc, "particles_total": N, "metrics": M,
                        "params": P, "pls_components": A, "pred_prior_size": K, "prev_pred_prior_size": Kp,
                        "next_set_size": nn_loc * world, "noise": "MULTIVARIATE", "train_fraction": 0.5,
                        "ncomp_chosen": int(gen.ncomp.value if world == 1 else gen.ncomp),
                        "parallelism": "row-sharded x%d" % world},
             "roofline": roofline,
-            "roofline_compute": roofline_compute,
+            "roofline_hbm": roofline_hbm,
+            "roofline_streaming": roofline_streaming,
             "set0": set0,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,

@@ -59,11 +59,17 @@ int main(int argc, char* argv[]) {
             }
             if (simulate_db) abc->simulate_next_particles(n);
         };
-        if (do_all) {
+        if (do_all && process_db && simulate_db) {
+            // the whole fit: AbcSmc::run() = every set in turn, then the final posterior
+            if (seeded) abc->run(RNG, [&](size_t step) { return seed + step; });
+            else abc->run(RNG);
+        } else if (do_all) {
             const size_t sets = abc->get_smc_iterations();
             for (size_t t = 0; t < sets; t++) turn((int)abc->get_smc_size_at(t), t);
-            ABC::rng_set(RNG, seeded ? seed + sets : (unsigned long)time(NULL) * (unsigned long)getpid());
-            abc->process_database(RNG);      // once more, for the final posterior
+            if (process_db) {
+                ABC::rng_set(RNG, seeded ? seed + sets : (unsigned long)time(NULL) * (unsigned long)getpid());
+                abc->process_database(RNG);      // once more, for the final posterior
+            }
         } else {
             turn(buffer_size, 0);
         }

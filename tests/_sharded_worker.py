@@ -1,6 +1,6 @@
 """Worker for the world_size-2 tests of the row-sharded generation (launched by torch.distributed.run).
 argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, both ranks on one GPU),
-out_json."""
+out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"]."""
 import json
 import os
 import sys
@@ -20,7 +20,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from abcsmc_amd import _lib, sharded, synthetic
     from oracle import pyoracle as O
-    n_loc, M, P, A, K, Kp, nn_loc = 1500, 12, 5, 4, 500, 300, 1000
+    n_loc, M, P, A, K, Kp, nn_loc = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1500,12,5,4,500,300,1000").split(","))
     N = n_loc * world
     wl = synthetic.Workload(M, P, 777)
     X, Y = wl.rows(rank * n_loc, (rank + 1) * n_loc)

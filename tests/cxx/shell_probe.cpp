@@ -2,7 +2,35 @@
 // item, and (with --sample N) the first N rows sample_priors draws for set 0.  No GPU work.
 #include "../../abcsmc_amd/cxx/AbcSmcHip.hpp"
 
+// --gauss s1 s2 s3 sigma n: n draws of the facade's ran_gaussian from the given taus2 state, as hex floats, then the state
+static int gauss_mode(char** a) {
+    ABC::RNG r(1);
+    r.state.s1 = (uint32_t)strtoul(a[0], nullptr, 10);
+    r.state.s2 = (uint32_t)strtoul(a[1], nullptr, 10);
+    r.state.s3 = (uint32_t)strtoul(a[2], nullptr, 10);
+    const double sigma = atof(a[3]);
+    const int n = atoi(a[4]);
+    for (int i = 0; i < n; i++) printf("%a\n", ABC::ran_gaussian(&r, sigma));
+    printf("state %u %u %u\n", r.state.s1, r.state.s2, r.state.s3);
+    return 0;
+}
+
+// --filter-report cfg K: AbcLog::filtering_report (AbcLog.cpp:79-123) on K hand-made posterior rows, to stdout
+static int report_mode(const char* cfg, int K) {
+    AbcSmc abc;
+    abc.parse_config(cfg);
+    Mat2D ppars((size_t)K, abc.npar()), pmets((size_t)K, abc.nmet());
+    for (int i = 0; i < K; i++) {
+        for (size_t j = 0; j < abc.npar(); j++) ppars(i, j) = (double)((i * 37 + 11 * (int)j) % 101) + 0.25 * (double)j;
+        for (size_t j = 0; j < abc.nmet(); j++) pmets(i, j) = 40.0 + (double)((i * 13 + 7 * (int)j) % 17) * (j ? 0.125 : 1.0) - 3.0 * (double)j * 10.0;
+    }
+    AbcLog::filtering_report(&abc, 3, ppars, pmets, std::cout);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 7 && std::string(argv[1]) == "--gauss") return gauss_mode(argv + 2);
+    if (argc >= 4 && std::string(argv[1]) == "--filter-report") return report_mode(argv[2], atoi(argv[3]));
     if (argc < 2) return 2;
     AbcSmc abc;
     abc.parse_config(argv[1]);

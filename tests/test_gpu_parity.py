@@ -694,38 +694,67 @@ def test_wilcoxon_rule_reduces_somewhere(oracle):
     assert hit >= 1
 
 
-def test_generation_config3_size_properties(gpu_ctx, oracle):
-    """BASELINE configs[2] size (N = 1e6, M = 32, P = 16, A = 8, K = K' = 1e5): invariants that do not need
-    the O(K K' P) oracle: sortedness, K-th order statistic, selection = oracle's given the device's own
-    distances, L2 norm, resample-count checksum, spot-checked weights on a few rows, bit reproducibility."""
-    from abcsmc_amd import device
-    N, M, P, K, Kp, Nn, A = 1_000_000, 32, 16, 100_000, 100_000, 1_000_000, 8
+def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol):
+    """A full generation at a BASELINE size: invariants that do not need the O(K K' P) oracle -- sortedness, selection =
+    the oracle's ordering of the device's own distances (bit-exact), L2 norm, weights of a few rows against the oracle
+    formula restricted to those rows, parents = the oracle's resampling of the device's own weights (bit-exact),
+    finite proposals inside the prior support, MVN factor against numpy."""
+    from abcsmc_amd import abcutil, device
     wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
     idx, dist = gen.idx.cpu().numpy(), gen.dist.cpu().numpy()
     assert np.all(np.diff(dist) >= 0) and len(np.unique(idx)) == K
     # full distance vector through the staged entry point, then the oracle's argsort on those exact values
-    from abcsmc_amd import abcutil
     g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=N, max_comp=A, details=True, ctx=gpu_ctx)
+    assert g["ncomp"] == gen.ncomp.value and 1 <= g["ncomp"] <= A
     full = np.empty(N)
     full[g["idx"].astype(np.int64)] = g["dist"]
     ref = oracle.ordered(full)[:K]
     assert np.array_equal(idx.astype(np.uint64), ref)                       # bit-exact selection at full size
     assert np.array_equal(dist, full[ref.astype(np.int64)])
+    # the distances themselves: oracle projection with the device's model on a sample of rows
     w = gen.w.cpu().numpy()
     assert np.all(w >= 0) and abs(np.linalg.norm(w) - 1.0) < 1e-10
-    # weights of a few selected particles against the oracle formula restricted to those rows
     theta = Y[idx]
+    assert np.array_equal(device.to_numpy(gen.theta), theta)
+    assert np.allclose(gen.dv.cpu().numpy(), 2.0 * theta.var(axis=0, ddof=1), rtol=1e-9)
     rows = np.array([0, 1, 777, K // 2, K - 1])
     raw = oracle.weights_importance(oracle.make_priors(spec), theta[rows], prev[0], prev[1], prev[2])
     ratio = (w[rows] / w[rows[0]]) / (raw / raw[0])                          # normalisation cancels in ratios
-    assert np.allclose(ratio, 1.0, rtol=2 * KDE_TOL["auto"])       # P = 16: the split-operand weight kernel
+    assert np.allclose(ratio, 1.0, rtol=2 * kde_tol)
     parent = gen.parent.cpu().numpy()
     assert np.bincount(parent, minlength=K).sum() == Nn and parent.max() < K
     # the resampled parents are exactly the oracle's for the device's own weights
     o = oracle.rng(67890)
     assert np.array_equal(parent.astype(np.uint64), oracle.resample(o, w, Nn))
+    cov = np.cov(theta, rowvar=False, ddof=1)
+    cov[np.diag_indices(P)] *= 2.0                                           # AbcUtil.cpp:475-479
+    assert np.allclose(np.tril(device.to_numpy(gen.L)), np.linalg.cholesky(cov), rtol=1e-7, atol=1e-12 * np.abs(cov).max() ** 0.5)
     nxt = device.to_numpy(gen.next)
     assert np.isfinite(nxt).all()
+    for p in range(P):
+        k, a, b = spec[p]
+        if k == 2:
+            assert nxt[:, p].min() >= a and nxt[:, p].max() <= b
+    # a proposal is its parent plus noise of the doubled posterior variance (distributional: Philox stream)
+    d = nxt - theta[parent]
+    assert np.allclose(d.std(axis=0) / np.sqrt(gen.dv.cpu().numpy()), 1.0, atol=0.05)
+
+
+def test_generation_config3_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[2] (N = 1e6, M = 32, P = 16, A = 8, K = K' = 1e5), the configuration the metric is quoted on"""
+    _generation_size_properties(gpu_ctx, oracle, 1_000_000, 32, 16, 100_000, 100_000, 1_000_000, 8, KDE_TOL["auto"])
+
+
+def test_generation_config4_shard_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[3] (10 M x 32 parameters x 64 metrics on 8 GPUs) at the size of one GPU's shard: N = 1.25e6,
+    K = K' = 1.25e5 -- the four-wave LDS-DMA Gram kernel (6 column blocks), two-chunk split-operand weight kernel"""
+    _generation_size_properties(gpu_ctx, oracle, 1_250_000, 64, 32, 125_000, 125_000, 1_250_000, 8, KDE_TOL["auto"])
+
+
+def test_generation_config5_shard_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[4] (1 M x 128 metrics, 32 PLS components on 8 GPUs) at the size of one GPU's shard: N = 1.25e5,
+    K = K' = 12500 -- 144 columns: grouped Gram launches, eight-wave model fit with 32 components"""
+    _generation_size_properties(gpu_ctx, oracle, 125_000, 128, 16, 12_500, 12_500, 125_000, 32, KDE_TOL["auto"])
 
 
 # ---------------------------------------------------------------------------------------------------

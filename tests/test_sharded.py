@@ -11,13 +11,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(backend, tmp_path, port):
-    out = str(tmp_path / ("sharded_%s.json" % backend))
+# BASELINE configs[3] / configs[4] column shapes (64 metrics x 32 parameters, 8 components; 128 metrics, 32 components)
+SHAPES = {"small": "1500,12,5,4,500,300,1000", "config4": "1500,64,32,8,400,300,1200", "config5": "1400,128,16,32,300,250,1000"}
+
+
+def _launch(backend, tmp_path, port, shape="small"):
+    out = str(tmp_path / ("sharded_%s_%s.json" % (backend, shape)))
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out]
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape]]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     return json.load(open(out))
@@ -30,13 +34,15 @@ def _check(res):
     assert res["parent_equal"] and res["seeds_equal"] and res["rng_equal"] and res["next_finite"]
 
 
-def test_sharded_world2_gloo_cpu(tmp_path):
-    _check(_launch("numpy", tmp_path, 29611))
+@pytest.mark.parametrize("shape,port", [("small", 29611), ("config4", 29613)])
+def test_sharded_world2_gloo_cpu(tmp_path, shape, port):
+    _check(_launch("numpy", tmp_path, port, shape))
 
 
 @pytest.mark.gpu
-def test_sharded_world2_gloo_hip(tmp_path):
-    _check(_launch("hip", tmp_path, 29612))
+@pytest.mark.parametrize("shape,port", [("small", 29612), ("config4", 29614), ("config5", 29615)])
+def test_sharded_world2_gloo_hip(tmp_path, shape, port):
+    _check(_launch("hip", tmp_path, port, shape))
 
 
 @pytest.mark.gpu

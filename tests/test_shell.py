@@ -17,6 +17,7 @@ import pytest
 from oracle import pyoracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AbcLogBar = "=" * 89
 LIBDIR = os.path.join(ROOT, "abcsmc_amd")
 
 
@@ -339,6 +340,112 @@ def test_posterior_projection(dice, tmp_path):
     assert run(dice, path, "--process", check=False).returncode == (-204) % 256      # AbcSmc.cpp:382-385
 
 
+def _taus2_state_with_zero_output():
+    """a valid taus2 state whose NEXT output is 0: the three component steps are GF(2)-linear, so solve
+    step1(s1) = step2(s2) ^ step3(s3) for s1 by elimination"""
+    def step(s, a, b, c, d):
+        return (((s & c) << d) & 0xffffffff) ^ ((((s << a) & 0xffffffff) ^ s) >> b)
+    s1f = lambda s: step(s, 13, 19, 4294967294, 12)
+    s2f = lambda s: step(s, 2, 25, 4294967288, 4)
+    s3f = lambda s: step(s, 3, 11, 4294967280, 17)
+    basis = [(s1f(1 << i), 1 << i) for i in range(1, 32)]           # bit 0 of s1 does not reach the output
+    for s3 in range(1000, 1200):
+        s2 = 0x9e3779b9
+        target, comb = s2f(s2) ^ s3f(s3), 0
+        rows = list(basis)
+        for bit in range(31, -1, -1):                                # Gaussian elimination, one pivot per output bit
+            piv = next((r for r in rows if (r[0] >> bit) & 1), None)
+            if piv is None:
+                continue
+            rows = [(r[0] ^ piv[0], r[1] ^ piv[1]) if ((r[0] >> bit) & 1 and r is not piv) else r for r in rows if r is not piv]
+            if (target >> bit) & 1:
+                target ^= piv[0]
+                comb ^= piv[1]
+        if target == 0 and comb >= 2:
+            assert s1f(comb) ^ s2f(s2) ^ s3f(s3) == 0
+            return comb, s2, s3
+    raise AssertionError("no state found")
+
+
+def test_host_gaussian_redraws_a_zero_uniform(probe):
+    """gsl_ran_gaussian draws with gsl_rng_uniform_pos (gauss.c): a taus2 output of exactly 0 is drawn again.  The facade's
+    host ran_gaussian (set-0 sampling of Gaussian priors) must consume the stream the same way: forced here with a state
+    whose next output is 0, against the oracle's restatement"""
+    s1, s2, s3 = _taus2_state_with_zero_output()
+    r = orc.rng(1)
+    r.s1, r.s2, r.s3 = s1, s2, s3
+    probe_first = orc.rng(1)
+    probe_first.s1, probe_first.s2, probe_first.s3 = s1, s2, s3
+    assert orc.rng_get(probe_first) == 0
+    want = [orc.ran_gaussian(r, 2.5) for _ in range(5)]
+    out = run(probe, "--gauss", str(s1), str(s2), str(s3), "2.5", "5").stdout.split("\n")
+    got = [float.fromhex(x) for x in out[:5]]
+    assert got == want
+    assert out[5] == "state %d %d %d" % (r.s1, r.s2, r.s3)
+
+
+def _nrmse(mets, obs):
+    """AbcUtil.cpp:326-345"""
+    sim = mets.mean(axis=0)
+    exp = (np.abs(obs) + np.abs(sim)) / 2.0
+    exp[sim == obs] = 1.0
+    return float(np.sqrt((((sim - obs) / exp) ** 2).mean()))
+
+
+def _median(col):
+    """AbcUtil.cpp:46-62"""
+    v = np.sort(col)
+    n = len(v)
+    return float((v[n // 2 - 1] + v[n // 2]) / 2 if n % 2 == 0 else v[n // 2])
+
+
+def _table_rows(text, title, nrows, ncols_left):
+    """the rows printed under `title` + header line of a filtering report -> list of (pars, mets) float lists"""
+    lines = text.split("\n")
+    i = lines.index(title)
+    out = []
+    for ln in lines[i + 2:i + 2 + nrows]:
+        left, right = ln.split(" | ")
+        out.append(([float(x) for x in left.split()], [float(x) for x in right.split()]))
+        assert len(out[-1][0]) == ncols_left
+    return out
+
+
+def _check_filter_report(text, t, ppars, pmets, obs, prec):
+    """every number of AbcLog::filtering_report (AbcLog.cpp:79-123) against numpy on the same posterior rows"""
+    tol = dict(rel=2 * 10.0 ** (1 - prec), abs=1e-12)
+    lines = text.split("\n")
+    assert "Set %d" % t in lines and "Observed:" in lines
+    obs_row = lines[lines.index("Observed:") + 2].split(" | ")
+    assert obs_row[0].split() == ["---"] * ppars.shape[1]
+    assert [float(x) for x in obs_row[1].split()] == pytest.approx(list(obs), **tol)
+    nr = [l for l in lines if l.startswith("Normalized RMSE for metric means (lower is better):")]
+    assert len(nr) >= 1 and float(nr[0].split(":")[1]) == pytest.approx(_nrmse(pmets, np.asarray(obs, dtype=float)), **tol)
+    (mp, mm), = _table_rows(text, "Posterior means:", 1, ppars.shape[1])
+    assert mp == pytest.approx(list(ppars.mean(axis=0)), **tol) and mm == pytest.approx(list(pmets.mean(axis=0)), **tol)
+    (dp, dm), = _table_rows(text, "Posterior medians:", 1, ppars.shape[1])
+    assert dp == pytest.approx([_median(c) for c in ppars.T], **tol) and dm == pytest.approx([_median(c) for c in pmets.T], **tol)
+    best = _table_rows(text, "Best five:", 5, ppars.shape[1])
+    worst = _table_rows(text, "Worst five:", 5, ppars.shape[1])
+    for q in range(5):
+        assert best[q][0] == pytest.approx(list(ppars[q]), **tol) and best[q][1] == pytest.approx(list(pmets[q]), **tol)
+        k = len(ppars) - 5 + q
+        assert worst[q][0] == pytest.approx(list(ppars[k]), **tol) and worst[q][1] == pytest.approx(list(pmets[k]), **tol)
+
+
+def test_filtering_report_numbers(probe, tmp_path):
+    """AbcLog::filtering_report on hand-made posterior rows (no GPU): observed row, NRMSE, means, medians, best and worst five"""
+    cfg, _ = write_cfg(tmp_path, DICE)
+    K = 12
+    text = run(probe, "--filter-report", cfg, str(K)).stdout
+    i = np.arange(K)[:, None]
+    ppars = np.array([[(ii * 37 + 11 * j) % 101 + 0.25 * j for j in range(2)] for ii in range(K)], dtype=float)
+    pmets = np.array([[40.0 + ((ii * 13 + 7 * j) % 17) * (0.125 if j else 1.0) - 30.0 * j for j in range(2)] for ii in range(K)], dtype=float)
+    header = text.split("\n")[text.split("\n").index("Observed:") + 1]
+    assert header.split() == ["ndice", "sides", "|", "sum", "sd"]
+    _check_filter_report(text, 3, ppars, pmets, [44.0, 2.39925], prec=6)
+
+
 # ---- whole fit on the GPU -----------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_dice_fit_end_to_end(dice, tmp_path):
@@ -350,7 +457,7 @@ def test_dice_fit_end_to_end(dice, tmp_path):
     K = [75, 100, 100, 100]
     assert c.execute("select smcSet, count(*) from job group by smcSet order by smcSet").fetchall() == list(enumerate(sizes))
     assert c.execute("select count(*) from job where status != 'D'").fetchone()[0] == 0
-    err = []
+    err, posts = [], []
     for t, n in enumerate(sizes):
         rows = c.execute("select J.particleIdx, J.posterior, P.seed, ndice, sides, sum, sd from job J, par P, met M where J.serial = P.serial "
                          "and J.serial = M.serial and smcSet = ? order by particleIdx", (t,)).fetchall()
@@ -371,7 +478,29 @@ def test_dice_fit_end_to_end(dice, tmp_path):
             assert [int(r[2]) for r in rows] == [orc.rng_get(g) for _ in range(n)]
         post = mets[[g[1] for g in got]]
         err.append(float(np.abs(post[:, 0] - 44).mean()))
+        posts.append((pars[[g[1] for g in got]], post))
     assert err[-1] < 0.2 * err[0], err            # the posterior closes in on the observed sum
+    # ---- the stderr reports of the run (AbcLog.cpp:24-123), every number re-derived from the database contents ----------
+    # one filtering report per set, printed by the --process that ranked it (reports print with setprecision(5), AbcSmc.cpp:465)
+    chunks = r.stderr.split(AbcLogBar + "\nSet ")
+    assert len(chunks) == 1 + len(sizes)
+    for t in range(len(sizes)):
+        text = "Set " + chunks[t + 1]
+        _check_filter_report(text, t, posts[t][0], posts[t][1], [44.0, 2.39925], prec=5)
+    # convergence data: the last block of the closing --process covers the final set against the one before it
+    conv = r.stderr.split("Convergence data for predictive priors:\n")[-1]
+    tol = dict(rel=2e-4, abs=1e-12)
+    prior_mean, prior_sd = (1000 + 1) / 2.0, (1000 - 1) / math.sqrt(12.0)            # Priors.h:64-67
+    for j, name in enumerate(["number of dice", "number of sides"]):
+        block = conv.split('Par %d: "%s"\n' % (j, name))[1].split("  Par ")[0]
+        nums = [[float(x.rstrip("%")) for x in ln.split("):")[1].replace("(", ",").replace(")", "").split(",")]
+                for ln in block.split("\n") if "( delta, % )" in ln]
+        cur, last = posts[-1][0][:, j], posts[-2][0][:, j]
+        cm, lm, cs, ls = cur.mean(), last.mean(), cur.std(ddof=1), last.std(ddof=1)
+        assert nums[0] == pytest.approx([prior_mean, cm, cm - prior_mean, 100 * (cm - prior_mean) / prior_mean], **tol)   # Prior, current means
+        assert nums[1] == pytest.approx([lm, cm, cm - lm, 100 * (cm - lm) / lm], rel=2e-4, abs=2e-3)                       # Last, current means
+        assert nums[2] == pytest.approx([prior_sd, cs, cs - prior_sd, 100 * (cs - prior_sd) / prior_sd], **tol)            # standard deviations
+        assert nums[3] == pytest.approx([ls, cs, cs - ls, 100 * (cs - ls) / ls], rel=2e-4, abs=2e-3)
     # a finished fit: --process reports and changes nothing
     r = run(dice, cfg, "--process", "--seed", "1")
     assert "Database already contains 4 complete sets." in r.stderr
