@@ -10,6 +10,9 @@ PRIOR_GAUSS, PRIOR_UNIF_INT, PRIOR_UNIF_REAL = 0, 1, 2
 RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
 KDE_AUTO, KDE_FP64 = 0, 1
 KDE_RAN_NONE, KDE_RAN_FP64, KDE_RAN_SPLIT = 0, 1, 2
+DT_F64, DT_I32, DT_I64 = 0, 1, 2
+COMM_ID_BYTES = 128
+COMM_NONE, COMM_RCCL, COMM_CALLBACKS = 0, 1, 2
 
 
 class LibraryMissing(ImportError):
@@ -42,6 +45,24 @@ class GenerationIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "X", "Y", "obs", "priors", "theta_prev", "w_prev", "dv_prev", "idx", "dist", "theta", "w",
         "dv", "L", "next", "parent", "seeds")]
+
+
+class ShardedCfg(C.Structure):
+    _fields_ = [("n_local", C.c_size_t), ("row0", C.c_size_t), ("N_total", C.c_size_t),
+                ("M", C.c_size_t), ("P", C.c_size_t), ("K", C.c_size_t), ("Kp", C.c_size_t),
+                ("nnext_local", C.c_size_t), ("next0", C.c_size_t), ("Nnext_total", C.c_size_t),
+                ("train_frac", C.c_double),
+                ("max_comp", C.c_int32), ("rule", C.c_int32), ("multivariate", C.c_int32), ("reserved", C.c_int32)]
+
+
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class CommCallbacks(C.Structure):
+    _fields_ = [("all_reduce_sum", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN), ("broadcast", BROADCAST_FN),
+                ("user", C.c_void_p)]
 
 
 def make_priors(spec):
@@ -103,6 +124,14 @@ SIGNATURES = {
     "abc_setup_mvn_sampler_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "abc_resample_dev": (_i, [_vp, _vp, _vp, _sz, _u64, _sz, _vp]),
     "abc_perturb_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _u64, _sz, _i, _vp, _vp, _vp, _u64]),
+    "abc_comm_unique_id": (_i, [_vp]),
+    "abc_comm_init_rank": (_i, [_vp, _i, _i, _vp]),
+    "abc_comm_init_callbacks": (_i, [_vp, _i, _i, _vp]),
+    "abc_comm_destroy": (_i, [_vp]),
+    "abc_comm_info": (_i, [_vp, _vp, _vp, _vp]),
+    "abc_ctx_create_multi": (_i, [_vp, _i, _vp]),
+    "abc_generation_sharded_dev": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "abc_generation_multi": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
 }
 
 _LIB = None
@@ -180,10 +209,72 @@ class Context:
         """KDE_AUTO (split-operand matrix-pipe kernel where it applies) or KDE_FP64 (abc_ctx_set_kde_mode)"""
         self.check(lib().abc_ctx_set_kde_mode(self._h, int(mode)))
 
+    # ---- communicator of the row-sharded generation (include/abcsmc_hip.h, "Multi-GPU") ----------------------
+    def comm_init_rccl(self, world, rank, unique_id):
+        """RCCL communicator from the 128-byte id rank 0 obtained with comm_unique_id() and handed to every rank"""
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self.check(lib().abc_comm_init_rank(self._h, int(world), int(rank), buf))
+
+    def comm_init_callbacks(self, world, rank, all_reduce_sum, all_gather, broadcast):
+        """collectives supplied by the caller: python callables (buf_ptr, count, dtype, stream) etc. -> 0 on success"""
+        self._cb = CommCallbacks(ALL_REDUCE_FN(lambda u, b, n, dt, st: int(all_reduce_sum(b, n, dt, st))),
+                                 ALL_GATHER_FN(lambda u, s, r, nb, st: int(all_gather(s, r, nb, st))),
+                                 BROADCAST_FN(lambda u, b, nb, root, st: int(broadcast(b, nb, root, st))), None)
+        self.check(lib().abc_comm_init_callbacks(self._h, int(world), int(rank), C.byref(self._cb)))
+
+    def comm_info(self):
+        k, w, r = C.c_int(0), C.c_int(1), C.c_int(0)
+        self.check(lib().abc_comm_info(self._h, C.byref(k), C.byref(w), C.byref(r)))
+        return k.value, w.value, r.value
+
+    def comm_destroy(self):
+        self.check(lib().abc_comm_destroy(self._h))
+
     def close(self):
         if self._h:
             lib().abc_ctx_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    """128-byte RCCL id (abc_comm_unique_id); created on ONE rank and sent to the others"""
+    buf = (C.c_char * COMM_ID_BYTES)()
+    rc = lib().abc_comm_unique_id(buf)
+    if rc:
+        raise AbcError(rc, "abc_comm_unique_id failed (librccl.so.1 not loadable?)")
+    return bytes(buf)
+
+
+class MultiContext:
+    """ndev contexts of ONE process joined by RCCL communicators (abc_ctx_create_multi)"""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        n = len(self.devices)
+        self._arr = (C.c_void_p * n)()
+        rc = lib().abc_ctx_create_multi((C.c_int * n)(*self.devices), n, self._arr)
+        if rc:
+            raise AbcError(rc, "abc_ctx_create_multi(%r) failed" % (self.devices,))
+
+    def generation(self, cfg, io, rng):
+        """host-pointer generation over all devices (abc_generation_multi); -> ncomp"""
+        nc = C.c_int32(0)
+        rc = lib().abc_generation_multi(self._arr, len(self.devices), C.byref(cfg), C.byref(io), C.byref(rng), C.byref(nc))
+        if rc:
+            raise AbcError(rc, lib().abc_last_error(self._arr[0]).decode())
+        return nc.value
+
+    def close(self):
+        for i in range(len(self.devices)):
+            if self._arr[i]:
+                lib().abc_ctx_destroy(self._arr[i])
+                self._arr[i] = None
 
     def __del__(self):
         try:

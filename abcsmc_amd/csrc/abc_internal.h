@@ -13,7 +13,7 @@
 
 // timed stages (abc_timing_names in api.hip must match)
 enum { ST_GRAM = 0, ST_STATS_REDUCE, ST_PLS_MODEL, ST_PROJECT, ST_SELECT, ST_SORT, ST_GATHER_DV, ST_KDE,
-       ST_WEIGHTS_MISC, ST_MVN, ST_ALIAS_HOST, ST_RESAMPLE, ST_PERTURB, ABC_NSTAGE };
+       ST_WEIGHTS_MISC, ST_MVN, ST_ALIAS_HOST, ST_RESAMPLE, ST_PERTURB, ST_COMM, ABC_NSTAGE };
 
 struct abc_ctx {
     int device;
@@ -43,6 +43,13 @@ struct abc_ctx {
     bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
     int nev;
     struct { hipEvent_t a, b; int stage; } ev[256];
+    // communicator of the row-sharded generation (sharded.hip): none, RCCL or caller-supplied collectives
+    int comm_kind;            // 0 = none (world 1), 1 = RCCL, 2 = callbacks
+    int comm_world, comm_rank;
+    void* comm_nccl;          // ncclComm_t
+    abc_comm_callbacks comm_cb;
+    char* xbuf;               // exchange buffers of the sharded generation (winner lists, packed posterior rows), grown on demand
+    size_t xbuf_bytes;
     double stage_ms[ABC_NSTAGE];
     double stage_host_ms[ABC_NSTAGE];
     long long stage_cnt[ABC_NSTAGE];
@@ -165,7 +172,9 @@ inline size_t abc_kde_slices(size_t kn, size_t Kp, int PP) {
     if (s > 1024) s = 1024;
     return s;
 }
-int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx);
+// osrc (optional): for every output position the flat input position q * len + i it came from
+int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx,
+                      uint64_t* osrc = nullptr);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
 // distributed radix select stages (state: 8 x int64, hist: 2048 x int32, all-reduced by the caller between hist and pick)
 int launch_select_begin(abc_ctx*, uint64_t K, long long* state, int* hist);
@@ -208,6 +217,11 @@ int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, 
 // [GSL] gsl_ran_discrete_preproc on the host (alias_host.cpp, a host-only translation unit built with the host compiler):
 // scratch E: K doubles, smalls / bigs: K + 1 uint32 each
 void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs);
+
+// arena bound shared by api.hip and sharded.hip
+size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext);
+int abc_timing_flush(abc_ctx* ctx);
+void abc_comm_release(abc_ctx* ctx);     // sharded.hip: called by abc_ctx_destroy
 
 // taus2 helpers shared by host code
 void taus2_set(abc_rng* r, unsigned long seed);

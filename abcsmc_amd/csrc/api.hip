@@ -41,7 +41,7 @@ static size_t wx_need(size_t nt, size_t P, size_t A) {
 }
 
 // generous upper bound of the arena needed by any single API call on these sizes
-static size_t ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext) {
+size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext) {
     const size_t C = (M + P + 15) / 16;
     const size_t psz = (C * (C + 1) / 2) * 256 + 16 * C;
     size_t b = 0;
@@ -91,6 +91,8 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->alias_A) (void)hipFree(ctx->alias_A);
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
     if (ctx->kde_which) (void)hipFree(ctx->kde_which);
+    abc_comm_release(ctx);
+    if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -137,7 +139,7 @@ extern "C" int abc_ctx_synchronize(abc_ctx* ctx) {
 
 static const char* const kStageNames[ABC_NSTAGE] = {
     "k_gram", "stats_reduce", "pls_model", "project_distance", "select", "sort_winners", "gather_dv", "k_kde",
-    "weights_misc", "mvn_setup", "alias_host", "resample", "perturb"};
+    "weights_misc", "mvn_setup", "alias_host", "resample", "perturb", "collectives"};
 
 extern "C" int abc_timing_enable(abc_ctx* ctx, int on) {
     if (!ctx) return ABC_ERR_INVALID;
@@ -147,7 +149,7 @@ extern "C" int abc_timing_enable(abc_ctx* ctx, int on) {
     return ABC_OK;
 }
 
-static int timing_flush(abc_ctx* ctx) {
+int abc_timing_flush(abc_ctx* ctx) {
     if (!ctx->nev) return ABC_OK;
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ctx->nev; i++) {
@@ -164,7 +166,7 @@ static int timing_flush(abc_ctx* ctx) {
 extern "C" int abc_timing_read(abc_ctx* ctx, const char** names, double* ms, double* host_ms, long long* count,
                                int max_stages, int reset) {
     if (!ctx) return ABC_ERR_INVALID;
-    ABC_TRY(timing_flush(ctx));
+    ABC_TRY(abc_timing_flush(ctx));
     for (int i = 0; i < ABC_NSTAGE && i < max_stages; i++) {
         if (names) names[i] = kStageNames[i];
         if (ms) ms[i] = ctx->stage_ms[i];
@@ -218,7 +220,7 @@ extern "C" void abc_rng_jump(abc_rng* r, uint64_t n) { taus2_jump(r, n); }
         if (!(ctx)) return ABC_ERR_INVALID;    \
         (ctx)->err[0] = 0;                     \
         if (hipSetDevice((ctx)->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed"); \
-        if ((ctx)->timing && (ctx)->nev > 128) ABC_TRY(timing_flush(ctx)); \
+        if ((ctx)->timing && (ctx)->nev > 128) ABC_TRY(abc_timing_flush(ctx)); \
     } while (0)
 
 static size_t default_A(size_t M, size_t P, int max_comp) {
@@ -239,7 +241,7 @@ extern "C" int abc_stats_accumulate_dev(abc_ctx* ctx, const double* X, const dou
                                         size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
                                         double* stats) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, 1, 0, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, M, P, 1, 0, 0, 0)));
     return launch_stats_accumulate(ctx, X, Y, n, ldx, ldy, M, P, row0, n_train_global, stats);
 }
 
@@ -249,7 +251,7 @@ extern "C" int abc_pls_model_dev(abc_ctx* ctx, const double* stats, const double
     if (rule != ABC_RULE_MIN_PRESS)
         ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "abc_pls_model_dev fits from statistics only: call abc_pls_wilcoxon_dev "
                  "afterwards for rule %d (needs the validation rows)", rule);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, M, P, A, 0, 0, 0)));
     return launch_pls_model(ctx, stats, obs, M, P, A, rule, model);
 }
 
@@ -257,7 +259,7 @@ extern "C" int abc_pls_wilcoxon_dev(abc_ctx* ctx, const double* X, const double*
                                     size_t M, size_t P, size_t A, size_t row_test, double* model) {
     CHECK_CTX(ctx);
     const size_t nt = row_test < n ? n - row_test : 0;
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0) + wx_need(nt, P, A)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, M, P, A, 0, 0, 0) + wx_need(nt, P, A)));
     return launch_wilcoxon(ctx, X, Y, n, ldx, ldy, M, P, A, row_test, model);
 }
 
@@ -279,14 +281,14 @@ extern "C" int abc_model_ncomp(abc_ctx* ctx, const double* model, size_t M, size
 extern "C" int abc_project_distance_dev(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P,
                                         size_t A, const double* model, int simple, double* dist) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, M, P, A, 0, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, M, P, A, 0, 0, 0)));
     return launch_project_distance(ctx, X, n, ldx, M, P, A, model, simple, dist);
 }
 
 extern "C" int abc_select_smallest_dev(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base,
                                        uint64_t* idx, double* dist_out) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, K, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(n, 1, 1, 1, K, 0, 0)));
     return launch_select_smallest(ctx, dist, n, K, idx_base, idx, dist_out);
 }
 
@@ -305,19 +307,19 @@ extern "C" int abc_select_pick_dev(abc_ctx* ctx, int64_t* state, int pass, int32
 }
 extern "C" int abc_select_count_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, int64_t* counts) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, 0, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(n, 1, 1, 1, 0, 0, 0)));
     return launch_select_count(ctx, dist, n, (const long long*)state, (long long*)counts);
 }
 extern "C" int abc_select_compact_dev(abc_ctx* ctx, const double* dist, size_t n, const int64_t* state, uint64_t n_less,
                                       uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, n_less + ties_take, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(n, 1, 1, 1, n_less + ties_take, 0, 0)));
     return launch_select_compact(ctx, dist, n, (const long long*)state, n_less, ties_take, idx_base, idx_out, dist_out);
 }
 
 extern "C" int abc_sort_pairs_dev(abc_ctx* ctx, double* key, uint64_t* idx, size_t n) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(n, 1, 1, 1, n, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(n, 1, 1, 1, n, 0, 0)));
     return launch_sort_pairs(ctx, key, idx, n);
 }
 
@@ -337,7 +339,7 @@ extern "C" int abc_gather_rows_dev(abc_ctx* ctx, const double* Y, size_t n_local
 
 extern "C" int abc_doubled_variance_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* dv) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, P, 0, 1, 0, 0, 0)));     // the moments go through the Gram kernel's partial records
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, P, 0, 1, 0, 0, 0)));     // the moments go through the Gram kernel's partial records
     return launch_doubled_variance(ctx, theta, K, P, dv);
 }
 
@@ -345,7 +347,7 @@ extern "C" int abc_weights_raw_dev(abc_ctx* ctx, const abc_prior* priors, const 
                                    size_t k0, size_t kn, const double* theta_prev, size_t Kp, const double* w_prev,
                                    const double* dv_prev, double* w_raw) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, kn, Kp, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, P, 1, kn, Kp, 0)));
     return launch_weights_raw(ctx, priors, theta, K, P, k0, kn, theta_prev, Kp, w_prev, dv_prev, w_raw);
 }
 
@@ -357,7 +359,7 @@ extern "C" int abc_normalize_l2_dev(abc_ctx* ctx, double* w, size_t K) {
 
 extern "C" int abc_setup_mvn_sampler_dev(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, P, 0, 1, 0, 0, 0)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, P, 0, 1, 0, 0, 0)));
     int st = 0;
     ABC_TRY(launch_mvn_setup(ctx, theta, K, P, L, &st, nullptr));
     if (st) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
@@ -367,7 +369,7 @@ extern "C" int abc_setup_mvn_sampler_dev(abc_ctx* ctx, const double* theta, size
 extern "C" int abc_resample_dev(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                                 uint64_t* parent) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, 1, 1, 0, 0, n)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, 1, 1, 0, 0, n)));
     return launch_resample(ctx, rng, w, K, i0, n, parent);
 }
 
@@ -376,7 +378,7 @@ extern "C" int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* t
                                int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
                                uint64_t seed_stream_offset) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, K, 0, n)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, P, 1, K, 0, n)));
     return launch_perturb(ctx, rng, theta, K, P, priors, parent, i0, n, multivariate, L_or_dv, out, seeds,
                           seed_stream_offset);
 }
@@ -483,7 +485,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
     }
-    if (ctx->timing && ctx->nev > 128) ABC_TRY(timing_flush(ctx));
+    if (ctx->timing && ctx->nev > 128) ABC_TRY(abc_timing_flush(ctx));
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
     return ABC_OK;
 }
@@ -493,7 +495,7 @@ extern "C" int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, c
     CHECK_CTX(ctx);
     if (!cfg || !io || !io->X || !io->obs || !io->idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: null argument");
     const size_t A = default_A(cfg->M, cfg->P, cfg->max_comp);
-    size_t need = ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext);
+    size_t need = abc_ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext);
     if (cfg->rule == ABC_RULE_WILCOXON) need += wx_need(cfg->N, cfg->P, A);
     ABC_TRY(abc_ws_reserve(ctx, need));
     return generation_core(ctx, cfg, io, rng, ncomp_host, 0);
@@ -523,7 +525,7 @@ static int ranking_host(abc_ctx* ctx, const double* X, const double* Y, const do
                         int32_t* ncomp, double* R, double* mean, double* sd, int simple) {
     if (!X || !obs || !idx || (!simple && !Y)) ABC_FAIL(ctx, ABC_ERR_INVALID, "ranking: null argument");
     const size_t A = simple ? 0 : default_A(M, P, max_comp);
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(N, M, P, A, K, 0, 0) + (N * (M + P) + M + 2 * K) * 8 +
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(N, M, P, A, K, 0, 0) + (N * (M + P) + M + 2 * K) * 8 +
                                     ((!simple && rule == ABC_RULE_WILCOXON) ? wx_need(N, P, A) : 0)));
     Stage s{ctx};
     abc_generation_io io;
@@ -598,7 +600,7 @@ extern "C" int abc_weight_predictive_prior(abc_ctx* ctx, const abc_prior* priors
     CHECK_CTX(ctx);
     if (!priors || !theta || !theta_prev || !w_prev || !dv_prev || !w)
         ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: null argument");
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, K, Kp, 0) + ((K + Kp) * (P + 1) + 2 * P) * 8 + P * sizeof(abc_prior)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, P, 1, K, Kp, 0) + ((K + Kp) * (P + 1) + 2 * P) * 8 + P * sizeof(abc_prior)));
     Stage s{ctx};
     abc_prior* dpr = s.up(priors, P);
     double* dth = s.up(theta, K * P);
@@ -617,7 +619,7 @@ extern "C" int abc_weight_predictive_prior(abc_ctx* ctx, const abc_prior* priors
 extern "C" int abc_setup_mvn_sampler(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L) {
     CHECK_CTX(ctx);
     if (!theta || !L) ABC_FAIL(ctx, ABC_ERR_INVALID, "mvn: null argument");
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, P, 0, 1, 0, 0, 0) + (K * P + P * P) * 8));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, P, 0, 1, 0, 0, 0) + (K * P + P * P) * 8));
     Stage s{ctx};
     double* dth = s.up(theta, K * P);
     double* dL = s.dev<double>(P * P);
@@ -632,7 +634,7 @@ extern "C" int abc_setup_mvn_sampler(abc_ctx* ctx, const double* theta, size_t K
 extern "C" int abc_sample_posterior(abc_ctx* ctx, abc_rng* rng, const double* w, size_t K, size_t n, uint64_t* idx) {
     CHECK_CTX(ctx);
     if (!rng || !w || !idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "sample_posterior: null argument");
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, 1, 1, 0, 0, n) + K * 8 + n * 8));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, 1, 1, 0, 0, n) + K * 8 + n * 8));
     Stage s{ctx};
     double* dw = s.up(w, K);
     uint64_t* dp = s.dev<uint64_t>(n);
@@ -647,7 +649,7 @@ static int sample_host(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w, co
                        const abc_prior* priors, const double* L_or_dv, int multivariate, double* out, uint64_t* parent,
                        uint64_t* seeds) {
     if (!rng || !w || !theta || !priors || !L_or_dv || !out) ABC_FAIL(ctx, ABC_ERR_INVALID, "sample: null argument");
-    ABC_TRY(abc_ws_reserve(ctx, ws_need(0, 1, P, 1, K, 0, n) + (K * (P + 1) + P * P + n * (P + 2)) * 8 + P * sizeof(abc_prior)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, P, 1, K, 0, n) + (K * (P + 1) + P * P + n * (P + 2)) * 8 + P * sizeof(abc_prior)));
     Stage s{ctx};
     double* dw = s.up(w, K);
     double* dth = s.up(theta, K * P);

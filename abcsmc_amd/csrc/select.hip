@@ -661,7 +661,8 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
 // (elements of a lower run first), i.e. the result equals a stable sort of the concatenation.
 __global__ __launch_bounds__(256) void k_merge_runs(const double* __restrict__ key, const unsigned long long* __restrict__ idx,
                                                     int W, size_t len, double* __restrict__ okey,
-                                                    unsigned long long* __restrict__ oidx) {
+                                                    unsigned long long* __restrict__ oidx,
+                                                    unsigned long long* __restrict__ osrc /* optional: input position */) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)W * len) return;
     const int q = (int)(t / len);
@@ -699,15 +700,17 @@ __global__ __launch_bounds__(256) void k_merge_runs(const double* __restrict__ k
     }
     okey[pos] = d;
     oidx[pos] = idx[t];
+    if (osrc) osrc[pos] = t;
 }
 
-int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx) {
+int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx,
+                      uint64_t* osrc) {
     if (W < 1) ABC_FAIL(ctx, ABC_ERR_INVALID, "merge: W = %d", W);
     const size_t n = (size_t)W * len;
     if (n == 0) return ABC_OK;
     StageTimer tm(ctx, ST_SORT);
     hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, key,
-                       (const unsigned long long*)idx, W, len, okey, (unsigned long long*)oidx);
+                       (const unsigned long long*)idx, W, len, okey, (unsigned long long*)oidx, (unsigned long long*)osrc);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

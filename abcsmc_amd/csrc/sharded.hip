@@ -1,0 +1,550 @@
+// Row-sharded generation over several GPUs: communicators (RCCL over xGMI, or collectives supplied by the
+// caller) and the protocol of one generation turn-over, in C++ behind the C ABI (include/abcsmc_hip.h, "Multi-GPU").
+// The reference has no device or multi-device path; what is sharded is the per-generation numerical path of
+// AbcSmc::process_database (AbcSmc.cpp:634-664 rank + truncate, :1041-1066 weights, :490-518 proposals, :535 seeds).
+//
+// Exchange steps of one generation (everything else is local to a rank):
+//   1. broadcast of rank 0's pilot shift (16 ceil((M+P)/16) doubles)
+//   2. ONE packed all-reduce of the sufficient-statistics record (counts, column sums, Gram blocks; <= 0.35 MB); the
+//      model fit is then replicated (deterministic: identical on every rank)
+//   3. exact distributed radix select: six all-reduces of a 2048-bin histogram give every rank the global K-th
+//      distance; an all-gather of (#below, #equal) decides how many ties each rank keeps (lowest global rows first)
+//   4. all-gather of the per-rank winner lists (dist, global row), each sorted, padded to the longest; every rank merges
+//      the runs (stable: equal distances keep rank = row order) -> the K selected rows in ascending (distance, row) order
+//   5. all-gather of the winners' parameter rows, packed per rank in its run order; the merge's source map puts them in
+//      rank order (K x P posterior on every rank: the perturbation reads arbitrary parents)
+//   6. all-gather of the per-rank slices of the raw importance weights (pair sums sharded K / G rows per rank)
+//   7. none for resampling / perturbation / seeds: every rank regenerates its slice of the sequential taus2 stream by
+//      jump-ahead.
+// The only host round trip beyond abc_generation_dev's own (alias table, final status) is the 16 G bytes of step 3's
+// counts: the lengths of the exchanged winner lists have to be known to the host that posts the all-gathers.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <thread>
+#include <vector>
+
+#include "abc_internal.h"
+
+namespace {
+
+// ---- RCCL, loaded on first use (the library stays loadable, and single-GPU use needs nothing of it) -------------------
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+Rccl* rccl() {
+    static Rccl R = [] {
+        Rccl r;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
+        if (!r.h) return r;
+#define RCCL_SYM(f) r.f = (decltype(r.f))dlsym(r.h, "nccl" #f)
+        RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommInitAll); RCCL_SYM(CommDestroy); RCCL_SYM(AllReduce);
+        RCCL_SYM(AllGather); RCCL_SYM(Broadcast); RCCL_SYM(GetErrorString);
+#undef RCCL_SYM
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.AllGather && r.Broadcast;
+        return r;
+    }();
+    return &R;
+}
+static_assert(sizeof(ncclUniqueId) == ABC_COMM_ID_BYTES, "ABC_COMM_ID_BYTES must match ncclUniqueId");
+
+#define ABC_NCCL(ctx, call)                                                                                   \
+    do {                                                                                                      \
+        ncclResult_t r_ = (call);                                                                             \
+        if (r_ != ncclSuccess)                                                                                \
+            ABC_FAIL(ctx, ABC_ERR_COMM, "%s:%d %s -> %s", __FILE__, __LINE__, #call,                          \
+                     rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error");                    \
+    } while (0)
+
+// ---- collectives on the context's stream ----------------------------------------------------------------------------------
+int comm_all_reduce(abc_ctx* ctx, void* buf, size_t count, int dtype) {
+    if (ctx->comm_kind == 0 || count == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_COMM);
+    if (ctx->comm_kind == 1) {
+        const ncclDataType_t dt = dtype == ABC_DT_F64 ? ncclFloat64 : dtype == ABC_DT_I32 ? ncclInt32 : ncclInt64;
+        ABC_NCCL(ctx, rccl()->AllReduce(buf, buf, count, dt, ncclSum, (ncclComm_t)ctx->comm_nccl, ctx->stream));
+        return ABC_OK;
+    }
+    if (ctx->comm_cb.all_reduce_sum(ctx->comm_cb.user, buf, count, dtype, (void*)ctx->stream))
+        ABC_FAIL(ctx, ABC_ERR_COMM, "all_reduce callback failed");
+    return ABC_OK;
+}
+int comm_all_gather(abc_ctx* ctx, const void* send, void* recv, size_t bytes) {
+    if (bytes == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_COMM);
+    if (ctx->comm_kind == 0) {
+        if (send != recv) ABC_HIP(ctx, hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABC_OK;
+    }
+    if (ctx->comm_kind == 1) {
+        ABC_NCCL(ctx, rccl()->AllGather(send, recv, bytes, ncclUint8, (ncclComm_t)ctx->comm_nccl, ctx->stream));
+        return ABC_OK;
+    }
+    if (ctx->comm_cb.all_gather(ctx->comm_cb.user, send, recv, bytes, (void*)ctx->stream))
+        ABC_FAIL(ctx, ABC_ERR_COMM, "all_gather callback failed");
+    return ABC_OK;
+}
+int comm_broadcast(abc_ctx* ctx, void* buf, size_t bytes, int root) {
+    if (ctx->comm_kind == 0 || bytes == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_COMM);
+    if (ctx->comm_kind == 1) {
+        ABC_NCCL(ctx, rccl()->Broadcast(buf, buf, bytes, ncclUint8, root, (ncclComm_t)ctx->comm_nccl, ctx->stream));
+        return ABC_OK;
+    }
+    if (ctx->comm_cb.broadcast(ctx->comm_cb.user, buf, bytes, root, (void*)ctx->stream))
+        ABC_FAIL(ctx, ABC_ERR_COMM, "broadcast callback failed");
+    return ABC_OK;
+}
+
+int xbuf_reserve(abc_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->xbuf_bytes) return ABC_OK;
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->xbuf) { ABC_HIP(ctx, hipFree(ctx->xbuf)); ctx->xbuf = nullptr; ctx->xbuf_bytes = 0; }
+    bytes = abc_align(bytes + bytes / 8, 1 << 20);          // some head room: the longest winner list varies from set to set
+    ABC_HIP(ctx, hipMalloc((void**)&ctx->xbuf, bytes));
+    ctx->xbuf_bytes = bytes;
+    return ABC_OK;
+}
+
+// ---- small kernels of the exchange steps ------------------------------------------------------------------------------------
+// winner lists shorter than the longest one are padded with sentinels that sort last
+__global__ __launch_bounds__(256) void k_pad_tail(double* __restrict__ key, unsigned long long* __restrict__ idx, size_t from, size_t to) {
+    const size_t i = from + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < to) { key[i] = INFINITY; idx[i] = 1ull << 62; }
+}
+// theta[k, p] = rows[q][j, p] with src[k] = q * maxw + j: rows holds, per rank q, a column-major maxw x P block of that rank's
+// winners in its run order
+__global__ __launch_bounds__(256) void k_place_rows(const double* __restrict__ rows, const unsigned long long* __restrict__ src,
+                                                    size_t K, int P, size_t maxw, double* __restrict__ theta) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * (size_t)P) return;
+    const size_t k = e % K, p = e / K;
+    const unsigned long long s = src[k];
+    const size_t q = (size_t)(s / maxw), j = (size_t)(s % maxw);
+    theta[k + K * p] = rows[(q * (size_t)P + p) * maxw + j];
+}
+// w[k0_q + i] = slices[q * kmax + i] for i < kn_q  (K = base * W + rem rows split as evenly as possible, low ranks first)
+__global__ __launch_bounds__(256) void k_unpad_slices(const double* __restrict__ slices, size_t K, int W, size_t kmax,
+                                                      double* __restrict__ w) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const size_t base = K / (size_t)W, rem = K % (size_t)W;
+    // rows [0, rem * (base + 1)) belong to the first `rem` ranks (base + 1 rows each), the rest to ranks of `base` rows
+    size_t q, i;
+    if (k < rem * (base + 1)) { q = k / (base + 1); i = k % (base + 1); }
+    else { const size_t t = k - rem * (base + 1); q = rem + (base ? t / base : 0); i = base ? t % base : 0; }
+    w[k] = slices[q * kmax + i];
+}
+
+size_t default_A(size_t M, size_t P, int max_comp) { return (max_comp > 0) ? (size_t)max_comp : (M < P ? M : P); }
+
+}  // namespace
+
+// ---- communicators ------------------------------------------------------------------------------------------------------------
+extern "C" int abc_comm_unique_id(void* id128) {
+    if (!id128) return ABC_ERR_INVALID;
+    if (!rccl()->ok) return ABC_ERR_COMM;
+    ncclUniqueId id;
+    if (rccl()->GetUniqueId(&id) != ncclSuccess) return ABC_ERR_COMM;
+    memcpy(id128, &id, sizeof(id));
+    return ABC_OK;
+}
+
+void abc_comm_release(abc_ctx* ctx) {
+    if (ctx->comm_kind == 1 && ctx->comm_nccl && rccl()->ok) (void)rccl()->CommDestroy((ncclComm_t)ctx->comm_nccl);
+    ctx->comm_nccl = nullptr;
+    ctx->comm_kind = 0;
+    ctx->comm_world = 1;
+    ctx->comm_rank = 0;
+}
+
+extern "C" int abc_comm_destroy(abc_ctx* ctx) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed");
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    abc_comm_release(ctx);
+    return ABC_OK;
+}
+
+extern "C" int abc_comm_init_rank(abc_ctx* ctx, int world, int rank, const void* id128) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !id128) ABC_FAIL(ctx, ABC_ERR_INVALID, "comm: world %d, rank %d", world, rank);
+    if (!rccl()->ok) ABC_FAIL(ctx, ABC_ERR_COMM, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    if (hipSetDevice(ctx->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed");
+    abc_comm_release(ctx);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    ABC_NCCL(ctx, rccl()->CommInitRank(&c, world, id, rank));
+    ctx->comm_nccl = c;
+    ctx->comm_kind = 1;
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return ABC_OK;
+}
+
+extern "C" int abc_comm_init_callbacks(abc_ctx* ctx, int world, int rank, const abc_comm_callbacks* cb) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !cb || !cb->all_reduce_sum || !cb->all_gather || !cb->broadcast)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "comm: world %d, rank %d, or a null callback", world, rank);
+    abc_comm_release(ctx);
+    ctx->comm_cb = *cb;
+    ctx->comm_kind = 2;
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return ABC_OK;
+}
+
+extern "C" int abc_comm_info(const abc_ctx* ctx, int* kind, int* world, int* rank) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (kind) *kind = ctx->comm_kind;
+    if (world) *world = ctx->comm_kind ? ctx->comm_world : 1;
+    if (rank) *rank = ctx->comm_kind ? ctx->comm_rank : 0;
+    return ABC_OK;
+}
+
+extern "C" int abc_ctx_create_multi(const int* devices, int ndev, abc_ctx** out) {
+    if (!devices || !out || ndev < 1) return ABC_ERR_INVALID;
+    for (int i = 0; i < ndev; i++) out[i] = nullptr;
+    if (!rccl()->ok) return ABC_ERR_COMM;
+    for (int i = 0; i < ndev; i++) {
+        const int rc = abc_ctx_create(devices[i], &out[i]);
+        if (rc != ABC_OK) {
+            for (int j = 0; j < i; j++) { abc_ctx_destroy(out[j]); out[j] = nullptr; }
+            return rc;
+        }
+    }
+    std::vector<ncclComm_t> comms((size_t)ndev, nullptr);
+    if (rccl()->CommInitAll(comms.data(), ndev, devices) != ncclSuccess) {
+        for (int j = 0; j < ndev; j++) { abc_ctx_destroy(out[j]); out[j] = nullptr; }
+        return ABC_ERR_COMM;
+    }
+    for (int i = 0; i < ndev; i++) {
+        out[i]->comm_nccl = comms[(size_t)i];
+        out[i]->comm_kind = 1;
+        out[i]->comm_world = ndev;
+        out[i]->comm_rank = i;
+    }
+    return ABC_OK;
+}
+
+// ---- one generation, rows sharded over the communicator ------------------------------------------------------------------------
+extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
+                                          int32_t* ncomp_host) {
+    if (!ctx) return ABC_ERR_INVALID;
+    ctx->err[0] = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed");
+    if (ctx->timing && ctx->nev > 96) ABC_TRY(abc_timing_flush(ctx));
+    if (!cfg || !io || !io->X || !io->Y || !io->obs || !io->idx || !io->w || !rng)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: null argument");
+    const int W = ctx->comm_kind ? ctx->comm_world : 1, r = ctx->comm_kind ? ctx->comm_rank : 0;
+    const size_t n = cfg->n_local, N = cfg->N_total, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->nnext_local;
+    const uint64_t row0 = cfg->row0;
+    if (!N || !M || !P || K == 0 || K > N || row0 + n > N || cfg->next0 + Nn > cfg->Nnext_total)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: bad sizes N=%zu n_local=%zu row0=%zu M=%zu P=%zu K=%zu", N, n, (size_t)row0, M, P, K);
+    if (!(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "training fraction %g outside (0,1]", cfg->train_frac);
+    if (cfg->rule != ABC_RULE_MIN_PRESS && cfg->rule != ABC_RULE_WILCOXON)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "unknown component rule %d", cfg->rule);
+    if (cfg->rule == ABC_RULE_WILCOXON && W > 1)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "the Wilcoxon component rule needs the validation rows on one device");
+    const size_t A = default_A(M, P, cfg->max_comp);
+    const size_t kloc = K < n ? K : n;                       // most winners this rank can hold
+    const size_t kbase = K / (size_t)W, krem = K % (size_t)W, kmax = kbase + (krem ? 1 : 0);
+    const size_t k0 = (size_t)r * kbase + ((size_t)r < krem ? (size_t)r : krem), kn = kbase + ((size_t)r < krem ? 1 : 0);
+
+    size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20);
+    ABC_TRY(abc_ws_reserve(ctx, need));
+    const StatsLayout SL = stats_layout(M, P);
+    const ModelLayout ML = model_layout(M, P, A);
+    double* stats = (double*)abc_ws_alloc(ctx, SL.len * 8);
+    double* model = (double*)abc_ws_alloc(ctx, ML.len * 8);
+    double* dist = (double*)abc_ws_alloc(ctx, (n ? n : 1) * 8);
+    int* spd_dev = (int*)abc_ws_alloc(ctx, sizeof(int));
+    long long* sel_state = (long long*)abc_ws_alloc(ctx, 8 * sizeof(long long));
+    int* sel_hist = (int*)abc_ws_alloc(ctx, 2048 * sizeof(int));
+    long long* counts = (long long*)abc_ws_alloc(ctx, (size_t)(2 + 2 * W) * sizeof(long long));
+    double* w_mine = (double*)abc_ws_alloc(ctx, (kmax ? kmax : 1) * 8);
+    double* w_slices = (double*)abc_ws_alloc(ctx, (size_t)W * (kmax ? kmax : 1) * 8);
+    if (!stats || !model || !dist || !spd_dev || !sel_state || !sel_hist || !counts || !w_mine || !w_slices)
+        ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+    ABC_TRY(abc_pin_reserve(ctx, (size_t)(2 * W) * sizeof(long long) + 64));
+
+    // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
+    const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
+    ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
+    ABC_TRY(comm_broadcast(ctx, stats + SL.off_shift, SL.C16 * 8, 0));
+    ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
+    if (W > 1) {
+        if (r != 0) ABC_HIP(ctx, hipMemsetAsync(stats + SL.off_shift, 0, SL.C16 * 8, ctx->stream));    // the sum keeps rank 0's shift
+        ABC_TRY(comm_all_reduce(ctx, stats, SL.len, ABC_DT_F64));
+    }
+    ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
+    if (cfg->rule == ABC_RULE_WILCOXON)
+        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, (size_t)ntrain, model));
+    ABC_TRY(launch_project_distance(ctx, io->X, n, n, M, P, A, model, 0, dist));
+
+    // ---- 3-5: the K smallest distances of the whole set, their rows ---------------------------------------------------------
+    double* theta = io->theta ? io->theta : (double*)abc_ws_alloc(ctx, K * P * 8);
+    if (!theta) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+    if (W == 1) {
+        ABC_TRY(launch_select_smallest(ctx, dist, n, K, row0, io->idx, io->dist));
+        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, io->idx, K, row0, theta, K));
+    } else {
+        ABC_TRY(launch_select_begin(ctx, K, sel_state, sel_hist));
+        for (int p = 0; p < 6; p++) {
+            ABC_TRY(launch_select_hist(ctx, dist, n, sel_state, p, sel_hist));
+            ABC_TRY(comm_all_reduce(ctx, sel_hist, 2048, ABC_DT_I32));
+            ABC_TRY(launch_select_pick(ctx, sel_state, p, sel_hist, K));
+        }
+        ABC_TRY(launch_select_count(ctx, dist, n, sel_state, counts));
+        ABC_TRY(comm_all_gather(ctx, counts, counts + 2, 2 * sizeof(long long)));
+        long long* hc = (long long*)ctx->pin;
+        ABC_HIP(ctx, hipMemcpyAsync(hc, counts + 2, (size_t)(2 * W) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // ties at the threshold go to the lowest global rows first = to the lowest ranks first (contiguous shards)
+        long long remaining = (long long)K, maxw = 0, my_less = 0, my_take = 0;
+        for (int q = 0; q < W; q++) remaining -= hc[2 * q];
+        if (remaining < 0) ABC_FAIL(ctx, ABC_ERR_COMM, "distributed selection: %lld keys below the K-th", (long long)K - remaining);
+        for (int q = 0; q < W; q++) {
+            const long long tq = hc[2 * q + 1] < remaining ? hc[2 * q + 1] : remaining;
+            remaining -= tq;
+            const long long nwq = hc[2 * q] + tq;
+            if (nwq > maxw) maxw = nwq;
+            if (q == r) { my_less = hc[2 * q]; my_take = tq; }
+        }
+        if (remaining != 0) ABC_FAIL(ctx, ABC_ERR_COMM, "distributed selection: %lld winners missing", remaining);
+        const size_t mw = (size_t)maxw, nw = (size_t)(my_less + my_take), tot = (size_t)W * mw;
+        // exchange buffers: my run (idx, dist), all runs, merged runs + source map, packed rows of mine and of all
+        const size_t xb = (2 * mw + 5 * tot) * 8 + (mw + tot) * P * 8 + 4096;
+        ABC_TRY(xbuf_reserve(ctx, xb));
+        char* xp = ctx->xbuf;
+        auto take = [&](size_t bytes) { char* p0 = xp; xp += abc_align(bytes, 256); return p0; };
+        uint64_t* loc_idx = (uint64_t*)take(mw * 8);
+        double* loc_dist = (double*)take(mw * 8);
+        uint64_t* cand_idx = (uint64_t*)take(tot * 8);
+        double* cand_dist = (double*)take(tot * 8);
+        uint64_t* mrg_idx = (uint64_t*)take(tot * 8);
+        double* mrg_dist = (double*)take(tot * 8);
+        uint64_t* mrg_src = (uint64_t*)take(tot * 8);
+        double* rows_mine = (double*)take(mw * P * 8);
+        double* rows_all = (double*)take(tot * P * 8);
+        if ((size_t)(xp - ctx->xbuf) > ctx->xbuf_bytes) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: exchange buffer");
+        ABC_TRY(launch_select_compact(ctx, dist, n, sel_state, (uint64_t)my_less, (uint64_t)my_take, row0, loc_idx, loc_dist));
+        if (nw > 1) ABC_TRY(launch_sort_pairs(ctx, loc_dist, loc_idx, nw));       // stable: ties stay in row order
+        if (nw < mw)
+            hipLaunchKernelGGL(k_pad_tail, dim3((unsigned)((mw - nw + 255) / 256)), dim3(256), 0, ctx->stream, loc_dist,
+                               (unsigned long long*)loc_idx, nw, mw);
+        ABC_TRY(comm_all_gather(ctx, loc_idx, cand_idx, mw * 8));
+        ABC_TRY(comm_all_gather(ctx, loc_dist, cand_dist, mw * 8));
+        // G sorted runs -> one sequence; equal distances: lower rank (= lower global rows) first
+        ABC_TRY(launch_merge_runs(ctx, cand_dist, cand_idx, W, mw, mrg_dist, mrg_idx, mrg_src));
+        ABC_HIP(ctx, hipMemcpyAsync(io->idx, mrg_idx, K * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (io->dist) ABC_HIP(ctx, hipMemcpyAsync(io->dist, mrg_dist, K * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        // the winners' parameter rows: packed in run order, gathered from every rank, placed by the merge's source map
+        if (nw) ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, loc_idx, nw, row0, rows_mine, mw));
+        ABC_TRY(comm_all_gather(ctx, rows_mine, rows_all, mw * P * 8));
+        hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((K * P + 255) / 256)), dim3(256), 0, ctx->stream, rows_all,
+                           (const unsigned long long*)mrg_src, K, (int)P, mw, theta);
+        ABC_HIP(ctx, hipGetLastError());
+    }
+
+    // ---- doubled variance, importance weights (pair sums: K / G rows per rank) ----------------------------------------------
+    double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
+    double* theta_stats = nullptr;
+    if (P <= 64 && K >= 2) {
+        StageTimer tm(ctx, ST_GATHER_DV);
+        ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats));
+        ABC_TRY(launch_dv_from_stats(ctx, theta_stats, P, dv));
+    } else {
+        ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
+    }
+    if (Kp == 0 || !io->theta_prev) {
+        ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                           // AbcUtil.cpp:543-544
+    } else {
+        if (W == 1) {
+            ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, io->w));
+        } else {
+            if (kn) ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, k0, kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, w_mine));
+            ABC_TRY(comm_all_gather(ctx, w_mine, w_slices, kmax * 8));
+            hipLaunchKernelGGL(k_unpad_slices, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w_slices, K, W, kmax, io->w);
+            ABC_HIP(ctx, hipGetLastError());
+        }
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K));                                    // AbcUtil.cpp:583
+    }
+
+    // ---- proposals for this rank's slice of the next set --------------------------------------------------------------------
+    int spd = 0;
+    bool have_spd = false;
+    if (Nn) {
+        if (!io->next) ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: null proposal buffer");
+        uint64_t* parent = io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8);
+        if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        double* L = nullptr;
+        if (cfg->multivariate) {
+            L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
+            have_spd = true;
+        }
+        abc_perturb_prep prep = {nullptr, 0};
+        struct PrepArg {
+            abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
+            uint64_t i0, seed_off; uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev;
+        };
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, cfg->next0, cfg->Nnext_total, io->seeds, &prep, L, spd_dev};
+        auto hook = [](void* a) -> int {          // GPU work that does not need the alias table runs while the host builds it
+            PrepArg* q = (PrepArg*)a;
+            if (q->L) {
+                if (q->theta_stats) {
+                    StageTimer tm(q->ctx, ST_MVN);
+                    ABC_TRY(launch_mvn_from_stats(q->ctx, q->theta_stats, q->P, q->L, q->spd_dev));
+                } else {
+                    ABC_TRY(launch_mvn_setup(q->ctx, q->theta, q->K, q->P, q->L, nullptr, q->spd_dev));
+                }
+            }
+            return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep);
+        };
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa));
+        ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,
+                               cfg->multivariate ? L : dv, io->next, io->seeds, cfg->Nnext_total, &prep));
+    } else if (cfg->multivariate && io->L) {
+        have_spd = true;
+        if (theta_stats) ABC_TRY(launch_mvn_from_stats(ctx, theta_stats, P, io->L, spd_dev));
+        else ABC_TRY(launch_mvn_setup(ctx, theta, K, P, io->L, nullptr, spd_dev));
+    }
+    taus2_jump(rng, 2 * (uint64_t)cfg->Nnext_total);          // Nnext resampling draws + Nnext seeds of the whole set
+    {
+        double hdr[4] = {0, 0, 0, 0};
+        ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(&spd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
+    }
+    if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
+    return ABC_OK;
+}
+
+// ---- host-pointer generation over several GPUs of one process -------------------------------------------------------------------
+extern "C" int abc_generation_multi(abc_ctx* const* ctxs, int ndev, const abc_generation_cfg* cfg, const abc_generation_io* h,
+                                    abc_rng* rng, int32_t* ncomp) {
+    if (!ctxs || ndev < 1 || !ctxs[0]) return ABC_ERR_INVALID;
+    abc_ctx* c0 = ctxs[0];
+    if (!cfg || !h || !h->X || !h->Y || !h->obs || !h->priors || !h->idx || !h->w || !rng)
+        ABC_FAIL(c0, ABC_ERR_INVALID, "multi-GPU generation: null argument");
+    for (int d = 0; d < ndev; d++)
+        if (!ctxs[d] || (ndev > 1 && (ctxs[d]->comm_kind != 1 || ctxs[d]->comm_world != ndev || ctxs[d]->comm_rank != d)))
+            ABC_FAIL(c0, ABC_ERR_INVALID, "multi-GPU generation: context %d is not rank %d of an %d-rank communicator", d, d, ndev);
+    const size_t N = cfg->N, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->Nnext;
+    if (!N || !M || !P || !K || K > N) ABC_FAIL(c0, ABC_ERR_INVALID, "multi-GPU generation: bad sizes");
+    if (Kp && (!h->theta_prev || !h->w_prev || !h->dv_prev)) ABC_FAIL(c0, ABC_ERR_INVALID, "multi-GPU generation: previous set missing");
+    std::vector<int> rcs((size_t)ndev, ABC_OK);
+    std::vector<int32_t> ncs((size_t)ndev, 0);
+    std::vector<abc_rng> rngs((size_t)ndev, *rng);
+    auto worker = [&](int d) {
+        abc_ctx* ctx = ctxs[d];
+        auto fail = [&](int rc) { rcs[(size_t)d] = rc; };
+        if (hipSetDevice(ctx->device) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipSetDevice failed"); return fail(ABC_ERR_HIP); }
+        // contiguous shards, as even as possible (low ranks first)
+        auto lo = [&](size_t tot, int q) { return tot / (size_t)ndev * (size_t)q + ((size_t)q < tot % (size_t)ndev ? (size_t)q : tot % (size_t)ndev); };
+        const size_t r0 = lo(N, d), n = lo(N, d + 1) - r0, i0 = lo(Nn, d), nn = lo(Nn, d + 1) - i0;
+        // device buffers of this call (freed at the end; the host-pointer path is the convenience, not the fast one)
+        std::vector<void*> bufs;
+        auto dmalloc = [&](size_t bytes) -> void* {
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
+            bufs.push_back(p);
+            return p;
+        };
+        auto cleanup = [&] { (void)hipStreamSynchronize(ctx->stream); for (void* p : bufs) (void)hipFree(p); };
+        double* dX = (double*)dmalloc(n * M * 8);
+        double* dY = (double*)dmalloc(n * P * 8);
+        double* dobs = (double*)dmalloc(M * 8);
+        abc_prior* dpri = (abc_prior*)dmalloc(P * sizeof(abc_prior));
+        double *dtp = nullptr, *dwp = nullptr, *ddvp = nullptr;
+        if (Kp) { dtp = (double*)dmalloc(Kp * P * 8); dwp = (double*)dmalloc(Kp * 8); ddvp = (double*)dmalloc(P * 8); }
+        uint64_t* didx = (uint64_t*)dmalloc(K * 8);
+        double* ddist = (double*)dmalloc(K * 8);
+        double* dth = (double*)dmalloc(K * P * 8);
+        double* dw = (double*)dmalloc(K * 8);
+        double* ddv = (double*)dmalloc(P * 8);
+        double* dL = (double*)dmalloc(P * P * 8);
+        double* dnext = (double*)dmalloc(nn * P * 8);
+        uint64_t* dpar = (uint64_t*)dmalloc(nn * 8);
+        uint64_t* dseed = (uint64_t*)dmalloc(nn * 8);
+        if (!dX || !dY || !dobs || !dpri || (Kp && (!dtp || !dwp || !ddvp)) || !didx || !ddist || !dth || !dw || !ddv || !dL || !dnext ||
+            !dpar || !dseed) {
+            snprintf(ctx->err, sizeof(ctx->err), "multi-GPU generation: device allocation failed");
+            cleanup();
+            return fail(ABC_ERR_NOMEM);
+        }
+        hipStream_t st = ctx->stream;
+        bool ok = true;
+        auto H = [&](hipError_t e) { if (e != hipSuccess && ok) { ok = false; snprintf(ctx->err, sizeof(ctx->err), "multi-GPU generation: %s", hipGetErrorString(e)); } };
+        // a row shard of a column-major host matrix: one strided copy per matrix
+        if (n) {
+            H(hipMemcpy2DAsync(dX, n * 8, h->X + r0, N * 8, n * 8, M, hipMemcpyHostToDevice, st));
+            H(hipMemcpy2DAsync(dY, n * 8, h->Y + r0, N * 8, n * 8, P, hipMemcpyHostToDevice, st));
+        }
+        H(hipMemcpyAsync(dobs, h->obs, M * 8, hipMemcpyHostToDevice, st));
+        H(hipMemcpyAsync(dpri, h->priors, P * sizeof(abc_prior), hipMemcpyHostToDevice, st));
+        if (Kp) {
+            H(hipMemcpyAsync(dtp, h->theta_prev, Kp * P * 8, hipMemcpyHostToDevice, st));
+            H(hipMemcpyAsync(dwp, h->w_prev, Kp * 8, hipMemcpyHostToDevice, st));
+            H(hipMemcpyAsync(ddvp, h->dv_prev, P * 8, hipMemcpyHostToDevice, st));
+        }
+        if (!ok) { cleanup(); return fail(ABC_ERR_HIP); }
+        abc_sharded_cfg sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.n_local = n; sc.row0 = r0; sc.N_total = N; sc.M = M; sc.P = P; sc.K = K; sc.Kp = Kp;
+        sc.nnext_local = nn; sc.next0 = i0; sc.Nnext_total = Nn; sc.train_frac = cfg->train_frac;
+        sc.max_comp = cfg->max_comp; sc.rule = cfg->rule; sc.multivariate = cfg->multivariate;
+        abc_generation_io io;
+        memset(&io, 0, sizeof(io));
+        io.X = dX; io.Y = dY; io.obs = dobs; io.priors = dpri; io.theta_prev = dtp; io.w_prev = dwp; io.dv_prev = ddvp;
+        io.idx = didx; io.dist = ddist; io.theta = dth; io.w = dw; io.dv = ddv; io.L = dL; io.next = dnext; io.parent = dpar; io.seeds = dseed;
+        const int rc = abc_generation_sharded_dev(ctx, &sc, &io, &rngs[(size_t)d], &ncs[(size_t)d]);
+        if (rc != ABC_OK) { cleanup(); return fail(rc); }
+        if (d == 0) {          // replicated outputs: rank 0's copy
+            H(hipMemcpyAsync(h->idx, didx, K * 8, hipMemcpyDeviceToHost, st));
+            if (h->dist) H(hipMemcpyAsync(h->dist, ddist, K * 8, hipMemcpyDeviceToHost, st));
+            if (h->theta) H(hipMemcpyAsync(h->theta, dth, K * P * 8, hipMemcpyDeviceToHost, st));
+            H(hipMemcpyAsync(h->w, dw, K * 8, hipMemcpyDeviceToHost, st));
+            if (h->dv) H(hipMemcpyAsync(h->dv, ddv, P * 8, hipMemcpyDeviceToHost, st));
+            if (h->L && cfg->multivariate) H(hipMemcpyAsync(h->L, dL, P * P * 8, hipMemcpyDeviceToHost, st));
+        }
+        if (nn) {              // this rank's rows of the next set
+            if (h->next) H(hipMemcpy2DAsync(h->next + i0, Nn * 8, dnext, nn * 8, nn * 8, P, hipMemcpyDeviceToHost, st));
+            if (h->parent) H(hipMemcpyAsync(h->parent + i0, dpar, nn * 8, hipMemcpyDeviceToHost, st));
+            if (h->seeds) H(hipMemcpyAsync(h->seeds + i0, dseed, nn * 8, hipMemcpyDeviceToHost, st));
+        }
+        H(hipStreamSynchronize(st));
+        cleanup();
+        if (!ok) return fail(ABC_ERR_HIP);
+    };
+    if (ndev == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < ndev; d++) th.emplace_back(worker, d);
+        for (auto& t : th) t.join();
+    }
+    for (int d = 0; d < ndev; d++)
+        if (rcs[(size_t)d] != ABC_OK) {
+            if (d != 0) snprintf(c0->err, sizeof(c0->err), "device %d: %s", ctxs[d]->device, ctxs[d]->err);
+            return rcs[(size_t)d];
+        }
+    *rng = rngs[0];
+    if (ncomp) *ncomp = ncs[0];
+    return ABC_OK;
+}

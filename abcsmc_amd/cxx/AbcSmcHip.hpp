@@ -637,6 +637,24 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
         if (!posterior_pairs.empty()) {          // already filtered and ranked
             _predictive_prior.push_back(std::vector<size_t>(posterior_pairs.size()));
             for (const auto& pr : posterior_pairs) _predictive_prior.back()[pr.first] = (size_t)pr.second;
+        } else if (ABC::multi_device() && _filtering == ABC::FILTER::PLS) {
+            // several GPUs (ABC::use_devices): rank + truncate + doubled variance + weights of this set in one row-sharded call
+            const size_t K = get_pred_prior_size_at(t);
+            Mat2D prev_post;
+            if (t > 0) prev_post = ABC::select_rows(_particle_parameters[t - 1], _predictive_prior[t - 1]);
+            ABC::RankedSet rs = ABC::rank_and_weight(_particle_metrics[t], _particle_parameters[t], _met_vals, _pls_training_fraction, K,
+                                                     _model_pars, t > 0 ? &prev_post : nullptr, t > 0 ? &_weights[t - 1] : nullptr,
+                                                     t > 0 ? &_doubled_variance[t - 1] : nullptr);
+            _predictive_prior.push_back(rs.idx);
+            AbcLog::filtering_report(this, t, rs.theta, ABC::select_rows(_particle_metrics[t], _predictive_prior[t]), *log_stream);
+            _transaction(db, "recording posterior ranks", [&] {
+                for (size_t i = 0; i < K; i++)
+                    db.exec(std::string("update ") + JOB_TABLE + " set posterior = " + std::to_string(i) + " where serial = " +
+                            std::to_string(serials[t][_predictive_prior[t][i]]) + ";");
+            });
+            _doubled_variance.push_back(rs.doubled_variance);
+            _weights.push_back(rs.weights);
+            continue;
         } else {                                 // rank on the GPU, keep the best K, record the ranks
             switch (_filtering) {
                 case ABC::FILTER::PLS:

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -220,6 +221,56 @@ inline std::vector<abc_prior> to_pod(const std::vector<const Parameter*>& pars) 
     std::vector<abc_prior> p;
     for (const Parameter* q : pars) p.push_back(q->pod());
     return p;
+}
+
+// ---- several GPUs of one node (include/abcsmc_hip.h, "Multi-GPU"; the reference has no multi-device path) ----------
+// use_devices({0, 1, ...}) joins the listed GPUs with RCCL communicators (abc_ctx_create_multi); rank_and_weight() then
+// runs the rank + truncate + doubled variance + weights of one finished set (AbcSmc.cpp:634-664, 1041-1066) with the set's
+// rows sharded over them (abc_generation_multi).  Without it every call below runs on the one default device.
+inline std::vector<abc_ctx*>& multi_contexts() { static std::vector<abc_ctx*> v; return v; }
+inline void use_devices(const std::vector<int>& devices) {
+    for (abc_ctx* c : multi_contexts()) abc_ctx_destroy(c);
+    multi_contexts().clear();
+    if (devices.empty()) return;
+    std::vector<abc_ctx*> v(devices.size(), nullptr);
+    const int rc = abc_ctx_create_multi(devices.data(), (int)devices.size(), v.data());
+    if (rc != ABC_OK) throw HipError(rc, "abc_ctx_create_multi failed (RCCL not loadable, or a listed GPU is not usable)");
+    multi_contexts() = v;
+}
+inline bool multi_device() { return !multi_contexts().empty(); }
+struct RankedSet {
+    std::vector<size_t> idx;      // the K best particles, ascending distance
+    Row dist;                     // their distances
+    Mat2D theta;                  // their parameter rows (K x P)
+    Row weights, doubled_variance;
+    int ncomp = 0;
+};
+inline RankedSet rank_and_weight(const Mat2D& X, const Mat2D& Y, const Row& obs, float_type training_fraction, size_t K,
+                                 const std::vector<const Parameter*>& mpars, const Mat2D* prev_params = nullptr,
+                                 const Row* prev_weights = nullptr, const Row* prev_doubled_variance = nullptr) {
+    if (!multi_device()) throw HipError(ABC_ERR_INVALID, "rank_and_weight: call use_devices() first");
+    const size_t N = X.rows(), M = X.cols(), P = Y.cols();
+    RankedSet out;
+    std::vector<uint64_t> idx(K);
+    out.dist.assign(K, 0.0); out.theta = Mat2D(K, P); out.weights.assign(K, 0.0); out.doubled_variance.assign(P, 0.0);
+    const std::vector<abc_prior> pr = to_pod(mpars);
+    abc_generation_cfg cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.N = N; cfg.M = M; cfg.P = P; cfg.K = K; cfg.Kp = prev_params ? prev_params->rows() : 0; cfg.Nnext = 0;
+    cfg.train_frac = training_fraction; cfg.max_comp = 0; cfg.rule = ABC_RULE_MIN_PRESS; cfg.multivariate = 0;
+    abc_generation_io io;
+    memset(&io, 0, sizeof(io));
+    io.X = X.data(); io.Y = Y.data(); io.obs = obs.data(); io.priors = pr.data();
+    if (prev_params) { io.theta_prev = prev_params->data(); io.w_prev = prev_weights->data(); io.dv_prev = prev_doubled_variance->data(); }
+    io.idx = idx.data(); io.dist = out.dist.data(); io.theta = out.theta.data(); io.w = out.weights.data();
+    io.dv = out.doubled_variance.data();
+    abc_rng unused = {0, 0, 0};
+    int32_t nc = 0;
+    const int rc = abc_generation_multi(multi_contexts().data(), (int)multi_contexts().size(), &cfg, &io, &unused, &nc);
+    if (rc != ABC_OK) throw HipError(rc, abc_last_error(multi_contexts()[0]));
+    out.idx.assign(idx.begin(), idx.end());
+    out.ncomp = nc;
+    return out;
 }
 
 // ---- AbcUtil.h:144-153 ----------------------------------------------------------------------------------

@@ -275,3 +275,98 @@ class ShardedGeneration:
             lib().abc_rng_jump(C.addressof(rng), 2 * self.Nnext)   # Nnext resampling draws + Nnext seeds (host-only call)
         self.ncomp = be.model_ncomp(self.model, M, P, A)
         return self
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same protocol inside the C ABI: abc_generation_sharded_dev (abcsmc_amd/csrc/sharded.hip) with an RCCL
+# communicator, or with the collectives of torch.distributed handed in as callbacks (any backend: the tests run two
+# ranks over gloo on one GPU).  This is the product path of bench.py --gpus N; the Python driver above is the test
+# harness that documents the protocol stage by stage.
+# ---------------------------------------------------------------------------------------------------------------------
+class _DevView:
+    """zero-copy torch view of a raw device buffer (CUDA array interface)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(nbytes),), "typestr": "|u1", "version": 2}
+
+
+def _view(ptr, nbytes, dtype, device):
+    return torch.as_tensor(_DevView(ptr, nbytes), device=device).view(dtype)
+
+
+def attach_torch_distributed(ctx, device, group=None):
+    """abc_comm_init_callbacks over torch.distributed: every collective of the C++ driver is forwarded to the process
+    group (gloo or nccl).  The context must run on torch's current stream (Context.set_stream)."""
+    dev = torch.device(device)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dts = {_lib.DT_F64: (torch.float64, 8), _lib.DT_I32: (torch.int32, 4), _lib.DT_I64: (torch.int64, 8)}
+
+    def all_reduce_sum(buf, count, dtype, stream):
+        t, sz = dts[dtype]
+        dist.all_reduce(_view(buf, count * sz, t, dev), op=dist.ReduceOp.SUM, group=group)
+        return 0
+
+    def all_gather(send, recv, nbytes, stream):
+        dist.all_gather_into_tensor(_view(recv, nbytes * world, torch.uint8, dev), _view(send, nbytes, torch.uint8, dev).clone(),
+                                    group=group)
+        return 0
+
+    def broadcast(buf, nbytes, root, stream):
+        dist.broadcast(_view(buf, nbytes, torch.uint8, dev), src=dist.get_global_rank(group, root) if group is not None else root,
+                       group=group)
+        return 0
+
+    ctx.comm_init_callbacks(world, rank, all_reduce_sum, all_gather, broadcast)
+
+
+def attach_rccl(ctx, device, group=None):
+    """abc_comm_init_rank: the 128-byte RCCL id is created on rank 0 and broadcast through torch.distributed"""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ident = [_lib.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ident, src=0, group=group)
+    ctx.comm_init_rccl(world, rank, ident[0])
+
+
+class CabiShardedGeneration:
+    """abc_generation_sharded_dev with pre-allocated torch buffers; same attributes as ShardedGeneration.
+    The context's communicator decides the world (Context.comm_info); without one it is a single-GPU generation."""
+
+    def __init__(self, ctx, device, n_local, M, P, K, Kp, nnext_local, train_frac=0.5, max_comp=0,
+                 rule=_lib.RULE_MIN_PRESS, multivariate=True, row0=None, N_total=None, next0=None, Nnext_total=None):
+        self.ctx, self.device = ctx, torch.device(device)
+        _, world, rank = ctx.comm_info()
+        self.world, self.rank = world, rank
+        N_total = n_local * world if N_total is None else N_total
+        Nnext_total = nnext_local * world if Nnext_total is None else Nnext_total
+        row0 = rank * n_local if row0 is None else row0
+        next0 = rank * nnext_local if next0 is None else next0
+        self.cfg = _lib.ShardedCfg(n_local, row0, N_total, M, P, K, Kp, nnext_local, next0, Nnext_total, float(train_frac),
+                                   int(max_comp), int(rule), int(bool(multivariate)), 0)
+        f64, i64, d = torch.float64, torch.int64, self.device
+        self.idx = torch.empty(K, dtype=i64, device=d)
+        self.dist = torch.empty(K, dtype=f64, device=d)
+        self.theta = torch.empty((P, K), dtype=f64, device=d)
+        self.w = torch.empty(K, dtype=f64, device=d)
+        self.dv = torch.empty(P, dtype=f64, device=d)
+        self.L = torch.empty((P, P), dtype=f64, device=d)
+        self.next = torch.empty((P, max(nnext_local, 1)), dtype=f64, device=d)
+        self.parent = torch.empty(max(nnext_local, 1), dtype=i64, device=d)
+        self.seeds = torch.empty(max(nnext_local, 1), dtype=i64, device=d)
+        self.ncomp = 0
+
+    def run(self, X, Y, obs, priors, rng, theta_prev=None, w_prev=None, dv_prev=None):
+        cfg = self.cfg
+        assert X.shape == (cfg.M, cfg.n_local) and Y.shape == (cfg.P, cfg.n_local) and X.is_contiguous() and Y.is_contiguous()
+        io = _lib.GenerationIO()
+        io.X, io.Y, io.obs, io.priors = X.data_ptr(), Y.data_ptr(), obs.data_ptr(), priors.data_ptr()
+        if theta_prev is not None and cfg.Kp:
+            io.theta_prev, io.w_prev, io.dv_prev = theta_prev.data_ptr(), w_prev.data_ptr(), dv_prev.data_ptr()
+        io.idx, io.dist, io.theta = self.idx.data_ptr(), self.dist.data_ptr(), self.theta.data_ptr()
+        io.w, io.dv, io.L = self.w.data_ptr(), self.dv.data_ptr(), self.L.data_ptr()
+        io.next, io.parent, io.seeds = self.next.data_ptr(), self.parent.data_ptr(), self.seeds.data_ptr()
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        nc = C.c_int32(0)
+        self.ctx.check(lib().abc_generation_sharded_dev(self.ctx.handle, C.addressof(cfg), C.addressof(io), C.addressof(rng),
+                                                        C.addressof(nc)))
+        self.ncomp = nc.value
+        return self

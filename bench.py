@@ -117,14 +117,32 @@ def main():
 
     ctx = _lib.default_context(local_rank)
     ctx.set_kde_mode(_lib.KDE_FP64 if args.kde_mode == "fp64" else _lib.KDE_AUTO)
+    comm_kind = None
     if world == 1:
         gen = device.Generation(N, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
 
         def step():
             gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
     else:
-        be = sharded.HipBackend(dev, ctx)
-        gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+        # the row-sharded driver inside the C ABI (abc_generation_sharded_dev): RCCL communicator created from an id that
+        # rank 0 broadcasts; if RCCL cannot be initialised from the library, the same C++ driver runs with torch.distributed's
+        # (RCCL) collectives handed in as callbacks -- said loudly and recorded in the JSON line
+        ctx.set_stream(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            sharded.attach_rccl(ctx, dev)
+        except Exception as e:           # noqa: BLE001 -- any failure of the in-library communicator
+            print("bench.py rank %d: in-library RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # the choice is collective: every rank runs the same transport
+        if int(ok.item()) == 1:
+            comm_kind = "rccl (C ABI)"
+        else:
+            if rank == 0:
+                print("bench.py: using torch.distributed collectives as callbacks of the C++ driver", file=sys.stderr)
+            sharded.attach_torch_distributed(ctx, dev)
+            comm_kind = "torch.distributed callbacks"
+        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
 
         def step():
             gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
@@ -263,7 +281,7 @@ def main():
                        "params": P, "pls_components": A, "pred_prior_size": K, "prev_pred_prior_size": Kp,
                        "next_set_size": nn_loc * world, "noise": "MULTIVARIATE", "train_fraction": 0.5,
                        "ncomp_chosen": int(gen.ncomp.value if world == 1 else gen.ncomp),
-                       "parallelism": "row-sharded x%d" % world},
+                       "parallelism": "row-sharded x%d" % world, "collectives": comm_kind},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "roofline_streaming": roofline_streaming,

@@ -38,7 +38,8 @@ typedef enum {
     ABC_ERR_HIP = -2,           /* HIP runtime failure                                        */
     ABC_ERR_NOT_SPD = -3,       /* covariance not positive definite (reference: GSL abort)    */
     ABC_ERR_UNSUPPORTED = -4,   /* size outside what the kernels are built for                */
-    ABC_ERR_NOMEM = -5
+    ABC_ERR_NOMEM = -5,
+    ABC_ERR_COMM = -6           /* RCCL / caller-supplied collective failed, or librccl is missing */
 } abc_status;
 
 /* POD form of the concrete priors in Priors.h:46-110 (likelihood / recast / valid / mean). */
@@ -257,6 +258,62 @@ int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_
                     const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
                     int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
                     uint64_t seed_stream_offset);
+
+/* ======================================================================================== */
+/* Multi-GPU: rows (particles) sharded over several GPUs of one node             */
+/* ======================================================================================== */
+/* The reference has no multi-device path (its MPI farm distributes simulator calls, AbcMPI.cpp:28-143, and is compiled
+ * out); this is the particle sharding BASELINE.json's north_star asks for.  One context per GPU; a communicator is attached
+ * to each context and the sharded entry points below run the same protocol on every rank:
+ *   broadcast of the pilot shift, ONE packed all-reduce of the sufficient statistics (<= 0.35 MB), six all-reduces of a
+ *   2048-bin radix histogram (exact global K-th distance), all-gathers of the per-rank winner lists and of the winners'
+ *   parameter rows, all-gather of the per-rank weight slices; resampling / perturbation need no exchange.
+ * Communicators: RCCL over xGMI (one process per GPU: abc_comm_unique_id + abc_comm_init_rank; or one process driving
+ * several GPUs: abc_ctx_create_multi), or collectives supplied by the caller (abc_comm_init_callbacks: any transport; used
+ * by the tests to run two ranks over gloo on one GPU). */
+#define ABC_COMM_ID_BYTES 128
+enum { ABC_DT_F64 = 0, ABC_DT_I32 = 1, ABC_DT_I64 = 2 };
+/* every callback works on DEVICE buffers, in stream order of `hip_stream`, and returns 0 on success */
+typedef struct {
+    int (*all_reduce_sum)(void* user, void* buf, size_t count, int dtype, void* hip_stream);
+    int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank, void* hip_stream);
+    int (*broadcast)(void* user, void* buf, size_t bytes, int root, void* hip_stream);
+    void* user;
+} abc_comm_callbacks;
+/* rank 0 creates the id and hands its 128 bytes to the other ranks (any channel), then every rank calls init_rank */
+int abc_comm_unique_id(void* id128);
+int abc_comm_init_rank(abc_ctx* ctx, int world, int rank, const void* id128);
+int abc_comm_init_callbacks(abc_ctx* ctx, int world, int rank, const abc_comm_callbacks* cb);
+int abc_comm_destroy(abc_ctx* ctx);
+/* 0 = none, 1 = RCCL, 2 = callbacks; world and rank of the attached communicator (1, 0 without one) */
+int abc_comm_info(const abc_ctx* ctx, int* kind, int* world, int* rank);
+/* one process, ndev GPUs: creates ndev contexts (out[0..ndev)) joined by RCCL communicators (ncclCommInitAll); each is then
+ * driven from its own host thread (abc_generation_multi below does that); destroy every context with abc_ctx_destroy */
+int abc_ctx_create_multi(const int* devices, int ndev, abc_ctx** out);
+
+/* One generation turn-over with the rows of the set sharded over the ranks of ctx's communicator (every rank calls this with
+ * its shard; the call is collective).  Global row g of the set lives on the rank with row0 <= g < row0 + n_local; the next
+ * set's particles [next0, next0 + nnext_local) are proposed by this rank.  io: X, Y are the LOCAL rows (leading dimension
+ * n_local); idx / dist / theta / w / dv / L are replicated outputs (global row numbers in idx); next / parent / seeds
+ * hold this rank's nnext_local proposals (leading dimension nnext_local).  rng: the same state on every rank; advanced by
+ * the 2 Nnext_total draws of the whole generation.  Results equal abc_generation_dev on the unsharded set bit for bit
+ * (indices, parents, seeds) and to rounding of the reduction order (statistics -> model -> distances within 1e-12). */
+typedef struct {
+    size_t n_local, row0, N_total;        /* this rank's rows of the current set                      */
+    size_t M, P;
+    size_t K, Kp;                         /* pred-prior size, previous pred-prior size (0 = set 0)    */
+    size_t nnext_local, next0, Nnext_total;
+    double train_frac;
+    int32_t max_comp, rule, multivariate, reserved;
+} abc_sharded_cfg;
+int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
+                               int32_t* ncomp_host);
+
+/* HOST-pointer generation over the ndev contexts of abc_ctx_create_multi: splits the N rows into contiguous shards, uploads
+ * them, runs abc_generation_sharded_dev on one host thread per GPU and collects the outputs.  Same argument meaning as
+ * abc_generation_cfg / abc_generation_io with HOST pointers (X: N x M, Y: N x P, next: Nnext x P, column-major). */
+int abc_generation_multi(abc_ctx* const* ctxs, int ndev, const abc_generation_cfg* cfg, const abc_generation_io* host_io,
+                         abc_rng* rng, int32_t* ncomp);
 
 #ifdef __cplusplus
 }

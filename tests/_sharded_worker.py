@@ -1,5 +1,6 @@
 """Worker for the world_size-2 tests of the row-sharded generation (launched by torch.distributed.run).
-argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, both ranks on one GPU),
+argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, both ranks on one GPU, stage by stage from
+Python; "cabi" -> the same two ranks through abc_generation_sharded_dev with the gloo collectives handed in as callbacks),
 out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"]."""
 import json
 import os
@@ -39,7 +40,14 @@ def main():
         a = np.asarray(a, dtype=np.float64)
         return torch.from_numpy(np.ascontiguousarray(a.T if a.ndim == 2 else a)).to(dev)
 
-    gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+    if backend == "cabi":
+        ctx = _lib.Context(0)                       # a context of its own: the communicator is attached to it
+        ctx.set_stream(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
+        sharded.attach_torch_distributed(ctx, dev)
+        assert ctx.comm_info() == (_lib.COMM_CALLBACKS, world, rank)
+        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+    else:
+        gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
     rng = _lib.Rng()
     _lib.lib().abc_rng_set(__import__("ctypes").byref(rng), 4242)
     gen.run(cm(X), cm(Y), cm(obs), priors, rng, cm(thp), cm(wp), cm(dvp))

@@ -46,6 +46,76 @@ def test_sharded_world2_gloo_hip(tmp_path, shape, port):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,port", [("small", 29616), ("config4", 29617), ("config5", 29618)])
+def test_sharded_world2_cabi_driver(tmp_path, shape, port):
+    """abc_generation_sharded_dev (the C++ driver behind the C ABI) on two ranks sharing cuda:0, its collectives forwarded to
+    gloo through abc_comm_init_callbacks: the same checks against the single-process oracle as the Python driver"""
+    _check(_launch("cabi", tmp_path, port, shape))
+
+
+@pytest.mark.gpu
+def test_cabi_rccl_world1_and_multi_context(gpu_ctx):
+    """RCCL inside the C ABI on the one GPU of the box: a one-rank communicator from abc_comm_unique_id /
+    abc_comm_init_rank runs every collective of the sharded generation through RCCL, and abc_ctx_create_multi +
+    abc_generation_multi (host pointers, ncclCommInitAll) -- both must reproduce abc_generation_dev bit for bit"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from abcsmc_amd import _lib, abcutil, device, sharded, synthetic
+    N, M, P, K, Kp, Nn, A = 6000, 32, 16, 700, 500, 5000, 8
+    wl = synthetic.Workload(M, P)
+    X, Y = wl.rows(0, N)
+    obs, spec = wl.observed(), wl.prior_spec()
+    thp, wp, dvp = wl.previous_set(Kp)
+    dev = "cuda:0"
+    args = [device.colmajor(a, dev) for a in (X, Y, obs)]
+    pri = device.priors_to_device(_lib.make_priors(spec), dev)
+    prev = [device.colmajor(a, dev) for a in (thp, wp, dvp)]
+    g1 = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, device=dev, ctx=gpu_ctx)
+    r1 = abcutil.rng(5)
+    g1.run(*args, pri, r1, *prev)
+    torch.cuda.synchronize()
+    # (a) one-rank RCCL communicator
+    ctx = _lib.Context(0)
+    ctx.comm_init_rccl(1, 0, _lib.comm_unique_id())
+    assert ctx.comm_info() == (_lib.COMM_RCCL, 1, 0)
+    g2 = sharded.CabiShardedGeneration(ctx, dev, N, M, P, K, Kp, Nn, 0.5, A)
+    r2 = abcutil.rng(5)
+    g2.run(*args, pri, r2, *prev)
+    torch.cuda.synchronize()
+    for a, b in ((g1.idx, g2.idx), (g1.w, g2.w), (g1.dv, g2.dv), (g1.parent, g2.parent), (g1.seeds, g2.seeds),
+                 (g1.next, g2.next), (g1.theta, g2.theta), (g1.L, g2.L)):
+        assert torch.equal(a, b)
+    assert (r1.s1, r1.s2, r1.s3) == (r2.s1, r2.s2, r2.s3) and g2.ncomp == g1.ncomp.value
+    ctx.comm_destroy()
+    assert ctx.comm_info() == (_lib.COMM_NONE, 1, 0)
+    ctx.close()
+    # (b) one process, "several" GPUs (one here), host pointers
+    mc = _lib.MultiContext([0])
+    cfg = _lib.GenerationCfg(N, M, P, K, Kp, Nn, 0.5, A, _lib.RULE_MIN_PRESS, 1, 0)
+    host = dict(idx=np.zeros(K, np.uint64), dist=np.zeros(K), theta=np.zeros((K, P), order="F"), w=np.zeros(K), dv=np.zeros(P),
+                L=np.zeros((P, P), order="F"), next=np.zeros((Nn, P), order="F"), parent=np.zeros(Nn, np.uint64),
+                seeds=np.zeros(Nn, np.uint64))
+    io = _lib.GenerationIO()
+    keep = [np.asfortranarray(X), np.asfortranarray(Y), np.ascontiguousarray(obs), _lib.make_priors(spec),
+            np.asfortranarray(thp), np.ascontiguousarray(wp), np.ascontiguousarray(dvp)]
+    io.X, io.Y, io.obs = (a.ctypes.data for a in keep[:3])
+    io.priors = C.addressof(keep[3])
+    io.theta_prev, io.w_prev, io.dv_prev = (a.ctypes.data for a in keep[4:])
+    for k, v in host.items():
+        setattr(io, k, v.ctypes.data)
+    r3 = abcutil.rng(5)
+    assert mc.generation(cfg, io, r3) == g1.ncomp.value
+    assert np.array_equal(host["idx"], g1.idx.cpu().numpy().astype(np.uint64))
+    assert np.array_equal(host["w"], g1.w.cpu().numpy()) and np.array_equal(host["theta"], device.to_numpy(g1.theta))
+    assert np.array_equal(host["parent"], g1.parent.cpu().numpy().astype(np.uint64))
+    assert np.array_equal(host["seeds"], g1.seeds.cpu().numpy().astype(np.uint64))
+    assert np.array_equal(host["next"], device.to_numpy(g1.next)) and np.array_equal(host["L"], device.to_numpy(g1.L))
+    assert (r3.s1, r3.s2, r3.s3) == (r1.s1, r1.s2, r1.s3)
+    mc.close()
+
+
+@pytest.mark.gpu
 def test_sharded_world1_equals_fused(gpu_ctx):
     import numpy as np
     import torch

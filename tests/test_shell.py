@@ -493,7 +493,7 @@ def test_dice_fit_end_to_end(dice, tmp_path):
     prior_mean, prior_sd = (1000 + 1) / 2.0, (1000 - 1) / math.sqrt(12.0)            # Priors.h:64-67
     for j, name in enumerate(["number of dice", "number of sides"]):
         block = conv.split('Par %d: "%s"\n' % (j, name))[1].split("  Par ")[0]
-        nums = [[float(x.rstrip("%")) for x in ln.split("):")[1].replace("(", ",").replace(")", "").split(",")]
+        nums = [[float(x.strip().rstrip("%")) for x in ln.split("):")[1].replace("(", ",").replace(")", "").split(",")]
                 for ln in block.split("\n") if "( delta, % )" in ln]
         cur, last = posts[-1][0][:, j], posts[-2][0][:, j]
         cm, lm, cs, ls = cur.mean(), last.mean(), cur.std(ddof=1), last.std(ddof=1)
@@ -505,3 +505,19 @@ def test_dice_fit_end_to_end(dice, tmp_path):
     r = run(dice, cfg, "--process", "--seed", "1")
     assert "Database already contains 4 complete sets." in r.stderr
     assert c.execute("select count(*) from job").fetchone()[0] == sum(sizes)
+
+
+@pytest.mark.gpu
+def test_dice_fit_through_the_multi_device_path(dice, tmp_path):
+    """--devices 0: every set is ranked and weighted by abc_generation_multi over the contexts of abc_ctx_create_multi (RCCL
+    communicator, one rank on this box); the database must equal the one the single-context path writes for the same seeds"""
+    dbs = []
+    for tag, extra in (("single", []), ("multi", ["--devices", "0"])):
+        d = tmp_path / tag
+        d.mkdir()
+        cfg, db = write_cfg(d, DICE)
+        run(dice, cfg, "--process", "--simulate", "--all", "--seed", "21", *extra)
+        c = sqlite3.connect(db)
+        dbs.append(c.execute("select J.serial, smcSet, particleIdx, posterior, P.seed, ndice, sides, sum, sd from job J, par P, met M "
+                             "where J.serial = P.serial and J.serial = M.serial order by J.serial").fetchall())
+    assert len(dbs[0]) == 1500 and dbs[0] == dbs[1]
