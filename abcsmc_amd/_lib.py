@@ -13,6 +13,7 @@ KDE_RAN_NONE, KDE_RAN_FP64, KDE_RAN_SPLIT = 0, 1, 2
 DT_F64, DT_I32, DT_I64 = 0, 1, 2
 COMM_ID_BYTES = 128
 COMM_NONE, COMM_RCCL, COMM_CALLBACKS = 0, 1, 2
+NOISE_DEVICE, NOISE_REFERENCE_STREAM = 0, 1
 
 
 class LibraryMissing(ImportError):
@@ -82,6 +83,8 @@ SIGNATURES = {
     "abc_ctx_use_own_stream": (_i, [_vp]),
     "abc_ctx_set_kde_mode": (_i, [_vp, _i]),
     "abc_kde_last_kernel": (_i, [_vp, _vp]),
+    "abc_ctx_set_noise_mode": (_i, [_vp, _i]),
+    "abc_perturb_giveups": (_i, [_vp, _vp, _i]),
     "abc_ctx_synchronize": (_i, [_vp]),
     "abc_version": (_i, []),
     "abc_timing_enable": (_i, [_vp, _i]),
@@ -204,6 +207,17 @@ class Context:
         w = C.c_int(0)
         self.check(lib().abc_kde_last_kernel(self._h, C.byref(w)))
         return w.value
+
+    def set_noise_mode(self, mode):
+        """NOISE_DEVICE (Philox stream on the device, default) or NOISE_REFERENCE_STREAM (the reference's sequential taus2
+        consumption, host loop): abc_ctx_set_noise_mode"""
+        self.check(lib().abc_ctx_set_noise_mode(self._h, int(mode)))
+
+    def perturb_giveups(self, reset=False):
+        """proposals the perturbation gave up on (abc_perturb_giveups)"""
+        n = C.c_uint64(0)
+        self.check(lib().abc_perturb_giveups(self._h, C.byref(n), int(reset)))
+        return n.value
 
     def set_kde_mode(self, mode):
         """KDE_AUTO (split-operand matrix-pipe kernel where it applies) or KDE_FP64 (abc_ctx_set_kde_mode)"""

@@ -39,6 +39,9 @@ struct abc_ctx {
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
     bool timing;
     int kde_mode;  // ABC_KDE_AUTO / ABC_KDE_FP64
+    int noise_mode;  // ABC_NOISE_DEVICE / ABC_NOISE_REFERENCE_STREAM
+    unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
+    unsigned long long giveups_host;   // ... and in the reference-stream host loop
     int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish
     bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
     int nev;
@@ -213,6 +216,11 @@ int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, 
                    const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
                    int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
                    uint64_t seed_stream_offset, const abc_perturb_prep* prep = nullptr);
+
+// reference-stream proposals (host loop, refstream_host.cpp): rng = state after the n resampling draws, advanced past all it consumes
+int launch_perturb_reference(abc_ctx*, abc_rng* rng_after_draws, const double* theta, size_t K, size_t P, const abc_prior* priors,
+                             const uint64_t* parent, size_t n, int multivariate, const double* L_or_dv, double* out,
+                             uint64_t* seeds);
 
 // [GSL] gsl_ran_discrete_preproc on the host (alias_host.cpp, a host-only translation unit built with the host compiler):
 // scratch E: K doubles, smalls / bigs: K + 1 uint32 each

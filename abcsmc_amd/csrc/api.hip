@@ -91,6 +91,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->alias_A) (void)hipFree(ctx->alias_A);
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
     if (ctx->kde_which) (void)hipFree(ctx->kde_which);
+    if (ctx->giveups_dev) (void)hipFree(ctx->giveups_dev);
     abc_comm_release(ctx);
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
@@ -119,6 +120,28 @@ extern "C" int abc_ctx_set_kde_mode(abc_ctx* ctx, int mode) {
     if (!ctx) return ABC_ERR_INVALID;
     if (mode != ABC_KDE_AUTO && mode != ABC_KDE_FP64) ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_kde_mode: unknown mode %d", mode);
     ctx->kde_mode = mode;
+    return ABC_OK;
+}
+
+extern "C" int abc_ctx_set_noise_mode(abc_ctx* ctx, int mode) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (mode != ABC_NOISE_DEVICE && mode != ABC_NOISE_REFERENCE_STREAM)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_noise_mode: unknown mode %d", mode);
+    ctx->noise_mode = mode;
+    return ABC_OK;
+}
+
+extern "C" int abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset) {
+    if (!ctx || !count) return ABC_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) ABC_FAIL(ctx, ABC_ERR_HIP, "hipSetDevice failed");
+    unsigned long long dev = 0;
+    if (ctx->giveups_dev) {
+        ABC_HIP(ctx, hipMemcpyAsync(&dev, ctx->giveups_dev, sizeof(dev), hipMemcpyDeviceToHost, ctx->stream));
+        if (reset) ABC_HIP(ctx, hipMemsetAsync(ctx->giveups_dev, 0, sizeof(dev), ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *count = (uint64_t)dev + (uint64_t)ctx->giveups_host;
+    if (reset) ctx->giveups_host = 0;
     return ABC_OK;
 }
 
@@ -378,6 +401,9 @@ extern "C" int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* t
                                int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,
                                uint64_t seed_stream_offset) {
     CHECK_CTX(ctx);
+    if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "abc_perturb_dev works on row slices; the reference stream is sequential over the whole "
+                 "set (use abc_sample_*_predictive_priors or abc_generation_dev)");
     ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, P, 1, K, 0, n)));
     return launch_perturb(ctx, rng, theta, K, P, priors, parent, i0, n, multivariate, L_or_dv, out, seeds,
                           seed_stream_offset);
@@ -471,12 +497,19 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                     ABC_TRY(launch_mvn_setup(q->ctx, q->theta, q->K, q->P, q->L, nullptr, q->spd_dev));
                 }
             }
+            if (q->ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) return ABC_OK;     // nothing of the device stream is needed
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep);
         };
         ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa));
-        ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, 0, Nn, cfg->multivariate,
-                               cfg->multivariate ? L : dv, io->next, io->seeds, Nn, &prep));
-        taus2_jump(rng, 2 * (uint64_t)Nn);   // Nnext resampling draws + Nnext seeds
+        if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {
+            taus2_jump(rng, (uint64_t)Nn);   // the Nnext resampling draws; the host loop consumes the rest as the reference does
+            ABC_TRY(launch_perturb_reference(ctx, rng, theta, K, P, io->priors, parent, Nn, cfg->multivariate,
+                                             cfg->multivariate ? L : dv, io->next, io->seeds));
+        } else {
+            ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, 0, Nn, cfg->multivariate,
+                                   cfg->multivariate ? L : dv, io->next, io->seeds, Nn, &prep));
+            taus2_jump(rng, 2 * (uint64_t)Nn);   // Nnext resampling draws + Nnext seeds
+        }
     }
     {
         double hdr[4] = {0, 0, 0, 0};
@@ -660,12 +693,17 @@ static int sample_host(abc_ctx* ctx, abc_rng* rng, size_t n, const double* w, co
     uint64_t* dseed = seeds ? s.dev<uint64_t>(n) : nullptr;
     if (!dw || !dth || !dpr || !dl || !dout || !dpar) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sample: workspace exhausted");
     ABC_TRY(launch_resample(ctx, rng, dw, K, 0, n, dpar));
-    ABC_TRY(launch_perturb(ctx, rng, dth, K, P, dpr, dpar, 0, n, multivariate, dl, dout, dseed, n));
+    if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {
+        taus2_jump(rng, (uint64_t)n);
+        ABC_TRY(launch_perturb_reference(ctx, rng, dth, K, P, dpr, dpar, n, multivariate, dl, dout, dseed));
+    } else {
+        ABC_TRY(launch_perturb(ctx, rng, dth, K, P, dpr, dpar, 0, n, multivariate, dl, dout, dseed, n));
+        taus2_jump(rng, seeds ? 2 * (uint64_t)n : (uint64_t)n);
+    }
     s.down(out, dout, n * P);
     s.down(parent, dpar, n);
     s.down(seeds, dseed, n);
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    taus2_jump(rng, seeds ? 2 * (uint64_t)n : (uint64_t)n);
     return ABC_OK;
 }
 

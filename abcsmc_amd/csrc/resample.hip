@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "abc_internal.h"
+#include "refstream_host.h"
 
 // ------------------------------------------------------------------------------------------------
 // taus2 (host): [GSL] rng/taus.c
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
                                                  const abc_prior* __restrict__ priors,
                                                  const unsigned long long* __restrict__ parent,
                                                  unsigned long long i0, size_t n,
-                                                 const double* __restrict__ L_or_dv, double* __restrict__ out) {
+                                                 const double* __restrict__ L_or_dv, double* __restrict__ out,
+                                                 unsigned long long* __restrict__ giveups) {
     __shared__ double sL[PP * PP];     // MV: lower-triangular factor (column-major, zero above the diagonal);
                                        // otherwise sqrt(dv) on the diagonal (AbcUtil.cpp:150)
     __shared__ abc_prior sp[PP];
@@ -269,7 +271,8 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
             if (ok) break;
             if (attempt + 1 == MVN_MAX_TRIES) {
 #pragma unroll
-                for (int p = 0; p < PP; p++) val[p] = mu[p];   // give up: keep the (valid) parent
+                for (int p = 0; p < PP; p++) val[p] = mu[p];   // give up: keep the (valid) parent, and say so (abc_perturb_giveups)
+                atomicAdd(giveups, 1ull);
             }
         }
     } else {
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
                     ok = d_valid(sp[p], v);
                 }
                 val[p] = ok ? v : d_prior_mean(sp[p]);
+                if (!ok) atomicAdd(giveups, 1ull);       // the reference prints an error line per fallback (Priors.h:27-29)
             }
         }
     }
@@ -303,7 +307,8 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
                                                         const abc_prior* __restrict__ priors,
                                                         const unsigned long long* __restrict__ parent,
                                                         unsigned long long i0, size_t n,
-                                                        const double* __restrict__ L_or_dv, double* __restrict__ out) {
+                                                        const double* __restrict__ L_or_dv, double* __restrict__ out,
+                                                        unsigned long long* __restrict__ giveups) {
     extern __shared__ double smem[];
     double* sL = smem;                                  // MV: PP x PP, column-major, zero above the diagonal
     abc_prior* sp = reinterpret_cast<abc_prior*>(smem + (MV ? PP * PP : PP));
@@ -351,8 +356,10 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
                 }
             }
         }
-        if (!ok)
+        if (!ok) {
             for (int p = 0; p < P; p++) out[i + n * (size_t)p] = mu[p];      // give up: keep the (valid) parent
+            atomicAdd(giveups, 1ull);
+        }
     } else {
         for (int p = 0; p < P; p++) {
             const double m = mu[p];
@@ -365,6 +372,7 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
                 ok = d_valid(sp[p], v);
             }
             out[i + n * (size_t)p] = ok ? v : d_prior_mean(sp[p]);
+            if (!ok) atomicAdd(giveups, 1ull);
         }
     }
 }
@@ -495,6 +503,10 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 64", P);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
+    if (!ctx->giveups_dev) {
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, sizeof(unsigned long long)));
+        ABC_HIP(ctx, hipMemsetAsync(ctx->giveups_dev, 0, sizeof(unsigned long long), ctx->stream));
+    }
     StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     double* rows = (prep && prep->rows) ? prep->rows : (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
@@ -505,10 +517,10 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     do {                                                                                                               \
         if (multivariate)                                                                                              \
             hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
-                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);   \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out, ctx->giveups_dev);   \
         else                                                                                                           \
             hipLaunchKernelGGL((k_perturb<PPV, false>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
-                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);   \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out, ctx->giveups_dev);   \
     } while (0)
     switch (PP) {
         case 2: LAUNCH_PT(2); break;
@@ -520,16 +532,50 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
             if (multivariate) {
                 const size_t lds = (64 * 64) * sizeof(double) + 64 * sizeof(abc_prior);
                 hipLaunchKernelGGL((k_perturb_stream<64, true>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
-                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);
+                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,
+                                   ctx->giveups_dev);
             } else {
                 const size_t lds = 64 * sizeof(double) + 64 * sizeof(abc_prior);
                 hipLaunchKernelGGL((k_perturb_stream<64, false>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
-                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out);
+                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,
+                                   ctx->giveups_dev);
             }
         } break;
     }
 #undef LAUNCH_PT
     ABC_HIP(ctx, hipGetLastError());
     if (seeds && !(prep && prep->seeds_done)) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset));
+    return ABC_OK;
+}
+
+// ---- reference-stream proposals (abc_ctx_set_noise_mode): everything the host loop needs comes down, the proposals go back up
+int launch_perturb_reference(abc_ctx* ctx, abc_rng* rng_after_draws, const double* theta, size_t K, size_t P,
+                             const abc_prior* priors, const uint64_t* parent, size_t n, int multivariate, const double* L_or_dv,
+                             double* out, uint64_t* seeds) {
+    if (n == 0) return ABC_OK;
+    StageTimer tm(ctx, ST_PERTURB);
+    std::vector<double> hth(K * P), hl(multivariate ? P * P : P), hout(n * P);
+    std::vector<uint64_t> hpar(n), hseeds(seeds ? n : 0);
+    std::vector<abc_prior> hpr(P);
+    ABC_HIP(ctx, hipMemcpyAsync(hth.data(), theta, hth.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipMemcpyAsync(hl.data(), L_or_dv, hl.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipMemcpyAsync(hpar.data(), parent, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipMemcpyAsync(hpr.data(), priors, P * sizeof(abc_prior), hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (multivariate) {
+        for (size_t a = 0; a < P; a++)           // the factor as gsl_linalg_cholesky_decomp1 leaves it has covariance entries above
+            for (size_t b = a + 1; b < P; b++) hl[a + P * b] = 0.0;      // the diagonal: dtrmv(Lower) never reads them; neither do we
+        ctx->giveups_host += abc_ref_perturb_mvn(rng_after_draws, n, K, P, hth.data(), hpar.data(), hl.data(), hpr.data(),
+                                                 MVN_MAX_TRIES, hout.data());
+    } else {
+        ctx->giveups_host += abc_ref_perturb_indep(rng_after_draws, n, K, P, hth.data(), hpar.data(), hl.data(), hpr.data(),
+                                                   hout.data());
+    }
+    if (seeds) abc_ref_seeds(rng_after_draws, n, hseeds.data());
+    ctx->stage_host_ms[ST_PERTURB] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ABC_HIP(ctx, hipMemcpyAsync(out, hout.data(), hout.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (seeds) ABC_HIP(ctx, hipMemcpyAsync(seeds, hseeds.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the host vectors go out of scope
     return ABC_OK;
 }

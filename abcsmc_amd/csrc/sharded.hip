@@ -259,6 +259,8 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         ABC_FAIL(ctx, ABC_ERR_INVALID, "training fraction %g outside (0,1]", cfg->train_frac);
     if (cfg->rule != ABC_RULE_MIN_PRESS && cfg->rule != ABC_RULE_WILCOXON)
         ABC_FAIL(ctx, ABC_ERR_INVALID, "unknown component rule %d", cfg->rule);
+    if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "the reference noise stream is sequential over the whole set: not available to the sharded generation");
     if (cfg->rule == ABC_RULE_WILCOXON && W > 1)
         ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "the Wilcoxon component rule needs the validation rows on one device");
     const size_t A = default_A(M, P, cfg->max_comp);

@@ -217,6 +217,14 @@ inline abc_ctx* context() {
     return ctx;
 }
 inline void check(int rc) { if (rc != ABC_OK) throw HipError(rc, abc_last_error(context())); }
+// Proposals from the reference's own sequential taus2 stream (abc_ctx_set_noise_mode): values, seeds and the final RNG state
+// of sample_*_predictive_priors then equal a CPU run of the reference bit for bit; default off (device Philox stream).
+inline void set_reference_stream(bool on) { check(abc_ctx_set_noise_mode(context(), on ? ABC_NOISE_REFERENCE_STREAM : ABC_NOISE_DEVICE)); }
+inline uint64_t perturb_giveups(bool reset = false) {
+    uint64_t n = 0;
+    check(abc_perturb_giveups(context(), &n, reset ? 1 : 0));
+    return n;
+}
 inline std::vector<abc_prior> to_pod(const std::vector<const Parameter*>& pars) {
     std::vector<abc_prior> p;
     for (const Parameter* q : pars) p.push_back(q->pod());

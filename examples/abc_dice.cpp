@@ -30,7 +30,7 @@ static std::vector<double> simulator(std::vector<double> parameters, const unsig
 static void usage() {
     std::cerr << "\n\tUsage: ./abc_dice config.json --process\n\n"
               << "\t       ./abc_dice config.json --simulate [-n <simulations per database write>]\n\n"
-              << "\t       ./abc_dice config.json --process --simulate [-n <...>] [--all] [--seed <s>] [--configured-simulator] [--devices 0,1,...]\n\n";
+              << "\t       ./abc_dice config.json --process --simulate [-n <...>] [--all] [--seed <s>] [--configured-simulator] [--devices 0,1,...] [--reference-stream]\n\n";
 }
 
 int main(int argc, char* argv[]) {
@@ -39,12 +39,14 @@ int main(int argc, char* argv[]) {
     unsigned long seed = 0;
     int buffer_size = 1;
     std::vector<int> devices;
+    bool reference_stream = false;
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--process")) process_db = true;
         else if (!strcmp(argv[i], "--simulate")) simulate_db = true;
         else if (!strcmp(argv[i], "--all")) do_all = true;
         else if (!strcmp(argv[i], "--configured-simulator")) configured = true;   // use the "shared" / "executable" of the configuration
         else if (!strcmp(argv[i], "-n") && i + 1 < argc) buffer_size = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--reference-stream")) reference_stream = true;   // proposals from the reference's own taus2 stream
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {              // e.g. --devices 0,1,2,3: rows sharded over these GPUs
             for (char* tok = strtok(argv[++i], ","); tok; tok = strtok(nullptr, ",")) devices.push_back(atoi(tok));
         }
@@ -55,6 +57,7 @@ int main(int argc, char* argv[]) {
     abc->parse_config(argv[1]);
     try {
         if (!devices.empty()) ABC::use_devices(devices);
+        if (reference_stream && process_db) ABC::set_reference_stream(true);
     } catch (const ABC::HipError& e) {
         std::cerr << "abc_dice: " << e.what() << std::endl;
         return 3;

@@ -79,6 +79,21 @@ int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
 /* Which of the two kernels produced the pair sums of the most recent weight call on this context (synchronises). */
 enum { ABC_KDE_RAN_NONE = 0, ABC_KDE_RAN_FP64 = 1, ABC_KDE_RAN_SPLIT = 2 };
 int  abc_kde_last_kernel(abc_ctx* ctx, int* which);
+/* Which stream the Gaussian noise of the proposals comes from (sample_*_predictive_priors, abc_generation_dev).
+ * ABC_NOISE_DEVICE (default): counter-based Philox stream keyed by (rng state, draw, attempt), evaluated on the device -- same
+ *   distribution as the reference, different numbers; the simulator seeds are the taus2 outputs right after the resampling draws.
+ * ABC_NOISE_REFERENCE_STREAM: the shared taus2 stream consumed EXACTLY as the reference does (AbcUtil.cpp:122-158,
+ *   Priors.h:19-43: polar Box-Muller on gsl_rng_uniform_pos per coordinate, whole-vector / per-coordinate rejection, then one
+ *   gsl_rng_get per row for the seeds, AbcSmc.cpp:535): proposals, seeds and the final rng state equal a CPU run of the
+ *   reference bit for bit.  Inherently sequential -- a host loop inside the library, ~50 ns per normal; not available to the
+ *   row-sliced entry points (abc_perturb_dev, abc_generation_sharded_dev). */
+enum { ABC_NOISE_DEVICE = 0, ABC_NOISE_REFERENCE_STREAM = 1 };
+int  abc_ctx_set_noise_mode(abc_ctx* ctx, int mode);
+/* Proposals the perturbation gave up on since the context was created (or since the last reset): multivariate rows whose
+ * 16384 whole-vector draws were all rejected (the valid parent is emitted; the reference would retry for ever,
+ * AbcUtil.cpp:132) plus independent-noise coordinates that fell back to the prior mean after 1000 tries (the reference prints
+ * an error line per fallback, Priors.h:27-29).  Synchronises. */
+int  abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
  * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]

@@ -535,6 +535,97 @@ def test_sample_predictive_priors_independent(gpu_ctx, oracle):
         assert abs(out[:, p].std() / oout[:, p].std() - 1) < 0.02
 
 
+class _noise_mode:
+    def __init__(self, ctx, mode):
+        self.ctx, self.mode = ctx, mode
+
+    def __enter__(self):
+        self.ctx.set_noise_mode(self.mode)
+
+    def __exit__(self, *a):
+        from abcsmc_amd import _lib
+        self.ctx.set_noise_mode(_lib.NOISE_DEVICE)
+
+
+@pytest.mark.parametrize("multivariate", [True, False])
+def test_reference_stream_proposals_bit_exact(gpu_ctx, oracle, multivariate):
+    """ABC_NOISE_REFERENCE_STREAM: the proposals consume the taus2 stream exactly as the reference does (polar Box-Muller per
+    coordinate on uniform_pos draws, whole-vector / per-coordinate rejection, AbcUtil.cpp:122-158, Priors.h:19-43), the seeds
+    follow the noise (AbcSmc.cpp:535): values, parents, seeds and the final rng state equal the oracle's bit for bit.
+    Narrow priors make rejections (data-dependent consumption) frequent."""
+    from abcsmc_amd import abcutil, _lib
+    g = np.random.default_rng(31)
+    K, P, n = 257, 5, 6000
+    th = np.column_stack([g.normal(5, 1, K), np.round(g.uniform(3, 18, K)), g.uniform(0.3, 0.7, K), g.normal(0, 2, K),
+                          g.normal(-3, 0.5, K)])
+    spec = [(_lib.PRIOR_GAUSS, 5.0, 3.0), (_lib.PRIOR_UNIF_INT, 1, 20), (_lib.PRIOR_UNIF_REAL, 0.25, 0.75),
+            (_lib.PRIOR_GAUSS, 0.0, 10.0), (_lib.PRIOR_UNIF_REAL, -4.2, -1.5)]
+    w = g.random(K)
+    rc, L, _ = oracle.mvn_setup(th)                       # one factor for both sides: this test is about the stream
+    assert rc == 0
+    dv = oracle.doubled_variance(th)
+    r, o = abcutil.rng(1234), oracle.rng(1234)
+    with _noise_mode(gpu_ctx, _lib.NOISE_REFERENCE_STREAM):
+        if multivariate:
+            out, parent, seeds = abcutil.sample_mvn_predictive_priors(r, n, w, th, _lib.make_priors(spec), L, seeds=True, ctx=gpu_ctx)
+            oout, opar, rej = oracle.sample_mvn_predictive_priors(o, n, w, th, oracle.make_priors(spec), L)
+        else:
+            out, parent, seeds = abcutil.sample_predictive_priors(r, n, w, th, _lib.make_priors(spec), dv, seeds=True, ctx=gpu_ctx)
+            oout, opar, rej = oracle.sample_predictive_priors(o, n, w, th, oracle.make_priors(spec), dv)
+    oseeds = np.array([oracle.rng_get(o) for _ in range(n)], dtype=np.uint64)
+    assert np.array_equal(parent, opar)
+    assert np.array_equal(out, oout)                      # bit for bit
+    assert np.array_equal(seeds, oseeds)
+    assert (r.s1, r.s2, r.s3) == (o.s1, o.s2, o.s3)
+    if multivariate:
+        assert rej > 100                                  # the stream position really was data dependent
+    # the default mode is untouched: same parents, different (Philox) noise
+    r2 = abcutil.rng(1234)
+    out2, parent2 = abcutil.sample_mvn_predictive_priors(r2, n, w, th, _lib.make_priors(spec), L, ctx=gpu_ctx)[:2]
+    assert np.array_equal(parent2, opar) and not np.array_equal(out2, oout)
+
+
+def test_reference_stream_generation(gpu_ctx, oracle):
+    """abc_generation_dev in reference-stream mode against oracle.generation: selection, parents, seeds and the rng state bit
+    for bit; the proposals to the rounding of the covariance factor (the device's reduction order differs from the
+    oracle's in the last bits; integer-valued priors would make them identical, see the dice fit in tests/test_shell.py)"""
+    import torch
+    from abcsmc_amd import abcutil, device, _lib
+    N, M, P, K, Kp, Nn, A = 3000, 12, 5, 300, 250, 2500, 4
+    wl, X, Y, obs = _wl(M, P, N, 99)
+    spec = wl.prior_spec()
+    prev = wl.previous_set(Kp)
+    dev = "cuda:0"
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, multivariate=True, device=dev, ctx=gpu_ctx)
+    r, o = abcutil.rng(77), oracle.rng(77)
+    with _noise_mode(gpu_ctx, _lib.NOISE_REFERENCE_STREAM):
+        gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev),
+                device.priors_to_device(_lib.make_priors(spec), dev), r, *(device.colmajor(a, dev) for a in prev))
+        torch.cuda.synchronize()
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A, multivariate=True)
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    assert np.array_equal(gen.seeds.cpu().numpy().astype(np.uint64), ref["seeds"])
+    assert (r.s1, r.s2, r.s3) == (o.s1, o.s2, o.s3)
+    assert np.allclose(device.to_numpy(gen.next), ref["next"], rtol=1e-9, atol=0)
+    assert gpu_ctx.perturb_giveups() == 0
+
+
+def test_perturb_giveups_are_counted(gpu_ctx):
+    """a prior so narrow that no proposal can land in it: the device emits the (valid) parent after 16384 whole-vector
+    rejections and says so through abc_perturb_giveups (the reference would never return, AbcUtil.cpp:132)"""
+    from abcsmc_amd import abcutil, _lib
+    K, n = 16, 40
+    th = np.column_stack([np.full(K, 0.5), np.linspace(-1, 1, K)])
+    spec = [(_lib.PRIOR_UNIF_REAL, 0.5, 0.5 + 1e-300), (_lib.PRIOR_GAUSS, 0.0, 5.0)]
+    L = np.asfortranarray(np.array([[1.0, 0.0], [0.0, 1.0]]))
+    gpu_ctx.perturb_giveups(reset=True)
+    out, parent = abcutil.sample_mvn_predictive_priors(abcutil.rng(3), n, np.full(K, 1.0 / K), th, _lib.make_priors(spec), L, ctx=gpu_ctx)[:2]
+    assert gpu_ctx.perturb_giveups() == n
+    assert np.array_equal(out, th[parent.astype(int)])
+    assert gpu_ctx.perturb_giveups(reset=True) == n and gpu_ctx.perturb_giveups() == 0
+
+
 @pytest.mark.parametrize("multivariate", [True, False])
 def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate):
     """33..64 parameters take the streaming perturb kernel: same parents, same support rules, same spread"""

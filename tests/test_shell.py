@@ -521,3 +521,42 @@ def test_dice_fit_through_the_multi_device_path(dice, tmp_path):
         dbs.append(c.execute("select J.serial, smcSet, particleIdx, posterior, P.seed, ndice, sides, sum, sd from job J, par P, met M "
                              "where J.serial = P.serial and J.serial = M.serial order by J.serial").fetchall())
     assert len(dbs[0]) == 1500 and dbs[0] == dbs[1]
+
+
+@pytest.mark.gpu
+def test_dice_fit_reference_stream_reproduces_an_oracle_driven_fit(dice, tmp_path):
+    """--reference-stream: proposals and simulator seeds of every set come from the shared taus2 stream consumed as the
+    reference consumes it.  The whole database -- parameters and seeds of all four sets, posterior ranks -- is re-derived
+    here with the oracle alone (set-0 sampling, ranking, weights, covariance factor, resampling, sequential Gaussian noise
+    with rejection, seeds) from the same per-step seeds, and must be identical."""
+    cfg, db = write_cfg(tmp_path, DICE)
+    run(dice, cfg, "--process", "--simulate", "--all", "--seed", "33", "--reference-stream")
+    c = sqlite3.connect(db)
+    sizes, K = [300, 400, 400, 400], [75, 100, 100, 100]
+    pri = orc.make_priors([(1, 1, 1000), (1, 1, 1000)])
+    obs = np.array([44.0, 2.39925])
+    # set 0 from the oracle's stream: all parameter draws, then all seeds (AbcUtil.cpp:515-521, AbcSmc.cpp:843-871)
+    r = orc.rng(33)
+    pars = np.array([[orc.rng_uniform_int(r, 1000) + 1 for _ in range(2)] for _ in range(sizes[0])], dtype=float)
+    seeds = np.array([orc.rng_get(r) for _ in range(sizes[0])], dtype=np.uint64)
+    prev = None
+    for t, n in enumerate(sizes):
+        rows = c.execute("select J.particleIdx, J.posterior, P.seed, ndice, sides, sum, sd from job J, par P, met M where J.serial = P.serial "
+                         "and J.serial = M.serial and smcSet = ? order by particleIdx", (t,)).fetchall()
+        assert np.array_equal(np.array([[q[3], q[4]] for q in rows]), pars), "parameters of set %d" % t
+        assert [int(q[2]) for q in rows] == [int(x) for x in seeds], "seeds of set %d" % t
+        mets = np.array([[six(v) for v in dice_metrics(int(a), int(b), int(sd))] for (a, b), sd in zip(pars, seeds)])
+        assert np.allclose(mets, np.array([[q[5], q[6]] for q in rows]), rtol=1e-5)
+        mets = np.array([[q[5], q[6]] for q in rows])                       # what the next --process reads back
+        idx = orc.particle_ranking_pls(mets, pars, obs, 0.5)["idx"][:K[t]].astype(int)
+        assert [q[0] for q in sorted((q for q in rows if q[1] > -1), key=lambda q: q[1])] == [int(i) for i in idx]
+        theta = np.asfortranarray(pars[idx])
+        dv = orc.doubled_variance(theta)
+        w = orc.weights_uniform(len(idx)) if prev is None else orc.weights_importance(pri, theta, prev[0], prev[1], prev[2])
+        prev = (theta, w, dv)
+        if t + 1 < len(sizes):
+            rc, L, _ = orc.mvn_setup(theta)
+            assert rc == 0
+            r = orc.rng(33 + t + 1)                                         # the step-th --process of AbcSmc::run reseeds
+            pars, _, _ = orc.sample_mvn_predictive_priors(r, sizes[t + 1], w, theta, pri, L)
+            seeds = np.array([orc.rng_get(r) for _ in range(sizes[t + 1])], dtype=np.uint64)
