@@ -181,6 +181,7 @@ class Context:
             self._stream = stream_ptr
 
     def timing_enable(self, on=True):
+        """False / 0: off; True / 1: every stage; 2: only the k_gram / k_kde kernel brackets"""
         self.check(lib().abc_timing_enable(self._h, int(on)))
 
     def timing_read(self, reset=True):

@@ -37,7 +37,7 @@ struct abc_ctx {
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
-    bool timing;
+    int timing;            // 0 off, 1 every stage, 2 only the two kernel brackets bench.py's roofline needs (k_gram, k_kde)
     int kde_mode;  // ABC_KDE_AUTO / ABC_KDE_FP64
     int noise_mode;  // ABC_NOISE_DEVICE / ABC_NOISE_REFERENCE_STREAM
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
@@ -63,6 +63,7 @@ struct StageTimer {
     abc_ctx* ctx; int slot;
     StageTimer(abc_ctx* c, int stage) : ctx(c), slot(-1) {
         if (!c->timing || c->nev >= 256 || stage < 0) return;
+        if (c->timing == 2 && stage != ST_GRAM && stage != ST_KDE) return;
         slot = c->nev++;
         if (!c->ev[slot].a) { (void)hipEventCreate(&c->ev[slot].a); (void)hipEventCreate(&c->ev[slot].b); }
         c->ev[slot].stage = stage;
@@ -209,9 +210,12 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
 // GPU work launched there runs while the host builds the alias table
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr);
-struct abc_perturb_prep { double* rows; int seeds_done; };     // what launch_perturb_prepare has already done
+// what launch_perturb_prepare has already done: row-major posterior copy, seeds, first-attempt noise (n x P) + rejection list
+struct abc_perturb_prep { double* rows; int seeds_done; double* noise; unsigned* list; };
+// multivariate / L_or_dv (optional): with them the first-attempt noise of all n proposals is generated as well
 int launch_perturb_prepare(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
-                           uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep);
+                           uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate = 0,
+                           const double* L_or_dv = nullptr);
 int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P,
                    const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
                    int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,

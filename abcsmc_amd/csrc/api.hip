@@ -58,6 +58,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
+    b += Nnext * (P * 8 + 4) + 4096;                              // first-attempt noise of the proposals, rejection list
     b += 64 * 256;                                                // alignment slack
     return b + (4u << 20);
 }
@@ -167,7 +168,7 @@ static const char* const kStageNames[ABC_NSTAGE] = {
 extern "C" int abc_timing_enable(abc_ctx* ctx, int on) {
     if (!ctx) return ABC_ERR_INVALID;
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->timing = on != 0;
+    ctx->timing = (on == 2) ? 2 : (on != 0);
     ctx->nev = 0;
     return ABC_OK;
 }
@@ -481,12 +482,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // The alias-table host round trip sits inside launch_resample.  What does not depend on the weights runs on the GPU
         // meanwhile: the MVN factor (covariance + Cholesky), the row-major posterior copy and the seed stream of the
         // perturbation.
-        abc_perturb_prep prep = {nullptr, 0};
+        abc_perturb_prep prep = {nullptr, 0, nullptr, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
-            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev;
+            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
         };
-        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev};
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev, dv};
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
             if (q->L) {
@@ -498,7 +499,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                 }
             }
             if (q->ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) return ABC_OK;     // nothing of the device stream is needed
-            return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep);
+            // ... and the first-attempt noise of every proposal (it needs the factor, not the parents)
+            return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep,
+                                          q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
         ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa));
         if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {

@@ -199,17 +199,45 @@ __global__ __launch_bounds__(256) void k_theta_rows(const double* __restrict__ t
     }
 }
 
-// one new particle per lane
+// The Gaussian noise of one proposal attempt, L z (multivariate) -- one Philox block -> two normals -> two columns of L.
+// L is lower triangular: the column pairs of its right half are zero in rows < PP/2, so the second loop only touches the
+// lower half of x (a quarter of the FMAs).  Shared by the first-attempt noise kernel and the rejection loop: same counters,
+// same operation order, same bits.
+template <int PP>
+__device__ __forceinline__ void mv_noise(const double* __restrict__ sL, unsigned long long gi, unsigned attempt, uint32_t k0,
+                                         uint32_t k1, double (&x)[PP]) {
+#pragma unroll
+    for (int a = 0; a < PP; a++) x[a] = 0.0;
+#pragma unroll 1
+    for (int pr = 0; pr < (PP + 2) / 4; pr++) {      // ceil(PP/4) pairs = columns below PP/2 (all of them for PP = 2)
+        U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
+        double z0, z1;
+        normal2(philox(c, k0, k1), z0, z1);
+        const double* l0 = sL + PP * (2 * pr);
+        const double* l1 = l0 + PP;
+#pragma unroll
+        for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
+    }
+#pragma unroll 1
+    for (int pr = (PP + 2) / 4; pr < PP / 2; pr++) {
+        U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
+        double z0, z1;
+        normal2(philox(c, k0, k1), z0, z1);
+        const double* l0 = sL + PP * (2 * pr);
+        const double* l1 = l0 + PP;
+#pragma unroll
+        for (int a = PP / 2; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
+    }
+}
+// independent noise of coordinate p: sqrt(dv_p) z
+__device__ __forceinline__ double indep_noise(double sigma, unsigned long long gi, unsigned attempt, int p, uint32_t k0, uint32_t k1) {
+    U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0x80000000u | (uint32_t)p;
+    double z0, z1;
+    normal2(philox(c, k0, k1), z0, z1);
+    return sigma * z0;
+}
 template <int PP, bool MV>
-__global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __restrict__ theta, size_t K, int P,
-                                                 const abc_prior* __restrict__ priors,
-                                                 const unsigned long long* __restrict__ parent,
-                                                 unsigned long long i0, size_t n,
-                                                 const double* __restrict__ L_or_dv, double* __restrict__ out,
-                                                 unsigned long long* __restrict__ giveups) {
-    __shared__ double sL[PP * PP];     // MV: lower-triangular factor (column-major, zero above the diagonal);
-                                       // otherwise sqrt(dv) on the diagonal (AbcUtil.cpp:150)
-    __shared__ abc_prior sp[PP];
+__device__ __forceinline__ void load_factor(double* sL, const double* __restrict__ L_or_dv, int P) {
     for (int e = threadIdx.x; e < PP * PP; e += 256) {
         const int a = e % PP, b = e / PP;
         double v = 0.0;
@@ -217,6 +245,40 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
         else if (a == b && a < P) v = sqrt(L_or_dv[a]);
         sL[e] = v;
     }
+}
+
+// First-attempt noise of every proposal, noise[i + n p]: it does not depend on the parent, so the fused driver generates it
+// while the host builds the alias table (launch_perturb_prepare); what is left behind the table is a streaming pass
+// (k_perturb_fast) plus the rejection loop of the few rows whose first attempt fell outside the prior support.
+template <int PP, bool MV>
+__global__ __launch_bounds__(256) void k_noise_first(abc_rng key, int P, unsigned long long i0, size_t n,
+                                                     const double* __restrict__ L_or_dv, double* __restrict__ noise) {
+    __shared__ double sL[PP * PP];
+    load_factor<PP, MV>(sL, L_or_dv, P);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long gi = i0 + i;
+    const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
+    if (MV) {
+        double x[PP];
+        mv_noise<PP>(sL, gi, 0u, k0, k1, x);
+#pragma unroll
+        for (int p = 0; p < PP; p++) if (p < P) noise[i + n * (size_t)p] = x[p];
+    } else {
+#pragma unroll
+        for (int p = 0; p < PP; p++) if (p < P) noise[i + n * (size_t)p] = indep_noise(sL[p + PP * p], gi, 0u, p, k0, k1);
+    }
+}
+
+// proposal = recast(parent + first-attempt noise) where every coordinate is valid; the other rows go on the list of the
+// rejection loop (k_perturb with a row list: the same draws from attempt 0 on, i.e. the same result as without the split)
+template <int PP>
+__global__ __launch_bounds__(256) void k_perturb_fast(const double* __restrict__ rows, int P, const abc_prior* __restrict__ priors,
+                                                      const unsigned long long* __restrict__ parent, size_t n,
+                                                      const double* __restrict__ noise, double* __restrict__ out,
+                                                      unsigned* __restrict__ list, unsigned* __restrict__ count) {
+    __shared__ abc_prior sp[PP];
     for (int p = threadIdx.x; p < PP; p += 256) {
         abc_prior q; q.kind = ABC_PRIOR_UNIF_REAL; q.pad_ = 0; q.a = -1e300; q.b = 1e300;
         sp[p] = (p < P) ? priors[p] : q;
@@ -224,6 +286,49 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const size_t par = (size_t)parent[i];
+    double val[PP];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < PP; p += 2) {
+        const double2 m = *reinterpret_cast<const double2*>(rows + par * PP + p);
+        const double e0 = (p < P) ? __builtin_nontemporal_load(&noise[i + n * (size_t)p]) : 0.0;
+        const double e1 = (p + 1 < P) ? __builtin_nontemporal_load(&noise[i + n * (size_t)(p + 1)]) : 0.0;
+        val[p] = d_recast(sp[p], e0 + m.x);
+        val[p + 1] = d_recast(sp[p + 1], e1 + m.y);
+        ok = ok && d_valid(sp[p], val[p]) && d_valid(sp[p + 1], val[p + 1]);
+    }
+    if (ok) {
+#pragma unroll
+        for (int p = 0; p < PP; p++)
+            if (p < P) __builtin_nontemporal_store(val[p], &out[i + n * (size_t)p]);
+    } else {
+        list[atomicAdd(count, 1u)] = (unsigned)i;
+    }
+}
+
+// one new particle per lane (list == NULL: rows 0..n-1; else the rows list[0 .. *count) of the rejection loop)
+template <int PP, bool MV>
+__global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __restrict__ theta, size_t K, int P,
+                                                 const abc_prior* __restrict__ priors,
+                                                 const unsigned long long* __restrict__ parent,
+                                                 unsigned long long i0, size_t n,
+                                                 const double* __restrict__ L_or_dv, double* __restrict__ out,
+                                                 unsigned long long* __restrict__ giveups,
+                                                 const unsigned* __restrict__ list, const unsigned* __restrict__ count) {
+    __shared__ double sL[PP * PP];     // MV: lower-triangular factor (column-major, zero above the diagonal);
+                                       // otherwise sqrt(dv) on the diagonal (AbcUtil.cpp:150)
+    __shared__ abc_prior sp[PP];
+    load_factor<PP, MV>(sL, L_or_dv, P);
+    for (int p = threadIdx.x; p < PP; p += 256) {
+        abc_prior q; q.kind = ABC_PRIOR_UNIF_REAL; q.pad_ = 0; q.a = -1e300; q.b = 1e300;
+        sp[p] = (p < P) ? priors[p] : q;
+    }
+    __syncthreads();
+    // list mode: a small grid strides over the listed rows; otherwise one row per thread
+    const size_t limit = list ? (size_t)*count : n, stride = list ? (size_t)gridDim.x * 256 : n;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < limit; t += stride) {
+    const size_t i = list ? (size_t)list[t] : t;
     const unsigned long long gi = i0 + i;
     const size_t par = (size_t)parent[i];
     double mu[PP], val[PP];
@@ -237,30 +342,7 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
         // AbcUtil.cpp:132-139: draw the whole vector x = mu + L z, accept iff every coordinate is valid
         for (unsigned attempt = 0; attempt < MVN_MAX_TRIES; attempt++) {
             double x[PP];
-#pragma unroll
-            for (int a = 0; a < PP; a++) x[a] = 0.0;
-            // one Philox block -> two normals -> two columns of L.  L is lower triangular: the column pairs of its right
-            // half are zero in rows < PP/2, so the second loop only touches the lower half of x (a quarter of the FMAs)
-#pragma unroll 1
-            for (int pr = 0; pr < (PP + 2) / 4; pr++) {      // ceil(PP/4) pairs = columns below PP/2 (all of them for PP = 2)
-                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
-                double z0, z1;
-                normal2(philox(c, k0, k1), z0, z1);
-                const double* l0 = sL + PP * (2 * pr);
-                const double* l1 = l0 + PP;
-#pragma unroll
-                for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
-            }
-#pragma unroll 1
-            for (int pr = (PP + 2) / 4; pr < PP / 2; pr++) {
-                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
-                double z0, z1;
-                normal2(philox(c, k0, k1), z0, z1);
-                const double* l0 = sL + PP * (2 * pr);
-                const double* l1 = l0 + PP;
-#pragma unroll
-                for (int a = PP / 2; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
-            }
+            mv_noise<PP>(sL, gi, attempt, k0, k1, x);
             bool ok = true;
 #pragma unroll
             for (int a = 0; a < PP; a++) {
@@ -282,10 +364,7 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
             if (p < P) {
                 double v = 0.0; bool ok = false;
                 for (unsigned attempt = 0; attempt < 1000 && !ok; attempt++) {
-                    U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0x80000000u | (uint32_t)p;
-                    double z0, z1;
-                    normal2(philox(c, k0, k1), z0, z1);
-                    v = d_recast(sp[p], sL[p + PP * p] * z0 + mu[p]);
+                    v = d_recast(sp[p], indep_noise(sL[p + PP * p], gi, attempt, p, k0, k1) + mu[p]);
                     ok = d_valid(sp[p], v);
                 }
                 val[p] = ok ? v : d_prior_mean(sp[p]);
@@ -297,6 +376,7 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
     for (int p = 0; p < PP; p++)
         if (p < P) __builtin_nontemporal_store(val[p], &out[i + n * (size_t)p]);   // read next by the host / simulators, not by a kernel:
                                                                                     // keep the 8 P N bytes out of L2 / Infinity Cache
+    }
 }
 
 // 32 < P <= 64: same draws and acceptance rule as k_perturb, but only the accumulators x[PP] live in registers;
@@ -481,9 +561,12 @@ static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n,
     return ABC_OK;
 }
 int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
-                           uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep) {
+                           uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate,
+                           const double* L_or_dv) {
     prep->rows = nullptr;
     prep->seeds_done = 0;
+    prep->noise = nullptr;
+    prep->list = nullptr;
     if (n == 0 || P > 64) return ABC_OK;
     int PP = 2;
     while (PP < (int)P) PP *= 2;
@@ -493,6 +576,33 @@ int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta
     ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows));
     prep->rows = rows;
     if (seeds) { ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset)); prep->seeds_done = 1; }
+    // first-attempt noise of every proposal (independent of the parents): up to 32 parameters, row numbers in 32 bits
+    if (L_or_dv && PP <= 32 && n <= 0xffffffffull) {
+        double* noise = (double*)abc_ws_alloc(ctx, n * P * sizeof(double));
+        unsigned* list = (unsigned*)abc_ws_alloc(ctx, (n + 1) * sizeof(unsigned));       // [0]: count, then the rows
+        if (noise && list) {
+            const unsigned blocks = (unsigned)((n + 255) / 256);
+            ABC_HIP(ctx, hipMemsetAsync(list, 0, sizeof(unsigned), ctx->stream));
+#define LAUNCH_NF(PPV)                                                                                                        \
+    do {                                                                                                                      \
+        if (multivariate) hipLaunchKernelGGL((k_noise_first<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, (int)P,  \
+                                             (unsigned long long)i0, n, L_or_dv, noise);                                      \
+        else hipLaunchKernelGGL((k_noise_first<PPV, false>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, (int)P,             \
+                                (unsigned long long)i0, n, L_or_dv, noise);                                                   \
+    } while (0)
+            switch (PP) {
+                case 2: LAUNCH_NF(2); break;
+                case 4: LAUNCH_NF(4); break;
+                case 8: LAUNCH_NF(8); break;
+                case 16: LAUNCH_NF(16); break;
+                default: LAUNCH_NF(32); break;
+            }
+#undef LAUNCH_NF
+            ABC_HIP(ctx, hipGetLastError());
+            prep->noise = noise;
+            prep->list = list;
+        }
+    }
     return ABC_OK;
 }
 
@@ -513,14 +623,24 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
     if (!(prep && prep->rows)) ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows));
     theta = rows;
+    // with the first-attempt noise prepared: a streaming pass, then the rejection loop over the listed rows only
+    const double* noise = (prep && PP <= 32) ? prep->noise : nullptr;
+    unsigned* list = noise ? prep->list + 1 : nullptr;
+    unsigned* count = noise ? prep->list : nullptr;
+    const unsigned lblocks = blocks < 256 ? blocks : 256;     // the rejection loop strides over its (short) row list
 #define LAUNCH_PT(PPV)                                                                                                 \
     do {                                                                                                               \
+        if (noise)                                                                                                     \
+            hipLaunchKernelGGL((k_perturb_fast<PPV>), dim3(blocks), dim3(256), 0, ctx->stream, theta, (int)P, priors,   \
+                               (const unsigned long long*)parent, n, noise, out, list, count);                       \
         if (multivariate)                                                                                              \
-            hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
-                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out, ctx->giveups_dev);   \
+            hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(noise ? lblocks : blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,    \
+                               ctx->giveups_dev, (const unsigned*)list, (const unsigned*)count);                      \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_perturb<PPV, false>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
-                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out, ctx->giveups_dev);   \
+            hipLaunchKernelGGL((k_perturb<PPV, false>), dim3(noise ? lblocks : blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,    \
+                               ctx->giveups_dev, (const unsigned*)list, (const unsigned*)count);                      \
     } while (0)
     switch (PP) {
         case 2: LAUNCH_PT(2); break;

@@ -400,12 +400,12 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
             have_spd = true;
         }
-        abc_perturb_prep prep = {nullptr, 0};
+        abc_perturb_prep prep = {nullptr, 0, nullptr, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
-            uint64_t i0, seed_off; uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev;
+            uint64_t i0, seed_off; uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
         };
-        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, cfg->next0, cfg->Nnext_total, io->seeds, &prep, L, spd_dev};
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, cfg->next0, cfg->Nnext_total, io->seeds, &prep, L, spd_dev, dv};
         auto hook = [](void* a) -> int {          // GPU work that does not need the alias table runs while the host builds it
             PrepArg* q = (PrepArg*)a;
             if (q->L) {
@@ -416,7 +416,8 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
                     ABC_TRY(launch_mvn_setup(q->ctx, q->theta, q->K, q->P, q->L, nullptr, q->spd_dev));
                 }
             }
-            return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep);
+            return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep,
+                                          q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
         ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa));
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,

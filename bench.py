@@ -155,8 +155,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.timing_enable(True)          # HIP events on the stream the kernels are launched on
-    ctx.timing_read(reset=True)
+    ctx.timing_enable(2)             # HIP events on the stream the kernels are launched on: only the k_gram / k_kde brackets
+    ctx.timing_read(reset=True)      # (a pair per STAGE costs ~10 us of dispatch gap each, ~0.15 ms per generation)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -164,6 +164,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stages = ctx.timing_read(reset=True)
+    # per-stage breakdown (informational): a separate short pass with every stage timer on, outside the timed region
+    nb = min(args.steps, 5)
+    ctx.timing_enable(1)
+    for _ in range(nb):
+        step()
+    barrier()
+    stages_all = ctx.timing_read(reset=True)
     ctx.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -180,7 +187,7 @@ def main():
         return ms / cnt, cnt // args.steps
 
     event_overhead_ms = ctx.timing_overhead(50)      # what an event pair reports beyond the kernel itself (empty-kernel calibration)
-    stage_ms = {k: round((v[0] + v[1]) / max(args.steps, 1), 5) for k, v in stages.items()}
+    stage_ms = {k: round((v[0] + v[1]) / nb, 5) for k, v in stages_all.items()}
 
     # ---- roofline of the DOMINANT kernel: the pair sums of the importance weights (k_kde_split / k_kde) ------------------
     # Two kernels can run them.  k_kde_split: pair dot products as exact bf16 limb products on the

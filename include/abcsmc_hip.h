@@ -97,7 +97,9 @@ int  abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
  * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]
- * accumulated host-side time (alias-table build), count[i] the number of launches; reset != 0 clears. */
+ * accumulated host-side time (alias-table build), count[i] the number of launches; reset != 0 clears.
+ * on: 0 = off, 1 = every stage (an event pair per stage: ~10 us of host / dispatch gap each, i.e. ~0.15 ms per generation),
+ *     2 = only the brackets around the k_gram and k_kde kernels (what bench.py's roofline needs inside its timed region). */
 int  abc_timing_enable(abc_ctx* ctx, int on);
 int  abc_timing_read(abc_ctx* ctx, const char** names, double* ms, double* host_ms, long long* count,
                      int max_stages, int reset);
