@@ -88,8 +88,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
-    if (ctx->alias_F) (void)hipFree(ctx->alias_F);
-    if (ctx->alias_A) (void)hipFree(ctx->alias_A);
+    if (ctx->alias_F) (void)hipFree(ctx->alias_F);       // alias_A lives in the same allocation
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
     if (ctx->kde_which) (void)hipFree(ctx->kde_which);
     if (ctx->giveups_dev) (void)hipFree(ctx->giveups_dev);

@@ -519,13 +519,15 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     StageTimer tm(ctx, ST_RESAMPLE);
     if (ctx->alias_K < K) {
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->alias_F) { (void)hipFree(ctx->alias_F); (void)hipFree(ctx->alias_A); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * sizeof(double)));
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_A, K * sizeof(uint32_t)));
+        if (ctx->alias_F) { (void)hipFree(ctx->alias_F); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * (sizeof(double) + sizeof(uint32_t))));     // F[K] then A[K]: one allocation,
+        ctx->alias_A = (uint32_t*)(ctx->alias_F + K);                                               // one host-to-device copy
         ctx->alias_K = K;
     }
-    ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_F, hF, K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_A, hA, K * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ctx->alias_A = (uint32_t*)(ctx->alias_F + K);
+    // hF and hA are not adjacent in the pinned scratch (hE lies between them): A is moved up against F for a single copy
+    memmove(hF + K, hA, K * sizeof(uint32_t));
+    ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_F, hF, K * (sizeof(double) + sizeof(uint32_t)), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
                        ctx->alias_A, K, (unsigned long long*)parent);
     ABC_HIP(ctx, hipGetLastError());

@@ -622,8 +622,9 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict_
 
 __global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t K, const double* __restrict__ part,
                                                   int nparts) {
-    double sq = 0.0;
-    for (int b = 0; b < nparts; b++) sq += part[b];
+    // every work-group adds the (<= 256) partial sums in the same fixed order: one per thread, then the block tree
+    __shared__ double sm[4];
+    const double sq = block_sum_256(((int)threadIdx.x < nparts) ? part[threadIdx.x] : 0.0, sm);
     if (!(sq > 0.0)) return;                     // Eigen normalize(): only if squaredNorm > 0
     const double nrm = sqrt(sq);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
