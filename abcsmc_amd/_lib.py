@@ -14,6 +14,7 @@ DT_F64, DT_I32, DT_I64 = 0, 1, 2
 COMM_ID_BYTES = 128
 COMM_NONE, COMM_RCCL, COMM_CALLBACKS = 0, 1, 2
 NOISE_DEVICE, NOISE_REFERENCE_STREAM = 0, 1
+WEIGHT_GAUSSIAN, WEIGHT_EPANECHNIKOV = 0, 1
 
 
 class LibraryMissing(ImportError):
@@ -84,6 +85,7 @@ SIGNATURES = {
     "abc_ctx_set_kde_mode": (_i, [_vp, _i]),
     "abc_kde_last_kernel": (_i, [_vp, _vp]),
     "abc_ctx_set_noise_mode": (_i, [_vp, _i]),
+    "abc_ctx_set_weight_kernel": (_i, [_vp, _i]),
     "abc_perturb_giveups": (_i, [_vp, _vp, _i]),
     "abc_ctx_synchronize": (_i, [_vp]),
     "abc_version": (_i, []),
@@ -208,6 +210,10 @@ class Context:
         w = C.c_int(0)
         self.check(lib().abc_kde_last_kernel(self._h, C.byref(w)))
         return w.value
+
+    def set_weight_kernel(self, kernel):
+        """WEIGHT_GAUSSIAN (the reference's, default) or WEIGHT_EPANECHNIKOV (extension): abc_ctx_set_weight_kernel"""
+        self.check(lib().abc_ctx_set_weight_kernel(self._h, int(kernel)))
 
     def set_noise_mode(self, mode):
         """NOISE_DEVICE (Philox stream on the device, default) or NOISE_REFERENCE_STREAM (the reference's sequential taus2

@@ -40,6 +40,7 @@ struct abc_ctx {
     int timing;            // 0 off, 1 every stage, 2 only the two kernel brackets bench.py's roofline needs (k_gram, k_kde)
     int kde_mode;  // ABC_KDE_AUTO / ABC_KDE_FP64
     int noise_mode;  // ABC_NOISE_DEVICE / ABC_NOISE_REFERENCE_STREAM
+    int weight_kernel;  // ABC_WEIGHT_GAUSSIAN / ABC_WEIGHT_EPANECHNIKOV
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
     int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish

@@ -123,6 +123,14 @@ extern "C" int abc_ctx_set_kde_mode(abc_ctx* ctx, int mode) {
     return ABC_OK;
 }
 
+extern "C" int abc_ctx_set_weight_kernel(abc_ctx* ctx, int kernel) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (kernel != ABC_WEIGHT_GAUSSIAN && kernel != ABC_WEIGHT_EPANECHNIKOV)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_weight_kernel: unknown kernel %d", kernel);
+    ctx->weight_kernel = kernel;
+    return ABC_OK;
+}
+
 extern "C" int abc_ctx_set_noise_mode(abc_ctx* ctx, int mode) {
     if (!ctx) return ABC_ERR_INVALID;
     if (mode != ABC_NOISE_DEVICE && mode != ABC_NOISE_REFERENCE_STREAM)

@@ -199,6 +199,34 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
     if (active) part[sl * kn + i] = acc;
 }
 
+// ---- optional Epanechnikov kernel (ABC_WEIGHT_EPANECHNIKOV; an extension, see include/abcsmc_hip.h) -------------------------
+// part[slice*kn + i] = sum_{j in slice} w'_j max(0, 1 - |a_i - b_j|^2 c),  a, b the scaled rows of k_wscale (scale
+// sqrt(log2 e) / sqrt(dv_p), 0 for dv_p = 0) and c = 1 / (log2 e (P' + 4)).  One new particle per lane, previous rows wave-uniform.
+template <int PP>
+__global__ __launch_bounds__(256) void k_epan(const double* __restrict__ a, size_t kn, const double* __restrict__ b, size_t Kp,
+                                              const double* __restrict__ w_prev, const WConst* __restrict__ wc, int P,
+                                              double* __restrict__ part) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t slices = gridDim.y, sl = blockIdx.y;
+    const unsigned j0 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * sl / slices));
+    const unsigned j1 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * (sl + 1) / slices));
+    const bool active = i < kn;
+    double ai[PP];
+#pragma unroll
+    for (int p = 0; p < PP; p++) ai[p] = active ? a[i * PP + p] : 0.0;
+    const double c = 1.0 / (1.4426950408889634 * (double)(P - wc->nzero + 4));
+    double acc = 0.0;
+    for (unsigned j = j0; j < j1; j++) {
+        const double* bj = b + (size_t)j * PP;
+        double d2 = 0.0;
+#pragma unroll
+        for (int p = 0; p < PP; p++) { const double d = ai[p] - bj[p]; d2 = fma(d, d, d2); }
+        const double k = 1.0 - d2 * c;
+        acc += (k > 0.0) ? w_prev[j] * k : 0.0;
+    }
+    if (active) part[sl * kn + i] = acc;
+}
+
 // ---- split-operand weight kernel: the pair dot products on the bf16 matrix pipe, exactly ---------------
 // The fp64 body above spends 17 of its 30 vector instructions per pair on the dot product a_i.b_j.  Here every
 // scaled coordinate is written as a sum of four bf16 "limbs",
@@ -587,7 +615,7 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
                                                  size_t K, int P, size_t k0, size_t kn,
                                                  const double* __restrict__ part, int slices,
                                                  const WConst* __restrict__ wc, double* __restrict__ w_raw,
-                                                 int split_launched, int* __restrict__ which,
+                                                 int split_launched, int epan, int* __restrict__ which,
                                                  const unsigned char* __restrict__ far_flag, const double* __restrict__ fix_i,
                                                  const double* __restrict__ fix_j) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -603,7 +631,8 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
         for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
         if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far_cols)
     }
-    w_raw[i] = num / (wc->C * den);
+    if (epan) w_raw[i] = (den > 0.0) ? num / den : 0.0;          // compact support: a particle nothing supports gets weight 0
+    else w_raw[i] = num / (wc->C * den);
 }
 
 __global__ __launch_bounds__(256) void k_fill(double* __restrict__ w, size_t K, double v) {
@@ -681,7 +710,8 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (slices > 1024) slices = 1024;
     // split-operand kernel: 5 <= P <= 32 parameters (padded width 8, 16 or 32; below that the fp64 body is as short), unless the caller asked for fp64
     const int NCH = (P <= 16) ? 1 : 2;
-    const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64);
+    const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
+    const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
     const int opa = NCH * KS_NL + 2, opb = NCH * KS_NL + 1;
     if (split) {
@@ -738,7 +768,19 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #define LAUNCH_KDE(PPV)                                                                                        \
     hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
                        Kp, hb, wc, theta, K, k0, theta_prev, part, split ? 1 : 0)
-    {
+    if (epan) {
+        StageTimer tk(ctx, ST_KDE);
+#define LAUNCH_EPAN(PPV) hipLaunchKernelGGL(k_epan<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, Kp, w_prev, wc, (int)P, part)
+        switch (PP) {
+            case 2: LAUNCH_EPAN(2); break;
+            case 4: LAUNCH_EPAN(4); break;
+            case 8: LAUNCH_EPAN(8); break;
+            case 16: LAUNCH_EPAN(16); break;
+            case 32: LAUNCH_EPAN(32); break;
+            default: LAUNCH_EPAN(64); break;
+        }
+#undef LAUNCH_EPAN
+    } else {
         StageTimer tk(ctx, ST_KDE);
         if (split) {
 #define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
@@ -775,7 +817,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #undef LAUNCH_FAR
     }
     hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
-                       (int)slices, wc, w_raw, split ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j);
+                       (int)slices, wc, w_raw, split ? 1 : 0, epan ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

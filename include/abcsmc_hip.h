@@ -79,6 +79,13 @@ int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
 /* Which of the two kernels produced the pair sums of the most recent weight call on this context (synchronises). */
 enum { ABC_KDE_RAN_NONE = 0, ABC_KDE_RAN_FP64 = 1, ABC_KDE_RAN_SPLIT = 2 };
 int  abc_kde_last_kernel(abc_ctx* ctx, int* which);
+/* Kernel of the importance weights (weight_predictive_prior, set > 0).  ABC_WEIGHT_GAUSSIAN (default) is the reference's product
+ * of Gaussian factors (AbcUtil.cpp:572-576).  ABC_WEIGHT_EPANECHNIKOV is an EXTENSION with no reference counterpart (the
+ * reference only mentions the name in a comment, AbcUtil.cpp:476; BASELINE.json's north_star asks for it): the radial
+ * Epanechnikov kernel of the same covariance, K = max(0, 1 - r2 / (P' + 4)), r2 = sum_p (theta_ip - theta'_jp)^2 / dv'_p over the
+ * P' parameters with dv'_p != 0; a particle without support among the previous ones gets weight 0.  fp64 vector kernel. */
+enum { ABC_WEIGHT_GAUSSIAN = 0, ABC_WEIGHT_EPANECHNIKOV = 1 };
+int  abc_ctx_set_weight_kernel(abc_ctx* ctx, int kernel);
 /* Which stream the Gaussian noise of the proposals comes from (sample_*_predictive_priors, abc_generation_dev).
  * ABC_NOISE_DEVICE (default): counter-based Philox stream keyed by (rng state, draw, attempt), evaluated on the device -- same
  *   distribution as the reference, different numbers; the simulator seeds are the taus2 outputs right after the resampling draws.

@@ -620,6 +620,38 @@ uint64_t orc_discrete_draw(orc_rng_t* r, size_t K, const double* F, const uint64
     return (u < f) ? c : A[c];
 }
 
+/* Optional Epanechnikov weight kernel (BASELINE.json north_star names one; the reference has none -- only a comment at
+ * AbcUtil.cpp:476 -- so this is an EXTENSION, off by default, with no reference semantics to match): the product of
+ * Gaussian factors of AbcUtil.cpp:572-576 is replaced by the radial Epanechnikov kernel of the same covariance,
+ *   K(r2) = max(0, 1 - r2 / (P' + 4)),   r2 = sum_p (theta_ip - theta'_jp)^2 / dv'_p   over the P' parameters with dv'_p != 0
+ * (a d-variate Epanechnikov kernel with support radius h has covariance h^2 I / (d + 4)); the constant in front cancels in
+ * the L2 normalisation and is left out; a particle no previous particle supports gets weight 0. */
+void orc_weights_epanechnikov(const orc_prior_t* priors, const double* theta, size_t K,
+                              const double* theta_prev, size_t Kp, const double* w_prev,
+                              const double* dv_prev, size_t P, double* w) {
+    size_t pnz = 0;
+    for (size_t p = 0; p < P; p++) pnz += dv_prev[p] != 0.0;
+    const double h2 = static_cast<double>(pnz) + 4.0;
+    for (size_t i = 0; i < K; i++) {
+        double numerator = 1.0, denominator = 0.0;
+        for (size_t p = 0; p < P; p++) numerator *= orc_prior_likelihood(&priors[p], theta[i + K * p]);
+        for (size_t j = 0; j < Kp; j++) {
+            double r2 = 0.0;
+            for (size_t p = 0; p < P; p++) {
+                if (dv_prev[p] == 0.0) continue;
+                const double d = theta[i + K * p] - theta_prev[j + Kp * p];
+                r2 += d * d / dv_prev[p];
+            }
+            const double k = 1.0 - r2 / h2;
+            if (k > 0.0) denominator += w_prev[j] * k;
+        }
+        w[i] = denominator > 0.0 ? numerator / denominator : 0.0;
+    }
+    double sq = 0.0;
+    for (size_t i = 0; i < K; i++) sq += w[i] * w[i];
+    if (sq > 0.0) { const double nrm = std::sqrt(sq); for (size_t i = 0; i < K; i++) w[i] /= nrm; }
+}
+
 /* ============================ resample + perturb ================================== */
 /* AbcUtil.cpp:111-120 */
 void orc_resample(orc_rng_t* r, const double* w, size_t K, size_t n, uint64_t* idx) {

@@ -109,6 +109,9 @@ double orc_prior_mean(const orc_prior_t* pr);
 void   orc_weights_uniform(size_t K, double* w);
 /* zero_dv_policy: 0 = declared deviation (factor 0 when dv==0 and values differ),
  *                 1 = reference-literal gsl_ran_gaussian_pdf(x,0) (NaN poison) */
+/* extension (no reference counterpart): radial Epanechnikov kernel of the same covariance, see abc_oracle.cpp */
+void   orc_weights_epanechnikov(const orc_prior_t* priors, const double* theta, size_t K, const double* theta_prev, size_t Kp,
+                                const double* w_prev, const double* dv_prev, size_t P, double* w);
 void   orc_weights_importance(const orc_prior_t* priors, const double* theta, size_t K,
                               const double* theta_prev, size_t Kp, const double* w_prev,
                               const double* dv_prev, size_t P, int zero_dv_policy, double* w);

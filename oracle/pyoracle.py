@@ -232,6 +232,14 @@ def weights_uniform(K):
     return w
 
 
+def weights_epanechnikov(priors, theta, theta_prev, w_prev, dv_prev):
+    theta, theta_prev, w_prev, dv_prev = _f(theta), _f(theta_prev), _f(w_prev), _f(dv_prev)
+    K, P = theta.shape; Kp = theta_prev.shape[0]
+    w = np.empty(K)
+    lib().orc_weights_epanechnikov(priors, _p(theta), _sz(K), _p(theta_prev), _sz(Kp), _p(w_prev), _p(dv_prev), _sz(P), _p(w))
+    return w
+
+
 def weights_importance(priors, theta, theta_prev, w_prev, dv_prev, zero_dv_policy=0):
     theta, theta_prev, w_prev, dv_prev = _f(theta), _f(theta_prev), _f(w_prev), _f(dv_prev)
     K, P = theta.shape; Kp = theta_prev.shape[0]

@@ -248,6 +248,35 @@ def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp, mode):
     assert np.linalg.norm(w) == pytest.approx(1.0, rel=1e-12)          # L2, not L1 (AbcUtil.cpp:583)
 
 
+@pytest.mark.parametrize("K,Kp,P", [(300, 257, 3), (1000, 700, 16), (129, 64, 40)])
+def test_weight_epanechnikov_extension(gpu_ctx, oracle, K, Kp, P):
+    """ABC_WEIGHT_EPANECHNIKOV (an extension without a reference counterpart: AbcUtil.cpp:476 only names it) against its
+    oracle restatement; off by default; particles outside every previous particle's support get weight 0; a converged
+    parameter (dv' = 0) takes no part"""
+    from abcsmc_amd import abcutil, _lib
+    wl, th, tp, wp, dv = _weights_case(P, K, Kp, 7)
+    spec = wl.prior_spec()
+    dv = dv.copy()
+    if P > 4:
+        dv[2] = 0.0
+    th = th.copy()
+    th[5] = th[5] + 40 * np.sqrt(np.where(dv > 0, dv, 1.0))            # far from everything: no support
+    pri, opri = _lib.make_priors(spec), oracle.make_priors(spec)
+    w_gauss = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx) if P <= 4 or dv[2] != 0 else None
+    gpu_ctx.set_weight_kernel(_lib.WEIGHT_EPANECHNIKOV)
+    try:
+        w = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    finally:
+        gpu_ctx.set_weight_kernel(_lib.WEIGHT_GAUSSIAN)
+    ref = oracle.weights_epanechnikov(opri, th, tp, wp, dv)
+    assert w[5] == 0.0 and ref[5] == 0.0
+    ok = ref > 0
+    assert ok.sum() > K // 2 and np.allclose(w[ok], ref[ok], rtol=1e-9) and np.array_equal(w == 0, ref == 0)
+    assert np.linalg.norm(w) == pytest.approx(1.0, rel=1e-12)
+    if w_gauss is not None:
+        assert not np.allclose(w, w_gauss, rtol=1e-3)                   # it is a different kernel
+
+
 def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle):
     """the split-operand kernel on a set large enough for many column slices and tiles: against the oracle and against
     the fp64 kernel; previous particles of weight exactly 0 (inside the exact range) contribute exactly nothing"""
