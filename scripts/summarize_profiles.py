@@ -1,10 +1,19 @@
-"""Copies the rocprofv3 summaries a gpurun call left under gpurun_out/ into profiles/ (tracked) and derives the
-per-kernel HBM traffic from the separate FETCH_SIZE / WRITE_SIZE PMC passes, with the gfx950 correction of
+"""Copies the rocprofv3 summaries a gpurun call of scripts/gpu_profile_round.sh left under gpurun_out/ into profiles/
+(tracked) and re-derives from them, without bench.py's own event brackets, every fraction bench.py's JSON line carries:
+
+  roofline            k_kde_split: bf16 MFMA work issued / rocprofv3 kernel duration against the dense bf16 peak, the
+                      matrix-pipe busy fraction and the vector-issue fraction from the PMC pass, the clock the kernel ran at
+  roofline_hbm        k_gram: algorithmic bytes / rocprofv3 kernel duration, PMC traffic beside it
+  roofline_streaming  SURVEY 8(d): algorithmic bytes of a generation / (bench step time - pair-sum kernel), and set 0
+
+HBM traffic = the separate FETCH_SIZE / WRITE_SIZE PMC passes with the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of a wide coalesced read; WRITE_SIZE exact).
-usage: python scripts/summarize_profiles.py <round-tag> <stats-prefix> <pmc-prefix>"""
-import csv, glob, json, re, shutil, sys
+usage: python scripts/summarize_profiles.py <round-tag> <stats-prefix> <pmc-prefix>      (e.g. r02 prof pmc)"""
+import csv, glob, json, os, re, shutil, sys
 
 tag, sp, pp = sys.argv[1], sys.argv[2], sys.argv[3]
+G = 'gpurun_out/'
+HBM_PEAK, MFMA_PEAK_TF, NSIMD = 8000.0, 2500.0, 1024
 
 
 def find(d, suffix):
@@ -16,22 +25,43 @@ def short(k):
     return m.group(1) if m else k.split('(')[0].strip()
 
 
-def pmc(d, counter):
+def pmc(d, counter=None, kernel=None):
+    """per-kernel (or one kernel's per-counter) per-dispatch averages of a counter_collection.csv"""
     out = {}
     for r in csv.DictReader(open(find(d, 'counter_collection.csv'))):
-        if r['Counter_Name'] == counter:
-            out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
+        if counter is not None and r['Counter_Name'] != counter:
+            continue
+        if kernel is not None and kernel not in r['Kernel_Name']:
+            continue
+        key = r['Kernel_Name'] if counter is not None else r['Counter_Name']
+        out.setdefault(key, []).append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in out.items()}
 
 
+def stats(cfg):
+    """kernel -> (calls, average ns) from the --kernel-trace --stats pass"""
+    return {short(r['Name']): (int(r['Calls']), float(r['AverageNs'])) for r in csv.DictReader(open(find(G + '%s_c%d' % (sp, cfg), 'kernel_stats.csv')))}
+
+
+def bench(cfg):
+    return json.loads(open(G + 'bench_c%d.json' % cfg).read().strip().splitlines()[-1])
+
+
+# ---- copies ---------------------------------------------------------------------------------------------------------------
+cfgs = [c for c in (2, 3, 4, 5) if os.path.exists(G + 'bench_c%d.json' % c)]
+for c in cfgs:
+    shutil.copy(find(G + '%s_c%d' % (sp, c), 'kernel_stats.csv'), 'profiles/%s_kernel_stats_config%d.csv' % (tag, c))
+    shutil.copy(G + 'bench_c%d.json' % c, 'profiles/%s_bench_config%d.json' % (tag, c))
+
+# ---- HBM traffic per kernel -------------------------------------------------------------------------------------------------
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `python3 bench.py --config N --steps 2 "
                 "--warmup 1 --no-cpu-baseline`; per-dispatch averages in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                 "(gfx950: FETCH_SIZE counts 64 B per 128-B request).", "configs": {}}
 rows = []
 for cfg in (2, 3):
-    shutil.copy(find('gpurun_out/%s_c%d' % (sp, cfg), 'kernel_stats.csv'),
-                'profiles/%s_kernel_stats_config%d.csv' % (tag, cfg))
-    fe, wr = pmc('gpurun_out/%s_fetch_c%d' % (pp, cfg), 'FETCH_SIZE'), pmc('gpurun_out/%s_write_c%d' % (pp, cfg), 'WRITE_SIZE')
+    if not os.path.isdir(G + '%s_fetch_c%d' % (pp, cfg)):
+        continue
+    fe, wr = pmc(G + '%s_fetch_c%d' % (pp, cfg), 'FETCH_SIZE'), pmc(G + '%s_write_c%d' % (pp, cfg), 'WRITE_SIZE')
     ent = {}
     for k in fe:
         hbm = (2 * fe[k] + wr.get(k, 0)) * 1024
@@ -43,58 +73,87 @@ with open('profiles/%s_pmc_hbm_traffic.csv' % tag, 'w') as f:
     f.write("config,kernel,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB,hbm_bytes_corrected\n")
     for r in rows:
         f.write('%d,"%s",%.1f,%.1f,%.0f\n' % r)
-print("k_gram traffic:", {c: [v["hbm_bytes_per_launch"] for k, v in e.items() if k.startswith(("k_gram<3", "k_gram_dma<3"))] for c, e in res["configs"].items()})
 
-# SQ counters of the Gram kernel (two passes: pmcf_sq_c3, pmcf_sq2_c3)
+
+def traffic(cfg, prefix):
+    for k, v in res["configs"].get(str(cfg), {}).items():
+        if k.startswith(prefix) and v["hbm_bytes_per_launch"] > 1e6:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
+# ---- SQ counters of the Gram kernel -------------------------------------------------------------------------------------------
 sq = {}
-for d in ('gpurun_out/%s_sq_c3' % pp, 'gpurun_out/%s_sq2_c3' % pp):
-    try:
-        fs = [find(d, 'counter_collection.csv')]
-    except IndexError:
-        continue
-    acc = {}
-    for r in csv.DictReader(open(fs[0])):
-        if 'k_gram_dma<3' in r['Kernel_Name'] or 'k_gram<3' in r['Kernel_Name']:
-            acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-            sq['_kernel'] = short(r['Kernel_Name'])
-    for k, v in acc.items():
-        sq[k] = sum(v) / len(v)
+for d in (G + '%s_sq_c3' % pp, G + '%s_sq2_c3' % pp):
+    if os.path.isdir(d):
+        for kern in ('k_gram<3', 'k_gram_dma<3'):
+            sq.update(pmc(d, kernel=kern))
 if sq:
     sq['_note'] = ("rocprofv3 --pmc (two passes) on `python3 bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline`, per-dispatch "
-                   "averages; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)")
+                   "averages of the k_gram<3,1> launch; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)")
     if 'GRBM_GUI_ACTIVE' in sq and 'SQ_VALU_MFMA_BUSY_CYCLES' in sq:
-        sq['MfmaUtil_percent'] = 100 * sq['SQ_VALU_MFMA_BUSY_CYCLES'] / (sq['GRBM_GUI_ACTIVE'] / 8 * 1024)
+        sq['MfmaUtil_percent'] = 100 * sq['SQ_VALU_MFMA_BUSY_CYCLES'] / (sq['GRBM_GUI_ACTIVE'] / 8 * NSIMD)
     if 'SQ_WAIT_INST_ANY' in sq and 'SQ_WAVE_CYCLES' in sq:
         sq['wait_fraction_of_wave_cycles'] = sq['SQ_WAIT_INST_ANY'] / sq['SQ_WAVE_CYCLES']
     json.dump(sq, open('profiles/%s_pmc_sq_k_gram_config3.json' % tag, 'w'), indent=1, sort_keys=True)
-    print("sq:", sq)
 
-# the weight kernel (k_kde_split / k_kde): clock and matrix-pipe utilisation from the pmcf_kde_c3 pass + the kernel stats
-try:
-    kd = {}
-    for r in csv.DictReader(open(find('gpurun_out/%s_kde_c3' % pp, 'counter_collection.csv'))):
-        if 'k_kde' in r['Kernel_Name']:
-            kd.setdefault(short(r['Kernel_Name']), {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-    dur = {}
-    for r in csv.DictReader(open(find('gpurun_out/%s_c3' % sp, 'kernel_stats.csv'))):
-        if 'k_kde' in r['Name']:
-            dur[short(r['Name'])] = float(r['AverageNs'])
-    out = {"_note": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU on `python3 bench.py "
-                    "--config 3 --steps 2 --warmup 1 --no-cpu-baseline` (per-dispatch averages) + the kernel duration of the "
-                    "--kernel-trace --stats pass; GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = cycles / 8 / duration; "
-                    "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles per XCD"}
-    for k, c in kd.items():
-        c = {n: sum(v) / len(v) for n, v in c.items()}
-        if c.get('GRBM_GUI_ACTIVE', 0) < 1e6:          # the kernel that was not its turn returns at once
-            continue
-        cyc = c['GRBM_GUI_ACTIVE'] / 8
-        ent = {"counters": {n: round(v) for n, v in c.items()}, "cycles_per_xcd": round(cyc),
-               "mfma_busy_frac": round(c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cyc, 3)}
-        if k in dur:
-            ent["kernel_avg_ms"] = round(dur[k] / 1e6, 4)
-            ent["clock_ghz"] = round(cyc / dur[k], 3)
-        out[k] = ent
-    json.dump(out, open('profiles/%s_pmc_kde_config3.json' % tag, 'w'), indent=1, sort_keys=True)
-    print("kde:", {k: v for k, v in out.items() if k != "_note"})
-except (IndexError, FileNotFoundError) as e:
-    print("no kde pmc pass:", e)
+# ---- the roofline numbers of bench.py, re-derived from the CSVs ----------------------------------------------------------------
+roof = {"_note": "every number below is recomputed from profiles/%s_kernel_stats_config*.csv (rocprofv3 kernel durations), the PMC "
+                 "passes and the sizes in profiles/%s_bench_config*.json; bench.py's own JSON line carries the same quantities from its "
+                 "live HIP-event brackets" % (tag, tag)}
+for c in cfgs:
+    b, st = bench(c), stats(c)
+    cfgd = b["config"]
+    n, M, P = cfgd["particles_per_gpu"], cfgd["metrics"], cfgd["params"]
+    K, Kp, Nn = cfgd["pred_prior_size"], cfgd["prev_pred_prior_size"], cfgd["next_set_size"]
+    ent = {"ms_per_step_bench": b["ms_per_step"], "set0_ms_per_step_bench": b["set0"]["ms_per_step"] if b.get("set0") else None}
+    kk = [k for k in st if k.startswith('k_kde_split')]
+    kde_ms = 0.0
+    if kk:
+        calls, ns = st[kk[0]]
+        kde_ms = ns / 1e6
+        pairs = float(K) * Kp
+        mf = 13 * ((P + 15) // 16) + 2
+        tf = pairs * mf * 32.0 / (ns * 1e-9) / 1e12
+        ent["roofline"] = {"kernel": kk[0], "bound": "mfma", "kernel_avg_ms": round(kde_ms, 4), "pairs_per_launch": pairs,
+                           "mfma_32x32x16_bf16_per_1024_pairs": mf, "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_PEAK_TF,
+                           "frac": round(tf / MFMA_PEAK_TF, 4), "traffic_hbm_bytes": traffic(c, 'k_kde_split')}
+        d = G + '%s_kde_c%d' % (pp, c)
+        if os.path.isdir(d):
+            cn = pmc(d, kernel='k_kde_split')
+            cyc = cn['GRBM_GUI_ACTIVE'] / 8
+            ent["roofline"].update({
+                "pmc": {k: round(v) for k, v in cn.items()}, "cycles_per_xcd": round(cyc),
+                "clock_ghz": round(cyc / ns, 3),
+                "mfma_busy_frac": round(cn.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / NSIMD / cyc, 3),
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs
+                "valu_active_frac_of_kernel_cycles": round(4 * cn.get('SQ_ACTIVE_INST_VALU', 0) / NSIMD / cyc, 3),
+                "valu_active_frac_of_2.4GHz_issue_peak": round(cn.get('SQ_ACTIVE_INST_VALU', 0) / (ns * 1e-9) / (NSIMD * 2.4e9 / 4), 3)})
+    # the wide Gram of the ranking: every k_gram* launch except the K x P moment pass of the posterior (k_gram<1, 0, ...>)
+    gk = [k for k in st if k.startswith('k_gram') and not k.startswith('k_gram<1, 0')]
+    ngen = sum(st[k][0] for k in st if k.startswith('k_project_dist'))          # one projection per generation
+    if gk and ngen:
+        gb = 8.0 * n * (M + P)
+        tot_ns = sum(st[k][1] * st[k][0] for k in gk) / ngen
+        ent["roofline_hbm"] = {"kernels": gk, "launches_per_step": sum(st[k][0] for k in gk) / ngen, "algorithmic_bytes_per_step": gb,
+                               "kernel_ms_per_step": round(tot_ns / 1e6, 5), "achieved_GBs": round(gb / tot_ns, 1),
+                               "peak_GBs": HBM_PEAK, "frac": round(gb / tot_ns / HBM_PEAK, 4), "traffic_hbm_bytes": traffic(c, 'k_gram<3')}
+
+    def alg(kp):
+        return 8.0 * n * (M + P) + 8.0 * n * M + 8.0 * n + 16.0 * n + 16.0 * K * P + Nn * (16.0 * P + 8.0) + 8.0 * kp * P + 8.0 * (K + kp)
+    sm = b["ms_per_step"] - b["roofline"]["kernel_ms"] * b["roofline"]["launches_per_step"]
+    ent["roofline_streaming"] = {"algorithmic_bytes_per_step": alg(Kp), "ms": round(sm, 5), "achieved_GBs": round(alg(Kp) / sm / 1e6, 1),
+                                 "frac": round(alg(Kp) / sm / 1e6 / HBM_PEAK, 4),
+                                 "note": "bench step time minus bench's pair-sum kernel bracket (the profiled pass is slower: rocprofv3 overhead)"}
+    if b.get("set0"):
+        s0 = b["set0"]["ms_per_step"]
+        ent["set0_roofline_streaming"] = {"algorithmic_bytes_per_step": alg(0), "ms": round(s0, 5),
+                                          "achieved_GBs": round(alg(0) / s0 / 1e6, 1), "frac": round(alg(0) / s0 / 1e6 / HBM_PEAK, 4)}
+    roof["config%d" % c] = ent
+json.dump(roof, open('profiles/%s_roofline.json' % tag, 'w'), indent=1)
+for c in cfgs:
+    e = roof["config%d" % c]
+    print("config", c, "step %.3f ms" % e["ms_per_step_bench"], "| kde", e.get("roofline", {}).get("kernel_avg_ms"), "ms frac",
+          e.get("roofline", {}).get("frac"), "clock", e.get("roofline", {}).get("clock_ghz"), "valu", e.get("roofline", {}).get("valu_active_frac_of_kernel_cycles"),
+          "| gram", e.get("roofline_hbm", {}).get("frac"), "| streaming", e["roofline_streaming"]["frac"], "| set0",
+          e.get("set0_roofline_streaming", {}).get("frac"))
