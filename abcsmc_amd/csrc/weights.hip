@@ -241,9 +241,10 @@ __global__ __launch_bounds__(256) void k_epan(const double* __restrict__ a, size
 // where hb_j = 1/2|b_j|^2 - log2 w'_j and ha_i = 1/2|a_i|^2 (each = Top, a multiple of 1/(4 U1), + Low) enter through
 // ONE more K-step whose operands hold the bf16 pieces of hb / ha against -1s / 1s on the other side.  X + Y is then
 // the whole base-2 exponent of the term (<= log2 w'_j), and the vector pipe only converts, adds and exponentiates:
-//   term = 2^floor(X) * 2^(fract(X) + Y)      7 instructions per pair instead of 30 (ks_exp2: f32 split + v_exp_f32, fp64 sum).
-// Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32); error of a term
-// with the f32 evaluation: 3e-8 rms, 1e-7 max.  Measured error of a weight against the oracle: see
+//   terms of a batch = 2^n * sum of 2^((X - n) + Y),  n = floor(max X of the batch)      5 issue slots per pair instead of 30
+//   (ks_slots: f32 subtract, add, v_exp_f32, f32 add; one fp64 scaling and add per 16 pairs).
+// Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32); error of a batch
+// sum (16 terms) with the f32 evaluation: 5e-8 rms, 2e-7 max (+ one ulp of v_exp_f32).  Measured error of a weight against the oracle: see
 // tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
 // Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400]) are "far": k_wsplit gives them
 // all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up kernels add
@@ -472,24 +473,6 @@ __global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__
     fix_j[i] = s;
 }
 
-// 2^(X + Y) for the split kernel.  X is exact in f32 (a multiple of 1/(4 U1) below 2^12), so n = floor(X) and fract(X) are
-// exact too, and
-//   2^(X + Y) = 2^n * 2^g,   g = fract(X) + Y   (one f32 rounding, <= 2^-24 absolute; |Y| is ~0.02, 0.25 at the very worst),
-// with 2^g from the hardware's v_exp_f32: measured on gfx950 over every float of [-0.3, 1.3] (scripts/exp2_hw_accuracy.hip)
-// max 8.2e-8, rms 2.6e-8, mean -2e-9 relative -- tighter than the degree-6 float polynomial it replaced (1.1e-7 / 3.8e-8).
-// Only the last three instructions are fp64: convert, ldexp (exponents down to 2^-1100 stay exact / flush to zero) and
-// the running sum.  7 vector instructions per pair (the transcendental issues in 8 cycles, the others in 4) against 14.5
-// fp64 ones for the all-fp64 evaluation of round 1 (2 converts, 3 adds for the split, 6 FMAs, ldexp, add).  Measured at
-// 1e10 pairs, P = 16: 5.7 ms (fp64) -> 4.4 ms (f32 polynomial) -> 3.6 ms (v_exp_f32); packed f32 FMAs for the polynomial
-// were slower than plain ones beside the MFMAs (4.6 ms), an f32 running sum flushed per batch would give another 4 %
-// and lose the range.
-__device__ __forceinline__ double ks_exp2(float X, float Y) {
-    int n;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(n) : "v"(X));       // the compiler would emit v_floor_f32 + v_cvt_i32_f32
-    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fractf(X) + Y);
-    return ldexp((double)e, n);
-}
-
 // The 13 limb cross-products of one 16-parameter chunk, in issue order: which accumulator, which limb of the previous
 // (A operand) and of the new (B operand) particle.  X takes the three products that are multiples of 1/(4 U1); the two
 // chains alternate at the start so that no MFMA waits for the one just issued.
@@ -525,25 +508,59 @@ __device__ __forceinline__ void ks_mfma_range(const bf16x8* A, const bf16x8* B, 
 // batch's MFMAs (into Xn, Yn), then exponentiates G elements of the finished batch (Xc, Yc).  A wave issues in order
 // and an MFMA occupies the matrix pipe for 32 cycles, so 15 of them in a row would hold the wave's own exponentials
 // back for ~480 cycles; spread over the slots they keep both pipes of the SIMD fed from a single wave.
+// The vector side, 2^(X + Y) summed over the batch: the 16 terms a lane owns of one 32 x 32 block share ONE power of two,
+// n = floor(max X) over the lane's 16 exponents (8 v_max3_f32); every term is 2^((X - n) + Y) straight from v_exp_f32 --
+// X - n is exact (both are multiples of 1/(4 U1) below 2^12; where |X - n| reaches 2^12 the term is 2^-4096 of the batch's
+// largest), the add rounds once at 2^-24 |g| with g < 1.25 for the terms that carry the sum; the hardware's 2^g measured on
+// gfx950 over every float of [-0.3, 1.3] (scripts/exp2_hw_accuracy.hip): max 8.2e-8, rms 2.6e-8 relative -- the 16 terms
+// are added in f32 (four chains of four, then a tree: <= 5 roundings on a term's path) and ONE convert / v_ldexp_f64 /
+// fp64 add per batch takes the partial sum to the lane's running fp64 sum (exponents down to 2^-1100 stay exact / flush to
+// zero).  Terms more than 2^126 below their batch's largest flush to zero.  Per pair: v_sub_f32, v_add_f32, v_exp_f32,
+// v_add_f32 = 5 issue slots (the transcendental counts two) + 1 of batch overhead, against 8 for the per-pair form of the
+// first half of round 2 (floor, fract, add, exp, convert, ldexp, fp64 add) and 14.5 fp64 instructions in round 1.  Error
+// of a batch sum (scripts/split_precision.py): rms 4.6e-8, max 2.0e-7 relative (P <= 16; 5.0e-8 / 2.2e-7 at P <= 32).
+// Measured at 1e10 pairs, P = 16, same box: 3.85 ms (per-pair form) -> 3.51 ms; 620 cycles per 1024 pairs and SIMD at
+// the power-limited 1.70 GHz, matrix pipe 0.78 busy, vector issue 0.73 (PMC).
+__device__ __forceinline__ float ks_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // (fmaxf would canonicalise its inputs first)
+    return r;
+}
+struct KsRef { float nf; int n; float p0, p1, p2, p3; };
 template <int NCH, int G, int R>
 __device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32x16& Xn, f32x16& Yn,
-                                         const f32x16& Xc, const f32x16& Yc, double& s) {
+                                             const f32x16& Xc, const f32x16& Yc, double& s, KsRef& q) {
     if constexpr (R < 16 / G) {
-        // the MFMAs go into the first 14 / G slots, so the last results are ready when the next batch's first slot reads them
         constexpr int NS = ks_nsteps(NCH), SL = 14 / G;
         constexpr int s0 = (R < SL) ? (R * NS) / SL : NS, s1 = (R < SL) ? ((R + 1) * NS) / SL : NS;
-        // Empty asm "uses" of the accumulators written in EARLIER slots (X from step 0, Y from step 1 on) and of the
-        // running sum: without them the optimiser sinks matrix work whose results are only consumed in the next loop
-        // iteration, and the sums, to the end of the loop body.  A slot later the result has long been written: no wait.
         if constexpr (s0 > 0 && s0 < NS) asm volatile("" : "+v"(Xn));
         if constexpr (s0 > 1 && s0 < NS) asm volatile("" : "+v"(Yn));
         ks_mfma_range<NCH, s0, s1>(An, Bn, Xn, Yn);
-        if constexpr (G == 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (R == 0) {
+            const float m0 = ks_max3(Xc[0], Xc[1], Xc[2]), m1 = ks_max3(Xc[3], Xc[4], Xc[5]), m2 = ks_max3(Xc[6], Xc[7], Xc[8]),
+                        m3 = ks_max3(Xc[9], Xc[10], Xc[11]), m4 = ks_max3(Xc[12], Xc[13], Xc[14]);
+            const float m = ks_max3(ks_max3(m0, m1, m2), ks_max3(m3, m4, Xc[15]), Xc[15]);
+            q.nf = __builtin_floorf(m);
+            q.n = (int)q.nf;
+        }
 #pragma unroll
-        for (int g = 0; g < G; g++) s += ks_exp2(Xc[R * G + g], Yc[R * G + g]);
-        asm volatile("" : "+v"(s));
+        for (int g = 0; g < G; g++) {
+            const int i = R * G + g;
+            const float e = __builtin_amdgcn_exp2f((Xc[i] - q.nf) + Yc[i]);
+            float& p = (i & 3) == 0 ? q.p0 : (i & 3) == 1 ? q.p1 : (i & 3) == 2 ? q.p2 : q.p3;
+            if (i < 4) p = e; else p += e;
+        }
+        if constexpr (R == 16 / G - 1) {
+            float t = q.p0 + q.p1;
+            asm volatile("" : "+v"(t));                       // (keeps the two adds from being packed: v_pk_add_f32 beside MFMAs costs more)
+            t += q.p2 + q.p3;
+            s += ldexp((double)t, q.n);
+            asm volatile("" : "+v"(s));
+        } else {
+            asm volatile("" : "+v"(q.p0), "+v"(q.p1), "+v"(q.p2), "+v"(q.p3));
+        }
         __builtin_amdgcn_sched_barrier(0);
-        ks_slots<NCH, G, R + 1>(An, Bn, Xn, Yn, Xc, Yc, s);
+        ks_slots<NCH, G, R + 1>(An, Bn, Xn, Yn, Xc, Yc, s, q);
     }
 }
 
@@ -583,8 +600,9 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4
 #pragma unroll
             for (int q = 0; q < OPB; q++) An[q] = __builtin_bit_cast(bf16x8, bt[((size_t)tn * OPB + q) * 64 + lane]);
             __builtin_amdgcn_sched_barrier(0);
-            ks_slots<NCH, G, 0>(A, B1, X1, Y1, X0, Y0, acc0);       // matrix: (t, columns 1); vector: (t, columns 0)
-            ks_slots<NCH, G, 0>(An, B0, X0, Y0, X1, Y1, acc1);      // matrix: (t+1, columns 0); vector: (t, columns 1)
+            KsRef q;
+            ks_slots<NCH, G, 0>(A, B1, X1, Y1, X0, Y0, acc0, q);      // matrix: (t, columns 1); vector: (t, columns 0)
+            ks_slots<NCH, G, 0>(An, B0, X0, Y0, X1, Y1, acc1, q);     // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
             for (int q = 0; q < OPB; q++) A[q] = An[q];       // (two tiles per trip with A / An trading places: no gain, measured)
         }
@@ -786,7 +804,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
     hipLaunchKernelGGL((k_kde_split<NCHV, GV>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, \
                        (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, part)
-            if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot
+            if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot (one: +1 %, four: +5 %)
             else LAUNCH_SPLIT(2, 2);
 #undef LAUNCH_SPLIT
         }

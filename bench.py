@@ -191,8 +191,9 @@ def main():
 
     # ---- roofline of the DOMINANT kernel: the pair sums of the importance weights (k_kde_split / k_kde) ------------------
     # Two kernels can run them.  k_kde_split: pair dot products as exact bf16 limb products on the
-    # matrix pipe -- 13 ceil(P/16) + 2 v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs = 32 flop per pair and MFMA -- and 7 vector
-    # instructions per pair (floor, fract, add, v_exp_f32 [8 issue cycles], convert, ldexp, fp64 add) = 8 issue slots.
+    # matrix pipe -- 13 ceil(P/16) + 2 v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs = 32 flop per pair and MFMA -- and 4 vector
+    # instructions per pair (subtract, add, v_exp_f32 [8 issue cycles], f32 add) + 12 per batch of 16 pairs (8 v_max3_f32,
+    # floor, two converts, v_ldexp_f64, fp64 add, tree adds) = 5.75 issue slots per pair.
     # k_kde (fp64 fallback): 1 add + PP FMAs + 13 for 2^x per pair, no matrix work.
     kde_bracket_ms, kde_launches = per_launch_ms("k_kde") if Kp else (0.0, 0)
     kde_ms = max(kde_bracket_ms - event_overhead_ms, 0.0)
@@ -205,7 +206,7 @@ def main():
     if which == _lib.KDE_RAN_SPLIT:
         mfma_per_block = 13 * ((P + 15) // 16) + 2
         flops = pairs * mfma_per_block * 32.0          # 32 x 32 x 16 x 2 flop per MFMA over 1024 pairs
-        slots_per_pair = 8.0
+        slots_per_pair = 5.75
         achieved_tf = flops / (kde_ms * 1e-3) / 1e12 if kde_ms > 0 else 0.0
         roofline = {"kernel": "k_kde_split", "bound": "mfma", "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_PEAK_TF,
                     "unit": "TFLOP/s", "frac": round(achieved_tf / MFMA_BF16_PEAK_TF, 4),

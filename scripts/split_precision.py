@@ -3,9 +3,9 @@ the pair dot product a.b (= error of the base-2 exponent of a term) against fp64
 ones.  Limbs: l0 = rint(4 v)/4, l1 = rint(U1 (v - l0))/U1, then bf16 roundings of what is left.  X = l0.l0' + l0.l1' + l1.l0'
 is accumulated exactly (every partial sum is a multiple of 1/(4 U1) below 2^24/(4 U1)); Y = the remaining products goes
 through an f32 accumulator, emulated here with ONE rounding per added product (pessimistic: the MFMA rounds less often).
-For the shipped split the f32 evaluation of the term (ks_exp2: X = n + fract(X) exactly, g = fract + Y in f32, 2^g in f32,
-then an exact scaling by 2^n) is emulated as well and the RELATIVE error of
-2^(a.b) reported: that, not the exponent error, is what a weight inherits.
+For the shipped split the f32 evaluation of the terms (ks_slots_ref: the 16 terms of a lane's batch share n = floor(max X),
+g = (X - n) + Y in f32, 2^g in f32, an f32 sum of the 16, then an exact scaling by 2^n) is emulated as well and the RELATIVE
+error of the batch sums reported: that, not the exponent error, is what a weight inherits.
     python scripts/split_precision.py [P] [n]"""
 import sys
 
@@ -54,15 +54,26 @@ cases = [("shipped: 4 limbs, 13 products", 4, full),
          ("3 limbs, 9 products", 3, [(2, 2), (2, 1), (1, 2), (2, 0), (0, 2), (1, 1)]),
          ("5 limbs, 15 products", 5, [(4, 0), (0, 4)] + full)]
 def term_f32(X, Y32):
-    """ks_exp2 of weights.hip: n = floor(X) and fract(X) exact in f32, g = fract + Y rounded to f32, 2^g from the hardware's
-    v_exp_f32 -- emulated here by the correctly rounded float of exp2(g); the hardware adds at most one more ulp
-    (measured 8.2e-8 max / 2.6e-8 rms relative on [-0.3, 1.3], scripts/exp2_hw_accuracy.hip) -- then an exact scaling by 2^n"""
+    """ks_slots_ref of weights.hip: the 16 terms a lane owns of one 32 x 32 block share n = floor(max X); every term is
+    2^((X - n) + Y) with X - n exact and one f32 rounding in the add, 2^g from the hardware's v_exp_f32 -- emulated here by
+    the correctly rounded float of exp2(g); the hardware adds at most one more ulp (measured 8.2e-8 max / 2.6e-8 rms relative
+    on [-0.3, 1.3], scripts/exp2_hw_accuracy.hip) --, the 16 terms are added in f32 (four chains of four, then (p0 + p1) +
+    (p2 + p3)) and the batch sum is scaled by 2^n exactly.  Returns the batch sums (rows x columns / 16) and g."""
     Xf = X.astype(np.float32)
     assert np.array_equal(Xf.astype(np.float64), X)
-    nfl = np.floor(Xf)
-    g = ((Xf - nfl).astype(np.float32) + Y32).astype(np.float32)
-    pv = np.exp2(g.astype(np.float64)).astype(np.float32)
-    return np.ldexp(pv.astype(np.float64), nfl.astype(np.int64)), g
+    r, c = Xf.shape
+    c16 = c // 16 * 16
+    Xb, Yb = Xf[:, :c16].reshape(r, -1, 16), Y32[:, :c16].reshape(r, -1, 16)
+    nfl = np.floor(Xb.max(axis=2, keepdims=True)).astype(np.float32)
+    d = (Xb - nfl).astype(np.float32)
+    assert np.array_equal(d.astype(np.float64), Xb.astype(np.float64) - nfl.astype(np.float64)), "X - n is not exact in f32"
+    g = (d + Yb).astype(np.float32)
+    e = np.exp2(g.astype(np.float64)).astype(np.float32)
+    p = [e[:, :, k] for k in range(4)]
+    for i in range(4, 16):
+        p[i & 3] = (p[i & 3] + e[:, :, i]).astype(np.float32)
+    t = ((p[0] + p[1]).astype(np.float32) + (p[2] + p[3]).astype(np.float32)).astype(np.float32)
+    return np.ldexp(t.astype(np.float64), nfl[:, :, 0].astype(np.int64)), g
 
 
 print("P = %d, %d x %d pairs, U1 = %g" % (P, n, n, U1))
@@ -80,6 +91,7 @@ for name, nl, pairs in cases:
         name, (3 + len(pairs)) * ((P + 15) // 16) + 2, np.sqrt((e_tr ** 2).mean()), e_tr.max(), np.sqrt((e_all ** 2).mean()), e_all.max()))
     if name.startswith("shipped"):
         t, g = term_f32(X, Y)
-        rel = np.abs(t / np.exp2(ref) - 1.0)
-        print("   f32 term 2^(a.b) of the shipped split: relative error rms %.2e max %.2e mean %.2e;  g = fract + Y in [%.3f, %.3f]" % (
-            np.sqrt((rel ** 2).mean()), rel.max(), (t / np.exp2(ref) - 1.0).mean(), g.min(), g.max()))
+        exact = np.exp2(ref)[:, :t.shape[1] * 16].reshape(n, -1, 16).sum(axis=2)
+        rel = np.abs(t / exact - 1.0)
+        print("   f32 term sums (16 terms 2^(a.b) per batch) of the shipped split: relative error rms %.2e max %.2e mean %.2e;  g = X - n + Y in [%.3f, %.3f]" % (
+            np.sqrt((rel ** 2).mean()), rel.max(), (t / exact - 1.0).mean(), g.min(), g.max()))
