@@ -31,8 +31,11 @@ struct abc_ctx {
     double* alias_F;
     uint32_t* alias_A;
     size_t alias_K;
-    uint64_t alias_tag;
-    bool alias_valid;
+    // alias table of K equal weights 1/K (set 0, AbcUtil.cpp:539-545): built once per K, kept (abc_uniform_alias)
+    double* ualias_F;
+    uint32_t* ualias_A;
+    size_t ualias_cap, ualias_K;
+    char* ualias_pin;      // its own pinned staging (the upload is asynchronous: the shared scratch may be reused before it ran)
     hipEvent_t ev_copy;    // marks the end of the weights' device-to-host copy (the host waits on it, not on the stream)
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
@@ -209,8 +212,14 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
                      int* status_dev);
 // while_host_builds (optional): called after the weights' copy to the host has been queued and before the host waits for it:
 // GPU work launched there runs while the host builds the alias table
+// uniform_weights: w is K copies of 1.0 / K (launch_fill): the table comes from abc_uniform_alias, no host round trip here
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
-                    uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr);
+                    uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr,
+                    bool uniform_weights = false);
+// Alias table of K equal weights: gsl_ran_discrete_preproc on K copies of 1.0 / K (bit-identical to the table of the filled
+// weight vector), built on the host on first use for this K and kept in HBM.  The fused drivers call it right after queueing
+// the ranking kernels, so the host builds the table while the GPU ranks.
+int abc_uniform_alias(abc_ctx* ctx, size_t K);
 // what launch_perturb_prepare has already done: row-major posterior copy, seeds, first-attempt noise (n x P) + rejection list
 struct abc_perturb_prep { double* rows; int seeds_done; double* noise; unsigned* list; };
 // multivariate / L_or_dv (optional): with them the first-attempt noise of all n proposals is generated as well

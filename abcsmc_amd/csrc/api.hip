@@ -89,6 +89,8 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->alias_F) (void)hipFree(ctx->alias_F);       // alias_A lives in the same allocation
+    if (ctx->ualias_F) (void)hipFree(ctx->ualias_F);
+    if (ctx->ualias_pin) (void)hipHostFree(ctx->ualias_pin);
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
     if (ctx->kde_which) (void)hipFree(ctx->kde_which);
     if (ctx->giveups_dev) (void)hipFree(ctx->giveups_dev);
@@ -449,6 +451,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist));
+    // first set: the weights will be 1/K whatever the ranking says, so the host builds their alias table now, while the GPU ranks
+    const bool uniform_w = io->w && (Kp == 0 || !io->theta_prev);
+    if (uniform_w && Nn) ABC_TRY(abc_uniform_alias(ctx, K));
     if (!simple && ncomp_host && !io->w) {
         double hdr[4];
         ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
@@ -510,7 +515,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa));
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w));
         if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {
             taus2_jump(rng, (uint64_t)Nn);   // the Nnext resampling draws; the host loop consumes the rest as the reference does
             ABC_TRY(launch_perturb_reference(ctx, rng, theta, K, P, io->priors, parent, Nn, cfg->multivariate,

@@ -482,10 +482,58 @@ int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
 
 }  // namespace
 
+int abc_uniform_alias(abc_ctx* ctx, size_t K) {
+    if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
+    if (ctx->ualias_K == K) return ABC_OK;
+    ctx->ualias_K = 0;
+    if (ctx->ualias_cap < K) {
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ualias_F) { (void)hipFree(ctx->ualias_F); ctx->ualias_F = nullptr; }
+        if (ctx->ualias_pin) { (void)hipHostFree(ctx->ualias_pin); ctx->ualias_pin = nullptr; }
+        ctx->ualias_cap = 0;
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->ualias_F, K * (sizeof(double) + sizeof(uint32_t))));
+        ABC_HIP(ctx, hipHostMalloc((void**)&ctx->ualias_pin, K * (sizeof(double) + sizeof(uint32_t)), hipHostMallocDefault));
+        ctx->ualias_cap = K;
+    }
+    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 2 + sizeof(uint32_t) * 2) + 2 * sizeof(uint32_t)));
+    double* hw = (double*)ctx->pin;                        // host-only scratch of the build
+    double* hE = hw + K;
+    uint32_t* hS = (uint32_t*)(hE + K);
+    uint32_t* hB = hS + K + 1;
+    double* hF = (double*)ctx->ualias_pin;                 // the tables, F[K] then A[K]: uploaded from their own staging buffer
+    uint32_t* hA = (uint32_t*)(hF + K);
+    const double v = 1.0 / (double)K;                      // what launch_fill writes (AbcUtil.cpp:543-544)
+    for (size_t k = 0; k < K; k++) hw[k] = v;
+    const auto t0 = std::chrono::steady_clock::now();
+    abc_alias_preproc(K, hw, hF, hA, hE, hS, hB);
+    if (ctx->timing) {
+        ctx->stage_host_ms[ST_ALIAS_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->stage_cnt[ST_ALIAS_HOST] += 1;
+    }
+    ctx->ualias_A = (uint32_t*)(ctx->ualias_F + K);
+    ABC_HIP(ctx, hipMemcpyAsync(ctx->ualias_F, hF, K * (sizeof(double) + sizeof(uint32_t)), hipMemcpyHostToDevice, ctx->stream));
+    ctx->ualias_K = K;
+    return ABC_OK;
+}
+
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
-                    uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg) {
+                    uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights) {
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
+    if (uniform_weights) {
+        ABC_TRY(abc_uniform_alias(ctx, K));               // (already built by the fused drivers; here for any other caller)
+        uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+        if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
+        abc_rng base = *rng;
+        taus2_jump(&base, i0);
+        StageTimer tm(ctx, ST_RESAMPLE);
+        ABC_TRY(taus_stream(ctx, base, n, raw));
+        if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));
+        hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->ualias_F,
+                           ctx->ualias_A, K, (unsigned long long*)parent);
+        ABC_HIP(ctx, hipGetLastError());
+        return ABC_OK;
+    }
     // alias table: weights to the host, serial Walker build, tables back to HBM
     ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
     double* hw = (double*)ctx->pin;

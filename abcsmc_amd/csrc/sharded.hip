@@ -298,6 +298,9 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     if (cfg->rule == ABC_RULE_WILCOXON)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, (size_t)ntrain, model));
     ABC_TRY(launch_project_distance(ctx, io->X, n, n, M, P, A, model, 0, dist));
+    // first set: uniform weights, their alias table is built by the host while the GPU ranks
+    const bool uniform_w = (Kp == 0 || !io->theta_prev);
+    if (uniform_w && Nn) ABC_TRY(abc_uniform_alias(ctx, K));
 
     // ---- 3-5: the K smallest distances of the whole set, their rows ---------------------------------------------------------
     double* theta = io->theta ? io->theta : (double*)abc_ws_alloc(ctx, K * P * 8);
@@ -419,7 +422,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa));
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w));
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,
                                cfg->multivariate ? L : dv, io->next, io->seeds, cfg->Nnext_total, &prep));
     } else if (cfg->multivariate && io->L) {

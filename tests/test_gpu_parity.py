@@ -739,6 +739,19 @@ def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp):
             assert nxt[:, p].min() >= a and nxt[:, p].max() <= b
 
 
+def test_first_set_alias_table_is_kept_per_size(gpu_ctx, oracle):
+    """set 0 (uniform weights, AbcUtil.cpp:539-545): the alias table of K equal weights is built while the GPU ranks and kept
+    for the next call with the same K; a different K, and a weighted set in between, must not see a stale table"""
+    N, M, P, Nn, A = 3000, 12, 5, 3000, 4
+    for K, Kp in [(400, 0), (400, 0), (250, 0), (400, 300), (250, 0), (400, 0)]:
+        wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+        o = oracle.rng(67890)
+        ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A,
+                                multivariate=True)
+        assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"]), (K, Kp)
+        assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
+
+
 def test_generation_full_size_properties(gpu_ctx):
     """BASELINE config 2 size (N = 1e5, M = 32, P = 16, A = 8): size-independent invariants."""
     from abcsmc_amd import device
