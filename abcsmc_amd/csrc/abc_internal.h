@@ -220,9 +220,9 @@ int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uin
 // weight vector), built on the host on first use for this K and kept in HBM.  The fused drivers call it right after queueing
 // the ranking kernels, so the host builds the table while the GPU ranks.
 int abc_uniform_alias(abc_ctx* ctx, size_t K);
-// what launch_perturb_prepare has already done: row-major posterior copy, seeds, first-attempt noise (n x P) + rejection list
-struct abc_perturb_prep { double* rows; int seeds_done; double* noise; unsigned* list; };
-// multivariate / L_or_dv (optional): with them the first-attempt noise of all n proposals is generated as well
+// what launch_perturb_prepare has already done: row-major posterior copy, seeds, the padded Cholesky factor
+struct abc_perturb_prep { double* rows; int seeds_done; double* Lpad; };
+// multivariate / L_or_dv (optional): with them the factor is padded for the perturbation kernel as well
 int launch_perturb_prepare(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
                            uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate = 0,
                            const double* L_or_dv = nullptr);

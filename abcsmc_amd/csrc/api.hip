@@ -58,7 +58,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
-    b += Nnext * (P * 8 + 4) + 4096;                              // first-attempt noise of the proposals, rejection list
+    b += 64 * 64 * 8 + 4096;                                      // padded Cholesky factor of the proposals
     b += 64 * 256;                                                // alignment slack
     return b + (4u << 20);
 }
@@ -494,7 +494,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // The alias-table host round trip sits inside launch_resample.  What does not depend on the weights runs on the GPU
         // meanwhile: the MVN factor (covariance + Cholesky), the row-major posterior copy and the seed stream of the
         // perturbation.
-        abc_perturb_prep prep = {nullptr, 0, nullptr, nullptr};
+        abc_perturb_prep prep = {nullptr, 0, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
@@ -511,7 +511,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                 }
             }
             if (q->ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) return ABC_OK;     // nothing of the device stream is needed
-            // ... and the first-attempt noise of every proposal (it needs the factor, not the parents)
+            // ... and the row-major posterior copy, the padded factor and the seeds of the proposals
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };

@@ -149,16 +149,25 @@ __device__ __forceinline__ U4 philox(U4 c, uint32_t k0, uint32_t k1) {
     }
     return c;
 }
-__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // (0,1), 53 bits
-    return ((double)(((unsigned long long)(hi >> 5) << 26) | (lo >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
-}
-// two independent N(0,1) from one Philox block
-__device__ __forceinline__ void normal2(U4 r, double& z0, double& z1) {
-    const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);        // exact argument reduction in units of pi: no large-argument slow path
-    z0 = rad * c; z1 = rad * s;
+// FOUR independent N(0,1) from one Philox block: two Box-Muller pairs on the f32 transcendental hardware (v_log_f32,
+// v_sqrt_f32, v_sin_f32 / v_cos_f32, 8 issue cycles each) instead of double-precision library calls -- the fp64 log, sqrt and
+// sincospi of round 1 were ~300 vector instructions per pair and made the noise kernels compute-bound (71 us for 1.6e7
+// deviates); this is ~20 per pair plus half a Philox block.  The radius comes from all 32 bits of its word,
+//   -2 ln u = -2 ln 2 (log2(r + 1/2) - 32),   u in [2^-33, 1):  |z| <= 6.76,
+// (the conversion of r to f32 rounds at 6e-8 relative: 9e-8 absolute in the logarithm), the angle from the top 24 bits of
+// its word, in revolutions (what v_sin_f32 / v_cos_f32 take).  The deviates carry f32 rounding (~1e-7 relative): the device
+// noise stream is distributional by contract (declared deviations); the reference-stream mode is untouched.
+__device__ __forceinline__ void normal4(U4 r, double (&z)[4]) {
+    const float NEG2LN2 = -1.3862943611198906f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t ru = h ? r.z : r.x, ra = h ? r.w : r.y;
+        const float lg = __builtin_amdgcn_logf((float)ru + 0.5f) - 32.0f;           // log2 u, in [-33, 0)
+        const float rad = __builtin_amdgcn_sqrtf(__builtin_fmaxf(NEG2LN2 * lg, 0.0f));   // (v_log_f32 may return 32 + 1 ulp at the top)
+        const float ang = (float)(ra >> 8) * 5.9604644775390625e-08f;             // [0, 1) revolutions, exact
+        z[2 * h] = (double)(rad * __builtin_amdgcn_cosf(ang));
+        z[2 * h + 1] = (double)(rad * __builtin_amdgcn_sinf(ang));
+    }
 }
 
 __device__ __forceinline__ double d_recast(const abc_prior& pr, double v) {          // Priors.h:58,80,106
@@ -175,6 +184,21 @@ __device__ __forceinline__ bool d_valid(const abc_prior& pr, double v) {        
     if (pr.kind == ABC_PRIOR_UNIF_INT) return (v == round(v)) && (pr.a <= v) && (v <= pr.b);
     return (pr.a <= v) && (v <= pr.b);
 }
+// recast + support test of one coordinate in the proposal loop.  The prior of a coordinate is the same in every lane: its
+// kind goes through an SGPR, so only the code of that kind runs (scalar branches), and the Gaussian support test
+// (likelihood != 0, i.e. |u| below ~38.6) multiplies by 1 / |sigma| first: t^2 < 1399 implies u^2 < 1400 for u = (v - a) / |sigma|
+// (the two differ by rounding only), which d_valid accepts without evaluating anything; the exact test runs at the edge.
+__device__ __forceinline__ double recast_valid(const abc_prior& pr, double inv_sigma, double v, bool& ok) {
+    const int kind = __builtin_amdgcn_readfirstlane(pr.kind);
+    if (kind == ABC_PRIOR_GAUSS) {
+        const double t = (v - pr.a) * inv_sigma;
+        if (!(t * t < 1399.0 && inv_sigma != 0.0)) ok = ok && d_valid(pr, v);
+        return v;
+    }
+    if (kind == ABC_PRIOR_UNIF_INT) v = round(v);               // Priors.h:80; v == round(v) then holds by construction
+    ok = ok && (pr.a <= v) && (v <= pr.b);
+    return v;
+}
 __device__ __forceinline__ double d_prior_mean(const abc_prior& pr) {                 // Priors.h:35
     return (pr.kind == ABC_PRIOR_GAUSS) ? pr.a : (pr.b + pr.a) / 2.0;
 }
@@ -182,11 +206,20 @@ __device__ __forceinline__ double d_prior_mean(const abc_prior& pr) {           
 constexpr unsigned MVN_MAX_TRIES = 1u << 14;   // the reference retries for ever (AbcUtil.cpp:132); bounded here
 
 // theta (K x P column-major) -> row-major K x PP, zero padded: a parent row is then one contiguous PP*8-byte line
-// instead of P strided 8-byte reads that each pull a whole 64-byte sector (PMC: 1.2 GB fetched for 128 MB used)
+// instead of P strided 8-byte reads that each pull a whole 64-byte sector (PMC: 1.2 GB fetched for 128 MB used).
+// Block 0 also pads the Cholesky factor (P x P, lower) to Lpad (PP x PP, column-major, zero above the diagonal and in the
+// padding): k_perturb streams it through the scalar cache.
 template <int PP>
 __global__ __launch_bounds__(256) void k_theta_rows(const double* __restrict__ theta, size_t K, int P,
-                                                    double* __restrict__ rows) {
+                                                    double* __restrict__ rows, const double* __restrict__ L,
+                                                    double* __restrict__ Lpad) {
     __shared__ double t[PP][65];
+    if (blockIdx.x == 0 && L) {
+        for (int e = threadIdx.x; e < PP * PP; e += 256) {
+            const int a = e % PP, b = e / PP;
+            Lpad[e] = (a < P && b < P && b <= a) ? L[a + (size_t)P * b] : 0.0;
+        }
+    }
     const size_t k0 = (size_t)blockIdx.x * 64;
     for (int e = threadIdx.x; e < PP * 64; e += 256) {
         const int p = e >> 6, r = e & 63;
@@ -199,161 +232,100 @@ __global__ __launch_bounds__(256) void k_theta_rows(const double* __restrict__ t
     }
 }
 
-// The Gaussian noise of one proposal attempt, L z (multivariate) -- one Philox block -> two normals -> two columns of L.
-// L is lower triangular: the column pairs of its right half are zero in rows < PP/2, so the second loop only touches the
-// lower half of x (a quarter of the FMAs).  Shared by the first-attempt noise kernel and the rejection loop: same counters,
-// same operation order, same bits.
+// The Gaussian noise of one proposal attempt, L z (multivariate) -- one Philox block -> four normals -> four columns of L.
+// L is lower triangular: the columns of its right half are zero in rows < PP/2, so their blocks only touch the lower half
+// of x (a quarter of the FMAs).  sL: the padded factor (k_theta_rows), wave-uniform addresses: in k_perturb it lives in
+// global memory and arrives through the scalar cache as SGPR operands of the FMAs (from LDS every FMA needed its own
+// broadcast read: 192 LDS instructions per attempt at 16 parameters).
 template <int PP>
 __device__ __forceinline__ void mv_noise(const double* __restrict__ sL, unsigned long long gi, unsigned attempt, uint32_t k0,
                                          uint32_t k1, double (&x)[PP]) {
 #pragma unroll
     for (int a = 0; a < PP; a++) x[a] = 0.0;
-#pragma unroll 1
-    for (int pr = 0; pr < (PP + 2) / 4; pr++) {      // ceil(PP/4) pairs = columns below PP/2 (all of them for PP = 2)
-        U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
-        double z0, z1;
-        normal2(philox(c, k0, k1), z0, z1);
-        const double* l0 = sL + PP * (2 * pr);
-        const double* l1 = l0 + PP;
+    if constexpr (PP < 4) {
+        U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0u;
+        double z[4];
+        normal4(philox(c, k0, k1), z);
 #pragma unroll
-        for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
-    }
-#pragma unroll 1
-    for (int pr = (PP + 2) / 4; pr < PP / 2; pr++) {
-        U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
-        double z0, z1;
-        normal2(philox(c, k0, k1), z0, z1);
-        const double* l0 = sL + PP * (2 * pr);
-        const double* l1 = l0 + PP;
+        for (int b = 0; b < PP; b++)
 #pragma unroll
-        for (int a = PP / 2; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
+            for (int a = 0; a < PP; a++) x[a] = fma(sL[PP * b + a], z[b], x[a]);
+    } else {
+        // columns 4 qd .. 4 qd + 3 of L per Philox block; L is lower triangular, so the blocks of its right half only touch
+        // the lower half of x
+#pragma unroll 1
+        for (int qd = 0; qd < PP / 4; qd++) {
+            U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)qd;
+            double z[4];
+            normal4(philox(c, k0, k1), z);
+            const double* l = sL + PP * (4 * qd);
+            if (qd < (PP / 4 + 1) / 2) {
+#pragma unroll
+                for (int a = 0; a < PP; a++) {
+                    x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
+                    x[a] = fma(l[2 * PP + a], z[2], x[a]); x[a] = fma(l[3 * PP + a], z[3], x[a]);
+                }
+            } else {
+#pragma unroll
+                for (int a = PP / 2; a < PP; a++) {
+                    x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
+                    x[a] = fma(l[2 * PP + a], z[2], x[a]); x[a] = fma(l[3 * PP + a], z[3], x[a]);
+                }
+            }
+        }
     }
 }
 // independent noise of coordinate p: sqrt(dv_p) z
 __device__ __forceinline__ double indep_noise(double sigma, unsigned long long gi, unsigned attempt, int p, uint32_t k0, uint32_t k1) {
     U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0x80000000u | (uint32_t)p;
-    double z0, z1;
-    normal2(philox(c, k0, k1), z0, z1);
-    return sigma * z0;
+    double z[4];
+    normal4(philox(c, k0, k1), z);
+    return sigma * z[0];
 }
+// one new particle per lane
 template <int PP, bool MV>
-__device__ __forceinline__ void load_factor(double* sL, const double* __restrict__ L_or_dv, int P) {
-    for (int e = threadIdx.x; e < PP * PP; e += 256) {
-        const int a = e % PP, b = e / PP;
-        double v = 0.0;
-        if (MV) { if (a < P && b < P && b <= a) v = L_or_dv[a + (size_t)P * b]; }
-        else if (a == b && a < P) v = sqrt(L_or_dv[a]);
-        sL[e] = v;
-    }
-}
-
-// First-attempt noise of every proposal, noise[i + n p]: it does not depend on the parent, so the fused driver generates it
-// while the host builds the alias table (launch_perturb_prepare); what is left behind the table is a streaming pass
-// (k_perturb_fast) plus the rejection loop of the few rows whose first attempt fell outside the prior support.
-template <int PP, bool MV>
-__global__ __launch_bounds__(256) void k_noise_first(abc_rng key, int P, unsigned long long i0, size_t n,
-                                                     const double* __restrict__ L_or_dv, double* __restrict__ noise) {
-    __shared__ double sL[PP * PP];
-    load_factor<PP, MV>(sL, L_or_dv, P);
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long gi = i0 + i;
-    const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
-    if (MV) {
-        double x[PP];
-        mv_noise<PP>(sL, gi, 0u, k0, k1, x);
-#pragma unroll
-        for (int p = 0; p < PP; p++) if (p < P) noise[i + n * (size_t)p] = x[p];
-    } else {
-#pragma unroll
-        for (int p = 0; p < PP; p++) if (p < P) noise[i + n * (size_t)p] = indep_noise(sL[p + PP * p], gi, 0u, p, k0, k1);
-    }
-}
-
-// proposal = recast(parent + first-attempt noise) where every coordinate is valid; the other rows go on the list of the
-// rejection loop (k_perturb with a row list: the same draws from attempt 0 on, i.e. the same result as without the split)
-template <int PP>
-__global__ __launch_bounds__(256) void k_perturb_fast(const double* __restrict__ rows, int P, const abc_prior* __restrict__ priors,
-                                                      const unsigned long long* __restrict__ parent, size_t n,
-                                                      const double* __restrict__ noise, double* __restrict__ out,
-                                                      unsigned* __restrict__ list, unsigned* __restrict__ count) {
-    __shared__ abc_prior sp[PP];
-    for (int p = threadIdx.x; p < PP; p += 256) {
-        abc_prior q; q.kind = ABC_PRIOR_UNIF_REAL; q.pad_ = 0; q.a = -1e300; q.b = 1e300;
-        sp[p] = (p < P) ? priors[p] : q;
-    }
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t par = (size_t)parent[i];
-    double val[PP];
-    bool ok = true;
-#pragma unroll
-    for (int p = 0; p < PP; p += 2) {
-        const double2 m = *reinterpret_cast<const double2*>(rows + par * PP + p);
-        const double e0 = (p < P) ? __builtin_nontemporal_load(&noise[i + n * (size_t)p]) : 0.0;
-        const double e1 = (p + 1 < P) ? __builtin_nontemporal_load(&noise[i + n * (size_t)(p + 1)]) : 0.0;
-        val[p] = d_recast(sp[p], e0 + m.x);
-        val[p + 1] = d_recast(sp[p + 1], e1 + m.y);
-        ok = ok && d_valid(sp[p], val[p]) && d_valid(sp[p + 1], val[p + 1]);
-    }
-    if (ok) {
-#pragma unroll
-        for (int p = 0; p < PP; p++)
-            if (p < P) __builtin_nontemporal_store(val[p], &out[i + n * (size_t)p]);
-    } else {
-        list[atomicAdd(count, 1u)] = (unsigned)i;
-    }
-}
-
-// one new particle per lane (list == NULL: rows 0..n-1; else the rows list[0 .. *count) of the rejection loop)
-template <int PP, bool MV>
-__global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __restrict__ theta, size_t K, int P,
+__global__ __launch_bounds__(256, (MV && PP <= 16) ? 3 : (PP <= 16 ? 2 : 1)) void k_perturb(abc_rng key, const double* __restrict__ theta, size_t K, int P,
                                                  const abc_prior* __restrict__ priors,
                                                  const unsigned long long* __restrict__ parent,
                                                  unsigned long long i0, size_t n,
-                                                 const double* __restrict__ L_or_dv, double* __restrict__ out,
-                                                 unsigned long long* __restrict__ giveups,
-                                                 const unsigned* __restrict__ list, const unsigned* __restrict__ count) {
-    __shared__ double sL[PP * PP];     // MV: lower-triangular factor (column-major, zero above the diagonal);
-                                       // otherwise sqrt(dv) on the diagonal (AbcUtil.cpp:150)
+                                                 const double* __restrict__ L_or_dv /* MV: the padded factor */, double* __restrict__ out,
+                                                 unsigned long long* __restrict__ giveups) {
+    __shared__ double sS[PP];          // independent mode: sqrt(dv) (AbcUtil.cpp:150)
     __shared__ abc_prior sp[PP];
-    load_factor<PP, MV>(sL, L_or_dv, P);
+    __shared__ double sinv[PP];        // Gaussian priors: 1 / |sigma| for the fast side of the support test (0: always the exact test)
+    if (!MV) for (int p = threadIdx.x; p < PP; p += 256) sS[p] = (p < P) ? sqrt(L_or_dv[p]) : 0.0;
     for (int p = threadIdx.x; p < PP; p += 256) {
         abc_prior q; q.kind = ABC_PRIOR_UNIF_REAL; q.pad_ = 0; q.a = -1e300; q.b = 1e300;
         sp[p] = (p < P) ? priors[p] : q;
+        sinv[p] = (p < P && priors[p].kind == ABC_PRIOR_GAUSS && fabs(priors[p].b) < 1e10 && fabs(priors[p].b) > 1e-300) ? 1.0 / fabs(priors[p].b) : 0.0;
     }
     __syncthreads();
-    // list mode: a small grid strides over the listed rows; otherwise one row per thread
-    const size_t limit = list ? (size_t)*count : n, stride = list ? (size_t)gridDim.x * 256 : n;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < limit; t += stride) {
-    const size_t i = list ? (size_t)list[t] : t;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    {
     const unsigned long long gi = i0 + i;
-    const size_t par = (size_t)parent[i];
-    double mu[PP], val[PP];
-#pragma unroll
-    for (int p = 0; p < PP; p += 2) {                      // theta: row-major K x PP (k_theta_rows), 16-byte loads
-        const double2 v = *reinterpret_cast<const double2*>(theta + par * PP + p);
-        mu[p] = v.x; mu[p + 1] = v.y; val[p] = v.x; val[p + 1] = v.y;
-    }
+    const double* mrow = theta + (size_t)parent[i] * PP;   // theta: row-major K x PP (k_theta_rows), read with 16-byte loads
     const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
+    // Only the noise / proposal vector x[PP] lives in registers across the attempt loop: the parent row is (re-)read where it is
+    // added (a cached 128-byte line), so the kernel stays near 110 VGPRs (four waves per SIMD) instead of 260 with the row,
+    // the noise and the candidate all resident (one wave per SIMD: 141 us at N+ = 1e6, latency-bound on the parent gather).
+    double x[PP];
     if (MV) {
         // AbcUtil.cpp:132-139: draw the whole vector x = mu + L z, accept iff every coordinate is valid
         for (unsigned attempt = 0; attempt < MVN_MAX_TRIES; attempt++) {
-            double x[PP];
-            mv_noise<PP>(sL, gi, attempt, k0, k1, x);
+            mv_noise<PP>(L_or_dv, gi, attempt, k0, k1, x);
             bool ok = true;
+            asm volatile("" ::: "memory");      // the prior table is re-read from LDS here (hoisted out of the loop it costs 96 VGPRs)
 #pragma unroll
-            for (int a = 0; a < PP; a++) {
-                const double v = d_recast(sp[a], x[a] + mu[a]);
-                val[a] = v;
-                ok = ok && d_valid(sp[a], v);
+            for (int a = 0; a < PP; a += 2) {
+                const double2 m = *reinterpret_cast<const double2*>(mrow + a);
+                x[a] = recast_valid(sp[a], sinv[a], x[a] + m.x, ok);
+                x[a + 1] = recast_valid(sp[a + 1], sinv[a + 1], x[a + 1] + m.y, ok);
             }
             if (ok) break;
             if (attempt + 1 == MVN_MAX_TRIES) {
 #pragma unroll
-                for (int p = 0; p < PP; p++) val[p] = mu[p];   // give up: keep the (valid) parent, and say so (abc_perturb_giveups)
+                for (int a = 0; a < PP; a++) x[a] = mrow[a];   // give up: keep the (valid) parent, and say so (abc_perturb_giveups)
                 atomicAdd(giveups, 1ull);
             }
         }
@@ -361,21 +333,24 @@ __global__ __launch_bounds__(256) void k_perturb(abc_rng key, const double* __re
         // Priors.h:19-33: per coordinate, up to 1000 tries, then the prior mean
 #pragma unroll
         for (int p = 0; p < PP; p++) {
+            x[p] = 0.0;
             if (p < P) {
+                const double m = mrow[p];
                 double v = 0.0; bool ok = false;
+                asm volatile("" ::: "memory");          // (as above: this coordinate's prior is read from LDS here, not hoisted)
                 for (unsigned attempt = 0; attempt < 1000 && !ok; attempt++) {
-                    v = d_recast(sp[p], indep_noise(sL[p + PP * p], gi, attempt, p, k0, k1) + mu[p]);
+                    v = d_recast(sp[p], indep_noise(sS[p], gi, attempt, p, k0, k1) + m);
                     ok = d_valid(sp[p], v);
                 }
-                val[p] = ok ? v : d_prior_mean(sp[p]);
+                x[p] = ok ? v : d_prior_mean(sp[p]);
                 if (!ok) atomicAdd(giveups, 1ull);       // the reference prints an error line per fallback (Priors.h:27-29)
             }
         }
     }
 #pragma unroll
     for (int p = 0; p < PP; p++)
-        if (p < P) __builtin_nontemporal_store(val[p], &out[i + n * (size_t)p]);   // read next by the host / simulators, not by a kernel:
-                                                                                    // keep the 8 P N bytes out of L2 / Infinity Cache
+        if (p < P) __builtin_nontemporal_store(x[p], &out[i + n * (size_t)p]);   // read next by the host / simulators, not by a kernel:
+                                                                                  // keep the 8 P N bytes out of L2 / Infinity Cache
     }
 }
 
@@ -417,14 +392,16 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
 #pragma unroll
             for (int a = 0; a < PP; a++) x[a] = 0.0;
 #pragma unroll 1
-            for (int pr = 0; pr < PP / 2; pr++) {
-                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)pr;
-                double z0, z1;
-                normal2(philox(c, k0, k1), z0, z1);
-                const double* l0 = sL + PP * (2 * pr);
-                const double* l1 = l0 + PP;
+            for (int qd = 0; qd < PP / 4; qd++) {
+                U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)qd;
+                double z[4];
+                normal4(philox(c, k0, k1), z);
+                const double* l = sL + PP * (4 * qd);
 #pragma unroll
-                for (int a = 0; a < PP; a++) { x[a] = fma(l0[a], z0, x[a]); x[a] = fma(l1[a], z1, x[a]); }
+                for (int a = 0; a < PP; a++) {
+                    x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
+                    x[a] = fma(l[2 * PP + a], z[2], x[a]); x[a] = fma(l[3 * PP + a], z[3], x[a]);
+                }
             }
             ok = true;
 #pragma unroll
@@ -446,9 +423,9 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
             double v = 0.0; bool ok = false;
             for (unsigned attempt = 0; attempt < 1000 && !ok; attempt++) {
                 U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = 0x80000000u | (uint32_t)p;
-                double z0, z1;
-                normal2(philox(c, k0, k1), z0, z1);
-                v = d_recast(sp[p], sL[p] * z0 + m);
+                double z[4];
+                normal4(philox(c, k0, k1), z);
+                v = d_recast(sp[p], sL[p] * z[0] + m);
                 ok = d_valid(sp[p], v);
             }
             out[i + n * (size_t)p] = ok ? v : d_prior_mean(sp[p]);
@@ -585,15 +562,16 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
 // The parts of the perturbation that need neither the parents nor the alias table: the row-major copy of the posterior the
 // kernel gathers parents from, and the simulator seeds (taus2 outputs seed_stream_offset + i0 + i).  launch_perturb does them
 // itself unless the caller already has (the fused driver runs them while the host builds the alias table).
-static int launch_theta_rows(abc_ctx* ctx, const double* theta, size_t K, size_t P, int PP, double* rows) {
+static int launch_theta_rows(abc_ctx* ctx, const double* theta, size_t K, size_t P, int PP, double* rows, const double* L,
+                             double* Lpad) {
     const unsigned grid = (unsigned)((K + 63) / 64);
     switch (PP) {
-        case 2: hipLaunchKernelGGL((k_theta_rows<2>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
-        case 4: hipLaunchKernelGGL((k_theta_rows<4>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
-        case 8: hipLaunchKernelGGL((k_theta_rows<8>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
-        case 16: hipLaunchKernelGGL((k_theta_rows<16>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
-        case 32: hipLaunchKernelGGL((k_theta_rows<32>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
-        default: hipLaunchKernelGGL((k_theta_rows<64>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows); break;
+        case 2: hipLaunchKernelGGL((k_theta_rows<2>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
+        case 4: hipLaunchKernelGGL((k_theta_rows<4>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
+        case 8: hipLaunchKernelGGL((k_theta_rows<8>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
+        case 16: hipLaunchKernelGGL((k_theta_rows<16>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
+        case 32: hipLaunchKernelGGL((k_theta_rows<32>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
+        default: hipLaunchKernelGGL((k_theta_rows<64>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
     }
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -615,44 +593,18 @@ int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta
                            const double* L_or_dv) {
     prep->rows = nullptr;
     prep->seeds_done = 0;
-    prep->noise = nullptr;
-    prep->list = nullptr;
+    prep->Lpad = nullptr;
     if (n == 0 || P > 64) return ABC_OK;
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     StageTimer tm(ctx, ST_PERTURB);
     double* rows = (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
-    if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
-    ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows));
+    double* Lpad = (multivariate && L_or_dv) ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
+    if (!rows || (multivariate && L_or_dv && !Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+    ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, Lpad ? L_or_dv : nullptr, Lpad));
     prep->rows = rows;
+    prep->Lpad = Lpad;
     if (seeds) { ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset)); prep->seeds_done = 1; }
-    // first-attempt noise of every proposal (independent of the parents): up to 32 parameters, row numbers in 32 bits
-    if (L_or_dv && PP <= 32 && n <= 0xffffffffull) {
-        double* noise = (double*)abc_ws_alloc(ctx, n * P * sizeof(double));
-        unsigned* list = (unsigned*)abc_ws_alloc(ctx, (n + 1) * sizeof(unsigned));       // [0]: count, then the rows
-        if (noise && list) {
-            const unsigned blocks = (unsigned)((n + 255) / 256);
-            ABC_HIP(ctx, hipMemsetAsync(list, 0, sizeof(unsigned), ctx->stream));
-#define LAUNCH_NF(PPV)                                                                                                        \
-    do {                                                                                                                      \
-        if (multivariate) hipLaunchKernelGGL((k_noise_first<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, (int)P,  \
-                                             (unsigned long long)i0, n, L_or_dv, noise);                                      \
-        else hipLaunchKernelGGL((k_noise_first<PPV, false>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, (int)P,             \
-                                (unsigned long long)i0, n, L_or_dv, noise);                                                   \
-    } while (0)
-            switch (PP) {
-                case 2: LAUNCH_NF(2); break;
-                case 4: LAUNCH_NF(4); break;
-                case 8: LAUNCH_NF(8); break;
-                case 16: LAUNCH_NF(16); break;
-                default: LAUNCH_NF(32); break;
-            }
-#undef LAUNCH_NF
-            ABC_HIP(ctx, hipGetLastError());
-            prep->noise = noise;
-            prep->list = list;
-        }
-    }
     return ABC_OK;
 }
 
@@ -671,26 +623,25 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     const unsigned blocks = (unsigned)((n + 255) / 256);
     double* rows = (prep && prep->rows) ? prep->rows : (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
     if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
-    if (!(prep && prep->rows)) ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows));
+    const double* Lpad = (prep && prep->rows) ? prep->Lpad : nullptr;
+    if (!(prep && prep->rows)) {
+        double* lp = (multivariate && PP <= 32) ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
+        if (multivariate && PP <= 32 && !lp) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+        ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, lp ? L_or_dv : nullptr, lp));
+        Lpad = lp;
+    }
     theta = rows;
-    // with the first-attempt noise prepared: a streaming pass, then the rejection loop over the listed rows only
-    const double* noise = (prep && PP <= 32) ? prep->noise : nullptr;
-    unsigned* list = noise ? prep->list + 1 : nullptr;
-    unsigned* count = noise ? prep->list : nullptr;
-    const unsigned lblocks = blocks < 256 ? blocks : 256;     // the rejection loop strides over its (short) row list
+    if (multivariate && PP <= 32 && !Lpad) ABC_FAIL(ctx, ABC_ERR_INVALID, "perturb: the padded factor was not prepared");
 #define LAUNCH_PT(PPV)                                                                                                 \
     do {                                                                                                               \
-        if (noise)                                                                                                     \
-            hipLaunchKernelGGL((k_perturb_fast<PPV>), dim3(blocks), dim3(256), 0, ctx->stream, theta, (int)P, priors,   \
-                               (const unsigned long long*)parent, n, noise, out, list, count);                       \
         if (multivariate)                                                                                              \
-            hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(noise ? lblocks : blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
-                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,    \
-                               ctx->giveups_dev, (const unsigned*)list, (const unsigned*)count);                      \
+            hipLaunchKernelGGL((k_perturb<PPV, true>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
+                               priors, (const unsigned long long*)parent, (unsigned long long)i0, n, Lpad, out,       \
+                               ctx->giveups_dev);                                                                     \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_perturb<PPV, false>), dim3(noise ? lblocks : blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
+            hipLaunchKernelGGL((k_perturb<PPV, false>), dim3(blocks), dim3(256), 0, ctx->stream, *rng, theta, K, (int)P, \
                                priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,    \
-                               ctx->giveups_dev, (const unsigned*)list, (const unsigned*)count);                      \
+                               ctx->giveups_dev);                                                                     \
     } while (0)
     switch (PP) {
         case 2: LAUNCH_PT(2); break;

@@ -403,7 +403,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
             have_spd = true;
         }
-        abc_perturb_prep prep = {nullptr, 0, nullptr, nullptr};
+        abc_perturb_prep prep = {nullptr, 0, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t i0, seed_off; uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
