@@ -37,6 +37,10 @@ struct abc_ctx {
     size_t ualias_cap, ualias_K;
     char* ualias_pin;      // its own pinned staging (the upload is asynchronous: the shared scratch may be reused before it ran)
     hipEvent_t ev_copy;    // marks the end of the weights' device-to-host copy (the host waits on it, not on the stream)
+    // side stream of the fused drivers: the two taus2 streams of a generation (draws, seeds) depend on the rng state alone and
+    // run there from the first launch on, beside the ranking chain (abc_rng_streams_early); ev_fork / ev_side order them
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_side;
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
@@ -47,6 +51,9 @@ struct abc_ctx {
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
     int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish
+    int* sel_fail_dev;       // device: the sampled-range bin selection gave up (select.hip); read by abc_select_check
+    bool sel_bins_ran;       // the last launch_select_smallest took the bin path and has not been checked yet
+    bool sel_force_radix;    // set by a caller that repeats its work after a failed bin selection
     bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
     int nev;
     struct { hipEvent_t a, b; int stage; } ev[256];
@@ -162,7 +169,8 @@ int launch_simple_model(abc_ctx*, const double* stats, const double* obs, size_t
 int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P,
                             size_t A, const double* model, int simple, double* dist);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
-                           uint64_t* idx, double* dist_out);
+                           uint64_t* idx, double* dist_out, bool defer_check = false);
+int abc_select_check(abc_ctx* ctx, int* failed);
 // column slices of the weight kernel (weights.hip) and the bytes of partial sums they need; shared with the
 // workspace sizing in api.hip
 inline size_t abc_kde_slices(size_t kn, size_t Kp, int PP) {
@@ -213,15 +221,21 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
 // while_host_builds (optional): called after the weights' copy to the host has been queued and before the host waits for it:
 // GPU work launched there runs while the host builds the alias table
 // uniform_weights: w is K copies of 1.0 / K (launch_fill): the table comes from abc_uniform_alias, no host round trip here
+// raw_ready (optional): the n taus2 outputs of the draws, already queued on the side stream (abc_rng_streams_early)
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr,
-                    bool uniform_weights = false);
+                    bool uniform_weights = false, const uint32_t* raw_ready = nullptr);
+// Queues on the context's side stream everything of the proposals that depends on the rng state alone: the taus2 outputs
+// i0 .. i0 + n - 1 of the resampling draws (-> *raw) and, if seeds != NULL, the simulator seeds = outputs seed_stream_offset +
+// i0 + i.  The main stream waits for them in launch_resample (raw_ready).  Call before the first kernel of the generation.
+int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
+                          uint32_t** raw);
 // Alias table of K equal weights: gsl_ran_discrete_preproc on K copies of 1.0 / K (bit-identical to the table of the filled
 // weight vector), built on the host on first use for this K and kept in HBM.  The fused drivers call it right after queueing
 // the ranking kernels, so the host builds the table while the GPU ranks.
 int abc_uniform_alias(abc_ctx* ctx, size_t K);
 // what launch_perturb_prepare has already done: row-major posterior copy, seeds, the padded Cholesky factor
-struct abc_perturb_prep { double* rows; int seeds_done; double* Lpad; };
+struct abc_perturb_prep { double* rows; int seeds_done; double* Lpad; };   // seeds_done may be preset by the caller
 // multivariate / L_or_dv (optional): with them the factor is padded for the perturbation kernel as well
 int launch_perturb_prepare(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
                            uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate = 0,

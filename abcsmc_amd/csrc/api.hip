@@ -50,6 +50,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     b += (2 * M * P + 2 * M * M + P + A * M + A * A + P * A + M * 40) * 8;
     b += N * 8;                                                   // distances
     b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort
+    b += 2 * (K + 1024) * 8 + 34 * 4096 * 4 + 4096;               // ... or the bin selection's pair buffer, counts and cursors
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
     b += K * P * 8 + K * 64 * 8;                                  // theta, and its row-major copy for the perturb gather
     b += (K + Kp) * 64 * 8 + 1024 * 8;                            // weights: scaled copies of both sets
@@ -97,6 +98,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     abc_comm_release(ctx);
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_side); }
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -426,6 +428,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                            int32_t* ncomp_host, int simple, const double** model_out = nullptr) {
     const size_t N = cfg->N, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->Nnext;
     if (!N || !M || K > N) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: bad sizes N=%zu M=%zu K=%zu", N, M, K);
+    const size_t ws_entry = ctx->ws_off;              // a failed bin selection (select.hip) repeats the call from here
+    abc_rng rng_entry;
+    if (rng) rng_entry = *rng;
     if (!simple && !(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))      // AbcUtil.cpp:428
         ABC_FAIL(ctx, ABC_ERR_INVALID, "training fraction %g outside (0,1]", cfg->train_frac);
     if (!simple && cfg->rule != ABC_RULE_MIN_PRESS && cfg->rule != ABC_RULE_WILCOXON)
@@ -440,6 +445,10 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (!stats || !model || !dist || !spd_dev) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
     if (model_out) *model_out = model;
     const uint64_t ntrain = simple ? N : (uint64_t)llround((double)N * cfg->train_frac);   // AbcUtil.cpp:438
+    // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, beside the ranking
+    uint32_t* raw_early = nullptr;
+    const bool early = io->w && Nn && K && rng && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
+    if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early));
     const double* Yp = io->Y ? io->Y : io->X;
     const size_t Pstat = io->Y ? P : 0;
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
@@ -450,7 +459,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
-    ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist));
+    ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/io->w != nullptr));
     // first set: the weights will be 1/K whatever the ranking says, so the host builds their alias table now, while the GPU ranks
     const bool uniform_w = io->w && (Kp == 0 || !io->theta_prev);
     if (uniform_w && Nn) ABC_TRY(abc_uniform_alias(ctx, K));
@@ -494,7 +503,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // The alias-table host round trip sits inside launch_resample.  What does not depend on the weights runs on the GPU
         // meanwhile: the MVN factor (covariance + Cholesky), the row-major posterior copy and the seed stream of the
         // perturbation.
-        abc_perturb_prep prep = {nullptr, 0, nullptr};
+        abc_perturb_prep prep = {nullptr, (early && io->seeds) ? 1 : 0, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
@@ -515,7 +524,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w));
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early));
         if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {
             taus2_jump(rng, (uint64_t)Nn);   // the Nnext resampling draws; the host loop consumes the rest as the reference does
             ABC_TRY(launch_perturb_reference(ctx, rng, theta, K, P, io->priors, parent, Nn, cfg->multivariate,
@@ -532,6 +541,20 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(&spd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
+    }
+    {
+        // the sampled-range bin selection gave up (degenerate distances, an atypical sample): everything downstream of it
+        // worked on a placeholder; once more, from the top, with the radix select
+        int failed = 0;
+        ABC_TRY(abc_select_check(ctx, &failed));
+        if (failed && !ctx->sel_force_radix) {
+            ctx->ws_off = ws_entry;
+            if (rng) *rng = rng_entry;
+            ctx->sel_force_radix = true;
+            const int rc = generation_core(ctx, cfg, io, rng, ncomp_host, simple, model_out);
+            ctx->sel_force_radix = false;
+            return rc;
+        }
     }
     if (ctx->timing && ctx->nev > 128) ABC_TRY(abc_timing_flush(ctx));
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");

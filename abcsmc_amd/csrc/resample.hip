@@ -446,10 +446,10 @@ int ensure_jump_tab(abc_ctx* ctx) {
     return ABC_OK;
 }
 
-int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out) {
+int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out, hipStream_t st = nullptr) {
     ABC_TRY(ensure_jump_tab(ctx));
     const size_t threads = (n + RUN - 1) / RUN;
-    hipLaunchKernelGGL(k_taus_stream, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, base, n,
+    hipLaunchKernelGGL(k_taus_stream, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st ? st : ctx->stream, base, n,
                        ctx->jump_tab, out);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -493,18 +493,48 @@ int abc_uniform_alias(abc_ctx* ctx, size_t K) {
     return ABC_OK;
 }
 
+static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
+                        hipStream_t st);
+
+int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
+                          uint32_t** raw_out) {
+    *raw_out = nullptr;
+    if (n == 0) return ABC_OK;
+    if (!ctx->side) {
+        ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+    }
+    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
+    ABC_TRY(ensure_jump_tab(ctx));                       // (its first-use upload is synchronous: before the fork)
+    // the side stream starts behind everything already queued on the main one (earlier users of the seed buffer)
+    ABC_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    abc_rng base = *rng;
+    taus2_jump(&base, i0);
+    ABC_TRY(taus_stream(ctx, base, n, raw, ctx->side));
+    if (seeds) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, ctx->side));
+    ABC_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->side));
+    *raw_out = raw;
+    return ABC_OK;
+}
+
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
-                    uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights) {
+                    uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights,
+                    const uint32_t* raw_ready) {
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     if (uniform_weights) {
         ABC_TRY(abc_uniform_alias(ctx, K));               // (already built by the fused drivers; here for any other caller)
-        uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+        uint32_t* raw = const_cast<uint32_t*>(raw_ready);
+        if (!raw) raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
         if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
         abc_rng base = *rng;
         taus2_jump(&base, i0);
         StageTimer tm(ctx, ST_RESAMPLE);
-        ABC_TRY(taus_stream(ctx, base, n, raw));
+        if (raw_ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        else ABC_TRY(taus_stream(ctx, base, n, raw));
         if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));
         hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->ualias_F,
                            ctx->ualias_A, K, (unsigned long long*)parent);
@@ -523,11 +553,15 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     if (!ctx->ev_copy) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
     ABC_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream));
     // the raw taus2 outputs of the draws do not depend on the table: queued behind the copy, generated while the host builds it
-    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+    // (or long since, on the side stream: raw_ready)
+    uint32_t* raw = const_cast<uint32_t*>(raw_ready);
+    if (!raw) raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
     if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
     abc_rng base = *rng;
     taus2_jump(&base, i0);
-    {
+    if (raw_ready) {
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+    } else {
         StageTimer tm(ctx, ST_RESAMPLE);
         ABC_TRY(taus_stream(ctx, base, n, raw));
     }
@@ -576,15 +610,16 @@ static int launch_theta_rows(abc_ctx* ctx, const double* theta, size_t K, size_t
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
-static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset) {
+static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
+                        hipStream_t st) {
     // AbcSmc.cpp:535: one gsl_rng_get per new particle; here taken from the taus2 stream at
     // position seed_stream_offset + i0 + i (after the resampling draws)
     uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
     if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
     abc_rng base = *rng;
     taus2_jump(&base, seed_stream_offset + i0);
-    ABC_TRY(taus_stream(ctx, base, n, raw));
-    hipLaunchKernelGGL(k_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, (unsigned long long*)seeds);
+    ABC_TRY(taus_stream(ctx, base, n, raw, st));
+    hipLaunchKernelGGL(k_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st ? st : ctx->stream, raw, n, (unsigned long long*)seeds);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
@@ -592,7 +627,6 @@ int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta
                            uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate,
                            const double* L_or_dv) {
     prep->rows = nullptr;
-    prep->seeds_done = 0;
     prep->Lpad = nullptr;
     if (n == 0 || P > 64) return ABC_OK;
     int PP = 2;
@@ -604,7 +638,7 @@ int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta
     ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, Lpad ? L_or_dv : nullptr, Lpad));
     prep->rows = rows;
     prep->Lpad = Lpad;
-    if (seeds) { ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset)); prep->seeds_done = 1; }
+    if (seeds && !prep->seeds_done) { ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, nullptr)); prep->seeds_done = 1; }
     return ABC_OK;
 }
 
@@ -665,7 +699,7 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     }
 #undef LAUNCH_PT
     ABC_HIP(ctx, hipGetLastError());
-    if (seeds && !(prep && prep->seeds_done)) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset));
+    if (seeds && !(prep && prep->seeds_done)) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, nullptr));
     return ABC_OK;
 }
 

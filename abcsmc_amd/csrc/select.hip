@@ -171,6 +171,222 @@ __global__ __launch_bounds__(256) void k_sel_hist_fused(const double* __restrict
     }
 }
 
+
+// ---- single-GPU selection by sampled range + linear bins (round 2) ------------------------------------------------------
+// The radix select above reads the distances eight times (six digit passes, count, write) and the winners are then sorted
+// by a chunk sort + rank merge: 105 + 97 us at N = 1e6, K = 1e5, all of it launch- and latency-bound.  Here:
+//   k_bs_sample   one work-group: 4096 evenly spaced keys into LDS, their minimum (lo) and -- by an LDS radix select on the
+//                 leading 24 bits -- an upper bound (hi) of the sample key of rank K/N * 4096 + 4 sigma + 8: the K-th
+//                 smallest of the whole set lies below hi unless the sample is atypical (~3e-5) or the data are degenerate
+//   k_bs_hist     NB = 4096 linear bins of the key range [lo, hi] (keys are order-preserving integers, so (key - lo) >> shift
+//                 is monotone); per-block LDS histogram, flushed with global atomics.  Keys above hi are not counted.
+//   k_bs_scan     exclusive scan of the bin counts; the bin b* holding the K-th key; checks (below): sets `fail` if a rule breaks
+//   k_bs_scatter  every key of a bin <= b* goes to its bin's range of a (key, index) pair buffer (unordered inside the bin)
+//   k_bs_sort     one work-group per bin: bitonic sort by (key, index) in LDS, written to its final position; of bin b* only
+//                 the first K - #below are kept -- which is exactly "ties by lowest index" -- distances converted on the way.
+// The result is the same array the radix select + stable sort produce (ascending (key, index) is a total order).
+// `fail` (any bin above BS_CAP keys, or fewer than K keys at or below hi): k_bs_sort writes a harmless result (indices
+// idx_base .. idx_base + K - 1) and the host, when it next synchronises, repeats the selection with the radix path.
+constexpr int BS_NB = 4096;          // bins
+constexpr int BS_S = 4096;           // sampled keys
+constexpr int BS_CAP = 1024;         // keys one work-group sorts
+constexpr int BS_CSTRIDE = 32;       // the scatter's per-bin cursors sit 128 bytes apart: neighbouring (equally busy) bins on the
+                                     // same cache line serialised their atomics (63 us for 1e5 winners; 4096 x 4-byte cursors packed)
+struct BinSel {
+    unsigned long long lo, hi;
+    int shift;
+    int bstar;                       // bin of the K-th key
+    unsigned long long need;         // keys kept of bin b*
+    int fail;
+    int pad_;
+};
+
+__global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ dist, size_t n, unsigned long long K,
+                                                    BinSel* __restrict__ bs, unsigned int* __restrict__ hist /* BS_NB + 1 */,
+                                                    int* __restrict__ fail_flag) {
+    __shared__ unsigned long long sk[BS_S];
+    __shared__ unsigned int h[256];
+    __shared__ unsigned long long red[16];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned int s_rank;
+    const int t = threadIdx.x;
+    for (int i = t; i < BS_NB + 1; i += 1024) hist[i] = 0;
+    const size_t stride = n / BS_S;
+    unsigned long long mn = ~0ull;
+    for (int i = t; i < BS_S; i += 1024) {
+        const unsigned long long k = key_of(dist[(size_t)i * stride + stride / 2]);
+        sk[i] = k;
+        mn = k < mn ? k : mn;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned long long v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
+    if ((t & 63) == 0) red[t >> 6] = mn;
+    // rank (0-based) of the upper key among the samples: expected position of the K-th + 4 standard deviations + 8
+    const double f = (double)K / (double)n;
+    double qd = f * BS_S + 4.0 * sqrt(BS_S * f * (1.0 - f)) + 8.0;
+    unsigned int q = (qd >= (double)(BS_S - 1)) ? BS_S - 1 : (unsigned int)qd;
+    if (t == 0) { s_prefix = 0; s_rank = q; }
+    __syncthreads();
+    for (int w = 0; w < 16; w++) mn = red[w] < mn ? red[w] : mn;
+    // LDS radix select of the sample's q-th key, most significant bits first.  hi only has to lie at or above it: three passes
+    // decide its top 24 bits (sign, exponent, 12 mantissa bits), the rest is filled with ones
+    unsigned long long mask = 0;
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 56 - 8 * pass;
+        if (t < 256) h[t] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for (int i = t; i < BS_S; i += 1024)
+            if ((sk[i] & mask) == prefix) atomicAdd(&h[(unsigned int)(sk[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (t < 64) {          // one wave: four digits per lane, scan, pick
+            unsigned int c[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { c[j] = h[4 * t + j]; sum += c[j]; }
+            unsigned int inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o, 64); if (t >= o) inc += u; }
+            unsigned int run = inc - sum;
+            const unsigned int r = s_rank;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (run <= r && r < run + c[j]) { s_prefix = prefix | ((unsigned long long)(4 * t + j) << shift); s_rank = r - run; }
+                run += c[j];
+            }
+        }
+        mask |= 255ull << shift;
+        __syncthreads();
+    }
+    if (t == 0) {
+        const unsigned long long lo = mn, hi = s_prefix | ~mask;
+        const unsigned long long span = hi - lo;
+        int shift = 0;
+        while (shift < 63 && (span >> shift) >= (unsigned long long)(BS_NB - 1)) shift++;
+        bs->lo = lo; bs->hi = hi; bs->shift = shift; bs->bstar = 0; bs->need = 0; bs->fail = 0; bs->pad_ = 0;
+        *fail_flag = 0;
+    }
+}
+
+__device__ __forceinline__ int bs_bin(unsigned long long k, unsigned long long lo, int shift) {
+    return (k <= lo) ? 0 : (int)((k - lo) >> shift);
+}
+
+__global__ __launch_bounds__(256) void k_bs_hist(const double* __restrict__ dist, size_t n, const BinSel* __restrict__ bs,
+                                                 unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor) {
+    __shared__ unsigned int lh[BS_NB];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)BS_NB * BS_CSTRIDE; i += (size_t)gridDim.x * 256) cursor[i] = 0;
+    for (int i = threadIdx.x; i < BS_NB; i += 256) lh[i] = 0;
+    __syncthreads();
+    const unsigned long long lo = bs->lo, hi = bs->hi;
+    const int shift = bs->shift;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long k = key_of(dist[i]);
+        if (k <= hi) atomicAdd(&lh[bs_bin(k, lo, shift)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BS_NB; i += 256) {
+        const unsigned int c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// hist[b] -> exclusive offsets in place (hist[BS_NB] = total); b*, need, fail
+__global__ __launch_bounds__(1024) void k_bs_scan(BinSel* __restrict__ bs, unsigned int* __restrict__ hist, unsigned long long K,
+                                                  int* __restrict__ fail_flag) {
+    __shared__ unsigned int wsum[16];
+    __shared__ int s_fail;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_fail = 0;
+    unsigned int c[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { c[j] = hist[4 * t + j]; sum += c[j]; }
+    unsigned int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int run = inc - sum;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+    unsigned int tot = 0;
+    for (int w = 0; w < 16; w++) tot += wsum[w];
+    // keys of bins <= b* are sorted by one work-group each: none may exceed BS_CAP
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const unsigned int off = run;
+        hist[4 * t + j] = off;
+        if ((unsigned long long)off < K && K <= (unsigned long long)off + c[j]) { bs->bstar = 4 * t + j; bs->need = K - off; }
+        if ((unsigned long long)off < K && c[j] > (unsigned int)BS_CAP) s_fail = 1;
+        run += c[j];
+    }
+    if (t == 0) hist[BS_NB] = tot;
+    __syncthreads();
+    if (t == 0) {
+        const int fail = (s_fail || (unsigned long long)tot < K) ? 1 : 0;
+        bs->fail = fail;
+        *fail_flag = fail;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bs_scatter(const double* __restrict__ dist, size_t n, const BinSel* __restrict__ bs,
+                                                    const unsigned int* __restrict__ offs, unsigned int* __restrict__ cursor,
+                                                    unsigned long long idx_base, unsigned long long* __restrict__ tkey,
+                                                    unsigned long long* __restrict__ tidx) {
+    if (bs->fail) return;
+    const unsigned long long lo = bs->lo, hi = bs->hi;
+    const int shift = bs->shift, bstar = bs->bstar;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = key_of(dist[i]);
+    if (k > hi) return;
+    const int b = bs_bin(k, lo, shift);
+    if (b > bstar) return;
+    const unsigned int p = offs[b] + atomicAdd(&cursor[(size_t)b * BS_CSTRIDE], 1u);
+    tkey[p] = k;
+    tidx[p] = idx_base + i;
+}
+
+__global__ __launch_bounds__(256) void k_bs_sort(const BinSel* __restrict__ bs, const unsigned int* __restrict__ offs,
+                                                 const unsigned long long* __restrict__ tkey,
+                                                 const unsigned long long* __restrict__ tidx, unsigned long long K,
+                                                 unsigned long long idx_base, unsigned long long* __restrict__ oidx,
+                                                 double* __restrict__ odist) {
+    __shared__ unsigned long long sk[BS_CAP];
+    __shared__ unsigned long long si[BS_CAP];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (bs->fail) {          // harmless, in-range result; the host repeats the selection with the radix path
+        for (unsigned long long i = (unsigned long long)b * 256 + t; i < K; i += (unsigned long long)gridDim.x * 256) {
+            oidx[i] = idx_base + i;
+            if (odist) odist[i] = 0.0;
+        }
+        return;
+    }
+    if (b > bs->bstar) return;
+    const unsigned int o0 = offs[b], cnt = offs[b + 1] - o0;
+    if (cnt == 0) return;
+    const unsigned int keep = (b == bs->bstar) ? (unsigned int)bs->need : cnt;
+    unsigned int n2 = 2;
+    while (n2 < cnt) n2 <<= 1;
+    for (unsigned int e = t; e < n2; e += 256) {
+        sk[e] = (e < cnt) ? tkey[o0 + e] : ~0ull;
+        si[e] = (e < cnt) ? tidx[o0 + e] : ~0ull;
+    }
+    __syncthreads();
+    for (unsigned int k = 2; k <= n2; k <<= 1)
+        for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned int p = t; p < n2 / 2; p += 256) {
+                const unsigned int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const unsigned long long ka = sk[i], kb = sk[i + j], ia = si[i], ib = si[i + j];
+                const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                if (gt == ((i & k) == 0)) { sk[i] = kb; sk[i + j] = ka; si[i] = ib; si[i + j] = ia; }
+            }
+            __syncthreads();
+        }
+    for (unsigned int e = t; e < keep; e += 256) {
+        oidx[o0 + e] = si[e];
+        if (odist) odist[o0 + e] = dist_of(sk[e]);
+    }
+}
+
 constexpr int CP_ITEMS = 8;
 constexpr int CP_CHUNK = 256 * CP_ITEMS;
 
@@ -611,10 +827,31 @@ int launch_select_compact(abc_ctx* ctx, const double* dist, size_t n, const long
     return ABC_OK;
 }
 
-int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx,
-                           double* dist_out) {
-    if (K == 0) return ABC_OK;
-    if (K > n) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: K = %zu > n = %zu", K, n);
+// bin path: the caller (defer_check) or this function reads ctx->sel_fail_dev afterwards; see abc_select_check
+static int select_by_bins(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx, double* dist_out) {
+    if (!ctx->sel_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->sel_fail_dev, sizeof(int)));
+    BinSel* bs = (BinSel*)abc_ws_alloc(ctx, sizeof(BinSel));
+    unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, (BS_NB + 1) * sizeof(unsigned int));
+    unsigned int* cursor = (unsigned int*)abc_ws_alloc(ctx, (size_t)BS_NB * BS_CSTRIDE * sizeof(unsigned int));
+    unsigned long long* tkey = (unsigned long long*)abc_ws_alloc(ctx, (K + BS_CAP) * 8);
+    unsigned long long* tidx = (unsigned long long*)abc_ws_alloc(ctx, (K + BS_CAP) * 8);
+    if (!bs || !hist || !cursor || !tkey || !tidx) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
+    StageTimer tm(ctx, ST_SELECT);
+    hipLaunchKernelGGL(k_bs_sample, dim3(1), dim3(1024), 0, ctx->stream, dist, n, (unsigned long long)K, bs, hist, ctx->sel_fail_dev);
+    size_t hb = (n + 255) / 256;
+    if (hb > 512) hb = 512;
+    hipLaunchKernelGGL(k_bs_hist, dim3((unsigned)hb), dim3(256), 0, ctx->stream, dist, n, (const BinSel*)bs, hist, cursor);
+    hipLaunchKernelGGL(k_bs_scan, dim3(1), dim3(1024), 0, ctx->stream, bs, hist, (unsigned long long)K, ctx->sel_fail_dev);
+    hipLaunchKernelGGL(k_bs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dist, n, (const BinSel*)bs,
+                       (const unsigned int*)hist, cursor, (unsigned long long)idx_base, tkey, tidx);
+    hipLaunchKernelGGL(k_bs_sort, dim3(BS_NB), dim3(256), 0, ctx->stream, (const BinSel*)bs, (const unsigned int*)hist,
+                       (const unsigned long long*)tkey, (const unsigned long long*)tidx, (unsigned long long)K,
+                       (unsigned long long)idx_base, (unsigned long long*)idx, dist_out);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+static int select_by_radix(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx, double* dist_out) {
     unsigned long long* key0 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
     unsigned long long* key1 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
     unsigned long long* idx1 = (unsigned long long*)abc_ws_alloc(ctx, K * 8);
@@ -653,6 +890,38 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
                            dist_out);
         ABC_HIP(ctx, hipGetLastError());
     }
+    return ABC_OK;
+}
+
+// Sampled-range bins when they apply (a large set, at most half of it kept, K within one work-group's reach per bin), the
+// radix select + sort otherwise.  defer_check = true: the caller calls abc_select_check after its next synchronisation and,
+// if that reports a failed bin selection, repeats its work with ctx->sel_force_radix set.
+int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx,
+                           double* dist_out, bool defer_check) {
+    if (K == 0) return ABC_OK;
+    if (K > n) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: K = %zu > n = %zu", K, n);
+    const bool bins = !ctx->sel_force_radix && n >= 4 * (size_t)BS_S && 2 * K <= n && K <= ((size_t)1 << 18);
+    ctx->sel_bins_ran = bins;
+    if (!bins) return select_by_radix(ctx, dist, n, K, idx_base, idx, dist_out);
+    const size_t mark = ctx->ws_off;
+    ABC_TRY(select_by_bins(ctx, dist, n, K, idx_base, idx, dist_out));
+    if (defer_check) return ABC_OK;
+    int failed = 0;
+    ABC_TRY(abc_select_check(ctx, &failed));
+    if (!failed) return ABC_OK;
+    ctx->ws_off = mark;
+    return select_by_radix(ctx, dist, n, K, idx_base, idx, dist_out);
+}
+
+// after a synchronisation point of the caller: did the last bin selection give up?  (synchronises the stream itself)
+int abc_select_check(abc_ctx* ctx, int* failed) {
+    *failed = 0;
+    if (!ctx->sel_bins_ran || !ctx->sel_fail_dev) return ABC_OK;
+    int f = 0;
+    ABC_HIP(ctx, hipMemcpyAsync(&f, ctx->sel_fail_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sel_bins_ran = false;
+    *failed = f;
     return ABC_OK;
 }
 

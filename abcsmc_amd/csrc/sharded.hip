@@ -285,6 +285,9 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
     ABC_TRY(abc_pin_reserve(ctx, (size_t)(2 * W) * sizeof(long long) + 64));
 
+    // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, beside the ranking
+    uint32_t* raw_early = nullptr;
+    if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
     // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
     const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
@@ -403,7 +406,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
             have_spd = true;
         }
-        abc_perturb_prep prep = {nullptr, 0, nullptr};
+        abc_perturb_prep prep = {nullptr, io->seeds ? 1 : 0, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t i0, seed_off; uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
@@ -422,7 +425,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w));
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early));
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,
                                cfg->multivariate ? L : dv, io->next, io->seeds, cfg->Nnext_total, &prep));
     } else if (cfg->multivariate && io->L) {

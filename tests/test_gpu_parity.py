@@ -160,6 +160,60 @@ def test_select_smallest_random(gpu_ctx, oracle, n, K):
     assert np.array_equal(out, d[ref.astype(int)])
 
 
+@pytest.mark.parametrize("n,K,kind", [(200000, 20000, "chi"), (200000, 1, "chi"), (50000, 25000, "lognormal"),
+                                      (1000000, 100000, "chi"), (65536, 300, "ties_at_threshold"), (100000, 5000, "outliers"),
+                                      (16384, 8192, "chi"), (300000, 150000, "binades")])
+def test_select_smallest_sampled_bins(gpu_ctx, oracle, n, K, kind):
+    """large sets, at most half kept: the sampled-range bin selection (k_bs_*) instead of radix select + sort; same array"""
+    rng = np.random.default_rng(n + 7 * K)
+    if kind == "chi":
+        d = np.sqrt((rng.normal(size=(n, 8)) ** 2).sum(axis=1))            # distances in an 8-dimensional score space
+    elif kind == "lognormal":
+        d = np.exp(3.0 * rng.normal(size=n))
+    elif kind == "binades":
+        d = np.abs(rng.normal(size=n)) * 2.0 ** rng.integers(-40, 40, size=n)
+    elif kind == "outliers":
+        d = np.abs(rng.normal(size=n)) + 1.0
+        d[rng.integers(0, n, 50)] = np.inf
+        d[rng.integers(0, n, 50)] = 1e300
+        d[rng.integers(0, n, 5)] = 0.0
+    else:
+        d = np.abs(rng.normal(size=n))
+        t = np.partition(d, K - 1)[K - 1]
+        d[rng.integers(0, n, 500)] = t                                     # 500 more keys equal to the K-th: lowest indices win
+    idx, out = _select(gpu_ctx, d, K, base=12345)
+    ref = oracle.ordered(d)[:K]
+    assert np.array_equal(idx, ref + np.uint64(12345))
+    assert np.array_equal(out, d[ref.astype(int)])
+
+
+def test_generation_with_massive_distance_ties_repeats_with_the_radix_select(gpu_ctx, oracle):
+    """2048 copies of each of 16 particles: every bin of the sampled-range selection overflows, the generation notices at its
+    final synchronisation and repeats itself with the radix select; the result is the oracle's"""
+    import torch
+    from abcsmc_amd import abcutil, device, _lib
+    M, P, A, reps = 6, 3, 2, 2048
+    wl, X0, Y0, obs = _wl(M, P, 16)
+    X, Y = np.asfortranarray(np.tile(X0, (reps, 1))), np.asfortranarray(np.tile(Y0, (reps, 1)))
+    N, K, Nn = X.shape[0], 5000, 4096
+    spec = wl.prior_spec()
+    dev = "cuda:0"
+    gen = device.Generation(N, M, P, K, 0, Nn, 0.5, A, multivariate=False, device=dev)
+    r = abcutil.rng(99)
+    gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev),
+            device.priors_to_device(_lib.make_priors(spec), dev), r)
+    torch.cuda.synchronize()
+    o = oracle.rng(99)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, None, None, None, train_frac=0.5, max_comp=A,
+                            multivariate=False)
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    import ctypes as C
+    r2 = abcutil.rng(99)                                   # the repeated call must not have advanced the stream twice
+    _lib.lib().abc_rng_jump(C.byref(r2), 2 * Nn)
+    assert (r.s1, r.s2, r.s3) == (r2.s1, r2.s2, r2.s3)
+
+
 def test_select_smallest_ties_and_offsets(gpu_ctx, oracle):
     rng = np.random.default_rng(4)
     d = rng.integers(0, 50, size=30000).astype(np.float64)      # massive ties: index tie-break decides
