@@ -54,7 +54,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
     b += K * P * 8 + K * 64 * 8;                                  // theta, and its row-major copy for the perturb gather
     b += (K + Kp) * 64 * 8 + 1024 * 8;                            // weights: scaled copies of both sets
-    b += (K + Kp + 512) * (10 * 32 + 8) + 8192;                   // ... and their bf16 limb tiles (<= 10 operands of 32 B a row)
+    b += (K + Kp + 512) * (9 * 32 + 8 + 12) + 8192;               // ... and their f16 limb tiles (<= 9 operands of 32 B a row), 1/2|a|^2 parts
     b += (K + 512) * 17 + 16384;                                   // far-row flags, list and fix-up sums
     if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;

@@ -16,7 +16,7 @@
 // 13 instructions for the exponential, 30 per pair at P = 16, instead of ~40 for the library exp alone.
 // Two kernels evaluate the pair sums (include/abcsmc_hip.h: abc_ctx_set_kde_mode):
 //   k_kde        fp64 vector kernel: one new particle per lane, previous-set rows wave-uniform through the scalar cache;
-//   k_kde_split  (default for 5..32 parameters) the dot products a_i.b_j on the bf16 matrix pipe from exact limb products,
+//   k_kde_split  (default for 5..32 parameters) the dot products a_i.b_j on the f16 matrix pipe from limb products,
 //                the vector pipe left with convert + add + 2^x: see the section "split-operand weight kernel" below,
 // plus two fp64 fix-up kernels for the rows the split kernel cannot represent exactly.
 #include <stdlib.h>
@@ -227,39 +227,50 @@ __global__ __launch_bounds__(256) void k_epan(const double* __restrict__ a, size
     if (active) part[sl * kn + i] = acc;
 }
 
-// ---- split-operand weight kernel: the pair dot products on the bf16 matrix pipe, exactly ---------------
+// ---- split-operand weight kernel: the pair dot products on the f16 matrix pipe ------------------------------------
 // The fp64 body above spends 17 of its 30 vector instructions per pair on the dot product a_i.b_j.  Here every
-// scaled coordinate is written as a sum of four bf16 "limbs",
-//   v = l0 + l1 + l2 + l3,   l0 = rint(4 v)/4 (|v| <= 10),  l1 = rint(U1 (v - l0))/U1 (U1 = 1024; 512 for P > 16),
-//   l2, l3 = bf16 roundings of what is left (|v - l0 - l1 - l2 - l3| <= 2^-29),
-// and the dot product as the sum of the limb cross-products, which v_mfma_f32_32x32x16_bf16 evaluates with the
-// parameter index as its K dimension (P <= 16: one K-step; P <= 32: two), 32 previous x 32 new particles per
-// instruction.  Two f32 accumulators keep the result at fp64-class accuracy:
-//   X = l0.l0' + l0.l1' + l1.l0' - hbTop_j - haTop_i   every term a multiple of 1/(4 U1), all partial sums below
-//                                                      2^24/(4 U1): EXACT in f32 whatever the order of accumulation
-//   Y = the ten smaller cross-products - hbLow_j - haLow_i      |Y| ~ 0.02, so its f32 rounding is ~1e-9 absolute
-// where hb_j = 1/2|b_j|^2 - log2 w'_j and ha_i = 1/2|a_i|^2 (each = Top, a multiple of 1/(4 U1), + Low) enter through
-// ONE more K-step whose operands hold the bf16 pieces of hb / ha against -1s / 1s on the other side.  X + Y is then
-// the whole base-2 exponent of the term (<= log2 w'_j), and the vector pipe only converts, adds and exponentiates:
+// scaled coordinate is written as a sum of three "limbs" that f16 operands carry without loss,
+//   v = h0 + h1 + r2,   h0 = rint(128 v)/128 (|v| <= 8: at most 1024 units),  h1 = rint(2^18 (v - h0))/2^18 (at most 1024 units;
+//   below 2^-14 an f16 SUBNORMAL, which v_mfma_f32_32x32x16_f16 takes at its value: scripts/mfma_f16_probe.hip),
+//   r2 = v - h0 - h1, |r2| <= 2^-19, entering as (h0 2^-11).(r2' 2^11) -- both factors f16-representable, the product unscaled,
+// and the dot product as the sum of the limb products, which the MFMA evaluates with the parameter index as its K
+// dimension (P <= 16: one chunk; P <= 32: two), 32 previous x 32 new particles per instruction.  Two f32 accumulators:
+//   X = h0.h0' - hbTop_j          every term a multiple of 2^-14, every partial sum below 2^10: EXACT in f32 whatever the
+//                                 order of accumulation (bound: KS_NORM2 below; probe: 0 inexact sums of 102400)
+//   Y = h0.h1' + h1.h0' + h1.h1' + h0.r2' + r2.h0' - hbLow_j      |Y| ~ 0.01, so its f32 rounding is ~1e-9 absolute
+// where hb_j = 1/2|b_j|^2 - log2 w'_j (= Top, a multiple of 2^-14, + Low) enters through one more (bf16) K-step per accumulator
+// against constant -1 operands.  6 + 2 MFMAs per 16 parameters and 1024 pairs; round 1 / the first half of round 2 used four
+// bf16 limbs, 13 + 2 (bf16 carries 8 significant bits: 15 -> 10 MFMAs alone took the kernel from 3.5 to 2.5 ms, diagnostic
+// build).  1/2|a_i|^2 is the same in every term of row i: it stays out of the sums (integer part: subtracted from every batch's
+// power of two; fraction: k_wfinish, fp64), which also halves the range X has to be exact on.  Left out: h1.r2' + r2.h1'
+// (1.4e-8 rms / 7e-8 max on the exponent at 16 parameters, 2e-8 / 9e-8 at 32: scripts/split_precision.py) and r2.r2'.
+// X + Y is the base-2 exponent of the term up to the row's factor, and the vector pipe only adds and exponentiates:
 //   terms of a batch = 2^n * sum of 2^((X - n) + Y),  n = floor(max X of the batch)      5 issue slots per pair instead of 30
 //   (ks_slots: f32 subtract, add, v_exp_f32, f32 add; one fp64 scaling and add per 16 pairs).
-// Error of the exponent (scripts/split_precision.py): 3e-9 rms, 2e-8 max (P <= 16); 9e-9, 5e-8 (P <= 32); error of a batch
-// sum (16 terms) with the f32 evaluation: 5e-8 rms, 2e-7 max (+ one ulp of v_exp_f32).  Measured error of a weight against the oracle: see
-// tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
-// Rows outside the exact range (|coordinate| > 10, weights outside {0} U [2^-600, 2^400]) are "far": k_wsplit gives them
-// all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up kernels add
-// their pairs (k_kde_far_rows: a far new particle against the whole previous set; k_kde_far_cols: the far previous
+// Error of a batch sum (16 terms) with the f32 evaluation: 5e-8 rms, 2e-7 max (+ one ulp of v_exp_f32).  Measured error of a
+// weight against the oracle: tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
+// Rows outside the exact range (a |coordinate| > 8, |row|^2 > 400, a weight outside {0} U [2^-300, 2^100]) are "far": k_wsplit
+// gives them all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up
+// kernels add their pairs (k_kde_far_rows: a far new particle against the whole previous set; k_kde_far_cols: the far previous
 // particles against every new one), k_wfinish picking per row.  With converged parameters, coordinates beyond the int32
 // exponent range, or too many far rows (> K/16 + 32 new, > 1024 previous) the fp64 kernel above takes the whole call: every
 // kernel is always launched and those whose turn it is not return at once, so no flag travels to the host.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int KS_NL = 4;                       // limbs per coordinate
-constexpr double KS_BOUND = 10.0;              // |scaled coordinate|: 16 NCH B^2 + 2 (8 NCH B^2) + 600 + ... < 2^24/(4 U1)
-constexpr double KS_LW_CAP = 600.0;            // -log2 w' of a non-zero weight (w' = 0 is an all-zero row with hb = KS_HB_ZERO)
+constexpr int KS_NL = 4;                       // f16 operands per 16-parameter chunk and side
+constexpr int KS_NP = 6;                       // limb products per chunk
+// Exact range of the split kernel (rows outside are "far": fp64 fix-ups).  X = sum h0.h0' - hbTop counts in units of 2^-14 and
+// must stay below 2^10 in every partial sum: with |a|^2, |b|^2 <= KS_NORM2 the products of any number of chunks sum to at most
+// |a||b| <= 400 in absolute value (Cauchy-Schwarz), hbTop = 1/2|b|^2 - log2 w' lies in [-100, 500]: at most 900.
+constexpr double KS_BOUND = 8.0;               // |scaled coordinate| (h0 <= 1024 units of 2^-7: one f16)
+constexpr double KS_NORM2 = 400.0;             // |scaled row|^2  (typical: 0.7 x parameters)
+constexpr double KS_LW_CAP = 300.0, KS_LW_MIN = -100.0;   // -log2 w' of a non-zero weight (w' = 0: an all-zero row with hb = KS_HB_ZERO)
 constexpr double KS_HB_ZERO = 1100.0;          // 2^-1100 == 0 in double
-__host__ __device__ constexpr double ks_u1(int nch) { return nch == 1 ? 1024.0 : 512.0; }
+constexpr double KS_U0 = 128.0;                // h0 = rint(v U0) / U0
+constexpr double KS_UH = KS_U0 * 2048.0;       // h1 = rint((v - h0) UH) / UH
+constexpr double KS_XUNIT_INV = KS_U0 * KS_U0; // X counts in units of 2^-14
 
 // Centre of both sets -> wc->centre (one work-group per parameter): the first previous particle plus the mean offset
 // of the previous set from it, each offset clipped at +-16 proposal sigmas.  Without outliers this is the column
@@ -298,7 +309,19 @@ __device__ __forceinline__ unsigned bf16_bits(double v, double* back) {      // 
     *back = (double)__uint_as_float(u);
     return u >> 16;
 }
-// h = top (a multiple of 1/(4 U1), <= 24 significant bits: three bf16 pieces hold it exactly) + low (three more pieces)
+// IEEE binary16 bits of x (|x| < 2^15), round to nearest even, subnormals kept (v_mfma_f32_32x32x16_f16 takes them at
+// their value: scripts/mfma_f16_probe.hip); by integer arithmetic, so the result does not depend on conversion modes
+__device__ __forceinline__ unsigned f16_bits(double x) {
+    const unsigned sg = (x < 0.0) ? 0x8000u : 0u;
+    const double ax = fabs(x);
+    if (ax == 0.0) return sg;
+    int e = ilogb(ax);
+    if (e < -14) return sg | (unsigned)rint(ldexp(ax, 24));            // subnormal grid 2^-24 (1024 = the smallest normal)
+    unsigned m = (unsigned)rint(ldexp(ax, 10 - e));                     // [1024, 2048]
+    if (m == 2048u) { m = 1024u; e++; }
+    return sg | ((unsigned)(e + 15) << 10) | (m - 1024u);
+}
+// h = top (a multiple of 1/unit_inv = 2^-14, <= 24 significant bits: three bf16 pieces hold it exactly) + low (three more pieces)
 __device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc[6]) {
     const double top = rint(h * unit_inv) / unit_inv;
     double back, rem = top;
@@ -306,22 +329,25 @@ __device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc
     rem = h - top;
     for (int k = 3; k < 6; k++) { pc[k] = bf16_bits(rem, &back); rem -= back; }
 }
-constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
+constexpr unsigned KS_MONE = 0xBF80u;      // bf16 -1
 
 // Limb tiles of one set.  Input: the scaled row-major copy (rows x PPsrc) written by k_wscale.
-// Output, per tile of 32 rows: `ops` operands of 1 KiB in MFMA fragment order [half h][row r][8 bf16] (lane 32h + r
-// reads its 16 bytes at 16*(32h + r)): operand (c*KS_NL + k) = limb k of parameters 16c..16c+15, then the norm step:
-//   previous set (w != NULL), ONE operand:  K-slots 0..2 hbTop pieces, 3..5 hbLow pieces, 8..13 ones
-//   new set, TWO operands (for X and for Y): K-slots 0..2 (X) / 3..5 (Y) = -1, 8..10 (X) = -haTop pieces,
-//                                            11..13 (Y) = -haLow pieces
-// so that (previous operand) . (new X operand) = -hbTop - haTop and . (new Y operand) = -hbLow - haLow.
+// Output, per tile of 32 rows: `ops` operands of 1 KiB in MFMA fragment order [half h][row r][8 x 16 bit] (lane 32h + r
+// reads its 16 bytes at 16*(32h + r)): operand (c*KS_NL + k) = f16 operand k of parameters 16c..16c+15
+//   0: h0    1: h1    2: h0 2^-11    3: r2 2^11        (v = h0 + h1 + r2; operands 2 and 3 meet in h0.r2' = (h0 2^-11).(r2' 2^11):
+//                                                        r2 itself, below 2^-19, would fall on f16's subnormal grid)
+// and, for the previous set (w != NULL), ONE more operand (bf16) for the norm step: K-slots 0..2 hbTop pieces, 3..5 hbLow pieces,
+// hb = 1/2|b|^2 - log2 w' = Top (a multiple of 2^-14) + Low; the kernel multiplies it with constant -1 patterns.
+// The new set's 1/2|a_i|^2 is common to every term of row i and stays OUT of the sums: its integer part goes to ha_int
+// (subtracted from the exponent of every batch's power of two), its fraction to ha_frac (k_wfinish, fp64).
 // Rows >= rows are padding: zero limbs; a padded previous row has hb = KS_HB_ZERO (a term of exactly 0).
 template <int NCH>
 __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, int PPsrc, size_t rows, size_t rows_pad,
                                                 const double* __restrict__ w, int is_prev, WConst* __restrict__ wc,
                                                 unsigned short* __restrict__ tiles, int ops,
                                                 unsigned char* __restrict__ far_flag /* new set */,
-                                                unsigned* __restrict__ far_list /* previous set, KS_MAX_FAR_J */) {
+                                                unsigned* __restrict__ far_list /* previous set, KS_MAX_FAR_J */,
+                                                int* __restrict__ ha_int, double* __restrict__ ha_frac /* new set */) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows_pad) return;
     bool valid = r < rows;
@@ -332,12 +358,18 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
         if (wr == 0.0) valid = false;                         // weight 0: contributes exactly nothing, like padding
         else {
             lw = -log2(wr);
-            if (!(lw >= -400.0 && lw <= KS_LW_CAP)) far = true;      // w' > 2^400, < 2^-600, negative or NaN
+            if (!(lw >= KS_LW_MIN && lw <= KS_LW_CAP)) far = true;      // w' > 2^100, < 2^-300, negative or NaN
         }
     }
     constexpr int PPK = 16 * NCH;
     if (valid) {
-        for (int p = 0; p < PPK && p < PPsrc; p++) far = far || !(fabs(sc[r * (size_t)PPsrc + p]) <= KS_BOUND);
+        double n2 = 0.0;
+        for (int p = 0; p < PPK && p < PPsrc; p++) {
+            const double v = sc[r * (size_t)PPsrc + p];
+            far = far || !(fabs(v) <= KS_BOUND);
+            n2 = fma(v, v, n2);
+        }
+        far = far || !(n2 <= KS_NORM2);
     }
     // a far row takes no part in the matrix work (all-zero limbs, and hb = KS_HB_ZERO on the previous side): the fp64
     // fix-up kernels (k_kde_far_rows / k_kde_far_cols) add its pairs
@@ -349,7 +381,6 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
     if (!is_prev) far_flag[r] = far ? 1 : 0;
     unsigned short* tb = tiles + (r >> 5) * (size_t)ops * 512;
     const unsigned rr = (unsigned)(r & 31);
-    constexpr double U1 = ks_u1(NCH);
     double nn = 0.0;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -361,17 +392,15 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
                 const int p = c * 16 + h * 8 + j;            // the copy is PPsrc wide (zero padded to a power of two)
                 const double v = (valid && p < PPsrc) ? sc[r * (size_t)PPsrc + p] : 0.0;
                 nn = fma(v, v, nn);
-                double back;
-                const double l0 = rint(v * 4.0) * 0.25;
-                const double r1 = v - l0;
-                const double l1 = rint(r1 * U1) * (1.0 / U1);
-                const double r2 = r1 - l1;
+                const double h0 = rint(v * KS_U0) * (1.0 / KS_U0);       // <= 1024 units of 2^-7: exact in f16
+                const double r1 = v - h0;                                // |r1| <= 2^-8
+                const double h1 = rint(r1 * KS_UH) * (1.0 / KS_UH);      // <= 1024 units of 2^-18: exact in f16 (subnormal below 2^-14)
+                const double r2 = r1 - h1;                               // |r2| <= 2^-19
                 unsigned b[KS_NL];
-                b[0] = bf16_bits(l0, &back);
-                b[1] = bf16_bits(l1, &back);
-                b[2] = bf16_bits(r2, &back);
-                const double r3 = r2 - back;
-                b[3] = bf16_bits(r3, &back);
+                b[0] = f16_bits(h0);
+                b[1] = f16_bits(h1);
+                b[2] = f16_bits(h0 * 0x1p-11);                           // exact: multiples of 2^-18, on the subnormal grid 2^-24
+                b[3] = f16_bits(r2 * 0x1p11);                            // |.| <= 2^-8, eleven significant bits
 #pragma unroll
                 for (int k = 0; k < KS_NL; k++) {
                     if (j & 1) pk[k][j >> 1] |= b[k] << 16; else pk[k][j >> 1] = b[k];
@@ -382,18 +411,16 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
                 *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + rr) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
         }
     }
-    unsigned pc[6];
-    unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
     if (is_prev) {
-        ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, 4.0 * U1, pc);
+        unsigned pc[6];
+        unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
+        ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
         *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), 0u);
-        *(uint4*)(ob + (32 + rr) * 8) = make_uint4(KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), KS_ONE | (KS_ONE << 16), 0u);
+        *(uint4*)(ob + (32 + rr) * 8) = make_uint4(0u, 0u, 0u, 0u);
     } else {
-        ks_pieces(-0.5 * nn, 4.0 * U1, pc);                     // negated: the operand holds -ha  (0 for a far row)
-        *(uint4*)(ob + rr * 8) = make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u);                       // X operand
-        *(uint4*)(ob + (32 + rr) * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2], 0u, 0u);
-        *(uint4*)(ob + 512 + rr * 8) = make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u);           // Y operand
-        *(uint4*)(ob + 512 + (32 + rr) * 8) = make_uint4(0u, pc[3] << 16, pc[4] | (pc[5] << 16), 0u);
+        const double ha = 0.5 * nn, hi = floor(ha);          // 0 for a far / padded row
+        ha_int[r] = (int)hi;
+        ha_frac[r] = ha - hi;
     }
 }
 
@@ -473,44 +500,45 @@ __global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__
     fix_j[i] = s;
 }
 
-// The 13 limb cross-products of one 16-parameter chunk, in issue order: which accumulator, which limb of the previous
-// (A operand) and of the new (B operand) particle.  X takes the three products that are multiples of 1/(4 U1); the two
-// chains alternate at the start so that no MFMA waits for the one just issued.
-constexpr signed char KS_LX[13] = {1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
-constexpr signed char KS_LA[13] = {0, 3, 0, 1, 1, 2, 3, 0, 2, 1, 2, 0, 1};
-constexpr signed char KS_LB[13] = {0, 1, 1, 3, 0, 2, 0, 3, 1, 2, 0, 2, 1};
-__host__ __device__ constexpr int ks_nsteps(int nch) { return 13 * nch + 2; }
+// The limb products of one 16-parameter chunk, in issue order: which accumulator, which operand of the previous (A) and
+// of the new (B) particle.  X takes h0.h0' (multiples of 2^-14); Y takes h0.h1', h1.h0', h1.h1', h0.r2', r2.h0'.  Left out:
+// h1.r2' + r2.h1' (each factor pair below 2^-8 x 2^-19: 1.4e-8 rms on the exponent at 16 parameters, scripts/split_precision.py)
+// and r2.r2'.
+constexpr signed char KS_LX[KS_NP] = {1, 0, 0, 0, 0, 0};
+constexpr signed char KS_LA[KS_NP] = {0, 0, 1, 1, 2, 3};
+constexpr signed char KS_LB[KS_NP] = {0, 1, 0, 1, 3, 2};
+__host__ __device__ constexpr int ks_nsteps(int nch) { return KS_NP * nch + 2; }
 
-// step S of a batch (one 32 x 32 block of pairs): 13 products per chunk, then the norm step into X and into Y
+// step S of a batch (one 32 x 32 block of pairs).  The norm step comes FIRST in each accumulator's chain (X: -hbTop, then
+// the h0.h0' of every chunk -- the order the exactness bound above is stated for); NB: the two constant B operands of the norm step
 template <int NCH, int S>
-__device__ __forceinline__ void ks_mfma(const bf16x8* A, const bf16x8* B, f32x16& X, f32x16& Y) {
-    constexpr int NS = 13 * NCH;
-    if constexpr (S < NS) {
-        constexpr int c = S / 13, l = S % 13;
-        const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const bf16x8 a = A[c * KS_NL + KS_LA[l]], b = B[c * KS_NL + KS_LB[l]];
-        if constexpr (KS_LX[l] != 0) X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, (c == 0 && l == 0) ? Z : X, 0, 0, 0);
-        else Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, (c == 0 && l == 1) ? Z : Y, 0, 0, 0);
-    } else if constexpr (S == NS) {
-        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NCH * KS_NL], B[NCH * KS_NL], X, 0, 0, 0);
+__device__ __forceinline__ void ks_mfma(const uint4* A, const uint4* B, const uint4 (&NB)[2], f32x16& X, f32x16& Y) {
+    const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (S == 0) {
+        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[0]), Z, 0, 0, 0);
+    } else if constexpr (S == 1) {
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[1]), Z, 0, 0, 0);
     } else {
-        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NCH * KS_NL], B[NCH * KS_NL + 1], Y, 0, 0, 0);
+        constexpr int c = (S - 2) / KS_NP, l = (S - 2) % KS_NP;
+        const f16x8 a = __builtin_bit_cast(f16x8, A[c * KS_NL + KS_LA[l]]), b = __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]);
+        if constexpr (KS_LX[l] != 0) X = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, X, 0, 0, 0);
+        else Y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Y, 0, 0, 0);
     }
 }
 template <int NCH, int S0, int S1>
-__device__ __forceinline__ void ks_mfma_range(const bf16x8* A, const bf16x8* B, f32x16& X, f32x16& Y) {
+__device__ __forceinline__ void ks_mfma_range(const uint4* A, const uint4* B, const uint4 (&NB)[2], f32x16& X, f32x16& Y) {
     if constexpr (S0 < S1) {
-        ks_mfma<NCH, S0>(A, B, X, Y);
-        ks_mfma_range<NCH, S0 + 1, S1>(A, B, X, Y);
+        ks_mfma<NCH, S0>(A, B, NB, X, Y);
+        ks_mfma_range<NCH, S0 + 1, S1>(A, B, NB, X, Y);
     }
 }
 // One batch of vector work interleaved with the NEXT batch's matrix work: slot R issues its share of the next
 // batch's MFMAs (into Xn, Yn), then exponentiates G elements of the finished batch (Xc, Yc).  A wave issues in order
-// and an MFMA occupies the matrix pipe for 32 cycles, so 15 of them in a row would hold the wave's own exponentials
-// back for ~480 cycles; spread over the slots they keep both pipes of the SIMD fed from a single wave.
+// and an MFMA occupies the matrix pipe for 32 cycles, so 8 of them in a row would hold the wave's own exponentials
+// back for ~256 cycles; spread over the slots they keep both pipes of the SIMD fed from a single wave.
 // The vector side, 2^(X + Y) summed over the batch: the 16 terms a lane owns of one 32 x 32 block share ONE power of two,
 // n = floor(max X) over the lane's 16 exponents (8 v_max3_f32); every term is 2^((X - n) + Y) straight from v_exp_f32 --
-// X - n is exact (both are multiples of 1/(4 U1) below 2^12; where |X - n| reaches 2^12 the term is 2^-4096 of the batch's
+// X - n is exact (both are multiples of 2^-14 below 2^10; where |X - n| reaches 2^10 the term is 2^-1024 of the batch's
 // largest), the add rounds once at 2^-24 |g| with g < 1.25 for the terms that carry the sum; the hardware's 2^g measured on
 // gfx950 over every float of [-0.3, 1.3] (scripts/exp2_hw_accuracy.hip): max 8.2e-8, rms 2.6e-8 relative -- the 16 terms
 // are added in f32 (four chains of four, then a tree: <= 5 roundings on a term's path) and ONE convert / v_ldexp_f64 /
@@ -519,8 +547,9 @@ __device__ __forceinline__ void ks_mfma_range(const bf16x8* A, const bf16x8* B, 
 // v_add_f32 = 5 issue slots (the transcendental counts two) + 1 of batch overhead, against 8 for the per-pair form of the
 // first half of round 2 (floor, fract, add, exp, convert, ldexp, fp64 add) and 14.5 fp64 instructions in round 1.  Error
 // of a batch sum (scripts/split_precision.py): rms 4.6e-8, max 2.0e-7 relative (P <= 16; 5.0e-8 / 2.2e-7 at P <= 32).
-// Measured at 1e10 pairs, P = 16, same box: 3.85 ms (per-pair form) -> 3.51 ms; 620 cycles per 1024 pairs and SIMD at
-// the power-limited 1.70 GHz, matrix pipe 0.78 busy, vector issue 0.73 (PMC).
+// Measured at 1e10 pairs, P = 16, same box, with the 15-MFMA bf16 split: 3.85 ms (per-pair form) -> 3.51 ms (620 cycles per
+// 1024 pairs and SIMD at the power-limited 1.70 GHz, matrix pipe 0.78 busy, vector issue 0.73: PMC); with the 8-MFMA f16 split
+// 2.3 ms: the vector side is what is left.
 __device__ __forceinline__ float ks_max3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // (fmaxf would canonicalise its inputs first)
@@ -528,14 +557,14 @@ __device__ __forceinline__ float ks_max3(float a, float b, float c) {
 }
 struct KsRef { float nf; int n; float p0, p1, p2, p3; };
 template <int NCH, int G, int R>
-__device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32x16& Xn, f32x16& Yn,
-                                             const f32x16& Xc, const f32x16& Yc, double& s, KsRef& q) {
+__device__ __forceinline__ void ks_slots(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Xn, f32x16& Yn,
+                                         const f32x16& Xc, const f32x16& Yc, double& s, KsRef& q, int hsub) {
     if constexpr (R < 16 / G) {
         constexpr int NS = ks_nsteps(NCH), SL = 14 / G;
         constexpr int s0 = (R < SL) ? (R * NS) / SL : NS, s1 = (R < SL) ? ((R + 1) * NS) / SL : NS;
         if constexpr (s0 > 0 && s0 < NS) asm volatile("" : "+v"(Xn));
         if constexpr (s0 > 1 && s0 < NS) asm volatile("" : "+v"(Yn));
-        ks_mfma_range<NCH, s0, s1>(An, Bn, Xn, Yn);
+        ks_mfma_range<NCH, s0, s1>(An, Bn, NB, Xn, Yn);
         if constexpr (R == 0) {
             const float m0 = ks_max3(Xc[0], Xc[1], Xc[2]), m1 = ks_max3(Xc[3], Xc[4], Xc[5]), m2 = ks_max3(Xc[6], Xc[7], Xc[8]),
                         m3 = ks_max3(Xc[9], Xc[10], Xc[11]), m4 = ks_max3(Xc[12], Xc[13], Xc[14]);
@@ -554,17 +583,17 @@ __device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32
             float t = q.p0 + q.p1;
             asm volatile("" : "+v"(t));                       // (keeps the two adds from being packed: v_pk_add_f32 beside MFMAs costs more)
             t += q.p2 + q.p3;
-            s += ldexp((double)t, q.n);
+            s += ldexp((double)t, q.n - hsub);               // hsub = floor(1/2|a_i|^2): the row's own factor, see k_wsplit
             asm volatile("" : "+v"(s));
         } else {
             asm volatile("" : "+v"(q.p0), "+v"(q.p1), "+v"(q.p2), "+v"(q.p3));
         }
         __builtin_amdgcn_sched_barrier(0);
-        ks_slots<NCH, G, R + 1>(An, Bn, Xn, Yn, Xc, Yc, s, q);
+        ks_slots<NCH, G, R + 1>(An, Bn, NB, Xn, Yn, Xc, Yc, s, q, hsub);
     }
 }
 
-// part[slice*kn + i] = sum_{j in slice} 2^(a_i.b_j - 1/2|a_i|^2 - hb_j).  256 threads = 4 waves x 64 new particles
+// part[slice*kn + i] = 2^frac(1/2|a_i|^2) sum_{j in slice} 2^(a_i.b_j - 1/2|a_i|^2 - hb_j).  256 threads = 4 waves x 64 new particles
 // (two 32-column tiles per wave, resident as B operands); the previous set streams through as A operands, 32 rows a
 // tile, each lane loading its own 16-byte fragments one tile ahead (the four waves of a group and its neighbours
 // read the same tile at about the same time: L1 / L2 hits).  D = A.B puts the new particle on the lane and 16
@@ -572,37 +601,43 @@ __device__ __forceinline__ void ks_slots(const bf16x8* An, const bf16x8* Bn, f32
 template <int NCH, int G>
 __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4* __restrict__ at, size_t kn,
                                                       const uint4* __restrict__ bt, unsigned nbt,
-                                                      const WConst* __restrict__ wc, double* __restrict__ part) {
+                                                      const WConst* __restrict__ wc, const int* __restrict__ ha_int,
+                                                      double* __restrict__ part) {
     if (!ks_split_on(wc)) return;                             // the fp64 kernel's turn
-    constexpr int OPA = NCH * KS_NL + 2, OPB = NCH * KS_NL + 1;
+    constexpr int OPA = NCH * KS_NL, OPB = NCH * KS_NL + 1;
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
     const unsigned slices = gridDim.y, sl = blockIdx.y;
     const unsigned t0 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * sl / slices));
     const unsigned t1 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * (sl + 1) / slices));
 
-    bf16x8 B0[OPA], B1[OPA];
+    uint4 B0[OPA], B1[OPA];
 #pragma unroll
     for (int q = 0; q < OPA; q++) {
-        B0[q] = __builtin_bit_cast(bf16x8, at[((it0 + 0) * OPA + q) * 64 + lane]);
-        B1[q] = __builtin_bit_cast(bf16x8, at[((it0 + 1) * OPA + q) * 64 + lane]);
+        B0[q] = at[((it0 + 0) * OPA + q) * 64 + lane];
+        B1[q] = at[((it0 + 1) * OPA + q) * 64 + lane];
     }
+    // constant B operands of the norm step (bf16 -1 in K-slots 0..2: X takes -hbTop; in 3..5: Y takes -hbLow)
+    uint4 NB[2];
+    NB[0] = (lane < 32) ? make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    NB[1] = (lane < 32) ? make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u) : make_uint4(0u, 0u, 0u, 0u);
+    const int hs0 = ha_int[(it0 + 0) * 32 + (lane & 31)], hs1 = ha_int[(it0 + 1) * 32 + (lane & 31)];
     double acc0 = 0.0, acc1 = 0.0;
     if (t0 < t1) {
-        bf16x8 A[OPB];
+        uint4 A[OPB];
 #pragma unroll
-        for (int q = 0; q < OPB; q++) A[q] = __builtin_bit_cast(bf16x8, bt[((size_t)t0 * OPB + q) * 64 + lane]);
+        for (int q = 0; q < OPB; q++) A[q] = bt[((size_t)t0 * OPB + q) * 64 + lane];
         f32x16 X0, Y0, X1, Y1;
-        ks_mfma_range<NCH, 0, ks_nsteps(NCH)>(A, B0, X0, Y0);                    // (t0, columns 0)
+        ks_mfma_range<NCH, 0, ks_nsteps(NCH)>(A, B0, NB, X0, Y0);                // (t0, columns 0)
         for (unsigned t = t0; t < t1; t++) {
-            bf16x8 An[OPB];
+            uint4 An[OPB];
             const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass re-reads its own tile (no branch); unused
 #pragma unroll
-            for (int q = 0; q < OPB; q++) An[q] = __builtin_bit_cast(bf16x8, bt[((size_t)tn * OPB + q) * 64 + lane]);
+            for (int q = 0; q < OPB; q++) An[q] = bt[((size_t)tn * OPB + q) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
             KsRef q;
-            ks_slots<NCH, G, 0>(A, B1, X1, Y1, X0, Y0, acc0, q);      // matrix: (t, columns 1); vector: (t, columns 0)
-            ks_slots<NCH, G, 0>(An, B0, X0, Y0, X1, Y1, acc1, q);     // matrix: (t+1, columns 0); vector: (t, columns 1)
+            ks_slots<NCH, G, 0>(A, B1, NB, X1, Y1, X0, Y0, acc0, q, hs0);      // matrix: (t, columns 1); vector: (t, columns 0)
+            ks_slots<NCH, G, 0>(An, B0, NB, X0, Y0, X1, Y1, acc1, q, hs1);     // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
             for (int q = 0; q < OPB; q++) A[q] = An[q];       // (two tiles per trip with A / An trading places: no gain, measured)
         }
@@ -635,7 +670,7 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
                                                  const WConst* __restrict__ wc, double* __restrict__ w_raw,
                                                  int split_launched, int epan, int* __restrict__ which,
                                                  const unsigned char* __restrict__ far_flag, const double* __restrict__ fix_i,
-                                                 const double* __restrict__ fix_j) {
+                                                 const double* __restrict__ fix_j, const double* __restrict__ ha_frac) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool split_on = split_launched && ks_split_on(wc);
     if (i == 0) *which = split_on ? ABC_KDE_RAN_SPLIT : ABC_KDE_RAN_FP64;       // abc_kde_last_kernel
@@ -647,6 +682,7 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
         den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far_rows
     } else {
         for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
+        if (split_on) den *= exp2(-ha_frac[i]);              // the fraction of 1/2|a_i|^2 the split kernel left out (k_wsplit)
         if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far_cols)
     }
     if (epan) w_raw[i] = (den > 0.0) ? num / den : 0.0;          // compact support: a particle nothing supports gets weight 0
@@ -731,7 +767,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
     const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
-    const int opa = NCH * KS_NL + 2, opb = NCH * KS_NL + 1;
+    const int opa = NCH * KS_NL, opb = NCH * KS_NL + 1;
     if (split) {
         // Every work-group of the split kernel loads its 48-96 KB of resident operands once per slice: with the 65 slices
         // the fp64 kernel likes that was 1.2 GB of fabric traffic per launch at K = K' = 1e5 (PMC).  Its time is flat between
@@ -749,7 +785,8 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     unsigned short *at = nullptr, *bt = nullptr;
     unsigned char* far_flag = nullptr;
     unsigned* far_list = nullptr;
-    double *fix_i = nullptr, *fix_j = nullptr;
+    double *fix_i = nullptr, *fix_j = nullptr, *ha_frac = nullptr;
+    int* ha_int = nullptr;
     if (split) {
         at = (unsigned short*)abc_ws_alloc(ctx, nat * opa * 1024);
         bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
@@ -757,7 +794,9 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         far_list = (unsigned*)abc_ws_alloc(ctx, KS_MAX_FAR_J * sizeof(unsigned));
         fix_i = (double*)abc_ws_alloc(ctx, kn * sizeof(double));
         fix_j = (double*)abc_ws_alloc(ctx, kn * sizeof(double));
-        if (!at || !bt || !far_flag || !far_list || !fix_i || !fix_j) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+        ha_frac = (double*)abc_ws_alloc(ctx, nat * 32 * sizeof(double));
+        ha_int = (int*)abc_ws_alloc(ctx, nat * 32 * sizeof(int));
+        if (!at || !bt || !far_flag || !far_list || !fix_i || !fix_j || !ha_frac || !ha_int) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     }
     if (!wc || !a || !b || !part || !hb || !cpart) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
@@ -773,14 +812,14 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         const size_t ra = nat * 32, rbp = nbt * 32;
         if (NCH == 1) {
             hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
-                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list);
+                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list, ha_int, ha_frac);
             hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb, far_flag, far_list);
+                               w_prev, 1, wc, bt, opb, far_flag, far_list, ha_int, ha_frac);
         } else {
             hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
-                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list);
+                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list, ha_int, ha_frac);
             hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb, far_flag, far_list);
+                               w_prev, 1, wc, bt, opb, far_flag, far_list, ha_int, ha_frac);
         }
     }
 #define LAUNCH_KDE(PPV)                                                                                        \
@@ -803,7 +842,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         if (split) {
 #define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
     hipLaunchKernelGGL((k_kde_split<NCHV, GV>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, \
-                       (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, part)
+                       (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part)
             if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot (one: +1 %, four: +5 %)
             else LAUNCH_SPLIT(2, 2);
 #undef LAUNCH_SPLIT
@@ -835,7 +874,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #undef LAUNCH_FAR
     }
     hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
-                       (int)slices, wc, w_raw, split ? 1 : 0, epan ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j);
+                       (int)slices, wc, w_raw, split ? 1 : 0, epan ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j, ha_frac);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

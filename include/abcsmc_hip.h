@@ -69,10 +69,11 @@ int  abc_ctx_use_own_stream(abc_ctx* ctx);
 int  abc_ctx_synchronize(abc_ctx* ctx);
 int  abc_version(void);
 /* Which kernel evaluates the O(K K' P) pair sums of weight_predictive_prior (AbcUtil.cpp:556-581).
- * ABC_KDE_AUTO (default): 5 <= P <= 32 parameters run the split-operand kernel (pair dot products on the bf16 matrix
- * pipe from four exact limbs per coordinate, <= 2e-8 (P <= 16) / 5e-8 (P <= 32) absolute error in the base-2 exponent of a
- * term; the term itself is evaluated in f32 and summed in fp64: <= 1.3e-7 relative on a term, rms 4e-8, measured <= 1e-7 on a
- * weight, budget 1e-6; sets it cannot represent exactly fall back by themselves); P < 5 and 32 < P run the fp64 kernel.
+ * ABC_KDE_AUTO (default): 5 <= P <= 32 parameters run the split-operand kernel (pair dot products on the f16 matrix
+ * pipe from three limbs per coordinate, 1.4e-8 rms / 7e-8 max (P <= 16), 2e-8 / 9e-8 (P <= 32) absolute error in the base-2
+ * exponent of a term; the terms are evaluated in f32, sixteen at a time, and summed in fp64: 5e-8 rms / 2e-7 max relative on such
+ * a partial sum, tests hold every weight to 2e-7, budget 1e-6; rows it cannot represent exactly are summed in fp64, sets it
+ * cannot take fall back by themselves); P < 5 and 32 < P run the fp64 kernel.
  * ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);

@@ -1,9 +1,10 @@
 """Numpy emulation of the operand split of the weight kernel k_kde_split (abcsmc_amd/csrc/weights.hip): absolute error of
-the pair dot product a.b (= error of the base-2 exponent of a term) against fp64, for the shipped split and for cheaper
-ones.  Limbs: l0 = rint(4 v)/4, l1 = rint(U1 (v - l0))/U1, then bf16 roundings of what is left.  X = l0.l0' + l0.l1' + l1.l0'
-is accumulated exactly (every partial sum is a multiple of 1/(4 U1) below 2^24/(4 U1)); Y = the remaining products goes
-through an f32 accumulator, emulated here with ONE rounding per added product (pessimistic: the MFMA rounds less often).
-For the shipped split the f32 evaluation of the terms (ks_slots_ref: the 16 terms of a lane's batch share n = floor(max X),
+the pair dot product a.b (= error of the base-2 exponent of a term) against fp64, for the shipped split and for variants.
+Limbs (f16 operands of v_mfma_f32_32x32x16_f16): h0 = rint(128 v)/128, h1 = rint(2^18 (v - h0))/2^18, r2 = v - h0 - h1 (enters
+scaled: (h0 2^-11).(r2' 2^11)).  X = h0.h0' is accumulated exactly (every partial sum is a multiple of 2^-14 below 2^10); Y =
+h0.h1' + h1.h0' + h1.h1' + h0.r2' + r2.h0' goes through an f32 accumulator, emulated here with ONE rounding per added product
+(pessimistic: the MFMA rounds less often).  Left out: h1.r2' + r2.h1' (the "cross" variant adds them) and r2.r2'.
+For the shipped split the f32 evaluation of the terms (ks_slots: the 16 terms of a lane's batch share n = floor(max X),
 g = (X - n) + Y in f32, 2^g in f32, an f32 sum of the 16, then an exact scaling by 2^n) is emulated as well and the RELATIVE
 error of the batch sums reported: that, not the exponent error, is what a weight inherits.
     python scripts/split_precision.py [P] [n]"""
@@ -13,30 +14,25 @@ import numpy as np
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
-U1 = 1024.0 if P <= 16 else 512.0
 rng = np.random.default_rng(1)
 # scaled coordinates of a posterior against the previous one: N(0, 0.85) (sqrt(log2 e) / sqrt(2) proposal sigmas)
 a = rng.normal(0, 0.85, (n, P))
 b = rng.normal(0, 0.85, (n, P))
 
 
-def bf16(v):
-    f = v.astype(np.float32).view(np.uint32)
-    f = (f + 0x7fff + ((f >> 16) & 1)) & 0xffff0000
-    return f.view(np.float32).astype(np.float64)
+def f16(v):
+    return v.astype(np.float16).astype(np.float64)          # IEEE binary16, round to nearest even, subnormals kept
 
 
-def split(v, nl):
-    l0 = np.rint(v * 4) / 4
-    r = v - l0
-    l1 = np.rint(r * U1) / U1
-    r = r - l1
-    L = [l0, l1]
-    for _ in range(nl - 2):
-        l = bf16(r)
-        r = r - l
-        L.append(l)
-    return L
+def split(v):
+    h0 = np.rint(v * 128.0) / 128.0
+    r1 = v - h0
+    h1 = np.rint(r1 * 2.0 ** 18) / 2.0 ** 18
+    r2 = r1 - h1
+    ops = [h0, h1, h0 * 2.0 ** -11, f16(r2 * 2.0 ** 11), h1 * 2.0 ** -4, f16(r2 * 2.0 ** 4)]
+    for k in (0, 1, 2, 4):
+        assert np.array_equal(f16(ops[k]), ops[k]), "operand %d is not exact in f16" % k
+    return ops
 
 
 def acc_f32(x, y, acc):
@@ -47,12 +43,10 @@ def acc_f32(x, y, acc):
 
 
 ref = a @ b.T
-full = [(3, 1), (1, 3), (2, 2), (3, 0), (0, 3), (2, 1), (1, 2), (2, 0), (0, 2), (1, 1)]      # issue order of KS_LA / KS_LB
-cases = [("shipped: 4 limbs, 13 products", 4, full),
-         ("without (1,3),(3,1)", 4, [p for p in full if p not in [(1, 3), (3, 1)]]),
-         ("without (1,3),(3,1),(2,2)", 4, [p for p in full if p not in [(1, 3), (3, 1), (2, 2)]]),
-         ("3 limbs, 9 products", 3, [(2, 2), (2, 1), (1, 2), (2, 0), (0, 2), (1, 1)]),
-         ("5 limbs, 15 products", 5, [(4, 0), (0, 4)] + full)]
+base = [(0, 1), (1, 0), (1, 1), (2, 3), (3, 2)]                  # (operand of a, operand of b'), issue order of KS_LA / KS_LB
+cases = [("shipped: 3 limbs, 6 products", base),
+         ("cross: + h1.r2' + r2.h1'", base + [(4, 5), (5, 4)]),
+         ("without h1.h1'", [p for p in base if p != (1, 1)])]
 def term_f32(X, Y32):
     """ks_slots_ref of weights.hip: the 16 terms a lane owns of one 32 x 32 block share n = floor(max X); every term is
     2^((X - n) + Y) with X - n exact and one f32 rounding in the add, 2^g from the hardware's v_exp_f32 -- emulated here by
@@ -76,11 +70,11 @@ def term_f32(X, Y32):
     return np.ldexp(t.astype(np.float64), nfl[:, :, 0].astype(np.int64)), g
 
 
-print("P = %d, %d x %d pairs, U1 = %g" % (P, n, n, U1))
-for name, nl, pairs in cases:
-    A, B = split(a, nl), split(b, nl)
-    X = A[0] @ B[0].T + A[0] @ B[1].T + A[1] @ B[0].T          # exact by construction (checked below)
-    Xf = acc_f32(A[1], B[0], acc_f32(A[0], B[1], acc_f32(A[0], B[0], np.zeros((n, n), np.float32))))
+print("P = %d, %d x %d pairs" % (P, n, n))
+for name, pairs in cases:
+    A, B = split(a), split(b)
+    X = A[0] @ B[0].T                                           # exact by construction (checked below)
+    Xf = acc_f32(A[0], B[0], np.zeros((n, n), np.float32))
     assert np.array_equal(Xf.astype(np.float64), X), "X is not exact in f32"
     Ye = sum(A[i] @ B[j].T for i, j in pairs)
     Y = np.zeros((n, n), np.float32)
@@ -88,7 +82,7 @@ for name, nl, pairs in cases:
         Y = acc_f32(A[i], B[j], Y)
     e_tr, e_all = np.abs(X + Ye - ref), np.abs(X + Y.astype(np.float64) - ref)
     print("%-32s MFMAs %2d   truncation only: rms %.2e max %.2e   with the f32 accumulator: rms %.2e max %.2e" % (
-        name, (3 + len(pairs)) * ((P + 15) // 16) + 2, np.sqrt((e_tr ** 2).mean()), e_tr.max(), np.sqrt((e_all ** 2).mean()), e_all.max()))
+        name, (1 + len(pairs)) * ((P + 15) // 16) + 2, np.sqrt((e_tr ** 2).mean()), e_tr.max(), np.sqrt((e_all ** 2).mean()), e_all.max()))
     if name.startswith("shipped"):
         t, g = term_f32(X, Y)
         exact = np.exp2(ref)[:, :t.shape[1] * 16].reshape(n, -1, 16).sum(axis=2)

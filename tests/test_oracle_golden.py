@@ -257,11 +257,11 @@ def test_alias_host_build_is_bit_exact(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("P,bound_rms,bound_max", [(16, 1e-8, 5e-8), (32, 3e-8, 1.5e-7)])
+@pytest.mark.parametrize("P,bound_rms,bound_max", [(16, 2e-8, 1e-7), (32, 3e-8, 1.5e-7)])
 def test_split_operand_arithmetic_emulation(P, bound_rms, bound_max):
     """the operand split of the weight kernel k_kde_split, emulated in numpy (scripts/split_precision.py): the leading
-    accumulator X is exact in f32 (asserted inside the script for every case) and the exponent error of the shipped
-    split (4 limbs, 13 products per 16 parameters) stays inside the bound the header states"""
+    accumulator X is exact in f32 and the f16 operands that have to be exact are (asserted inside the script for every case)
+    and the exponent error of the shipped split (3 limbs, 6 products per 16 parameters) stays inside the bound the header states"""
     import os
     import re
     import subprocess
