@@ -40,7 +40,7 @@ struct abc_ctx {
     // side stream of the fused drivers: the two taus2 streams of a generation (draws, seeds) depend on the rng state alone and
     // run there from the first launch on, beside the ranking chain (abc_rng_streams_early); ev_fork / ev_side order them
     hipStream_t side;
-    hipEvent_t ev_fork, ev_side;
+    hipEvent_t ev_fork, ev_side, ev_prev;
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
@@ -211,9 +211,19 @@ int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, d
 int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);
 int launch_dv_from_stats(abc_ctx*, const double* stats, size_t P, double* dv);
 int launch_mvn_from_stats(abc_ctx*, const double* stats, size_t P, double* L, int* status_dev);
+// the previous set's share of the weight stage (weights.hip: launch_weights_prev), prepared ahead of launch_weights_raw
+struct abc_wprev {
+    void* wc /* WConst */; double* b; double* hb; unsigned short* bt; unsigned* far_list;
+    size_t Kp, P, kn_max; int split, ready;
+};
+int launch_weights_prev(abc_ctx*, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
+                        const double* dv_prev, abc_wprev* out, hipStream_t st);
 int launch_weights_raw(abc_ctx*, const abc_prior* priors, const double* theta, size_t K, size_t P,
                        size_t k0, size_t kn, const double* theta_prev, size_t Kp,
-                       const double* w_prev, const double* dv_prev, double* w_raw);
+                       const double* w_prev, const double* dv_prev, double* w_raw, const abc_wprev* prev = nullptr);
+// launch_weights_prev on the side stream (resample.hip); the caller makes its stream wait for ctx->ev_prev before the rest
+int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
+                           const double* dv_prev, abc_wprev* out);
 int launch_fill(abc_ctx*, double* w, size_t K, double v);
 int launch_normalize_l2(abc_ctx*, double* w, size_t K);
 int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* L, int* status_host,
@@ -252,7 +262,8 @@ int launch_perturb_reference(abc_ctx*, abc_rng* rng_after_draws, const double* t
 
 // [GSL] gsl_ran_discrete_preproc on the host (alias_host.cpp, a host-only translation unit built with the host compiler):
 // scratch E: K doubles, smalls / bigs: K + 1 uint32 each
-void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs);
+// knuth = false: without the final KNUTH_CONVENTION pass (k_alias_draw applies it when it reads the table)
+void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs, bool knuth = true);
 
 // arena bound shared by api.hip and sharded.hip
 size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext);

@@ -68,7 +68,10 @@ inline double alias_sequential_sum(const double* w, size_t K) {
 
 // [GSL] gsl_ran_discrete_preproc (randist/discrete.c): Walker alias with two LIFO stacks.
 // scratch: K doubles (E) + 2 (K + 1) uint32 (the stacks), caller-provided so the hot loop never allocates.
-inline void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs) {
+// knuth = false: F is left as the cut-off fractions in [0, 1]; the caller applies GSL's KNUTH_CONVENTION map (F[k] + k) / K where
+// the table is read (k_alias_draw does, with the same two IEEE operations), which takes the last pass over K off the host.
+inline void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs,
+                          bool knuth = true) {
     // Same sequence of floating-point operations as GSL's loop (sequential total, E = w / total, one subtraction
     // per small from the big on top of the stack); only the bookkeeping differs: a big that stays big after serving
     // a small is pushed and popped again at once upstream, here it simply stays in registers.  (Threading the
@@ -105,5 +108,5 @@ inline void alias_preproc(size_t K, const double* w, double* F, uint32_t* A, dou
     }
     if (have) { A[cb] = cb; F[cb] = 1.0; }
     while (nb) { const uint32_t b = bigs[--nb]; A[b] = b; F[b] = 1.0; }
-    for (size_t k = 0; k < K; k++) F[k] = (F[k] + (double)k) / dK;            // KNUTH_CONVENTION
+    if (knuth) for (size_t k = 0; k < K; k++) F[k] = (F[k] + (double)k) / dK;            // KNUTH_CONVENTION
 }

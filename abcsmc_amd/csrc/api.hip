@@ -98,7 +98,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     abc_comm_release(ctx);
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_side); }
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_side); if (ctx->ev_prev) (void)hipEventDestroy(ctx->ev_prev); }
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -449,6 +449,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     uint32_t* raw_early = nullptr;
     const bool early = io->w && Nn && K && rng && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
     if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early));
+    // ... and so does everything the weight stage needs of the PREVIOUS set (scales, centre, scaled copy, limb tiles)
+    abc_wprev wprev;
+    memset(&wprev, 0, sizeof(wprev));
+    if (io->w && K && Kp && io->theta_prev && P <= 64)
+        ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     const double* Yp = io->Y ? io->Y : io->X;
     const size_t Pstat = io->Y ? P : 0;
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
@@ -486,8 +491,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (Kp == 0 || !io->theta_prev) {
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
     } else {
+        if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
         ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
-                                   io->w));
+                                   io->w, &wprev));
         ABC_TRY(launch_normalize_l2(ctx, io->w, K));                          // AbcUtil.cpp:583
     }
     int spd = 0;

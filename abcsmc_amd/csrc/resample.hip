@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void k_taus_stream(abc_rng base, size_t n, con
     }
 }
 
-// [GSL] gsl_ran_discrete (KNUTH_CONVENTION): u = get/2^32; c = floor(u*K); F[c]==1 ? c : (u<F[c] ? c : A[c])
+// [GSL] gsl_ran_discrete (KNUTH_CONVENTION): u = get/2^32; c = floor(u*K); F[c]==1 ? c : (u<F[c] ? c : A[c]), with F[k] the
+// preprocessed (F[k] + k) / K: the host leaves that last pass out (alias_preproc, knuth = false) and the two operations run
+// here on the one entry a draw reads -- the same IEEE addition and division, hence the same bits.
 __global__ __launch_bounds__(256) void k_alias_draw(const uint32_t* __restrict__ raw, size_t n,
                                                     const double* __restrict__ F, const uint32_t* __restrict__ A,
                                                     size_t K, unsigned long long* __restrict__ parent) {
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_alias_draw(const uint32_t* __restrict__
     if (i >= n) return;
     const double u = (double)raw[i] / 4294967296.0;
     const size_t c = (size_t)(u * (double)K);
-    const double f = F[c];
+    const double f = (F[c] + (double)c) / (double)K;
     parent[i] = (f == 1.0) ? c : ((u < f) ? c : (size_t)A[c]);
 }
 
@@ -482,7 +484,7 @@ int abc_uniform_alias(abc_ctx* ctx, size_t K) {
     const double v = 1.0 / (double)K;                      // what launch_fill writes (AbcUtil.cpp:543-544)
     for (size_t k = 0; k < K; k++) hw[k] = v;
     const auto t0 = std::chrono::steady_clock::now();
-    abc_alias_preproc(K, hw, hF, hA, hE, hS, hB);
+    abc_alias_preproc(K, hw, hF, hA, hE, hS, hB, /*knuth=*/false);
     if (ctx->timing) {
         ctx->stage_host_ms[ST_ALIAS_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ctx->stage_cnt[ST_ALIAS_HOST] += 1;
@@ -517,6 +519,23 @@ int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t 
     if (seeds) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, ctx->side));
     ABC_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->side));
     *raw_out = raw;
+    return ABC_OK;
+}
+
+// the previous set's share of the weight stage on the side stream (behind whatever abc_rng_streams_early queued there, or
+// forked here); the main stream waits for ev_prev before launch_weights_raw
+int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
+                           const double* dv_prev, abc_wprev* out) {
+    if (!ctx->side) {
+        ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+    }
+    if (!ctx->ev_prev) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_prev, hipEventDisableTiming));
+    ABC_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    ABC_TRY(launch_weights_prev(ctx, P, kn_max, theta_prev, Kp, w_prev, dv_prev, out, ctx->side));
+    ABC_HIP(ctx, hipEventRecord(ctx->ev_prev, ctx->side));
     return ABC_OK;
 }
 
@@ -569,7 +588,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     ABC_HIP(ctx, hipEventSynchronize(ctx->ev_copy));
     {
         const auto t0 = std::chrono::steady_clock::now();
-        abc_alias_preproc(K, hw, hF, hA, hE, hS, hB);
+        abc_alias_preproc(K, hw, hF, hA, hE, hS, hB, /*knuth=*/false);
         if (ctx->timing) {
             ctx->stage_host_ms[ST_ALIAS_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             ctx->stage_cnt[ST_ALIAS_HOST] += 1;

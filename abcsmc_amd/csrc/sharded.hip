@@ -288,6 +288,11 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, beside the ranking
     uint32_t* raw_early = nullptr;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
+    // ... and so does the previous set's share of the weight stage
+    abc_wprev wprev;
+    memset(&wprev, 0, sizeof(wprev));
+    if (Kp && io->theta_prev && P <= 64 && kn)
+        ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
     const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
@@ -383,10 +388,11 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     if (Kp == 0 || !io->theta_prev) {
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                           // AbcUtil.cpp:543-544
     } else {
+        if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
         if (W == 1) {
-            ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, io->w));
+            ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, io->w, &wprev));
         } else {
-            if (kn) ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, k0, kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, w_mine));
+            if (kn) ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, k0, kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, w_mine, &wprev));
             ABC_TRY(comm_all_gather(ctx, w_mine, w_slices, kmax * 8));
             hipLaunchKernelGGL(k_unpad_slices, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w_slices, K, W, kmax, io->w);
             ABC_HIP(ctx, hipGetLastError());

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_epan(const double* __restrict__ a, size
 // weight against the oracle: tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
 // Rows outside the exact range (a |coordinate| > 8, |row|^2 > 400, a weight outside {0} U [2^-300, 2^100]) are "far": k_wsplit
 // gives them all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up
-// kernels add their pairs (k_kde_far_rows: a far new particle against the whole previous set; k_kde_far_cols: the far previous
+// kernels add their pairs (k_kde_far: a far new particle against the whole previous set; the far previous
 // particles against every new one), k_wfinish picking per row.  With converged parameters, coordinates beyond the int32
 // exponent range, or too many far rows (> K/16 + 32 new, > 1024 previous) the fp64 kernel above takes the whole call: every
 // kernel is always launched and those whose turn it is not return at once, so no flag travels to the host.
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
         far = far || !(n2 <= KS_NORM2);
     }
     // a far row takes no part in the matrix work (all-zero limbs, and hb = KS_HB_ZERO on the previous side): the fp64
-    // fix-up kernels (k_kde_far_rows / k_kde_far_cols) add its pairs
+    // fix-up kernel (k_kde_far) adds its pairs
     if (far) {
         if (is_prev) { const int pos = atomicAdd(&wc->nfar_j, 1); if (pos < KS_MAX_FAR_J) far_list[pos] = (unsigned)r; }
         else atomicAdd(&wc->nfar_i, 1);
@@ -425,27 +425,6 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
 }
 
 // ---- far rows: pairs the split-operand kernel leaves out, in fp64 -----------------------------------------------------
-// ascending order of the (atomically appended, hence unordered) list of far previous rows: one work-group, bitonic in LDS;
-// a fixed order makes the column fix-up's sums bit-reproducible
-__global__ __launch_bounds__(1024) void k_wfarsort(const WConst* __restrict__ wc, unsigned* __restrict__ list) {
-    __shared__ unsigned sl[KS_MAX_FAR_J];
-    const int n = wc->nfar_j;
-    if (n <= 1 || n > KS_MAX_FAR_J || !ks_split_on(wc)) return;
-    const unsigned t = threadIdx.x;
-    sl[t] = ((int)t < n) ? list[t] : 0xffffffffu;
-    for (unsigned k = 2; k <= KS_MAX_FAR_J; k <<= 1)
-        for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            const unsigned u = t ^ j;
-            if (u > t) {
-                const unsigned a = sl[t], b = sl[u];
-                if ((a > b) == ((t & k) == 0)) { sl[t] = b; sl[u] = a; }
-            }
-        }
-    __syncthreads();
-    if ((int)t < n) list[t] = sl[t];
-}
-
 // the base-2 exponent of one pair from the scaled fp64 rows, as k_kde's guarded loop computes it
 template <int PP>
 __device__ __forceinline__ double ks_pair_term(const double (&ai)[PP], double ha, const double* __restrict__ bj, double hbj) {
@@ -455,38 +434,51 @@ __device__ __forceinline__ double ks_pair_term(const double (&ai)[PP], double ha
     return exp2_neg<true>(e);
 }
 
-// far NEW particles: their whole sum over the previous set.  One work-group per tile of 32 new rows; tiles without a
-// far row (nearly all) return at once.
+// The pairs of far rows, ONE launch (it returns at once when there are none): work-groups [0, nat) take the far NEW particles
+// -- their whole sum over the previous set, one work-group per tile of 32 new rows, tiles without a far row return --,
+// work-groups [nat, nat + rb) the far PREVIOUS particles: their terms for every new particle (one per lane), in ascending row
+// order (the atomically appended list is sorted in LDS by every work-group: a fixed order makes the sums bit-reproducible).
 template <int PP>
-__global__ __launch_bounds__(256) void k_kde_far_rows(const double* __restrict__ a, size_t kn, const double* __restrict__ b,
-                                                      size_t Kp, const double* __restrict__ hb, const WConst* __restrict__ wc,
-                                                      const unsigned char* __restrict__ far_flag, double* __restrict__ fix_i) {
-    if (!ks_split_on(wc) || wc->nfar_i == 0) return;
+__global__ __launch_bounds__(256) void k_kde_far(const double* __restrict__ a, size_t kn, const double* __restrict__ b,
+                                                 size_t Kp, const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                                 const unsigned char* __restrict__ far_flag, const unsigned* __restrict__ list,
+                                                 unsigned nat, double* __restrict__ fix_i, double* __restrict__ fix_j) {
+    if (!ks_split_on(wc)) return;
     __shared__ double sm[4];
-    const size_t i0 = (size_t)blockIdx.x * 32;
-    for (int r = 0; r < 32; r++) {
-        const size_t i = i0 + r;
-        if (i >= kn || !far_flag[i]) continue;               // work-group uniform
-        double ai[PP], ha = 0.0;
+    __shared__ unsigned sl[KS_MAX_FAR_J];
+    if (blockIdx.x < nat) {
+        if (wc->nfar_i == 0) return;
+        const size_t i0 = (size_t)blockIdx.x * 32;
+        for (int r = 0; r < 32; r++) {
+            const size_t i = i0 + r;
+            if (i >= kn || !far_flag[i]) continue;               // work-group uniform
+            double ai[PP], ha = 0.0;
 #pragma unroll
-        for (int p = 0; p < PP; p++) { ai[p] = a[i * PP + p]; ha = fma(ai[p], ai[p], ha); }
-        ha *= 0.5;
-        double s = 0.0;
-        for (size_t j = threadIdx.x; j < Kp; j += 256) s += ks_pair_term<PP>(ai, ha, b + j * PP, hb[j]);
-        s = block_sum_256(s, sm);
-        if (threadIdx.x == 0) fix_i[i] = s;
-        __syncthreads();
+            for (int p = 0; p < PP; p++) { ai[p] = a[i * PP + p]; ha = fma(ai[p], ai[p], ha); }
+            ha *= 0.5;
+            double s = 0.0;
+            for (size_t j = threadIdx.x; j < Kp; j += 256) s += ks_pair_term<PP>(ai, ha, b + j * PP, hb[j]);
+            s = block_sum_256(s, sm);
+            if (threadIdx.x == 0) fix_i[i] = s;
+            __syncthreads();
+        }
+        return;
     }
-}
-
-// far PREVIOUS particles: their terms for every new particle (one per lane), in list order
-template <int PP>
-__global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__ a, size_t kn, const double* __restrict__ b,
-                                                      const double* __restrict__ hb, const WConst* __restrict__ wc,
-                                                      const unsigned* __restrict__ list, double* __restrict__ fix_j) {
     const int n = wc->nfar_j;
-    if (!ks_split_on(wc) || n == 0) return;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (n == 0) return;
+    const unsigned t = threadIdx.x;
+    for (unsigned e = t; e < KS_MAX_FAR_J; e += 256) sl[e] = ((int)e < n) ? list[e] : 0xffffffffu;
+    for (unsigned k = 2; k <= KS_MAX_FAR_J; k <<= 1)
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (unsigned p = t; p < KS_MAX_FAR_J / 2; p += 256) {
+                const unsigned i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const unsigned x = sl[i], y = sl[i + j];
+                if ((x > y) == ((i & k) == 0)) { sl[i] = y; sl[i + j] = x; }
+            }
+        }
+    __syncthreads();
+    const size_t i = (size_t)(blockIdx.x - nat) * 256 + t;
     if (i >= kn) return;
     double ai[PP], ha = 0.0;
 #pragma unroll
@@ -494,7 +486,7 @@ __global__ __launch_bounds__(256) void k_kde_far_cols(const double* __restrict__
     ha *= 0.5;
     double s = 0.0;
     for (int q = 0; q < n; q++) {
-        const size_t j = list[q];
+        const size_t j = sl[q];
         s += ks_pair_term<PP>(ai, ha, b + j * PP, hb[j]);
     }
     fix_j[i] = s;
@@ -679,11 +671,11 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
     for (int p = 0; p < P; p++) num *= prior_likelihood(priors[p], theta[(k0 + i) + K * (size_t)p]);
     double den = 0.0;
     if (split_on && far_flag[i]) {
-        den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far_rows
+        den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far
     } else {
         for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
         if (split_on) den *= exp2(-ha_frac[i]);              // the fraction of 1/2|a_i|^2 the split kernel left out (k_wsplit)
-        if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far_cols)
+        if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far)
     }
     if (epan) w_raw[i] = (den > 0.0) ? num / den : 0.0;          // compact support: a particle nothing supports gets weight 0
     else w_raw[i] = num / (wc->C * den);
@@ -740,9 +732,59 @@ int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t 
     return launch_dv_from_stats(ctx, stats, P, dv);
 }
 
+// Everything of the weight stage that needs the PREVIOUS set only: scales and constants (k_wprep), robust centre, the scaled
+// row-major copy b with hb, the limb tiles of the split kernel.  The fused drivers queue it on the side stream at the start of a
+// generation (it runs beside the ranking); st == NULL: the context's stream.  kn_max: the most rows a later launch_weights_raw
+// will handle (its far-row budget).
+int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
+                        const double* dv_prev, abc_wprev* out, hipStream_t st) {
+    memset(out, 0, sizeof(*out));
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
+    if (Kp > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: K' = %zu >= 2^32", Kp);
+    hipStream_t s = st ? st : ctx->stream;
+    int PP = 2;
+    while (PP < (int)P) PP *= 2;
+    const int NCH = (P <= 16) ? 1 : 2;
+    const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
+    const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
+    const size_t nbt = (Kp + 31) / 32;
+    const int opb = NCH * KS_NL + 1;
+    WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
+    double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
+    double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
+    double* cpart = (double*)abc_ws_alloc(ctx, 64 * WC_NB * sizeof(double));
+    unsigned short* bt = nullptr;
+    unsigned* far_list = nullptr;
+    if (split) {
+        bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
+        far_list = (unsigned*)abc_ws_alloc(ctx, KS_MAX_FAR_J * sizeof(unsigned));
+        if (!bt || !far_list) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    }
+    if (!wc || !b || !hb || !cpart) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
+    hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, s, dv_prev, (int)P, wc, (int)(kn_max / 16 + 32));
+    hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, s, theta_prev, Kp, wc, cpart);
+    hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(64), 0, s, theta_prev, Kp, (int)P, cpart, wc);
+    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
+                       (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
+    if (split) {
+        const size_t rbp = nbt * 32;
+        if (NCH == 1)
+            hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, s, b, PP, Kp, rbp,
+                               w_prev, 1, wc, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+        else
+            hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, s, b, PP, Kp, rbp,
+                               w_prev, 1, wc, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    out->wc = wc; out->b = b; out->hb = hb; out->bt = bt; out->far_list = far_list;
+    out->Kp = Kp; out->P = P; out->kn_max = kn_max; out->split = split ? 1 : 0; out->ready = 1;
+    return ABC_OK;
+}
+
 int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P, size_t k0,
                        size_t kn, const double* theta_prev, size_t Kp, const double* w_prev, const double* dv_prev,
-                       double* w_raw) {
+                       double* w_raw, const abc_wprev* prev) {
     if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
     if (kn == 0) return ABC_OK;
     if (!ctx->kde_which) {
@@ -767,60 +809,56 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
     const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
-    const int opa = NCH * KS_NL, opb = NCH * KS_NL + 1;
+    const int opa = NCH * KS_NL;
     if (split) {
-        // Every work-group of the split kernel loads its 48-96 KB of resident operands once per slice: with the 65 slices
+        // Every work-group of the split kernel loads its 32-64 KB of resident operands once per slice: with the 65 slices
         // the fp64 kernel likes that was 1.2 GB of fabric traffic per launch at K = K' = 1e5 (PMC).  Its time is flat between
         // 24 and 130 slices, so it gets about 12k work-groups (16 residencies of the chip) and no more.
         size_t cap = 12288 / rb;
         if (cap < 8) cap = 8;
         if (slices > cap) slices = cap;
     }
-    WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
+    // the previous set's share: prepared by the caller (side stream, already joined) or here
+    abc_wprev own;
+    if (!prev || !prev->ready) {
+        ABC_TRY(launch_weights_prev(ctx, P, kn, theta_prev, Kp, w_prev, dv_prev, &own, nullptr));
+        prev = &own;
+    }
+    if (prev->Kp != Kp || prev->P != P || prev->kn_max < kn || (prev->split != 0) != split)
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: the prepared previous set does not match this call");
+    WConst* wc = (WConst*)prev->wc;
+    double* b = prev->b;
+    double* hb = prev->hb;
+    unsigned short* bt = prev->bt;
+    unsigned* far_list = prev->far_list;
     double* a = (double*)abc_ws_alloc(ctx, kn * PP * sizeof(double));
-    double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* part = (double*)abc_ws_alloc(ctx, slices * kn * sizeof(double));
-    double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
-    double* cpart = (double*)abc_ws_alloc(ctx, 64 * WC_NB * sizeof(double));
-    unsigned short *at = nullptr, *bt = nullptr;
+    unsigned short* at = nullptr;
     unsigned char* far_flag = nullptr;
-    unsigned* far_list = nullptr;
     double *fix_i = nullptr, *fix_j = nullptr, *ha_frac = nullptr;
     int* ha_int = nullptr;
     if (split) {
         at = (unsigned short*)abc_ws_alloc(ctx, nat * opa * 1024);
-        bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
         far_flag = (unsigned char*)abc_ws_alloc(ctx, nat * 32);
-        far_list = (unsigned*)abc_ws_alloc(ctx, KS_MAX_FAR_J * sizeof(unsigned));
         fix_i = (double*)abc_ws_alloc(ctx, kn * sizeof(double));
         fix_j = (double*)abc_ws_alloc(ctx, kn * sizeof(double));
         ha_frac = (double*)abc_ws_alloc(ctx, nat * 32 * sizeof(double));
         ha_int = (int*)abc_ws_alloc(ctx, nat * 32 * sizeof(int));
-        if (!at || !bt || !far_flag || !far_list || !fix_i || !fix_j || !ha_frac || !ha_int) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+        if (!at || !far_flag || !fix_i || !fix_j || !ha_frac || !ha_int) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     }
-    if (!wc || !a || !b || !part || !hb || !cpart) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+    if (!a || !part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
-    hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, ctx->stream, dv_prev, (int)P, wc, (int)(kn / 16 + 32));
-    hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, ctx->stream, theta_prev, Kp, wc, cpart);
-    hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(64), 0, ctx->stream, theta_prev, Kp, (int)P, cpart, wc);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
                        (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
-    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, ctx->stream, theta_prev, Kp, Kp,
-                       (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
     if (split) {
-        const size_t ra = nat * 32, rbp = nbt * 32;
-        if (NCH == 1) {
+        const size_t ra = nat * 32;
+        if (NCH == 1)
             hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
                                (const double*)nullptr, 0, wc, at, opa, far_flag, far_list, ha_int, ha_frac);
-            hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb, far_flag, far_list, ha_int, ha_frac);
-        } else {
+        else
             hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
                                (const double*)nullptr, 0, wc, at, opa, far_flag, far_list, ha_int, ha_frac);
-            hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, ctx->stream, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb, far_flag, far_list, ha_int, ha_frac);
-        }
     }
 #define LAUNCH_KDE(PPV)                                                                                        \
     hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
@@ -857,15 +895,10 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         }
     }
 #undef LAUNCH_KDE
-    if (split) {        // far rows (outside the split kernel's exact range): both kernels return at once when there are none
-        hipLaunchKernelGGL(k_wfarsort, dim3(1), dim3(1024), 0, ctx->stream, wc, far_list);
+    if (split) {        // far rows (outside the split kernel's exact range): returns at once when there are none
 #define LAUNCH_FAR(PPV)                                                                                                  \
-    do {                                                                                                                 \
-        hipLaunchKernelGGL(k_kde_far_rows<PPV>, dim3((unsigned)nat), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc,    \
-                           far_flag, fix_i);                                                                             \
-        hipLaunchKernelGGL(k_kde_far_cols<PPV>, dim3((unsigned)rb), dim3(256), 0, ctx->stream, a, kn, b, hb, wc, far_list, \
-                           fix_j);                                                                                       \
-    } while (0)
+    hipLaunchKernelGGL(k_kde_far<PPV>, dim3((unsigned)(nat + rb)), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc,      \
+                       far_flag, far_list, (unsigned)nat, fix_i, fix_j)
         switch (PP) {
             case 8: LAUNCH_FAR(8); break;
             case 16: LAUNCH_FAR(16); break;
