@@ -267,6 +267,7 @@ void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double
 
 // arena bound shared by api.hip and sharded.hip
 size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext);
+size_t abc_wx_need(size_t n_validation, size_t P, size_t A);     // arena of the Wilcoxon reduction (launch_wilcoxon)
 int abc_timing_flush(abc_ctx* ctx);
 void abc_comm_release(abc_ctx* ctx);     // sharded.hip: called by abc_ctx_destroy
 

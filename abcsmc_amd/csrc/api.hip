@@ -35,7 +35,7 @@ int abc_pin_reserve(abc_ctx* ctx, size_t bytes) {
 }
 
 // arena needed by the Wilcoxon reduction: scores + 4 key/value buffers over (segments x validation rows)
-static size_t wx_need(size_t nt, size_t P, size_t A) {
+size_t abc_wx_need(size_t nt, size_t P, size_t A) {
     const size_t seg = P * (A > 0 ? A - 1 : 0);
     return nt * A * 8 + 4 * seg * nt * 8 + 256 * ((seg * nt) / 2048 + 2) * 4 + (1u << 20);
 }
@@ -294,7 +294,7 @@ extern "C" int abc_pls_wilcoxon_dev(abc_ctx* ctx, const double* X, const double*
                                     size_t M, size_t P, size_t A, size_t row_test, double* model) {
     CHECK_CTX(ctx);
     const size_t nt = row_test < n ? n - row_test : 0;
-    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, M, P, A, 0, 0, 0) + wx_need(nt, P, A)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, M, P, A, 0, 0, 0) + abc_wx_need(nt, P, A)));
     return launch_wilcoxon(ctx, X, Y, n, ldx, ldy, M, P, A, row_test, model);
 }
 
@@ -573,7 +573,7 @@ extern "C" int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, c
     if (!cfg || !io || !io->X || !io->obs || !io->idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: null argument");
     const size_t A = default_A(cfg->M, cfg->P, cfg->max_comp);
     size_t need = abc_ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext);
-    if (cfg->rule == ABC_RULE_WILCOXON) need += wx_need(cfg->N, cfg->P, A);
+    if (cfg->rule == ABC_RULE_WILCOXON) need += abc_wx_need(cfg->N, cfg->P, A);
     ABC_TRY(abc_ws_reserve(ctx, need));
     return generation_core(ctx, cfg, io, rng, ncomp_host, 0);
 }
@@ -603,7 +603,7 @@ static int ranking_host(abc_ctx* ctx, const double* X, const double* Y, const do
     if (!X || !obs || !idx || (!simple && !Y)) ABC_FAIL(ctx, ABC_ERR_INVALID, "ranking: null argument");
     const size_t A = simple ? 0 : default_A(M, P, max_comp);
     ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(N, M, P, A, K, 0, 0) + (N * (M + P) + M + 2 * K) * 8 +
-                                    ((!simple && rule == ABC_RULE_WILCOXON) ? wx_need(N, P, A) : 0)));
+                                    ((!simple && rule == ABC_RULE_WILCOXON) ? abc_wx_need(N, P, A) : 0)));
     Stage s{ctx};
     abc_generation_io io;
     memset(&io, 0, sizeof(io));

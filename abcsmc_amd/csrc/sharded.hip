@@ -149,6 +149,27 @@ __global__ __launch_bounds__(256) void k_unpad_slices(const double* __restrict__
     w[k] = slices[q * kmax + i];
 }
 
+// validation rows of the Wilcoxon rule: rows [v0, v0 + nv) of every column of a shard, packed column-major with leading
+// dimension vmax (zero padded) for the all-gather ...
+__global__ __launch_bounds__(256) void k_pack_valid(const double* __restrict__ src, size_t ld, size_t v0, size_t nv, size_t vmax,
+                                                    int C, double* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= vmax * (size_t)C) return;
+    const size_t j = e % vmax, c = e / vmax;
+    dst[e] = (j < nv) ? src[v0 + j + ld * c] : 0.0;
+}
+// ... and, from the gathered blocks [rank q][column c][vmax], the validation rows of the whole set in global row order
+// (rank q's rows start at voff[q]): dst is Nv x C, column-major
+__global__ __launch_bounds__(256) void k_place_valid(const double* __restrict__ all, const long long* __restrict__ voff /* W + 1 */,
+                                                     int W, size_t vmax, int C, size_t Nv, double* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= Nv * (size_t)C) return;
+    const size_t i = e % Nv, c = e / Nv;
+    int q = 0;
+    while (q + 1 < W && (long long)i >= voff[q + 1]) q++;
+    dst[e] = all[((size_t)q * C + c) * vmax + (i - (size_t)voff[q])];
+}
+
 size_t default_A(size_t M, size_t P, int max_comp) { return (max_comp > 0) ? (size_t)max_comp : (M < P ? M : P); }
 
 }  // namespace
@@ -261,14 +282,18 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         ABC_FAIL(ctx, ABC_ERR_INVALID, "unknown component rule %d", cfg->rule);
     if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM)
         ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "the reference noise stream is sequential over the whole set: not available to the sharded generation");
-    if (cfg->rule == ABC_RULE_WILCOXON && W > 1)
-        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "the Wilcoxon component rule needs the validation rows on one device");
     const size_t A = default_A(M, P, cfg->max_comp);
     const size_t kloc = K < n ? K : n;                       // most winners this rank can hold
     const size_t kbase = K / (size_t)W, krem = K % (size_t)W, kmax = kbase + (krem ? 1 : 0);
     const size_t k0 = (size_t)r * kbase + ((size_t)r < krem ? (size_t)r : krem), kn = kbase + ((size_t)r < krem ? 1 : 0);
 
     size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20);
+    const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
+    if (cfg->rule == ABC_RULE_WILCOXON) {
+        // the validation rows of the whole set are assembled on every rank (all-gather of the shards' validation rows)
+        const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
+        need += abc_wx_need(NvT, P, A) + ((size_t)(W + 1) * (n ? n : 1) + NvT) * (M + P) * 8 + (1u << 20);
+    }
     ABC_TRY(abc_ws_reserve(ctx, need));
     const StatsLayout SL = stats_layout(M, P);
     const ModelLayout ML = model_layout(M, P, A);
@@ -294,7 +319,6 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     if (Kp && io->theta_prev && P <= 64 && kn)
         ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
-    const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
     ABC_TRY(comm_broadcast(ctx, stats + SL.off_shift, SL.C16 * 8, 0));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
@@ -303,8 +327,50 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         ABC_TRY(comm_all_reduce(ctx, stats, SL.len, ABC_DT_F64));
     }
     ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
-    if (cfg->rule == ABC_RULE_WILCOXON)
+    if (cfg->rule == ABC_RULE_WILCOXON && W == 1)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, (size_t)ntrain, model));
+    if (cfg->rule == ABC_RULE_WILCOXON && W > 1) {
+        // The rank sums need the paired differences of ALL validation rows ranked together: every rank gathers the shards'
+        // validation rows (global rows >= ntrain, AbcUtil.cpp:438-446), rebuilds the validation block in global row order and
+        // runs the single-device reduction on it -- the same code on the same numbers on every rank, so the (replicated)
+        // model stays identical everywhere without a broadcast.
+        const size_t v0 = (ntrain > row0) ? (size_t)((ntrain - row0) < n ? (ntrain - row0) : n) : 0, nv = n - v0;
+        long long* vcnt = (long long*)abc_ws_alloc(ctx, (size_t)(2 * W + 2) * sizeof(long long));
+        if (!vcnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        const long long mine = (long long)nv;
+        ABC_HIP(ctx, hipMemcpyAsync(vcnt, &mine, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        ABC_TRY(comm_all_gather(ctx, vcnt, vcnt + 1, sizeof(long long)));
+        long long* hv = (long long*)ctx->pin;
+        ABC_HIP(ctx, hipMemcpyAsync(hv, vcnt + 1, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<long long> off((size_t)W + 1, 0);
+        long long vmax = 0;
+        for (int q = 0; q < W; q++) { off[(size_t)q + 1] = off[(size_t)q] + hv[q]; if (hv[q] > vmax) vmax = hv[q]; }
+        const size_t Nv = (size_t)off[(size_t)W], vm = (size_t)vmax;
+        if (Nv) {
+            long long* voff = vcnt + 1 + W;
+            double* sendb = (double*)abc_ws_alloc(ctx, vm * (M + P) * 8);
+            double* recvb = (double*)abc_ws_alloc(ctx, (size_t)W * vm * (M + P) * 8);
+            double* Xv = (double*)abc_ws_alloc(ctx, Nv * M * 8);
+            double* Yv = (double*)abc_ws_alloc(ctx, Nv * P * 8);
+            if (!sendb || !recvb || !Xv || !Yv) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted (Wilcoxon rows)");
+            ABC_HIP(ctx, hipMemcpyAsync(voff, off.data(), (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+            // X and Y travel in one block: [M + P columns][vmax rows] per rank
+            hipLaunchKernelGGL(k_pack_valid, dim3((unsigned)((vm * M + 255) / 256)), dim3(256), 0, ctx->stream, io->X, n, v0, nv, vm,
+                               (int)M, sendb);
+            hipLaunchKernelGGL(k_pack_valid, dim3((unsigned)((vm * P + 255) / 256)), dim3(256), 0, ctx->stream, io->Y, n, v0, nv, vm,
+                               (int)P, sendb + vm * M);
+            ABC_TRY(comm_all_gather(ctx, sendb, recvb, vm * (M + P) * 8));
+            const int C = (int)(M + P);
+            // place: columns 0..M-1 -> Xv, M..M+P-1 -> Yv (two launches over the same gathered blocks, column offset by pointer)
+            hipLaunchKernelGGL(k_place_valid, dim3((unsigned)((Nv * M + 255) / 256)), dim3(256), 0, ctx->stream, recvb, voff, W, vm, C, Nv, Xv);
+            ABC_HIP(ctx, hipGetLastError());
+            // Y columns: the block of rank q starts M columns into its record
+            hipLaunchKernelGGL(k_place_valid, dim3((unsigned)((Nv * P + 255) / 256)), dim3(256), 0, ctx->stream, recvb + vm * M, voff, W, vm, C, Nv, Yv);
+            ABC_HIP(ctx, hipGetLastError());
+            ABC_TRY(launch_wilcoxon(ctx, Xv, Yv, Nv, Nv, Nv, M, P, A, 0, model));
+        }
+    }
     ABC_TRY(launch_project_distance(ctx, io->X, n, n, M, P, A, model, 0, dist));
     // first set: uniform weights, their alias table is built by the host while the GPU ranks
     const bool uniform_w = (Kp == 0 || !io->theta_prev);

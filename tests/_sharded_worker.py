@@ -1,7 +1,7 @@
 """Worker for the world_size-2 tests of the row-sharded generation (launched by torch.distributed.run).
 argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, both ranks on one GPU, stage by stage from
 Python; "cabi" -> the same two ranks through abc_generation_sharded_dev with the gloo collectives handed in as callbacks),
-out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"]."""
+out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"], [rule = "press" | "wilcoxon" (cabi only)]."""
 import json
 import os
 import sys
@@ -23,6 +23,7 @@ def main():
     from oracle import pyoracle as O
     n_loc, M, P, A, K, Kp, nn_loc = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1500,12,5,4,500,300,1000").split(","))
     N = n_loc * world
+    rule = _lib.RULE_WILCOXON if (len(sys.argv) > 4 and sys.argv[4] == "wilcoxon") else _lib.RULE_MIN_PRESS
     wl = synthetic.Workload(M, P, 777)
     X, Y = wl.rows(rank * n_loc, (rank + 1) * n_loc)
     obs, spec = wl.observed(), wl.prior_spec()
@@ -45,7 +46,7 @@ def main():
         ctx.set_stream(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
         sharded.attach_torch_distributed(ctx, dev)
         assert ctx.comm_info() == (_lib.COMM_CALLBACKS, world, rank)
-        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, rule=rule, multivariate=True)
     else:
         gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
     rng = _lib.Rng()
@@ -63,7 +64,7 @@ def main():
         Xa, Ya = wl.rows(0, N)
         o = O.rng(4242)
         ref = O.generation(Xa, Ya, obs, O.make_priors(spec), K, nn_loc * world, o, thp, wp, dvp, train_frac=0.5,
-                           max_comp=A, multivariate=True)
+                           max_comp=A, rule=(O.RULE_WILCOXON if rule == _lib.RULE_WILCOXON else O.RULE_MIN_PRESS), multivariate=True)
         # declared deviation: seeds are the taus2 outputs right after the Nnext resampling draws
         # (the reference draws them after its data-dependent noise consumption)
         o2 = O.rng(4242)

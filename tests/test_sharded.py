@@ -12,16 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # BASELINE configs[3] / configs[4] column shapes (64 metrics x 32 parameters, 8 components; 128 metrics, 32 components)
-SHAPES = {"small": "1500,12,5,4,500,300,1000", "config4": "1500,64,32,8,400,300,1200", "config5": "1400,128,16,32,300,250,1000"}
+SHAPES = {"small": "1500,12,5,4,500,300,1000", "wx": "2100,10,3,6,400,300,900", "config4": "1500,64,32,8,400,300,1200", "config5": "1400,128,16,32,300,250,1000"}
 
 
-def _launch(backend, tmp_path, port, shape="small"):
-    out = str(tmp_path / ("sharded_%s_%s.json" % (backend, shape)))
+def _launch(backend, tmp_path, port, shape="small", rule="press"):
+    out = str(tmp_path / ("sharded_%s_%s_%s.json" % (backend, shape, rule)))
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape]]
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape], rule]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     return json.load(open(out))
@@ -51,6 +51,14 @@ def test_sharded_world2_cabi_driver(tmp_path, shape, port):
     """abc_generation_sharded_dev (the C++ driver behind the C ABI) on two ranks sharing cuda:0, its collectives forwarded to
     gloo through abc_comm_init_callbacks: the same checks against the single-process oracle as the Python driver"""
     _check(_launch("cabi", tmp_path, port, shape))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,port", [("small", 29621), ("wx", 29622)])
+def test_sharded_world2_cabi_driver_wilcoxon_rule(tmp_path, shape, port):
+    """the Wilcoxon component rule (AbcUtil.cpp:447-449) on two ranks: the validation rows of both shards are gathered and
+    ranked together on every rank; component count, selection and everything downstream equal the single-process oracle's"""
+    _check(_launch("cabi", tmp_path, port, shape, "wilcoxon"))
 
 
 @pytest.mark.gpu
