@@ -666,9 +666,6 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     GRAM_CASE(4, 0); GRAM_CASE(4, 1); GRAM_CASE(4, 2); GRAM_CASE(5, 0); GRAM_CASE(5, 1); GRAM_CASE(5, 2);
     GRAM_CASE(6, 0); GRAM_CASE(6, 1); GRAM_CASE(6, 2);
 #undef GRAM_CASE
-    if (C > 6 && M + P <= 480) return run_gram_grouped(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
-    switch (C) {
-        default:
-            ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "gram: M+P = %zu exceeds 480 columns", M + P);
-    }
+    // wider sets: column groups of 48, one launch per pair of groups (every column is read ceil(columns / 48) - 1 times)
+    return run_gram_grouped(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
 }

@@ -44,9 +44,11 @@ __global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats
     const StatsLayout L = stats_layout(M, P);
     const ModelLayout ML = model_layout(M, P, A);
     const ZLayout Z = z_layout(M, P);
-    __shared__ double delta[160], sd[160];
+    extern __shared__ double zsh[];          // 2 (M + P) doubles
     const int t = threadIdx.x;
     const int C = M + P;
+    double* delta = zsh;
+    double* sd = zsh + C;
     const double n0 = stats[L.off_n], n1 = stats[L.off_n + 1];
     const double n = n0 + n1;
     for (int c = t; c < C; c += 256) {
@@ -202,8 +204,10 @@ template <int NW>
 __device__ __forceinline__ double pls_sum(double v, double* red) {
     v = wave_sum(v);
     if constexpr (NW == 1) return v;
+    __threadfence_block();
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __threadfence_block();
     __syncthreads();
     double s = 0.0;
 #pragma unroll
@@ -218,8 +222,15 @@ __device__ __forceinline__ double pls_sum(double v, double* red) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
                                                 int M, int P, int A, double* __restrict__ model,
-                                                double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds) {
-    extern __shared__ double lds[];
+                                                double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds,
+                                                double* __restrict__ gbase /* NULL: the work arrays live in LDS */) {
+    extern __shared__ double lds_[];
+    // wide sets (M P + 2 M A + ... beyond the 160 KB of LDS): the same arrays in global memory; every barrier is then preceded
+    // by a work-group fence so the stores are visible to the other waves of the (single) work-group
+    double* const lds = gbase ? gbase : lds_;
+    const bool gmem = gbase != nullptr;
+#define PLS_SYNC() do { if (gmem) __threadfence_block(); __syncthreads(); } while (0)
+#define PLS_WSYNC() do { if (gmem) __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
 #ifdef PLS_STAMPS
     long long st_last = __builtin_readcyclecounter();
     double* st_out = scratch + (size_t)A * M + (size_t)A * A + (size_t)P * A;     // 16 doubles of diagnostics
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     double* Pm = model + ML.off_P;
 
     for (int e = lane; e < M * P; e += NT) XY[e] = zwork[Z.off_XY[0] + e];
-    __syncthreads();
+    PLS_SYNC();
 
     STAMP(9);
     for (int comp = 0; comp < A; comp++) {
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             if (n <= 16) tr = eig_square<1>(XY, M, n, S, Bc);
             else if (n <= 32) tr = eig_square<2>(XY, M, n, S, Bc);
             else tr = eig_square<4>(XY, M, n, S, Bc);
-            if constexpr (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if constexpr (NW == 1) PLS_SYNC(); else PLS_WSYNC();
             STAMP(2);
             // column of the converged power with the largest diagonal entry (wave arg-max, ties -> lowest index)
             double dg = (lane < n) ? Bc[lane + n * lane] : -1.0;
@@ -295,14 +306,14 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             double qi = (lane < n) ? Bc[lane + n * best] : 0.0;
             if (tr > 0.0) {
                 if (lane < n) qv[lane] = qi;
-                if constexpr (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+                if constexpr (NW == 1) PLS_SYNC(); else PLS_WSYNC();
                 double v = 0.0;
                 if (lane < n) {
 #pragma unroll 8
                     for (int k = 0; k < n; k++) v = fma(S[lane + n * k], qv[k], v);
                 }
                 qi = v;
-                if constexpr (NW == 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+                if constexpr (NW == 1) PLS_SYNC(); else PLS_WSYNC();
             }
             const double nrm = sqrt(wave_sum(qi * qi));
             double am = fabs(qi);
@@ -317,20 +328,20 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             const double sgn = (sv < 0.0) ? -1.0 : 1.0;
             if (lane < n) qv[lane] = sgn * qi / nrm;
             }
-            __syncthreads();
+            PLS_SYNC();
             for (int m = lane; m < M; m += NT) {
                 double s = 0.0;
                 _Pragma("unroll 8") for (int j = 0; j < P; j++) s = fma(XY[m + M * j], qv[j], s);
                 wv[m] = s;
             }
         }
-        __syncthreads();
+        PLS_SYNC();
         STAMP(3);
         double ww = 0.0;
         for (int m = lane; m < M; m += NT) ww = fma(wv[m], wv[m], ww);
         ww = sqrt(pls_sum<NW>(ww, red));
         for (int m = lane; m < M; m += NT) { const double x = wv[m] / ww; wv[m] = x; rv[m] = x; }
-        __syncthreads();
+        PLS_SYNC();
         if constexpr (NW == 1) {
             for (int j = 0; j < comp; j++) {
                 double pw = 0.0;
@@ -347,14 +358,14 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
                 pw = wave_sum(pw);
                 if ((lane & 63) == 0) pwv[j] = pw;
             }
-            __syncthreads();
+            PLS_SYNC();
             for (int m = lane; m < M; m += NT) {
                 double r = rv[m];
                 for (int j = 0; j < comp; j++) r -= pwv[j] * Rl[m + (size_t)M * j];
                 rv[m] = r;
             }
         }
-        __syncthreads();
+        PLS_SYNC();
         STAMP(4);
         // type 2: xr = XX r ; tt = r' xr ; p = xr / tt
         double tt = 0.0;
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
                 _Pragma("unroll 8") for (int b = b0; b < b1; b++) s = fma(XXtr[a + (size_t)M * b], rv[b], s);
                 xp[e] = s;
             }
-            __syncthreads();
+            PLS_SYNC();
             for (int a = lane; a < M; a += NT) {
                 const double s = (xp[a] + xp[M + a]) + (xp[2 * M + a] + xp[3 * M + a]);
                 xr[a] = s;
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             Rm[m + (size_t)M * comp] = rv[m];
             Rl[m + (size_t)M * comp] = rv[m];
         }
-        __syncthreads();
+        PLS_SYNC();
         STAMP(5);
         for (int j = lane; j < P; j += NT) {
             double s = 0.0;
@@ -402,13 +413,12 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             qv[j] = s;
             Qm[j + (size_t)P * comp] = s;
         }
-        __syncthreads();
+        PLS_SYNC();
         for (int e = lane; e < M * P; e += NT) {
             const int m = e % M, j = e / M;
             XY[e] -= tt * (pv[m] * qv[j]);
         }
-        __threadfence_block();
-        __syncthreads();
+        PLS_SYNC();
         STAMP(6);
     }
 
@@ -428,8 +438,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
         _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
         vk[e] = s;
     }
-    __threadfence_block();
-    __syncthreads();
+    PLS_SYNC();
     for (int e = lane; e < A * A; e += NT) {
         const int k = e % A, l = e / A;
         double s = 0.0;
@@ -442,8 +451,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
         _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
         cm[e] = s;
     }
-    __threadfence_block();
-    __syncthreads();
+    PLS_SYNC();
     double* press = model + ML.off_press;   // A x P, column-major
     for (int j = lane; j < P; j += NT) {
         double lin = 0.0, quad = 0.0;
@@ -461,8 +469,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
         }
         model[ML.off_per + j] = (double)(besta + 1);
     }
-    __threadfence_block();
-    __syncthreads();
+    PLS_SYNC();
     STAMP(8);
     // ncomp = max over responses; observed z-scores and scores (m-ascending fma chain per component)
     int ncomp = 1;
@@ -472,8 +479,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
         const double sdv = model[ML.off_sd + m];
         model[ML.off_zobs + m] = (sdv == 0.0) ? 0.0 : (obs[m] - model[ML.off_mean + m]) / sdv;
     }
-    __threadfence_block();
-    __syncthreads();
+    PLS_SYNC();
     for (int k = lane; k < A; k += NT) {
         double s = 0.0;
         _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(model[ML.off_zobs + m], Rm[m + (size_t)M * k], s);
@@ -499,34 +505,41 @@ static double g_pls_stamps[16];
 
 int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
                      double* model) {
-    if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M+P = %zu > 160", M + P);
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: P = %zu > 64 responses", P);
     if (A < 1 || A > M) ABC_FAIL(ctx, ABC_ERR_INVALID, "pls: components A=%zu must be in [1, M=%zu]", A, M);
     StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
     double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
     double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A + 16) * sizeof(double));
     if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
-    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
+    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
     const int xx_in_lds = M <= 64;
     const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8 + (8 + A + 4 * M);
-    const size_t lds_bytes = lds_d * sizeof(double);
-    if (lds_bytes > 160 * 1024) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: M*P too large for LDS (%zu B)", lds_bytes);
+    size_t lds_bytes = lds_d * sizeof(double);
+    // beyond the LDS (about 500 metrics at 16 parameters and 8 components) the same work arrays live in global memory: the
+    // reference has no size limit here (PLS::Model on Eigen matrices); slower, one work-group either way
+    double* gbase = nullptr;
+    if (lds_bytes > 160 * 1024) {
+        gbase = (double*)abc_ws_alloc(ctx, lds_bytes);
+        if (!gbase) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted (%zu B of work arrays)", lds_bytes);
+        lds_bytes = 64;
+    }
     // up to 16 metrics ONE wavefront (no work-group barriers at all), four up to 64 (measured: 0.119 -> 0.105 ms at M = 32,
     // P = 16, A = 8; 0.308 -> 0.262 ms at M = 64, P = 32), eight beyond
     if (M > 16 && M <= 64) {
         ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(k_pls_fit<4>, dim3(1), dim3(256), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                           scratch, xx_in_lds);
+                           scratch, xx_in_lds, gbase);
     } else if (M <= 64) {      // one wavefront
         ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(k_pls_fit<1>, dim3(1), dim3(64), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                           scratch, xx_in_lds);
+                           scratch, xx_in_lds, gbase);
     } else {            // eight waves for the vector phases
         ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(k_pls_fit<8>, dim3(1), dim3(512), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                           scratch, xx_in_lds);
+                           scratch, xx_in_lds, gbase);
     }
     ABC_HIP(ctx, hipGetLastError());
 #ifdef PLS_STAMPS
@@ -542,8 +555,7 @@ extern "C" void abc_debug_pls_stamps(double* out16) { for (int i = 0; i < 16; i+
 #endif
 
 int launch_simple_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, double* model) {
-    if (M + P > 160) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "simple: M+P = %zu > 160", M + P);
-    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 0, ctx->stream, stats, (int)M, (int)P, 0, model, (double*)nullptr);
+    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, 0, model, (double*)nullptr);
     ABC_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_simple_obs, dim3(1), dim3(64), 0, ctx->stream, obs, (int)M, (int)P, model);
     ABC_HIP(ctx, hipGetLastError());

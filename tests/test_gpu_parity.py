@@ -57,6 +57,8 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (90, 50, 14, 4, 0.5),        # 4 blocks, fewer rows than one 64-row tile per partition
     (1000, 80, 16, 6, 1.0),      # 6 blocks, f = 1: empty validation partition on the four-wave kernel
     (600, 130, 20, 10, 0.5),     # 150 columns: grouped pairs through the pointer-table mode, 4 groups
+    (900, 300, 12, 6, 0.5),      # 312 columns: beyond the LDS-resident model fit's former 160-column limit
+    (1200, 600, 16, 8, 0.5),     # 616 columns: the PLS work arrays live in global memory (> 160 KB), 13 column groups
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
