@@ -446,7 +446,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (!stats || !model || !dist || !spd_dev) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
     if (model_out) *model_out = model;
     const uint64_t ntrain = simple ? N : (uint64_t)llround((double)N * cfg->train_frac);   // AbcUtil.cpp:438
-    // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, beside the ranking
+    const double* Yp = io->Y ? io->Y : io->X;
+    const size_t Pstat = io->Y ? P : 0;
+    ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
+    ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
+    // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, forked behind the Gram
+    // kernel (which wants the whole memory system) and running beside the reduce / model fit that leave the chip empty
     uint32_t* raw_early = nullptr;
     const bool early = io->w && Nn && K && rng && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
     if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early));
@@ -455,10 +460,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     memset(&wprev, 0, sizeof(wprev));
     if (io->w && K && Kp && io->theta_prev && P <= 64)
         ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
-    const double* Yp = io->Y ? io->Y : io->X;
-    const size_t Pstat = io->Y ? P : 0;
-    ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
-    ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
     if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
     else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
     if (!simple && cfg->rule == ABC_RULE_WILCOXON)

@@ -310,7 +310,12 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
     ABC_TRY(abc_pin_reserve(ctx, (size_t)(2 * W) * sizeof(long long) + 64));
 
-    // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, beside the ranking
+    // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
+    ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
+    ABC_TRY(comm_broadcast(ctx, stats + SL.off_shift, SL.C16 * 8, 0));
+    ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
+    // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, forked
+    // behind the Gram kernel
     uint32_t* raw_early = nullptr;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
     // ... and so does the previous set's share of the weight stage
@@ -318,10 +323,6 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     memset(&wprev, 0, sizeof(wprev));
     if (Kp && io->theta_prev && P <= 64 && kn)
         ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
-    // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
-    ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
-    ABC_TRY(comm_broadcast(ctx, stats + SL.off_shift, SL.C16 * 8, 0));
-    ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
     if (W > 1) {
         if (r != 0) ABC_HIP(ctx, hipMemsetAsync(stats + SL.off_shift, 0, SL.C16 * 8, ctx->stream));    // the sum keeps rank 0's shift
         ABC_TRY(comm_all_reduce(ctx, stats, SL.len, ABC_DT_F64));

@@ -1,7 +1,7 @@
 """Copies the rocprofv3 summaries a gpurun call of scripts/gpu_profile_round.sh left under gpurun_out/ into profiles/
 (tracked) and re-derives from them, without bench.py's own event brackets, every fraction bench.py's JSON line carries:
 
-  roofline            k_kde_split: bf16 MFMA work issued / rocprofv3 kernel duration against the dense bf16 peak, the
+  roofline            k_kde_split: f16 / bf16 MFMA work issued / rocprofv3 kernel duration against the dense 16-bit peak, the
                       matrix-pipe busy fraction and the vector-issue fraction from the PMC pass, the clock the kernel ran at
   roofline_hbm        k_gram: algorithmic bytes / rocprofv3 kernel duration, PMC traffic beside it
   roofline_streaming  SURVEY 8(d): algorithmic bytes of a generation / (bench step time - pair-sum kernel), and set 0
@@ -113,10 +113,10 @@ for c in cfgs:
         calls, ns = st[kk[0]]
         kde_ms = ns / 1e6
         pairs = float(K) * Kp
-        mf = 13 * ((P + 15) // 16) + 2
+        mf = 6 * ((P + 15) // 16) + 2
         tf = pairs * mf * 32.0 / (ns * 1e-9) / 1e12
         ent["roofline"] = {"kernel": kk[0], "bound": "mfma", "kernel_avg_ms": round(kde_ms, 4), "pairs_per_launch": pairs,
-                           "mfma_32x32x16_bf16_per_1024_pairs": mf, "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_PEAK_TF,
+                           "mfma_32x32x16_per_1024_pairs": mf, "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_PEAK_TF,
                            "frac": round(tf / MFMA_PEAK_TF, 4), "traffic_hbm_bytes": traffic(c, 'k_kde_split')}
         d = G + '%s_kde_c%d' % (pp, c)
         if os.path.isdir(d):
