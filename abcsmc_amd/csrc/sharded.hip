@@ -45,10 +45,17 @@ struct Rccl {
 Rccl* rccl() {
     static Rccl R = [] {
         Rccl r;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // an RCCL the process has already loaded comes first (PyTorch ships its own librccl.so: one library, one set of
+        // proxy threads and IPC state for both its communicators and this one), then the system's
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.h) break;
         }
+        if (!r.h)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.h) break;
+            }
         if (!r.h) return r;
 #define RCCL_SYM(f) r.f = (decltype(r.f))dlsym(r.h, "nccl" #f)
         RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommInitAll); RCCL_SYM(CommDestroy); RCCL_SYM(AllReduce);
