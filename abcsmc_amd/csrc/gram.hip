@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__
     using D = GramDims<C, CY>;
     const StatsLayout L = stats_layout(D::C16, 0);
     const int part = blockIdx.y;
-    // 16 record elements x 16 slices of the G partial records per block; slices are combined in a fixed order
+    // 16 record elements x 16 slices of the G partial records per block; slices are combined in a fixed order (each slice
+    // as four interleaved running sums, so a thread keeps four loads in flight instead of one dependent chain)
     __shared__ double red[16][17];
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
@@ -431,8 +432,16 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__
     if (e < D::PSZ) {
         const double* p = partial + (size_t)part * G * D::PSZ + e;
         const int g0 = (int)((long long)G * sl / 16), g1 = (int)((long long)G * (sl + 1) / 16);
-#pragma unroll 4
-        for (int g = g0; g < g1; g++) ps += p[(size_t)g * D::PSZ];
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+        int g = g0;
+        for (; g + 3 < g1; g += 4) {
+            q0 += p[(size_t)g * D::PSZ];
+            q1 += p[(size_t)(g + 1) * D::PSZ];
+            q2 += p[(size_t)(g + 2) * D::PSZ];
+            q3 += p[(size_t)(g + 3) * D::PSZ];
+        }
+        for (; g < g1; g++) q0 += p[(size_t)g * D::PSZ];
+        ps = (q0 + q1) + (q2 + q3);
     }
     red[sl][el] = ps;
     __syncthreads();

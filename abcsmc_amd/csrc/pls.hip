@@ -140,6 +140,7 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
             for (int J = 0; J < NB; J++) D[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], a[I], D[I][J], 0, 0, 0);
     }
     const double tr = trace_cd<NB>(D);
+    const double itr = (tr > 0.0) ? 1.0 / tr : 0.0;     // (the scale of B is immaterial: every group renormalises by its own trace)
 #pragma unroll
     for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -148,7 +149,7 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
             for (int r = 0; r < 4; r++) {
                 const int i = 16 * I + c, j = 16 * J + q + 4 * r;
                 if (i < n && j < n) S[i + n * j] = D[I][J][r];          // kept in LDS for the power step
-                D[I][J][r] = (tr > 0.0) ? D[I][J][r] / tr : ((i == 0 && j == 0) ? 1.0 : 0.0);
+                D[I][J][r] = (tr > 0.0) ? D[I][J][r] * itr : ((i == 0 && j == 0) ? 1.0 : 0.0);
             }
     // Groups of 3 un-normalised squarings of the trace-1 matrix (B -> B^8, entries >= n^-8), then one trace
     // normalisation.  With eigenvalues lambda_i (sum 1), t = trace(B^8) = sum lambda_i^8.  t > 0.95 forces
