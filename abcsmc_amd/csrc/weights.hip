@@ -234,19 +234,19 @@ __global__ __launch_bounds__(256) void k_epan(const double* __restrict__ a, size
 //   below 2^-14 an f16 SUBNORMAL, which v_mfma_f32_32x32x16_f16 takes at its value: scripts/mfma_f16_probe.hip),
 //   r2 = v - h0 - h1, |r2| <= 2^-19, entering as (h0 2^-11).(r2' 2^11) -- both factors f16-representable, the product unscaled,
 // and the dot product as the sum of the limb products, which the MFMA evaluates with the parameter index as its K
-// dimension (P <= 16: one chunk; P <= 32: two), 32 previous x 32 new particles per instruction.  Two f32 accumulators:
+// dimension (P <= 16: one chunk; P <= 32: two), 32 previous x 32 new particles per instruction.  One f32 accumulator, in this order:
 //   X = h0.h0' - hbTop_j          every term a multiple of 2^-14, every partial sum below 2^10: EXACT in f32 whatever the
 //                                 order of accumulation (bound: KS_NORM2 below; probe: 0 inexact sums of 102400)
-//   Y = h0.h1' + h1.h0' + h1.h1' + h0.r2' + r2.h0' - hbLow_j      |Y| ~ 0.01, so its f32 rounding is ~1e-9 absolute
-// where hb_j = 1/2|b_j|^2 - log2 w'_j (= Top, a multiple of 2^-14, + Low) enters through one more (bf16) K-step per accumulator
-// against constant -1 operands.  6 + 2 MFMAs per 16 parameters and 1024 pairs; round 1 / the first half of round 2 used four
-// bf16 limbs, 13 + 2 (bf16 carries 8 significant bits: 15 -> 10 MFMAs alone took the kernel from 3.5 to 2.5 ms, diagnostic
-// build).  1/2|a_i|^2 is the same in every term of row i: it stays out of the sums (integer part: subtracted from every batch's
+//   - n                           n = floor(max X) of the 16 values a lane owns: still exact, and now small for the terms that matter
+//   + Y = h0.h1' + h1.h0' + h1.h1' + h0.r2' + r2.h0' - hbLow_j      small terms into a small accumulator: roundings ~1e-8 |Z|
+// where hb_j = 1/2|b_j|^2 - log2 w'_j (= Top, a multiple of 2^-14, + Low) enters through (bf16) K-steps against constant -1
+// operands.  6 + 3 MFMAs per 16 parameters and 1024 pairs; round 1 / the first half of round 2 used four bf16 limbs, 13 + 2
+// (bf16 carries 8 significant bits: 15 -> 10 MFMAs alone took that kernel from 3.5 to 2.5 ms, diagnostic build).  1/2|a_i|^2 is the same in every term of row i: it stays out of the sums (integer part: subtracted from every batch's
 // power of two; fraction: k_wfinish, fp64), which also halves the range X has to be exact on.  Left out: h1.r2' + r2.h1'
 // (1.4e-8 rms / 7e-8 max on the exponent at 16 parameters, 2e-8 / 9e-8 at 32: scripts/split_precision.py) and r2.r2'.
-// X + Y is the base-2 exponent of the term up to the row's factor, and the vector pipe only adds and exponentiates:
-//   terms of a batch = 2^n * sum of 2^((X - n) + Y),  n = floor(max X of the batch)      5 issue slots per pair instead of 30
-//   (ks_slots: f32 subtract, add, v_exp_f32, f32 add; one fp64 scaling and add per 16 pairs).
+// Z is the base-2 exponent of the term up to the row's factor and the batch's 2^n, and the vector pipe only exponentiates and adds:
+//   terms of a batch = 2^n * sum of 2^Z      3 issue slots per pair instead of 30 (kz_slots: v_exp_f32, f32 add; one fp64 scaling
+//   and add per 16 pairs).
 // Error of a batch sum (16 terms) with the f32 evaluation: 5e-8 rms, 2e-7 max (+ one ulp of v_exp_f32).  Measured error of a
 // weight against the oracle: tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
 // Rows outside the exact range (a |coordinate| > 8, |row|^2 > 400, a weight outside {0} U [2^-300, 2^100]) are "far": k_wsplit
@@ -329,7 +329,7 @@ __device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc
     rem = h - top;
     for (int k = 3; k < 6; k++) { pc[k] = bf16_bits(rem, &back); rem -= back; }
 }
-constexpr unsigned KS_MONE = 0xBF80u;      // bf16 -1
+constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
 
 // Limb tiles of one set.  Input: the scaled row-major copy (rows x PPsrc) written by k_wscale.
 // Output, per tile of 32 rows: `ops` operands of 1 KiB in MFMA fragment order [half h][row r][8 x 16 bit] (lane 32h + r
@@ -415,8 +415,12 @@ __global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, i
         unsigned pc[6];
         unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
         ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
-        *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), 0u);
-        *(uint4*)(ob + (32 + rr) * 8) = make_uint4(0u, 0u, 0u, 0u);
+        // K-slots 6,7 = 1 for the rows an MFMA result holds in its lanes 0..31 (bit 2 of the row clear), 8,9 = 1 for the others:
+        // against a B operand whose slots 6,7 / 8,9 carry the pieces of -n, the lane's own batch reference is subtracted from
+        // exactly its rows (k_kde_split)
+        const unsigned ones = KS_ONE | (KS_ONE << 16);
+        *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), (rr & 4) ? 0u : ones);
+        *(uint4*)(ob + (32 + rr) * 8) = make_uint4((rr & 4) ? ones : 0u, 0u, 0u, 0u);
     } else {
         const double ha = 0.5 * nn, hi = floor(ha);          // 0 for a far / padded row
         ha_int[r] = (int)hi;
@@ -492,106 +496,117 @@ __global__ __launch_bounds__(256) void k_kde_far(const double* __restrict__ a, s
     fix_j[i] = s;
 }
 
-// The limb products of one 16-parameter chunk, in issue order: which accumulator, which operand of the previous (A) and
-// of the new (B) particle.  X takes h0.h0' (multiples of 2^-14); Y takes h0.h1', h1.h0', h1.h1', h0.r2', r2.h0'.  Left out:
-// h1.r2' + r2.h1' (each factor pair below 2^-8 x 2^-19: 1.4e-8 rms on the exponent at 16 parameters, scripts/split_precision.py)
-// and r2.r2'.
-constexpr signed char KS_LX[KS_NP] = {1, 0, 0, 0, 0, 0};
+// The limb products of one 16-parameter chunk: which operand of the previous (A) and of the new (B) particle.  Product 0 is the
+// exact h0.h0' (multiples of 2^-14); then h0.h1', h1.h0', h1.h1', h0.r2', r2.h0'.  Left out: h1.r2' + r2.h1' (each factor pair
+// below 2^-8 x 2^-19: 1.4e-8 rms on the exponent at 16 parameters, scripts/split_precision.py) and r2.r2'.
 constexpr signed char KS_LA[KS_NP] = {0, 0, 1, 1, 2, 3};
 constexpr signed char KS_LB[KS_NP] = {0, 1, 0, 1, 3, 2};
-__host__ __device__ constexpr int ks_nsteps(int nch) { return KS_NP * nch + 2; }
-
-// step S of a batch (one 32 x 32 block of pairs).  The norm step comes FIRST in each accumulator's chain (X: -hbTop, then
-// the h0.h0' of every chunk -- the order the exactness bound above is stated for); NB: the two constant B operands of the norm step
+__device__ __forceinline__ float ks_max3(float a, float b, float c) {
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // (fmaxf would canonicalise its inputs first)
+    return r;
+}
+struct KsRef { float p0, p1, p2, p3; };        // the four running f32 sums of a batch
+// ---- one accumulator per batch ----------------------------------------------------------------------------------------------
+// Z = X - n + Y in ONE f32 accumulator.  The chain starts with the exact part X (norm top, h0.h0'); the vector pipe takes
+// n = floor(max X) over the 16 values a lane owns of the 32 x 32 block (8 v_max3_f32) and hands -n back to the matrix pipe as
+// the B operand of one more bf16 step -- its two bf16 pieces in K-slots 6,7 of lanes 0..31 and 8,9 of lanes 32..63, against the
+// ones k_wsplit put in the previous set's norm operand, so each lane's n lands on exactly the rows that lane holds -- which is
+// still exact (multiples of 2^-14 below 2^11); then -hbLow and the five small products follow into the SAME accumulator, which
+// by then is small (< 1.3 for the terms that carry the sum), so their roundings are 2^-25 |Z| each.  The vector pipe is left with
+// v_exp_f32 (measured on gfx950 over every float of [-0.3, 1.3], scripts/exp2_hw_accuracy.hip: max 8.2e-8, rms 2.6e-8 relative)
+// and the running sums (four f32 chains of four, a tree, ONE convert / v_ldexp_f64 / fp64 add per batch; terms more than 2^126
+// below their batch's largest flush to zero): 3 issue slots per pair + 1.1 of batch overhead (66 per 16 pairs).  History of the
+// vector side: 14.5 fp64 instructions per pair (round 1) -> 8 slots (floor / fract split of an exact X, per-pair ldexp) -> 5.75
+// (one power of two per batch, two accumulators: subtract, add, exp, add) -> 4.1, for one MFMA more (9 per 1024 pairs at 16
+// parameters).  Error of a batch sum (emulation, scripts/split_precision.py): rms 4.8e-8 / max 2.0e-7 (4.6e-8 / 2.0e-7 with two
+// accumulators).  Measured at 1e10 pairs, P = 16: 2.38 -> 2.24 ms -- the chip clocks 6 % lower under the ninth MFMA (1.78 against
+// 1.90 GHz, PMC), which eats most of what the 26 % shorter instruction stream buys.
+template <int NCH>
+__host__ __device__ constexpr int kz_nsteps() { return 3 + 6 * NCH; }
+// step S of a batch: 0 norm top; 1..NCH h0.h0'; [vector: n]; NCH+1: -n; NCH+2: norm low; then 5 products per chunk
 template <int NCH, int S>
-__device__ __forceinline__ void ks_mfma(const uint4* A, const uint4* B, const uint4 (&NB)[2], f32x16& X, f32x16& Y) {
-    const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void kz_mfma(const uint4* A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
+    const f32x16 Z0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (S == 0) {
-        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[0]), Z, 0, 0, 0);
-    } else if constexpr (S == 1) {
-        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[1]), Z, 0, 0, 0);
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[0]), Z0, 0, 0, 0);
+    } else if constexpr (S <= NCH) {
+        constexpr int c = S - 1;
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c * KS_NL]), __builtin_bit_cast(f16x8, B[c * KS_NL]), Z, 0, 0, 0);
+    } else if constexpr (S == NCH + 1) {
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, BN), Z, 0, 0, 0);
+    } else if constexpr (S == NCH + 2) {
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[1]), Z, 0, 0, 0);
     } else {
-        constexpr int c = (S - 2) / KS_NP, l = (S - 2) % KS_NP;
-        const f16x8 a = __builtin_bit_cast(f16x8, A[c * KS_NL + KS_LA[l]]), b = __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]);
-        if constexpr (KS_LX[l] != 0) X = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, X, 0, 0, 0);
-        else Y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Y, 0, 0, 0);
+        constexpr int q = S - (NCH + 3), c = q / 5, l = 1 + q % 5;          // products 1..5 of KS_LA / KS_LB
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c * KS_NL + KS_LA[l]]),
+                                                   __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]), Z, 0, 0, 0);
     }
 }
 template <int NCH, int S0, int S1>
-__device__ __forceinline__ void ks_mfma_range(const uint4* A, const uint4* B, const uint4 (&NB)[2], f32x16& X, f32x16& Y) {
+__device__ __forceinline__ void kz_mfma_range(const uint4* A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
     if constexpr (S0 < S1) {
-        ks_mfma<NCH, S0>(A, B, NB, X, Y);
-        ks_mfma_range<NCH, S0 + 1, S1>(A, B, NB, X, Y);
+        kz_mfma<NCH, S0>(A, B, NB, BN, Z);
+        kz_mfma_range<NCH, S0 + 1, S1>(A, B, NB, BN, Z);
     }
 }
-// One batch of vector work interleaved with the NEXT batch's matrix work: slot R issues its share of the next
-// batch's MFMAs (into Xn, Yn), then exponentiates G elements of the finished batch (Xc, Yc).  A wave issues in order
-// and an MFMA occupies the matrix pipe for 32 cycles, so 8 of them in a row would hold the wave's own exponentials
-// back for ~256 cycles; spread over the slots they keep both pipes of the SIMD fed from a single wave.
-// The vector side, 2^(X + Y) summed over the batch: the 16 terms a lane owns of one 32 x 32 block share ONE power of two,
-// n = floor(max X) over the lane's 16 exponents (8 v_max3_f32); every term is 2^((X - n) + Y) straight from v_exp_f32 --
-// X - n is exact (both are multiples of 2^-14 below 2^10; where |X - n| reaches 2^10 the term is 2^-1024 of the batch's
-// largest), the add rounds once at 2^-24 |g| with g < 1.25 for the terms that carry the sum; the hardware's 2^g measured on
-// gfx950 over every float of [-0.3, 1.3] (scripts/exp2_hw_accuracy.hip): max 8.2e-8, rms 2.6e-8 relative -- the 16 terms
-// are added in f32 (four chains of four, then a tree: <= 5 roundings on a term's path) and ONE convert / v_ldexp_f64 /
-// fp64 add per batch takes the partial sum to the lane's running fp64 sum (exponents down to 2^-1100 stay exact / flush to
-// zero).  Terms more than 2^126 below their batch's largest flush to zero.  Per pair: v_sub_f32, v_add_f32, v_exp_f32,
-// v_add_f32 = 5 issue slots (the transcendental counts two) + 1 of batch overhead, against 8 for the per-pair form of the
-// first half of round 2 (floor, fract, add, exp, convert, ldexp, fp64 add) and 14.5 fp64 instructions in round 1.  Error
-// of a batch sum (scripts/split_precision.py): rms 4.6e-8, max 2.0e-7 relative (P <= 16; 5.0e-8 / 2.2e-7 at P <= 32).
-// Measured at 1e10 pairs, P = 16, same box, with the 15-MFMA bf16 split: 3.85 ms (per-pair form) -> 3.51 ms (620 cycles per
-// 1024 pairs and SIMD at the power-limited 1.70 GHz, matrix pipe 0.78 busy, vector issue 0.73: PMC); with the 8-MFMA f16 split
-// 2.3 ms: the vector side is what is left.
-__device__ __forceinline__ float ks_max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // (fmaxf would canonicalise its inputs first)
-    return r;
+// n = floor(max of the lane's 16 values) and the B operand that subtracts it (see above); |n| < 2048: two bf16 pieces
+__device__ __forceinline__ void kz_reference(const f32x16& Z, unsigned lane, int& n, uint4& BN) {
+    // The first read of the freshly written accumulator is an instruction the compiler knows (it places the wait states a VALU
+    // read of an MFMA result needs; it does not look inside inline assembly), the v_max3_f32 tree follows behind a barrier.
+    const float f01 = __builtin_fmaxf(Z[0], Z[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m0 = ks_max3(f01, Z[2], Z[3]), m1 = ks_max3(Z[4], Z[5], Z[6]), m2 = ks_max3(Z[7], Z[8], Z[9]),
+                m3 = ks_max3(Z[10], Z[11], Z[12]), m4 = ks_max3(Z[13], Z[14], Z[15]);
+    const float m = ks_max3(ks_max3(m0, m1, m2), m3, m4);
+    const float nf = __builtin_floorf(m);
+    n = (int)nf;
+    const unsigned u = __float_as_uint(nf), t1 = u & 0xffff0000u;                 // leading eight bits: a bf16
+    const float r = nf - __uint_as_float(t1);                                      // at most three more bits: a bf16 too
+    const unsigned pack = ((t1 ^ 0x80000000u) >> 16) | ((__float_as_uint(r) ^ 0x80000000u) & 0xffff0000u);   // (-t1, -r)
+    BN = (lane < 32) ? make_uint4(0u, 0u, 0u, pack) : make_uint4(pack, 0u, 0u, 0u);
 }
-struct KsRef { float nf; int n; float p0, p1, p2, p3; };
-template <int NCH, int G, int R>
-__device__ __forceinline__ void ks_slots(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Xn, f32x16& Yn,
-                                         const f32x16& Xc, const f32x16& Yc, double& s, KsRef& q, int hsub) {
-    if constexpr (R < 16 / G) {
-        constexpr int NS = ks_nsteps(NCH), SL = 14 / G;
-        constexpr int s0 = (R < SL) ? (R * NS) / SL : NS, s1 = (R < SL) ? ((R + 1) * NS) / SL : NS;
-        if constexpr (s0 > 0 && s0 < NS) asm volatile("" : "+v"(Xn));
-        if constexpr (s0 > 1 && s0 < NS) asm volatile("" : "+v"(Yn));
-        ks_mfma_range<NCH, s0, s1>(An, Bn, NB, Xn, Yn);
-        if constexpr (R == 0) {
-            const float m0 = ks_max3(Xc[0], Xc[1], Xc[2]), m1 = ks_max3(Xc[3], Xc[4], Xc[5]), m2 = ks_max3(Xc[6], Xc[7], Xc[8]),
-                        m3 = ks_max3(Xc[9], Xc[10], Xc[11]), m4 = ks_max3(Xc[12], Xc[13], Xc[14]);
-            const float m = ks_max3(ks_max3(m0, m1, m2), ks_max3(m3, m4, Xc[15]), Xc[15]);
-            q.nf = __builtin_floorf(m);
-            q.n = (int)q.nf;
+// One step of a wave: the vector work of the finished batch (Zc, reference nc) interleaved with the whole chain of the next one
+// (An x Bn -> Zn, reference nn).  Eight slots of two exponentials; the next batch's exact part goes first, its reference is taken
+// in slot 3 (its two MFMAs have ~100 cycles behind them by then), the rest of the chain follows.
+template <int NCH, int R>
+__device__ __forceinline__ void kz_slots(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
+                                         const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
+    if constexpr (R < 8) {
+        constexpr int NS = kz_nsteps<NCH>(), NA = 1 + NCH;            // NA exact steps, then the reference, then NS - NA more
+        if constexpr (R == 0) kz_mfma_range<NCH, 0, NA>(An, Bn, NB, BN, Zn);
+        if constexpr (R == 3) {
+            kz_reference(Zn, lane, nn, BN);
+        }
+        if constexpr (R >= 3 && R < 7) {
+            constexpr int r = R - 3, M = NS - NA;                        // spread the remaining M steps over slots 3..6
+            constexpr int s0 = NA + (r * M) / 4, s1 = NA + ((r + 1) * M) / 4;
+            if constexpr (r > 0) asm volatile("" : "+v"(Zn));
+            kz_mfma_range<NCH, s0, s1>(An, Bn, NB, BN, Zn);
         }
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int i = R * G + g;
-            const float e = __builtin_amdgcn_exp2f((Xc[i] - q.nf) + Yc[i]);
+        for (int g = 0; g < 2; g++) {
+            const int i = R * 2 + g;
+            const float e = __builtin_amdgcn_exp2f(Zc[i]);
             float& p = (i & 3) == 0 ? q.p0 : (i & 3) == 1 ? q.p1 : (i & 3) == 2 ? q.p2 : q.p3;
             if (i < 4) p = e; else p += e;
         }
-        if constexpr (R == 16 / G - 1) {
+        if constexpr (R == 7) {
             float t = q.p0 + q.p1;
-            asm volatile("" : "+v"(t));                       // (keeps the two adds from being packed: v_pk_add_f32 beside MFMAs costs more)
+            asm volatile("" : "+v"(t));
             t += q.p2 + q.p3;
-            s += ldexp((double)t, q.n - hsub);               // hsub = floor(1/2|a_i|^2): the row's own factor, see k_wsplit
+            s += ldexp((double)t, nc - hsub);
             asm volatile("" : "+v"(s));
         } else {
             asm volatile("" : "+v"(q.p0), "+v"(q.p1), "+v"(q.p2), "+v"(q.p3));
         }
         __builtin_amdgcn_sched_barrier(0);
-        ks_slots<NCH, G, R + 1>(An, Bn, NB, Xn, Yn, Xc, Yc, s, q, hsub);
+        kz_slots<NCH, R + 1>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
     }
 }
 
-// part[slice*kn + i] = 2^frac(1/2|a_i|^2) sum_{j in slice} 2^(a_i.b_j - 1/2|a_i|^2 - hb_j).  256 threads = 4 waves x 64 new particles
-// (two 32-column tiles per wave, resident as B operands); the previous set streams through as A operands, 32 rows a
-// tile, each lane loading its own 16-byte fragments one tile ahead (the four waves of a group and its neighbours
-// read the same tile at about the same time: L1 / L2 hits).  D = A.B puts the new particle on the lane and 16
-// previous particles in the registers, so a lane owns ONE running sum per column tile.
-template <int NCH, int G>
-__global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4* __restrict__ at, size_t kn,
+template <int NCH, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict__ at, size_t kn,
                                                       const uint4* __restrict__ bt, unsigned nbt,
                                                       const WConst* __restrict__ wc, const int* __restrict__ ha_int,
                                                       double* __restrict__ part) {
@@ -602,14 +617,12 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4
     const unsigned slices = gridDim.y, sl = blockIdx.y;
     const unsigned t0 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * sl / slices));
     const unsigned t1 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * (sl + 1) / slices));
-
     uint4 B0[OPA], B1[OPA];
 #pragma unroll
     for (int q = 0; q < OPA; q++) {
         B0[q] = at[((it0 + 0) * OPA + q) * 64 + lane];
         B1[q] = at[((it0 + 1) * OPA + q) * 64 + lane];
     }
-    // constant B operands of the norm step (bf16 -1 in K-slots 0..2: X takes -hbTop; in 3..5: Y takes -hbLow)
     uint4 NB[2];
     NB[0] = (lane < 32) ? make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
     NB[1] = (lane < 32) ? make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u) : make_uint4(0u, 0u, 0u, 0u);
@@ -619,8 +632,15 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4
         uint4 A[OPB];
 #pragma unroll
         for (int q = 0; q < OPB; q++) A[q] = bt[((size_t)t0 * OPB + q) * 64 + lane];
-        f32x16 X0, Y0, X1, Y1;
-        ks_mfma_range<NCH, 0, ks_nsteps(NCH)>(A, B0, NB, X0, Y0);                // (t0, columns 0)
+        f32x16 Z0, Z1;
+        int n0 = 0, n1 = 0;
+        uint4 BN;
+        {   // (t0, columns 0): the whole chain up front
+            constexpr int NA = 1 + NCH;
+            kz_mfma_range<NCH, 0, NA>(A, B0, NB, BN, Z0);
+            kz_reference(Z0, lane, n0, BN);
+            kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
+        }
         for (unsigned t = t0; t < t1; t++) {
             uint4 An[OPB];
             const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass re-reads its own tile (no branch); unused
@@ -628,10 +648,10 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void k_kde_split(const uint4
             for (int q = 0; q < OPB; q++) An[q] = bt[((size_t)tn * OPB + q) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
             KsRef q;
-            ks_slots<NCH, G, 0>(A, B1, NB, X1, Y1, X0, Y0, acc0, q, hs0);      // matrix: (t, columns 1); vector: (t, columns 0)
-            ks_slots<NCH, G, 0>(An, B0, NB, X0, Y0, X1, Y1, acc1, q, hs1);     // matrix: (t+1, columns 0); vector: (t, columns 1)
+            kz_slots<NCH, 0>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
+            kz_slots<NCH, 0>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
-            for (int q = 0; q < OPB; q++) A[q] = An[q];       // (two tiles per trip with A / An trading places: no gain, measured)
+            for (int q2 = 0; q2 < OPB; q2++) A[q2] = An[q2];
         }
     }
     {
@@ -878,12 +898,13 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     } else {
         StageTimer tk(ctx, ST_KDE);
         if (split) {
-#define LAUNCH_SPLIT(NCHV, GV)                                                                                      \
-    hipLaunchKernelGGL((k_kde_split<NCHV, GV>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, \
-                       (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part)
-            if (NCH == 1) LAUNCH_SPLIT(1, 2);        // two exponentials per scheduling slot (one: +1 %, four: +5 %)
-            else LAUNCH_SPLIT(2, 2);
-#undef LAUNCH_SPLIT
+            // three waves per SIMD at 16 parameters (129 VGPRs; four, with two spills: no faster), two at 32 (192)
+            if (NCH == 1)
+                hipLaunchKernelGGL((k_kde_split<1, 3>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+            else
+                hipLaunchKernelGGL((k_kde_split<2, 2>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
         }
         switch (PP) {
             case 2: LAUNCH_KDE(2); break;

@@ -191,9 +191,9 @@ def main():
 
     # ---- roofline of the DOMINANT kernel: the pair sums of the importance weights (k_kde_split / k_kde) ------------------
     # Two kernels can run them.  k_kde_split: pair dot products as exact bf16 limb products on the
-    # matrix pipe -- 6 ceil(P/16) + 2 v_mfma_f32_32x32x16_{f16,bf16} per 32 x 32 pairs = 32 flop per pair and MFMA -- and 4 vector
-    # instructions per pair (subtract, add, v_exp_f32 [8 issue cycles], f32 add) + 12 per batch of 16 pairs (8 v_max3_f32,
-    # floor, two converts, v_ldexp_f64, fp64 add, tree adds) = 5.75 issue slots per pair.
+    # matrix pipe -- 6 ceil(P/16) + 3 v_mfma_f32_32x32x16_{f16,bf16} per 32 x 32 pairs = 32 flop per pair and MFMA -- and 2 vector
+    # instructions per pair (v_exp_f32 [8 issue cycles], f32 add) + 18 per batch of 16 pairs (8 v_max3_f32, floor, the pieces of
+    # -n, two converts, v_ldexp_f64, fp64 add, tree adds) = 4.1 issue slots per pair.
     # k_kde (fp64 fallback): 1 add + PP FMAs + 13 for 2^x per pair, no matrix work.
     kde_bracket_ms, kde_launches = per_launch_ms("k_kde") if Kp else (0.0, 0)
     kde_ms = max(kde_bracket_ms - event_overhead_ms, 0.0)
@@ -204,9 +204,9 @@ def main():
     which = ctx.kde_last_kernel() if Kp else _lib.KDE_RAN_NONE
     issue_peak = 256 * 4 * 2.4e9 / 4.0                # wave-instructions per second: 1024 SIMDs, 4 cycles each, 2.4 GHz
     if which == _lib.KDE_RAN_SPLIT:
-        mfma_per_block = 6 * ((P + 15) // 16) + 2
+        mfma_per_block = 6 * ((P + 15) // 16) + 3
         flops = pairs * mfma_per_block * 32.0          # 32 x 32 x 16 x 2 flop per MFMA over 1024 pairs
-        slots_per_pair = 5.75
+        slots_per_pair = 4.125
         achieved_tf = flops / (kde_ms * 1e-3) / 1e12 if kde_ms > 0 else 0.0
         roofline = {"kernel": "k_kde_split", "bound": "mfma", "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_PEAK_TF,
                     "unit": "TFLOP/s", "frac": round(achieved_tf / MFMA_BF16_PEAK_TF, 4),

@@ -4,9 +4,10 @@ Limbs (f16 operands of v_mfma_f32_32x32x16_f16): h0 = rint(128 v)/128, h1 = rint
 scaled: (h0 2^-11).(r2' 2^11)).  X = h0.h0' is accumulated exactly (every partial sum is a multiple of 2^-14 below 2^10); Y =
 h0.h1' + h1.h0' + h1.h1' + h0.r2' + r2.h0' goes through an f32 accumulator, emulated here with ONE rounding per added product
 (pessimistic: the MFMA rounds less often).  Left out: h1.r2' + r2.h1' (the "cross" variant adds them) and r2.r2'.
-For the shipped split the f32 evaluation of the terms (ks_slots: the 16 terms of a lane's batch share n = floor(max X),
-g = (X - n) + Y in f32, 2^g in f32, an f32 sum of the 16, then an exact scaling by 2^n) is emulated as well and the RELATIVE
-error of the batch sums reported: that, not the exponent error, is what a weight inherits.
+For the shipped split the f32 evaluation of the terms (kz_slots: the 16 terms of a lane's batch share n = floor(max X),
+X - n exact, the small products accumulated on top of it in the same f32 accumulator, 2^Z in f32, an f32 sum of the 16, then an
+exact scaling by 2^n) is emulated as well and the RELATIVE error of the batch sums reported: that, not the exponent error, is
+what a weight inherits.
     python scripts/split_precision.py [P] [n]"""
 import sys
 
@@ -47,27 +48,31 @@ base = [(0, 1), (1, 0), (1, 1), (2, 3), (3, 2)]                  # (operand of a
 cases = [("shipped: 3 limbs, 6 products", base),
          ("cross: + h1.r2' + r2.h1'", base + [(4, 5), (5, 4)]),
          ("without h1.h1'", [p for p in base if p != (1, 1)])]
-def term_f32(X, Y32):
-    """ks_slots_ref of weights.hip: the 16 terms a lane owns of one 32 x 32 block share n = floor(max X); every term is
-    2^((X - n) + Y) with X - n exact and one f32 rounding in the add, 2^g from the hardware's v_exp_f32 -- emulated here by
-    the correctly rounded float of exp2(g); the hardware adds at most one more ulp (measured 8.2e-8 max / 2.6e-8 rms relative
-    on [-0.3, 1.3], scripts/exp2_hw_accuracy.hip) --, the 16 terms are added in f32 (four chains of four, then (p0 + p1) +
-    (p2 + p3)) and the batch sum is scaled by 2^n exactly.  Returns the batch sums (rows x columns / 16) and g."""
+def term_f32(X, A, B, pairs):
+    """kz_slots of weights.hip: the 16 terms a lane owns of one 32 x 32 block share n = floor(max X); X - n is exact, the
+    small products are then added INTO THE SAME f32 accumulator -- emulated with one rounding per product and 16-parameter
+    chunk (what an MFMA step does at most) --, 2^Z from the hardware's v_exp_f32 -- emulated by the correctly rounded float of
+    exp2(Z); the hardware adds at most one more ulp (measured 8.2e-8 max / 2.6e-8 rms relative on [-0.3, 1.3],
+    scripts/exp2_hw_accuracy.hip) --, the 16 terms are added in f32 (four chains of four, then (p0 + p1) + (p2 + p3)) and the
+    batch sum is scaled by 2^n exactly.  Returns the batch sums (rows x columns / 16) and Z."""
     Xf = X.astype(np.float32)
     assert np.array_equal(Xf.astype(np.float64), X)
     r, c = Xf.shape
     c16 = c // 16 * 16
-    Xb, Yb = Xf[:, :c16].reshape(r, -1, 16), Y32[:, :c16].reshape(r, -1, 16)
+    Xb = Xf[:, :c16].reshape(r, -1, 16)
     nfl = np.floor(Xb.max(axis=2, keepdims=True)).astype(np.float32)
-    d = (Xb - nfl).astype(np.float32)
-    assert np.array_equal(d.astype(np.float64), Xb.astype(np.float64) - nfl.astype(np.float64)), "X - n is not exact in f32"
-    g = (d + Yb).astype(np.float32)
-    e = np.exp2(g.astype(np.float64)).astype(np.float32)
+    Z = (Xb - nfl).astype(np.float32)
+    assert np.array_equal(Z.astype(np.float64), Xb.astype(np.float64) - nfl.astype(np.float64)), "X - n is not exact in f32"
+    for i, j in pairs:
+        for c0 in range(0, P, 16):
+            ch = (A[i][:, c0:c0 + 16] @ B[j][:, c0:c0 + 16].T)[:, :c16].reshape(r, -1, 16)
+            Z = (Z.astype(np.float64) + ch).astype(np.float32)
+    e = np.exp2(Z.astype(np.float64)).astype(np.float32)
     p = [e[:, :, k] for k in range(4)]
     for i in range(4, 16):
         p[i & 3] = (p[i & 3] + e[:, :, i]).astype(np.float32)
     t = ((p[0] + p[1]).astype(np.float32) + (p[2] + p[3]).astype(np.float32)).astype(np.float32)
-    return np.ldexp(t.astype(np.float64), nfl[:, :, 0].astype(np.int64)), g
+    return np.ldexp(t.astype(np.float64), nfl[:, :, 0].astype(np.int64)), Z
 
 
 print("P = %d, %d x %d pairs" % (P, n, n))
@@ -82,10 +87,10 @@ for name, pairs in cases:
         Y = acc_f32(A[i], B[j], Y)
     e_tr, e_all = np.abs(X + Ye - ref), np.abs(X + Y.astype(np.float64) - ref)
     print("%-32s MFMAs %2d   truncation only: rms %.2e max %.2e   with the f32 accumulator: rms %.2e max %.2e" % (
-        name, (1 + len(pairs)) * ((P + 15) // 16) + 2, np.sqrt((e_tr ** 2).mean()), e_tr.max(), np.sqrt((e_all ** 2).mean()), e_all.max()))
+        name, (1 + len(pairs)) * ((P + 15) // 16) + 3, np.sqrt((e_tr ** 2).mean()), e_tr.max(), np.sqrt((e_all ** 2).mean()), e_all.max()))
     if name.startswith("shipped"):
-        t, g = term_f32(X, Y)
+        t, g = term_f32(X, A, B, pairs)
         exact = np.exp2(ref)[:, :t.shape[1] * 16].reshape(n, -1, 16).sum(axis=2)
         rel = np.abs(t / exact - 1.0)
-        print("   f32 term sums (16 terms 2^(a.b) per batch) of the shipped split: relative error rms %.2e max %.2e mean %.2e;  g = X - n + Y in [%.3f, %.3f]" % (
+        print("   f32 term sums (16 terms 2^(a.b) per batch) of the shipped split: relative error rms %.2e max %.2e mean %.2e;  Z = X - n + Y in [%.3f, %.3f]" % (
             np.sqrt((rel ** 2).mean()), rel.max(), (t / exact - 1.0).mean(), g.min(), g.max()))

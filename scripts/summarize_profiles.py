@@ -113,7 +113,7 @@ for c in cfgs:
         calls, ns = st[kk[0]]
         kde_ms = ns / 1e6
         pairs = float(K) * Kp
-        mf = 6 * ((P + 15) // 16) + 2
+        mf = 6 * ((P + 15) // 16) + 3
         tf = pairs * mf * 32.0 / (ns * 1e-9) / 1e12
         ent["roofline"] = {"kernel": kk[0], "bound": "mfma", "kernel_avg_ms": round(kde_ms, 4), "pairs_per_launch": pairs,
                            "mfma_32x32x16_per_1024_pairs": mf, "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_PEAK_TF,
