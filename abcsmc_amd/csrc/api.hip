@@ -53,14 +53,15 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort
     b += 2 * (K + 1024) * 8 + 34 * 4096 * 4 + 4096;               // ... or the bin selection's pair buffer, counts and cursors
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
-    b += K * P * 8 + K * 64 * 8;                                  // theta, and its row-major copy for the perturb gather
-    b += (K + Kp) * 64 * 8 + 1024 * 8;                            // weights: scaled copies of both sets
+    const size_t PPw = P <= 64 ? 64 : (P + 63) / 64 * 64;         // padded row width of the row-major copies
+    b += K * P * 8 + K * PPw * 8;                                 // theta, and its row-major copy for the perturb gather
+    b += (K + Kp) * PPw * 8 + 1024 * 8 + 64 * PPw * 8 + 32768;    // weights: scaled copies of both sets, centre partials, constants
     b += (K + Kp + 512) * (9 * 32 + 8 + 12) + 8192;               // ... and their f16 limb tiles (<= 9 operands of 32 B a row), 1/2|a|^2 parts
     b += (K + 512) * 17 + 16384;                                   // far-row flags, list and fix-up sums
     if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
-    b += 64 * 64 * 8 + 4096;                                      // padded Cholesky factor of the proposals
+    b += 2 * PPw * PPw * 8 + 4096;                                // padded Cholesky factor of the proposals, factorisation scratch
     b += 64 * 256;                                                // alignment slack
     return b + (4u << 20);
 }
@@ -458,7 +459,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // ... and so does everything the weight stage needs of the PREVIOUS set (scales, centre, scaled copy, limb tiles)
     abc_wprev wprev;
     memset(&wprev, 0, sizeof(wprev));
-    if (io->w && K && Kp && io->theta_prev && P <= 64)
+    if (io->w && K && Kp && io->theta_prev)
         ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
     else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));

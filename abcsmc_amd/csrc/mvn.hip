@@ -8,15 +8,18 @@
 
 namespace {
 
+// gA != NULL (more than 128 parameters: P x P doubles exceed the LDS): the work matrix lives there instead
 __global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stats, int P, double* __restrict__ Lout,
-                                                 int* __restrict__ status) {
-    extern __shared__ double A[];   // P x P column-major
-    __shared__ double delta[64];
+                                                 int* __restrict__ status, double* __restrict__ gA) {
+    extern __shared__ double Ash[];   // P x P column-major (or just delta when gA is given), then delta[P]
+    double* A = gA ? gA : Ash;
+    double* delta = gA ? Ash : Ash + (size_t)P * P;
+#define CH_SYNC() do { if (gA) __threadfence_block(); __syncthreads(); } while (0)
     const StatsLayout SL = stats_layout(P, 0);
     const int lane = threadIdx.x;
     const double n = stats[SL.off_n] + stats[SL.off_n + 1];
     for (int c = lane; c < P; c += 64) delta[c] = (stats[SL.off_sum[0] + c] + stats[SL.off_sum[1] + c]) / n;
-    __syncthreads();
+    CH_SYNC();
     for (int e = lane; e < P * P; e += 64) {
         const int a = e % P, b = e / P;
         const double g = stats[SL.off_G[0] + a + SL.C16 * b] + stats[SL.off_G[1] + a + SL.C16 * b];
@@ -24,7 +27,7 @@ __global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stat
         if (a == b) c = 2.0 * c;                       // AbcUtil.cpp:475-479
         A[e] = c;
     }
-    __syncthreads();
+    CH_SYNC();
     int ok = 1;
     for (int j = 0; j < P; j++) {
         for (int i = j + lane; i < P; i += 64) {
@@ -32,16 +35,17 @@ __global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stat
             for (int k = 0; k < j; k++) temp += A[j + P * k] * A[i + P * k];
             A[i + P * j] += -1.0 * temp;
         }
-        __syncthreads();
+        CH_SYNC();
         const double ajj = A[j + P * j];
         if (!(ajj > 0.0)) { ok = 0; break; }           // GSL_EDOM in the reference (process abort)
         const double inv = 1.0 / sqrt(ajj);
-        __syncthreads();
+        CH_SYNC();
         for (int i = j + lane; i < P; i += 64) A[i + P * j] *= inv;
-        __syncthreads();
+        CH_SYNC();
     }
     for (int e = lane; e < P * P; e += 64) Lout[e] = A[e];
     if (lane == 0) *status = ok ? 0 : -1;
+#undef CH_SYNC
 }
 
 // dv_p = 2 * Var_p (n-1 denominator) from the same statistics record (AbcUtil.cpp:528-537)
@@ -79,14 +83,21 @@ int launch_dv_from_stats(abc_ctx* ctx, const double* stats, size_t P, double* dv
 }
 
 int launch_mvn_from_stats(abc_ctx* ctx, const double* stats, size_t P, double* L, int* status_dev) {
-    hipLaunchKernelGGL(k_cov_chol, dim3(1), dim3(64), P * P * sizeof(double), ctx->stream, stats, (int)P, L, status_dev);
+    double* gA = nullptr;
+    size_t lds = (P * P + P) * sizeof(double);
+    if (lds > 150 * 1024) {            // beyond the LDS: the work matrix in the arena
+        gA = (double*)abc_ws_alloc(ctx, P * P * sizeof(double));
+        if (!gA) ABC_FAIL(ctx, ABC_ERR_NOMEM, "mvn: workspace exhausted");
+        lds = P * sizeof(double);
+    }
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_cov_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cov_chol, dim3(1), dim3(64), lds, ctx->stream, stats, (int)P, L, status_dev, gA);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
 
 int launch_mvn_setup(abc_ctx* ctx, const double* theta, size_t K, size_t P, double* L, int* status_host,
                      int* status_dev) {
-    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "mvn: P = %zu > 64", P);
     if (K < 2) ABC_FAIL(ctx, ABC_ERR_INVALID, "mvn: need at least 2 particles (K=%zu)", K);
     int* status = status_dev ? status_dev : (int*)abc_ws_alloc(ctx, sizeof(int));
     if (!status) ABC_FAIL(ctx, ABC_ERR_NOMEM, "mvn: workspace exhausted");

@@ -436,6 +436,90 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
     }
 }
 
+// ---- more than 64 parameters (the reference's loops have no size limit): runtime width, nothing resident across chunks -------
+// theta -> row-major K x PP (PP a multiple of 64) and, block 0, the padded factor
+__global__ __launch_bounds__(256) void k_theta_rows_gen(const double* __restrict__ theta, size_t K, int P, int PP,
+                                                        double* __restrict__ rows, const double* __restrict__ L,
+                                                        double* __restrict__ Lpad) {
+    if (blockIdx.x == 0 && L) {
+        for (size_t e = threadIdx.x; e < (size_t)PP * PP; e += 256) {
+            const int a = (int)(e % PP), b = (int)(e / PP);
+            Lpad[e] = (a < P && b < P && b <= a) ? L[a + (size_t)P * b] : 0.0;
+        }
+    }
+    const size_t tot = K * (size_t)PP;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (size_t)gridDim.x * 256) {
+        const size_t r = e / PP;
+        const int p = (int)(e % PP);
+        rows[e] = (p < P) ? theta[r + K * (size_t)p] : 0.0;
+    }
+}
+// Same draws and acceptance rule as k_perturb (counter (row, attempt, column quad) -> four normals), in chunks of 64
+// coordinates: x = L z for rows 64 c .. 64 c + 63 needs the normals of columns 0 .. 64 c + 63, which are REGENERATED per chunk
+// (they are a pure function of the counter); accepted coordinates are stored as they are produced, a rejected attempt is
+// overwritten by the next one.  The factor comes through the scalar cache.
+template <bool MV>
+__global__ __launch_bounds__(256) void k_perturb_gen(abc_rng key, const double* __restrict__ rows, int P, int PP,
+                                                     const abc_prior* __restrict__ priors,
+                                                     const unsigned long long* __restrict__ parent,
+                                                     unsigned long long i0, size_t n, const double* __restrict__ L_or_dv,
+                                                     double* __restrict__ out, unsigned long long* __restrict__ giveups) {
+    extern __shared__ abc_prior spg[];          // P priors
+    for (int p = threadIdx.x; p < P; p += 256) spg[p] = priors[p];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long gi = i0 + i;
+    const double* mu = rows + (size_t)parent[i] * PP;
+    const uint32_t k0 = key.s1 ^ 0x5bd1e995u, k1 = key.s2 ^ (key.s3 * 0x9E3779B1u);
+    if (MV) {
+        bool ok = false;
+        for (unsigned attempt = 0; attempt < MVN_MAX_TRIES && !ok; attempt++) {
+            ok = true;
+            for (int c = 0; c < PP / 64; c++) {
+                double x[64];
+#pragma unroll
+                for (int a = 0; a < 64; a++) x[a] = 0.0;
+                for (int qd = 0; qd < 16 * (c + 1); qd++) {          // columns 4 qd .. 4 qd + 3 <= the chunk's last row
+                    U4 cn; cn.x = (uint32_t)gi; cn.y = (uint32_t)(gi >> 32); cn.z = attempt; cn.w = (uint32_t)qd;
+                    double z[4];
+                    normal4(philox(cn, k0, k1), z);
+                    const double* l = L_or_dv + (size_t)PP * (4 * qd) + 64 * c;
+#pragma unroll
+                    for (int a = 0; a < 64; a++) {
+                        x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
+                        x[a] = fma(l[2 * (size_t)PP + a], z[2], x[a]); x[a] = fma(l[3 * (size_t)PP + a], z[3], x[a]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 64; a++) {
+                    const int p = 64 * c + a;
+                    if (p < P) {
+                        const double v = d_recast(spg[p], x[a] + mu[p]);
+                        out[i + n * (size_t)p] = v;
+                        ok = ok && d_valid(spg[p], v);
+                    }
+                }
+            }
+        }
+        if (!ok) {
+            for (int p = 0; p < P; p++) out[i + n * (size_t)p] = mu[p];      // give up: keep the (valid) parent
+            atomicAdd(giveups, 1ull);
+        }
+    } else {
+        for (int p = 0; p < P; p++) {
+            const double m = mu[p], sg = sqrt(L_or_dv[p]);
+            double v = 0.0; bool ok = false;
+            for (unsigned attempt = 0; attempt < 1000 && !ok; attempt++) {
+                v = d_recast(spg[p], indep_noise(sg, gi, attempt, p, k0, k1) + m);
+                ok = d_valid(spg[p], v);
+            }
+            out[i + n * (size_t)p] = ok ? v : d_prior_mean(spg[p]);
+            if (!ok) atomicAdd(giveups, 1ull);
+        }
+    }
+}
+
 int ensure_jump_tab(abc_ctx* ctx) {
     if (ctx->jump_tab) return ABC_OK;
     const BitMat(*tab)[3] = taus_pow2();
@@ -618,6 +702,13 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
 static int launch_theta_rows(abc_ctx* ctx, const double* theta, size_t K, size_t P, int PP, double* rows, const double* L,
                              double* Lpad) {
     const unsigned grid = (unsigned)((K + 63) / 64);
+    if (PP > 64) {
+        size_t gb = (K * (size_t)PP + 255) / 256;
+        if (gb > 4096) gb = 4096;
+        hipLaunchKernelGGL(k_theta_rows_gen, dim3((unsigned)gb), dim3(256), 0, ctx->stream, theta, K, (int)P, PP, rows, L, Lpad);
+        ABC_HIP(ctx, hipGetLastError());
+        return ABC_OK;
+    }
     switch (PP) {
         case 2: hipLaunchKernelGGL((k_theta_rows<2>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
         case 4: hipLaunchKernelGGL((k_theta_rows<4>), dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, rows, L, Lpad); break;
@@ -647,9 +738,10 @@ int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta
                            const double* L_or_dv) {
     prep->rows = nullptr;
     prep->Lpad = nullptr;
-    if (n == 0 || P > 64) return ABC_OK;
+    if (n == 0) return ABC_OK;
     int PP = 2;
     while (PP < (int)P) PP *= 2;
+    if (P > 64) PP = (int)((P + 63) / 64 * 64);
     StageTimer tm(ctx, ST_PERTURB);
     double* rows = (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
     double* Lpad = (multivariate && L_or_dv) ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
@@ -665,9 +757,9 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
                    const uint64_t* parent, uint64_t i0, size_t n, int multivariate, const double* L_or_dv, double* out,
                    uint64_t* seeds, uint64_t seed_stream_offset, const abc_perturb_prep* prep) {
     if (n == 0) return ABC_OK;
-    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "perturb: P = %zu > 64", P);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
+    if (P > 64) PP = (int)((P + 63) / 64 * 64);
     if (!ctx->giveups_dev) {
         ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, sizeof(unsigned long long)));
         ABC_HIP(ctx, hipMemsetAsync(ctx->giveups_dev, 0, sizeof(unsigned long long), ctx->stream));
@@ -678,13 +770,26 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
     const double* Lpad = (prep && prep->rows) ? prep->Lpad : nullptr;
     if (!(prep && prep->rows)) {
-        double* lp = (multivariate && PP <= 32) ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
-        if (multivariate && PP <= 32 && !lp) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+        const bool need_lp = multivariate && (PP <= 32 || PP > 64);
+        double* lp = need_lp ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
+        if (need_lp && !lp) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
         ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, lp ? L_or_dv : nullptr, lp));
         Lpad = lp;
     }
     theta = rows;
-    if (multivariate && PP <= 32 && !Lpad) ABC_FAIL(ctx, ABC_ERR_INVALID, "perturb: the padded factor was not prepared");
+    if (multivariate && (PP <= 32 || PP > 64) && !Lpad) ABC_FAIL(ctx, ABC_ERR_INVALID, "perturb: the padded factor was not prepared");
+    if (PP > 64) {
+        const size_t lds = P * sizeof(abc_prior);
+        if (multivariate)
+            hipLaunchKernelGGL((k_perturb_gen<true>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, (int)P, PP, priors,
+                               (const unsigned long long*)parent, (unsigned long long)i0, n, Lpad, out, ctx->giveups_dev);
+        else
+            hipLaunchKernelGGL((k_perturb_gen<false>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, (int)P, PP, priors,
+                               (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out, ctx->giveups_dev);
+        ABC_HIP(ctx, hipGetLastError());
+        if (seeds && !(prep && prep->seeds_done)) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, nullptr));
+        return ABC_OK;
+    }
 #define LAUNCH_PT(PPV)                                                                                                 \
     do {                                                                                                               \
         if (multivariate)                                                                                              \

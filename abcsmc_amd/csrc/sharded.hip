@@ -328,7 +328,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     // ... and so does the previous set's share of the weight stage
     abc_wprev wprev;
     memset(&wprev, 0, sizeof(wprev));
-    if (Kp && io->theta_prev && P <= 64 && kn)
+    if (Kp && io->theta_prev && kn)
         ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     if (W > 1) {
         if (r != 0) ABC_HIP(ctx, hipMemsetAsync(stats + SL.off_shift, 0, SL.C16 * 8, ctx->stream));    // the sum keeps rank 0's shift

@@ -65,16 +65,17 @@ __global__ __launch_bounds__(256) void k_doubled_variance(const double* __restri
 }
 
 // ---- weights --------------------------------------------------------------------------------------
+constexpr int W_MAXP = 1024;   // parameters the weight stage takes (arrays of WConst; beyond 64 the generic fp64 kernels run)
 struct WConst {           // per-parameter constants, built on the device by k_wprep
-    double scale[64];     // sqrt(log2 e)/sqrt(dv_p), or 0 when dv_p == 0
+    double scale[W_MAXP]; // sqrt(log2 e)/sqrt(dv_p), or 0 when dv_p == 0
     double logC;          // unused
     double C;             // prod over dv_p != 0 of 1/(sqrt(2 pi) sqrt(dv_p))
     int nzero;            // number of parameters with dv_p == 0
-    int zero_idx[64];
+    int zero_idx[W_MAXP];
     int far;              // set by k_wscale when a scaled coordinate is so large that exponents may leave int32
     int nfar_i, nfar_j;   // rows of the new / previous set outside the range the split-operand kernel is exact on (k_wsplit)
     int lim_i;            // more far new rows than this: the fp64 kernel takes the whole call
-    double centre[64];    // robust column centre of the previous set (k_wcentre): both sets are centred here
+    double centre[W_MAXP]; // robust column centre of the previous set (k_wcentre): both sets are centred here
 };
 
 constexpr double W_SQRT_LOG2E = 1.2011224087864497825;     // sqrt(log2 e): a.b then comes out in base 2
@@ -90,7 +91,8 @@ __device__ __forceinline__ bool ks_split_on(const WConst* wc) {
 __global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc, int lim_i) {
     if (threadIdx.x != 0) return;
     double C = 1.0; int nz = 0;
-    for (int p = 0; p < 64; p++) {
+    const int pmax = (P > 64) ? ((P + 63) / 64) * 64 : 64;
+    for (int p = 0; p < pmax; p++) {
         double sc = 0.0;
         if (p < P) {
             const double dv = dv_prev[p];
@@ -225,6 +227,47 @@ __global__ __launch_bounds__(256) void k_epan(const double* __restrict__ a, size
         acc += (k > 0.0) ? w_prev[j] * k : 0.0;
     }
     if (active) part[sl * kn + i] = acc;
+}
+
+// ---- more than 64 parameters: the same sums without register-resident rows (the reference's loops have no size limit) ----------
+// one new particle per thread, its scaled row re-read from global memory (L1), the previous row through the scalar cache; the
+// guarded exponential and the converged-parameter rule of k_kde's general branch
+__global__ __launch_bounds__(256) void k_kde_gen(const double* __restrict__ a, size_t kn, const double* __restrict__ b, size_t Kp,
+                                                 const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                                 const double* __restrict__ theta_raw, size_t K, size_t k0,
+                                                 const double* __restrict__ prev_raw, double* __restrict__ part, int PP, int epan, int P,
+                                                 const double* __restrict__ w_prev) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t slices = gridDim.y, sl = blockIdx.y;
+    const unsigned j0 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * sl / slices));
+    const unsigned j1 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * (sl + 1) / slices));
+    if (i >= kn) return;
+    const double* ai = a + i * (size_t)PP;
+    double ha = 0.0;
+    for (int p = 0; p < PP; p++) ha = fma(ai[p], ai[p], ha);
+    ha *= 0.5;
+    const int nzero = wc->nzero;
+    const double c = 1.0 / (1.4426950408889634 * (double)(P - nzero + 4));
+    double acc = 0.0;
+    for (unsigned j = j0; j < j1; j++) {
+        const double* bj = b + (size_t)j * PP;
+        if (epan) {
+            double d2 = 0.0;
+            for (int p = 0; p < PP; p++) { const double d = ai[p] - bj[p]; d2 = fma(d, d, d2); }
+            const double k = 1.0 - d2 * c;
+            acc += (k > 0.0) ? w_prev[j] * k : 0.0;
+        } else {
+            double e = -(ha + hb[j]);
+            for (int p = 0; p < PP; p++) e = fma(ai[p], bj[p], e);
+            double term = exp2_neg<true>(e);
+            for (int z = 0; z < nzero; z++) {
+                const int p = wc->zero_idx[z];
+                if (theta_raw[(k0 + i) + K * (size_t)p] != prev_raw[j + Kp * (size_t)p]) term = 0.0;
+            }
+            acc += term;
+        }
+    }
+    part[sl * kn + i] = acc;
 }
 
 // ---- split-operand weight kernel: the pair dot products on the f16 matrix pipe ------------------------------------
@@ -759,11 +802,12 @@ int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t 
 int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                         const double* dv_prev, abc_wprev* out, hipStream_t st) {
     memset(out, 0, sizeof(*out));
-    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
+    if (P > (size_t)W_MAXP) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > %d parameters", P, W_MAXP);
     if (Kp > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: K' = %zu >= 2^32", Kp);
     hipStream_t s = st ? st : ctx->stream;
     int PP = 2;
     while (PP < (int)P) PP *= 2;
+    if (P > 64) PP = (int)((P + 63) / 64 * 64);
     const int NCH = (P <= 16) ? 1 : 2;
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
     const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
@@ -772,7 +816,7 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
-    double* cpart = (double*)abc_ws_alloc(ctx, 64 * WC_NB * sizeof(double));
+    double* cpart = (double*)abc_ws_alloc(ctx, (P > 64 ? P : 64) * WC_NB * sizeof(double));
     unsigned short* bt = nullptr;
     unsigned* far_list = nullptr;
     if (split) {
@@ -784,7 +828,7 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, s, dv_prev, (int)P, wc, (int)(kn_max / 16 + 32));
     hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, s, theta_prev, Kp, wc, cpart);
-    hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(64), 0, s, theta_prev, Kp, (int)P, cpart, wc);
+    hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(P > 64 ? 1024 : 64), 0, s, theta_prev, Kp, (int)P, cpart, wc);
     hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
                        (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
     if (split) {
@@ -805,7 +849,7 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
 int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P, size_t k0,
                        size_t kn, const double* theta_prev, size_t Kp, const double* w_prev, const double* dv_prev,
                        double* w_raw, const abc_wprev* prev) {
-    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > 64 parameters", P);
+    if (P > (size_t)W_MAXP) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > %d parameters", P, W_MAXP);
     if (kn == 0) return ABC_OK;
     if (!ctx->kde_which) {
         ABC_HIP(ctx, hipMalloc((void**)&ctx->kde_which, sizeof(int)));
@@ -815,6 +859,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (k0 + kn > K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: row range [%zu,%zu) outside K=%zu", k0, k0 + kn, K);
     int PP = 2;
     while (PP < (int)P) PP *= 2;
+    if (P > 64) PP = (int)((P + 63) / 64 * 64);
     const size_t rb = (kn + 255) / 256;
     // Column slices: many short ones.  Work-groups are dispatched slice by slice, so the ~2000 resident groups all
     // stream the same few hundred KB of the previous set through the scalar cache / L2; with 6 slices of 2 MB each
@@ -886,6 +931,10 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (epan) {
         StageTimer tk(ctx, ST_KDE);
 #define LAUNCH_EPAN(PPV) hipLaunchKernelGGL(k_epan<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, Kp, w_prev, wc, (int)P, part)
+        if (PP > 64)
+            hipLaunchKernelGGL(k_kde_gen, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc, theta, K, k0,
+                               theta_prev, part, PP, 1, (int)P, w_prev);
+        else
         switch (PP) {
             case 2: LAUNCH_EPAN(2); break;
             case 4: LAUNCH_EPAN(4); break;
@@ -906,6 +955,10 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
                 hipLaunchKernelGGL((k_kde_split<2, 2>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
         }
+        if (PP > 64)
+            hipLaunchKernelGGL(k_kde_gen, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc, theta, K, k0,
+                               theta_prev, part, PP, 0, (int)P, w_prev);
+        else
         switch (PP) {
             case 2: LAUNCH_KDE(2); break;
             case 4: LAUNCH_KDE(4); break;

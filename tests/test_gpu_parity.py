@@ -472,6 +472,28 @@ def test_weight_kernels_agree_on_random_shapes(gpu_ctx):
         assert np.array_equal(out["auto"] == 0, out["fp64"] == 0)
 
 
+@pytest.mark.parametrize("P,K,Kp,epan", [(70, 300, 257, False), (130, 200, 300, False), (100, 150, 200, True)])
+def test_weight_more_than_64_parameters(gpu_ctx, oracle, P, K, Kp, epan):
+    """the reference's loops take any number of parameters (AbcUtil.cpp:556-581): beyond 64 the generic fp64 kernel"""
+    from abcsmc_amd import abcutil, _lib
+    rng = np.random.default_rng(P + K)
+    th = rng.normal(size=(K, P)) * 0.5 + 3.0
+    tp = rng.normal(size=(Kp, P)) * 0.7 + 3.0
+    wp = rng.random(Kp) + 0.1
+    wp /= np.linalg.norm(wp)
+    dv = 2.0 * tp.var(axis=0, ddof=1)
+    spec = [(_lib.PRIOR_GAUSS, 3.0, 4.0) if p % 2 else (_lib.PRIOR_UNIF_REAL, -10.0, 10.0) for p in range(P)]
+    if epan:
+        gpu_ctx.set_weight_kernel(_lib.WEIGHT_EPANECHNIKOV)
+    try:
+        w = abcutil.weight_predictive_prior(_lib.make_priors(spec), th, tp, wp, dv, ctx=gpu_ctx)
+    finally:
+        gpu_ctx.set_weight_kernel(_lib.WEIGHT_GAUSSIAN)
+    ref = (oracle.weights_epanechnikov if epan else oracle.weights_importance)(oracle.make_priors(spec), th, tp, wp, dv)
+    m = ref > 0
+    assert np.array_equal(m, w > 0) and np.max(np.abs(w[m] - ref[m]) / ref[m]) < 1e-9
+
+
 def test_weight_uniform_first_set(gpu_ctx):
     from abcsmc_amd import abcutil
     w = abcutil.weight_predictive_prior(None, np.zeros((123, 4)), ctx=gpu_ctx)
@@ -527,7 +549,7 @@ def test_weight_far_particles_and_zero_weights(gpu_ctx, oracle, mode):
     assert np.array_equal(np.isfinite(raw), np.isfinite(rref))
 
 
-@pytest.mark.parametrize("K,P", [(400, 6), (50, 16), (5000, 32), (33, 1)])
+@pytest.mark.parametrize("K,P", [(400, 6), (50, 16), (5000, 32), (33, 1), (900, 100), (700, 200)])
 def test_setup_mvn_sampler(gpu_ctx, oracle, K, P):
     from abcsmc_amd import abcutil
     rng = np.random.default_rng(K + P)
@@ -711,12 +733,13 @@ def test_perturb_giveups_are_counted(gpu_ctx):
     assert gpu_ctx.perturb_giveups(reset=True) == n and gpu_ctx.perturb_giveups() == 0
 
 
-@pytest.mark.parametrize("multivariate", [True, False])
-def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate):
-    """33..64 parameters take the streaming perturb kernel: same parents, same support rules, same spread"""
+@pytest.mark.parametrize("multivariate,P", [(True, 48), (False, 48), (True, 150), (False, 150)])
+def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate, P):
+    """33..64 parameters take the streaming perturb kernel, more than 64 the chunked one (the reference's loops have no size
+    limit): same parents, same support rules, same spread"""
     from abcsmc_amd import abcutil, _lib
     rng = np.random.default_rng(23)
-    K, P, n = 500, 48, 30000
+    K, n = 500, 30000
     cols, spec = [], []
     for p in range(P):
         if p % 3 == 0:
@@ -1064,11 +1087,13 @@ def test_error_codes_and_messages(gpu_ctx):
     rc = L.abc_particle_ranking_pls(h, X.ctypes.data, Y.ctypes.data, X[0].copy().ctypes.data, 50, 4, 2, 0.5, 0, 7, 10,
                                     idx.ctypes.data, None, None, None, None, None)
     assert rc == -1 and b"rule" in L.abc_last_error(h)
-    # more than 64 parameters in the weight kernel -> ABC_ERR_UNSUPPORTED (-4), not a crash
+    # more than 64 PLS responses -> ABC_ERR_UNSUPPORTED (-4), not a crash (weights / samplers take any number: tests above)
+    X70 = np.asfortranarray(np.random.default_rng(2).normal(size=(200, 80)))
+    Y70 = np.asfortranarray(np.random.default_rng(3).normal(size=(200, 70)))
+    idx70 = np.zeros(10, dtype=np.uint64)
+    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 80, 70, 0.5, 4, 0, 10,
+                                    idx70.ctypes.data, None, None, None, None, None)
+    assert rc == -4 and b"responses" in L.abc_last_error(h)
     th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 70)))
-    pri = _lib.make_priors([(_lib.PRIOR_GAUSS, 0.0, 1.0)] * 70)
-    with pytest.raises(_lib.AbcError) as e:
-        abcutil.weight_predictive_prior(pri, th, th, np.full(20, 0.05), np.ones(70), ctx=gpu_ctx)
-    assert e.value.code == -4
     # a later valid call on the same context still works
     assert abcutil.calculate_doubled_variance(th[:, :3], ctx=gpu_ctx).shape == (3,)
