@@ -150,6 +150,14 @@ def lib():
             raise LibraryMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C abcsmc_amd/csrc` (there is no CPU fallback)" % SO_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Loaded after
+        # PyTorch's, this library binds to that copy; loaded BEFORE it, it pulls in the system copy and PyTorch later adds its
+        # own -- two runtimes, and the second to touch the device fails (abc_ctx_create then reports no usable GPU).  The
+        # device / multi-GPU drivers of this package use torch for memory and streams anyway, so it goes first when present.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
