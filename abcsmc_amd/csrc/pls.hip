@@ -200,6 +200,75 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
     return tr;
 }
 
+// More than 64 responses (the reference has no limit; the register-resident squaring above stops at 64 x 64): the same
+// algorithm -- S = XY'XY, B = S / trace, groups of three squarings with a trace normalisation until trace(B^8) > 0.95, the column
+// of the largest diagonal entry, one power step with S, unit norm, largest |component| positive -- by the whole work-group on
+// matrices in memory (S, B, T: n x n each; wide sets always run the global-memory mode).  qv receives the eigenvector.
+template <int NT>
+__device__ void eig_generic(const double* __restrict__ XY, int M, int n, double* __restrict__ S, double* __restrict__ Bm,
+                            double* __restrict__ T, double* __restrict__ qv, double* __restrict__ red /* >= 8 */) {
+    const int t = threadIdx.x;
+    for (int e = t; e < n * n; e += NT) {
+        const int i = e % n, j = e / n;
+        double s = 0.0;
+        for (int m = 0; m < M; m++) s = fma(XY[m + M * i], XY[m + M * j], s);
+        S[e] = s;
+    }
+    __threadfence_block(); __syncthreads();
+    if (t == 0) { double tr = 0.0; for (int i = 0; i < n; i++) tr += S[i + n * i]; red[0] = tr; }
+    __threadfence_block(); __syncthreads();
+    const double tr = red[0];
+    for (int e = t; e < n * n; e += NT) Bm[e] = (tr > 0.0) ? S[e] / tr : ((e == 0) ? 1.0 : 0.0);
+    __threadfence_block(); __syncthreads();
+    for (int grp = 0; grp < 24; grp++) {
+        for (int sq = 0; sq < 3; sq++) {
+            for (int e = t; e < n * n; e += NT) {
+                const int i = e % n, j = e / n;
+                double s = 0.0;
+                for (int k = 0; k < n; k++) s = fma(Bm[i + n * k], Bm[k + n * j], s);
+                T[e] = s;
+            }
+            __threadfence_block(); __syncthreads();
+            for (int e = t; e < n * n; e += NT) Bm[e] = T[e];
+            __threadfence_block(); __syncthreads();
+        }
+        if (t == 0) { double tt = 0.0; for (int i = 0; i < n; i++) tt += Bm[i + n * i]; red[1] = tt; }
+        __threadfence_block(); __syncthreads();
+        const double tt = red[1];
+        for (int e = t; e < n * n; e += NT) Bm[e] = Bm[e] / tt;
+        __threadfence_block(); __syncthreads();
+        if (tt > 0.95) break;
+    }
+    if (t == 0) {
+        int best = 0;
+        for (int i = 1; i < n; i++) if (Bm[i + n * i] > Bm[best + n * best]) best = i;       // ties -> lowest index
+        red[2] = (double)best;
+    }
+    __threadfence_block(); __syncthreads();
+    const int best = (int)red[2];
+    for (int i = t; i < n; i += NT) T[i] = Bm[i + n * best];
+    __threadfence_block(); __syncthreads();
+    if (tr > 0.0) {
+        for (int i = t; i < n; i += NT) {
+            double v = 0.0;
+            for (int k = 0; k < n; k++) v = fma(S[i + n * k], T[k], v);
+            T[n + i] = v;
+        }
+        __threadfence_block(); __syncthreads();
+        for (int i = t; i < n; i += NT) T[i] = T[n + i];
+        __threadfence_block(); __syncthreads();
+    }
+    if (t == 0) {
+        double nn = 0.0, am = -1.0, sv = 1.0;
+        for (int i = 0; i < n; i++) { nn = fma(T[i], T[i], nn); if (fabs(T[i]) > am) { am = fabs(T[i]); sv = T[i]; } }
+        red[3] = sqrt(nn);
+        red[4] = (sv < 0.0) ? -1.0 : 1.0;
+    }
+    __threadfence_block(); __syncthreads();
+    for (int i = t; i < n; i += NT) qv[i] = red[4] * T[i] / red[3];
+    __threadfence_block(); __syncthreads();
+}
+
 // sum over the work-group (NW waves); NW == 1: the wave sum
 template <int NW>
 __device__ __forceinline__ double pls_sum(double v, double* red) {
@@ -260,6 +329,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     double* red = XXl + (xx_in_lds ? (size_t)M * M : 0);   // 8: work-group sums
     double* pwv = red + 8;              // A: projections of w on the earlier loadings (NW > 1)
     double* xp = pwv + A;               // 4*M: partial dot products of X'X r (NW > 1)
+    double* Tg = xp + 4 * (size_t)M;    // np*np + np: third matrix of the memory-resident eigen-squaring (P > 64 only)
 
     const double* XXtr = zwork + Z.off_XX[0];
     if (xx_in_lds) {
@@ -285,6 +355,9 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             const int n = P;
             double* Bc = V;
             STAMP(1);
+            if (n > 64) {
+                eig_generic<NT>(XY, M, n, S, Bc, Tg, qv, red);
+            } else
             if (NW == 1 || wave == 0) {          // the whole eigenvector step is one wave's work (wave-uniform branch)
             double tr;
             if (n <= 16) tr = eig_square<1>(XY, M, n, S, Bc);
@@ -506,7 +579,6 @@ static double g_pls_stamps[16];
 
 int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
                      double* model) {
-    if (P > 64) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "pls: P = %zu > 64 responses", P);
     if (A < 1 || A > M) ABC_FAIL(ctx, ABC_ERR_INVALID, "pls: components A=%zu must be in [1, M=%zu]", A, M);
     StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
@@ -517,7 +589,8 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
     const int xx_in_lds = M <= 64;
-    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8 + (8 + A + 4 * M);
+    const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8 + (8 + A + 4 * M) +
+                         (P > 64 ? np * np + np : 0);
     size_t lds_bytes = lds_d * sizeof(double);
     // beyond the LDS (about 500 metrics at 16 parameters and 8 components) the same work arrays live in global memory: the
     // reference has no size limit here (PLS::Model on Eigen matrices); slower, one work-group either way

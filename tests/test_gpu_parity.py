@@ -59,6 +59,8 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (600, 130, 20, 10, 0.5),     # 150 columns: grouped pairs through the pointer-table mode, 4 groups
     (900, 300, 12, 6, 0.5),      # 312 columns: beyond the LDS-resident model fit's former 160-column limit
     (1200, 600, 16, 8, 0.5),     # 616 columns: the PLS work arrays live in global memory (> 160 KB), 13 column groups
+    (1500, 90, 70, 5, 0.5),      # 70 responses: the memory-resident eigen-squaring (the register-resident one stops at 64)
+    (800, 40, 100, 3, 0.6),      # more responses than metrics
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
@@ -1087,13 +1089,13 @@ def test_error_codes_and_messages(gpu_ctx):
     rc = L.abc_particle_ranking_pls(h, X.ctypes.data, Y.ctypes.data, X[0].copy().ctypes.data, 50, 4, 2, 0.5, 0, 7, 10,
                                     idx.ctypes.data, None, None, None, None, None)
     assert rc == -1 and b"rule" in L.abc_last_error(h)
-    # more than 64 PLS responses -> ABC_ERR_UNSUPPORTED (-4), not a crash (weights / samplers take any number: tests above)
+    # more than 32 PLS components -> ABC_ERR_UNSUPPORTED (-4), not a crash
     X70 = np.asfortranarray(np.random.default_rng(2).normal(size=(200, 80)))
-    Y70 = np.asfortranarray(np.random.default_rng(3).normal(size=(200, 70)))
+    Y70 = np.asfortranarray(np.random.default_rng(3).normal(size=(200, 40)))
     idx70 = np.zeros(10, dtype=np.uint64)
-    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 80, 70, 0.5, 4, 0, 10,
+    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 80, 40, 0.5, 40, 0, 10,
                                     idx70.ctypes.data, None, None, None, None, None)
-    assert rc == -4 and b"responses" in L.abc_last_error(h)
+    assert rc == -4 and b"components" in L.abc_last_error(h)
     th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 70)))
     # a later valid call on the same context still works
     assert abcutil.calculate_doubled_variance(th[:, :3], ctx=gpu_ctx).shape == (3,)
