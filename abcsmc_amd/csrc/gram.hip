@@ -414,6 +414,134 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Wide sets in ONE launch (8..10 column blocks, e.g. BASELINE configs[4]: 128 metrics + 16 parameters = 9 blocks, 44 Gram
+// blocks): the accumulators of all blocks do not fit one wave (44 x 8 VGPRs), so the BLOCKS are dealt out to the eight waves
+// of a work-group (block b to wave b mod 8, five or six each) and every wave runs its blocks over all 64 rows of the tile --
+// each block has one owner, so the epilogue needs no cross-wave reduction.  Staging as in k_gram (16-byte non-temporal loads a
+// tile ahead, z-shifted and masked on the way into LDS, column sums / sums of squares there).  Every column is read once
+// (the grouped path read each 48-column group twice, in three launches: 0.17 ms at N = 125 k against 0.07 here);
+// 44 fp64 MFMA blocks per 4 rows make this shape matrix-pipe bound.
+template <int C, int CY>
+struct GramWide {
+    static constexpr int C16 = 16 * C;
+    static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
+    static constexpr int NW = 8, NT = 512, TRW = 64, TRPW = TRW + 2;
+    static constexpr int NI = C;                          // one column of every 16-column block per thread and tile
+    static constexpr int PSZ = NBLK * 256 + 2 * C16;      // same partial record as k_gram
+    static constexpr int NBW = (NBLK + NW - 1) / NW;      // blocks per wave
+    static constexpr int LDS_D = C16 * TRPW;
+};
+template <int C, int CY>
+__global__ __launch_bounds__(512) void k_gram_wide(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy,
+                                                   int M, int P, long long n, long long split, const double* __restrict__ shift,
+                                                   double* __restrict__ partial, int vec_ok) {
+    using D = GramWide<C, CY>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
+    const long long r_begin = part ? split : 0, r_end = part ? n : split;
+    const long long t0 = r_begin & ~1LL;
+    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + D::TRW - 1) / D::TRW : 0;
+    // this wave's blocks: the b-th block of the (bi, bj >= bi, bi < C - CY) enumeration with b = wave + 8 k
+    int wbi[D::NBW], wbj[D::NBW];          // (indexed by unrolled constants only: they live in SGPRs)
+#pragma unroll
+    for (int k = 0; k < D::NBW; k++) {
+        int rem = wave + 8 * k, bi = 0;
+        while (bi < C - CY && rem >= C - bi) { rem -= C - bi; bi++; }
+        wbi[k] = (bi < C - CY) ? bi : -1;
+        wbj[k] = bi + rem;
+    }
+    d4 acc[D::NBW];
+#pragma unroll
+    for (int k = 0; k < D::NBW; k++) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+    // staging: thread -> (column 16 i + t / 32, row pair t % 32)
+    const int cq = t >> 5, rp = t & 31;
+    double colsum[D::NI], colsq[CY > 0 ? CY : 1], sh[D::NI], keep[D::NI];     // sums of squares: the trailing CY blocks only
+    const double* cptr[D::NI];
+#pragma unroll
+    for (int q0 = 0; q0 < (CY > 0 ? CY : 1); q0++) colsq[q0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D::NI; i++) {
+        const int c = 16 * i + cq;
+        colsum[i] = 0.0;
+        keep[i] = (c < M + P) ? 1.0 : 0.0;
+        cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+        sh[i] = (c < M + P) ? shift[c] : 0.0;
+    }
+    d2 v[D::NI];
+    auto fetch = [&](long long tile) {
+        const long long row0 = t0 + tile * D::TRW;
+        const long long r = row0 + 2 * rp;
+        const bool full = (row0 >= r_begin) && (row0 + D::TRW <= r_end);
+        if (full && vec_ok) {
+#pragma unroll
+            for (int i = 0; i < D::NI; i++) v[i] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(cptr[i] + r));
+        } else {
+            const long long ra = r < r_begin ? r_begin : (r >= r_end ? r_end - 1 : r);
+            const long long rb = r + 1 < r_begin ? r_begin : (r + 1 >= r_end ? r_end - 1 : r + 1);
+            const bool oka = (r >= r_begin) && (r < r_end), okb = (r + 1 >= r_begin) && (r + 1 < r_end);
+#pragma unroll
+            for (int i = 0; i < D::NI; i++) {
+                const double xa = cptr[i][ra], xb = cptr[i][rb];
+                v[i] = (d2){oka ? xa : sh[i], okb ? xb : sh[i]};
+            }
+        }
+    };
+    long long tile = g;
+    if (tile < ntiles) fetch(tile);
+    const int cl = lane & 15, q = lane >> 4;
+    for (; tile < ntiles; tile += G) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < D::NI; i++) {
+            const int c = 16 * i + cq;
+            d2 z = (d2){(v[i].x - sh[i]) * keep[i], (v[i].y - sh[i]) * keep[i]};
+            colsum[i] += z.x + z.y;
+            if constexpr (CY > 0) {
+                if (i >= C - CY) { colsq[i - (C - CY)] = fma(z.x, z.x, colsq[i - (C - CY)]); colsq[i - (C - CY)] = fma(z.y, z.y, colsq[i - (C - CY)]); }
+            }
+            *reinterpret_cast<d2*>(&lds[c * D::TRPW + 2 * rp]) = z;
+        }
+        __syncthreads();
+        if (tile + G < ntiles) fetch(tile + G);
+#pragma unroll 2
+        for (int s = 0; s < D::TRW / 4; s++) {
+            const int rb = 4 * s + q;
+#pragma unroll
+            for (int k = 0; k < D::NBW; k++) {
+                if (wbi[k] >= 0) {          // wave-uniform
+                    const double a = lds[(16 * wbi[k] + cl) * D::TRPW + rb], b = lds[(16 * wbj[k] + cl) * D::TRPW + rb];
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: every block has exactly one owner
+    double* out = partial + ((size_t)part * G + g) * D::PSZ;
+#pragma unroll
+    for (int k = 0; k < D::NBW; k++) {
+        if (wbi[k] >= 0) {
+            const int b = wave + 8 * k;
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[b * 256 + r * 64 + lane] = acc[k][r];
+        }
+    }
+    // column sums / sums of squares: 32 threads staged each column
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < D::NI; i++) lds[(16 * i + cq) * 32 + rp] = half ? ((CY > 0 && i >= C - CY) ? colsq[i >= C - CY ? i - (C - CY) : 0] : 0.0) : colsum[i];
+        __syncthreads();
+        if (t < D::C16) {
+            double s = 0.0;
+            for (int l = 0; l < 32; l++) s += lds[t * 32 + l];
+            out[D::NBLK * 256 + half * D::C16 + t] = s;
+        }
+    }
+}
+
 // Sum the per-work-group partial records in a fixed order and scatter into the stats record.
 template <int C, int CY>
 __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__ partial, int G,
@@ -557,6 +685,36 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     return ABC_OK;
 }
 
+template <int C, int CY>
+int run_gram_wide(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
+                  long long split, double* stats) {
+    using D = GramWide<C, CY>;
+    const StatsLayout L = stats_layout(M, P);
+    const long long ntr = split, nte = (long long)n - split;
+    const long long tiles = ((ntr > nte ? ntr : nte) + D::TRW - 1) / D::TRW + 1;
+    long long G = tiles / 2;
+    if (G < 1) G = 1;
+    if (G > 128) G = 128;              // 84 KB of LDS and 512 threads: one work-group per CU, 2 partitions x 128
+    const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
+    double* partial = (double*)abc_ws_alloc(ctx, pbytes);
+    if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
+    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
+    const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
+    const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_wide<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    {
+        StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
+        hipLaunchKernelGGL((k_gram_wide<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
+                           (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 15) / 16, 2), dim3(256), 0, ctx->stream, partial, (int)G,
+                       stats, ntr, nte);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
 // ---- wide sets (M+P > 96): column groups of <= 48, one k_gram<.,0,TABLE> launch per pair of groups ------------
 __global__ void k_group_table(const double* X, const double* Y, size_t ldx, size_t ldy, int M, int P, int ga0, int gan,
                               int gb0, int gbn, const double* __restrict__ shift_big, const double** __restrict__ tab,
@@ -675,6 +833,12 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     GRAM_CASE(4, 0); GRAM_CASE(4, 1); GRAM_CASE(4, 2); GRAM_CASE(5, 0); GRAM_CASE(5, 1); GRAM_CASE(5, 2);
     GRAM_CASE(6, 0); GRAM_CASE(6, 1); GRAM_CASE(6, 2);
 #undef GRAM_CASE
+    // 8..10 column blocks: one launch, the Gram blocks dealt out to the waves of a work-group (7 blocks: the compiler spills
+    // that instantiation; it stays on the grouped path)
+#define GRAM_WIDE_CASE(c, cy) if (C == c && CY == cy) return run_gram_wide<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+    GRAM_WIDE_CASE(8, 0); GRAM_WIDE_CASE(8, 1); GRAM_WIDE_CASE(8, 2);
+    GRAM_WIDE_CASE(9, 0); GRAM_WIDE_CASE(9, 1); GRAM_WIDE_CASE(9, 2); GRAM_WIDE_CASE(10, 0); GRAM_WIDE_CASE(10, 1); GRAM_WIDE_CASE(10, 2);
+#undef GRAM_WIDE_CASE
     // wider sets: column groups of 48, one launch per pair of groups (every column is read ceil(columns / 48) - 1 times)
     return run_gram_grouped(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
 }
