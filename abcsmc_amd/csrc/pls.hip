@@ -269,6 +269,33 @@ __device__ void eig_generic(const double* __restrict__ XY, int M, int n, double*
     __threadfence_block(); __syncthreads();
 }
 
+// Small GEMMs of the PRESS statistics on the fp64 matrix pipe: C[i + ldc j] = sum_k A(i,k) B(k,j), i < I, j < J, k < Kd, with
+// A(i,k) = pa[i sai + k sak], B(k,j) = pb[k sbk + j sbj]; the 16 x 16 output blocks are dealt out to the NW waves, every block
+// v_mfma_f64_16x16x4_f64 over Kd / 4 steps (A operand: lane (c, q) holds A[row c][k q]; B: B[k q][col c]; D: [q + 4 r][c]).
+// (One thread per output element walking Kd dependent fma's with L2 loads was 22 % of the fit at 32 components.)
+template <int NW>
+__device__ void pls_gemm(const double* __restrict__ pa, size_t sai, size_t sak, const double* __restrict__ pb, size_t sbk, size_t sbj,
+                         int I, int J, int Kd, double* __restrict__ Cm, size_t ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int nbi = (I + 15) / 16, nbj = (J + 15) / 16;
+    for (int b = wave; b < nbi * nbj; b += NW) {
+        const int bi = b % nbi, bj = b / nbi;
+        const int i = 16 * bi + c, j = 16 * bj + c;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kd; k0 += 4) {
+            const int k = k0 + q;
+            const double av = (i < I && k < Kd) ? pa[(size_t)i * sai + (size_t)k * sak] : 0.0;
+            const double bv = (j < J && k < Kd) ? pb[(size_t)k * sbk + (size_t)j * sbj] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * bi + q + 4 * r;
+            if (row < I && j < J) Cm[row + ldc * (size_t)j] = acc[r];
+        }
+    }
+}
+
 // sum over the work-group (NW waves); NW == 1: the wave sum
 template <int NW>
 __device__ __forceinline__ double pls_sum(double v, double* red) {
@@ -506,25 +533,10 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     double* vk = scratch;               // A*M
     double* H = vk + (size_t)A * M;     // A*A
     double* cm = H + (size_t)A * A;     // P*A
-    for (int e = lane; e < A * M; e += NT) {
-        const int m = e % M, k = e / M;
-        double s = 0.0;
-        _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
-        vk[e] = s;
-    }
+    pls_gemm<NW>(XXte, 1, (size_t)M, Rm, 1, (size_t)M, M, A, M, vk, (size_t)M);            // vk = XXte R        (M x A)
     PLS_SYNC();
-    for (int e = lane; e < A * A; e += NT) {
-        const int k = e % A, l = e / A;
-        double s = 0.0;
-        _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], vk[m + (size_t)M * l], s);
-        H[e] = s;
-    }
-    for (int e = lane; e < P * A; e += NT) {
-        const int j = e % P, k = e / P;
-        double s = 0.0;
-        _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
-        cm[e] = s;
-    }
+    pls_gemm<NW>(Rm, (size_t)M, 1, vk, 1, (size_t)M, A, A, M, H, (size_t)A);                 // H = R' vk          (A x A)
+    pls_gemm<NW>(XYte, (size_t)M, 1, Rm, 1, (size_t)M, P, A, M, cm, (size_t)P);              // c = XYte' R        (P x A)
     PLS_SYNC();
     double* press = model + ML.off_press;   // A x P, column-major
     for (int j = lane; j < P; j += NT) {
