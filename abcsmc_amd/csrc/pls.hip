@@ -479,7 +479,8 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             }
             tt = wave_sum(tt);
         } else {
-            // four threads per row, a quarter of the columns each (four independent chains of M/4 instead of one of M)
+            // four threads per row, a quarter of the columns each (four independent chains of M/4 instead of one of M; as a
+            // one-column GEMM on the fp64 matrix pipe the same product was twice as slow: 32 dependent steps with L2 loads)
             const int qb = (M + 3) / 4;
             for (int e = lane; e < 4 * M; e += NT) {
                 const int a = e % M, part = e / M;
@@ -507,12 +508,32 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
         }
         PLS_SYNC();
         STAMP(5);
+        if (NW > 1 && M > 64 && 4 * M >= 8 * P) {
+            // q_j = XY[:, j]' r / tt: eight threads per response, an eighth of the rows each, partial sums through xp (4 M doubles)
+            const int qb = (M + 7) / 8;
+            for (int e = lane; e < 8 * P; e += NT) {
+                const int j = e % P, part = e / P;
+                const int m0 = part * qb, m1 = (m0 + qb < M) ? m0 + qb : M;
+                double s = 0.0;
+                _Pragma("unroll 8") for (int m = m0; m < m1; m++) s = fma(XY[m + M * j], rv[m], s);
+                xp[e] = s;
+            }
+            PLS_SYNC();
+            for (int j = lane; j < P; j += NT) {
+                double s = 0.0;
+                for (int part = 0; part < 8; part++) s += xp[part * P + j];
+                s /= tt;
+                qv[j] = s;
+                Qm[j + (size_t)P * comp] = s;
+            }
+        } else {
         for (int j = lane; j < P; j += NT) {
             double s = 0.0;
             _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(XY[m + M * j], rv[m], s);
             s /= tt;
             qv[j] = s;
             Qm[j + (size_t)P * comp] = s;
+        }
         }
         PLS_SYNC();
         for (int e = lane; e < M * P; e += NT) {
@@ -533,10 +554,32 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     double* vk = scratch;               // A*M
     double* H = vk + (size_t)A * M;     // A*A
     double* cm = H + (size_t)A * A;     // P*A
-    pls_gemm<NW>(XXte, 1, (size_t)M, Rm, 1, (size_t)M, M, A, M, vk, (size_t)M);            // vk = XXte R        (M x A)
-    PLS_SYNC();
-    pls_gemm<NW>(Rm, (size_t)M, 1, vk, 1, (size_t)M, A, A, M, H, (size_t)A);                 // H = R' vk          (A x A)
-    pls_gemm<NW>(XYte, (size_t)M, 1, Rm, 1, (size_t)M, P, A, M, cm, (size_t)P);              // c = XYte' R        (P x A)
+    if (A * M >= 1024) {           // (below that one thread per element is as fast: 256 outputs at 32 metrics, 8 components)
+        pls_gemm<NW>(XXte, 1, (size_t)M, Rm, 1, (size_t)M, M, A, M, vk, (size_t)M);            // vk = XXte R        (M x A)
+        PLS_SYNC();
+        pls_gemm<NW>(Rm, (size_t)M, 1, vk, 1, (size_t)M, A, A, M, H, (size_t)A);                 // H = R' vk          (A x A)
+        pls_gemm<NW>(XYte, (size_t)M, 1, Rm, 1, (size_t)M, P, A, M, cm, (size_t)P);              // c = XYte' R        (P x A)
+    } else {
+        for (int e = lane; e < A * M; e += NT) {
+            const int m = e % M, k = e / M;
+            double s = 0.0;
+            _Pragma("unroll 8") for (int b = 0; b < M; b++) s = fma(XXte[m + (size_t)M * b], Rm[b + (size_t)M * k], s);
+            vk[e] = s;
+        }
+        PLS_SYNC();
+        for (int e = lane; e < A * A; e += NT) {
+            const int k = e % A, l = e / A;
+            double s = 0.0;
+            _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], vk[m + (size_t)M * l], s);
+            H[e] = s;
+        }
+        for (int e = lane; e < P * A; e += NT) {
+            const int j = e % P, k = e / P;
+            double s = 0.0;
+            _Pragma("unroll 8") for (int m = 0; m < M; m++) s = fma(Rm[m + (size_t)M * k], XYte[m + (size_t)M * j], s);
+            cm[e] = s;
+        }
+    }
     PLS_SYNC();
     double* press = model + ML.off_press;   // A x P, column-major
     for (int j = lane; j < P; j += NT) {
