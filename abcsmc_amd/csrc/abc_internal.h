@@ -27,6 +27,10 @@ struct abc_ctx {
     // pinned host scratch
     char* pin;
     size_t pin_bytes;
+    // 64 pinned bytes for the status words a generation reads back at its end (component count, Cholesky status, selection
+    // flag): into pinned memory the three small copies are queued back to back behind ONE synchronisation; into pageable
+    // memory each one is a blocking round trip (17 + 50 us of gaps at the end of a generation, rocprofv3 timeline)
+    char* status_pin;
     // cached alias table (device) for the last weights vector handed to abc_resample_dev
     double* alias_F;
     uint32_t* alias_A;
@@ -171,6 +175,10 @@ int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, siz
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out, bool defer_check = false);
 int abc_select_check(abc_ctx* ctx, int* failed);
+// the same in two halves for a caller with its own synchronisation: queue the flag's copy into *slot (pinned), then, after the
+// synchronisation, abc_select_check_done reads it
+int abc_select_check_queue(abc_ctx* ctx, int* slot);
+int abc_select_check_done(abc_ctx* ctx, const int* slot);
 // column slices of the weight kernel (weights.hip) and the bytes of partial sums they need; shared with the
 // workspace sizing in api.hip
 inline size_t abc_kde_slices(size_t kn, size_t Kp, int PP) {

@@ -80,6 +80,7 @@ extern "C" int abc_ctx_create(int device, abc_ctx** out) {
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ABC_ERR_HIP; }
+    if (hipHostMalloc((void**)&ctx->status_pin, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ABC_ERR_HIP; }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return ABC_OK;
@@ -91,6 +92,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->status_pin) (void)hipHostFree(ctx->status_pin);
     if (ctx->alias_F) (void)hipFree(ctx->alias_F);       // alias_A lives in the same allocation
     if (ctx->ualias_F) (void)hipFree(ctx->ualias_F);
     if (ctx->ualias_pin) (void)hipHostFree(ctx->ualias_pin);
@@ -545,17 +547,20 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         }
     }
     {
-        double hdr[4] = {0, 0, 0, 0};
-        if (!simple) ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
-        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(&spd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        // status words into the pinned block: [0..31] model header (component count), [32] Cholesky status, [36] selection flag
+        double* hdr = (double*)ctx->status_pin;
+        int* pspd = (int*)(ctx->status_pin + 32);
+        int* pfail = (int*)(ctx->status_pin + 36);
+        hdr[0] = 0.0; *pspd = 0; *pfail = 0;
+        if (!simple) ABC_HIP(ctx, hipMemcpyAsync(hdr, model, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(pspd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ABC_TRY(abc_select_check_queue(ctx, pfail));
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
-    }
-    {
+        spd = *pspd;
         // the sampled-range bin selection gave up (degenerate distances, an atypical sample): everything downstream of it
         // worked on a placeholder; once more, from the top, with the radix select
-        int failed = 0;
-        ABC_TRY(abc_select_check(ctx, &failed));
+        const int failed = abc_select_check_done(ctx, pfail);
         if (failed && !ctx->sel_force_radix) {
             ctx->ws_off = ws_entry;
             if (rng) *rng = rng_entry;

@@ -913,6 +913,18 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
     return select_by_radix(ctx, dist, n, K, idx_base, idx, dist_out);
 }
 
+int abc_select_check_queue(abc_ctx* ctx, int* slot) {
+    *slot = 0;
+    if (!ctx->sel_bins_ran || !ctx->sel_fail_dev) return ABC_OK;
+    ABC_HIP(ctx, hipMemcpyAsync(slot, ctx->sel_fail_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return ABC_OK;
+}
+int abc_select_check_done(abc_ctx* ctx, const int* slot) {
+    const int f = (ctx->sel_bins_ran && ctx->sel_fail_dev) ? *slot : 0;
+    ctx->sel_bins_ran = false;
+    return f;
+}
+
 // after a synchronisation point of the caller: did the last bin selection give up?  (synchronises the stream itself)
 int abc_select_check(abc_ctx* ctx, int* failed) {
     *failed = 0;

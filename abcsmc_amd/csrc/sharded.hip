@@ -515,11 +515,14 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     }
     taus2_jump(rng, 2 * (uint64_t)cfg->Nnext_total);          // Nnext resampling draws + Nnext seeds of the whole set
     {
-        double hdr[4] = {0, 0, 0, 0};
-        ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
-        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(&spd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        double* hdr = (double*)ctx->status_pin;             // pinned: the two copies queue behind one synchronisation
+        int* pspd = (int*)(ctx->status_pin + 32);
+        hdr[0] = 0.0; *pspd = 0;
+        ABC_HIP(ctx, hipMemcpyAsync(hdr, model, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(pspd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
+        spd = *pspd;
     }
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
     return ABC_OK;
