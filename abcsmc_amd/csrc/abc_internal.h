@@ -45,6 +45,7 @@ struct abc_ctx {
     // run there from the first launch on, beside the ranking chain (abc_rng_streams_early); ev_fork / ev_side order them
     hipStream_t side;
     hipEvent_t ev_fork, ev_side, ev_prev;
+    bool side_forked;      // ev_fork of the current generation is recorded (abc_side_fork); cleared when the generation ends
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
@@ -248,6 +249,7 @@ int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uin
 // i0 + i.  The main stream waits for them in launch_resample (raw_ready).  Call before the first kernel of the generation.
 int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
                           uint32_t** raw);
+int abc_side_fork(abc_ctx* ctx);      // records where on the main stream the side stream's work of this generation may start
 // Alias table of K equal weights: gsl_ran_discrete_preproc on K copies of 1.0 / K (bit-identical to the table of the filled
 // weight vector), built on the host on first use for this K and kept in HBM.  The fused drivers call it right after queueing
 // the ranking kernels, so the host builds the table while the GPU ranks.

@@ -453,6 +453,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const size_t Pstat = io->Y ? P : 0;
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
+    ctx->side_forked = false;
+    ABC_TRY(abc_side_fork(ctx));             // the side stream's work starts behind the Gram kernel; its launches follow the fit's
+    if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
+    else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
+    if (!simple && cfg->rule == ABC_RULE_WILCOXON)
+        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, forked behind the Gram
     // kernel (which wants the whole memory system) and running beside the reduce / model fit that leave the chip empty
     uint32_t* raw_early = nullptr;
@@ -463,10 +469,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     memset(&wprev, 0, sizeof(wprev));
     if (io->w && K && Kp && io->theta_prev)
         ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
-    if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
-    else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
-    if (!simple && cfg->rule == ABC_RULE_WILCOXON)
-        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
+    ctx->side_forked = false;
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/io->w != nullptr));

@@ -582,21 +582,30 @@ int abc_uniform_alias(abc_ctx* ctx, size_t K) {
 static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
                         hipStream_t st);
 
-int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
-                          uint32_t** raw_out) {
-    *raw_out = nullptr;
-    if (n == 0) return ABC_OK;
+// The point of the main stream the side stream's work of this generation starts behind (the end of the Gram kernel): recorded
+// once; the early launchers below find it and do not record their own.  The fused drivers record it, queue the model fit on
+// the main stream and only then spend host time on the side stream's launches, which catch up beside the (long, one-work-group) fit.
+int abc_side_fork(abc_ctx* ctx) {
     if (!ctx->side) {
         ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
     }
-    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
-    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
-    ABC_TRY(ensure_jump_tab(ctx));                       // (its first-use upload is synchronous: before the fork)
-    // the side stream starts behind everything already queued on the main one (earlier users of the seed buffer)
     ABC_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    ctx->side_forked = true;
+    return ABC_OK;
+}
+
+int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
+                          uint32_t** raw_out) {
+    *raw_out = nullptr;
+    if (n == 0) return ABC_OK;
+    uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+    if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
+    ABC_TRY(ensure_jump_tab(ctx));                       // (its first-use upload is synchronous)
+    // the side stream starts behind everything queued on the main one up to the fork (earlier users of the seed buffer)
+    if (!ctx->side_forked) ABC_TRY(abc_side_fork(ctx));
     abc_rng base = *rng;
     taus2_jump(&base, i0);
     ABC_TRY(taus_stream(ctx, base, n, raw, ctx->side));
@@ -610,14 +619,8 @@ int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t 
 // forked here); the main stream waits for ev_prev before launch_weights_raw
 int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                            const double* dv_prev, abc_wprev* out) {
-    if (!ctx->side) {
-        ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
-    }
+    if (!ctx->side_forked) ABC_TRY(abc_side_fork(ctx));
     if (!ctx->ev_prev) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_prev, hipEventDisableTiming));
-    ABC_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     ABC_TRY(launch_weights_prev(ctx, P, kn_max, theta_prev, Kp, w_prev, dv_prev, out, ctx->side));
     ABC_HIP(ctx, hipEventRecord(ctx->ev_prev, ctx->side));
     return ABC_OK;

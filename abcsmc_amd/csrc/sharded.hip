@@ -324,12 +324,14 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, forked
     // behind the Gram kernel
     uint32_t* raw_early = nullptr;
+    ctx->side_forked = false;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
     // ... and so does the previous set's share of the weight stage
     abc_wprev wprev;
     memset(&wprev, 0, sizeof(wprev));
     if (Kp && io->theta_prev && kn)
         ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
+    ctx->side_forked = false;
     if (W > 1) {
         if (r != 0) ABC_HIP(ctx, hipMemsetAsync(stats + SL.off_shift, 0, SL.C16 * 8, ctx->stream));    // the sum keeps rank 0's shift
         ABC_TRY(comm_all_reduce(ctx, stats, SL.len, ABC_DT_F64));
