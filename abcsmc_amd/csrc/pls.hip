@@ -12,15 +12,50 @@
 
 namespace {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave reductions on the DPP path (no LDS crossbar: hipcc turns every __shfl_xor into two ds_bpermute_b32, ~100 cycles each
+// on a dependent chain, and these kernels are nothing but dependent chains).  Inside a row of 16 lanes: quad_perm [1,0,3,2] and
+// [2,3,0,1], then row_half_mirror and row_mirror (every lane of a quad / half row already holds the same partial result, so the
+// mirrors act as xor 4 / xor 8); across the four rows: readlane of lanes 0, 16, 32, 48.  Additions commute, so every lane ends
+// with the same bits.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = dpp_i32<CTRL>(u.i[0]);
+    r.i[1] = dpp_i32<CTRL>(u.i[1]);
+    return r.d;
 }
-__device__ __forceinline__ double wave_max(double v) {
+__device__ __forceinline__ double lane_f64(double v, int src_lane) {         // wave-uniform broadcast of one lane's value
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+    return u.d;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+// arg-max over the wave of (key, index) with ties -> lowest index; `pay` travels with the winner
+__device__ __forceinline__ void argmax_step(double& k, int& i, double& p, double ok, int oi, double op) {
+    if (ok > k || (ok == k && oi < i)) { k = ok; i = oi; p = op; }
+}
+__device__ __forceinline__ void wave_argmax(double& key, int& idx, double& pay) {
+    argmax_step(key, idx, pay, dpp_f64<0xB1>(key), dpp_i32<0xB1>(idx), dpp_f64<0xB1>(pay));
+    argmax_step(key, idx, pay, dpp_f64<0x4E>(key), dpp_i32<0x4E>(idx), dpp_f64<0x4E>(pay));
+    argmax_step(key, idx, pay, dpp_f64<0x141>(key), dpp_i32<0x141>(idx), dpp_f64<0x141>(pay));
+    argmax_step(key, idx, pay, dpp_f64<0x140>(key), dpp_i32<0x140>(idx), dpp_f64<0x140>(pay));
+    double k = lane_f64(key, 0), p = lane_f64(pay, 0);
+    int i = __builtin_amdgcn_readlane(idx, 0);
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int row = 1; row < 4; row++)
+        argmax_step(k, i, p, lane_f64(key, 16 * row), __builtin_amdgcn_readlane(idx, 16 * row), lane_f64(pay, 16 * row));
+    key = k; idx = i; pay = p;
 }
 
 // zwork layout: [ XYtr M*P | XXtr M*M | XYte M*P | XXte M*M | YYte P ]
@@ -91,23 +126,20 @@ __global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {     // wave-uniform broadcast, no LDS crossbar
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
-    return u.d;
-}
 // trace of a matrix held as NB x NB blocks in the C/D layout: diagonal element 16 I + c sits in register c>>2 of
 // lane c + 16 (c & 3)
 template <int NB>
 __device__ __forceinline__ double trace_cd(const d4 (&D)[NB][NB]) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     double t = 0.0;
+    if ((c & 3) == q) {                  // this lane holds diagonal entries 16 I + c, in register c >> 2
 #pragma unroll
-    for (int I = 0; I < NB; I++)
-#pragma unroll
-        for (int c = 0; c < 16; c++) t += readlane_f64(D[I][I][c >> 2], c + 16 * (c & 3));
-    return t;
+        for (int I = 0; I < NB; I++) {
+            const double lo = (c & 4) ? D[I][I][1] : D[I][I][0], hi = (c & 4) ? D[I][I][3] : D[I][I][2];
+            t += (c & 8) ? hi : lo;
+        }
+    }
+    return wave_sum(t);
 }
 
 // Dominant-eigenvector helper: repeated squaring of B = S / trace(S) (S symmetric PSD, n <= 16*NB)
@@ -118,7 +150,8 @@ __device__ __forceinline__ double trace_cd(const d4 (&D)[NB][NB]) {
 // The error is squared every step once the spectral gap opens: "changed by < 1e-9", then one more.
 template <int NB>
 __device__ double eig_square(const double* __restrict__ XY, int M, int n, double* __restrict__ S,
-                             double* __restrict__ Bout) {
+                             double* __restrict__ Bout, double* __restrict__ grp_out = nullptr,
+                             const double* __restrict__ Sp = nullptr, int nparts = 0) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     // S = XY' XY straight into the C/D register layout with MFMA: block (I,J) = sum over 4-row slabs of
     // mfma(a_J, a_I), a_I(lane) = XY[4s + q][16 I + c]  (zero beyond M rows / n columns)
@@ -127,6 +160,16 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
     for (int I = 0; I < NB; I++)
 #pragma unroll
         for (int J = 0; J < NB; J++) D[I][J] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (NB == 1 && Sp) {
+        // the work-group's waves have each contracted their share of the slabs (k_pls_fit): block = sum of the partial blocks
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = 0.0;
+            for (int w = 0; w < nparts; w++) v += Sp[(4 * w + r) * 64 + lane];
+            D[0][0][r] = v;
+        }
+    } else
+#pragma unroll 4
     for (int m0 = 0; m0 < M; m0 += 4) {
         double a[NB];
 #pragma unroll
@@ -140,7 +183,7 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
             for (int J = 0; J < NB; J++) D[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], a[I], D[I][J], 0, 0, 0);
     }
     const double tr = trace_cd<NB>(D);
-    const double itr = (tr > 0.0) ? 1.0 / tr : 0.0;     // (the scale of B is immaterial: every group renormalises by its own trace)
+    const double itr = (tr > 0.0) ? __builtin_amdgcn_rcp(tr) : 0.0;     // (the scale of B is immaterial: every group renormalises by its own trace)
 #pragma unroll
     for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -155,7 +198,8 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
     // normalisation.  With eigenvalues lambda_i (sum 1), t = trace(B^8) = sum lambda_i^8.  t > 0.95 forces
     // lambda_1 > 0.9936, i.e. every other eigenvalue of the group's INPUT was < 6.4e-3 of it, so its OUTPUT has
     // them below (6.4e-3)^8 = 3e-18: converged to rounding, stop.
-    for (int grp = 0; grp < 24; grp++) {
+    int grp = 0;
+    for (; grp < 24; grp++) {
 #pragma unroll 1
         for (int sq = 0; sq < 3; sq++) {
             d4 T[NB][NB];
@@ -179,7 +223,7 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
                 for (int J = 0; J < NB; J++) D[I][J] = T[I][J];
         }
         const double t = trace_cd<NB>(D);
-        const double inv = 1.0 / t;
+        const double inv = __builtin_amdgcn_rcp(t);      // v_rcp_f64: the scale only keeps the entries in range
 #pragma unroll
         for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -188,6 +232,7 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
                 for (int r = 0; r < 4; r++) D[I][J][r] *= inv;
         if (t > 0.95) break;
     }
+    if (grp_out && lane == 0) *grp_out = (double)grp;
 #pragma unroll
     for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -316,7 +361,10 @@ __device__ __forceinline__ double pls_sum(double v, double* red) {
 // BASELINE configs[4]: 128 metrics, 32 components): the eigenvector work stays on wave 0 (register-resident MFMA), every
 // vector phase is spread over the work-group -- X'X r with each row's dot product split four ways, the r-update with one
 // wave per earlier component, the PRESS contractions one entry per thread.  LDS: XY (M*P), S and V (np*np each), vectors.
-template <int NW>
+// NBT: the register-resident eigen-squaring is compiled for 16 NBT x 16 NBT blocks (1: up to 16 responses, 2: up to 32); 0: 33..64
+// responses (4 x 4 blocks, an out-of-line call) or the memory-resident one beyond -- one kernel per case, so that the 16-response
+// kernel does not carry the registers of the 64-response one.
+template <int NW, bool GMEM, int NBT>
 __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ zwork, const double* __restrict__ obs,
                                                 int M, int P, int A, double* __restrict__ model,
                                                 double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds,
@@ -324,10 +372,11 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     extern __shared__ double lds_[];
     // wide sets (M P + 2 M A + ... beyond the 160 KB of LDS): the same arrays in global memory; every barrier is then preceded
     // by a work-group fence so the stores are visible to the other waves of the (single) work-group
-    double* const lds = gbase ? gbase : lds_;
-    const bool gmem = gbase != nullptr;
-#define PLS_SYNC() do { if (gmem) __threadfence_block(); __syncthreads(); } while (0)
-#define PLS_WSYNC() do { if (gmem) __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
+    // (a compile-time switch: with a run-time choice of base every access to the work arrays is a flat load -- the LDS through the
+    // flat aperture, each waited for with vmcnt(0) AND lgkmcnt(0))
+    double* const lds = GMEM ? gbase : lds_;
+#define PLS_SYNC() do { if constexpr (GMEM) __threadfence_block(); __syncthreads(); } while (0)
+#define PLS_WSYNC() do { if constexpr (GMEM) __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
 #ifdef PLS_STAMPS
     long long st_last = __builtin_readcyclecounter();
     double* st_out = scratch + (size_t)A * M + (size_t)A * A + (size_t)P * A;     // 16 doubles of diagnostics
@@ -357,6 +406,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     double* pwv = red + 8;              // A: projections of w on the earlier loadings (NW > 1)
     double* xp = pwv + A;               // 4*M: partial dot products of X'X r (NW > 1)
     double* Tg = xp + 4 * (size_t)M;    // np*np + np: third matrix of the memory-resident eigen-squaring (P > 64 only)
+    double* Sp = Tg + (P > 64 ? (size_t)np * np + np : 0);   // NW*256: the waves' partial XY'XY blocks (NW > 1, P <= 16)
 
     const double* XXtr = zwork + Z.off_XX[0];
     if (xx_in_lds) {
@@ -369,6 +419,18 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     double* Pm = model + ML.off_P;
 
     for (int e = lane; e < M * P; e += NT) XY[e] = zwork[Z.off_XY[0] + e];
+    // 65..128 metrics on eight waves: X'X (up to 128 KB, beside 64 KB of loadings: too much for the LDS) lives in REGISTERS, thread
+    // (row a, quarter part) keeping the <= 32 entries of its quarter row; X'X r is then 32 fma's on wave-uniform LDS reads of r
+    constexpr bool XXREG_OK = (NW == 8) && !GMEM;
+    const bool xx_in_reg = XXREG_OK && M <= 128;
+    double xxq[XXREG_OK ? 32 : 1];
+    if constexpr (XXREG_OK) {
+        if (xx_in_reg) {
+            const int qb = (M + 3) / 4, a = lane % M, part = lane / M, b0 = part * qb;
+#pragma unroll
+            for (int i = 0; i < 32; i++) xxq[i] = (part < 4 && i < qb && b0 + i < M) ? XXtr[a + (size_t)M * (b0 + i)] : 0.0;
+        }
+    }
     PLS_SYNC();
 
     STAMP(9);
@@ -382,25 +444,39 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             const int n = P;
             double* Bc = V;
             STAMP(1);
-            if (n > 64) {
+            if constexpr (NW > 1 && NBT == 1) {
+                // XY'XY: every wave contracts every NW-th slab of four rows on the matrix pipe (one wave: M/4 dependent MFMAs, the
+                // longest single item of a component at 128 metrics), wave 0 adds the partial blocks
+                const int l = lane & 63, c = l & 15, q = l >> 4;
+                d4 Dp = (d4){0.0, 0.0, 0.0, 0.0};
+                for (int m0 = 4 * wave; m0 < M; m0 += 4 * NW) {
+                    const int m = m0 + q;
+                    const double a = (m < M && c < n) ? XY[m + M * c] : 0.0;
+                    Dp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, Dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) Sp[(4 * wave + r) * 64 + l] = Dp[r];
+                PLS_SYNC();
+            }
+            if (NBT == 0 && n > 64) {
                 eig_generic<NT>(XY, M, n, S, Bc, Tg, qv, red);
             } else
             if (NW == 1 || wave == 0) {          // the whole eigenvector step is one wave's work (wave-uniform branch)
             double tr;
-            if (n <= 16) tr = eig_square<1>(XY, M, n, S, Bc);
-            else if (n <= 32) tr = eig_square<2>(XY, M, n, S, Bc);
-            else tr = eig_square<4>(XY, M, n, S, Bc);
+#ifdef PLS_STAMPS
+            double* const grp_out = st_out + 16 + (comp < 48 ? comp : 47);
+#else
+            double* const grp_out = nullptr;
+#endif
+            if constexpr (NBT == 1) tr = eig_square<1>(XY, M, n, S, Bc, grp_out, (NW > 1) ? Sp : nullptr, NW);
+            else if constexpr (NBT == 2) tr = eig_square<2>(XY, M, n, S, Bc, grp_out);
+            else tr = eig_square<4>(XY, M, n, S, Bc, grp_out);
             if constexpr (NW == 1) PLS_SYNC(); else PLS_WSYNC();
             STAMP(2);
             // column of the converged power with the largest diagonal entry (wave arg-max, ties -> lowest index)
-            double dg = (lane < n) ? Bc[lane + n * lane] : -1.0;
+            double dg = (lane < n) ? Bc[lane + n * lane] : -1.0, dpay = 0.0;
             int bi = lane;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const double od = __shfl_xor(dg, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (od > dg || (od == dg && oi < bi)) { dg = od; bi = oi; }
-            }
+            wave_argmax(dg, bi, dpay);
             const int best = bi;
             // one power step with S itself washes out the rounding of the squarings; then unit norm and
             // the sign convention (largest |component| positive; ties -> lowest index), all in registers
@@ -417,15 +493,9 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
                 if constexpr (NW == 1) PLS_SYNC(); else PLS_WSYNC();
             }
             const double nrm = sqrt(wave_sum(qi * qi));
-            double am = fabs(qi);
+            double am = fabs(qi), sv = qi;
             int ai = lane;
-            double sv = qi;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const double om = __shfl_xor(am, o, 64), os = __shfl_xor(sv, o, 64);
-                const int oi = __shfl_xor(ai, o, 64);
-                if (om > am || (om == am && oi < ai)) { am = om; ai = oi; sv = os; }
-            }
+            wave_argmax(am, ai, sv);
             const double sgn = (sv < 0.0) ? -1.0 : 1.0;
             if (lane < n) qv[lane] = sgn * qi / nrm;
             }
@@ -482,6 +552,20 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
             // four threads per row, a quarter of the columns each (four independent chains of M/4 instead of one of M; as a
             // one-column GEMM on the fp64 matrix pipe the same product was twice as slow: 32 dependent steps with L2 loads)
             const int qb = (M + 3) / 4;
+            bool done = false;
+            if constexpr (XXREG_OK) {
+                if (xx_in_reg) {
+                    if (lane < 4 * M) {
+                        const int b0 = (lane / M) * qb;
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 32; i++) { const int b = (b0 + i < M) ? b0 + i : M - 1; s = fma(xxq[i], rv[b], s); }
+                        xp[lane] = s;        // (entries past the quarter are zeros: same chain as the loop below)
+                    }
+                    done = true;
+                }
+            }
+            if (!done)
             for (int e = lane; e < 4 * M; e += NT) {
                 const int a = e % M, part = e / M;
                 const int b0 = part * qb, b1 = (b0 + qb < M) ? b0 + qb : M;
@@ -629,7 +713,7 @@ __global__ __launch_bounds__(64) void k_simple_obs(const double* __restrict__ ob
 }  // namespace
 
 #ifdef PLS_STAMPS
-static double g_pls_stamps[16];
+static double g_pls_stamps[64];
 #endif
 
 int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
@@ -638,14 +722,14 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
     double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
-    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A + 16) * sizeof(double));
+    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A + 64) * sizeof(double));
     if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
     hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
     const int xx_in_lds = M <= 64;
     const size_t lds_d = M * P + 2 * np * np + np + 4 * M + 2 * M * A + (xx_in_lds ? M * M : 0) + 8 + (8 + A + 4 * M) +
-                         (P > 64 ? np * np + np : 0);
+                         (P > 64 ? np * np + np : 0) + (P <= 16 ? 8 * 256 : 0);
     size_t lds_bytes = lds_d * sizeof(double);
     // beyond the LDS (about 500 metrics at 16 parameters and 8 components) the same work arrays live in global memory: the
     // reference has no size limit here (PLS::Model on Eigen matrices); slower, one work-group either way
@@ -657,22 +741,22 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     }
     // up to 16 metrics ONE wavefront (no work-group barriers at all), four up to 64 (measured: 0.119 -> 0.105 ms at M = 32,
     // P = 16, A = 8; 0.308 -> 0.262 ms at M = 64, P = 32), eight beyond
-    if (M > 16 && M <= 64) {
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_pls_fit<4>, dim3(1), dim3(256), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                           scratch, xx_in_lds, gbase);
-    } else if (M <= 64) {      // one wavefront
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_pls_fit<1>, dim3(1), dim3(64), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                           scratch, xx_in_lds, gbase);
-    } else {            // eight waves for the vector phases
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_pls_fit<8>, dim3(1), dim3(512), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model,
-                           scratch, xx_in_lds, gbase);
-    }
+#define PLS_LAUNCH(NW_, GM_, NB_) do { \
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit<NW_, GM_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((k_pls_fit<NW_, GM_, NB_>), dim3(1), dim3(64 * NW_), lds_bytes, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, \
+                           model, scratch, xx_in_lds, gbase); } while (0)
+#define PLS_LAUNCH_NB(NW_) do { if (P <= 16) PLS_LAUNCH(NW_, false, 1); else if (P <= 32) PLS_LAUNCH(NW_, false, 2); \
+                                else PLS_LAUNCH(NW_, false, 0); } while (0)
+    if (gbase) {                                    // wide sets: eight waves in every case
+        if (P <= 16) PLS_LAUNCH(8, true, 1); else PLS_LAUNCH(8, true, 0);
+    } else if (M > 64) PLS_LAUNCH_NB(8);            // eight waves for the vector phases
+    else if (M > 16) PLS_LAUNCH_NB(4);
+    else PLS_LAUNCH_NB(1);                          // one wavefront
+#undef PLS_LAUNCH_NB
+#undef PLS_LAUNCH
     ABC_HIP(ctx, hipGetLastError());
 #ifdef PLS_STAMPS
-    ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + P * A, 16 * sizeof(double), hipMemcpyDeviceToHost,
+    ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + P * A, 64 * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #endif
@@ -680,7 +764,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     return ABC_OK;
 }
 #ifdef PLS_STAMPS
-extern "C" void abc_debug_pls_stamps(double* out16) { for (int i = 0; i < 16; i++) out16[i] = g_pls_stamps[i]; }
+extern "C" void abc_debug_pls_stamps(double* out64) { for (int i = 0; i < 64; i++) out64[i] = g_pls_stamps[i]; }
 #endif
 
 int launch_simple_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, double* model) {

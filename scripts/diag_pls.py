@@ -7,7 +7,7 @@ from abcsmc_amd import _lib, device, synthetic, sharded
 dev = "cuda:0"
 ctx = _lib.default_context(0)
 be = sharded.HipBackend(dev, ctx)
-for (M, P, A) in [(32, 16, 1), (32, 16, 2), (32, 16, 4), (32, 16, 8), (32, 1, 8), (32, 4, 4), (64, 32, 8), (32, 16, 16)]:
+for (M, P, A) in [(32, 16, 1), (32, 16, 2), (32, 16, 4), (32, 16, 8), (32, 1, 8), (32, 4, 4), (64, 32, 8), (32, 16, 16), (128, 16, 32)]:
     wl = synthetic.Workload(M, P)
     X, Y = wl.rows(0, 20000)
     dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(wl.observed(), dev)

@@ -16,9 +16,10 @@ for (M, P, A) in [(32, 16, 8), (64, 32, 8), (128, 16, 32)]:
     stats = be.zeros(be.stats_len(M, P)); model = be.empty(be.model_len(M, P, A))
     be.stats_shift(dX, dY, stats); be.stats_accumulate(dX, dY, 0, 10000, stats)
     for _ in range(3): be.pls_model(stats, dobs, M, P, A, 0, model)
-    out = (C.c_double * 16)(); C.CDLL(_lib.SO_PATH).abc_debug_pls_stamps(out)
+    out = (C.c_double * 64)(); C.CDLL(_lib.SO_PATH).abc_debug_pls_stamps(out)
     names = {9: "prologue", 1: "S=XY'XY", 2: "eig squaring", 3: "eigvec post + w", 4: "normalise w, r-update", 5: "XX r, p",
              6: "q, deflate", 7: "(loop exit)", 8: "PRESS", 0: ""}
-    tot = sum(out)
+    tot = sum(out[:16])
     print("M=%d P=%d A=%d total %.0f kcycles" % (M, P, A, tot / 1e3), {names.get(i, i): round(out[i] / 1e3, 1) for i in range(10) if out[i]})
+    print("   squaring groups per component:", [int(out[16 + k] + 1) for k in range(min(A, 48))])
 PY
