@@ -47,7 +47,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     size_t b = 0;
     b += 2 * 384 * psz * 8 * 2;                                   // gram partials (PLS stats + covariance)
     b += 4 * (stats_layout(M, P).len + model_layout(M, P, A ? A : 1).len) * 8;
-    b += (2 * M * P + 2 * M * M + P + A * M + A * A + P * A + M * 40) * 8;
+    b += (2 * M * P + 2 * M * M + P + A * M + A * A + 2 * P * A + 64 + M * 40) * 8;
     b += (M * P + 3 * P * P + 2 * P + 8 * M + 2 * M * A + A + 64 + 2048) * 8 + 3 * 96 * 96 * 8 * 2;   // PLS work arrays beyond the LDS; group-pair records
     b += N * 8;                                                   // distances
     b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort

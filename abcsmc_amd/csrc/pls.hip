@@ -43,7 +43,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 // arg-max over the wave of (key, index) with ties -> lowest index; `pay` travels with the winner
 __device__ __forceinline__ void argmax_step(double& k, int& i, double& p, double ok, int oi, double op) {
-    if (ok > k || (ok == k && oi < i)) { k = ok; i = oi; p = op; }
+    const bool take = (ok > k) | ((ok == k) & (oi < i));
+    k = take ? ok : k; i = take ? oi : i; p = take ? op : p;
 }
 __device__ __forceinline__ void wave_argmax(double& key, int& idx, double& pay) {
     argmax_step(key, idx, pay, dpp_f64<0xB1>(key), dpp_i32<0xB1>(idx), dpp_f64<0xB1>(pay));
@@ -319,19 +320,31 @@ __device__ void eig_generic(const double* __restrict__ XY, int M, int n, double*
 // v_mfma_f64_16x16x4_f64 over Kd / 4 steps (A operand: lane (c, q) holds A[row c][k q]; B: B[k q][col c]; D: [q + 4 r][c]).
 // (One thread per output element walking Kd dependent fma's with L2 loads was 22 % of the fit at 32 components.)
 template <int NW>
-__device__ void pls_gemm(const double* __restrict__ pa, size_t sai, size_t sak, const double* __restrict__ pb, size_t sbk, size_t sbj,
-                         int I, int J, int Kd, double* __restrict__ Cm, size_t ldc) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+__device__ __forceinline__ void pls_gemm(const double* __restrict__ pa, size_t sai, size_t sak, const double* __restrict__ pb, size_t sbk,
+                                         size_t sbj, int I, int J, int Kd, double* __restrict__ Cm, size_t ldc, int wrot = 0) {
+    const int lane = threadIdx.x & 63, wave = ((threadIdx.x >> 6) + NW - wrot) % NW, c = lane & 15, q = lane >> 4;
     const int nbi = (I + 15) / 16, nbj = (J + 15) / 16;
     for (int b = wave; b < nbi * nbj; b += NW) {
         const int bi = b % nbi, bj = b / nbi;
         const int i = 16 * bi + c, j = 16 * bj + c;
+        const int ic = (i < I) ? i : I - 1, jc = (j < J) ? j : J - 1;       // in-range addresses, masked values
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < Kd; k0 += 4) {
-            const int k = k0 + q;
-            const double av = (i < I && k < Kd) ? pa[(size_t)i * sai + (size_t)k * sak] : 0.0;
-            const double bv = (j < J && k < Kd) ? pb[(size_t)k * sbk + (size_t)j * sbj] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        constexpr int U = 8;                       // k-steps whose operands are fetched together (the loads were waited for one by one)
+        for (int k0 = 0; k0 < Kd; k0 += 4 * U) {
+            double av[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = k0 + 4 * u + q, kc = (k < Kd) ? k : Kd - 1;
+                av[u] = pa[(size_t)ic * sai + (size_t)kc * sak];
+                bv[u] = pb[(size_t)kc * sbk + (size_t)jc * sbj];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = k0 + 4 * u + q;
+                if (k0 + 4 * u < Kd)               // (wave-uniform)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((i < I && k < Kd) ? av[u] : 0.0, (j < J && k < Kd) ? bv[u] : 0.0, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
 #define PLS_WSYNC() do { if constexpr (GMEM) __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
 #ifdef PLS_STAMPS
     long long st_last = __builtin_readcyclecounter();
-    double* st_out = scratch + (size_t)A * M + (size_t)A * A + (size_t)P * A;     // 16 doubles of diagnostics
+    double* st_out = scratch + (size_t)A * M + (size_t)A * A + 2 * (size_t)P * A;     // 16 doubles of diagnostics
     if (threadIdx.x < 16) st_out[threadIdx.x] = 0.0;
 #define STAMP(id) do { const long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) st_out[id] += (double)(now_ - st_last); st_last = now_; } while (0)
 #else
@@ -700,6 +713,374 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
     }
 }
 
+
+// s + sum_{i < cnt} a[i sa] b[i sb] as ONE fma chain in index order, the operands of U steps loaded ahead of their arithmetic.
+// (Left to itself hipcc emits load, s_waitcnt lgkmcnt(0), fma per element: an LDS round trip of ~120 cycles on every step of
+// chains that are 16 to 32 steps long -- most of what a component cost.)
+template <int U>
+__device__ __forceinline__ double dot_ahead(const double* __restrict__ a, int sa, const double* __restrict__ b, int sb, int cnt,
+                                            double s) {
+    int i = 0;
+    for (; i + U <= cnt; i += U) {
+        double av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { av[u] = a[(size_t)(i + u) * sa]; bv[u] = b[(size_t)(i + u) * sb]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) s = fma(av[u], bv[u], s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (U > 1) {                  // the rest in batches of U/2, U/4, ... (no masked lanes, no wasted loads)
+        if (i < cnt) s = dot_ahead<U / 2>(a + (size_t)i * sa, sa, b + (size_t)i * sb, sb, cnt - i, s);
+    }
+    return s;
+}
+
+// ---- up to 16 responses, more than one wave: the latency-tuned fit --------------------------------------------------------
+// Same algorithm and the same formulas as k_pls_fit; what differs is who does what between barriers, because a component is a
+// chain of short dependent phases and a work-group barrier per phase was a third of its time (15 per component there, 5 here):
+//   (1) every wave finishes the PREVIOUS component for the slabs of four rows it owns -- tt = r'X'X r and q recomputed by every
+//       wave from the partial sums (no cross-wave reduction), XY deflated in place -- and contracts those slabs into its partial
+//       XY'XY on the matrix pipe in the same pass;
+//   (2) wave 0: dominant eigenvector (eig_square's scheme; the closing power step with S is one more MFMA product, row `best` of
+//       B S, so nothing leaves the registers), then w = XY q;
+//   (3) every wave: |w| (itself), the projections p_j'w of its share of the earlier components;
+//   (4) r = w - sum_j (p_j'w) r_j, one row per thread;
+//   (5) partial sums of X'X r (four threads per row) and of XY'r (eight per response).
+// LDS: XY, the loadings and rotations, the partial blocks; X'X in LDS up to 64 metrics, in registers up to 128 on eight waves.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* __restrict__ zwork, const double* __restrict__ obs,
+                                                      int M, int P, int A, double* __restrict__ model,
+                                                      double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds) {
+    extern __shared__ double lds_[];
+    const ModelLayout ML = model_layout(M, P, A);
+    const ZLayout Z = z_layout(M, P);
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, c = l & 15, q4 = l >> 4;
+    const int n = P;
+    // XY column-major with the leading dimension padded to 2 (mod 4): the slab pass reads / writes four consecutive rows of all 16
+    // columns with one instruction, 16-way bank-conflicted at a leading dimension of 32 or 128 doubles, conflict-free at 34 / 130
+    const int LX = M + ((6 - (M & 3)) & 3);
+    double* XY = lds_;                        // LX*P
+    double* qv = XY + (size_t)LX * P;         // 16
+    double* wv = qv + 16;                     // M: w before normalisation
+    double* wn = wv + M;                      // M: w / |w|
+    double* rv = wn + M;                      // M + 4 (zero tail: the quarter rows of step (5) may read up to 4 ceil(M/4) entries)
+    double* xp = rv + M + 4;                  // 4*M: partial sums of X'X r
+    double* qp = xp + 4 * (size_t)M;          // 8*16: partial sums of XY'r
+    double* pwv = qp + 128;                   // A: p_j'w
+    double* Pl = pwv + A;                     // M*A
+    double* Rl = Pl + (size_t)M * A;          // M*A
+    double* Sp = Rl + (size_t)M * A;          // NW*256: partial XY'XY blocks, [wave][reg][lane]
+    double* XXl = Sp + NW * 256;              // M*M (xx_in_lds)
+    double* Hl = XXl + (xx_in_lds ? (size_t)M * M : 0);   // A*A   } PRESS statistics (vk = XXte R overlays Pl, which is dead by then)
+    double* cml = Hl + (size_t)A * A;         // P*A   }
+    double* addl = cml + (size_t)P * A;       // P*A   }
+    double* Ql = addl + (size_t)P * A;        // P*A: Q (LDS copy)
+    const double* XXtr = zwork + Z.off_XX[0];
+    if (xx_in_lds)
+        for (int e = tid; e < M * M; e += NT) XXl[e] = XXtr[e];
+    double* Rm = model + ML.off_R;
+    double* Qm = model + ML.off_Q;
+    double* Wm = model + ML.off_W;
+    double* Pm = model + ML.off_P;
+    for (int e = tid; e < M * P; e += NT) XY[e % M + LX * (e / M)] = zwork[Z.off_XY[0] + e];
+    if (tid < 4) rv[M + tid] = 0.0;
+    constexpr bool XXREG_OK = (NW == 8);
+    const bool xx_in_reg = XXREG_OK && !xx_in_lds && M <= 128;
+    const int qb = (M + 3) / 4, qb8 = (M + 7) / 8;
+    double xxq[XXREG_OK ? 32 : 1];
+    if constexpr (XXREG_OK) {
+        if (xx_in_reg) {
+            const int a = tid % M, part = tid / M, b0 = part * qb;
+#pragma unroll
+            for (int i = 0; i < 32; i++) xxq[i] = (part < 4 && i < qb && b0 + i < M) ? XXtr[a + (size_t)M * (b0 + i)] : 0.0;
+        }
+    }
+    __syncthreads();
+#ifdef PLS_STAMPS
+    long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#define STAMP16(id) do { const long long now_ = __builtin_readcyclecounter(); st_acc[id] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define STAMP16(id)
+#endif
+
+    for (int comp = 0; comp <= A; comp++) {
+        // ---- (1) close component comp - 1 (tt, p, q, stores, deflation) and contract the slabs into the partial S -------------
+        double tt = 0.0, itt = 0.0, qc = 0.0;
+        if (comp > 0) {
+            const int k = comp - 1;
+            double t = 0.0;
+            for (int a = l; a < M; a += 64) {
+                const double xr = (xp[a] + xp[M + a]) + (xp[2 * M + a] + xp[3 * M + a]);
+                t = fma(rv[a], xr, t);
+            }
+            tt = wave_sum(t);
+            STAMP16(8);
+            itt = 1.0 / tt;
+            STAMP16(9);
+            if (c < n) {
+                double qs = 0.0;
+#pragma unroll
+                for (int part = 0; part < 8; part++) qs += qp[part * P + c];
+                qc = qs * itt;
+            }
+            if (tid < n) { Qm[tid + (size_t)P * k] = qc; Ql[tid + (size_t)P * k] = qc; }
+            for (int m = tid; m < M; m += NT) {
+                const double xr = (xp[m] + xp[M + m]) + (xp[2 * M + m] + xp[3 * M + m]);
+                const double pm = xr * itt, rm = rv[m];
+                Pl[m + (size_t)M * k] = pm;
+                Rl[m + (size_t)M * k] = rm;
+                Pm[m + (size_t)M * k] = pm;
+                Rm[m + (size_t)M * k] = rm;
+                Wm[m + (size_t)M * k] = wn[m];
+            }
+            if (comp == A) break;
+        }
+        STAMP16(10);
+        {
+            d4 Dp = (d4){0.0, 0.0, 0.0, 0.0};
+            constexpr int SB = 2;                                  // slabs whose operands are fetched together
+            const int cc = (c < n) ? c : 0;
+            for (int base = 4 * wave; base < M; base += 4 * NW * SB) {
+                double av[SB], xr[SB];
+#pragma unroll
+                for (int sI = 0; sI < SB; sI++) {
+                    const int m = base + 4 * NW * sI + q4, mm = (m < M) ? m : 0;
+                    av[sI] = XY[mm + LX * cc];
+                    xr[sI] = (comp > 0) ? (xp[mm] + xp[M + mm]) + (xp[2 * M + mm] + xp[3 * M + mm]) : 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sI = 0; sI < SB; sI++) {
+                    const int m0 = base + 4 * NW * sI, m = m0 + q4;
+                    if (m0 < M) {                                  // (wave-uniform)
+                        const bool ok = m < M && c < n;
+                        double a = ok ? av[sI] : 0.0;
+                        if (comp > 0 && ok) {
+                            a -= tt * ((xr[sI] * itt) * qc);
+                            XY[m + LX * c] = a;
+                        }
+                        Dp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, Dp, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) Sp[(4 * wave + r) * 64 + l] = Dp[r];
+        }
+        STAMP16(11);
+        __syncthreads();
+        STAMP16(1);
+        // ---- (2) wave 0: dominant eigenvector of S = XY'XY, then w = XY q ----------------------------------------------------
+        if (wave == 0) {
+            d4 Sr, D;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) v += Sp[(4 * w + r) * 64 + l];
+                Sr[r] = v;
+            }
+            const bool on_diag = (c & 3) == q4;                   // diagonal entry c sits in register c >> 2 of lane c + 16 (c & 3)
+            auto diag_of = [&](const d4& X) {
+                const double lo = (c & 4) ? X[1] : X[0], hi = (c & 4) ? X[3] : X[2];
+                return (c & 8) ? hi : lo;
+            };
+            const double tr = wave_sum(on_diag ? diag_of(Sr) : 0.0);
+            const double itr = (tr > 0.0) ? __builtin_amdgcn_rcp(tr) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) D[r] = (tr > 0.0) ? Sr[r] * itr : ((l == 0 && r == 0) ? 1.0 : 0.0);
+            STAMP16(12);
+            // groups of three squarings, trace normalisation, stop at trace(B^8) > 0.95 (see eig_square)
+            for (int grp = 0; grp < 24; grp++) {
+#pragma unroll 1
+                for (int sq = 0; sq < 3; sq++) {
+                    // (one accumulator: back-to-back dependent MFMAs forward it; two chains cost four adds and a wait per squaring)
+                    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[1], D[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[2], D[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[3], D[3], acc, 0, 0, 0);
+                    D = acc;
+                }
+                const double t = wave_sum(on_diag ? diag_of(D) : 0.0);
+                const double inv = __builtin_amdgcn_rcp(t);
+#pragma unroll
+                for (int r = 0; r < 4; r++) D[r] *= inv;
+                if (t > 0.95) break;
+            }
+            STAMP16(13);
+            // column of the converged power with the largest diagonal entry (ties -> lowest index) ...
+            double dg = (on_diag && c < n) ? diag_of(D) : -1.0, dpay = 0.0;
+            int best = c;
+            wave_argmax(dg, best, dpay);
+            // ... and one power step with S itself: (S B)[:, best] = row `best` of B S, which the MFMA leaves in register
+            // best >> 2 of the lanes (c, best & 3) -- entry c in lane c of that row of lanes
+            // (with the trace-1 copy of S, so that the entries stay of order one: q is NOT brought to unit length -- only its
+            // direction and sign enter w = XY q, which is normalised in (3) -- that saves a reduction, a square root and a division)
+            d4 T = D;
+            if (tr > 0.0) {
+                d4 t0 = (d4){0.0, 0.0, 0.0, 0.0};
+                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], Sr[0] * itr, t0, 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[1], Sr[1] * itr, t0, 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[2], Sr[2] * itr, t0, 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[3], Sr[3] * itr, t0, 0, 0, 0);
+                T = t0;
+            }
+            const int br = best >> 2;                              // wave-uniform
+            const double yv = (br == 0) ? T[0] : (br == 1) ? T[1] : (br == 2) ? T[2] : T[3];
+            const bool mine = (q4 == (best & 3)) && c < n;
+            const double qi = mine ? yv : 0.0;
+            double am = mine ? fabs(qi) : -1.0, sv = qi;
+            int ai = c;
+            wave_argmax(am, ai, sv);                               // largest |component| positive (ties -> lowest index)
+            if (mine) qv[c] = (sv < 0.0) ? -qi : qi;
+            STAMP16(14);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int m = l; m < M; m += 64) wv[m] = dot_ahead<16>(XY + m, LX, qv, 1, P, 0.0);
+        }
+        STAMP16(2);
+        __syncthreads();
+        // ---- (3) |w| by every wave; projections on the earlier loadings, one wave per earlier component --------------------------
+        double iww;
+        {
+            double ss = 0.0;
+            for (int m = l; m < M; m += 64) ss = fma(wv[m], wv[m], ss);
+            iww = 1.0 / sqrt(wave_sum(ss));
+        }
+        for (int m = tid; m < M; m += NT) wn[m] = wv[m] * iww;
+        for (int j = wave; j < comp; j += NW) {
+            double pw = 0.0;
+            for (int m = l; m < M; m += 64) pw = fma(Pl[m + (size_t)M * j], wv[m], pw);
+            pw = wave_sum(pw) * iww;
+            if (l == 0) pwv[j] = pw;
+        }
+        __syncthreads();
+        STAMP16(3);
+        // ---- (4) r = w - sum_j (p_j'w) r_j --------------------------------------------------------------------------------------
+        for (int m = tid; m < M; m += NT) rv[m] = wn[m] - dot_ahead<16>(pwv, 1, Rl + m, M, comp, 0.0);
+        __syncthreads();
+        STAMP16(4);
+        // ---- (5) partial sums of X'X r (four threads per row) and of XY'r (eight per response, the last threads) ---------------
+        {
+            if (xx_in_reg) {
+                if constexpr (XXREG_OK) {
+                    if (tid < 4 * M) {
+                        const double* rb = rv + (tid / M) * qb;              // (rv is padded with zeros up to 4 qb entries)
+                        double rr[32];
+#pragma unroll
+                        for (int i = 0; i < 32; i++) rr[i] = rb[(i < qb) ? i : 0];
+                        __builtin_amdgcn_sched_barrier(0);
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 32; i++) s = fma(xxq[i], rr[i], s);  // (entries past the quarter are zeros)
+                        xp[tid] = s;
+                    }
+                }
+            } else if (xx_in_lds) {
+                for (int e = tid; e < 4 * M; e += NT) {
+                    const int a = e % M, part = e / M;
+                    const int b0 = part * qb, b1 = (b0 + qb < M) ? b0 + qb : M;
+                    xp[e] = dot_ahead<16>(XXl + a + (size_t)M * b0, M, rv + b0, 1, b1 - b0, 0.0);
+                }
+            } else {
+                const double* XXg = zwork + Z.off_XX[0];
+                for (int e = tid; e < 4 * M; e += NT) {
+                    const int a = e % M, part = e / M;
+                    const int b0 = part * qb, b1 = (b0 + qb < M) ? b0 + qb : M;
+                    xp[e] = dot_ahead<16>(XXg + a + (size_t)M * b0, M, rv + b0, 1, b1 - b0, 0.0);
+                }
+            }
+            const int e = NT - 1 - tid;
+            if (e < 8 * P) {
+                const int j = e % P, part = e / P;
+                const int m0 = part * qb8, m1 = (m0 + qb8 < M) ? m0 + qb8 : M;
+                qp[e] = dot_ahead<16>(XY + m0 + LX * j, 1, rv + m0, 1, m1 - m0, 0.0);
+            }
+        }
+        __syncthreads();
+        STAMP16(5);
+    }
+    __syncthreads();
+    STAMP16(6);
+
+    // ---- PRESS on the validation statistics (as in k_pls_fit; the inner sums of the quadratic form one (response, component)
+    // pair per thread, every chain with its operands fetched ahead) ------------------------------------------------------------
+    const double* XYte = zwork + Z.off_XY[1];
+    const double* XXte = zwork + Z.off_XX[1];
+    const double* YYte = zwork + Z.off_YY;
+    double* vk = Pl;                    // A*M (LDS: every operand of the phase but the validation statistics themselves is)
+    double* H = Hl;
+    double* cm = cml;
+    double* addm = addl;                // P*A: sum_{l < a} q_jl H_al
+    if (A * M >= 1024) {
+        pls_gemm<NW>(XXte, 1, (size_t)M, Rl, 1, (size_t)M, M, A, M, vk, (size_t)M);            // vk = XXte R        (M x A)
+        __syncthreads();
+        pls_gemm<NW>(Rl, (size_t)M, 1, vk, 1, (size_t)M, A, A, M, H, (size_t)A);                 // H = R' vk          (A x A)
+        pls_gemm<NW>(XYte, (size_t)M, 1, Rl, 1, (size_t)M, P, A, M, cm, (size_t)P, NW / 2);      // c = XYte' R        (P x A)
+    } else {
+        for (int e = tid; e < A * M; e += NT) {
+            const int m = e % M, k = e / M;
+            vk[e] = dot_ahead<16>(XXte + m, M, Rl + (size_t)M * k, 1, M, 0.0);
+        }
+        __syncthreads();
+        for (int e = tid; e < A * A + P * A; e += NT) {
+            if (e < A * A) {
+                const int k = e % A, l2 = e / A;
+                H[e] = dot_ahead<16>(Rl + (size_t)M * k, 1, vk + (size_t)M * l2, 1, M, 0.0);
+            } else {
+                const int e2 = e - A * A, j = e2 % P, k = e2 / P;
+                cm[e2] = dot_ahead<16>(Rl + (size_t)M * k, 1, XYte + (size_t)M * j, 1, M, 0.0);
+            }
+        }
+    }
+    for (int m = tid; m < M; m += NT) {          // observed z-scores (kept in LDS for the scores below)
+        const double sdv = model[ML.off_sd + m];
+        const double z = (sdv == 0.0) ? 0.0 : (obs[m] - model[ML.off_mean + m]) / sdv;
+        model[ML.off_zobs + m] = z;
+        wv[m] = z;
+    }
+    __syncthreads();
+    for (int e = tid; e < P * A; e += NT) {
+        const int j = e % P, a = e / P;
+        addm[e] = dot_ahead<16>(Ql + j, P, H + a, A, a, 0.0);
+    }
+    for (int k = tid; k < A; k += NT) model[ML.off_oscore + k] = dot_ahead<16>(wv, 1, Rl + (size_t)M * k, 1, M, 0.0);
+    __syncthreads();
+    double* press = model + ML.off_press;   // A x P, column-major
+    double* perl = qp;                      // P: per-response component counts
+    for (int j = tid; j < P; j += NT) {
+        double lin = 0.0, quad = 0.0;
+        double best = 0.0; int besta = 0;
+        const double yy = YYte[j];
+        for (int a = 0; a < A; a++) {
+            const double qa = Ql[j + (size_t)P * a];
+            lin = fma(qa, cm[j + (size_t)P * a], lin);
+            quad += 2.0 * qa * addm[j + (size_t)P * a] + qa * qa * H[a + (size_t)A * a];
+            const double pr = yy - 2.0 * lin + quad;
+            press[a + (size_t)A * j] = pr;
+            if (a == 0 || pr < best) { best = pr; besta = a; }
+        }
+        model[ML.off_per + j] = (double)(besta + 1);
+        perl[j] = (double)(besta + 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ncomp = 1;
+        for (int j = 0; j < P; j++) { const int v = (int)perl[j]; if (v > ncomp) ncomp = v; }
+        model[ML.off_hdr] = (double)ncomp;
+    }
+#ifdef PLS_STAMPS
+    STAMP16(7);
+    if (tid == 0) {
+        double* st_out = scratch + (size_t)A * M + (size_t)A * A + 2 * (size_t)P * A;
+        for (int i = 0; i < 16; i++) st_out[i] = (double)st_acc[i];
+    }
+#endif
+}
+
 __global__ __launch_bounds__(64) void k_simple_obs(const double* __restrict__ obs, int M, int P,
                                                    double* __restrict__ model) {
     const ModelLayout ML = model_layout(M, P, 0);
@@ -722,7 +1103,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
     double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
-    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + P * A + 64) * sizeof(double));
+    double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + 2 * P * A + 64) * sizeof(double));
     if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
     hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
     ABC_HIP(ctx, hipGetLastError());
@@ -747,6 +1128,18 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
                            model, scratch, xx_in_lds, gbase); } while (0)
 #define PLS_LAUNCH_NB(NW_) do { if (P <= 16) PLS_LAUNCH(NW_, false, 1); else if (P <= 32) PLS_LAUNCH(NW_, false, 2); \
                                 else PLS_LAUNCH(NW_, false, 0); } while (0)
+    // 2..16 responses on more than one wave: the latency-tuned kernel, when its arrays fit the LDS
+    const size_t lds16_d = (M + 3) * P + 16 + 3 * M + 4 + 4 * M + 128 + A + 2 * M * A + (M > 64 ? 8 : 4) * 256 + (xx_in_lds ? M * M : 0) + A * A + 3 * P * A;
+    if (P >= 2 && P <= 16 && M > 16 && lds16_d * sizeof(double) <= 160 * 1024) {
+        const int lb = (int)(lds16_d * sizeof(double));
+        if (M > 64) {
+            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            hipLaunchKernelGGL(k_pls_fit16<8>, dim3(1), dim3(512), lb, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds);
+        } else {
+            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            hipLaunchKernelGGL(k_pls_fit16<4>, dim3(1), dim3(256), lb, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds);
+        }
+    } else
     if (gbase) {                                    // wide sets: eight waves in every case
         if (P <= 16) PLS_LAUNCH(8, true, 1); else PLS_LAUNCH(8, true, 0);
     } else if (M > 64) PLS_LAUNCH_NB(8);            // eight waves for the vector phases
@@ -756,7 +1149,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
 #undef PLS_LAUNCH
     ABC_HIP(ctx, hipGetLastError());
 #ifdef PLS_STAMPS
-    ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + P * A, 64 * sizeof(double), hipMemcpyDeviceToHost,
+    ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + 2 * P * A, 64 * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #endif
