@@ -84,6 +84,39 @@ __global__ __launch_bounds__(256) void k_project_dist(const double* __restrict__
     }
 }
 
+// More than 32 components (the reference has no limit): the components in chunks of 32, the particle's metrics re-read and
+// re-scored per chunk (same z, same fma order per component), the squared distance carried across the chunks in component order --
+// the operation order of k_project_dist, so the same bits.  KCT = 32 ceil(A / 32) padded components.
+__global__ __launch_bounds__(256) void k_project_dist_wide(const double* __restrict__ X, size_t n, size_t ldx, int M, int KCT,
+                                                           const double* __restrict__ mean, const double* __restrict__ sd,
+                                                           const double* __restrict__ Rpad /* M x KCT, row-major */,
+                                                           const double* __restrict__ opad /* KCT */, double* __restrict__ dist) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double* xp = X + i;
+        double d2 = 0.0;
+        for (int c0 = 0; c0 < KCT; c0 += 32) {
+            double s[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) s[k] = 0.0;
+#pragma unroll 2
+            for (int m = 0; m < M; m++) {
+                const double x = xp[(size_t)m * ldx];
+                const double sdm = sd[m];
+                const double z = (sdm == 0.0) ? 0.0 : (x - mean[m]) / sdm;
+#pragma unroll
+                for (int k = 0; k < 32; k++) s[k] = fma(z, Rpad[(size_t)m * KCT + c0 + k], s[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const double t = s[k] - opad[c0 + k];
+                d2 = fma(t, t, d2);
+            }
+        }
+        dist[i] = sqrt(d2);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_simple_dist(const double* __restrict__ X, size_t n, size_t ldx, int M,
                                                      const double* __restrict__ mean,
                                                      const double* __restrict__ sd,
@@ -137,12 +170,18 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     // unused components are zero-padded (exact, see k_pad_model).
     int KC = 1;
     while (KC < (int)A) KC *= 2;
-    if (KC > 32) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "project: A = %zu > 32 components", A);
+    if (KC > 32) KC = (int)((A + 31) / 32) * 32;
     double* Rpad = (double*)abc_ws_alloc(ctx, (M * KC + KC) * sizeof(double));
     if (!Rpad) ABC_FAIL(ctx, ABC_ERR_NOMEM, "project: workspace exhausted");
     double* opad = Rpad + M * KC;
     hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
     ABC_HIP(ctx, hipGetLastError());
+    if (KC > 32) {
+        hipLaunchKernelGGL(k_project_dist_wide, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n, ldx, (int)M, KC,
+                           model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist);
+        ABC_HIP(ctx, hipGetLastError());
+        return ABC_OK;
+    }
     // fast path: row pairs with 16-B loads/stores; the odd last row (if any) goes through the scalar kernel
     const bool vec_ok = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)dist & 15) == 0) && n >= 2;
     const size_t npairs = vec_ok ? n / 2 : 0;

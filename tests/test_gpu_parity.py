@@ -61,6 +61,12 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (1200, 600, 16, 8, 0.5),     # 616 columns: the PLS work arrays live in global memory (> 160 KB), 13 column groups
     (1500, 90, 70, 5, 0.5),      # 70 responses: the memory-resident eigen-squaring (the register-resident one stops at 64)
     (800, 40, 100, 3, 0.6),      # more responses than metrics
+    (2000, 17, 2, 3, 0.5),       # smallest set on the four-wave latency-tuned fit (k_pls_fit16), two responses
+    (2500, 64, 16, 16, 0.5),     # k_pls_fit16, X'X in LDS at its largest, as many components as responses
+    (1800, 65, 13, 7, 0.5),      # k_pls_fit16 on eight waves, X'X in registers with ragged quarter rows (qb = 17)
+    (1500, 127, 16, 12, 0.45),   # ... odd leading dimension just below the register limit
+    (1500, 129, 5, 9, 0.5),      # ... just above it: X'X read from global memory
+    (700, 40, 16, 40, 0.5),      # as many components as metrics (XY exhausted after 16: the rest are rounding-level directions)
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
@@ -1089,13 +1095,14 @@ def test_error_codes_and_messages(gpu_ctx):
     rc = L.abc_particle_ranking_pls(h, X.ctypes.data, Y.ctypes.data, X[0].copy().ctypes.data, 50, 4, 2, 0.5, 0, 7, 10,
                                     idx.ctypes.data, None, None, None, None, None)
     assert rc == -1 and b"rule" in L.abc_last_error(h)
-    # more than 32 PLS components -> ABC_ERR_UNSUPPORTED (-4), not a crash
+    # the Wilcoxon component rule with more than 32 components -> ABC_ERR_UNSUPPORTED (-4), not a crash (the default
+    # minimum-PRESS rule takes any number: test_particle_ranking_pls at 40)
     X70 = np.asfortranarray(np.random.default_rng(2).normal(size=(200, 80)))
     Y70 = np.asfortranarray(np.random.default_rng(3).normal(size=(200, 40)))
     idx70 = np.zeros(10, dtype=np.uint64)
-    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 80, 40, 0.5, 40, 0, 10,
-                                    idx70.ctypes.data, None, None, None, None, None)
-    assert rc == -4 and b"components" in L.abc_last_error(h)
+    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 80, 40, 0.5, 40,
+                                    _lib.RULE_WILCOXON, 10, idx70.ctypes.data, None, None, None, None, None)
+    assert rc == -4 and b"wilcoxon" in L.abc_last_error(h)
     th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 70)))
     # a later valid call on the same context still works
     assert abcutil.calculate_doubled_variance(th[:, :3], ctx=gpu_ctx).shape == (3,)
