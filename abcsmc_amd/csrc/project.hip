@@ -53,6 +53,92 @@ __global__ __launch_bounds__(256) void k_project_dist2(const double* __restrict_
     }
 }
 
+// 16 / 32 components: the scalar-register operands of k_project_dist2 no longer fit (32 components x 8 metrics in flight = 256
+// SGPR pairs: hipcc spilled 488 of them to VGPR lanes and the kernel ran at a sixth of its memory time); here the padded loadings
+// live in LDS (M x KC doubles, every work-group copies them once) and are read with wave-uniform 16-byte reads (broadcast), the
+// metric columns of a row pair are fetched PF metrics ahead.  Same per-particle operation order as k_project_dist -> same bits.
+template <int KC>
+__global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restrict__ X, size_t npairs, size_t ldx, int M,
+                                                           const double* __restrict__ mean, const double* __restrict__ sd,
+                                                           const double* __restrict__ Rpad, const double* __restrict__ opad,
+                                                           double* __restrict__ dist) {
+    extern __shared__ double Rl[];                                       // M*KC
+    for (int e = threadIdx.x; e < M * KC; e += 256) Rl[e] = Rpad[e];
+    __syncthreads();
+    constexpr int PF = 4, H = KC / 4;                                    // H: 16-byte reads per half row of loadings
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
+        double s0[KC], s1[KC];
+#pragma unroll
+        for (int k = 0; k < KC; k++) { s0[k] = 0.0; s1[k] = 0.0; }
+        const double* xp = X + 2 * i;
+        // software pipeline, written out because hipcc would not build it: the metric columns two chunks of PF ahead in two
+        // register sets (xa / xb), the loadings of a metric in two halves (ra / rb), each half fetched while the other is used
+        d2 xa[PF], xb[PF], ra[H], rb[H];
+        auto load_x = [&](d2 (&xq)[PF], int m0) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int m = (m0 + u < M) ? m0 + u : M - 1;             // in-range address; unused beyond M
+                xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xp + (size_t)m * ldx));
+            }
+        };
+        auto load_r = [&](d2 (&rq)[H], int m, int half) {
+            const d2* rr = reinterpret_cast<const d2*>(Rl + (size_t)((m < M) ? m : M - 1) * KC) + half * H;
+#pragma unroll
+            for (int h = 0; h < H; h++) rq[h] = rr[h];
+        };
+        auto chunk = [&](const d2 (&xq)[PF], int m0) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int m = m0 + u;
+                if (m < M) {                                             // (uniform)
+                    const double sdm = sd[m], mu = mean[m];
+                    const double z0 = (sdm == 0.0) ? 0.0 : (xq[u].x - mu) / sdm;
+                    const double z1 = (sdm == 0.0) ? 0.0 : (xq[u].y - mu) / sdm;
+                    load_r(rb, m, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        s0[2 * h] = fma(z0, ra[h].x, s0[2 * h]);
+                        s1[2 * h] = fma(z1, ra[h].x, s1[2 * h]);
+                        s0[2 * h + 1] = fma(z0, ra[h].y, s0[2 * h + 1]);
+                        s1[2 * h + 1] = fma(z1, ra[h].y, s1[2 * h + 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_r(ra, m + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        s0[2 * H + 2 * h] = fma(z0, rb[h].x, s0[2 * H + 2 * h]);
+                        s1[2 * H + 2 * h] = fma(z1, rb[h].x, s1[2 * H + 2 * h]);
+                        s0[2 * H + 2 * h + 1] = fma(z0, rb[h].y, s0[2 * H + 2 * h + 1]);
+                        s1[2 * H + 2 * h + 1] = fma(z1, rb[h].y, s1[2 * H + 2 * h + 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        load_x(xa, 0);
+        load_r(ra, 0, 0);
+        for (int m0 = 0; m0 < M; m0 += 2 * PF) {
+            load_x(xb, m0 + PF);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(xa, m0);
+            load_x(xa, m0 + 2 * PF);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(xb, m0 + PF);
+        }
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const double t0 = s0[k] - opad[k], t1 = s1[k] - opad[k];
+            d0 = fma(t0, t0, d0);
+            d1 = fma(t1, t1, d1);
+        }
+        *reinterpret_cast<d2*>(dist + 2 * i) = (d2){sqrt(d0), sqrt(d1)};
+    }
+}
+
 template <int KC>
 __global__ __launch_bounds__(256) void k_project_dist(const double* __restrict__ X, size_t n, size_t ldx, int M,
                                                       const double* __restrict__ mean,
@@ -190,6 +276,20 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     if (pblocks > 256 * 16) pblocks = 256 * 16;
     blocks = (ntail + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    // (16 / 32 components with the loadings in LDS; beyond 64 KB of them the scalar-operand kernel)
+#define LAUNCH_PD_LDS(KCV)                                                                                             \
+    do {                                                                                                               \
+        const int lb = (int)(M * KCV * sizeof(double));                                                                \
+        if (npairs) {                                                                                                  \
+            if (pblocks > 1024) pblocks = 1024;                                                                        \
+            hipLaunchKernelGGL(k_project_dist2_lds<KCV>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X,       \
+                               npairs, ldx, (int)M, model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist);        \
+        }                                                                                                              \
+        if (ntail)                                                                                                     \
+            hipLaunchKernelGGL(k_project_dist<KCV>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,                 \
+                               X + 2 * npairs, ntail, ldx, (int)M, model + ML.off_mean, model + ML.off_sd, Rpad, opad, \
+                               dist + 2 * npairs);                                                                     \
+    } while (0)
 #define LAUNCH_PD(KCV)                                                                                                 \
     do {                                                                                                               \
         if (npairs)                                                                                                    \
@@ -205,10 +305,11 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
         case 2: LAUNCH_PD(2); break;
         case 4: LAUNCH_PD(4); break;
         case 8: LAUNCH_PD(8); break;
-        case 16: LAUNCH_PD(16); break;
-        default: LAUNCH_PD(32); break;
+        case 16: if (M * 16 * 8 <= 64 * 1024) LAUNCH_PD_LDS(16); else LAUNCH_PD(16); break;
+        default: if (M * 32 * 8 <= 64 * 1024) LAUNCH_PD_LDS(32); else LAUNCH_PD(32); break;
     }
 #undef LAUNCH_PD
+#undef LAUNCH_PD_LDS
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
