@@ -304,7 +304,7 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
         case 1: LAUNCH_PD(1); break;
         case 2: LAUNCH_PD(2); break;
         case 4: LAUNCH_PD(4); break;
-        case 8: LAUNCH_PD(8); break;
+        case 8: if (M * 8 * 8 <= 64 * 1024) LAUNCH_PD_LDS(8); else LAUNCH_PD(8); break;
         case 16: if (M * 16 * 8 <= 64 * 1024) LAUNCH_PD_LDS(16); else LAUNCH_PD(16); break;
         default: if (M * 32 * 8 <= 64 * 1024) LAUNCH_PD_LDS(32); else LAUNCH_PD(32); break;
     }
