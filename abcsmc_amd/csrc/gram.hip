@@ -415,6 +415,149 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
 
 
 // ---------------------------------------------------------------------------------------------------
+// 49..96 columns (4..6 column blocks, BASELINE configs[3]: 64 metrics + 32 parameters), EIGHT waves: the shape is bound by the
+// fp64 matrix pipe (18 blocks per four rows), and ONE wave per SIMD does not keep that pipe busy (33 TFLOP/s against 44-49 with
+// two: scripts/ubench.hip; the four-wave variant above ran at exactly that rate, 0.35-0.37 ms on the configs[3] shard).  Two
+// waves per SIMD need rings of at most 18 KB per wave: wave-private chunks of EIGHT rows (64-row tiles, three-chunk rings of
+// 6 KB per wave at 96 columns).  DMA instruction i of a chunk brings the 16 columns of MFMA block i: lane l fetches rows
+// 2 (l >> 4), +1 of column 16 i + (l & 15), 64-byte pieces of a column (the other half of the 128-byte line goes to the
+// neighbouring wave of the same work-group at the same time); in LDS that is element (column c, row r) of block i at
+// 128 i + 2 c + 32 (r >> 1) + (r & 1), so the operand read of k-step s (lane (cl, q) -> row 4 s + q) covers 64 consecutive
+// doubles: conflict-free without a swizzle.  Everything else (shift at operand read, masks, column sums, epilogue) as above.
+template <int C, int CY>
+__global__ __launch_bounds__(512) void k_gram_dma8(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy,
+                                                  int M, int P, long long n, long long split, const double* __restrict__ shift,
+                                                  double* __restrict__ partial) {
+    using D = GramDimsDma<C, CY, 8, 3>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NW = 8, NT = 512, R = 3, TRK = 64, CH = D::C16 * 8;      // CH: doubles per wave chunk (8 rows x C16 columns)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
+    const long long r_begin = part ? split : 0, r_end = part ? n : split;
+    const long long t0 = r_begin & ~1LL;
+    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + TRK - 1) / TRK : 0;
+    const long long rmax = (n - 2) & ~1LL;
+    const double* cptr[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        const int c = 16 * i + (lane & 15);              // padding columns re-read column 0, masked at operand read
+        cptr[i] = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+    }
+    double* const wring = lds + wave * (R * CH);
+    auto stage = [&](long long tile, int slot) {
+        long long r = t0 + tile * TRK + 8 * wave + 2 * (lane >> 4);
+        r = r > rmax ? rmax : r;                         // rows past the end are masked later; keep the address legal
+#pragma unroll
+        for (int i = 0; i < C; i++) dma16(cptr[i] + r, wring + slot * CH + i * 128);
+    };
+    const int cl = lane & 15, q = lane >> 4;
+    double sh[C], keep[C];
+#pragma unroll
+    for (int b = 0; b < C; b++) {
+        const int c = 16 * b + cl;
+        const bool real = c < M + P;
+        keep[b] = real ? 1.0 : 0.0;
+        sh[b] = real ? shift[c] : 0.0;
+    }
+    d4 acc[D::NBLK];
+#pragma unroll
+    for (int b = 0; b < D::NBLK; b++) acc[b] = (d4){0.0, 0.0, 0.0, 0.0};
+    double cs[C], cq[C];
+#pragma unroll
+    for (int b = 0; b < C; b++) { cs[b] = 0.0; cq[b] = 0.0; }
+    const int poff = 2 * cl + (q & 1) + 32 * (q >> 1);
+    int cur = 0;
+    long long tile = g;
+#pragma unroll
+    for (int d = 0; d < R - 1; d++)
+        if (tile + d * G < ntiles) stage(tile + d * G, d);
+    for (; tile < ntiles; tile += G) {
+        const double* buf = wring + cur * CH;
+        {   // this tile's DMA has landed; up to R - 2 later ones (C instructions each) may stay in flight
+            const long long ahead = (ntiles - 1 - tile) / G;
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (tile + (R - 1) * G < ntiles) stage(tile + (R - 1) * G, (cur + R - 1) % R);
+        const long long row0 = t0 + tile * TRK;
+        const bool full = (row0 >= r_begin) && (row0 + TRK <= r_end);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int rb = wave * 8 + 4 * s + q;
+            const long long grow = row0 + rb;
+            const bool ok = full || (grow >= r_begin && grow < r_end);
+            double a[C];
+#pragma unroll
+            for (int b = 0; b < C; b++) {
+                const double v = buf[b * 128 + poff + 64 * s];
+                const double z = (v - sh[b]) * keep[b];
+                a[b] = ok ? z : 0.0;
+                cs[b] += a[b];
+                if (b >= C - CY) cq[b] = fma(a[b], a[b], cq[b]);
+            }
+            int blk = 0;
+#pragma unroll
+            for (int bi = 0; bi < C - CY; bi++)
+#pragma unroll
+                for (int bj = bi; bj < C; bj++) {
+                    acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[blk], 0, 0, 0);
+                    blk++;
+                }
+        }
+        cur = (cur + 1) % R;
+    }
+
+    // ---- epilogue (same partial record as k_gram / k_gram_dma) ------------------------------------------
+    double* out = partial + ((size_t)part * G + g) * D::PSZ;
+    __syncthreads();
+    constexpr int EPT = (D::NBLK * 256 + NT - 1) / NT;
+    double tot[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) tot[k] = 0.0;
+    constexpr int EW = ((size_t)4 * D::NBLK * 256 * sizeof(double) <= 160 * 1024) ? 4 : 2;
+    for (int round = 0; round < NW / EW; round++) {
+        if ((wave / EW) == round) {
+#pragma unroll
+            for (int b = 0; b < D::NBLK; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) lds[(wave % EW) * (D::NBLK * 256) + b * 256 + r * 64 + lane] = acc[b][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int e = t + k * NT;
+            if (e < D::NBLK * 256) {
+                if constexpr (EW == 4)
+                    tot[k] += ((lds[e] + lds[D::NBLK * 256 + e]) + lds[2 * D::NBLK * 256 + e]) + lds[3 * D::NBLK * 256 + e];
+                else
+                    tot[k] += lds[e] + lds[D::NBLK * 256 + e];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int e = t + k * NT;
+        if (e < D::NBLK * 256) out[e] = tot[k];
+    }
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < C; b++) lds[b * NT + t] = half ? cq[b] : cs[b];
+        __syncthreads();
+        if (t < D::C16) {
+            const int b = t >> 4, c = t & 15;
+            double sacc = 0.0;
+            for (int w = 0; w < NW; w++)
+                for (int qq = 0; qq < 4; qq++) sacc += lds[b * NT + w * 64 + qq * 16 + c];
+            out[D::NBLK * 256 + half * D::C16 + t] = sacc;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Wide sets in ONE launch (8..10 column blocks, e.g. BASELINE configs[4]: 128 metrics + 16 parameters = 9 blocks, 44 Gram
 // blocks): the accumulators of all blocks do not fit one wave (44 x 8 VGPRs), so the BLOCKS are dealt out to the eight waves
 // of a work-group (block b to wave b mod 8, five or six each) and every wave runs its blocks over all 64 rows of the tile --
@@ -686,6 +829,40 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
 }
 
 template <int C, int CY>
+int run_gram_dma8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
+                  long long split, double* stats) {
+    using D = GramDimsDma<C, CY, 8, 3>;
+    const StatsLayout L = stats_layout(M, P);
+    const long long ntr = split, nte = (long long)n - split;
+    const long long tiles = ((ntr > nte ? ntr : nte) + 63) / 64 + 1;
+    long long G = tiles / 2;
+    if (G < 1) G = 1;
+    if (G > 128) G = 128;              // ~150 KB of LDS: one work-group (eight waves) per CU, 2 partitions x 128
+    const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
+    double* partial = (double*)abc_ws_alloc(ctx, pbytes);
+    if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
+    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
+    constexpr size_t epi4 = (size_t)4 * D::NBLK * 256;
+    constexpr size_t lds_ring = (size_t)8 * 3 * D::C16 * 8, lds_epi = (epi4 * sizeof(double) <= 160 * 1024) ? epi4 : epi4 / 2,
+                     lds_cs = (size_t)C * 512;
+    constexpr size_t lds_max = lds_ring > lds_epi ? (lds_ring > lds_cs ? lds_ring : lds_cs) : (lds_epi > lds_cs ? lds_epi : lds_cs);
+    static_assert(lds_max * sizeof(double) <= 160 * 1024, "k_gram_dma8: ring / epilogue exceed the 160 KB of LDS");
+    const size_t lds_bytes = lds_max * sizeof(double);
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma8<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    {
+        StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
+        hipLaunchKernelGGL((k_gram_dma8<C, CY>), dim3((unsigned)G, 2), dim3(512), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
+                           (long long)n, split, stats + L.off_shift, partial);
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 15) / 16, 2), dim3(256), 0, ctx->stream, partial, (int)G, stats, ntr,
+                       nte);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+template <int C, int CY>
 int run_gram_wide(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
                   long long split, double* stats) {
     using D = GramWide<C, CY>;
@@ -817,14 +994,15 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     if (CY > 2) CY = 2;
     // Two kernels.  Up to 48 columns (C <= 3) the VGPR-staged k_gram is the default since its loads carry the non-temporal
     // policy: 75 us against 84 us for the LDS-DMA kernel at N = 1e6, M = 32, P = 16 (0.68 against 0.60 of the HBM peak inside
-    // a generation); 49..96 columns run the four-wave LDS-DMA variant (0.35 against 0.68 ms on the configs[3] shape).
+    // a generation); 49..96 columns run the eight-wave LDS-DMA variant (0.29 against 0.68 ms on the configs[3] shape).
     // LDS-DMA staging needs 16-B aligned columns and an even row count (row pairs never straddle the array end).
     const bool dma_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) &&
                         (((uintptr_t)Y & 15) == 0) && n >= 2;
-    // 4..6 column blocks (49..96 columns, e.g. BASELINE configs[3]: 64 metrics + 32 parameters): the same kernel with FOUR
-    // waves of wave-private staging (64-row tiles; three-chunk rings of 8-12 KB per wave fit the LDS, eight would not).
+    // 4..6 column blocks (49..96 columns, e.g. BASELINE configs[3]: 64 metrics + 32 parameters): k_gram_dma8, EIGHT waves of
+    // wave-private staging in 8-row chunks (two waves per SIMD keep the fp64 matrix pipe busy: 0.36 -> 0.29 ms on the configs[3]
+    // shard against the four-wave, 16-row-chunk variant, which stays for the column-pointer-table mode of the grouped path).
     // (6, 0) needs 172 KB for its epilogue and stays on the VGPR-staged kernel.
-#define GRAM_DMA4_CASE(c, cy) if (C == c && CY == cy && dma_ok) return run_gram_dma<c, cy, 4, true>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+#define GRAM_DMA4_CASE(c, cy) if (C == c && CY == cy && dma_ok) return run_gram_dma8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_DMA4_CASE(4, 0); GRAM_DMA4_CASE(4, 1); GRAM_DMA4_CASE(4, 2); GRAM_DMA4_CASE(5, 0); GRAM_DMA4_CASE(5, 1); GRAM_DMA4_CASE(5, 2);
     GRAM_DMA4_CASE(6, 1); GRAM_DMA4_CASE(6, 2);
 #undef GRAM_DMA4_CASE
