@@ -428,6 +428,16 @@ extern "C" int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* t
 // ---- fused generation (device-resident) ----------------------------------------------------------
 // does NOT reserve/reset the arena: the caller has done so (lets host wrappers keep their staging
 // buffers in the same arena)
+// the status words of a generation (model header with the component count, Cholesky status, selection flag) stored by the GPU
+// straight into the context's pinned, device-visible block
+__global__ void k_status_words(const double* __restrict__ model_hdr, const int* __restrict__ spd, const int* __restrict__ fail,
+                               double* __restrict__ hdr_out, int* __restrict__ spd_out, int* __restrict__ fail_out) {
+    const int t = threadIdx.x;
+    if (model_hdr && t < 4) hdr_out[t] = model_hdr[t];
+    if (spd && t == 4) *spd_out = *spd;
+    if (fail && t == 5) *fail_out = *fail;
+}
+
 static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
                            int32_t* ncomp_host, int simple, const double** model_out = nullptr) {
     const size_t N = cfg->N, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->Nnext;
@@ -555,9 +565,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         int* pspd = (int*)(ctx->status_pin + 32);
         int* pfail = (int*)(ctx->status_pin + 36);
         hdr[0] = 0.0; *pspd = 0; *pfail = 0;
-        if (!simple) ABC_HIP(ctx, hipMemcpyAsync(hdr, model, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(pspd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        ABC_TRY(abc_select_check_queue(ctx, pfail));
+        // ONE tiny kernel stores the three words into the (device-visible) pinned block: three copies were three blit launches
+        const int* fail_dev = (ctx->sel_bins_ran && ctx->sel_fail_dev) ? (const int*)ctx->sel_fail_dev : nullptr;
+        hipLaunchKernelGGL(k_status_words, dim3(1), dim3(64), 0, ctx->stream, simple ? (const double*)nullptr : (const double*)model,
+                           have_spd ? (const int*)spd_dev : (const int*)nullptr, fail_dev, hdr, pspd, pfail);
+        ABC_HIP(ctx, hipGetLastError());
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
         spd = *pspd;

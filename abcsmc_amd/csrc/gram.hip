@@ -699,6 +699,15 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
     if (blockIdx.x == 0 && threadIdx.x == 0 && part == 0) { stats[L.off_n] = (double)n_train; stats[L.off_n + 1] = (double)n_test; }
+    if (CY > 0 && blockIdx.x == gridDim.x - 1) {
+        // the skipped pure-Y blocks: zero off their diagonal (a memset of the whole record used to do this: one launch more)
+        constexpr int y0 = 16 * (C - CY), ny = 16 * CY;
+        double* Gz = stats + L.off_G[part];
+        for (int i = threadIdx.x; i < ny * ny; i += 256) {
+            const int r = y0 + i % ny, c = y0 + i / ny;
+            if (r != c) Gz[r + (size_t)D::C16 * c] = 0.0;
+        }
+    }
     double ps = 0.0;
     if (e < D::PSZ) {
         const double* p = partial + (size_t)part * G * D::PSZ + e;
@@ -771,7 +780,6 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
-    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
     const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
     // per device and cheap: set on every launch (a function-level flag would be wrong for a second device)
@@ -804,7 +812,6 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
-    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     // wave-private staging: NW rings of R chunks of 16 rows x C16 columns; the epilogue stages four waves' accumulators
     constexpr size_t epi4 = (size_t)4 * D::NBLK * 256;          // the epilogue stages four waves' accumulators (two if that is too much)
     constexpr size_t lds_priv = (size_t)NW * R * D::C16 * 16, lds_epi = (epi4 * sizeof(double) <= 160 * 1024) ? epi4 : epi4 / 2,
@@ -841,7 +848,6 @@ int run_gram_dma8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
-    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     constexpr size_t epi4 = (size_t)4 * D::NBLK * 256;
     constexpr size_t lds_ring = (size_t)8 * 3 * D::C16 * 8, lds_epi = (epi4 * sizeof(double) <= 160 * 1024) ? epi4 : epi4 / 2,
                      lds_cs = (size_t)C * 512;
@@ -875,7 +881,6 @@ int run_gram_wide(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     const size_t pbytes = (size_t)2 * G * D::PSZ * sizeof(double);
     double* partial = (double*)abc_ws_alloc(ctx, pbytes);
     if (!partial) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
-    if (CY > 0) ABC_HIP(ctx, hipMemsetAsync(stats + L.off_G[0], 0, 2 * L.C16 * L.C16 * sizeof(double), ctx->stream));
     const int vec_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0);
     const size_t lds_bytes = (size_t)D::LDS_D * sizeof(double);
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_wide<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

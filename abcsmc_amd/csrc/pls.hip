@@ -77,20 +77,20 @@ __host__ __device__ static inline ZLayout z_layout(size_t M, size_t P) {
 // mean / n-1 stdev of every column, then the z-scored cross-products of both partitions.  A grid of work-groups: every one
 // derives the column moments itself (a few loads per column), the M (M + P) cross-product entries of each partition are dealt
 // out over the grid (one work-group took 69 us at 128 metrics: 144 dependent global loads per thread); block 0 writes the model.
-__global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats, int M, int P, int A,
-                                                double* __restrict__ model, double* __restrict__ zwork) {
+// (a device function: small sets run it as the prologue of k_pls_fit16 instead of as a launch of its own)
+__device__ __forceinline__ void zstats_body(const double* __restrict__ stats, int M, int P, int A, double* __restrict__ model,
+                                            double* __restrict__ zwork, double* __restrict__ zsh /* 2 (M + P) doubles of LDS */,
+                                            int t, int nt, int blk, int nblk) {
     const StatsLayout L = stats_layout(M, P);
     const ModelLayout ML = model_layout(M, P, A);
     const ZLayout Z = z_layout(M, P);
-    extern __shared__ double zsh[];          // 2 (M + P) doubles
-    const int t = threadIdx.x;
     const int C = M + P;
-    const bool first = blockIdx.x == 0;
+    const bool first = blk == 0;
     double* delta = zsh;
     double* sd = zsh + C;
     const double n0 = stats[L.off_n], n1 = stats[L.off_n + 1];
     const double n = n0 + n1;
-    for (int c = t; c < C; c += 256) {
+    for (int c = t; c < C; c += nt) {
         const double s = stats[L.off_sum[0] + c] + stats[L.off_sum[1] + c];
         const double d = (n > 0) ? s / n : 0.0;  // mean - shift
         const double g = stats[L.off_G[0] + c + L.C16 * c] + stats[L.off_G[1] + c + L.C16 * c];
@@ -107,13 +107,13 @@ __global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats
     if (first && t == 0) { model[ML.off_hdr + 1] = (double)A; model[ML.off_hdr + 2] = n; model[ML.off_hdr + 3] = 0.0; }
     __syncthreads();
     if (zwork == nullptr) return;
-    const int stride = 256 * gridDim.x;
+    const int stride = nt * nblk;
     for (int part = 0; part < 2; part++) {
         const double np = part ? n1 : n0;
         const double* G = stats + L.off_G[part];
         const double* S = stats + L.off_sum[part];
         // XX (M x M) and XY (M x P) in one sweep over columns b of [X|Y]
-        for (int e = blockIdx.x * 256 + t; e < M * C; e += stride) {
+        for (int e = blk * nt + t; e < M * C; e += stride) {
             const int a = e % M, b = e / M;
             const double cross = G[a + L.C16 * b] - delta[a] * S[b] - delta[b] * S[a] + np * delta[a] * delta[b];
             const double den = sd[a] * sd[b];
@@ -123,13 +123,18 @@ __global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats
         }
     }
     if (first)
-        for (int j = t; j < P; j += 256) {
+        for (int j = t; j < P; j += nt) {
             const int c = M + j;
             const double cross = stats[L.off_G[1] + c + L.C16 * c] - 2.0 * delta[c] * stats[L.off_sum[1] + c] +
                                  n1 * delta[c] * delta[c];
             const double den = sd[c] * sd[c];
             zwork[Z.off_YY + j] = (den > 0.0) ? cross / den : 0.0;
         }
+}
+__global__ __launch_bounds__(256) void k_zstats(const double* __restrict__ stats, int M, int P, int A,
+                                                double* __restrict__ model, double* __restrict__ zwork) {
+    extern __shared__ double zsh[];          // 2 (M + P) doubles
+    zstats_body(stats, M, P, A, model, zwork, zsh, threadIdx.x, 256, blockIdx.x, gridDim.x);
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -756,14 +761,22 @@ __device__ __forceinline__ double dot_ahead(const double* __restrict__ a, int sa
 //   (5) partial sums of X'X r (four threads per row) and of XY'r (eight per response).
 // LDS: XY, the loadings and rotations, the partial blocks; X'X in LDS up to 64 metrics, in registers up to 128 on eight waves.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* __restrict__ zwork, const double* __restrict__ obs,
+__global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, const double* __restrict__ obs,
                                                       int M, int P, int A, double* __restrict__ model,
-                                                      double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds) {
+                                                      double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds,
+                                                      const double* __restrict__ stats /* non-NULL: run k_zstats' work first */,
+                                                      double* __restrict__ zwork_w) {
     extern __shared__ double lds_[];
     const ModelLayout ML = model_layout(M, P, A);
     const ZLayout Z = z_layout(M, P);
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, c = l & 15, q4 = l >> 4;
+    if (stats) {
+        // small sets: the z-scored cross-products are this work-group's own prologue (a launch and its dependency gap less)
+        zstats_body(stats, M, P, A, model, zwork_w, lds_, tid, NT, 0, 1);
+        __threadfence_block();
+        __syncthreads();
+    }
     const int n = P;
     // XY column-major with the leading dimension padded to 2 (mod 4): the slab pass reads / writes four consecutive rows of all 16
     // columns with one instruction, 16-way bank-conflicted at a leading dimension of 32 or 128 doubles, conflict-free at 34 / 130
@@ -1112,8 +1125,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     double* zwork = (double*)abc_ws_alloc(ctx, Z.len * sizeof(double));
     double* scratch = (double*)abc_ws_alloc(ctx, (A * M + A * A + 2 * P * A + 64) * sizeof(double));
     if (!zwork || !scratch) ABC_FAIL(ctx, ABC_ERR_NOMEM, "pls: workspace exhausted");
-    const unsigned zblocks = (unsigned)((M * (M + P) + 1023) / 1024 > 64 ? 64 : (M * (M + P) + 1023) / 1024);      // ~4 entries per thread and partition
-    hipLaunchKernelGGL(k_zstats, dim3(zblocks), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
+    // (the z-scored cross-products: a launch of their own, or -- small sets on the latency-tuned fit -- that kernel's prologue)
     ABC_HIP(ctx, hipGetLastError());
     const size_t np = P;
     const int xx_in_lds = M <= 64;
@@ -1138,14 +1150,22 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
                                 else PLS_LAUNCH(NW_, false, 0); } while (0)
     // 2..16 responses on more than one wave: the latency-tuned kernel, when its arrays fit the LDS
     const size_t lds16_d = (M + 3) * P + 16 + 3 * M + 4 + 4 * M + 128 + A + 2 * M * A + (M > 64 ? 8 : 4) * 256 + (xx_in_lds ? M * M : 0) + A * A + 3 * P * A;
-    if (P >= 2 && P <= 16 && M > 16 && lds16_d * sizeof(double) <= 160 * 1024) {
+    const bool fit16 = P >= 2 && P <= 16 && M > 16 && lds16_d * sizeof(double) <= 160 * 1024;
+    const bool fold_z = fit16 && M * (M + P) <= 4096;
+    const double* stats_in = fold_z ? stats : nullptr;
+    if (!fold_z) {
+        const unsigned zblocks = (unsigned)((M * (M + P) + 255) / 256 > 128 ? 128 : (M * (M + P) + 255) / 256);      // one entry per thread and partition
+        hipLaunchKernelGGL(k_zstats, dim3(zblocks), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
+        ABC_HIP(ctx, hipGetLastError());
+    }
+    if (fit16) {
         const int lb = (int)(lds16_d * sizeof(double));
         if (M > 64) {
             ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            hipLaunchKernelGGL(k_pls_fit16<8>, dim3(1), dim3(512), lb, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds);
+            hipLaunchKernelGGL(k_pls_fit16<8>, dim3(1), dim3(512), lb, ctx->stream, (const double*)zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork);
         } else {
             ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            hipLaunchKernelGGL(k_pls_fit16<4>, dim3(1), dim3(256), lb, ctx->stream, zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds);
+            hipLaunchKernelGGL(k_pls_fit16<4>, dim3(1), dim3(256), lb, ctx->stream, (const double*)zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork);
         }
     } else
     if (gbase) {                                    // wide sets: eight waves in every case

@@ -60,10 +60,18 @@ __global__ __launch_bounds__(256) void k_project_dist2(const double* __restrict_
 template <int KC>
 __global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restrict__ X, size_t npairs, size_t ldx, int M,
                                                            const double* __restrict__ mean, const double* __restrict__ sd,
-                                                           const double* __restrict__ Rpad, const double* __restrict__ opad,
+                                                           const double* __restrict__ model, size_t off_R, size_t off_oscore,
                                                            double* __restrict__ dist) {
-    extern __shared__ double Rl[];                                       // M*KC
-    for (int e = threadIdx.x; e < M * KC; e += 256) Rl[e] = Rpad[e];
+    extern __shared__ double Rl[];                                       // M*KC + KC
+    double* const opad = Rl + (size_t)M * KC;
+    {   // the zero-padded loadings and observed scores straight from the model (what k_pad_model writes for the other kernels)
+        const int ncomp = (int)model[0];
+        for (int e = threadIdx.x; e < M * KC; e += 256) {
+            const int m = e / KC, k = e % KC;
+            Rl[e] = (k < ncomp) ? model[off_R + m + (size_t)M * k] : 0.0;
+        }
+        if (threadIdx.x < KC) opad[threadIdx.x] = (threadIdx.x < ncomp) ? model[off_oscore + threadIdx.x] : 0.0;
+    }
     __syncthreads();
     constexpr int PF = 4, H = KC / 4;                                    // H: 16-byte reads per half row of loadings
     const size_t stride = (size_t)gridDim.x * 256;
@@ -260,9 +268,9 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     double* Rpad = (double*)abc_ws_alloc(ctx, (M * KC + KC) * sizeof(double));
     if (!Rpad) ABC_FAIL(ctx, ABC_ERR_NOMEM, "project: workspace exhausted");
     double* opad = Rpad + M * KC;
-    hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
-    ABC_HIP(ctx, hipGetLastError());
     if (KC > 32) {
+        hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
+        ABC_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_project_dist_wide, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n, ldx, (int)M, KC,
                            model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist);
         ABC_HIP(ctx, hipGetLastError());
@@ -276,14 +284,21 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     if (pblocks > 256 * 16) pblocks = 256 * 16;
     blocks = (ntail + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    // the LDS kernel pads the loadings itself; the others read the padded copy k_pad_model leaves in the workspace
+    const bool lds_kernel = (KC == 8 || KC == 16 || KC == 32) && (M * KC + KC) * sizeof(double) <= 64 * 1024 && npairs;
+    if (!lds_kernel || ntail) {
+        hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
+        ABC_HIP(ctx, hipGetLastError());
+    }
     // (16 / 32 components with the loadings in LDS; beyond 64 KB of them the scalar-operand kernel)
 #define LAUNCH_PD_LDS(KCV)                                                                                             \
     do {                                                                                                               \
-        const int lb = (int)(M * KCV * sizeof(double));                                                                \
+        const int lb = (int)((M * KCV + KCV) * sizeof(double));                                                        \
         if (npairs) {                                                                                                  \
             if (pblocks > 1024) pblocks = 1024;                                                                        \
             hipLaunchKernelGGL(k_project_dist2_lds<KCV>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X,       \
-                               npairs, ldx, (int)M, model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist);        \
+                               npairs, ldx, (int)M, model + ML.off_mean, model + ML.off_sd, model, ML.off_R,           \
+                               ML.off_oscore, dist);                                                                   \
         }                                                                                                              \
         if (ntail)                                                                                                     \
             hipLaunchKernelGGL(k_project_dist<KCV>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,                 \
@@ -304,9 +319,9 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
         case 1: LAUNCH_PD(1); break;
         case 2: LAUNCH_PD(2); break;
         case 4: LAUNCH_PD(4); break;
-        case 8: if (M * 8 * 8 <= 64 * 1024) LAUNCH_PD_LDS(8); else LAUNCH_PD(8); break;
-        case 16: if (M * 16 * 8 <= 64 * 1024) LAUNCH_PD_LDS(16); else LAUNCH_PD(16); break;
-        default: if (M * 32 * 8 <= 64 * 1024) LAUNCH_PD_LDS(32); else LAUNCH_PD(32); break;
+        case 8: if (lds_kernel) LAUNCH_PD_LDS(8); else LAUNCH_PD(8); break;
+        case 16: if (lds_kernel) LAUNCH_PD_LDS(16); else LAUNCH_PD(16); break;
+        default: if (lds_kernel) LAUNCH_PD_LDS(32); else LAUNCH_PD(32); break;
     }
 #undef LAUNCH_PD
 #undef LAUNCH_PD_LDS
