@@ -17,19 +17,23 @@ int main(int argc, char** argv) {
         const double total = alias_sequential_sum(w.data(), K);
         double t1 = now_ms();
         const double mean = 1.0 / (double)K, dK = (double)K;
-        for (size_t k = 0; k < K; k++) E[k] = w[k] / total;
+        alias_divide(w.data(), total, E.data(), K);
         double t2 = now_ms();
         size_t ns = 0, nb = 0;
         uint32_t* smalls = S.data(); uint32_t* bigs = B.data();
-        for (size_t k = 0; k < K; k++) { const bool sm = E[k] < mean; smalls[ns] = (uint32_t)k; bigs[nb] = (uint32_t)k; ns += sm; nb += !sm; }
+        alias_classify(E.data(), mean, K, smalls, bigs, ns, nb);
         double t3 = now_ms();
         bool have = false; uint32_t cb = 0; double eb = 0.0;
         while (ns) {
             const uint32_t s = smalls[--ns];
             if (!have) { if (!nb) { A[s] = s; F[s] = 1.0; continue; } cb = bigs[--nb]; eb = E[cb]; have = true; }
             const double es = E[s]; A[s] = cb; F[s] = dK * es; eb -= mean - es;
-            if (eb < mean) { E[cb] = eb; smalls[ns++] = cb; have = false; }
-            else if (!(eb > mean)) { A[cb] = cb; F[cb] = 1.0; have = false; }
+            while (eb < mean) {
+                if (!nb) { A[cb] = cb; F[cb] = 1.0; have = false; break; }
+                const uint32_t nbig = bigs[--nb]; double enb = E[nbig];
+                A[cb] = nbig; F[cb] = dK * eb; enb -= mean - eb; cb = nbig; eb = enb;
+            }
+            if (have && !(eb > mean) && !(eb < mean)) { A[cb] = cb; F[cb] = 1.0; have = false; }
         }
         if (have) { A[cb] = cb; F[cb] = 1.0; }
         while (nb) { const uint32_t b = bigs[--nb]; A[b] = b; F[b] = 1.0; }
