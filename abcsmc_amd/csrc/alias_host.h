@@ -14,36 +14,38 @@
 // vector accumulators).  Blocks containing a tie (|RN(t) - t| == 1/2), a negative, huge or non-finite element, or
 // crossing into the next binade are redone by the plain loop; so are the first elements (s == 0).
 #if defined(__x86_64__)
-#define ALIAS_TARGET_CLONES __attribute__((target_clones("avx2", "default")))
+#define ALIAS_TARGET_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
 #else
 #define ALIAS_TARGET_CLONES
 #endif
-typedef double alias_v4d __attribute__((vector_size(32)));
-typedef long long alias_v4i __attribute__((vector_size(32)));
-// Explicit 4-wide vectors (two in flight): one AVX2 instruction each in the avx2 clone, two SSE2 ones in the default.
+typedef double alias_v8d __attribute__((vector_size(64)));
+typedef long long alias_v8i __attribute__((vector_size(64)));
+// Explicit 8-wide vectors (two in flight): one AVX-512 instruction each in that clone, two AVX2 / four SSE2 ones in the others.
 ALIAS_TARGET_CLONES static bool alias_sum_block(const double* w, double inv_u, double* inc_sum) {
     const double Ms = 4503599627370496.0;                    // 2^52: (t + M) - M = RN(t) for 0 <= t < 2^51
-    const alias_v4d M = {Ms, Ms, Ms, Ms}, IU = {inv_u, inv_u, inv_u, inv_u}, H = {0.5, 0.5, 0.5, 0.5}, Z = {0, 0, 0, 0};
     const double Ls = 17592186044416.0;                      // 2^44: 256 increments below it sum exactly (< 2^52)
-    const alias_v4d LIM = {Ls, Ls, Ls, Ls};
-    alias_v4d acc0 = Z, acc1 = Z;
-    alias_v4i bad = {0, 0, 0, 0};
-    for (int i = 0; i < 256; i += 8) {
-        alias_v4d a, b;
-        __builtin_memcpy(&a, w + i, 32);
-        __builtin_memcpy(&b, w + i + 4, 32);
-        const alias_v4d ta = a * IU, tb = b * IU;            // exact (power of two); overflow -> inf -> rejected
-        const alias_v4d ra = (ta + M) - M, rb = (tb + M) - M;
-        const alias_v4d da = ra - ta, db = rb - tb;
+    alias_v8d M, IU, H, Z, LIM;
+    for (int i = 0; i < 8; i++) { M[i] = Ms; IU[i] = inv_u; H[i] = 0.5; Z[i] = 0.0; LIM[i] = Ls; }
+    alias_v8d acc0 = Z, acc1 = Z;
+    alias_v8i bad = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 256; i += 16) {
+        alias_v8d a, b;
+        __builtin_memcpy(&a, w + i, 64);
+        __builtin_memcpy(&b, w + i + 8, 64);
+        const alias_v8d ta = a * IU, tb = b * IU;            // exact (power of two); overflow -> inf -> rejected
+        const alias_v8d ra = (ta + M) - M, rb = (tb + M) - M;
+        const alias_v8d da = ra - ta, db = rb - tb;
         acc0 += ra;                                          // integers: exact while the block total stays below 2^53
         acc1 += rb;
         // reject: a tie (the increment would depend on the parity of the running sum), negative, >= 2^44, NaN
         bad |= (da == H) | (da == -H) | (ta < Z) | !(ta < LIM);
         bad |= (db == H) | (db == -H) | (tb < Z) | !(tb < LIM);
     }
-    const alias_v4d acc = acc0 + acc1;
-    *inc_sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    return (bad[0] | bad[1] | bad[2] | bad[3]) == 0;
+    const alias_v8d acc = acc0 + acc1;
+    *inc_sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    long long anybad = 0;
+    for (int i = 0; i < 8; i++) anybad |= bad[i];
+    return anybad == 0;
 }
 inline double alias_sequential_sum(const double* w, size_t K) {
     double s = 0.0;
