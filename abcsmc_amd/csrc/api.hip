@@ -499,7 +499,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K));
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;        // moments of the posterior: shared by dv and the MVN factor
-    if (P <= 64 && K >= 2) {
+    // Weighted generations with proposals: the kernel density of the weights uses the PREVIOUS set's variance, so the new set's
+    // moments (pilot shift, Gram, reduce, dv: 25 us of small launches) are not needed before the host's alias round trip --
+    // they run in the GPU's idle time behind it (hook below) instead of in front of the pair sums.
+    const bool defer_moments = Nn && !uniform_w && P <= 64 && K >= 2;
+    if (defer_moments) {
+    } else if (P <= 64 && K >= 2) {
         StageTimer tm(ctx, ST_GATHER_DV);
         ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats));
         ABC_TRY(launch_dv_from_stats(ctx, theta_stats, P, dv));
@@ -530,11 +535,18 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         abc_perturb_prep prep = {nullptr, (early && io->seeds) ? 1 : 0, nullptr};
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
-            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
+            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments;
         };
-        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev, dv};
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev, dv, defer_moments};
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
+            if (q->moments) {
+                StageTimer tm(q->ctx, ST_GATHER_DV);
+                double* st = nullptr;
+                ABC_TRY(launch_theta_stats(q->ctx, q->theta, q->K, q->P, &st));
+                ABC_TRY(launch_dv_from_stats(q->ctx, st, q->P, q->dv));
+                q->theta_stats = st;
+            }
             if (q->L) {
                 if (q->theta_stats) {
                     StageTimer tm(q->ctx, ST_MVN);
