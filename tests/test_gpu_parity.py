@@ -93,6 +93,32 @@ def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     assert _near_tie_ok(g["idx"], o["idx"], o["dist"])
 
 
+def test_pls_fit_random_shapes_match_oracle_and_repeat_bitwise(gpu_ctx, oracle):
+    """the latency-tuned model fit (k_pls_fit16: five barriers per component, per-wave recomputation instead of cross-wave
+    reductions, register-resident X'X) on 24 random shapes: loadings against the oracle's independent algorithm, and the
+    whole model record bit-identical between two runs of the same input (a missing barrier shows up as run-to-run noise)"""
+    from abcsmc_amd import abcutil
+    rng = np.random.default_rng(20260103)
+    for case in range(24):
+        M = int(rng.integers(17, 141))
+        P = int(rng.integers(2, 17))
+        A = int(rng.integers(1, min(M, 20) + 1))
+        N = int(rng.integers(400, 2500))
+        f = float(rng.choice([0.4, 0.5, 0.63, 1.0]))
+        wl, X, Y, obs = _wl(M, P, N, seed=1000 + case)
+        g = abcutil.particle_ranking_PLS(X, Y, obs, f, max_comp=A, details=True, ctx=gpu_ctx)
+        g2 = abcutil.particle_ranking_PLS(X, Y, obs, f, max_comp=A, details=True, ctx=gpu_ctx)
+        tag = (case, M, P, A, N, f)
+        for key in ("R", "mean", "sd", "dist"):
+            assert np.array_equal(g[key], g2[key]), (tag, key)
+        assert np.array_equal(g["idx"], g2["idx"]) and g["ncomp"] == g2["ncomp"], tag
+        o = oracle.particle_ranking_pls(X, Y, obs, f, A)
+        assert g["ncomp"] == o["ncomp"], tag
+        for k in range(o["ncomp"]):
+            assert np.linalg.norm(g["R"][:, k] - o["R"][:, k]) <= RTOL * np.linalg.norm(o["R"][:, k]), (tag, k)
+        assert np.allclose(g["dist"], o["dist"][g["idx"].astype(int)], rtol=RTOL), tag
+
+
 def _fma_dot(a, b):
     """m-ascending fma chain in float64 (matches orc_* and the kernels) using exact arithmetic"""
     from fractions import Fraction
