@@ -852,6 +852,22 @@ def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp):
             assert nxt[:, p].min() >= a and nxt[:, p].max() <= b
 
 
+@pytest.mark.parametrize("N,M,P,K,Kp,A", [(20000, 32, 16, 2000, 2000, 8), (6000, 64, 32, 600, 600, 8), (4000, 128, 16, 400, 400, 32)])
+def test_generation_repeats_bit_identically(gpu_ctx, N, M, P, K, Kp, A):
+    """two runs of the same generation (side stream, deferred moments, host alias build between them) give the same bits in
+    every output: weights, proposals, parents, seeds, factor -- the three BASELINE column shapes"""
+    from abcsmc_amd import device
+    outs = []
+    for _ in range(2):
+        wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, N, A, True)
+        outs.append([gen.idx.cpu().numpy().copy(), gen.w.cpu().numpy().copy(), gen.dv.cpu().numpy().copy(),
+                     gen.parent.cpu().numpy().copy(), device.to_numpy(gen.next).copy(), device.to_numpy(gen.L).copy(),
+                     gen.seeds.cpu().numpy().copy() if hasattr(gen, "seeds") else np.zeros(1), int(gen.ncomp.value)])
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
+        assert np.array_equal(a, b)
+    assert outs[0][-1] == outs[1][-1]
+
+
 def test_first_set_alias_table_is_kept_per_size(gpu_ctx, oracle):
     """set 0 (uniform weights, AbcUtil.cpp:539-545): the alias table of K equal weights is built while the GPU ranks and kept
     for the next call with the same K; a different K, and a weighted set in between, must not see a stale table"""
