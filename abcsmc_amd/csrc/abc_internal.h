@@ -234,7 +234,7 @@ int launch_weights_raw(abc_ctx*, const abc_prior* priors, const double* theta, s
 int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                            const double* dv_prev, abc_wprev* out);
 int launch_fill(abc_ctx*, double* w, size_t K, double v);
-int launch_normalize_l2(abc_ctx*, double* w, size_t K);
+int launch_normalize_l2(abc_ctx*, double* w, size_t K, double* host_mirror = nullptr);
 int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* L, int* status_host,
                      int* status_dev);
 // while_host_builds (optional): called after the weights' copy to the host has been queued and before the host waits for it:
@@ -243,7 +243,9 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
 // raw_ready (optional): the n taus2 outputs of the draws, already queued on the side stream (abc_rng_streams_early)
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr,
-                    bool uniform_weights = false, const uint32_t* raw_ready = nullptr);
+                    bool uniform_weights = false, const uint32_t* raw_ready = nullptr, bool weights_on_host = false);
+// weights_on_host: the kernel that normalised w already stored them at the start of the context's pinned scratch
+// (launch_normalize_l2's host_mirror, reserved with the size used here): nothing to copy
 // Queues on the context's side stream everything of the proposals that depends on the rng state alone: the taus2 outputs
 // i0 .. i0 + n - 1 of the resampling draws (-> *raw) and, if seeds != NULL, the simulator seeds = outputs seed_stream_offset +
 // i0 + i.  The main stream waits for them in launch_resample (raw_ready).  Call before the first kernel of the generation.

@@ -511,13 +511,22 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     } else {
         ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
     }
+    bool w_on_host = false;
     if (Kp == 0 || !io->theta_prev) {
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
     } else {
         if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
         ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
                                    io->w, &wprev));
-        ABC_TRY(launch_normalize_l2(ctx, io->w, K));                          // AbcUtil.cpp:583
+        // (with proposals to draw the host builds the alias table of these weights next: the normalisation kernel stores them
+        // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
+        double* mirror = nullptr;
+        if (Nn) {
+            ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
+            mirror = (double*)ctx->pin;
+        }
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror));                  // AbcUtil.cpp:583
+        w_on_host = mirror != nullptr;
     }
     int spd = 0;
     bool have_spd = false;
@@ -560,7 +569,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early));
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host));
         if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {
             taus2_jump(rng, (uint64_t)Nn);   // the Nnext resampling draws; the host loop consumes the rest as the reference does
             ABC_TRY(launch_perturb_reference(ctx, rng, theta, K, P, io->priors, parent, Nn, cfg->multivariate,

@@ -182,7 +182,6 @@ __device__ double eig_square(const double* __restrict__ XY, int M, int n, double
             D[0][0][r] = v;
         }
     } else
-#pragma unroll 4
     for (int m0 = 0; m0 < M; m0 += 4) {
         double a[NB];
 #pragma unroll

@@ -628,7 +628,7 @@ int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* 
 
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights,
-                    const uint32_t* raw_ready) {
+                    const uint32_t* raw_ready, bool weights_on_host) {
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     if (uniform_weights) {
@@ -655,7 +655,8 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     uint32_t* hA = (uint32_t*)(hE + K);
     uint32_t* hS = hA + K;
     uint32_t* hB = hS + K + 1;
-    ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (!weights_on_host)         // (else already in hw: stored there by the kernel that normalised them)
+        ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (!ctx->ev_copy) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
     ABC_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream));
     // the raw taus2 outputs of the draws do not depend on the table: queued behind the copy, generated while the host builds it

@@ -758,15 +758,21 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict_
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// host_mirror (optional): a pinned, device-visible buffer that receives the normalised weights as they are written -- the
+// host's alias build needs them next, and a store over PCIe from here saves the blit copy and its launch gap behind this kernel
 __global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t K, const double* __restrict__ part,
-                                                  int nparts) {
+                                                  int nparts, double* __restrict__ host_mirror) {
     // every work-group adds the (<= 256) partial sums in the same fixed order: one per thread, then the block tree
     __shared__ double sm[4];
     const double sq = block_sum_256(((int)threadIdx.x < nparts) ? part[threadIdx.x] : 0.0, sm);
-    if (!(sq > 0.0)) return;                     // Eigen normalize(): only if squaredNorm > 0
-    const double nrm = sqrt(sq);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < K) w[i] = w[i] / nrm;
+    if (i >= K) return;
+    double v = w[i];
+    if (sq > 0.0) {                              // Eigen normalize(): only if squaredNorm > 0
+        v = v / sqrt(sq);
+        w[i] = v;
+    }
+    if (host_mirror) host_mirror[i] = v;
 }
 
 }  // namespace
@@ -993,7 +999,7 @@ int launch_fill(abc_ctx* ctx, double* w, size_t K, double v) {
     return ABC_OK;
 }
 
-int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K) {
+int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K, double* host_mirror) {
     if (!K) return ABC_OK;
     int nparts = (int)((K + 255) / 256);
     if (nparts > 256) nparts = 256;
@@ -1001,7 +1007,7 @@ int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K) {
     if (!part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "normalize: workspace exhausted");
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
     hipLaunchKernelGGL(k_sumsq_partial, dim3(nparts), dim3(256), 0, ctx->stream, w, K, part);
-    hipLaunchKernelGGL(k_div_norm, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, part, nparts);
+    hipLaunchKernelGGL(k_div_norm, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, part, nparts, host_mirror);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
