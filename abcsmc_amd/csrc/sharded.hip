@@ -461,6 +461,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     } else {
         ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
     }
+    bool w_on_host = false;
     if (Kp == 0 || !io->theta_prev) {
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                           // AbcUtil.cpp:543-544
     } else {
@@ -473,7 +474,14 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             hipLaunchKernelGGL(k_unpad_slices, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w_slices, K, W, kmax, io->w);
             ABC_HIP(ctx, hipGetLastError());
         }
-        ABC_TRY(launch_normalize_l2(ctx, io->w, K));                                    // AbcUtil.cpp:583
+        // (as in the single-GPU driver: the normalised weights go to the pinned scratch as they are written)
+        double* mirror = nullptr;
+        if (Nn) {
+            ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
+            mirror = (double*)ctx->pin;
+        }
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror));                            // AbcUtil.cpp:583
+        w_on_host = mirror != nullptr;
     }
 
     // ---- proposals for this rank's slice of the next set --------------------------------------------------------------------
@@ -507,7 +515,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early));
+        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host));
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,
                                cfg->multivariate ? L : dv, io->next, io->seeds, cfg->Nnext_total, &prep));
     } else if (cfg->multivariate && io->L) {
