@@ -235,6 +235,8 @@ int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* 
                            const double* dv_prev, abc_wprev* out);
 int launch_fill(abc_ctx*, double* w, size_t K, double v);
 int launch_normalize_l2(abc_ctx*, double* w, size_t K, double* host_mirror = nullptr);
+// pinned scratch of the alias build over K weights: w | F | A | (pad) | E | the two index stacks (K + 1 entries each)
+static inline size_t abc_alias_pin_bytes(size_t K) { return K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t) + 16; }
 int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* L, int* status_host,
                      int* status_dev);
 // while_host_builds (optional): called after the weights' copy to the host has been queued and before the host waits for it:

@@ -522,7 +522,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
         double* mirror = nullptr;
         if (Nn) {
-            ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
+            ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;
         }
         ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror));                  // AbcUtil.cpp:583

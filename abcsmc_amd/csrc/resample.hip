@@ -648,12 +648,12 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         return ABC_OK;
     }
     // alias table: weights to the host, serial Walker build, tables back to HBM
-    ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
+    ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
     double* hw = (double*)ctx->pin;
-    double* hF = hw + K;
-    double* hE = hF + K;
-    uint32_t* hA = (uint32_t*)(hE + K);
-    uint32_t* hS = hA + K;
+    double* hF = hw + K;                                    // F[K] and A[K] adjacent: ONE host-to-device copy, nothing to move
+    uint32_t* hA = (uint32_t*)(hF + K);
+    double* hE = (double*)(((uintptr_t)(hA + K) + 7) & ~(uintptr_t)7);
+    uint32_t* hS = (uint32_t*)(hE + K);
     uint32_t* hB = hS + K + 1;
     if (!weights_on_host)         // (else already in hw: stored there by the kernel that normalised them)
         ABC_HIP(ctx, hipMemcpyAsync(hw, w, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -691,8 +691,6 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         ctx->alias_K = K;
     }
     ctx->alias_A = (uint32_t*)(ctx->alias_F + K);
-    // hF and hA are not adjacent in the pinned scratch (hE lies between them): A is moved up against F for a single copy
-    memmove(hF + K, hA, K * sizeof(uint32_t));
     ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_F, hF, K * (sizeof(double) + sizeof(uint32_t)), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
                        ctx->alias_A, K, (unsigned long long*)parent);

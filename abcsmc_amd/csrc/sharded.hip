@@ -477,7 +477,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         // (as in the single-GPU driver: the normalised weights go to the pinned scratch as they are written)
         double* mirror = nullptr;
         if (Nn) {
-            ABC_TRY(abc_pin_reserve(ctx, K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t)));
+            ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;
         }
         ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror));                            // AbcUtil.cpp:583
