@@ -759,7 +759,8 @@ __device__ __forceinline__ double dot_ahead(const double* __restrict__ a, int sa
 //   (4) r = w - sum_j (p_j'w) r_j, one row per thread;
 //   (5) partial sums of X'X r (four threads per row) and of XY'r (eight per response).
 // LDS: XY, the loadings and rotations, the partial blocks; X'X in LDS up to 64 metrics, in registers up to 128 on eight waves.
-template <int NW>
+// NB: 16 x 16 blocks per side of XY'XY (1: up to 16 responses, 2: up to 32)
+template <int NW, int NB>
 __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, const double* __restrict__ obs,
                                                       int M, int P, int A, double* __restrict__ model,
                                                       double* __restrict__ scratch /* A*M + A*A + P*A */, int xx_in_lds,
@@ -781,17 +782,17 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
     // columns with one instruction, 16-way bank-conflicted at a leading dimension of 32 or 128 doubles, conflict-free at 34 / 130
     const int LX = M + ((6 - (M & 3)) & 3);
     double* XY = lds_;                        // LX*P
-    double* qv = XY + (size_t)LX * P;         // 16
-    double* wv = qv + 16;                     // M: w before normalisation
+    double* qv = XY + (size_t)LX * P;         // 16 NB
+    double* wv = qv + 16 * NB;                // M: w before normalisation
     double* wn = wv + M;                      // M: w / |w|
     double* rv = wn + M;                      // M + 4 (zero tail: the quarter rows of step (5) may read up to 4 ceil(M/4) entries)
     double* xp = rv + M + 4;                  // 4*M: partial sums of X'X r
-    double* qp = xp + 4 * (size_t)M;          // 8*16: partial sums of XY'r
-    double* pwv = qp + 128;                   // A: p_j'w
+    double* qp = xp + 4 * (size_t)M;          // 8 * 16 NB: partial sums of XY'r
+    double* pwv = qp + 128 * NB;              // A: p_j'w
     double* Pl = pwv + A;                     // M*A
     double* Rl = Pl + (size_t)M * A;          // M*A
-    double* Sp = Rl + (size_t)M * A;          // NW*256: partial XY'XY blocks, [wave][reg][lane]
-    double* XXl = Sp + NW * 256;              // M*M (xx_in_lds)
+    double* Sp = Rl + (size_t)M * A;          // NW * NB^2 * 256: partial XY'XY blocks, [wave][block][reg][lane]
+    double* XXl = Sp + NW * NB * NB * 256;    // M*M (xx_in_lds)
     double* Hl = XXl + (xx_in_lds ? (size_t)M * M : 0);   // A*A   } PRESS statistics (vk = XXte R overlays Pl, which is dead by then)
     double* cml = Hl + (size_t)A * A;         // P*A   }
     double* addl = cml + (size_t)P * A;       // P*A   }
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
     double* Pm = model + ML.off_P;
     for (int e = tid; e < M * P; e += NT) XY[e % M + LX * (e / M)] = zwork[Z.off_XY[0] + e];
     if (tid < 4) rv[M + tid] = 0.0;
-    constexpr bool XXREG_OK = (NW == 8);
+    constexpr bool XXREG_OK = (NW == 8) && (NB == 1);      // (two blocks per side: the eigen matrices take the registers)
     const bool xx_in_reg = XXREG_OK && !xx_in_lds && M <= 128;
     const int qb = (M + 3) / 4, qb8 = (M + 7) / 8;
     double xxq[XXREG_OK ? 32 : 1];
@@ -826,7 +827,9 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
 
     for (int comp = 0; comp <= A; comp++) {
         // ---- (1) close component comp - 1 (tt, p, q, stores, deflation) and contract the slabs into the partial S -------------
-        double tt = 0.0, itt = 0.0, qc = 0.0;
+        double tt = 0.0, itt = 0.0, qc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) qc[b] = 0.0;
         if (comp > 0) {
             const int k = comp - 1;
             double t = 0.0;
@@ -838,13 +841,21 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
             STAMP16(8);
             itt = 1.0 / tt;
             STAMP16(9);
-            if (c < n) {
-                double qs = 0.0;
 #pragma unroll
-                for (int part = 0; part < 8; part++) qs += qp[part * P + c];
-                qc = qs * itt;
+            for (int b = 0; b < NB; b++) {
+                const int col = c + 16 * b;
+                if (col < n) {
+                    double qs = 0.0;
+#pragma unroll
+                    for (int part = 0; part < 8; part++) qs += qp[part * P + col];
+                    qc[b] = qs * itt;
+                }
             }
-            if (tid < n) { Qm[tid + (size_t)P * k] = qc; Ql[tid + (size_t)P * k] = qc; }
+            if (tid < n) {                       // (lanes 0 .. n - 1 of wave 0: q4 = tid >> 4 is the column block, c = tid & 15)
+                const double qj = (NB == 1 || q4 == 0) ? qc[0] : qc[NB - 1];
+                Qm[tid + (size_t)P * k] = qj;
+                Ql[tid + (size_t)P * k] = qj;
+            }
             for (int m = tid; m < M; m += NT) {
                 const double xr = (xp[m] + xp[M + m]) + (xp[2 * M + m] + xp[3 * M + m]);
                 const double pm = xr * itt, rm = rv[m];
@@ -858,15 +869,19 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
         }
         STAMP16(10);
         {
-            d4 Dp = (d4){0.0, 0.0, 0.0, 0.0};
+            d4 Dp[NB][NB];
+#pragma unroll
+            for (int I = 0; I < NB; I++)
+#pragma unroll
+                for (int J = 0; J < NB; J++) Dp[I][J] = (d4){0.0, 0.0, 0.0, 0.0};
             constexpr int SB = 2;                                  // slabs whose operands are fetched together
-            const int cc = (c < n) ? c : 0;
             for (int base = 4 * wave; base < M; base += 4 * NW * SB) {
-                double av[SB], xr[SB];
+                double av[SB][NB], xr[SB];
 #pragma unroll
                 for (int sI = 0; sI < SB; sI++) {
                     const int m = base + 4 * NW * sI + q4, mm = (m < M) ? m : 0;
-                    av[sI] = XY[mm + LX * cc];
+#pragma unroll
+                    for (int b = 0; b < NB; b++) av[sI][b] = XY[mm + LX * ((c + 16 * b < n) ? c + 16 * b : 0)];
                     xr[sI] = (comp > 0) ? (xp[mm] + xp[M + mm]) + (xp[2 * M + mm] + xp[3 * M + mm]) : 0.0;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -874,86 +889,155 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
                 for (int sI = 0; sI < SB; sI++) {
                     const int m0 = base + 4 * NW * sI, m = m0 + q4;
                     if (m0 < M) {                                  // (wave-uniform)
-                        const bool ok = m < M && c < n;
-                        double a = ok ? av[sI] : 0.0;
-                        if (comp > 0 && ok) {
-                            a -= tt * ((xr[sI] * itt) * qc);
-                            XY[m + LX * c] = a;
+                        double a[NB];
+#pragma unroll
+                        for (int b = 0; b < NB; b++) {
+                            const int col = c + 16 * b;
+                            const bool ok = m < M && col < n;
+                            a[b] = ok ? av[sI][b] : 0.0;
+                            if (comp > 0 && ok) {
+                                a[b] -= tt * ((xr[sI] * itt) * qc[b]);
+                                XY[m + LX * col] = a[b];
+                            }
                         }
-                        Dp = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, Dp, 0, 0, 0);
+#pragma unroll
+                        for (int I = 0; I < NB; I++)
+#pragma unroll
+                            for (int J = 0; J < NB; J++)
+                                Dp[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], a[I], Dp[I][J], 0, 0, 0);
                     }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) Sp[(4 * wave + r) * 64 + l] = Dp[r];
+            for (int I = 0; I < NB; I++)
+#pragma unroll
+                for (int J = 0; J < NB; J++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Sp[(((wave * NB + I) * NB + J) * 4 + r) * 64 + l] = Dp[I][J][r];
         }
         STAMP16(11);
         __syncthreads();
         STAMP16(1);
         // ---- (2) wave 0: dominant eigenvector of S = XY'XY, then w = XY q ----------------------------------------------------
         if (wave == 0) {
-            d4 Sr, D;
+            d4 Sr[NB][NB], D[NB][NB];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double v = 0.0;
+            for (int I = 0; I < NB; I++)
 #pragma unroll
-                for (int w = 0; w < NW; w++) v += Sp[(4 * w + r) * 64 + l];
-                Sr[r] = v;
-            }
-            const bool on_diag = (c & 3) == q4;                   // diagonal entry c sits in register c >> 2 of lane c + 16 (c & 3)
+                for (int J = 0; J < NB; J++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int w = 0; w < NW; w++) v += Sp[(((w * NB + I) * NB + J) * 4 + r) * 64 + l];
+                        Sr[I][J][r] = v;
+                    }
+            const bool on_diag = (c & 3) == q4;                   // diagonal entry c of a block sits in register c >> 2 of lane c + 16 (c & 3)
             auto diag_of = [&](const d4& X) {
                 const double lo = (c & 4) ? X[1] : X[0], hi = (c & 4) ? X[3] : X[2];
                 return (c & 8) ? hi : lo;
             };
-            const double tr = wave_sum(on_diag ? diag_of(Sr) : 0.0);
+            auto trace_of = [&](const d4 (&X)[NB][NB]) {
+                double t = 0.0;
+                if (on_diag) {
+#pragma unroll
+                    for (int I = 0; I < NB; I++) t += diag_of(X[I][I]);
+                }
+                return wave_sum(t);
+            };
+            const double tr = trace_of(Sr);
             const double itr = (tr > 0.0) ? __builtin_amdgcn_rcp(tr) : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) D[r] = (tr > 0.0) ? Sr[r] * itr : ((l == 0 && r == 0) ? 1.0 : 0.0);
+            for (int I = 0; I < NB; I++)
+#pragma unroll
+                for (int J = 0; J < NB; J++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        D[I][J][r] = (tr > 0.0) ? Sr[I][J][r] * itr : ((l == 0 && r == 0 && I == 0 && J == 0) ? 1.0 : 0.0);
             STAMP16(12);
             // groups of three squarings, trace normalisation, stop at trace(B^8) > 0.95 (see eig_square)
             for (int grp = 0; grp < 24; grp++) {
 #pragma unroll 1
                 for (int sq = 0; sq < 3; sq++) {
-                    // (one accumulator: back-to-back dependent MFMAs forward it; two chains cost four adds and a wait per squaring)
-                    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], D[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[1], D[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[2], D[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[3], D[3], acc, 0, 0, 0);
-                    D = acc;
+                    // (one accumulator per block: back-to-back dependent MFMAs forward it; two chains cost four adds and a wait)
+                    d4 T2[NB][NB];
+#pragma unroll
+                    for (int I = 0; I < NB; I++)
+#pragma unroll
+                        for (int J = 0; J < NB; J++) {
+                            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int K2 = 0; K2 < NB; K2++)
+#pragma unroll
+                                for (int r = 0; r < 4; r++)
+                                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[J][K2][r], D[I][K2][r], acc, 0, 0, 0);
+                            T2[I][J] = acc;
+                        }
+#pragma unroll
+                    for (int I = 0; I < NB; I++)
+#pragma unroll
+                        for (int J = 0; J < NB; J++) D[I][J] = T2[I][J];
                 }
-                const double t = wave_sum(on_diag ? diag_of(D) : 0.0);
+                const double t = trace_of(D);
                 const double inv = __builtin_amdgcn_rcp(t);
 #pragma unroll
-                for (int r = 0; r < 4; r++) D[r] *= inv;
+                for (int I = 0; I < NB; I++)
+#pragma unroll
+                    for (int J = 0; J < NB; J++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) D[I][J][r] *= inv;
                 if (t > 0.95) break;
             }
             STAMP16(13);
             // column of the converged power with the largest diagonal entry (ties -> lowest index) ...
-            double dg = (on_diag && c < n) ? diag_of(D) : -1.0, dpay = 0.0;
+            double dg = -1.0, dpay = 0.0;
             int best = c;
+            if (on_diag) {
+#pragma unroll
+                for (int I = 0; I < NB; I++) {
+                    const double v = diag_of(D[I][I]);
+                    if (16 * I + c < n && v > dg) { dg = v; best = 16 * I + c; }
+                }
+            }
             wave_argmax(dg, best, dpay);
-            // ... and one power step with S itself: (S B)[:, best] = row `best` of B S, which the MFMA leaves in register
-            // best >> 2 of the lanes (c, best & 3) -- entry c in lane c of that row of lanes
+            // ... and one power step with S itself: (S B)[:, best] = row `best` of B S; the product of block row best >> 4 of B
+            // with block column J of S leaves entries 16 J + c of that row in register (best & 15) >> 2 of the lanes
+            // (c, best & 3)
             // (with the trace-1 copy of S, so that the entries stay of order one: q is NOT brought to unit length -- only its
             // direction and sign enter w = XY q, which is normalised in (3) -- that saves a reduction, a square root and a division)
-            d4 T = D;
-            if (tr > 0.0) {
-                d4 t0 = (d4){0.0, 0.0, 0.0, 0.0};
-                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[0], Sr[0] * itr, t0, 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[1], Sr[1] * itr, t0, 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[2], Sr[2] * itr, t0, 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(D[3], Sr[3] * itr, t0, 0, 0, 0);
-                T = t0;
+            const int Ib = best >> 4, rb = best & 15;              // wave-uniform
+            double yv[NB];
+#pragma unroll
+            for (int J = 0; J < NB; J++) {
+                d4 T;
+                if (tr > 0.0) {
+                    d4 t0 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int K2 = 0; K2 < NB; K2++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const double bop = (NB == 1 || Ib == 0) ? D[0][K2][r] : D[NB - 1][K2][r];
+                            t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bop, Sr[J][K2][r] * itr, t0, 0, 0, 0);
+                        }
+                    T = t0;
+                } else {
+                    T = (NB == 1 || Ib == 0) ? D[0][J] : D[NB - 1][J];
+                }
+                const int br = rb >> 2;
+                yv[J] = (br == 0) ? T[0] : (br == 1) ? T[1] : (br == 2) ? T[2] : T[3];
             }
-            const int br = best >> 2;                              // wave-uniform
-            const double yv = (br == 0) ? T[0] : (br == 1) ? T[1] : (br == 2) ? T[2] : T[3];
-            const bool mine = (q4 == (best & 3)) && c < n;
-            const double qi = mine ? yv : 0.0;
-            double am = mine ? fabs(qi) : -1.0, sv = qi;
+            const bool myrow = q4 == (rb & 3);
+            double am = -1.0, sv = 0.0;
             int ai = c;
+#pragma unroll
+            for (int J = 0; J < NB; J++) {
+                const bool mine = myrow && 16 * J + c < n;
+                if (mine && fabs(yv[J]) > am) { am = fabs(yv[J]); ai = 16 * J + c; sv = yv[J]; }
+            }
             wave_argmax(am, ai, sv);                               // largest |component| positive (ties -> lowest index)
-            if (mine) qv[c] = (sv < 0.0) ? -qi : qi;
+#pragma unroll
+            for (int J = 0; J < NB; J++)
+                if (myrow && 16 * J + c < n) qv[16 * J + c] = (sv < 0.0) ? -yv[J] : yv[J];
             STAMP16(14);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1148,8 +1232,9 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
 #define PLS_LAUNCH_NB(NW_) do { if (P <= 16) PLS_LAUNCH(NW_, false, 1); else if (P <= 32) PLS_LAUNCH(NW_, false, 2); \
                                 else PLS_LAUNCH(NW_, false, 0); } while (0)
     // 2..16 responses on more than one wave: the latency-tuned kernel, when its arrays fit the LDS
-    const size_t lds16_d = (M + 3) * P + 16 + 3 * M + 4 + 4 * M + 128 + A + 2 * M * A + (M > 64 ? 8 : 4) * 256 + (xx_in_lds ? M * M : 0) + A * A + 3 * P * A;
-    const bool fit16 = P >= 2 && P <= 16 && M > 16 && lds16_d * sizeof(double) <= 160 * 1024;
+    const size_t nb16 = P <= 16 ? 1 : 2;
+    const size_t lds16_d = (M + 3) * P + 16 * nb16 + 3 * M + 4 + 4 * M + 128 * nb16 + A + 2 * M * A + (M > 64 ? 8 : 4) * 256 * nb16 * nb16 + (xx_in_lds ? M * M : 0) + A * A + 3 * P * A;
+    const bool fit16 = P >= 2 && P <= 32 && M > 16 && lds16_d * sizeof(double) <= 160 * 1024;
     const bool fold_z = fit16 && M * (M + P) <= 4096;
     const double* stats_in = fold_z ? stats : nullptr;
     if (!fold_z) {
@@ -1159,13 +1244,13 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     }
     if (fit16) {
         const int lb = (int)(lds16_d * sizeof(double));
-        if (M > 64) {
-            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            hipLaunchKernelGGL(k_pls_fit16<8>, dim3(1), dim3(512), lb, ctx->stream, (const double*)zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork);
-        } else {
-            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            hipLaunchKernelGGL(k_pls_fit16<4>, dim3(1), dim3(256), lb, ctx->stream, (const double*)zwork, obs, (int)M, (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork);
-        }
+#define FIT16_LAUNCH(NW_, NB_) do { \
+            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<NW_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lb)); \
+            hipLaunchKernelGGL((k_pls_fit16<NW_, NB_>), dim3(1), dim3(64 * NW_), lb, ctx->stream, (const double*)zwork, obs, (int)M, \
+                               (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork); } while (0)
+        if (M > 64) { if (nb16 == 1) FIT16_LAUNCH(8, 1); else FIT16_LAUNCH(8, 2); }
+        else { if (nb16 == 1) FIT16_LAUNCH(4, 1); else FIT16_LAUNCH(4, 2); }
+#undef FIT16_LAUNCH
     } else
     if (gbase) {                                    // wide sets: eight waves in every case
         if (P <= 16) PLS_LAUNCH(8, true, 1); else PLS_LAUNCH(8, true, 0);

@@ -95,13 +95,13 @@ def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
 
 def test_pls_fit_random_shapes_match_oracle_and_repeat_bitwise(gpu_ctx, oracle):
     """the latency-tuned model fit (k_pls_fit16: five barriers per component, per-wave recomputation instead of cross-wave
-    reductions, register-resident X'X) on 24 random shapes: loadings against the oracle's independent algorithm, and the
+    reductions, register-resident X'X) on 36 random shapes (2..16 and 17..32 responses): loadings against the oracle's independent algorithm, and the
     whole model record bit-identical between two runs of the same input (a missing barrier shows up as run-to-run noise)"""
     from abcsmc_amd import abcutil
     rng = np.random.default_rng(20260103)
-    for case in range(24):
+    for case in range(36):
         M = int(rng.integers(17, 141))
-        P = int(rng.integers(2, 17))
+        P = int(rng.integers(2, 17)) if case < 24 else int(rng.integers(17, 33))      # one / two 16 x 16 blocks per side of XY'XY
         A = int(rng.integers(1, min(M, 20) + 1))
         N = int(rng.integers(400, 2500))
         f = float(rng.choice([0.4, 0.5, 0.63, 1.0]))
