@@ -797,6 +797,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
     double* cml = Hl + (size_t)A * A;         // P*A   }
     double* addl = cml + (size_t)P * A;       // P*A   }
     double* Ql = addl + (size_t)P * A;        // P*A: Q (LDS copy)
+    double* Ex = Ql + (size_t)P * A;          // NB == 2: two exchange buffers of the distributed squaring, NB^2 * 256 each
     const double* XXtr = zwork + Z.off_XX[0];
     if (xx_in_lds)
         for (int e = tid; e < M * M; e += NT) XXl[e] = XXtr[e];
@@ -919,8 +920,26 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
         __syncthreads();
         STAMP16(1);
         // ---- (2) wave 0: dominant eigenvector of S = XY'XY, then w = XY q ----------------------------------------------------
-        if (wave == 0) {
-            d4 Sr[NB][NB], D[NB][NB];
+        // Two blocks per side: the four blocks of a squaring are dealt out to waves 0..3 (8 dependent MFMAs each instead of 32 on
+        // one wave), exchanged through LDS (two buffers in turn: one barrier per squaring); every wave reads the product back and
+        // takes the trace itself, so the loop's control flow is uniform over the work-group without a flag.
+        constexpr bool SPLITSQ = (NB == 2);
+        d4 Sr[NB][NB], D[NB][NB];
+        double tr = 0.0, itr = 0.0;
+        const bool on_diag = (c & 3) == q4;                   // diagonal entry c of a block sits in register c >> 2 of lane c + 16 (c & 3)
+        auto diag_of = [&](const d4& X) {
+            const double lo = (c & 4) ? X[1] : X[0], hi = (c & 4) ? X[3] : X[2];
+            return (c & 8) ? hi : lo;
+        };
+        auto trace_of = [&](const d4 (&X)[NB][NB]) {
+            double t = 0.0;
+            if (on_diag) {
+#pragma unroll
+                for (int I = 0; I < NB; I++) t += diag_of(X[I][I]);
+            }
+            return wave_sum(t);
+        };
+        if (SPLITSQ || wave == 0) {
 #pragma unroll
             for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -932,21 +951,8 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
                         for (int w = 0; w < NW; w++) v += Sp[(((w * NB + I) * NB + J) * 4 + r) * 64 + l];
                         Sr[I][J][r] = v;
                     }
-            const bool on_diag = (c & 3) == q4;                   // diagonal entry c of a block sits in register c >> 2 of lane c + 16 (c & 3)
-            auto diag_of = [&](const d4& X) {
-                const double lo = (c & 4) ? X[1] : X[0], hi = (c & 4) ? X[3] : X[2];
-                return (c & 8) ? hi : lo;
-            };
-            auto trace_of = [&](const d4 (&X)[NB][NB]) {
-                double t = 0.0;
-                if (on_diag) {
-#pragma unroll
-                    for (int I = 0; I < NB; I++) t += diag_of(X[I][I]);
-                }
-                return wave_sum(t);
-            };
-            const double tr = trace_of(Sr);
-            const double itr = (tr > 0.0) ? __builtin_amdgcn_rcp(tr) : 0.0;
+            tr = trace_of(Sr);
+            itr = (tr > 0.0) ? __builtin_amdgcn_rcp(tr) : 0.0;
 #pragma unroll
             for (int I = 0; I < NB; I++)
 #pragma unroll
@@ -954,7 +960,47 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         D[I][J][r] = (tr > 0.0) ? Sr[I][J][r] * itr : ((l == 0 && r == 0 && I == 0 && J == 0) ? 1.0 : 0.0);
-            STAMP16(12);
+        }
+        STAMP16(12);
+        if constexpr (SPLITSQ) {
+            const int bI = (wave >> 1) & 1, bJ = wave & 1;
+            int buf = 0;
+            for (int grp = 0; grp < 24; grp++) {
+#pragma unroll 1
+                for (int sq = 0; sq < 3; sq++) {
+                    double* ex = Ex + buf * (NB * NB * 256);
+                    if (wave < 4) {
+                        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int K2 = 0; K2 < NB; K2++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const double aop = bJ ? D[1][K2][r] : D[0][K2][r], bop = bI ? D[1][K2][r] : D[0][K2][r];
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) ex[((bI * NB + bJ) * 4 + r) * 64 + l] = acc[r];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int I = 0; I < NB; I++)
+#pragma unroll
+                        for (int J = 0; J < NB; J++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) D[I][J][r] = ex[((I * NB + J) * 4 + r) * 64 + l];
+                    buf ^= 1;
+                }
+                const double t = trace_of(D);
+                const double inv = __builtin_amdgcn_rcp(t);
+#pragma unroll
+                for (int I = 0; I < NB; I++)
+#pragma unroll
+                    for (int J = 0; J < NB; J++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) D[I][J][r] *= inv;
+                if (t > 0.95) break;
+            }
+        } else if (wave == 0) {
             // groups of three squarings, trace normalisation, stop at trace(B^8) > 0.95 (see eig_square)
             for (int grp = 0; grp < 24; grp++) {
 #pragma unroll 1
@@ -988,7 +1034,9 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
                         for (int r = 0; r < 4; r++) D[I][J][r] *= inv;
                 if (t > 0.95) break;
             }
-            STAMP16(13);
+        }
+        STAMP16(13);
+        if (wave == 0) {
             // column of the converged power with the largest diagonal entry (ties -> lowest index) ...
             double dg = -1.0, dpay = 0.0;
             int best = c;
@@ -1233,7 +1281,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
                                 else PLS_LAUNCH(NW_, false, 0); } while (0)
     // 2..16 responses on more than one wave: the latency-tuned kernel, when its arrays fit the LDS
     const size_t nb16 = P <= 16 ? 1 : 2;
-    const size_t lds16_d = (M + 3) * P + 16 * nb16 + 3 * M + 4 + 4 * M + 128 * nb16 + A + 2 * M * A + (M > 64 ? 8 : 4) * 256 * nb16 * nb16 + (xx_in_lds ? M * M : 0) + A * A + 3 * P * A;
+    const size_t lds16_d = (M + 3) * P + 16 * nb16 + 3 * M + 4 + 4 * M + 128 * nb16 + A + 2 * M * A + (M > 64 ? 8 : 4) * 256 * nb16 * nb16 + (xx_in_lds ? M * M : 0) + A * A + 3 * P * A + (nb16 == 2 ? 2048 : 0);
     const bool fit16 = P >= 2 && P <= 32 && M > 16 && lds16_d * sizeof(double) <= 160 * 1024;
     const bool fold_z = fit16 && M * (M + P) <= 4096;
     const double* stats_in = fold_z ? stats : nullptr;
