@@ -19,7 +19,7 @@ for (M, P, A) in [(32, 16, 8), (64, 32, 8), (128, 16, 32)]:
     out = (C.c_double * 64)(); C.CDLL(_lib.SO_PATH).abc_debug_pls_stamps(out)
     names = {9: "prologue", 1: "S=XY'XY", 2: "eig squaring", 3: "eigvec post + w", 4: "normalise w, r-update", 5: "XX r, p",
              6: "q, deflate", 7: "(loop exit)", 8: "PRESS", 0: ""}
-    if 2 <= P <= 16 and M > 16:
+    if 2 <= P <= 32 and M > 16:
         names = {1: "close prev + deflate + partial S", 2: "wave 0: eig + w", 3: "(wait) + |w|, projections", 4: "r update", 5: "X'X r, XY'r partials",
                  6: "(loop exit)", 7: "PRESS + scores", 0: "", 8: "1a tt", 9: "1b 1/tt", 10: "1c q, stores", 11: "1d slabs", 12: "2a sum S, trace", 13: "2b squarings", 14: "2c column, power step, q"}
     tot = sum(out[:16])
