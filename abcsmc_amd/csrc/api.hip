@@ -37,7 +37,7 @@ int abc_pin_reserve(abc_ctx* ctx, size_t bytes) {
 // arena needed by the Wilcoxon reduction: scores + 4 key/value buffers over (segments x validation rows)
 size_t abc_wx_need(size_t nt, size_t P, size_t A) {
     const size_t seg = P * (A > 0 ? A - 1 : 0);
-    return nt * A * 8 + 4 * seg * nt * 8 + 256 * ((seg * nt) / 2048 + 2) * 4 + (1u << 20);
+    return nt * A * 8 + 4 * seg * nt * 8 + 256 * ((seg * nt) / 2048 + 2) * 4 + seg * 32 + P * 8 + (1u << 20);
 }
 
 // generous upper bound of the arena needed by any single API call on these sizes

@@ -12,27 +12,34 @@
 
 namespace {
 
-constexpr int MAXSEG = 1024;
+constexpr size_t MAXSEG = 65535;      // (response, candidate) tests of one call: the segment id travels in two payload bytes of the
+                                      // batched sort and in grid.y; P (A - 1) beyond that is ABC_ERR_UNSUPPORTED
 
-struct WxPlan {            // built on the device from the model record
+struct WxPlan {            // built on the device from the model record; the arrays live in the workspace (P (A - 1), P entries)
     int nseg;
-    int seg_j[MAXSEG];     // response
-    int seg_a[MAXSEG];     // candidate a' (1-based)
-    int astar[64];         // PRESS optimum per response
+    int pad_;
+    int* seg_j;            // response
+    int* seg_a;            // candidate a' (1-based)
+    int* astar;            // PRESS optimum per response
 };
 
 __global__ void k_wx_plan(const double* __restrict__ model, int M, int P, int A, WxPlan* __restrict__ plan,
+                          int* __restrict__ seg_j, int* __restrict__ seg_a, int* __restrict__ astar, int nseg_max,
                           unsigned long long* __restrict__ nz, double* __restrict__ W) {
+    for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; }
     if (threadIdx.x != 0) return;
     const ModelLayout ML = model_layout(M, P, A);
     int ns = 0;
     for (int j = 0; j < P; j++) {
         const int as = (int)model[ML.off_per + j];
-        plan->astar[j] = as;
-        for (int a = 1; a < as && ns < MAXSEG; a++) { plan->seg_j[ns] = j; plan->seg_a[ns] = a; ns++; }
+        astar[j] = as;
+        for (int a = 1; a < as && ns < nseg_max; a++) { seg_j[ns] = j; seg_a[ns] = a; ns++; }
     }
     plan->nseg = ns;
-    for (int s = 0; s < MAXSEG; s++) { nz[s] = 0; W[s] = 0.0; }
+    plan->pad_ = 0;
+    plan->seg_j = seg_j;
+    plan->seg_a = seg_a;
+    plan->astar = astar;
 }
 
 // scores of the validation rows: S[i + nt*k] = sum_m z(x_im) R[m,k]  (m ascending fma chain, as the oracle)
@@ -56,6 +63,30 @@ __global__ __launch_bounds__(256) void k_wx_scores(const double* __restrict__ X,
 #pragma unroll
     for (int k = 0; k < KC; k++)
         if (k < A) S[i + nt * k] = s[k];
+}
+
+// more than 32 components: chunks of 32 (the row's metrics re-read per chunk; same fma chain per component)
+__global__ __launch_bounds__(256) void k_wx_scores_wide(const double* __restrict__ X, size_t ldx, size_t row_test, size_t nt,
+                                                        int M, int P, int A, const double* __restrict__ model,
+                                                        double* __restrict__ S) {
+    const ModelLayout ML = model_layout(M, P, A);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    for (int k0 = 0; k0 < A; k0 += 32) {
+        double s[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) s[k] = 0.0;
+        for (int m = 0; m < M; m++) {
+            const double sd = model[ML.off_sd + m];
+            const double z = (sd == 0.0) ? 0.0 : (X[row_test + i + ldx * m] - model[ML.off_mean + m]) / sd;
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                if (k0 + k < A) s[k] = fma(z, model[ML.off_R + m + (size_t)M * (k0 + k)], s[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            if (k0 + k < A) S[i + nt * (k0 + k)] = s[k];
+    }
 }
 
 // one thread per (validation row, segment): key / payload of the paired difference
@@ -154,23 +185,27 @@ __global__ void k_wx_decide(double* __restrict__ model, int M, int P, int A, con
 int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
                     size_t P, size_t A, size_t row_test, double* model) {
     if (row_test >= n) return ABC_OK;                    // empty validation set: nothing to reduce
-    if (P > 64 || A > 32 || P * (A - 1) > (size_t)MAXSEG)
-        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "wilcoxon: P=%zu A=%zu outside the supported range", P, A);
+    if (P * (A - 1) > MAXSEG)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "wilcoxon: P (A - 1) = %zu tests, more than %zu", P * (A - 1), MAXSEG);
     StageTimer tm(ctx, ST_PLS_MODEL);
     const size_t nt = n - row_test;
     const size_t nseg_max = P * (A - 1);
     if (nseg_max == 0) return ABC_OK;
     WxPlan* plan = (WxPlan*)abc_ws_alloc(ctx, sizeof(WxPlan));
-    unsigned long long* nz = (unsigned long long*)abc_ws_alloc(ctx, MAXSEG * 8);
-    double* W = (double*)abc_ws_alloc(ctx, MAXSEG * 8);
+    int* seg_j = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    int* seg_a = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    int* astar = (int*)abc_ws_alloc(ctx, P * sizeof(int));
+    unsigned long long* nz = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * 8);
+    double* W = (double*)abc_ws_alloc(ctx, nseg_max * 8);
     double* S = (double*)abc_ws_alloc(ctx, nt * A * 8);
     unsigned long long* key0 = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
     unsigned long long* val0 = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
     unsigned long long* key1 = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
     unsigned long long* val1 = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
-    if (!plan || !nz || !W || !S || !key0 || !val0 || !key1 || !val1)
+    if (!plan || !seg_j || !seg_a || !astar || !nz || !W || !S || !key0 || !val0 || !key1 || !val1)
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu segments x %zu rows)", nseg_max, nt);
-    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(64), 0, ctx->stream, model, (int)M, (int)P, (int)A, plan, nz, W);
+    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar,
+                       (int)nseg_max, nz, W);
     // the number of segments actually needed lives on the device; size the grid for the maximum, idle blocks exit
     int nseg_host = 0;
     ABC_HIP(ctx, hipMemcpyAsync(&nseg_host, &plan->nseg, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -179,9 +214,14 @@ int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, si
     const unsigned rb = (unsigned)((nt + 255) / 256);
     int KC = 1;
     while (KC < (int)A) KC *= 2;
+    if (A > 32) {
+        hipLaunchKernelGGL(k_wx_scores_wide, dim3(rb), dim3(256), 0, ctx->stream, X, ldx, row_test, nt, (int)M, (int)P, (int)A, model, S);
+        KC = 0;
+    }
 #define LAUNCH_SC(KCV) hipLaunchKernelGGL(k_wx_scores<KCV>, dim3(rb), dim3(256), 0, ctx->stream, X, ldx, row_test, nt, \
                                           (int)M, (int)P, (int)A, model, S)
     switch (KC) {
+        case 0: break;
         case 1: LAUNCH_SC(1); break;
         case 2: LAUNCH_SC(2); break;
         case 4: LAUNCH_SC(4); break;

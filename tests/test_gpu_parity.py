@@ -927,7 +927,9 @@ def test_cxx_facade_demo(gpu_ctx, tmp_path):
 # Wilcoxon-reduced component count ([PLS] optimal_num_components)
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,M,P,A,f,seed", [(400, 10, 4, 0, 0.5, 1), (1000, 32, 16, 8, 0.5, 2), (250, 12, 3, 3, 0.6, 3),
-                                             (3000, 20, 6, 6, 0.5, 4), (120, 8, 5, 5, 0.5, 5), (5000, 32, 16, 8, 0.5, 6)])
+                                             (3000, 20, 6, 6, 0.5, 4), (120, 8, 5, 5, 0.5, 5), (5000, 32, 16, 8, 0.5, 6),
+                                             (600, 48, 70, 6, 0.5, 7),      # more than 64 responses
+                                             (500, 44, 9, 40, 0.5, 8)])     # more than 32 components (scores in chunks of 32)
 def test_particle_ranking_pls_wilcoxon_rule(gpu_ctx, oracle, N, M, P, A, f, seed):
     from abcsmc_amd import abcutil, _lib
     wl, X, Y, obs = _wl(M, P, N, seed)
@@ -1137,14 +1139,13 @@ def test_error_codes_and_messages(gpu_ctx):
     rc = L.abc_particle_ranking_pls(h, X.ctypes.data, Y.ctypes.data, X[0].copy().ctypes.data, 50, 4, 2, 0.5, 0, 7, 10,
                                     idx.ctypes.data, None, None, None, None, None)
     assert rc == -1 and b"rule" in L.abc_last_error(h)
-    # the Wilcoxon component rule with more than 32 components -> ABC_ERR_UNSUPPORTED (-4), not a crash (the default
-    # minimum-PRESS rule takes any number: test_particle_ranking_pls at 40)
-    X70 = np.asfortranarray(np.random.default_rng(2).normal(size=(200, 80)))
-    Y70 = np.asfortranarray(np.random.default_rng(3).normal(size=(200, 40)))
+    # more components than metrics -> ABC_ERR_INVALID (-1), not a crash
+    X70 = np.asfortranarray(np.random.default_rng(2).normal(size=(200, 8)))
+    Y70 = np.asfortranarray(np.random.default_rng(3).normal(size=(200, 4)))
     idx70 = np.zeros(10, dtype=np.uint64)
-    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 80, 40, 0.5, 40,
+    rc = L.abc_particle_ranking_pls(h, X70.ctypes.data, Y70.ctypes.data, X70[0].copy().ctypes.data, 200, 8, 4, 0.5, 9,
                                     _lib.RULE_WILCOXON, 10, idx70.ctypes.data, None, None, None, None, None)
-    assert rc == -4 and b"wilcoxon" in L.abc_last_error(h)
+    assert rc == -1 and b"components" in L.abc_last_error(h)
     th = np.asfortranarray(np.random.default_rng(2).normal(size=(20, 70)))
     # a later valid call on the same context still works
     assert abcutil.calculate_doubled_variance(th[:, :3], ctx=gpu_ctx).shape == (3,)
