@@ -279,6 +279,63 @@ def test_sort_pairs(gpu_ctx, oracle):
     assert np.array_equal(k.cpu().numpy(), key[o]) and np.array_equal(v.cpu().numpy(), val[o])
 
 
+def _tie_heavy_keys(rng, n):
+    """distances with every kind of trouble: rounded values (massive ties), 80 binades, zeros, subnormals, huge, inf"""
+    d = np.abs(rng.normal(size=n)) * 2.0 ** rng.integers(-40, 40, size=n)
+    q = rng.integers(0, 4, size=n)
+    d = np.where(q == 0, np.round(np.abs(rng.normal(size=n)), 2), d)       # ~300 distinct values over a quarter of the keys
+    d[rng.integers(0, n, 200)] = 0.0
+    d[rng.integers(0, n, 200)] = np.inf
+    d[rng.integers(0, n, 200)] = 5e-324
+    d[rng.integers(0, n, 200)] = 1e308
+    return d
+
+
+@pytest.mark.parametrize("n", [(1 << 18) + 1, 500_000, 1_000_000, 2_500_000])
+def test_sort_pairs_beyond_the_chunk_sort(gpu_ctx, n):
+    """more than SC_MAX_N = 2^18 pairs: the eight 8-bit LSD radix passes (k_sort_hist / k_sort_scan / k_sort_scatter with
+    n / ST_CHUNK histogram blocks under the one-block scan, select.hip: sort_pairs_u64) -- the path K = 1e6 winners of
+    BASELINE configs[3] and any 2-rank run of it (K / G = 5e5) take.  Stable order = numpy's stable argsort"""
+    import torch
+    from abcsmc_amd._lib import lib
+    rng = np.random.default_rng(n)
+    key = _tie_heavy_keys(rng, n)
+    val = rng.permutation(n).astype(np.int64)
+    k, v = torch.from_numpy(key.copy()).cuda(), torch.from_numpy(val.copy()).cuda()
+    gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    gpu_ctx.check(lib().abc_sort_pairs_dev(gpu_ctx.handle, k.data_ptr(), v.data_ptr(), key.size))
+    torch.cuda.synchronize()
+    o = np.argsort(key, kind="stable")
+    assert np.array_equal(k.cpu().numpy(), key[o]) and np.array_equal(v.cpu().numpy(), val[o])
+
+
+@pytest.mark.parametrize("n,K,kind", [
+    ((1 << 18) + 1, (1 << 18) + 1, "ties"),     # K == n just beyond the chunk sort: full LSD sort of all keys
+    (600_000, (1 << 18) + 1, "ties"),           # K one beyond the bin selection's reach (2 K <= n): radix select + LSD sort
+    (1_000_000, 500_000, "chi"),                # 2 K == n, K > 2^18: radix select
+    (1_000_000, 500_001, "ties"),               # 2 K > n
+    (2_000_000, 1_000_000, "ties"),             # configs[3] winners on one GPU
+    (3_000_000, 1_000_000, "ties_at_threshold"),
+    (1_000_000, 1_000_000, "chi"),              # K == n
+])
+def test_select_smallest_beyond_two_to_the_18(gpu_ctx, oracle, n, K, kind):
+    """K > 2^18 or 2 K > n: six-pass radix select (select.hip: select_by_radix), stable compaction, and for more than 2^18
+    winners the LSD radix sort; indices and distances bit-exact against the oracle's (distance, index) order"""
+    rng = np.random.default_rng(n + 13 * K)
+    if kind == "chi":
+        d = np.sqrt((rng.normal(size=(n, 8)) ** 2).sum(axis=1))
+    elif kind == "ties":
+        d = _tie_heavy_keys(rng, n)
+    else:
+        d = np.abs(rng.normal(size=n))
+        t = np.partition(d, K - 1)[K - 1]
+        d[rng.integers(0, n, 5000)] = t                 # 5000 more keys equal to the K-th: lowest indices win
+    idx, out = _select(gpu_ctx, d, K, base=1 << 40)
+    ref = oracle.ordered(d)[:K]
+    assert np.array_equal(idx, ref + np.uint64(1 << 40))
+    assert np.array_equal(out, d[ref.astype(np.int64)])
+
+
 # ---------------------------------------------------------------------------------------------------
 # doubled variance, weights, MVN setup
 # ---------------------------------------------------------------------------------------------------
@@ -827,6 +884,26 @@ def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890):
     return wl, X, Y, obs, spec, prev, gen, r
 
 
+def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=67890):
+    """_run_generation with the synthetic set generated ON the GPU (synthetic.Workload.rows_device: numpy takes minutes at
+    1e7 rows) and downloaded for the oracle: both sides see the same bits"""
+    import torch
+    from abcsmc_amd import abcutil, device, synthetic, _lib
+    dev = "cuda:0"
+    wl = synthetic.Workload(M, P, 12345)
+    dX, dY = wl.rows_device(0, N, dev)
+    obs = wl.observed()
+    spec = wl.prior_spec()
+    dprev = wl.previous_set_device(Kp, dev)
+    X, Y = dX.cpu().numpy().T, dY.cpu().numpy().T                  # (N, c) column-major views of the downloads
+    prev = (dprev[0].cpu().numpy().T, dprev[1].cpu().numpy(), dprev[2].cpu().numpy())
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, multivariate=multivariate, device=dev)
+    r = abcutil.rng(seed)
+    gen.run(dX, dY, device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
+    torch.cuda.synchronize()
+    return wl, X, Y, obs, spec, prev, gen, r
+
+
 @pytest.mark.parametrize("multivariate,Kp", [(True, 400), (False, 400), (True, 0)])
 def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp):
     from abcsmc_amd import device
@@ -958,13 +1035,16 @@ def test_wilcoxon_rule_reduces_somewhere(oracle):
     assert hit >= 1
 
 
-def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol):
-    """A full generation at a BASELINE size: invariants that do not need the O(K K' P) oracle -- sortedness, selection =
-    the oracle's ordering of the device's own distances (bit-exact), L2 norm, weights of a few rows against the oracle
-    formula restricted to those rows, parents = the oracle's resampling of the device's own weights (bit-exact),
-    finite proposals inside the prior support, MVN factor against numpy."""
+def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol, device_inputs=False, oracle_model=True):
+    """A full generation at a BASELINE size.  (1) The PLS model at size: the oracle's own ranking of the same set (its
+    independent algorithm) -- component count equal, every loading column within 1e-6 of the oracle's, the K winners the
+    oracle's up to near-ties, their distances within 1e-6.  (2) Invariants that do not need the O(K K' P) oracle --
+    sortedness, selection = the oracle's ordering of the device's own distances (bit-exact), L2 norm, weights of a few rows
+    against the oracle formula restricted to those rows, parents = the oracle's resampling of the device's own weights
+    (bit-exact), finite proposals inside the prior support, MVN factor against numpy."""
     from abcsmc_amd import abcutil, device
-    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    run = _run_generation_device_inputs if device_inputs else _run_generation
+    wl, X, Y, obs, spec, prev, gen, r = run(N, M, P, K, Kp, Nn, A, True)
     idx, dist = gen.idx.cpu().numpy(), gen.dist.cpu().numpy()
     assert np.all(np.diff(dist) >= 0) and len(np.unique(idx)) == K
     # full distance vector through the staged entry point, then the oracle's argsort on those exact values
@@ -975,6 +1055,27 @@ def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol)
     ref = oracle.ordered(full)[:K]
     assert np.array_equal(idx.astype(np.uint64), ref)                       # bit-exact selection at full size
     assert np.array_equal(dist, full[ref.astype(np.int64)])
+    if oracle_model:
+        # the model against the oracle's independent fit of the same N rows (AbcUtil.cpp:423-458)
+        o = oracle.particle_ranking_pls(X, Y, obs, 0.5, A)
+        assert g["ncomp"] == o["ncomp"]
+        assert np.allclose(g["mean"], o["mean"], rtol=1e-12) and np.allclose(g["sd"], o["sd"], rtol=1e-11)
+        worst = max(np.linalg.norm(g["R"][:, k] - o["R"][:, k]) / np.linalg.norm(o["R"][:, k]) for k in range(o["ncomp"]))
+        assert worst <= RTOL, worst                                         # loadings: 1e-6 of the column norm
+        od = o["dist"]
+        derr = float(np.max(np.abs(full - od) / od))
+        assert derr <= RTOL, derr                                           # all N distances
+        # the K winners are the oracle's up to near-ties: position by position the oracle's distance of the device's
+        # winner equals the oracle's distance of its own winner to 1e-7 (a tenth of the bar; measured ~1e-10: the models
+        # differ by rounding only)
+        oi = o["idx"][:K].astype(np.int64)
+        perr = float(np.max(np.abs(od[idx] - od[oi]) / od[oi]))
+        ndiff = len(np.setdiff1d(idx, oi))
+        print("model at size N=%d M=%d P=%d: ncomp %d, worst loading column %.2e, worst distance %.2e, winners: position "
+              "error %.2e, %d of %d differ as sets" % (N, M, P, o["ncomp"], worst, derr, perr, ndiff, K))
+        assert perr <= 1e-7, perr
+        assert ndiff <= max(4, K // 1000), ndiff                            # ... and the sets differ at the cut only
+        del o, od
     # the distances themselves: oracle projection with the device's model on a sample of rows
     w = gen.w.cpu().numpy()
     assert np.all(w >= 0) and abs(np.linalg.norm(w) - 1.0) < 1e-10
@@ -1013,6 +1114,21 @@ def test_generation_config4_shard_size_properties(gpu_ctx, oracle):
     """BASELINE configs[3] (10 M x 32 parameters x 64 metrics on 8 GPUs) at the size of one GPU's shard: N = 1.25e6,
     K = K' = 1.25e5 -- the four-wave LDS-DMA Gram kernel (6 column blocks), two-chunk split-operand weight kernel"""
     _generation_size_properties(gpu_ctx, oracle, 1_250_000, 64, 32, 125_000, 125_000, 1_250_000, 8, KDE_TOL["auto"])
+
+
+def test_generation_config4_full_size_on_one_gpu(gpu_ctx, oracle):
+    """BASELINE configs[3] at its STATED size on one MI355X: N = 1e7 particles x 32 parameters x 64 metrics, K = K' = 1e6
+    (AbcSmc.cpp:645-646: the reference keeps whatever K the configuration says), N_next = 1e7.  1e12 weight pairs; K = 1e6
+    winners go through the radix select and the LSD radix sort; inputs generated on the device (7.7 GB)"""
+    _generation_size_properties(gpu_ctx, oracle, 10_000_000, 64, 32, 1_000_000, 1_000_000, 10_000_000, 8, KDE_TOL["auto"],
+                                device_inputs=True)
+
+
+def test_generation_config5_full_size_on_one_gpu(gpu_ctx, oracle):
+    """BASELINE configs[4] at its STATED size on one MI355X: N = 1e6 particles x 16 parameters x 128 metrics, 32 PLS
+    components, K = K' = 1e5, N_next = 1e6"""
+    _generation_size_properties(gpu_ctx, oracle, 1_000_000, 128, 16, 100_000, 100_000, 1_000_000, 32, KDE_TOL["auto"],
+                                device_inputs=True)
 
 
 def test_generation_config5_shard_size_properties(gpu_ctx, oracle):
