@@ -18,10 +18,10 @@ K = N // 10
 Kp = 0 if mode == "set0" else K
 dev = "cuda:0"
 wl = synthetic.Workload(M, P, seed=12345)
-X, Y = wl.rows(0, N)
-dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(wl.observed(), dev)
+dX, dY = wl.rows_device(0, N, dev)
+dobs = device.colmajor(wl.observed(), dev)
 dpri = device.priors_to_device(_lib.make_priors(wl.prior_spec()), dev)
-prev = [device.colmajor(a, dev) for a in wl.previous_set(Kp)] if Kp else []
+prev = list(wl.previous_set_device(Kp, dev)) if Kp else []
 ctx = _lib.default_context(0)
 gen = device.Generation(N, M, P, K, Kp, N, 0.5, A, multivariate=True, device=dev, ctx=ctx)
 rng = abcutil.rng(67890)
