@@ -1,6 +1,7 @@
 """ctypes binding of libabcsmc_hip.so -- exactly the symbols include/abcsmc_hip.h declares."""
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ABCSMC_HIP_SO: developer override for A/B runs of diagnostic builds (scripts/); default = the in-tree build
@@ -246,9 +247,29 @@ class Context:
 
     def comm_init_callbacks(self, world, rank, all_reduce_sum, all_gather, broadcast):
         """collectives supplied by the caller: python callables (buf_ptr, count, dtype, stream) etc. -> 0 on success"""
-        self._cb = CommCallbacks(ALL_REDUCE_FN(lambda u, b, n, dt, st: int(all_reduce_sum(b, n, dt, st))),
-                                 ALL_GATHER_FN(lambda u, s, r, nb, st: int(all_gather(s, r, nb, st))),
-                                 BROADCAST_FN(lambda u, b, nb, root, st: int(broadcast(b, nb, root, st))), None)
+        # A Python exception inside a ctypes callback is printed and turned into a return value of 0 -- which the C++ driver
+        # reads as success and carries on with un-reduced statistics.  Every callback body is therefore guarded: an exception
+        # (transport timeout, shape error) is logged, remembered (Context.comm_callback_error) and reported as a non-zero
+        # status, so the collective -- and the generation -- fail with ABC_ERR_COMM.
+        self.comm_callback_error = None
+
+        def guarded(fn, what):
+            def run(*a):
+                try:
+                    rc = fn(*a)
+                    return int(rc) if rc is not None else 0
+                except BaseException as e:       # noqa: BLE001 -- nothing may propagate into the C++ caller
+                    import traceback
+                    self.comm_callback_error = e
+                    sys.stderr.write("abcsmc_amd: %s callback raised %s: %s\n" % (what, type(e).__name__, e))
+                    traceback.print_exc()
+                    return 1
+            return run
+
+        ar, ag, bc = guarded(all_reduce_sum, "all_reduce_sum"), guarded(all_gather, "all_gather"), guarded(broadcast, "broadcast")
+        self._cb = CommCallbacks(ALL_REDUCE_FN(lambda u, b, n, dt, st: ar(b, n, dt, st)),
+                                 ALL_GATHER_FN(lambda u, s, r, nb, st: ag(s, r, nb, st)),
+                                 BROADCAST_FN(lambda u, b, nb, root, st: bc(b, nb, root, st)), None)
         self.check(lib().abc_comm_init_callbacks(self._h, int(world), int(rank), C.byref(self._cb)))
 
     def comm_info(self):

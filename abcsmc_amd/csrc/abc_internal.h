@@ -213,8 +213,12 @@ int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* v
 // Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n)
 int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
                     size_t A, size_t row_test, double* model);
+// sel_fail / sel_fail_pin (fused drivers): the bin selection's give-up flag is stored into the pinned status block by this
+// kernel, and the proposals' give-up counter is snapshotted into its second slot
 int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, size_t P,
-                       const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt);
+                       const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt,
+                       const int* sel_fail = nullptr, int* sel_fail_pin = nullptr);
+#define ABC_INTERNAL_RETRY 1      // launch_resample: the caller's abort flag was set when the host looked (not an error code of the ABI)
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
 // K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor
 int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);
@@ -245,7 +249,10 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
 // raw_ready (optional): the n taus2 outputs of the draws, already queued on the side stream (abc_rng_streams_early)
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr,
-                    bool uniform_weights = false, const uint32_t* raw_ready = nullptr, bool weights_on_host = false);
+                    bool uniform_weights = false, const uint32_t* raw_ready = nullptr, bool weights_on_host = false,
+                    const volatile int* abort_flag = nullptr);
+// abort_flag (pinned, optional): read right after the host has waited for the weights; non-zero -> nothing more is queued and
+// ABC_INTERNAL_RETRY is returned (the weights belong to a placeholder selection: the caller repeats its generation)
 // weights_on_host: the kernel that normalised w already stored them at the start of the context's pinned scratch
 // (launch_normalize_l2's host_mirror, reserved with the size used here): nothing to copy
 // Queues on the context's side stream everything of the proposals that depends on the rng state alone: the taus2 outputs

@@ -496,7 +496,28 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
 
     double* theta = io->theta ? io->theta : (double*)abc_ws_alloc(ctx, K * P * 8);
     if (!theta) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
-    ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K));
+    // (the gather is the first kernel behind the selection: it also stores the selection's give-up flag into the pinned block)
+    int* pfail_early = (int*)(ctx->status_pin + 40);
+    *pfail_early = 0;
+    const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
+    ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early));
+    // A failed bin selection (degenerate distances) leaves placeholder winners: everything downstream of it is repeated with
+    // the radix select.  Weighted generations learn of it at the host's wait for the weights (launch_resample's abort flag),
+    // before the alias table, the draws and the proposals of the placeholder are queued; set 0 has no host wait before its
+    // end and finds out there.  Either way the proposals' give-up counter is put back to its snapshot.
+    auto repeat_with_radix = [&]() -> int {
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->side) ABC_HIP(ctx, hipStreamSynchronize(ctx->side));
+        if (ctx->giveups_dev)
+            ABC_HIP(ctx, hipMemcpyAsync(ctx->giveups_dev, ctx->giveups_dev + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->sel_bins_ran = false;
+        ctx->ws_off = ws_entry;
+        if (rng) *rng = rng_entry;
+        ctx->sel_force_radix = true;
+        const int rc = generation_core(ctx, cfg, io, rng, ncomp_host, simple, model_out);
+        ctx->sel_force_radix = false;
+        return rc;
+    };
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;        // moments of the posterior: shared by dv and the MVN factor
     // Weighted generations with proposals: the kernel density of the weights uses the PREVIOUS set's variance, so the new set's
@@ -569,7 +590,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, 0, q->Nn, q->seeds, q->Nn, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host));
+        {
+            const int rc = launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host,
+                                           bins_deferred ? pfail_early : nullptr);
+            if (rc == ABC_INTERNAL_RETRY) return repeat_with_radix();
+            ABC_TRY(rc);
+        }
         if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM) {
             taus2_jump(rng, (uint64_t)Nn);   // the Nnext resampling draws; the host loop consumes the rest as the reference does
             ABC_TRY(launch_perturb_reference(ctx, rng, theta, K, P, io->priors, parent, Nn, cfg->multivariate,
@@ -597,14 +623,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // the sampled-range bin selection gave up (degenerate distances, an atypical sample): everything downstream of it
         // worked on a placeholder; once more, from the top, with the radix select
         const int failed = abc_select_check_done(ctx, pfail);
-        if (failed && !ctx->sel_force_radix) {
-            ctx->ws_off = ws_entry;
-            if (rng) *rng = rng_entry;
-            ctx->sel_force_radix = true;
-            const int rc = generation_core(ctx, cfg, io, rng, ncomp_host, simple, model_out);
-            ctx->sel_force_radix = false;
-            return rc;
-        }
+        if (failed && !ctx->sel_force_radix) return repeat_with_radix();
     }
     if (ctx->timing && ctx->nev > 128) ABC_TRY(abc_timing_flush(ctx));
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");

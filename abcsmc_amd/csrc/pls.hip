@@ -4,7 +4,7 @@
 // Replaces PLS::Model ctor, cv_NEW_DATA, optimal_num_components (reference call sites
 // AbcUtil.cpp:432-449, 453).
 //
-// Latency-bound, tiny matrices: k_zstats is one 256-thread work-group; k_pls_fit is ONE wavefront
+// Latency-bound, tiny matrices: k_zstats is a grid of up to 128 256-thread work-groups (one for the simple model); k_pls_fit is ONE wavefront
 // (no inter-wave barriers): XY and the P x P eigen work matrices live in LDS, XX stays in L2.
 #include <stdlib.h>
 
@@ -1248,6 +1248,7 @@ __global__ __launch_bounds__(64) void k_simple_obs(const double* __restrict__ ob
 static double g_pls_stamps[64];
 #endif
 
+static int zstats_lds(abc_ctx* ctx, size_t M, size_t P, size_t* bytes);
 int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
                      double* model) {
     if (A < 1 || A > M) ABC_FAIL(ctx, ABC_ERR_INVALID, "pls: components A=%zu must be in [1, M=%zu]", A, M);
@@ -1287,7 +1288,9 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
     const double* stats_in = fold_z ? stats : nullptr;
     if (!fold_z) {
         const unsigned zblocks = (unsigned)((M * (M + P) + 255) / 256 > 128 ? 128 : (M * (M + P) + 255) / 256);      // one entry per thread and partition
-        hipLaunchKernelGGL(k_zstats, dim3(zblocks), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
+        size_t zb = 0;
+        ABC_TRY(zstats_lds(ctx, M, P, &zb));
+        hipLaunchKernelGGL(k_zstats, dim3(zblocks), dim3(256), zb, ctx->stream, stats, (int)M, (int)P, (int)A, model, zwork);
         ABC_HIP(ctx, hipGetLastError());
     }
     if (fit16) {
@@ -1320,8 +1323,21 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
 extern "C" void abc_debug_pls_stamps(double* out64) { for (int i = 0; i < 64; i++) out64[i] = g_pls_stamps[i]; }
 #endif
 
+// k_zstats keeps the two moment vectors of all M + P columns in dynamic LDS: beyond 64 KB (4096 columns) the launch needs the
+// attribute, beyond the 160 KB of a CU (10240 columns) the kernel does not apply
+static int zstats_lds(abc_ctx* ctx, size_t M, size_t P, size_t* bytes) {
+    *bytes = 2 * (M + P) * sizeof(double);
+    if (*bytes > 160 * 1024)
+        ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "z-score moments: %zu columns exceed the 10240 this kernel holds in LDS", M + P);
+    if (*bytes > 64 * 1024)
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_zstats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
+    return ABC_OK;
+}
+
 int launch_simple_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, double* model) {
-    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), 2 * (M + P) * sizeof(double), ctx->stream, stats, (int)M, (int)P, 0, model, (double*)nullptr);
+    size_t zb = 0;
+    ABC_TRY(zstats_lds(ctx, M, P, &zb));
+    hipLaunchKernelGGL(k_zstats, dim3(1), dim3(256), zb, ctx->stream, stats, (int)M, (int)P, 0, model, (double*)nullptr);
     ABC_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_simple_obs, dim3(1), dim3(64), 0, ctx->stream, obs, (int)M, (int)P, model);
     ABC_HIP(ctx, hipGetLastError());

@@ -628,7 +628,7 @@ int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* 
 
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights,
-                    const uint32_t* raw_ready, bool weights_on_host) {
+                    const uint32_t* raw_ready, bool weights_on_host, const volatile int* abort_flag) {
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     if (uniform_weights) {
@@ -674,6 +674,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     }
     if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));      // more table-independent GPU work of the caller
     ABC_HIP(ctx, hipEventSynchronize(ctx->ev_copy));
+    if (abort_flag && *abort_flag) return ABC_INTERNAL_RETRY;
     {
         const auto t0 = std::chrono::steady_clock::now();
         abc_alias_preproc(K, hw, hF, hA, hE, hS, hB, /*knuth=*/false);
@@ -763,8 +764,8 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     while (PP < (int)P) PP *= 2;
     if (P > 64) PP = (int)((P + 63) / 64 * 64);
     if (!ctx->giveups_dev) {
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, sizeof(unsigned long long)));
-        ABC_HIP(ctx, hipMemsetAsync(ctx->giveups_dev, 0, sizeof(unsigned long long), ctx->stream));
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, 2 * sizeof(unsigned long long)));      // [0] the counter, [1] its snapshot
+        ABC_HIP(ctx, hipMemsetAsync(ctx->giveups_dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
     }
     StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);

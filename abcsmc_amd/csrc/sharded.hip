@@ -22,6 +22,8 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -36,6 +38,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
@@ -58,7 +61,7 @@ Rccl* rccl() {
             }
         if (!r.h) return r;
 #define RCCL_SYM(f) r.f = (decltype(r.f))dlsym(r.h, "nccl" #f)
-        RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommInitAll); RCCL_SYM(CommDestroy); RCCL_SYM(AllReduce);
+        RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommInitAll); RCCL_SYM(CommDestroy); RCCL_SYM(CommAbort); RCCL_SYM(AllReduce);
         RCCL_SYM(AllGather); RCCL_SYM(Broadcast); RCCL_SYM(GetErrorString);
 #undef RCCL_SYM
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.AllGather && r.Broadcast;
@@ -270,6 +273,13 @@ extern "C" int abc_ctx_create_multi(const int* devices, int ndev, abc_ctx** out)
 }
 
 // ---- one generation, rows sharded over the communicator ------------------------------------------------------------------------
+static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_generation_io* io, abc_rng* rng, int32_t* ncomp_host);
+
+// Argument checks are local and deterministic (the same call on every rank passes or fails them alike) and happen before
+// the first collective.  Past them a failure on ONE rank only -- arena or exchange buffer exhausted, a HIP error, a failed
+// collective -- would leave its peers waiting inside RCCL for ever: the communicator is then ABORTED (ncclCommAbort), which
+// makes the peers' pending collectives return an error instead of hanging; the context is left without a communicator and
+// says so.  A covariance that is not positive definite is computed from replicated data, i.e. reported by every rank: no abort.
 extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
                                           int32_t* ncomp_host) {
     if (!ctx) return ABC_ERR_INVALID;
@@ -278,17 +288,36 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     if (ctx->timing && ctx->nev > 96) ABC_TRY(abc_timing_flush(ctx));
     if (!cfg || !io || !io->X || !io->Y || !io->obs || !io->idx || !io->w || !rng)
         ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: null argument");
-    const int W = ctx->comm_kind ? ctx->comm_world : 1, r = ctx->comm_kind ? ctx->comm_rank : 0;
-    const size_t n = cfg->n_local, N = cfg->N_total, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->nnext_local;
-    const uint64_t row0 = cfg->row0;
-    if (!N || !M || !P || K == 0 || K > N || row0 + n > N || cfg->next0 + Nn > cfg->Nnext_total)
-        ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: bad sizes N=%zu n_local=%zu row0=%zu M=%zu P=%zu K=%zu", N, n, (size_t)row0, M, P, K);
+    {
+        const size_t n = cfg->n_local, N = cfg->N_total, M = cfg->M, P = cfg->P, K = cfg->K, Nn = cfg->nnext_local;
+        const uint64_t row0 = cfg->row0;
+        if (!N || !M || !P || K == 0 || K > N || row0 + n > N || cfg->next0 + Nn > cfg->Nnext_total)
+            ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: bad sizes N=%zu n_local=%zu row0=%zu M=%zu P=%zu K=%zu", N, n, (size_t)row0, M, P, K);
+        if (Nn && !io->next) ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: null proposal buffer");
+    }
     if (!(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))
         ABC_FAIL(ctx, ABC_ERR_INVALID, "training fraction %g outside (0,1]", cfg->train_frac);
     if (cfg->rule != ABC_RULE_MIN_PRESS && cfg->rule != ABC_RULE_WILCOXON)
         ABC_FAIL(ctx, ABC_ERR_INVALID, "unknown component rule %d", cfg->rule);
     if (ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM)
         ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "the reference noise stream is sequential over the whole set: not available to the sharded generation");
+    const int rc = sharded_core(ctx, cfg, io, rng, ncomp_host);
+    if (rc != ABC_OK && rc != ABC_ERR_NOT_SPD && ctx->comm_kind == 1 && ctx->comm_world > 1 && ctx->comm_nccl) {
+        if (rccl()->CommAbort) (void)rccl()->CommAbort((ncclComm_t)ctx->comm_nccl);
+        ctx->comm_nccl = nullptr;
+        ctx->comm_kind = 0;
+        ctx->comm_world = 1;
+        ctx->comm_rank = 0;
+        const size_t len = strlen(ctx->err);
+        snprintf(ctx->err + len, sizeof(ctx->err) - len, " [rank-local failure: the RCCL communicator was aborted so that the other ranks do not hang; create a new one]");
+    }
+    return rc;
+}
+
+static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_generation_io* io, abc_rng* rng, int32_t* ncomp_host) {
+    const int W = ctx->comm_kind ? ctx->comm_world : 1, r = ctx->comm_kind ? ctx->comm_rank : 0;
+    const size_t n = cfg->n_local, N = cfg->N_total, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->nnext_local;
+    const uint64_t row0 = cfg->row0;
     const size_t A = default_A(M, P, cfg->max_comp);
     const size_t kloc = K < n ? K : n;                       // most winners this rank can hold
     const size_t kbase = K / (size_t)W, krem = K % (size_t)W, kmax = kbase + (krem ? 1 : 0);
@@ -299,7 +328,7 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     if (cfg->rule == ABC_RULE_WILCOXON) {
         // the validation rows of the whole set are assembled on every rank (all-gather of the shards' validation rows)
         const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
-        need += abc_wx_need(NvT, P, A) + ((size_t)(W + 1) * (n ? n : 1) + NvT) * (M + P) * 8 + (1u << 20);
+        need += abc_wx_need(NvT, P, A) + (1u << 20);      // (the gathered rows themselves live in the exchange buffer)
     }
     ABC_TRY(abc_ws_reserve(ctx, need));
     const StatsLayout SL = stats_layout(M, P);
@@ -359,11 +388,17 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
         const size_t Nv = (size_t)off[(size_t)W], vm = (size_t)vmax;
         if (Nv) {
             long long* voff = vcnt + 1 + W;
-            double* sendb = (double*)abc_ws_alloc(ctx, vm * (M + P) * 8);
-            double* recvb = (double*)abc_ws_alloc(ctx, (size_t)W * vm * (M + P) * 8);
-            double* Xv = (double*)abc_ws_alloc(ctx, Nv * M * 8);
-            double* Yv = (double*)abc_ws_alloc(ctx, Nv * P * 8);
-            if (!sendb || !recvb || !Xv || !Yv) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted (Wilcoxon rows)");
+            // sized from the GATHERED counts (vmax over all ranks, Nv): the same bytes on every rank whatever its own shard
+            // holds -- the arena is sized from the local row count and ran out on the smaller ranks of uneven shards only,
+            // which then left their peers waiting in the all-gather below
+            const size_t cb = (M + P) * 8;
+            ABC_TRY(xbuf_reserve(ctx, ((size_t)(W + 1) * vm + Nv) * cb + 4 * 256));
+            char* xq = ctx->xbuf;
+            auto takeq = [&](size_t bytes) { char* p0 = xq; xq += abc_align(bytes, 256); return (double*)p0; };
+            double* sendb = takeq(vm * cb);
+            double* recvb = takeq((size_t)W * vm * cb);
+            double* Xv = takeq(Nv * M * 8);
+            double* Yv = takeq(Nv * P * 8);
             ABC_HIP(ctx, hipMemcpyAsync(voff, off.data(), (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
             // X and Y travel in one block: [M + P columns][vmax rows] per rank
             hipLaunchKernelGGL(k_pack_valid, dim3((unsigned)((vm * M + 255) / 256)), dim3(256), 0, ctx->stream, io->X, n, v0, nv, vm,
@@ -488,7 +523,6 @@ extern "C" int abc_generation_sharded_dev(abc_ctx* ctx, const abc_sharded_cfg* c
     int spd = 0;
     bool have_spd = false;
     if (Nn) {
-        if (!io->next) ABC_FAIL(ctx, ABC_ERR_INVALID, "sharded generation: null proposal buffer");
         uint64_t* parent = io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8);
         if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         double* L = nullptr;
@@ -554,10 +588,21 @@ extern "C" int abc_generation_multi(abc_ctx* const* ctxs, int ndev, const abc_ge
     std::vector<int> rcs((size_t)ndev, ABC_OK);
     std::vector<int32_t> ncs((size_t)ndev, 0);
     std::vector<abc_rng> rngs((size_t)ndev, *rng);
+    // one rendezvous of all workers: everyone deposits its set-up status, the last one to arrive releases the others
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, any_failed = 0;
+    auto agree = [&](int my_status) -> bool {
+        std::unique_lock<std::mutex> lk(mu);
+        if (my_status != ABC_OK) any_failed = 1;
+        if (++arrived == ndev) cv.notify_all();
+        else cv.wait(lk, [&] { return arrived == ndev; });
+        return any_failed == 0;
+    };
     auto worker = [&](int d) {
         abc_ctx* ctx = ctxs[d];
         auto fail = [&](int rc) { rcs[(size_t)d] = rc; };
-        if (hipSetDevice(ctx->device) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipSetDevice failed"); return fail(ABC_ERR_HIP); }
+        if (hipSetDevice(ctx->device) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipSetDevice failed"); (void)agree(ABC_ERR_HIP); return fail(ABC_ERR_HIP); }
         // contiguous shards, as even as possible (low ranks first)
         auto lo = [&](size_t tot, int q) { return tot / (size_t)ndev * (size_t)q + ((size_t)q < tot % (size_t)ndev ? (size_t)q : tot % (size_t)ndev); };
         const size_t r0 = lo(N, d), n = lo(N, d + 1) - r0, i0 = lo(Nn, d), nn = lo(Nn, d + 1) - i0;
@@ -588,6 +633,7 @@ extern "C" int abc_generation_multi(abc_ctx* const* ctxs, int ndev, const abc_ge
         if (!dX || !dY || !dobs || !dpri || (Kp && (!dtp || !dwp || !ddvp)) || !didx || !ddist || !dth || !dw || !ddv || !dL || !dnext ||
             !dpar || !dseed) {
             snprintf(ctx->err, sizeof(ctx->err), "multi-GPU generation: device allocation failed");
+            (void)agree(ABC_ERR_NOMEM);
             cleanup();
             return fail(ABC_ERR_NOMEM);
         }
@@ -606,7 +652,13 @@ extern "C" int abc_generation_multi(abc_ctx* const* ctxs, int ndev, const abc_ge
             H(hipMemcpyAsync(dwp, h->w_prev, Kp * 8, hipMemcpyHostToDevice, st));
             H(hipMemcpyAsync(ddvp, h->dv_prev, P * 8, hipMemcpyHostToDevice, st));
         }
-        if (!ok) { cleanup(); return fail(ABC_ERR_HIP); }
+        // every worker reports whether its allocations and uploads went through BEFORE anyone enters the first collective:
+        // if one failed, all skip the generation (a lone early return left the others inside RCCL for ever)
+        if (!agree(ok ? ABC_OK : ABC_ERR_HIP)) {
+            cleanup();
+            if (ok) snprintf(ctx->err, sizeof(ctx->err), "multi-GPU generation: skipped, the set-up of another device failed");
+            return fail(ok ? ABC_ERR_COMM : ABC_ERR_HIP);
+        }
         abc_sharded_cfg sc;
         memset(&sc, 0, sizeof(sc));
         sc.n_local = n; sc.row0 = r0; sc.N_total = N; sc.M = M; sc.P = P; sc.K = K; sc.Kp = Kp;

@@ -42,8 +42,13 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm /* >= 4 */)
 __global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ Y, size_t n_local, size_t ldy,
                                                      int P, const unsigned long long* __restrict__ idx, size_t K,
                                                      unsigned long long idx_base, double* __restrict__ theta,
-                                                     size_t ldt) {
+                                                     size_t ldt, const int* __restrict__ sel_fail, int* __restrict__ sel_fail_pin,
+                                                     unsigned long long* __restrict__ giveups) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // (fused drivers) the first kernel behind the selection: the selection's give-up flag goes to the pinned status block
+    // now, so the host sees it at its next synchronisation -- before it builds an alias table of placeholder weights --, and the
+    // give-up counter of the proposals is snapshotted (a repeated generation restores it)
+    if (e == 0 && sel_fail) { *sel_fail_pin = *sel_fail; if (giveups) giveups[1] = giveups[0]; }
     if (e >= K * (size_t)P) return;
     const size_t i = e % K, p = e / K;
     const unsigned long long g = idx[i];
@@ -778,12 +783,13 @@ __global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t
 }  // namespace
 
 int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P, const uint64_t* idx,
-                       size_t K, uint64_t idx_base, double* theta, size_t ldt) {
+                       size_t K, uint64_t idx_base, double* theta, size_t ldt, const int* sel_fail, int* sel_fail_pin) {
     const size_t tot = K * P;
     if (!tot) return ABC_OK;
     StageTimer tm(ctx, ST_GATHER_DV);
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Y, n_local, ldy,
-                       (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt);
+                       (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt, sel_fail, sel_fail_pin,
+                       sel_fail ? ctx->giveups_dev : (unsigned long long*)nullptr);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

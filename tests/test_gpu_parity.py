@@ -250,6 +250,39 @@ def test_generation_with_massive_distance_ties_repeats_with_the_radix_select(gpu
     assert (r.s1, r.s2, r.s3) == (r2.s1, r2.s2, r2.s3)
 
 
+def test_weighted_generation_with_distance_ties_repeats_before_the_alias_build(gpu_ctx, oracle):
+    """the same degenerate distances (16 distinct metric rows, 2048 copies each) in a WEIGHTED, MULTIVARIATE generation: the
+    give-up flag of the bin selection reaches the host at its wait for the weights, the generation repeats itself with the radix
+    select before any alias table, draw or proposal of the placeholder winners is queued; results are the oracle's, the rng
+    advanced once, no phantom give-ups"""
+    import torch
+    from abcsmc_amd import abcutil, device, _lib
+    M, P, A, reps = 6, 3, 2, 2048
+    wl, X0, Y0, obs = _wl(M, P, 16)
+    X = np.asfortranarray(np.tile(X0, (reps, 1)))
+    _, Y = wl.rows(100, 100 + 16 * reps)                        # distinct parameter rows: the posterior covariance is regular
+    N, K, Kp, Nn = X.shape[0], 5000, 300, 4096
+    spec = wl.prior_spec()
+    prev = wl.previous_set(Kp)
+    dev = "cuda:0"
+    gpu_ctx.perturb_giveups(reset=True)
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, multivariate=True, device=dev, ctx=gpu_ctx)
+    r = abcutil.rng(99)
+    gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev),
+            device.priors_to_device(_lib.make_priors(spec), dev), r, *(device.colmajor(a, dev) for a in prev))
+    torch.cuda.synchronize()
+    o = oracle.rng(99)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A, multivariate=True)
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    assert np.isfinite(device.to_numpy(gen.next)).all()
+    r2 = abcutil.rng(99)
+    _lib.lib().abc_rng_jump(C.byref(r2), 2 * Nn)
+    assert (r.s1, r.s2, r.s3) == (r2.s1, r2.s2, r2.s3)
+    assert gpu_ctx.perturb_giveups() == 0
+
+
 def test_select_smallest_ties_and_offsets(gpu_ctx, oracle):
     rng = np.random.default_rng(4)
     d = rng.integers(0, 50, size=30000).astype(np.float64)      # massive ties: index tie-break decides
@@ -731,6 +764,55 @@ def test_sample_predictive_priors_independent(gpu_ctx, oracle):
     for p in range(P):
         assert abs(out[:, p].mean() - oout[:, p].mean()) < 0.02 * oout[:, p].std() + 1e-3
         assert abs(out[:, p].std() / oout[:, p].std() - 1) < 0.02
+
+
+def _assert_standard_normal(z, tag):
+    """z: (n, P) recovered deviates of the device noise stream, n = 1e6.  What the sample size supports: a 1 % scale error in
+    the normals fails the variance bound by 14 standard errors"""
+    from scipy import stats
+    n, P = z.shape
+    assert np.all(np.abs(z) <= 6.77), tag                              # the stream's stated truncation, |z| <= 6.76
+    for p in range(P):
+        v = z[:, p]
+        ks = stats.kstest(v, "norm")
+        assert ks.pvalue > 1e-3, (tag, p, ks)                          # Kolmogorov-Smirnov against N(0, 1)
+        assert abs(v.mean()) < 5.0 / np.sqrt(n), (tag, p, v.mean())
+        assert abs(v.var() - 1.0) < 0.005, (tag, p, v.var())           # standard error sqrt(2 / n) = 0.0014
+        kurt = np.mean((v - v.mean()) ** 4) / v.var() ** 2
+        assert abs(kurt - 3.0) < 0.03, (tag, p, kurt)                  # standard error sqrt(24 / n) = 0.005
+        assert abs(stats.skew(v)) < 0.0125, (tag, p)                   # standard error sqrt(6 / n) = 0.0025
+        for t in (3.0, 4.0):                                           # tail counts within 5 sigma of the binomial
+            q = 2.0 * stats.norm.sf(t)
+            c = np.count_nonzero(np.abs(v) > t)
+            assert abs(c - n * q) < 5.0 * np.sqrt(n * q * (1 - q)), (tag, p, t, c, n * q)
+    cc = np.corrcoef(z.T)
+    assert np.max(np.abs(cc - np.eye(P))) < 0.005, (tag, cc)           # independent coordinates (standard error 0.001)
+
+
+@pytest.mark.parametrize("P", [4, 16])
+def test_device_noise_stream_is_standard_normal(gpu_ctx, P):
+    """The default proposals draw from Philox4x32-10 + Box-Muller on the f32 transcendental hardware (resample.hip: normal4;
+    radius from all 32 bits of its word: |z| <= 6.76, deviates carry f32 rounding).  With priors that never reject, the
+    deviates are recovered from 1e6 proposals -- z = L^-1 (x - parent) for MULTIVARIATE (AbcUtil.cpp:122-143), z = (x - parent) /
+    sqrt(dv) per coordinate for INDEPENDENT (AbcUtil.cpp:145-158, Priors.h:19-43) -- and held to N(0, 1): KS, mean, variance to
+    0.5 %, kurtosis, skewness, 3 / 4 sigma tail counts, cross-coordinate correlation"""
+    from scipy.linalg import solve_triangular
+    from abcsmc_amd import abcutil, _lib
+    g = np.random.default_rng(40 + P)
+    K, n = 200, 1_000_000
+    mix = g.normal(size=(P, P)) / np.sqrt(P) + np.eye(P)
+    th = g.normal(size=(K, P)) @ mix * 10.0 ** g.integers(-2, 3, size=P)          # correlated posterior, scales 1e-2 .. 1e2
+    spec = [(_lib.PRIOR_GAUSS, 0.0, 1e9)] * P                                       # support = everything: no rejection
+    w = g.random(K)
+    L = abcutil.setup_mvn_sampler(th, ctx=gpu_ctx)
+    out, parent = abcutil.sample_mvn_predictive_priors(abcutil.rng(7), n, w, th, _lib.make_priors(spec), L, ctx=gpu_ctx)[:2]
+    z = solve_triangular(np.tril(L), (out - th[parent.astype(np.int64)]).T, lower=True).T
+    _assert_standard_normal(z, "mvn")
+    dv = abcutil.calculate_doubled_variance(th, ctx=gpu_ctx)
+    out, parent = abcutil.sample_predictive_priors(abcutil.rng(8), n, w, th, _lib.make_priors(spec), dv, ctx=gpu_ctx)[:2]
+    z = (out - th[parent.astype(np.int64)]) / np.sqrt(dv)
+    _assert_standard_normal(z, "independent")
+    assert gpu_ctx.perturb_giveups() == 0
 
 
 class _noise_mode:

@@ -146,3 +146,42 @@ def test_sharded_world1_equals_fused(gpu_ctx):
                  (g1.next, g2.next), (g1.theta, g2.theta)):
         assert torch.equal(a, b)
     assert (r1.s1, r1.s2, r1.s3) == (r2.s1, r2.s2, r2.s3)
+
+
+@pytest.mark.gpu
+def test_a_raising_collective_callback_fails_the_generation():
+    """abc_comm_init_callbacks with Python collectives: an exception inside one (transport timeout, shape error) must not be
+    swallowed by ctypes (which would report success and let the driver carry on with un-reduced statistics): the generation
+    returns ABC_ERR_COMM and the exception is kept on the context"""
+    import torch
+    from abcsmc_amd import _lib, abcutil, device, sharded, synthetic
+    N, M, P, K, Kp, Nn, A = 3000, 12, 5, 300, 200, 1000, 4
+    wl = synthetic.Workload(M, P)
+    X, Y = wl.rows(0, N)
+    dev = "cuda:0"
+    args = [device.colmajor(a, dev) for a in (X, Y, wl.observed())]
+    pri = device.priors_to_device(_lib.make_priors(wl.prior_spec()), dev)
+    prev = [device.colmajor(a, dev) for a in wl.previous_set(Kp)]
+    ctx = _lib.Context(0)
+    calls = []
+
+    def ok_reduce(buf, count, dtype, stream):
+        calls.append("reduce")
+        return 0
+
+    def ok_gather(send, recv, nbytes, stream):
+        calls.append("gather")
+        return 0
+
+    def bad_broadcast(buf, nbytes, root, stream):
+        calls.append("broadcast")
+        raise TimeoutError("peer did not answer")
+
+    ctx.comm_init_callbacks(1, 0, ok_reduce, ok_gather, bad_broadcast)
+    g = sharded.CabiShardedGeneration(ctx, dev, N, M, P, K, Kp, Nn, 0.5, A)
+    with pytest.raises(_lib.AbcError) as e:
+        g.run(*args, pri, abcutil.rng(5), *prev)
+    assert e.value.code == -6 and "broadcast" in str(e.value)                   # ABC_ERR_COMM
+    assert isinstance(ctx.comm_callback_error, TimeoutError) and calls == ["broadcast"]
+    torch.cuda.synchronize()
+    ctx.close()
