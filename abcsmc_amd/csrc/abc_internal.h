@@ -222,6 +222,9 @@ int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, si
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
 // K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor
 int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);
+// everything that follows from the posterior's statistics record in ONE launch (mvn.hip: k_post_tail; P <= 64; fields optional)
+struct abc_theta_fused { double* dv; double* L; int* spd; double* rows /* K x PP row-major, zero padded */; double* Lpad /* PP x PP */; };
+int launch_post_tail(abc_ctx*, const double* theta, size_t K, size_t P, const double* stats, const abc_theta_fused* f);
 int launch_dv_from_stats(abc_ctx*, const double* stats, size_t P, double* dv);
 int launch_mvn_from_stats(abc_ctx*, const double* stats, size_t P, double* L, int* status_dev);
 // the previous set's share of the weight stage (weights.hip: launch_weights_prev), prepared ahead of launch_weights_raw
@@ -233,12 +236,15 @@ int launch_weights_prev(abc_ctx*, size_t P, size_t kn_max, const double* theta_p
                         const double* dv_prev, abc_wprev* out, hipStream_t st);
 int launch_weights_raw(abc_ctx*, const abc_prior* priors, const double* theta, size_t K, size_t P,
                        size_t k0, size_t kn, const double* theta_prev, size_t Kp,
-                       const double* w_prev, const double* dv_prev, double* w_raw, const abc_wprev* prev = nullptr);
+                       const double* w_prev, const double* dv_prev, double* w_raw, const abc_wprev* prev = nullptr,
+                       const double** sumsq_out = nullptr);
+// sumsq_out (optional): when the call covers the whole set (k0 = 0, kn = K) the 64-row partials of the raw weights' sum of
+// squares are computed by the same launch; *sumsq_out then points at them (device) for launch_normalize_l2's sumsq_parts, else NULL
 // launch_weights_prev on the side stream (resample.hip); the caller makes its stream wait for ctx->ev_prev before the rest
 int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                            const double* dv_prev, abc_wprev* out);
 int launch_fill(abc_ctx*, double* w, size_t K, double v);
-int launch_normalize_l2(abc_ctx*, double* w, size_t K, double* host_mirror = nullptr);
+int launch_normalize_l2(abc_ctx*, double* w, size_t K, double* host_mirror = nullptr, const double* sumsq_parts = nullptr);
 // pinned scratch of the alias build over K weights: w | F | A | (pad) | E | the two index stacks (K + 1 entries each)
 static inline size_t abc_alias_pin_bytes(size_t K) { return K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t) + 16; }
 int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* L, int* status_host,
@@ -250,7 +256,8 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr,
                     bool uniform_weights = false, const uint32_t* raw_ready = nullptr, bool weights_on_host = false,
-                    const volatile int* abort_flag = nullptr);
+                    const volatile int* abort_flag = nullptr, bool parents_ready = false);
+// parents_ready (uniform weights only): abc_rng_streams_early has drawn the parents on the side stream already
 // abort_flag (pinned, optional): read right after the host has waited for the weights; non-zero -> nothing more is queued and
 // ABC_INTERNAL_RETRY is returned (the weights belong to a placeholder selection: the caller repeats its generation)
 // weights_on_host: the kernel that normalised w already stored them at the start of the context's pinned scratch
@@ -259,7 +266,9 @@ int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uin
 // i0 .. i0 + n - 1 of the resampling draws (-> *raw) and, if seeds != NULL, the simulator seeds = outputs seed_stream_offset +
 // i0 + i.  The main stream waits for them in launch_resample (raw_ready).  Call before the first kernel of the generation.
 int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
-                          uint32_t** raw);
+                          uint32_t** raw, uint64_t* parent_uniform = nullptr, size_t K_uniform = 0);
+// parent_uniform (set 0): the weights will be K_uniform copies of 1 / K_uniform whatever the ranking says, their alias table is
+// on the device already (abc_uniform_alias, called BEFORE the fork), so the parents are drawn here too, beside the ranking
 int abc_side_fork(abc_ctx* ctx);      // records where on the main stream the side stream's work of this generation may start
 // Alias table of K equal weights: gsl_ran_discrete_preproc on K copies of 1.0 / K (bit-identical to the table of the filled
 // weight vector), built on the host on first use for this K and kept in HBM.  The fused drivers call it right after queueing
@@ -271,6 +280,12 @@ struct abc_perturb_prep { double* rows; int seeds_done; double* Lpad; };   // se
 int launch_perturb_prepare(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
                            uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate = 0,
                            const double* L_or_dv = nullptr);
+// padded width of the row-major posterior copy the perturbation kernels read (and of their padded factor)
+static inline int abc_perturb_pp(size_t P) {
+    int PP = 2;
+    while (PP < (int)P) PP *= 2;
+    return (P > 64) ? (int)((P + 63) / 64 * 64) : PP;
+}
 int launch_perturb(abc_ctx*, const abc_rng* rng, const double* theta, size_t K, size_t P,
                    const abc_prior* priors, const uint64_t* parent, uint64_t i0, size_t n,
                    int multivariate, const double* L_or_dv, double* out, uint64_t* seeds,

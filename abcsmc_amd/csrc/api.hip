@@ -392,7 +392,7 @@ extern "C" int abc_weights_raw_dev(abc_ctx* ctx, const abc_prior* priors, const 
 
 extern "C" int abc_normalize_l2_dev(abc_ctx* ctx, double* w, size_t K) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, 1 << 20));
+    ABC_TRY(abc_ws_reserve(ctx, (K / 64 + 2) * sizeof(double) + (1 << 20)));
     return launch_normalize_l2(ctx, w, K);
 }
 
@@ -461,6 +461,18 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const uint64_t ntrain = simple ? N : (uint64_t)llround((double)N * cfg->train_frac);   // AbcUtil.cpp:438
     const double* Yp = io->Y ? io->Y : io->X;
     const size_t Pstat = io->Y ? P : 0;
+    // first set: the weights will be 1/K whatever the ranking says, so their alias table is built (once per K, then kept) before
+    // anything is queued, and the parents are drawn on the side stream beside the ranking
+    const bool uniform_w = io->w && K && (Kp == 0 || !io->theta_prev);
+    const bool early = io->w && Nn && K && rng && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
+    uint64_t* parent_early = nullptr;
+    if (uniform_w && Nn) {
+        ABC_TRY(abc_uniform_alias(ctx, K));
+        if (early) {
+            parent_early = io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8);
+            if (!parent_early) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+        }
+    }
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
     ctx->side_forked = false;
@@ -472,8 +484,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, forked behind the Gram
     // kernel (which wants the whole memory system) and running beside the reduce / model fit that leave the chip empty
     uint32_t* raw_early = nullptr;
-    const bool early = io->w && Nn && K && rng && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
-    if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early));
+    if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early, parent_early, K));
     // ... and so does everything the weight stage needs of the PREVIOUS set (scales, centre, scaled copy, limb tiles)
     abc_wprev wprev;
     memset(&wprev, 0, sizeof(wprev));
@@ -483,9 +494,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/io->w != nullptr));
-    // first set: the weights will be 1/K whatever the ranking says, so the host builds their alias table now, while the GPU ranks
-    const bool uniform_w = io->w && (Kp == 0 || !io->theta_prev);
-    if (uniform_w && Nn) ABC_TRY(abc_uniform_alias(ctx, K));
     if (!simple && ncomp_host && !io->w) {
         double hdr[4];
         ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
@@ -523,7 +531,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // Weighted generations with proposals: the kernel density of the weights uses the PREVIOUS set's variance, so the new set's
     // moments (pilot shift, Gram, reduce, dv: 25 us of small launches) are not needed before the host's alias round trip --
     // they run in the GPU's idle time behind it (hook below) instead of in front of the pair sums.
-    const bool defer_moments = Nn && !uniform_w && P <= 64 && K >= 2;
+    // (set 0 too: nothing in front of the proposals needs them, and up to 16 parameters ONE launch then delivers the moments,
+    // the doubled variance, the proposal factor and the perturbation's row-major copy: k_theta_moments)
+    const bool defer_moments = Nn && P <= 64 && K >= 2;
     if (defer_moments) {
     } else if (P <= 64 && K >= 2) {
         StageTimer tm(ctx, ST_GATHER_DV);
@@ -537,8 +547,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
     } else {
         if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
+        const double* sumsq = nullptr;       // the normalisation's sum of squares comes out of the weight stage's last kernel
         ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
-                                   io->w, &wprev));
+                                   io->w, &wprev, &sumsq));
         // (with proposals to draw the host builds the alias table of these weights next: the normalisation kernel stores them
         // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
         double* mirror = nullptr;
@@ -546,13 +557,13 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;
         }
-        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror));                  // AbcUtil.cpp:583
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror, sumsq));           // AbcUtil.cpp:583
         w_on_host = mirror != nullptr;
     }
     int spd = 0;
     bool have_spd = false;
     if (Nn) {
-        uint64_t* parent = io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8);
+        uint64_t* parent = parent_early ? parent_early : (io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8));
         if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
         double* L = nullptr;
         if (cfg->multivariate) {
@@ -570,14 +581,26 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev, dv, defer_moments};
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
+            int fused_done = 0;
             if (q->moments) {
                 StageTimer tm(q->ctx, ST_GATHER_DV);
                 double* st = nullptr;
                 ABC_TRY(launch_theta_stats(q->ctx, q->theta, q->K, q->P, &st));
-                ABC_TRY(launch_dv_from_stats(q->ctx, st, q->P, q->dv));
                 q->theta_stats = st;
+                // doubled variance, proposal factor and the perturbation's inputs (row-major copy, padded factor) in ONE launch
+                abc_theta_fused f = {q->dv, q->L, q->spd_dev, nullptr, nullptr};
+                if (q->ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM) {
+                    const int PP = abc_perturb_pp(q->P);
+                    f.rows = (double*)abc_ws_alloc(q->ctx, q->K * (size_t)PP * sizeof(double));
+                    if (q->L) f.Lpad = (double*)abc_ws_alloc(q->ctx, (size_t)PP * PP * sizeof(double));
+                    if (!f.rows || (q->L && !f.Lpad)) { snprintf(q->ctx->err, sizeof(q->ctx->err), "generation: workspace exhausted"); return ABC_ERR_NOMEM; }
+                }
+                ABC_TRY(launch_post_tail(q->ctx, q->theta, q->K, q->P, st, &f));
+                q->prep->rows = f.rows;
+                q->prep->Lpad = f.Lpad;
+                fused_done = 1;
             }
-            if (q->L) {
+            if (q->L && !fused_done) {
                 if (q->theta_stats) {
                     StageTimer tm(q->ctx, ST_MVN);
                     ABC_TRY(launch_mvn_from_stats(q->ctx, q->theta_stats, q->P, q->L, q->spd_dev));
@@ -592,7 +615,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         };
         {
             const int rc = launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host,
-                                           bins_deferred ? pfail_early : nullptr);
+                                           bins_deferred ? pfail_early : nullptr, parent_early != nullptr);
             if (rc == ABC_INTERNAL_RETRY) return repeat_with_radix();
             ABC_TRY(rc);
         }

@@ -8,15 +8,12 @@
 
 namespace {
 
-// gA != NULL (more than 128 parameters: P x P doubles exceed the LDS): the work matrix lives there instead
-__global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stats, int P, double* __restrict__ Lout,
-                                                 int* __restrict__ status, double* __restrict__ gA) {
-    extern __shared__ double Ash[];   // P x P column-major (or just delta when gA is given), then delta[P]
-    double* A = gA ? gA : Ash;
-    double* delta = gA ? Ash : Ash + (size_t)P * P;
-#define CH_SYNC() do { if (gA) __threadfence_block(); __syncthreads(); } while (0)
+// covariance (n - 1), diagonal doubled, and its lower Cholesky factor from a statistics record: ONE wavefront; A: P x P
+// work matrix, delta: P doubles (LDS, or global memory behind fences).  SYNC orders the wave's own memory operations.
+#define CH_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+__device__ __forceinline__ void cov_chol_wave(const double* __restrict__ stats, int P, double* A, double* delta,
+                                              double* __restrict__ Lout, int* __restrict__ status, int lane) {
     const StatsLayout SL = stats_layout(P, 0);
-    const int lane = threadIdx.x;
     const double n = stats[SL.off_n] + stats[SL.off_n + 1];
     for (int c = lane; c < P; c += 64) delta[c] = (stats[SL.off_sum[0] + c] + stats[SL.off_sum[1] + c]) / n;
     CH_SYNC();
@@ -45,19 +42,73 @@ __global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stat
     }
     for (int e = lane; e < P * P; e += 64) Lout[e] = A[e];
     if (lane == 0) *status = ok ? 0 : -1;
-#undef CH_SYNC
+    CH_SYNC();
 }
 
-// dv_p = 2 * Var_p (n-1 denominator) from the same statistics record (AbcUtil.cpp:528-537)
-__global__ void k_dv_from_stats(const double* __restrict__ stats, int P, double* __restrict__ dv) {
+// gA != NULL (more than 128 parameters: P x P doubles exceed the LDS): the work matrix lives there instead
+__global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stats, int P, double* __restrict__ Lout,
+                                                 int* __restrict__ status, double* __restrict__ gA) {
+    extern __shared__ double Ash[];   // P x P column-major (or just delta when gA is given), then delta[P]
+    double* A = gA ? gA : Ash;
+    double* delta = gA ? Ash : Ash + (size_t)P * P;
+    cov_chol_wave(stats, P, A, delta, Lout, status, (int)threadIdx.x);
+}
+
+__device__ __forceinline__ double dv_of_stats(const double* __restrict__ stats, int P, int p) {
     const StatsLayout SL = stats_layout(P, 0);
-    const int p = threadIdx.x;
-    if (p >= P) return;
     const double n = stats[SL.off_n] + stats[SL.off_n + 1];
     const double d = (stats[SL.off_sum[0] + p] + stats[SL.off_sum[1] + p]) / n;
     double ss = stats[SL.off_G[0] + p + SL.C16 * p] + stats[SL.off_G[1] + p + SL.C16 * p] - n * d * d;
     if (ss < 0.0) ss = 0.0;
-    dv[p] = (n > 1.0) ? 2.0 * (ss / (n - 1.0)) : 0.0;
+    return (n > 1.0) ? 2.0 * (ss / (n - 1.0)) : 0.0;
+}
+
+// ---- everything that follows from the posterior's statistics record, ONE launch ------------------------------------------------
+// Round 2 ran three dependent launches behind the record (doubled variance, covariance + Cholesky, row-major copy + padded
+// factor: 27 us of the 49 us the posterior's moments took, on the critical path of set 0).  Here work-group 0 computes the
+// doubled variance (AbcUtil.cpp:528-537), the proposal factor (AbcUtil.cpp:462-488), its status and its padded copy, while
+// work-groups 1.. write the padded row-major copy of the rows (k_perturb's parent table), which does not depend on the record.
+// (Also measured: the moments themselves by a direct kernel -- 128 groups, wave-level cross-product columns -- instead of pilot
+// shift + MFMA Gram + reduce: 47 + 34 us against 22, too few waves in flight; and any "last group finishes" ticket costs a
+// device-scope fence per group, i.e. an L2 write-back: 131 us.)
+template <int PP>
+__global__ __launch_bounds__(256) void k_post_tail(const double* __restrict__ theta, size_t K, int P, const double* __restrict__ stats,
+                                                   double* __restrict__ dv, double* __restrict__ Lout, int* __restrict__ spd,
+                                                   double* __restrict__ rows, double* __restrict__ Lpad) {
+    __shared__ double t[PP][65];                    // group 0: the P x P work matrix + P means; others: the transposed tile
+    if (blockIdx.x == 0) {
+        double* sA = &t[0][0];
+        if (dv) for (int p = threadIdx.x; p < P; p += 256) dv[p] = dv_of_stats(stats, P, p);
+        if (Lout && threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            cov_chol_wave(stats, P, sA, sA + P * P, Lout, spd, lane);
+            if (Lpad) {
+                for (int e = lane; e < PP * PP; e += 64) {
+                    const int a = e % PP, b = e / PP;
+                    Lpad[e] = (a < P && b < P && b <= a) ? sA[a + P * b] : 0.0;
+                }
+            }
+        }
+        return;
+    }
+    if (!rows) return;
+    const size_t k0 = (size_t)(blockIdx.x - 1) * 64;
+    for (int e = threadIdx.x; e < PP * 64; e += 256) {
+        const int p = e >> 6, r = e & 63;
+        t[p][r] = (p < P && k0 + r < K) ? theta[k0 + r + K * (size_t)p] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < PP * 64; e += 256) {
+        const int r = e / PP, p = e % PP;
+        if (k0 + r < K) rows[(k0 + r) * PP + p] = t[p][r];
+    }
+}
+
+// dv_p = 2 * Var_p (n-1 denominator) from the same statistics record (AbcUtil.cpp:528-537)
+__global__ void k_dv_from_stats(const double* __restrict__ stats, int P, double* __restrict__ dv) {
+    const int p = threadIdx.x;
+    if (p >= P) return;
+    dv[p] = dv_of_stats(stats, P, p);
 }
 
 }  // namespace
@@ -73,6 +124,26 @@ int launch_theta_stats(abc_ctx* ctx, const double* theta, size_t K, size_t P, do
     ctx->in_mvn = false;
     ABC_TRY(rc_acc);
     *stats_out = stats;
+    return ABC_OK;
+}
+
+// what follows from the record, one launch (P <= 64): every output optional; rows: K x PP row-major, Lpad: PP x PP (abc_perturb_pp)
+int launch_post_tail(abc_ctx* ctx, const double* theta, size_t K, size_t P, const double* stats, const abc_theta_fused* f) {
+    if (P > 64) ABC_FAIL(ctx, ABC_ERR_INVALID, "post tail: more than 64 parameters");
+    const int PP = abc_perturb_pp(P);
+    const unsigned grid = 1u + (f->rows ? (unsigned)((K + 63) / 64) : 0u);
+#define PT_LAUNCH(PPV) hipLaunchKernelGGL(k_post_tail<PPV>, dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, stats, f->dv, f->L, f->spd, \
+                                          f->rows, f->Lpad)
+    switch (PP) {
+        case 2: PT_LAUNCH(2); break;
+        case 4: PT_LAUNCH(4); break;
+        case 8: PT_LAUNCH(8); break;
+        case 16: PT_LAUNCH(16); break;
+        case 32: PT_LAUNCH(32); break;
+        default: PT_LAUNCH(64); break;
+    }
+#undef PT_LAUNCH
+    ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
 

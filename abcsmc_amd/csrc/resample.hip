@@ -598,7 +598,7 @@ int abc_side_fork(abc_ctx* ctx) {
 }
 
 int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset,
-                          uint32_t** raw_out) {
+                          uint32_t** raw_out, uint64_t* parent_uniform, size_t K_uniform) {
     *raw_out = nullptr;
     if (n == 0) return ABC_OK;
     uint32_t* raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
@@ -609,6 +609,11 @@ int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t 
     abc_rng base = *rng;
     taus2_jump(&base, i0);
     ABC_TRY(taus_stream(ctx, base, n, raw, ctx->side));
+    if (parent_uniform && ctx->ualias_K == K_uniform && K_uniform) {
+        hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->side, raw, n, ctx->ualias_F,
+                           ctx->ualias_A, K_uniform, (unsigned long long*)parent_uniform);
+        ABC_HIP(ctx, hipGetLastError());
+    }
     if (seeds) ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, ctx->side));
     ABC_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->side));
     *raw_out = raw;
@@ -628,7 +633,7 @@ int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* 
 
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights,
-                    const uint32_t* raw_ready, bool weights_on_host, const volatile int* abort_flag) {
+                    const uint32_t* raw_ready, bool weights_on_host, const volatile int* abort_flag, bool parents_ready) {
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     if (uniform_weights) {
@@ -642,9 +647,11 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         if (raw_ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
         else ABC_TRY(taus_stream(ctx, base, n, raw));
         if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));
-        hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->ualias_F,
-                           ctx->ualias_A, K, (unsigned long long*)parent);
-        ABC_HIP(ctx, hipGetLastError());
+        if (!(parents_ready && raw_ready)) {
+            hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->ualias_F,
+                               ctx->ualias_A, K, (unsigned long long*)parent);
+            ABC_HIP(ctx, hipGetLastError());
+        }
         return ABC_OK;
     }
     // alias table: weights to the host, serial Walker build, tables back to HBM
@@ -739,19 +746,17 @@ static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n,
 int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P, uint64_t i0, size_t n,
                            uint64_t* seeds, uint64_t seed_stream_offset, abc_perturb_prep* prep, int multivariate,
                            const double* L_or_dv) {
-    prep->rows = nullptr;
-    prep->Lpad = nullptr;
-    if (n == 0) return ABC_OK;
-    int PP = 2;
-    while (PP < (int)P) PP *= 2;
-    if (P > 64) PP = (int)((P + 63) / 64 * 64);
+    if (n == 0) { prep->rows = nullptr; prep->Lpad = nullptr; return ABC_OK; }
+    const int PP = abc_perturb_pp(P);
     StageTimer tm(ctx, ST_PERTURB);
-    double* rows = (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
-    double* Lpad = (multivariate && L_or_dv) ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
-    if (!rows || (multivariate && L_or_dv && !Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
-    ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, Lpad ? L_or_dv : nullptr, Lpad));
-    prep->rows = rows;
-    prep->Lpad = Lpad;
+    if (!prep->rows) {        // (preset: the caller's k_theta_moments launch has written the copy and the padded factor already)
+        double* rows = (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));
+        double* Lpad = (multivariate && L_or_dv) ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
+        if (!rows || (multivariate && L_or_dv && !Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
+        ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, Lpad ? L_or_dv : nullptr, Lpad));
+        prep->rows = rows;
+        prep->Lpad = Lpad;
+    }
     if (seeds && !prep->seeds_done) { ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, nullptr)); prep->seeds_done = 1; }
     return ABC_OK;
 }

@@ -501,8 +501,9 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                           // AbcUtil.cpp:543-544
     } else {
         if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
+        const double* sumsq = nullptr;
         if (W == 1) {
-            ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, io->w, &wprev));
+            ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, io->w, &wprev, &sumsq));
         } else {
             if (kn) ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, k0, kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, w_mine, &wprev));
             ABC_TRY(comm_all_gather(ctx, w_mine, w_slices, kmax * 8));
@@ -515,7 +516,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
             ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;
         }
-        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror));                            // AbcUtil.cpp:583
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror, sumsq));                     // AbcUtil.cpp:583
         w_on_host = mirror != nullptr;
     }
 

@@ -78,7 +78,7 @@ struct WConst {           // per-parameter constants, built on the device by k_w
     int nzero;            // number of parameters with dv_p == 0
     int zero_idx[W_MAXP];
     int far;              // set by k_wscale when a scaled coordinate is so large that exponents may leave int32
-    int nfar_i, nfar_j;   // rows of the new / previous set outside the range the split-operand kernel is exact on (k_wsplit)
+    int nfar_i, nfar_j;   // rows of the new / previous set outside the range the split-operand kernel is exact on (k_wrows)
     int lim_i;            // more far new rows than this: the fp64 kernel takes the whole call
     double centre[W_MAXP]; // robust column centre of the previous set (k_wcentre): both sets are centred here
 };
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_kde_gen(const double* __restrict__ a, s
 //   and add per 16 pairs).
 // Error of a batch sum (16 terms) with the f32 evaluation: 5e-8 rms, 2e-7 max (+ one ulp of v_exp_f32).  Measured error of a
 // weight against the oracle: tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
-// Rows outside the exact range (a |coordinate| > 8, |row|^2 > 400, a weight outside {0} U [2^-300, 2^100]) are "far": k_wsplit
+// Rows outside the exact range (a |coordinate| > 8, |row|^2 > 400, a weight outside {0} U [2^-300, 2^100]) are "far": k_wrows
 // gives them all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up
 // kernels add their pairs (k_kde_far: a far new particle against the whole previous set; the far previous
 // particles against every new one), k_wfinish picking per row.  With converged parameters, coordinates beyond the int32
@@ -379,7 +379,7 @@ __device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc
 }
 constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
 
-// Limb tiles of one set.  Input: the scaled row-major copy (rows x PPsrc) written by k_wscale.
+// Limb tiles of one set (written by k_wrows below).
 // Output, per tile of 32 rows: `ops` operands of 1 KiB in MFMA fragment order [half h][row r][8 x 16 bit] (lane 32h + r
 // reads its 16 bytes at 16*(32h + r)): operand (c*KS_NL + k) = f16 operand k of parameters 16c..16c+15
 //   0: h0    1: h1    2: h0 2^-11    3: r2 2^11        (v = h0 + h1 + r2; operands 2 and 3 meet in h0.r2' = (h0 2^-11).(r2' 2^11):
@@ -389,90 +389,128 @@ constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
 // The new set's 1/2|a_i|^2 is common to every term of row i and stays OUT of the sums: its integer part goes to ha_int
 // (subtracted from the exponent of every batch's power of two), its fraction to ha_frac (k_wfinish, fp64).
 // Rows >= rows are padding: zero limbs; a padded previous row has hb = KS_HB_ZERO (a term of exactly 0).
+
+// f16 bits of n 2^-s for an integer |n| <= 1024 whose value lies on f16's grid (the exact limbs h0 = n0 2^-7, h1 = n1 2^-18,
+// h0 2^-11 = n0 2^-18): integer arithmetic only -- f16_bits does the same through ilogb / ldexp / rint in fp64
+__device__ __forceinline__ unsigned f16_of_int(int n, int s) {
+    const unsigned sg = (n < 0) ? 0x8000u : 0u;
+    const unsigned a = (unsigned)(n < 0 ? -n : n);
+    if (a == 0u) return sg;
+    const int e = 31 - __clz((int)a), E = e - s;
+    if (E >= -14) return sg | ((unsigned)(E + 15) << 10) | ((a << (10 - e)) & 0x3ffu);
+    return sg | (a << (24 - s));                                   // subnormal: units of 2^-24
+}
+
+// Scaled copy and limb tiles in ONE pass over a set (round 3: as two kernels, k_wscale + a per-row split kernel, they were 37 us of the new set's prologue, in front of the
+// pair sums, one thread per row with ~2000 dependent instructions each): a row is dealt out to 2 NCH lanes of one wave, eight
+// parameters each -- lane g RW + rr handles parameters 8g .. 8g + 7 of row rr of the wave's RW = 64 / (2 NCH) rows -- which is
+// also the tile layout: the lane's four 16-byte limb operands go straight to [half][row][8 x 16 bit].  Row quantities (norm,
+// far flags) are combined across the row's lanes in fixed order.  Same outputs as the two kernels: the scaled fp64 row-major
+// copy (+ hb for the previous set), the limb tiles, far flags / list, ha_int / ha_frac.
 template <int NCH>
-__global__ __launch_bounds__(256) void k_wsplit(const double* __restrict__ sc, int PPsrc, size_t rows, size_t rows_pad,
-                                                const double* __restrict__ w, int is_prev, WConst* __restrict__ wc,
-                                                unsigned short* __restrict__ tiles, int ops,
-                                                unsigned char* __restrict__ far_flag /* new set */,
-                                                unsigned* __restrict__ far_list /* previous set, KS_MAX_FAR_J */,
-                                                int* __restrict__ ha_int, double* __restrict__ ha_frac /* new set */) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows_pad) return;
-    bool valid = r < rows;
+__global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP, size_t rows_pad,
+                                               WConst* __restrict__ wc, const double* __restrict__ w, int is_prev,
+                                               double* __restrict__ out, double* __restrict__ hb,
+                                               unsigned short* __restrict__ tiles, int ops, unsigned char* __restrict__ far_flag,
+                                               unsigned* __restrict__ far_list, int* __restrict__ ha_int, double* __restrict__ ha_frac) {
+    constexpr int G = 2 * NCH, RW = 64 / G;
+    const int lane = threadIdx.x & 63, g = lane / RW, rr = lane % RW;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave * RW >= rows_pad) return;                              // wave-uniform
+    const size_t r = wave * RW + rr;
+    const bool inrange = r < rows;
+    double v[8], nn = 0.0;
+    bool far2k = false, far8 = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int p = 8 * g + j;
+        v[j] = (inrange && p < P) ? (in[r + ld * (size_t)p] - wc->centre[p]) * wc->scale[p] : 0.0;
+        nn = fma(v[j], v[j], nn);
+        far2k = far2k || (fabs(v[j]) > W_COORD_BOUND);
+        far8 = far8 || !(fabs(v[j]) <= KS_BOUND);
+    }
+    if (inrange) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const int p = 8 * g + j;
+            if (p < PP) *reinterpret_cast<double2*>(out + r * (size_t)PP + p) = make_double2(v[j], v[j + 1]);
+        }
+    }
+    // the row's norm: its lanes' partial sums in ascending parameter order (every lane of the row gets the same value)
+    double nrow = __shfl(nn, rr, 64);
+#pragma unroll
+    for (int gg = 1; gg < G; gg++) nrow += __shfl(nn, gg * RW + rr, 64);
+    bool rfar2k = far2k, rfar8 = far8;
+#pragma unroll
+    for (int o = RW; o < 64; o <<= 1) {
+        rfar2k = rfar2k || (__shfl_xor((int)rfar2k, o, 64) != 0);
+        rfar8 = rfar8 || (__shfl_xor((int)rfar8, o, 64) != 0);
+    }
+    bool valid = inrange;
     double lw = 0.0;
     bool far = false;
     if (is_prev) {
-        const double wr = valid ? w[r] : 0.0;
-        if (wr == 0.0) valid = false;                         // weight 0: contributes exactly nothing, like padding
+        const double wr = inrange ? w[r] : 0.0;
+        const double lwr = -log2(wr);                                // w = 0 -> +inf
+        if (inrange && g == 0) hb[r] = 0.5 * nrow + ((lwr > W_HB_MAX) ? W_HB_MAX : lwr);     // fp64 kernels: capped, not NaN
+        if (wr == 0.0) valid = false;                                // weight 0: contributes exactly nothing, like padding
         else {
-            lw = -log2(wr);
-            if (!(lw >= KS_LW_MIN && lw <= KS_LW_CAP)) far = true;      // w' > 2^100, < 2^-300, negative or NaN
+            lw = lwr;
+            if (!(lw >= KS_LW_MIN && lw <= KS_LW_CAP)) far = true;   // w' > 2^100, < 2^-300, negative or NaN
         }
     }
-    constexpr int PPK = 16 * NCH;
-    if (valid) {
-        double n2 = 0.0;
-        for (int p = 0; p < PPK && p < PPsrc; p++) {
-            const double v = sc[r * (size_t)PPsrc + p];
-            far = far || !(fabs(v) <= KS_BOUND);
-            n2 = fma(v, v, n2);
-        }
-        far = far || !(n2 <= KS_NORM2);
-    }
+    if (rfar2k && inrange && g == 0) atomicOr(&wc->far, 1);
+    if (valid) far = far || rfar8 || !(nrow <= KS_NORM2);
     // a far row takes no part in the matrix work (all-zero limbs, and hb = KS_HB_ZERO on the previous side): the fp64
     // fix-up kernel (k_kde_far) adds its pairs
     if (far) {
-        if (is_prev) { const int pos = atomicAdd(&wc->nfar_j, 1); if (pos < KS_MAX_FAR_J) far_list[pos] = (unsigned)r; }
-        else atomicAdd(&wc->nfar_i, 1);
+        if (g == 0) {
+            if (is_prev) { const int pos = atomicAdd(&wc->nfar_j, 1); if (pos < KS_MAX_FAR_J) far_list[pos] = (unsigned)r; }
+            else atomicAdd(&wc->nfar_i, 1);
+        }
         valid = false;
     }
-    if (!is_prev) far_flag[r] = far ? 1 : 0;
+    if (!is_prev && g == 0) far_flag[r] = far ? 1 : 0;
     unsigned short* tb = tiles + (r >> 5) * (size_t)ops * 512;
-    const unsigned rr = (unsigned)(r & 31);
-    double nn = 0.0;
+    const unsigned r32 = (unsigned)(r & 31);
+    const int c = g >> 1, h = g & 1;
+    unsigned pk[KS_NL][4];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    for (int j = 0; j < 8; j++) {
+        const double x = valid ? v[j] : 0.0;
+        const int n0 = (int)rint(x * KS_U0);                         // h0 = n0 2^-7, |n0| <= 1024
+        const double r1 = x - (double)n0 * (1.0 / KS_U0);            // |r1| <= 2^-8, exact
+        const int n1 = (int)rint(r1 * KS_UH);                        // h1 = n1 2^-18, |n1| <= 1024
+        const double r2 = r1 - (double)n1 * (1.0 / KS_UH);           // |r2| <= 2^-19, exact
+        unsigned b[KS_NL];
+        b[0] = f16_of_int(n0, 7);
+        b[1] = f16_of_int(n1, 18);
+        b[2] = f16_of_int(n0, 18);                                   // h0 2^-11
+        b[3] = f16_bits(r2 * 0x1p11);                                // |.| <= 2^-8, rounded to eleven significant bits
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            unsigned pk[KS_NL][4];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int p = c * 16 + h * 8 + j;            // the copy is PPsrc wide (zero padded to a power of two)
-                const double v = (valid && p < PPsrc) ? sc[r * (size_t)PPsrc + p] : 0.0;
-                nn = fma(v, v, nn);
-                const double h0 = rint(v * KS_U0) * (1.0 / KS_U0);       // <= 1024 units of 2^-7: exact in f16
-                const double r1 = v - h0;                                // |r1| <= 2^-8
-                const double h1 = rint(r1 * KS_UH) * (1.0 / KS_UH);      // <= 1024 units of 2^-18: exact in f16 (subnormal below 2^-14)
-                const double r2 = r1 - h1;                               // |r2| <= 2^-19
-                unsigned b[KS_NL];
-                b[0] = f16_bits(h0);
-                b[1] = f16_bits(h1);
-                b[2] = f16_bits(h0 * 0x1p-11);                           // exact: multiples of 2^-18, on the subnormal grid 2^-24
-                b[3] = f16_bits(r2 * 0x1p11);                            // |.| <= 2^-8, eleven significant bits
-#pragma unroll
-                for (int k = 0; k < KS_NL; k++) {
-                    if (j & 1) pk[k][j >> 1] |= b[k] << 16; else pk[k][j >> 1] = b[k];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KS_NL; k++)
-                *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + rr) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+        for (int k = 0; k < KS_NL; k++) {
+            if (j & 1) pk[k][j >> 1] |= b[k] << 16; else pk[k][j >> 1] = b[k];
         }
     }
-    if (is_prev) {
-        unsigned pc[6];
-        unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
-        ks_pieces(valid ? 0.5 * nn + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
-        // K-slots 6,7 = 1 for the rows an MFMA result holds in its lanes 0..31 (bit 2 of the row clear), 8,9 = 1 for the others:
-        // against a B operand whose slots 6,7 / 8,9 carry the pieces of -n, the lane's own batch reference is subtracted from
-        // exactly its rows (k_kde_split)
-        const unsigned ones = KS_ONE | (KS_ONE << 16);
-        *(uint4*)(ob + rr * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), (rr & 4) ? 0u : ones);
-        *(uint4*)(ob + (32 + rr) * 8) = make_uint4((rr & 4) ? ones : 0u, 0u, 0u, 0u);
-    } else {
-        const double ha = 0.5 * nn, hi = floor(ha);          // 0 for a far / padded row
-        ha_int[r] = (int)hi;
-        ha_frac[r] = ha - hi;
+#pragma unroll
+    for (int k = 0; k < KS_NL; k++)
+        *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + r32) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+    if (g == 0) {
+        if (is_prev) {
+            unsigned pc[6];
+            unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
+            ks_pieces(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
+            // K-slots 6,7 = 1 for the rows an MFMA result holds in its lanes 0..31 (bit 2 of the row clear), 8,9 = 1 for the others:
+            // against a B operand whose slots 6,7 / 8,9 carry the pieces of -n, the lane's own batch reference is subtracted from
+            // exactly its rows (k_kde_split)
+            const unsigned ones = KS_ONE | (KS_ONE << 16);
+            *(uint4*)(ob + r32 * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), (r32 & 4) ? 0u : ones);
+            *(uint4*)(ob + (32 + r32) * 8) = make_uint4((r32 & 4) ? ones : 0u, 0u, 0u, 0u);
+        } else {
+            const double ha = valid ? 0.5 * nrow : 0.0, hi = floor(ha);          // 0 for a far / padded row
+            ha_int[r] = (int)hi;
+            ha_frac[r] = ha - hi;
+        }
     }
 }
 
@@ -559,7 +597,7 @@ struct KsRef { float p0, p1, p2, p3; };        // the four running f32 sums of a
 // Z = X - n + Y in ONE f32 accumulator.  The chain starts with the exact part X (norm top, h0.h0'); the vector pipe takes
 // n = floor(max X) over the 16 values a lane owns of the 32 x 32 block (8 v_max3_f32) and hands -n back to the matrix pipe as
 // the B operand of one more bf16 step -- its two bf16 pieces in K-slots 6,7 of lanes 0..31 and 8,9 of lanes 32..63, against the
-// ones k_wsplit put in the previous set's norm operand, so each lane's n lands on exactly the rows that lane holds -- which is
+// ones k_wrows put in the previous set's norm operand, so each lane's n lands on exactly the rows that lane holds -- which is
 // still exact (multiples of 2^-14 below 2^11); then -hbLow and the five small products follow into the SAME accumulator, which
 // by then is small (< 1.3 for the terms that carry the sum), so their roundings are 2^-25 |Z| each.  The vector pipe is left with
 // v_exp_f32 (measured on gfx950 over every float of [-0.3, 1.3], scripts/exp2_hw_accuracy.hip: max 8.2e-8, rms 2.6e-8 relative)
@@ -723,30 +761,74 @@ __device__ __forceinline__ double prior_likelihood(const abc_prior& pr, double v
     return ((pr.a <= v) && (v <= pr.b)) ? 1.0 / (pr.b - pr.a) : 0.0;
 }
 
+// Sum of squares of the weights (the L2 normalisation, AbcUtil.cpp:583) in a fixed, launch-independent order, so that every
+// path -- k_wfinish below, the stand-alone k_sumsq_partial -- produces the same bits: work-groups of 64 consecutive rows
+// (thread r < 64 of a 256-thread group holds row r's square, the other threads 0; block_sum_256's tree) write one partial each;
+// the total is the partials added in index order by ONE work-group's worth of threads -- thread t takes t, t + 256, ..., then
+// the same tree (sumsq_total) -- in the prologue of the normalisation kernel (every work-group repeats it: the same bits
+// everywhere) or, beyond SQ_INLINE_MAX partials, by a one-group launch in front of it.  (A "last group finishes" ticket inside
+// the producing kernel was measured first: the device-scope fence it needs writes back the XCD's L2 per work-group -- k_wfinish
+// went from 19 to 46 us.  Kernel boundaries are the cheap coherence point on this chip.)
+constexpr unsigned SQ_INLINE_MAX = 4096;
+__device__ __forceinline__ double sumsq_total(const double* __restrict__ sq_part, unsigned nparts, double* sm /* >= 4 */) {
+    double t = 0.0;
+    for (unsigned j = threadIdx.x; j < nparts; j += 256) t += sq_part[j];
+    return block_sum_256(t, sm);
+}
+__global__ __launch_bounds__(256) void k_sumsq_total(const double* __restrict__ sq_part, unsigned nparts, double* __restrict__ sq_total) {
+    __shared__ double sm[4];
+    const double t = sumsq_total(sq_part, nparts, sm);
+    if (threadIdx.x == 0) *sq_total = t;
+}
+
 // w_raw[i] = prod_p likelihood_p(theta_ip) / (C * sum over slices)   (AbcUtil.cpp:557-580)
+// FOUR waves per 64 rows (round 3: one thread per row walked 16 likelihoods -- a division, an exponential, a square root each --
+// and ~30 slice partials as ONE dependent chain, 19 us at K = 1e5 on a quarter-filled chip): wave q takes the parameters and the
+// slices = q (mod 4) -- the parameter stays wave-uniform: its prior comes through the scalar cache and only its kind's code runs --,
+// the four partial products / sums meet in LDS and wave 0 finishes the row.
+// sq_part != NULL: the 64-row partials of the raw weights' sum of squares come out of the same launch (see sumsq_total).
 __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ priors, const double* __restrict__ theta,
                                                  size_t K, int P, size_t k0, size_t kn,
                                                  const double* __restrict__ part, int slices,
                                                  const WConst* __restrict__ wc, double* __restrict__ w_raw,
                                                  int split_launched, int epan, int* __restrict__ which,
                                                  const unsigned char* __restrict__ far_flag, const double* __restrict__ fix_i,
-                                                 const double* __restrict__ fix_j, const double* __restrict__ ha_frac) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                 const double* __restrict__ fix_j, const double* __restrict__ ha_frac,
+                                                 double* __restrict__ sq_part) {
+    __shared__ double sm[4];
+    __shared__ double sn[4][64], sd[4][64];
+    const int wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
     const bool split_on = split_launched && ks_split_on(wc);
-    if (i == 0) *which = split_on ? ABC_KDE_RAN_SPLIT : ABC_KDE_RAN_FP64;       // abc_kde_last_kernel
-    if (i >= kn) return;
-    double num = 1.0;
-    for (int p = 0; p < P; p++) num *= prior_likelihood(priors[p], theta[(k0 + i) + K * (size_t)p]);
-    double den = 0.0;
-    if (split_on && far_flag[i]) {
-        den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far
-    } else {
-        for (int s = 0; s < slices; s++) den += part[(size_t)s * kn + i];
-        if (split_on) den *= exp2(-ha_frac[i]);              // the fraction of 1/2|a_i|^2 the split kernel left out (k_wsplit)
-        if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *which = split_on ? ABC_KDE_RAN_SPLIT : ABC_KDE_RAN_FP64;       // abc_kde_last_kernel
+    const bool active = i < kn;
+    double num = 1.0, den = 0.0;
+    const bool far_row = active && split_on && far_flag[i];
+    if (active) {
+        for (int p = wq; p < P; p += 4) num *= prior_likelihood(priors[p], theta[(k0 + i) + K * (size_t)p]);
+        if (!far_row) for (int s = wq; s < slices; s += 4) den += part[(size_t)s * kn + i];
     }
-    if (epan) w_raw[i] = (den > 0.0) ? num / den : 0.0;          // compact support: a particle nothing supports gets weight 0
-    else w_raw[i] = num / (wc->C * den);
+    sn[wq][lane] = num;
+    sd[wq][lane] = den;
+    __syncthreads();
+    double wv = 0.0;
+    if (wq == 0 && active) {
+        num = (sn[0][lane] * sn[1][lane]) * (sn[2][lane] * sn[3][lane]);
+        if (far_row) {
+            den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far
+        } else {
+            den = (sd[0][lane] + sd[1][lane]) + (sd[2][lane] + sd[3][lane]);
+            if (split_on) den *= exp2(-ha_frac[i]);              // the fraction of 1/2|a_i|^2 the split kernel left out (k_wrows)
+            if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far)
+        }
+        if (epan) wv = (den > 0.0) ? num / den : 0.0;            // compact support: a particle nothing supports gets weight 0
+        else wv = num / (wc->C * den);
+        w_raw[i] = wv;
+    }
+    if (sq_part) {
+        const double bs = block_sum_256(wv * wv, sm);
+        if (threadIdx.x == 0) sq_part[blockIdx.x] = bs;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill(double* __restrict__ w, size_t K, double v) {
@@ -754,22 +836,23 @@ __global__ __launch_bounds__(256) void k_fill(double* __restrict__ w, size_t K, 
     if (i < K) w[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict__ w, size_t K,
-                                                       double* __restrict__ part) {
+// the same partials for weights that are already in memory (stage-level callers, the sharded driver's gathered slices)
+__global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict__ w, size_t K, double* __restrict__ sq_part) {
     __shared__ double sm[4];
-    double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < K; i += (size_t)gridDim.x * 256) s = fma(w[i], w[i], s);
-    s = block_sum_256(s, sm);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    double wv = 0.0;
+    if (threadIdx.x < 64 && i < K) wv = w[i];
+    const double bs = block_sum_256(wv * wv, sm);
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = bs;
 }
 
 // host_mirror (optional): a pinned, device-visible buffer that receives the normalised weights as they are written -- the
 // host's alias build needs them next, and a store over PCIe from here saves the blit copy and its launch gap behind this kernel
-__global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t K, const double* __restrict__ part,
-                                                  int nparts, double* __restrict__ host_mirror) {
-    // every work-group adds the (<= 256) partial sums in the same fixed order: one per thread, then the block tree
+// nparts != 0: sq points at the partials, summed here (sumsq_total); nparts == 0: at the finished total
+__global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t K, const double* __restrict__ sq_in, unsigned nparts,
+                                                  double* __restrict__ host_mirror) {
     __shared__ double sm[4];
-    const double sq = block_sum_256(((int)threadIdx.x < nparts) ? part[threadIdx.x] : 0.0, sm);
+    const double sq = nparts ? sumsq_total(sq_in, nparts, sm) : *sq_in;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= K) return;
     double v = w[i];
@@ -781,6 +864,8 @@ __global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t
 }
 
 }  // namespace
+
+int abc_kde_words(abc_ctx* ctx);
 
 int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P, const uint64_t* idx,
                        size_t K, uint64_t idx_base, double* theta, size_t ldt, const int* sel_fail, int* sel_fail_pin) {
@@ -841,16 +926,17 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, s, dv_prev, (int)P, wc, (int)(kn_max / 16 + 32));
     hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, s, theta_prev, Kp, wc, cpart);
     hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(P > 64 ? 1024 : 64), 0, s, theta_prev, Kp, (int)P, cpart, wc);
-    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
-                       (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
-    if (split) {
+    if (split) {         // scaled copy, hb and the limb tiles in one pass (k_wrows)
         const size_t rbp = nbt * 32;
         if (NCH == 1)
-            hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, s, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+            hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((rbp / 32 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
         else
-            hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((rbp + 255) / 256)), dim3(256), 0, s, b, PP, Kp, rbp,
-                               w_prev, 1, wc, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+            hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((rbp / 16 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
+                           (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
     }
     ABC_HIP(ctx, hipGetLastError());
     out->wc = wc; out->b = b; out->hb = hb; out->bt = bt; out->far_list = far_list;
@@ -860,13 +946,11 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
 
 int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* theta, size_t K, size_t P, size_t k0,
                        size_t kn, const double* theta_prev, size_t Kp, const double* w_prev, const double* dv_prev,
-                       double* w_raw, const abc_wprev* prev) {
+                       double* w_raw, const abc_wprev* prev, const double** sumsq_out) {
+    if (sumsq_out) *sumsq_out = nullptr;
     if (P > (size_t)W_MAXP) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: P = %zu > %d parameters", P, W_MAXP);
     if (kn == 0) return ABC_OK;
-    if (!ctx->kde_which) {
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->kde_which, sizeof(int)));
-        ABC_HIP(ctx, hipMemsetAsync(ctx->kde_which, 0, sizeof(int), ctx->stream));
-    }
+    ABC_TRY(abc_kde_words(ctx));
     if (Kp > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "weights: K' = %zu >= 2^32", Kp);
     if (k0 + kn > K) ABC_FAIL(ctx, ABC_ERR_INVALID, "weights: row range [%zu,%zu) outside K=%zu", k0, k0 + kn, K);
     int PP = 2;
@@ -926,16 +1010,17 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (!a || !part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
-    hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
-                       (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
     if (split) {
         const size_t ra = nat * 32;
         if (NCH == 1)
-            hipLaunchKernelGGL(k_wsplit<1>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
-                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list, ha_int, ha_frac);
+            hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((ra / 32 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
         else
-            hipLaunchKernelGGL(k_wsplit<2>, dim3((unsigned)((ra + 255) / 256)), dim3(256), 0, ctx->stream, a, PP, kn, ra,
-                               (const double*)nullptr, 0, wc, at, opa, far_flag, far_list, ha_int, ha_frac);
+            hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((ra / 16 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
+    } else {
+        hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
+                           (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
     }
 #define LAUNCH_KDE(PPV)                                                                                        \
     hipLaunchKernelGGL(k_kde<PPV>, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, \
@@ -992,9 +1077,25 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         }
 #undef LAUNCH_FAR
     }
-    hipLaunchKernelGGL(k_wfinish, dim3((unsigned)rb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
-                       (int)slices, wc, w_raw, split ? 1 : 0, epan ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j, ha_frac);
+    // the whole set in one call (k0 = 0, kn = K) and a caller that normalises next: the sum of squares comes out of k_wfinish
+    const unsigned fb = (unsigned)((kn + 63) / 64);
+    double* sq_part = nullptr;
+    if (sumsq_out && k0 == 0 && kn == K) {
+        sq_part = (double*)abc_ws_alloc(ctx, ((size_t)fb + 1) * sizeof(double));
+        if (!sq_part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+        *sumsq_out = sq_part;                 // the partials (launch_normalize_l2 sums them; slot fb is scratch for the total)
+    }
+    hipLaunchKernelGGL(k_wfinish, dim3(fb), dim3(256), 0, ctx->stream, priors, theta, K, (int)P, k0, kn, part,
+                       (int)slices, wc, w_raw, split ? 1 : 0, epan ? 1 : 0, ctx->kde_which, far_flag, fix_i, fix_j, ha_frac, sq_part);
     ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
+// the context's device word: which weight kernel ran last (abc_kde_last_kernel)
+int abc_kde_words(abc_ctx* ctx) {
+    if (ctx->kde_which) return ABC_OK;
+    ABC_HIP(ctx, hipMalloc((void**)&ctx->kde_which, 2 * sizeof(int)));
+    ABC_HIP(ctx, hipMemsetAsync(ctx->kde_which, 0, 2 * sizeof(int), ctx->stream));
     return ABC_OK;
 }
 
@@ -1005,15 +1106,23 @@ int launch_fill(abc_ctx* ctx, double* w, size_t K, double v) {
     return ABC_OK;
 }
 
-int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K, double* host_mirror) {
+int launch_normalize_l2(abc_ctx* ctx, double* w, size_t K, double* host_mirror, const double* sumsq_parts) {
     if (!K) return ABC_OK;
-    int nparts = (int)((K + 255) / 256);
-    if (nparts > 256) nparts = 256;
-    double* part = (double*)abc_ws_alloc(ctx, nparts * sizeof(double));
-    if (!part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "normalize: workspace exhausted");
     StageTimer tm(ctx, ST_WEIGHTS_MISC);
-    hipLaunchKernelGGL(k_sumsq_partial, dim3(nparts), dim3(256), 0, ctx->stream, w, K, part);
-    hipLaunchKernelGGL(k_div_norm, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, part, nparts, host_mirror);
+    const unsigned fb = (unsigned)((K + 63) / 64);
+    double* sq_part = const_cast<double*>(sumsq_parts);      // (k_wfinish's: fb partials + one scratch slot)
+    if (!sq_part) {
+        sq_part = (double*)abc_ws_alloc(ctx, ((size_t)fb + 1) * sizeof(double));
+        if (!sq_part) ABC_FAIL(ctx, ABC_ERR_NOMEM, "normalize: workspace exhausted");
+        hipLaunchKernelGGL(k_sumsq_partial, dim3(fb), dim3(256), 0, ctx->stream, w, K, sq_part);
+    }
+    const unsigned db = (unsigned)((K + 255) / 256);
+    if (fb <= SQ_INLINE_MAX) {
+        hipLaunchKernelGGL(k_div_norm, dim3(db), dim3(256), 0, ctx->stream, w, K, sq_part, fb, host_mirror);
+    } else {
+        hipLaunchKernelGGL(k_sumsq_total, dim3(1), dim3(256), 0, ctx->stream, sq_part, fb, sq_part + fb);
+        hipLaunchKernelGGL(k_div_norm, dim3(db), dim3(256), 0, ctx->stream, w, K, sq_part + fb, 0u, host_mirror);
+    }
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
