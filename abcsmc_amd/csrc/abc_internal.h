@@ -208,6 +208,11 @@ int launch_select_pick(abc_ctx*, long long* state, int pass, int* hist, uint64_t
 int launch_select_count(abc_ctx*, const double* dist, size_t n, const long long* state, long long* counts);
 int launch_select_compact(abc_ctx*, const double* dist, size_t n, const long long* state, uint64_t n_less,
                           uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out);
+// distributed selection by a gathered sample (select.hip, "distributed selection by a gathered sample")
+int launch_select_sample(abc_ctx*, const double* dist, size_t n, int SL, double* out);
+int launch_select_threshold(abc_ctx*, const double* sample, int S, uint64_t K, uint64_t N, long long* state);
+int launch_select_candidates(abc_ctx*, const double* dist, size_t n, const long long* state, uint64_t idx_base, size_t cap,
+                             uint64_t* idx_out, double* dist_out, uint64_t* hdr);
 int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
                        unsigned long long* val1, size_t n, int byte_lo, int byte_hi);
 // Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n)
@@ -243,7 +248,7 @@ int launch_weights_raw(abc_ctx*, const abc_prior* priors, const double* theta, s
 // launch_weights_prev on the side stream (resample.hip); the caller makes its stream wait for ctx->ev_prev before the rest
 int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                            const double* dv_prev, abc_wprev* out);
-int launch_fill(abc_ctx*, double* w, size_t K, double v);
+int launch_fill(abc_ctx*, double* w, size_t K, double v, hipStream_t st = nullptr);     // st == NULL: the context's stream
 int launch_normalize_l2(abc_ctx*, double* w, size_t K, double* host_mirror = nullptr, const double* sumsq_parts = nullptr);
 // pinned scratch of the alias build over K weights: w | F | A | (pad) | E | the two index stacks (K + 1 entries each)
 static inline size_t abc_alias_pin_bytes(size_t K) { return K * (sizeof(double) * 3 + sizeof(uint32_t) * 3) + 2 * sizeof(uint32_t) + 16; }

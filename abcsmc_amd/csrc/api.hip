@@ -484,6 +484,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, forked behind the Gram
     // kernel (which wants the whole memory system) and running beside the reduce / model fit that leave the chip empty
     uint32_t* raw_early = nullptr;
+    bool filled_early = false;
+    if (early && uniform_w) {         // the uniform weights themselves (AbcUtil.cpp:543-544): nothing on the main stream reads them
+        ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K, ctx->side));
+        filled_early = true;
+    }
     if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early, parent_early, K));
     // ... and so does everything the weight stage needs of the PREVIOUS set (scales, centre, scaled copy, limb tiles)
     abc_wprev wprev;
@@ -544,7 +549,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     }
     bool w_on_host = false;
     if (Kp == 0 || !io->theta_prev) {
-        ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
+        if (!filled_early) ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
     } else {
         if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
         const double* sumsq = nullptr;       // the normalisation's sum of squares comes out of the weight stage's last kernel

@@ -180,6 +180,52 @@ __global__ __launch_bounds__(256) void k_place_valid(const double* __restrict__ 
     dst[e] = all[((size_t)q * C + c) * vmax + (i - (size_t)voff[q])];
 }
 
+// candidate lists of all ranks, as gathered: rank q's record = [header 256 B][dist cap][global row cap][rows cap x P column-major]
+struct CandRec {
+    size_t cap, P, rec_bytes;
+    __host__ __device__ const unsigned long long* hdr(const char* all, int q) const { return (const unsigned long long*)(all + (size_t)q * rec_bytes); }
+    __host__ __device__ const double* dist(const char* all, int q) const { return (const double*)(all + (size_t)q * rec_bytes + 256); }
+    __host__ __device__ const unsigned long long* idx(const char* all, int q) const { return (const unsigned long long*)(all + (size_t)q * rec_bytes + 256 + cap * 8); }
+    __host__ __device__ const double* rows(const char* all, int q) const { return (const double*)(all + (size_t)q * rec_bytes + 256 + cap * 16); }
+};
+// the candidates' distances as ONE array in (rank, row) = global row order with their positions as payload; thread 0 applies the
+// rule every rank applies alike: the lists must hold the K smallest (their total reaches K) and none may be truncated
+__global__ __launch_bounds__(256) void k_ds_unpack(const char* __restrict__ all, CandRec R, int W, unsigned long long K,
+                                                   double* __restrict__ cand_dist, unsigned long long* __restrict__ cand_pos,
+                                                   int* __restrict__ fail, int* __restrict__ fail_pin) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) {
+        unsigned long long tot = 0;
+        int bad = 0;
+        for (int q = 0; q < W; q++) { const unsigned long long c = R.hdr(all, q)[0]; tot += c; if (c > R.cap) bad = 1; }
+        if (tot < K) bad = 1;
+        *fail = bad;
+        if (fail_pin) *fail_pin = bad;
+    }
+    if (e >= (size_t)W * R.cap) return;
+    const int q = (int)(e / R.cap);
+    const size_t j = e % R.cap;
+    cand_dist[e] = R.dist(all, q)[j];
+    cand_pos[e] = e;
+}
+// the K winners in ascending (distance, global row) order = the first K of the sorted candidates: their rows and parameters
+__global__ __launch_bounds__(256) void k_ds_place(const char* __restrict__ all, CandRec R, const double* __restrict__ sdist,
+                                                  const unsigned long long* __restrict__ spos, size_t K, const int* __restrict__ fail,
+                                                  unsigned long long* __restrict__ idx, double* __restrict__ dist, double* __restrict__ theta) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * (R.P + 1)) return;
+    const size_t k = e % K, p = e / K;          // p == P: the index / distance pair
+    if (*fail) {                                // harmless, in-range placeholder; the generation repeats with the radix protocol
+        if (p == R.P) { idx[k] = k; if (dist) dist[k] = 0.0; } else theta[k + K * p] = 0.0;
+        return;
+    }
+    const unsigned long long pos = spos[k];
+    const int q = (int)(pos / R.cap);
+    const size_t j = (size_t)(pos % R.cap);
+    if (p == R.P) { idx[k] = R.idx(all, q)[j]; if (dist) dist[k] = sdist[k]; }
+    else theta[k + K * p] = R.rows(all, q)[j + R.cap * p];
+}
+
 size_t default_A(size_t M, size_t P, int max_comp) { return (max_comp > 0) ? (size_t)max_comp : (M < P ? M : P); }
 
 }  // namespace
@@ -323,7 +369,27 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     const size_t kbase = K / (size_t)W, krem = K % (size_t)W, kmax = kbase + (krem ? 1 : 0);
     const size_t k0 = (size_t)r * kbase + ((size_t)r < krem ? (size_t)r : krem), kn = kbase + ((size_t)r < krem ? 1 : 0);
 
-    size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20);
+    // Selection over the ranks: by a gathered sample (two all-gathers) when the set is large and at most half of it is kept,
+    // else -- and as the fallback when the sample's bound turns out too low or a list overflows -- the radix protocol (six
+    // all-reduced histograms).  The sample: DSL evenly spaced local distances per rank, a power of two <= N / (16 W), S = DSL W
+    // <= 16384 keys in all (128 KB of LDS in launch_select_threshold); the lists' common capacity follows from N, K, S alone.
+    int DSL = 4096;
+    while (DSL > 1 && (size_t)DSL * 16 > N / (size_t)W) DSL >>= 1;
+    while ((size_t)DSL * (size_t)W > 16384) DSL >>= 1;
+    const bool fast_sel = W > 1 && !ctx->sel_force_radix && 2 * K <= N && DSL >= 256;
+    size_t ds_cap = 0;
+    if (fast_sel) {
+        const double f = (double)K / (double)N, S = (double)DSL * W;
+        double q = f * S + 4.0 * sqrt(S * f * (1.0 - f)) + 8.0;      // rank of the bound among the samples (k_ds_threshold)
+        if (q > S - 1) q = S - 1;
+        const double expect = (q + 1.0) / S * (double)N / (double)W;  // keys below it per rank
+        ds_cap = (size_t)(1.10 * expect + 8.0 * sqrt(expect) + 256.0);
+        ds_cap = (ds_cap + 31) / 32 * 32;
+    }
+    int* pfail_early = nullptr;          // pinned: the candidate rule's verdict, seen by the host at its wait for the weights
+    int* ds_fail_dev = nullptr;
+    const abc_rng rng_entry = *rng;
+    size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20) + 8 * (size_t)W * ds_cap * 8;
     const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
     if (cfg->rule == ABC_RULE_WILCOXON) {
         // the validation rows of the whole set are assembled on every rank (all-gather of the shards' validation rows)
@@ -427,6 +493,40 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     if (W == 1) {
         ABC_TRY(launch_select_smallest(ctx, dist, n, K, row0, io->idx, io->dist));
         ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, io->idx, K, row0, theta, K));
+    } else if (fast_sel) {
+        // gathered sample -> bound of the K-th key -> fixed-capacity candidate lists with their rows, ONE all-gather -> the exact K
+        // smallest of the union, picked locally (select.hip: "distributed selection by a gathered sample")
+        const int S = DSL * W;
+        double* samp_mine = (double*)abc_ws_alloc(ctx, (size_t)DSL * 8);
+        double* samp_all = (double*)abc_ws_alloc(ctx, (size_t)S * 8);
+        int* ds_fail = (int*)abc_ws_alloc(ctx, sizeof(int));
+        if (!samp_mine || !samp_all || !ds_fail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        ABC_TRY(launch_select_sample(ctx, dist, n, DSL, samp_mine));
+        ABC_TRY(comm_all_gather(ctx, samp_mine, samp_all, (size_t)DSL * 8));
+        ABC_TRY(launch_select_threshold(ctx, samp_all, S, K, N, sel_state));
+        CandRec R;
+        R.cap = ds_cap; R.P = P; R.rec_bytes = abc_align(256 + ds_cap * (16 + 8 * P), 256);
+        const size_t tot = (size_t)W * ds_cap;
+        ABC_TRY(xbuf_reserve(ctx, (size_t)(W + 1) * R.rec_bytes + tot * 16 + 4096));
+        char* rec_mine = ctx->xbuf;
+        char* rec_all = rec_mine + R.rec_bytes;
+        double* cand_dist = (double*)(rec_all + (size_t)W * R.rec_bytes);
+        uint64_t* cand_pos = (uint64_t*)(cand_dist + tot);
+        ABC_TRY(launch_select_candidates(ctx, dist, n, sel_state, row0, ds_cap, (uint64_t*)R.idx(rec_mine, 0), (double*)R.dist(rec_mine, 0),
+                                         (uint64_t*)R.hdr(rec_mine, 0)));
+        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, (const uint64_t*)R.idx(rec_mine, 0), ds_cap, row0, (double*)R.rows(rec_mine, 0), ds_cap));
+        ABC_TRY(comm_all_gather(ctx, rec_mine, rec_all, R.rec_bytes));
+        pfail_early = (int*)(ctx->status_pin + 40);
+        *pfail_early = 0;
+        ds_fail_dev = ds_fail;
+        hipLaunchKernelGGL(k_ds_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R, W,
+                           (unsigned long long)K, cand_dist, (unsigned long long*)cand_pos, ds_fail, pfail_early);
+        ABC_HIP(ctx, hipGetLastError());
+        ABC_TRY(launch_sort_pairs(ctx, cand_dist, cand_pos, tot));      // stable: equal distances stay in global row order
+        hipLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R,
+                           (const double*)cand_dist, (const unsigned long long*)cand_pos, K, (const int*)ds_fail,
+                           (unsigned long long*)io->idx, io->dist, theta);
+        ABC_HIP(ctx, hipGetLastError());
     } else {
         ABC_TRY(launch_select_begin(ctx, K, sel_state, sel_hist));
         for (int p = 0; p < 6; p++) {
@@ -486,6 +586,16 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_HIP(ctx, hipGetLastError());
     }
 
+    // the gathered-sample selection gave up (every rank alike): once more, from the top, with the radix protocol
+    auto repeat_with_radix = [&]() -> int {
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->side) ABC_HIP(ctx, hipStreamSynchronize(ctx->side));
+        *rng = rng_entry;
+        ctx->sel_force_radix = true;
+        const int rc = sharded_core(ctx, cfg, io, rng, ncomp_host);
+        ctx->sel_force_radix = false;
+        return rc;
+    };
     // ---- doubled variance, importance weights (pair sums: K / G rows per rank) ----------------------------------------------
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;
@@ -550,7 +660,12 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
             return launch_perturb_prepare(q->ctx, q->rng, q->theta, q->K, q->P, q->i0, q->Nn, q->seeds, q->seed_off, q->prep,
                                           q->L ? 1 : 0, q->L ? q->L : q->dv);
         };
-        ABC_TRY(launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host));
+        {
+            const int rc = launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host,
+                                           (fast_sel && !uniform_w) ? pfail_early : nullptr);
+            if (rc == ABC_INTERNAL_RETRY) return repeat_with_radix();
+            ABC_TRY(rc);
+        }
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,
                                cfg->multivariate ? L : dv, io->next, io->seeds, cfg->Nnext_total, &prep));
     } else if (cfg->multivariate && io->L) {
@@ -568,6 +683,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
         spd = *pspd;
+        if (ds_fail_dev && pfail_early && *pfail_early) return repeat_with_radix();      // (set 0: no host wait before this one)
     }
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
     return ABC_OK;

@@ -1099,9 +1099,9 @@ int abc_kde_words(abc_ctx* ctx) {
     return ABC_OK;
 }
 
-int launch_fill(abc_ctx* ctx, double* w, size_t K, double v) {
+int launch_fill(abc_ctx* ctx, double* w, size_t K, double v, hipStream_t st) {
     if (!K) return ABC_OK;
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, w, K, v);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st ? st : ctx->stream, w, K, v);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

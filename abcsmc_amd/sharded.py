@@ -301,17 +301,22 @@ def attach_torch_distributed(ctx, device, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dts = {_lib.DT_F64: (torch.float64, 8), _lib.DT_I32: (torch.int32, 4), _lib.DT_I64: (torch.int64, 8)}
 
+    ctx.comm_calls = {"all_reduce": 0, "all_gather": 0, "broadcast": 0}      # collectives the driver has issued (tests, bench)
+
     def all_reduce_sum(buf, count, dtype, stream):
+        ctx.comm_calls["all_reduce"] += 1
         t, sz = dts[dtype]
         dist.all_reduce(_view(buf, count * sz, t, dev), op=dist.ReduceOp.SUM, group=group)
         return 0
 
     def all_gather(send, recv, nbytes, stream):
+        ctx.comm_calls["all_gather"] += 1
         dist.all_gather_into_tensor(_view(recv, nbytes * world, torch.uint8, dev), _view(send, nbytes, torch.uint8, dev).clone(),
                                     group=group)
         return 0
 
     def broadcast(buf, nbytes, root, stream):
+        ctx.comm_calls["broadcast"] += 1
         dist.broadcast(_view(buf, nbytes, torch.uint8, dev), src=dist.get_global_rank(group, root) if group is not None else root,
                        group=group)
         return 0

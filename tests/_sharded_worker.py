@@ -1,7 +1,9 @@
 """Worker for the world_size-2 tests of the row-sharded generation (launched by torch.distributed.run).
 argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, both ranks on one GPU, stage by stage from
-Python; "cabi" -> the same two ranks through abc_generation_sharded_dev with the gloo collectives handed in as callbacks),
-out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"], [rule = "press" | "wilcoxon" (cabi only)]."""
+Python; "cabi" -> the same two ranks through abc_generation_sharded_dev with the gloo collectives handed in as callbacks;
+"rccl" -> abc_generation_sharded_dev over an in-library RCCL communicator, ONE GPU PER RANK (needs as many GPUs as ranks)),
+out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"], [rule = "press" | "wilcoxon" (cabi only)], [data = "plain" | "ties":
+the metric rows repeat 4 distinct ones, so the distances are massively tied]."""
 import json
 import os
 import sys
@@ -25,27 +27,44 @@ def main():
     N = n_loc * world
     rule = _lib.RULE_WILCOXON if (len(sys.argv) > 4 and sys.argv[4] == "wilcoxon") else _lib.RULE_MIN_PRESS
     wl = synthetic.Workload(M, P, 777)
-    X, Y = wl.rows(rank * n_loc, (rank + 1) * n_loc)
+    ties = len(sys.argv) > 5 and sys.argv[5] == "ties"
+
+    def rows(lo, hi):
+        X, Y = wl.rows(lo, hi)
+        if ties:
+            X4, _ = wl.rows(0, 4)
+            X = np.asfortranarray(X4[np.arange(lo, hi) % 4])
+        return X, Y
+
+    X, Y = rows(rank * n_loc, (rank + 1) * n_loc)
     obs, spec = wl.observed(), wl.prior_spec()
-    thp, wp, dvp = wl.previous_set(Kp)
+    thp, wp, dvp = wl.previous_set(Kp) if Kp else (None, None, None)
     if backend == "numpy":
         from _numpy_backend import NumpyBackend
         be, dev = NumpyBackend(), "cpu"
         priors = O.make_priors(spec)
     else:
-        be, dev = sharded.HipBackend("cuda:0"), "cuda:0"
+        dev = ("cuda:%d" % rank) if backend == "rccl" else "cuda:0"
+        torch.cuda.set_device(torch.device(dev))
+        be = sharded.HipBackend(dev) if backend == "hip" else None
         from abcsmc_amd import device
         priors = device.priors_to_device(_lib.make_priors(spec), dev)
 
     def cm(a):
+        if a is None:
+            return None
         a = np.asarray(a, dtype=np.float64)
         return torch.from_numpy(np.ascontiguousarray(a.T if a.ndim == 2 else a)).to(dev)
 
-    if backend == "cabi":
-        ctx = _lib.Context(0)                       # a context of its own: the communicator is attached to it
+    if backend in ("cabi", "rccl"):
+        ctx = _lib.Context(torch.device(dev).index)  # a context of its own: the communicator is attached to it
         ctx.set_stream(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
-        sharded.attach_torch_distributed(ctx, dev)
-        assert ctx.comm_info() == (_lib.COMM_CALLBACKS, world, rank)
+        if backend == "rccl":
+            sharded.attach_rccl(ctx, dev)
+            assert ctx.comm_info() == (_lib.COMM_RCCL, world, rank)
+        else:
+            sharded.attach_torch_distributed(ctx, dev)
+            assert ctx.comm_info() == (_lib.COMM_CALLBACKS, world, rank)
         gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, rule=rule, multivariate=True)
     else:
         gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
@@ -61,7 +80,7 @@ def main():
     dist.all_gather(seeds, gen.seeds[:nn_loc].cpu())
     res = {"ok": True}
     if rank == 0:
-        Xa, Ya = wl.rows(0, N)
+        Xa, Ya = rows(0, N)
         o = O.rng(4242)
         ref = O.generation(Xa, Ya, obs, O.make_priors(spec), K, nn_loc * world, o, thp, wp, dvp, train_frac=0.5,
                            max_comp=A, rule=(O.RULE_WILCOXON if rule == _lib.RULE_WILCOXON else O.RULE_MIN_PRESS), multivariate=True)
@@ -85,6 +104,7 @@ def main():
             "seeds_equal": bool(np.array_equal(sd, exp_seeds)),
             "rng_equal": [rng.s1, rng.s2, rng.s3] == [o2.s1, o2.s2, o2.s3],
             "next_finite": bool(torch.isfinite(gen.next).all().item()),
+            "comm_calls": getattr(ctx, "comm_calls", None) if backend == "cabi" else None,
         }
         with open(out_path, "w") as f:
             json.dump(res, f)

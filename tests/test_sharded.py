@@ -12,16 +12,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # BASELINE configs[3] / configs[4] column shapes (64 metrics x 32 parameters, 8 components; 128 metrics, 32 components)
-SHAPES = {"small": "1500,12,5,4,500,300,1000", "wx": "2100,10,3,6,400,300,900", "config4": "1500,64,32,8,400,300,1200", "config5": "1400,128,16,32,300,250,1000"}
+SHAPES = {"small": "1500,12,5,4,500,300,1000", "wx": "2100,10,3,6,400,300,900", "config4": "1500,64,32,8,400,300,1200", "config5": "1400,128,16,32,300,250,1000",
+          # large enough for the gathered-sample selection of the C++ driver (N / W >= 4096): 2 x 40000 rows, 8000 kept
+          "big": "40000,32,16,8,8000,3000,20000", "big0": "40000,32,16,8,8000,0,20000"}
 
 
-def _launch(backend, tmp_path, port, shape="small", rule="press"):
-    out = str(tmp_path / ("sharded_%s_%s_%s.json" % (backend, shape, rule)))
+def _launch(backend, tmp_path, port, shape="small", rule="press", data="plain"):
+    out = str(tmp_path / ("sharded_%s_%s_%s_%s.json" % (backend, shape, rule, data)))
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape], rule]
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape], rule, data]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     return json.load(open(out))
@@ -51,6 +53,37 @@ def test_sharded_world2_cabi_driver(tmp_path, shape, port):
     """abc_generation_sharded_dev (the C++ driver behind the C ABI) on two ranks sharing cuda:0, its collectives forwarded to
     gloo through abc_comm_init_callbacks: the same checks against the single-process oracle as the Python driver"""
     _check(_launch("cabi", tmp_path, port, shape))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,data,port", [("big", "plain", 29631), ("big0", "plain", 29632), ("big", "ties", 29633), ("big0", "ties", 29634)])
+def test_sharded_world2_cabi_driver_gathered_sample_selection(tmp_path, shape, data, port):
+    """sets large enough for the C++ driver's gathered-sample selection (sample all-gather, bound of the K-th key, candidate
+    lists with their rows in one all-gather, exact pick of the K smallest on every rank): weighted and first-set generations
+    against the single-process oracle; with massively tied distances the candidate lists overflow, every rank takes the same
+    decision and the generation repeats itself with the radix protocol (weighted: at the host's wait for the weights; set 0:
+    at its end) -- same results"""
+    res = _launch("cabi", tmp_path, port, shape, "press", data)
+    _check(res)
+    calls = res["comm_calls"]
+    total = sum(calls.values())
+    if data == "plain":
+        # broadcast of the pilot shift, packed all-reduce of the statistics, sample all-gather, candidates-with-rows all-gather,
+        # and (weighted generations) the all-gather of the raw weight slices: 5 collectives, 4 in the first set
+        assert calls == {"broadcast": 1, "all_reduce": 1, "all_gather": 3 if shape == "big" else 2}, calls
+    else:
+        assert total > 10 and calls["all_reduce"] >= 7, calls           # ... + the whole radix protocol of the repeat
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,port", [("small", 29641), ("big", 29642)])
+def test_sharded_world2_rccl_two_gpus(tmp_path, shape, port):
+    """abc_comm_init_rank at world size 2, one GPU per rank: every collective of the sharded generation through RCCL itself
+    (the callbacks tests share one GPU, which RCCL does not allow).  Skipped on a one-GPU box; runs on any box with two."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (found %d)" % torch.cuda.device_count())
+    _check(_launch("rccl", tmp_path, port, shape))
 
 
 @pytest.mark.gpu
