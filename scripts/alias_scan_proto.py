@@ -275,13 +275,13 @@ def alias_by_scan(w, tree_scan=False):
             j = b
         if true != cd:
             raise Fallback("step %d (%s)" % (t, kind))
-        is_last_big = (j == nb)
-        if below:
-            if not (cd < mean):
-                raise Fallback("expected demotion at %d" % t)
-        else:
-            # the last step of the chain on the last big: the comparison does not change the output
-            if not (cd > mean) and not (is_last_big and t == Tn - 1):
+        # the last big after the last small: whichever way the comparison goes, that big ends as its own alias
+        at_last_small = (a == ns) if kind == "s" else (z[a - 1] == ns)
+        if not (j == nb and at_last_small):
+            if below:
+                if not (cd < mean):
+                    raise Fallback("expected demotion at %d" % t)
+            elif not (cd > mean):
                 raise Fallback("expected no demotion at %d" % t)
         # outputs
         if kind == "s":
