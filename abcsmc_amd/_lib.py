@@ -16,6 +16,7 @@ COMM_ID_BYTES = 128
 COMM_NONE, COMM_RCCL, COMM_CALLBACKS = 0, 1, 2
 NOISE_DEVICE, NOISE_REFERENCE_STREAM = 0, 1
 WEIGHT_GAUSSIAN, WEIGHT_EPANECHNIKOV = 0, 1
+ALIAS_DEVICE, ALIAS_HOST = 0, 1
 
 
 class LibraryMissing(ImportError):
@@ -88,6 +89,9 @@ SIGNATURES = {
     "abc_ctx_set_noise_mode": (_i, [_vp, _i]),
     "abc_ctx_set_weight_kernel": (_i, [_vp, _i]),
     "abc_perturb_giveups": (_i, [_vp, _vp, _i]),
+    "abc_ctx_set_alias_mode": (_i, [_vp, _i]),
+    "abc_alias_stats": (_i, [_vp, _vp, _vp, _i]),
+    "abc_alias_table": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "abc_ctx_synchronize": (_i, [_vp]),
     "abc_version": (_i, []),
     "abc_timing_enable": (_i, [_vp, _i]),
@@ -234,6 +238,24 @@ class Context:
         n = C.c_uint64(0)
         self.check(lib().abc_perturb_giveups(self._h, C.byref(n), int(reset)))
         return n.value
+
+    def set_alias_mode(self, mode):
+        """ALIAS_DEVICE (default: the resampling table built on the GPU by verified prefix scans) or ALIAS_HOST: abc_ctx_set_alias_mode"""
+        self.check(lib().abc_ctx_set_alias_mode(self._h, int(mode)))
+
+    def alias_stats(self, reset=False):
+        """(device builds, host fallbacks) of the resampling table (abc_alias_stats)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.check(lib().abc_alias_stats(self._h, C.byref(a), C.byref(b), int(reset)))
+        return a.value, b.value
+
+    def alias_table(self, w):
+        """(F, A, on_device): the Walker alias table of the weights w as the context builds it (abc_alias_table)"""
+        import numpy as np
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        F, A, on = np.empty(w.size), np.empty(w.size, dtype=np.uint64), C.c_int(0)
+        self.check(lib().abc_alias_table(self._h, w.ctypes.data, w.size, F.ctypes.data, A.ctypes.data, C.byref(on)))
+        return F, A, on.value
 
     def set_kde_mode(self, mode):
         """KDE_AUTO (split-operand matrix-pipe kernel where it applies) or KDE_FP64 (abc_ctx_set_kde_mode)"""

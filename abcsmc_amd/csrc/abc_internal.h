@@ -53,6 +53,9 @@ struct abc_ctx {
     int kde_mode;  // ABC_KDE_AUTO / ABC_KDE_FP64
     int noise_mode;  // ABC_NOISE_DEVICE / ABC_NOISE_REFERENCE_STREAM
     int weight_kernel;  // ABC_WEIGHT_GAUSSIAN / ABC_WEIGHT_EPANECHNIKOV
+    int alias_mode;     // ABC_ALIAS_DEVICE (default) / ABC_ALIAS_HOST
+    int* alias_fail_dev;               // device flag of the last device build
+    unsigned long long alias_dev_builds, alias_dev_fallbacks;   // device builds queued / found unusable (abc_alias_stats)
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
     int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish
@@ -261,7 +264,11 @@ int launch_mvn_setup(abc_ctx*, const double* theta, size_t K, size_t P, double* 
 int launch_resample(abc_ctx*, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*) = nullptr, void* hook_arg = nullptr,
                     bool uniform_weights = false, const uint32_t* raw_ready = nullptr, bool weights_on_host = false,
-                    const volatile int* abort_flag = nullptr, bool parents_ready = false);
+                    const volatile int* abort_flag = nullptr, bool parents_ready = false, int* alias_check_deferred = nullptr);
+// alias_check_deferred (optional): with the table built on the device (ctx->alias_mode) nothing waits for the build's verdict
+// here; *alias_check_deferred = 1 then tells the caller to read the pinned flag (ctx->status_pin + 44) at its next
+// synchronisation and, if it is set, to call launch_resample again with ctx->alias_mode = ABC_ALIAS_HOST.  NULL: this
+// function synchronises and falls back by itself.
 // parents_ready (uniform weights only): abc_rng_streams_early has drawn the parents on the side stream already
 // abort_flag (pinned, optional): read right after the host has waited for the weights; non-zero -> nothing more is queued and
 // ABC_INTERNAL_RETRY is returned (the weights belong to a placeholder selection: the caller repeats its generation)
@@ -305,6 +312,13 @@ int launch_perturb_reference(abc_ctx*, abc_rng* rng_after_draws, const double* t
 // scratch E: K doubles, smalls / bigs: K + 1 uint32 each
 // knuth = false: without the final KNUTH_CONVENTION pass (k_alias_draw applies it when it reads the table)
 void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double* E, uint32_t* smalls, uint32_t* bigs, bool knuth = true);
+
+// Walker alias table built on the device (alias_dev.hip): F without the KNUTH_CONVENTION map, as abc_alias_preproc(knuth = false);
+// *fail_dev / *fail_pin (optional, pinned) = 1: the speculation did not verify (or the weights are outside its grid) -- the table
+// must not be used, the caller builds it on the host
+int launch_alias_build_dev(abc_ctx*, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin);
+size_t abc_alias_dev_need(size_t K);       // arena bytes of one build
+constexpr size_t ABC_ALIAS_DEV_MAX_K = (size_t)2 << 20;
 
 // arena bound shared by api.hip and sharded.hip
 size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext);

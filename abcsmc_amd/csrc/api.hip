@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include <new>
+#include <vector>
 
 #include "abc_internal.h"
 
@@ -62,6 +63,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
     b += 2 * PPw * PPw * 8 + 4096;                                // padded Cholesky factor of the proposals, factorisation scratch
+    if (K) b += abc_alias_dev_need(K);                            // the resampling table's device build (alias_dev.hip)
     b += 64 * 256;                                                // alignment slack
     return b + (4u << 20);
 }
@@ -99,6 +101,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->jump_tab) (void)hipFree(ctx->jump_tab);
     if (ctx->kde_which) (void)hipFree(ctx->kde_which);
     if (ctx->giveups_dev) (void)hipFree(ctx->giveups_dev);
+    if (ctx->alias_fail_dev) (void)hipFree(ctx->alias_fail_dev);
     abc_comm_release(ctx);
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
@@ -144,6 +147,21 @@ extern "C" int abc_ctx_set_noise_mode(abc_ctx* ctx, int mode) {
     if (mode != ABC_NOISE_DEVICE && mode != ABC_NOISE_REFERENCE_STREAM)
         ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_noise_mode: unknown mode %d", mode);
     ctx->noise_mode = mode;
+    return ABC_OK;
+}
+
+extern "C" int abc_ctx_set_alias_mode(abc_ctx* ctx, int mode) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (mode != ABC_ALIAS_DEVICE && mode != ABC_ALIAS_HOST) ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_alias_mode: unknown mode %d", mode);
+    ctx->alias_mode = mode;
+    return ABC_OK;
+}
+
+extern "C" int abc_alias_stats(abc_ctx* ctx, uint64_t* device_builds, uint64_t* host_fallbacks, int reset) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (device_builds) *device_builds = ctx->alias_dev_builds;
+    if (host_fallbacks) *host_fallbacks = ctx->alias_dev_fallbacks;
+    if (reset) { ctx->alias_dev_builds = 0; ctx->alias_dev_fallbacks = 0; }
     return ABC_OK;
 }
 
@@ -408,7 +426,7 @@ extern "C" int abc_setup_mvn_sampler_dev(abc_ctx* ctx, const double* theta, size
 extern "C" int abc_resample_dev(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                                 uint64_t* parent) {
     CHECK_CTX(ctx);
-    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, 1, 1, 0, 0, n)));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, 1, 1, 0, 0, n) + abc_alias_dev_need(K)));
     return launch_resample(ctx, rng, w, K, i0, n, parent);
 }
 
@@ -558,7 +576,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // (with proposals to draw the host builds the alias table of these weights next: the normalisation kernel stores them
         // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
         double* mirror = nullptr;
-        if (Nn) {
+        const bool alias_on_device = ctx->alias_mode == ABC_ALIAS_DEVICE && K >= 2 && K <= ABC_ALIAS_DEV_MAX_K;
+        if (Nn && !alias_on_device) {          // (the device build reads the weights where they are)
             ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;
         }
@@ -567,6 +586,10 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     }
     int spd = 0;
     bool have_spd = false;
+    int alias_deferred = 0;
+    uint64_t* parent_used = nullptr;
+    double* L_used = nullptr;
+    abc_perturb_prep prep_used = {nullptr, 0, nullptr};
     if (Nn) {
         uint64_t* parent = parent_early ? parent_early : (io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8));
         if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
@@ -620,7 +643,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         };
         {
             const int rc = launch_resample(ctx, rng, io->w, K, 0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host,
-                                           bins_deferred ? pfail_early : nullptr, parent_early != nullptr);
+                                           bins_deferred ? pfail_early : nullptr, parent_early != nullptr,
+                                           ctx->noise_mode == ABC_NOISE_REFERENCE_STREAM ? nullptr : &alias_deferred);
             if (rc == ABC_INTERNAL_RETRY) return repeat_with_radix();
             ABC_TRY(rc);
         }
@@ -631,6 +655,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         } else {
             ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, 0, Nn, cfg->multivariate,
                                    cfg->multivariate ? L : dv, io->next, io->seeds, Nn, &prep));
+            parent_used = parent; L_used = L; prep_used = prep;
             taus2_jump(rng, 2 * (uint64_t)Nn);   // Nnext resampling draws + Nnext seeds
         }
     }
@@ -652,6 +677,20 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // worked on a placeholder; once more, from the top, with the radix select
         const int failed = abc_select_check_done(ctx, pfail);
         if (failed && !ctx->sel_force_radix) return repeat_with_radix();
+        // the device build of the resampling table did not verify: the draws and the proposals once more, with the table from the
+        // host (the weights are final; only what depends on the table is repeated)
+        if (alias_deferred && *(volatile int*)(ctx->status_pin + 44) && parent_used) {
+            ctx->alias_dev_fallbacks++;
+            const int mode = ctx->alias_mode;
+            ctx->alias_mode = ABC_ALIAS_HOST;
+            int rc = launch_resample(ctx, &rng_entry, io->w, K, 0, Nn, parent_used);
+            ctx->alias_mode = mode;
+            ABC_TRY(rc);
+            prep_used.seeds_done = 1;
+            ABC_TRY(launch_perturb(ctx, &rng_entry, theta, K, P, io->priors, parent_used, 0, Nn, cfg->multivariate,
+                                   cfg->multivariate ? L_used : dv, io->next, nullptr, Nn, &prep_used));
+            ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     if (ctx->timing && ctx->nev > 128) ABC_TRY(abc_timing_flush(ctx));
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
@@ -802,7 +841,7 @@ extern "C" int abc_setup_mvn_sampler(abc_ctx* ctx, const double* theta, size_t K
 extern "C" int abc_sample_posterior(abc_ctx* ctx, abc_rng* rng, const double* w, size_t K, size_t n, uint64_t* idx) {
     CHECK_CTX(ctx);
     if (!rng || !w || !idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "sample_posterior: null argument");
-    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, 1, 1, 0, 0, n) + K * 8 + n * 8));
+    ABC_TRY(abc_ws_reserve(ctx, abc_ws_need(0, 1, 1, 1, 0, 0, n) + K * 8 + n * 8 + abc_alias_dev_need(K)));
     Stage s{ctx};
     double* dw = s.up(w, K);
     uint64_t* dp = s.dev<uint64_t>(n);
@@ -810,6 +849,42 @@ extern "C" int abc_sample_posterior(abc_ctx* ctx, abc_rng* rng, const double* w,
     s.down(idx, dp, n);
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     taus2_jump(rng, n);
+    return ABC_OK;
+}
+
+// the resampling table as this context builds it (for inspection / tests): F with GSL's KNUTH_CONVENTION applied
+extern "C" int abc_alias_table(abc_ctx* ctx, const double* w, size_t K, double* F, uint64_t* A, int* on_device) {
+    CHECK_CTX(ctx);
+    if (!w || !F || !A || !K || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "alias table: null argument or K = %zu", K);
+    if (on_device) *on_device = 0;
+    std::vector<double> hF(K);
+    std::vector<uint32_t> hA(K);
+    bool done = false;
+    if (ctx->alias_mode == ABC_ALIAS_DEVICE && K >= 2 && K <= ABC_ALIAS_DEV_MAX_K) {
+        ABC_TRY(abc_ws_reserve(ctx, abc_alias_dev_need(K) + K * 20 + (1u << 20)));
+        Stage s{ctx};
+        double* dw = s.up(w, K);
+        double* dF = s.dev<double>(K);
+        uint32_t* dA = s.dev<uint32_t>(K);
+        int* dfail = s.dev<int>(1);
+        if (!dw || !dF || !dA || !dfail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "alias table: workspace exhausted");
+        ABC_TRY(launch_alias_build_dev(ctx, dw, K, dF, dA, dfail, nullptr));
+        int fail = 0;
+        ctx->alias_dev_builds++;
+        s.down(hF.data(), (const double*)dF, K);
+        s.down(hA.data(), (const uint32_t*)dA, K);
+        s.down(&fail, (const int*)dfail, 1);
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (fail) ctx->alias_dev_fallbacks++; else done = true;
+        if (done && on_device) *on_device = 1;
+    }
+    if (!done) {
+        std::vector<double> E(K);
+        std::vector<uint32_t> S(K + 1), B(K + 1);
+        abc_alias_preproc(K, w, hF.data(), hA.data(), E.data(), S.data(), B.data(), /*knuth=*/false);
+    }
+    const double dK = (double)K;
+    for (size_t k = 0; k < K; k++) { F[k] = (hF[k] + (double)k) / dK; A[k] = hA[k]; }      // KNUTH_CONVENTION, as k_alias_draw applies it
     return ABC_OK;
 }
 

@@ -633,7 +633,10 @@ int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* 
 
 int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K, uint64_t i0, size_t n,
                     uint64_t* parent, int (*while_host_builds)(void*), void* hook_arg, bool uniform_weights,
-                    const uint32_t* raw_ready, bool weights_on_host, const volatile int* abort_flag, bool parents_ready) {
+                    const uint32_t* raw_ready, bool weights_on_host, const volatile int* abort_flag, bool parents_ready,
+                    int* alias_check_deferred) {
+    if (alias_check_deferred) *alias_check_deferred = 0;
+    bool wait_side = raw_ready != nullptr;               // raw_ready comes from the side stream (abc_rng_streams_early)
     if (n == 0) return ABC_OK;
     if (K == 0 || K > 0xffffffffull) ABC_FAIL(ctx, ABC_ERR_INVALID, "resample: K = %zu", K);
     if (uniform_weights) {
@@ -653,6 +656,50 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
             ABC_HIP(ctx, hipGetLastError());
         }
         return ABC_OK;
+    }
+    if (ctx->alias_K < K) {       // the table's home in HBM: F[K] then A[K], one allocation
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->alias_F) { (void)hipFree(ctx->alias_F); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * (sizeof(double) + sizeof(uint32_t))));
+        ctx->alias_K = K;
+    }
+    ctx->alias_A = (uint32_t*)(ctx->alias_F + K);
+    // ---- the table built on the device (alias_dev.hip): no copy of the weights to the host, no host wait ------------------------
+    if (ctx->alias_mode == ABC_ALIAS_DEVICE && K >= 2 && K <= ABC_ALIAS_DEV_MAX_K && ctx->ws_off + abc_alias_dev_need(K) <= ctx->ws_bytes) {
+        if (!ctx->alias_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_fail_dev, sizeof(int)));
+        int* fail_pin = (int*)(ctx->status_pin + 44);
+        *fail_pin = 0;
+        uint32_t* raw = const_cast<uint32_t*>(raw_ready);
+        if (!raw) raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
+        if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
+        abc_rng base = *rng;
+        taus2_jump(&base, i0);
+        if (raw_ready) {
+            ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        } else {
+            StageTimer tm(ctx, ST_RESAMPLE);
+            ABC_TRY(taus_stream(ctx, base, n, raw));
+        }
+        {
+            StageTimer tm(ctx, ST_ALIAS_HOST);          // (the stage keeps its name: device time of the build in this mode)
+            ABC_TRY(launch_alias_build_dev(ctx, w, K, ctx->alias_F, ctx->alias_A, ctx->alias_fail_dev, fail_pin));
+        }
+        ctx->alias_dev_builds++;
+        if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));      // (nothing waits here: the caller's table-independent work simply follows)
+        {
+            StageTimer tm(ctx, ST_RESAMPLE);
+            hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
+                               ctx->alias_A, K, (unsigned long long*)parent);
+            ABC_HIP(ctx, hipGetLastError());
+        }
+        if (alias_check_deferred) { *alias_check_deferred = 1; return ABC_OK; }      // the caller reads the pinned flag at its next wait
+        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!*fail_pin) return ABC_OK;
+        ctx->alias_dev_fallbacks++;
+        while_host_builds = nullptr;                      // (already run)
+        raw_ready = raw;                                  // the draws' taus2 outputs exist: only the table is rebuilt
+        wait_side = false;
+        weights_on_host = false;
     }
     // alias table: weights to the host, serial Walker build, tables back to HBM
     ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
@@ -674,7 +721,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     abc_rng base = *rng;
     taus2_jump(&base, i0);
     if (raw_ready) {
-        ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        if (wait_side) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
     } else {
         StageTimer tm(ctx, ST_RESAMPLE);
         ABC_TRY(taus_stream(ctx, base, n, raw));
@@ -691,14 +738,6 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         }
     }
     StageTimer tm(ctx, ST_RESAMPLE);
-    if (ctx->alias_K < K) {
-        ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->alias_F) { (void)hipFree(ctx->alias_F); ctx->alias_F = nullptr; ctx->alias_A = nullptr; }
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_F, K * (sizeof(double) + sizeof(uint32_t))));     // F[K] then A[K]: one allocation,
-        ctx->alias_A = (uint32_t*)(ctx->alias_F + K);                                               // one host-to-device copy
-        ctx->alias_K = K;
-    }
-    ctx->alias_A = (uint32_t*)(ctx->alias_F + K);
     ABC_HIP(ctx, hipMemcpyAsync(ctx->alias_F, hF, K * (sizeof(double) + sizeof(uint32_t)), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
                        ctx->alias_A, K, (unsigned long long*)parent);

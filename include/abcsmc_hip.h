@@ -97,6 +97,18 @@ int  abc_ctx_set_weight_kernel(abc_ctx* ctx, int kernel);
  *   row-sliced entry points (abc_perturb_dev, abc_generation_sharded_dev). */
 enum { ABC_NOISE_DEVICE = 0, ABC_NOISE_REFERENCE_STREAM = 1 };
 int  abc_ctx_set_noise_mode(abc_ctx* ctx, int mode);
+/* Where the Walker alias table of the resampling step (gsl_ran_discrete_preproc, AbcUtil.cpp:111-120) is built.
+ * ABC_ALIAS_DEVICE (default): on the GPU, as two verified prefix scans (csrc/alias_dev.hip) -- the same table bit for bit; when
+ *   its verification does not hold (or the weights are outside its grid: negative, non-finite, spread over more than 2^44) the
+ *   host builds the table instead, and abc_alias_stats counts it.
+ * ABC_ALIAS_HOST: always on the host (the sequential algorithm, the GPU idle meanwhile): round 2's path, kept for A/B runs. */
+enum { ABC_ALIAS_DEVICE = 0, ABC_ALIAS_HOST = 1 };
+int  abc_ctx_set_alias_mode(abc_ctx* ctx, int mode);
+/* device builds queued / of those found unusable (rebuilt on the host) since the context was created or the last reset */
+int  abc_alias_stats(abc_ctx* ctx, uint64_t* device_builds, uint64_t* host_fallbacks, int reset);
+/* The table itself, for inspection: F (K doubles, GSL's KNUTH_CONVENTION applied: (F[k] + k) / K) and A (K uint64) from weights in
+ * host memory, built as the context's alias mode says; *on_device = 1 when the device build was used (0: host, incl. fallback). */
+int  abc_alias_table(abc_ctx* ctx, const double* w, size_t K, double* F, uint64_t* A, int* on_device);
 /* Proposals the perturbation gave up on since the context was created (or since the last reset): multivariate rows whose
  * 16384 whole-vector draws were all rejected (the valid parent is emitted; the reference would retry for ever,
  * AbcUtil.cpp:132) plus independent-noise coordinates that fell back to the prior mean after 1000 tries (the reference prints

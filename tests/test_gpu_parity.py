@@ -715,6 +715,64 @@ def test_resample_bit_exact(gpu_ctx, oracle, K, n, seed):
     assert np.array_equal(np.bincount(idx.astype(int), minlength=K), np.bincount(ref.astype(int), minlength=K))
 
 
+def _alias_weights(kind, K, rng):
+    if kind == "uniform":
+        w = rng.random(K)
+    elif kind == "lognormal1.5":
+        w = np.exp(1.5 * rng.normal(size=K))
+    elif kind == "lognormal3":
+        w = np.exp(3.0 * rng.normal(size=K))
+    elif kind == "zeros":
+        w = rng.random(K) ** 3
+        w[rng.integers(0, K, max(1, K // 50))] = 0.0
+    elif kind == "near_mean":
+        w = np.full(K, 1.0 / K) * (1 + 1e-9 * rng.normal(size=K))      # everything within 1e-9 of the mean
+    elif kind == "few_values":
+        w = np.round(rng.random(K) * 8) / 8.0 + 0.125                   # nine distinct values: exact ties abound
+    else:
+        w = np.ones(K)                                                   # "equal": every entry exactly at the mean
+    return w / np.linalg.norm(w)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lognormal1.5", "lognormal3", "zeros", "near_mean", "few_values", "equal"])
+def test_device_alias_table_is_gsls_table_bit_for_bit(gpu_ctx, oracle, kind):
+    """The Walker alias table of the resampling step, built on the GPU by verified prefix scans (csrc/alias_dev.hip), against
+    the oracle's gsl_ran_discrete_preproc (sequential): every cut-off F[k] (bit pattern) and every alias A[k], for 2 .. 1e6
+    weights of seven kinds -- and the build's own verification must hold (no fallback to the host)"""
+    rng = np.random.default_rng(hash(kind) % 1000)
+    gpu_ctx.alias_stats(reset=True)
+    sizes = [2, 3, 7, 64, 1000, 4097, 100_000, 300_001] + ([1_000_000] if kind in ("uniform", "lognormal1.5") else [])
+    for K in sizes:
+        w = _alias_weights(kind, K, rng)
+        F, A, on_device = gpu_ctx.alias_table(w)
+        oF, oA = oracle.discrete_preproc(w)
+        assert on_device == 1, (kind, K)
+        assert np.array_equal(A, oA), (kind, K)
+        assert np.array_equal(F.view(np.uint64), oF.view(np.uint64)), (kind, K)
+    builds, fallbacks = gpu_ctx.alias_stats()
+    assert builds == len(sizes) and fallbacks == 0
+
+
+def test_device_alias_table_falls_back_outside_its_grid(gpu_ctx, oracle):
+    """weights spread over more than 2^44 (a first weight of 1e-30 of the others'): the device build says so and the host's
+    sequential build delivers the table -- still GSL's; and ABC_ALIAS_HOST never touches the device build"""
+    from abcsmc_amd import _lib
+    rng = np.random.default_rng(3)
+    w = rng.random(5000)
+    w[0] = 1e-30
+    gpu_ctx.alias_stats(reset=True)
+    F, A, on_device = gpu_ctx.alias_table(w)
+    oF, oA = oracle.discrete_preproc(w)
+    assert on_device == 0 and gpu_ctx.alias_stats() == (1, 1)
+    assert np.array_equal(A, oA) and np.array_equal(F.view(np.uint64), oF.view(np.uint64))
+    gpu_ctx.set_alias_mode(_lib.ALIAS_HOST)
+    try:
+        F, A, on_device = gpu_ctx.alias_table(rng.random(3000))
+        assert on_device == 0 and gpu_ctx.alias_stats(reset=True) == (1, 1)
+    finally:
+        gpu_ctx.set_alias_mode(_lib.ALIAS_DEVICE)
+
+
 def test_sample_mvn_predictive_priors(gpu_ctx, oracle):
     from abcsmc_amd import abcutil, _lib
     rng = np.random.default_rng(21)
