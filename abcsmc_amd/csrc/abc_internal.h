@@ -45,6 +45,7 @@ struct abc_ctx {
     // run there from the first launch on, beside the ranking chain (abc_rng_streams_early); ev_fork / ev_side order them
     hipStream_t side;
     hipEvent_t ev_fork, ev_side, ev_prev;
+    hipEvent_t ev_theta, ev_moments;   // the posterior's moments on the side stream: start (rows gathered) and end
     bool side_forked;      // ev_fork of the current generation is recorded (abc_side_fork); cleared when the generation ends
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
@@ -316,7 +317,10 @@ void abc_alias_preproc(size_t K, const double* w, double* F, uint32_t* A, double
 // Walker alias table built on the device (alias_dev.hip): F without the KNUTH_CONVENTION map, as abc_alias_preproc(knuth = false);
 // *fail_dev / *fail_pin (optional, pinned) = 1: the speculation did not verify (or the weights are outside its grid) -- the table
 // must not be used, the caller builds it on the host
-int launch_alias_build_dev(abc_ctx*, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin);
+// verdict_src (optional): instead of a launch of its own that publishes the verdict, *verdict_src gets the device word that
+// holds it; the caller's next kernel copies it to fail_dev / fail_pin (k_alias_draw does)
+int launch_alias_build_dev(abc_ctx*, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
+                           const int** verdict_src = nullptr);
 size_t abc_alias_dev_need(size_t K);       // arena bytes of one build
 constexpr size_t ABC_ALIAS_DEV_MAX_K = (size_t)2 << 20;
 

@@ -23,7 +23,7 @@
 // scripts/alias_scan_proto.py is the same algorithm in exact Python integers (900 random weight vectors of six kinds, tie-heavy
 // and nearly uniform ones included: bit-exact, no flag); tests/test_gpu_parity.py::test_device_alias_table_* compare the device
 // table with the oracle's entry by entry.
-// Ten launches, no host involvement, no device-scope fences (reductions across work-groups go through kernel boundaries: every
+// Ten launches (the verdict is published by the caller's next kernel), no host involvement, no device-scope fences (reductions across work-groups go through kernel boundaries: every
 // "apply" kernel re-derives its block's prefix from the per-block aggregates of the launch before).
 #include "abc_internal.h"
 
@@ -168,9 +168,13 @@ __global__ __launch_bounds__(AL_T) void k_al_bsum(const double* __restrict__ w, 
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < AL_I; j++) if (base + j < K) { const double x = w[base + j]; s += x; bad = bad || !(x >= 0.0) || !(x < 1.0e300); }
-    const double bs = block_sum_d(s, sm);
+    // a negative / non-finite / huge weight poisons its block sum: the next kernel (the first that may raise the flag) sees it
+    const double bs = block_sum_d(bad ? (double)NAN : s, sm);
     if (threadIdx.x == 0) bsum[blockIdx.x] = bs;
-    if (bad) al_fail(head);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {            // this build's header (nothing else writes it in this launch)
+        head->approx_total = 0.0; head->total = 0.0; head->e0_sum = 0; head->e0 = 0; head->ns = 0; head->nb = 0; head->nsteps = 0;
+        head->fail = 0; head->MEAN = 0;
+    }
 }
 
 // approximate sum in front of this block and of the whole array, from the block sums (same arithmetic in every block and launch)
@@ -211,7 +215,7 @@ __device__ __forceinline__ double block_excl_prefix_d(double mine, double* sd /*
 }
 
 __global__ __launch_bounds__(AL_T) void k_al_sum_reduce(const double* __restrict__ w, size_t K, const double* __restrict__ bsum, int nblk,
-                                                        RMap* __restrict__ agg, AlHead* __restrict__ head) {
+                                                        RMap* __restrict__ agg, RMap* __restrict__ tpre, AlHead* __restrict__ head) {
     __shared__ RMap buf[2][AL_T];
     __shared__ double sd[AL_T];
     __shared__ double sm[4];
@@ -231,12 +235,13 @@ __global__ __launch_bounds__(AL_T) void k_al_sum_reduce(const double* __restrict
     for (int j = 0; j < AL_I; j++) { run += x[j]; m = compose(m, sum_map(x[j], run, e0, head)); }
     RMap ex;
     const RMap inc = block_scan_maps(m, buf, &ex);
+    tpre[(size_t)blockIdx.x * AL_T + threadIdx.x] = ex;            // the apply kernel starts from here instead of scanning again
     if (threadIdx.x == AL_T - 1) agg[blockIdx.x] = inc;
     if (blockIdx.x == 0 && threadIdx.x == 0) { head->approx_total = all; head->e0_sum = e0; }
 }
 
 __global__ __launch_bounds__(AL_T) void k_al_sum_apply(const double* __restrict__ w, size_t K, const double* __restrict__ bsum, int nblk,
-                                                       const RMap* __restrict__ agg, AlHead* __restrict__ head) {
+                                                       const RMap* __restrict__ agg, const RMap* __restrict__ tpre, AlHead* __restrict__ head) {
     __shared__ RMap buf[2][AL_T];
     __shared__ double sd[AL_T];
     __shared__ double sm[4];
@@ -251,11 +256,10 @@ __global__ __launch_bounds__(AL_T) void k_al_sum_apply(const double* __restrict_
 #pragma unroll
     for (int j = 0; j < AL_I; j++) { x[j] = (base + j < K) ? w[base + j] : 0.0; ts += x[j]; }
     double run = before + block_excl_prefix_d(ts, sd);
-    RMap mj[AL_I], m = rmap_identity();
+    RMap mj[AL_I];
 #pragma unroll
-    for (int j = 0; j < AL_I; j++) { run += x[j]; mj[j] = sum_map(x[j], run, e0, head); m = compose(m, mj[j]); }
-    RMap ex;
-    (void)block_scan_maps(m, buf, &ex);
+    for (int j = 0; j < AL_I; j++) { run += x[j]; mj[j] = sum_map(x[j], run, e0, head); }
+    const RMap ex = tpre[(size_t)blockIdx.x * AL_T + threadIdx.x];
     i128 v = rapply(ex, rapply(pre, 0));
     bool ok = true;
     double prev = from_grid(v, e0, &ok);
@@ -481,7 +485,8 @@ __device__ __forceinline__ RMap serve_map(const ServeArgs& a, const AlHead* head
     return compose(m1, m2);
 }
 
-__global__ __launch_bounds__(AL_T) void k_al_serve_reduce(ServeArgs a, const AlHead* __restrict__ head, RMap* __restrict__ agg) {
+__global__ __launch_bounds__(AL_T) void k_al_serve_reduce(ServeArgs a, const AlHead* __restrict__ head, RMap* __restrict__ agg,
+                                                          RMap* __restrict__ tpre) {
     __shared__ RMap buf[2][AL_T];
     const unsigned n = head->nsteps;
     if ((size_t)blockIdx.x * AL_B >= n) { if (threadIdx.x == 0) agg[blockIdx.x] = rmap_identity(); return; }
@@ -491,10 +496,12 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_reduce(ServeArgs a, const AlH
     for (int j = 0; j < AL_I; j++) if (base + j < n) m = compose(m, serve_map(a, head, (unsigned)(base + j)));
     RMap ex;
     const RMap inc = block_scan_maps(m, buf, &ex);
+    tpre[(size_t)blockIdx.x * AL_T + threadIdx.x] = ex;
     if (threadIdx.x == AL_T - 1) agg[blockIdx.x] = inc;
 }
 
-__global__ __launch_bounds__(AL_T) void k_al_serve_apply(ServeArgs a, AlHead* __restrict__ head, const RMap* __restrict__ agg, double mean,
+__global__ __launch_bounds__(AL_T) void k_al_serve_apply(ServeArgs a, AlHead* __restrict__ head, const RMap* __restrict__ agg,
+                                                         const RMap* __restrict__ tpre, double mean,
                                                          double dK, double* __restrict__ F, uint32_t* __restrict__ A, int* __restrict__ fail_out,
                                                          int* __restrict__ fail_pin) {
     __shared__ RMap buf[2][AL_T];
@@ -507,14 +514,10 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_apply(ServeArgs a, AlHead* __
     }
     const RMap pre = prefix_of_blocks(agg, blockIdx.x, buf);
     const size_t base = (size_t)blockIdx.x * AL_B + (size_t)threadIdx.x * AL_I;
-    RMap mj[AL_I], m = rmap_identity();
+    RMap mj[AL_I];
 #pragma unroll
-    for (int j = 0; j < AL_I; j++) {
-        mj[j] = (base + j < n) ? serve_map(a, head, (unsigned)(base + j)) : rmap_identity();
-        m = compose(m, mj[j]);
-    }
-    RMap ex;
-    (void)block_scan_maps(m, buf, &ex);
+    for (int j = 0; j < AL_I; j++) mj[j] = (base + j < n) ? serve_map(a, head, (unsigned)(base + j)) : rmap_identity();
+    const RMap ex = tpre[(size_t)blockIdx.x * AL_T + threadIdx.x];
     const int e0 = head->e0;
     i128 v = rapply(ex, rapply(pre, a.VI[0]));                     // the chain starts at E[b_1]
     bool ok = true;
@@ -568,17 +571,19 @@ __global__ void k_al_flag(const AlHead* __restrict__ head, int* __restrict__ fai
 
 size_t abc_alias_dev_need(size_t K) {
     const size_t nblk = (K + AL_B - 1) / AL_B + 1, nblk2 = (2 * K + AL_B - 1) / AL_B + 1;
-    return K * (8 + 4 + 4 + 8 + 16 + 16 + 16 + 4 + 4 + 8) + nblk * (8 + 4 + 64 + 32) + nblk2 * 64 + sizeof(AlHead) + 64 * 256;
+    return K * (8 + 4 + 4 + 8 + 16 + 16 + 16 + 4 + 4 + 8) + nblk * (8 + 4 + 64 + 32) + nblk2 * 64 * (AL_T + 1) + sizeof(AlHead) + 64 * 256;
 }
 
 // F (K doubles, cut-off fractions WITHOUT the KNUTH_CONVENTION map, as alias_preproc(..., knuth = false)) and A (K uint32) on the
 // device; *fail_dev (and *fail_pin, optional, pinned) = 1 when the table must not be used (the caller builds it on the host)
-int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin) {
+int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
+                           const int** verdict_src) {
     if (K == 0 || K > (size_t)AL_MAXBLK * AL_B / 2) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "device alias build: K = %zu", K);
     const int nblk = (int)((K + AL_B - 1) / AL_B), nblk2 = (int)((2 * K + AL_B - 1) / AL_B);
     AlHead* head = (AlHead*)abc_ws_alloc(ctx, sizeof(AlHead));
     double* bsum = (double*)abc_ws_alloc(ctx, (size_t)nblk * 8);
     RMap* agg = (RMap*)abc_ws_alloc(ctx, (size_t)(nblk2 > nblk ? nblk2 : nblk) * sizeof(RMap));
+    RMap* tpre = (RMap*)abc_ws_alloc(ctx, (size_t)(nblk2 > nblk ? nblk2 : nblk) * AL_T * sizeof(RMap));
     double* E = (double*)abc_ws_alloc(ctx, K * 8);
     unsigned* cnt = (unsigned*)abc_ws_alloc(ctx, (size_t)nblk * 4);
     uint32_t* sidx = (uint32_t*)abc_ws_alloc(ctx, K * 4);
@@ -591,14 +596,13 @@ int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, u
     uint32_t* z = (uint32_t*)abc_ws_alloc(ctx, K * 4);
     uint32_t* jof = (uint32_t*)abc_ws_alloc(ctx, K * 4);
     uint32_t* step = (uint32_t*)abc_ws_alloc(ctx, 2 * K * 4);
-    if (!head || !bsum || !agg || !E || !cnt || !sidx || !bidx || !dI || !VI || !D || !X || !bs || !z || !jof || !step)
+    if (!head || !bsum || !agg || !tpre || !E || !cnt || !sidx || !bidx || !dI || !VI || !D || !X || !bs || !z || !jof || !step)
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "device alias build: workspace exhausted");
     const double mean = 1.0 / (double)K, dK = (double)K;
     hipStream_t st = ctx->stream;
-    ABC_HIP(ctx, hipMemsetAsync(head, 0, sizeof(AlHead), st));
     hipLaunchKernelGGL(k_al_bsum, dim3(nblk), dim3(AL_T), 0, st, w, K, bsum, head);
-    hipLaunchKernelGGL(k_al_sum_reduce, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, agg, head);
-    hipLaunchKernelGGL(k_al_sum_apply, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, (const RMap*)agg, head);
+    hipLaunchKernelGGL(k_al_sum_reduce, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, agg, tpre, head);
+    hipLaunchKernelGGL(k_al_sum_apply, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, (const RMap*)agg, (const RMap*)tpre, head);
     hipLaunchKernelGGL(k_al_classify, dim3(nblk), dim3(AL_T), 0, st, w, K, mean, head, E, cnt, F, A);
     hipLaunchKernelGGL(k_al_lists, dim3(nblk), dim3(AL_T), 0, st, (const double*)E, K, mean, (const unsigned*)cnt, nblk, head, sidx, dI, bidx, VI);
     hipLaunchKernelGGL(k_al_psum_reduce, dim3(nblk, 2), dim3(AL_T), 0, st, (const u64*)dI, (const i128*)VI, (const AlHead*)head, bs, nblk);
@@ -606,9 +610,10 @@ int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, u
                        (const i128*)bs, nblk, D, X);
     hipLaunchKernelGGL(k_al_structure, dim3((unsigned)((K + AL_T - 1) / AL_T)), dim3(AL_T), 0, st, (const i128*)D, (const i128*)X, head, z, jof, step);
     ServeArgs a = {E, sidx, bidx, dI, VI, D, X, z, jof, step};
-    hipLaunchKernelGGL(k_al_serve_reduce, dim3(nblk2), dim3(AL_T), 0, st, a, (const AlHead*)head, agg);
-    hipLaunchKernelGGL(k_al_serve_apply, dim3(nblk2), dim3(AL_T), 0, st, a, head, (const RMap*)agg, mean, dK, F, A, fail_dev, fail_pin);
-    hipLaunchKernelGGL(k_al_flag, dim3(1), dim3(64), 0, st, (const AlHead*)head, fail_dev, fail_pin);
+    hipLaunchKernelGGL(k_al_serve_reduce, dim3(nblk2), dim3(AL_T), 0, st, a, (const AlHead*)head, agg, tpre);
+    hipLaunchKernelGGL(k_al_serve_apply, dim3(nblk2), dim3(AL_T), 0, st, a, head, (const RMap*)agg, (const RMap*)tpre, mean, dK, F, A, fail_dev, fail_pin);
+    if (verdict_src) *verdict_src = &head->fail;          // the caller's next kernel publishes the verdict (k_alias_draw)
+    else hipLaunchKernelGGL(k_al_flag, dim3(1), dim3(64), 0, st, (const AlHead*)head, fail_dev, fail_pin);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

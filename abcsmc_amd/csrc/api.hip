@@ -105,6 +105,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     abc_comm_release(ctx);
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    if (ctx->ev_theta) { (void)hipEventDestroy(ctx->ev_theta); (void)hipEventDestroy(ctx->ev_moments); }
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_side); if (ctx->ev_prev) (void)hipEventDestroy(ctx->ev_prev); }
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -565,6 +566,42 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     } else {
         ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
     }
+    // The posterior's moments and what follows from them (doubled variance, proposal factor, the perturbation's row-major copy
+    // and padded factor) need the gathered rows only: with the resampling table built on the device nothing waits for the host
+    // any more, so they run on the SIDE stream from here on, beside the weight stage, and are long done when the proposals need
+    // them (round 2 hid them behind the host's alias build).
+    double* L_early = nullptr;
+    abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool moments_on_side = false;
+    // (set 0 has nothing to overlap them with: two cross-stream hand-overs for nothing, measured +35 us)
+    static const int side_moments_on = getenv("ABC_MOMENTS_MAIN") ? 0 : 1;        // A/B switch for measurements
+    if (defer_moments && !uniform_w && side_moments_on && ctx->side && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM) {
+        if (cfg->multivariate) {
+            L_early = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
+            if (!L_early) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+        }
+        const int PPr = abc_perturb_pp(P);
+        side_out.dv = dv; side_out.L = L_early; side_out.spd = spd_dev;
+        side_out.rows = (double*)abc_ws_alloc(ctx, K * (size_t)PPr * sizeof(double));
+        if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
+        if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+        if (!ctx->ev_theta) {
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, hipEventDisableTiming));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, hipEventDisableTiming));
+        }
+        ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_theta, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->side;                        // the launchers below queue on the context's stream
+        double* st = nullptr;
+        int rc = launch_theta_stats(ctx, theta, K, P, &st);
+        if (rc == ABC_OK) rc = launch_post_tail(ctx, theta, K, P, st, &side_out);
+        ctx->stream = main_stream;
+        ABC_TRY(rc);
+        ABC_HIP(ctx, hipEventRecord(ctx->ev_moments, ctx->side));
+        theta_stats = st;
+        moments_on_side = true;
+    }
     bool w_on_host = false;
     if (Kp == 0 || !io->theta_prev) {
         if (!filled_early) ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
@@ -595,18 +632,20 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
         double* L = nullptr;
         if (cfg->multivariate) {
-            L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
+            L = L_early ? L_early : (io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8));
             have_spd = true;
         }
         // The alias-table host round trip sits inside launch_resample.  What does not depend on the weights runs on the GPU
         // meanwhile: the MVN factor (covariance + Cholesky), the row-major posterior copy and the seed stream of the
         // perturbation.
-        abc_perturb_prep prep = {nullptr, (early && io->seeds) ? 1 : 0, nullptr};
+        abc_perturb_prep prep = {moments_on_side ? side_out.rows : nullptr, (early && io->seeds) ? 1 : 0, moments_on_side ? side_out.Lpad : nullptr};
+        if (moments_on_side) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_moments, 0));
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments;
         };
-        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, L, spd_dev, dv, defer_moments};
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, moments_on_side ? nullptr : L, spd_dev, dv,
+                      defer_moments && !moments_on_side};
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
             int fused_done = 0;

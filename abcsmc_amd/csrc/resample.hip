@@ -119,8 +119,11 @@ __global__ __launch_bounds__(256) void k_taus_stream(abc_rng base, size_t n, con
 // here on the one entry a draw reads -- the same IEEE addition and division, hence the same bits.
 __global__ __launch_bounds__(256) void k_alias_draw(const uint32_t* __restrict__ raw, size_t n,
                                                     const double* __restrict__ F, const uint32_t* __restrict__ A,
-                                                    size_t K, unsigned long long* __restrict__ parent) {
+                                                    size_t K, unsigned long long* __restrict__ parent,
+                                                    const int* __restrict__ verdict_src = nullptr, int* __restrict__ verdict_dev = nullptr,
+                                                    int* __restrict__ verdict_pin = nullptr) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && verdict_src) { const int v = *verdict_src; *verdict_dev = v; *verdict_pin = v; }      // the device build's verdict (alias_dev.hip)
     if (i >= n) return;
     const double u = (double)raw[i] / 4294967296.0;
     const size_t c = (size_t)(u * (double)K);
@@ -669,6 +672,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         if (!ctx->alias_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_fail_dev, sizeof(int)));
         int* fail_pin = (int*)(ctx->status_pin + 44);
         *fail_pin = 0;
+        const int* verdict = nullptr;
         uint32_t* raw = const_cast<uint32_t*>(raw_ready);
         if (!raw) raw = (uint32_t*)abc_ws_alloc(ctx, n * sizeof(uint32_t));
         if (!raw) ABC_FAIL(ctx, ABC_ERR_NOMEM, "resample: workspace exhausted");
@@ -682,14 +686,14 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         }
         {
             StageTimer tm(ctx, ST_ALIAS_HOST);          // (the stage keeps its name: device time of the build in this mode)
-            ABC_TRY(launch_alias_build_dev(ctx, w, K, ctx->alias_F, ctx->alias_A, ctx->alias_fail_dev, fail_pin));
+            ABC_TRY(launch_alias_build_dev(ctx, w, K, ctx->alias_F, ctx->alias_A, ctx->alias_fail_dev, fail_pin, &verdict));
         }
         ctx->alias_dev_builds++;
         if (while_host_builds) ABC_TRY(while_host_builds(hook_arg));      // (nothing waits here: the caller's table-independent work simply follows)
         {
             StageTimer tm(ctx, ST_RESAMPLE);
             hipLaunchKernelGGL(k_alias_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, raw, n, ctx->alias_F,
-                               ctx->alias_A, K, (unsigned long long*)parent);
+                               ctx->alias_A, K, (unsigned long long*)parent, verdict, ctx->alias_fail_dev, fail_pin);
             ABC_HIP(ctx, hipGetLastError());
         }
         if (alias_check_deferred) { *alias_check_deferred = 1; return ABC_OK; }      // the caller reads the pinned flag at its next wait
