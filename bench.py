@@ -449,22 +449,29 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
         out["host_entry_pcie_floor_ms"] = round(pcie, 4)
         out["host_entry_over_pcie_floor"] = round(ms / pcie, 3)
         del pin, dst
-    # (5) host alias build (gsl_ran_discrete_preproc restated, the GPU idles behind it): the bench's weights and log-normal ones
+    # (5) the resampling table (gsl_ran_discrete_preproc): device build (default; HIP-event bracket of its ten launches) and the
+    # host's sequential build it replaces (host ms; the GPU idles behind it, plus two PCIe hops), on log-normal weights
     g = np.random.default_rng(5)
     r = abcutil.rng(3)
+    ctx.alias_stats(reset=True)
     for name, w in (("lognormal_sigma1.5", np.exp(1.5 * g.normal(size=K))), ("lognormal_sigma3", np.exp(3.0 * g.normal(size=K)))):
         dw = torch.from_numpy(w / np.linalg.norm(w)).to(dev)
         par = be.empty(1024, torch.int64)
-        be.resample(r, dw, 0, 1024, par)
-        torch.cuda.synchronize()
-        ctx.timing_enable(1)
-        ctx.timing_read(reset=True)
-        for _ in range(5):
+        for mode, key, col in ((_lib.ALIAS_DEVICE, "alias_device_ms_", 0), (_lib.ALIAS_HOST, "alias_host_ms_", 1)):
+            ctx.set_alias_mode(mode)
             be.resample(r, dw, 0, 1024, par)
-        torch.cuda.synchronize()
-        st = ctx.timing_read(reset=True)
-        ctx.timing_enable(False)
-        out["alias_host_ms_" + name] = round(st["alias_host"][1] / max(st["alias_host"][2], 1), 5)
+            torch.cuda.synchronize()
+            ctx.timing_enable(1)
+            ctx.timing_read(reset=True)
+            for _ in range(5):
+                be.resample(r, dw, 0, 1024, par)
+            torch.cuda.synchronize()
+            st = ctx.timing_read(reset=True)
+            ctx.timing_enable(False)
+            out[key + name] = round(st["alias_host"][col] / max(st["alias_host"][2], 1), 5)
+    ctx.set_alias_mode(_lib.ALIAS_DEVICE)
+    builds, fallbacks = ctx.alias_stats(reset=True)
+    out["alias_device_builds"], out["alias_device_fallbacks"] = builds, fallbacks
     return out
 
 

@@ -9,31 +9,39 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# (configs 4 / 5 = BASELINE configs[3] / configs[4] at their STATED totals on this one GPU: 1e7 / 1e6 particles)
 python3 bench.py > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
-for c in 2 4 5; do
-  python3 bench.py --config $c --no-cpu-baseline > "$OUT/bench_c$c.json" 2> "$OUT/bench_c$c.err"
-done
-for c in 2 3 4 5; do
+python3 bench.py --config 2 --no-cpu-baseline > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+python3 bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config 5 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
+for c in 2 3 5; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_c$c" -o runc --output-format csv -- \
-      python3 "$ROOT/bench.py" --config $c --steps 5 --warmup 2 --no-cpu-baseline) > "$OUT/prof_c$c.log" 2>&1
+      python3 "$ROOT/bench.py" --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-extra) > "$OUT/prof_c$c.log" 2>&1
+done
+(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_c4" -o runc --output-format csv -- \
+    python3 "$ROOT/bench.py" --config 4 --steps 3 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/prof_c4.log" 2>&1
+# the kernel timeline of one generation (configs[2], weighted and first set)
+for m in full set0; do
+  (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/trace_$m" -o t --output-format csv -- python3 "$ROOT/scripts/trace_step.py" 3 $m 5) > "$OUT/trace_$m.log" 2>&1
+  python3 scripts/timeline.py $(find "$OUT/trace_$m" -name "*kernel_trace.csv" | head -1) > "$OUT/timeline_$m.txt"
 done
 for c in 2 3; do
   (cd /tmp && rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch_c$c" -o runc --output-format csv -- \
-      python3 "$ROOT/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmc_fetch_c$c.log" 2>&1
+      python3 "$ROOT/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/pmc_fetch_c$c.log" 2>&1
   (cd /tmp && rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write_c$c" -o runc --output-format csv -- \
-      python3 "$ROOT/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmc_write_c$c.log" 2>&1
+      python3 "$ROOT/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/pmc_write_c$c.log" 2>&1
 done
 # the Gram kernel: matrix-pipe utilisation, wait fractions
 (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES \
     -d "$OUT/pmc_sq_c3" -o runc --output-format csv -- \
-    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmc_sq_c3.log" 2>&1
+    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/pmc_sq_c3.log" 2>&1
 (cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU \
     -d "$OUT/pmc_sq2_c3" -o runc --output-format csv -- \
-    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmc_sq2_c3.log" 2>&1
+    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/pmc_sq2_c3.log" 2>&1
 # the weight kernel: cycles (clock = GRBM_GUI_ACTIVE / 8 XCDs / duration), matrix-pipe busy cycles, vector instructions
 (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU \
     -d "$OUT/pmc_kde_c3" -o runc --output-format csv -- \
-    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline) > "$OUT/pmc_kde_c3.log" 2>&1
+    python3 "$ROOT/bench.py" --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/pmc_kde_c3.log" 2>&1
 # trim what travels back: only the stats / counter CSVs are needed
 find "$OUT" -name '*_kernel_trace.csv' -size +8M -delete
 ls "$OUT"/prof_c3/ "$OUT"/pmc_fetch_c3/ 2>/dev/null | head

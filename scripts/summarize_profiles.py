@@ -1,7 +1,8 @@
 """Copies the rocprofv3 summaries a gpurun call of scripts/gpu_profile_round.sh left under gpurun_out/ into profiles/
 (tracked) and re-derives from them, without bench.py's own event brackets, every fraction bench.py's JSON line carries:
 
-  roofline            k_kde_split: f16 / bf16 MFMA work issued / rocprofv3 kernel duration against the dense 16-bit peak, the
+  roofline            k_kde_split: ALGORITHMIC flops K K' (3 P + 1) / rocprofv3 kernel duration against the dense 16-bit MFMA peak
+                      (frac, frac_algorithmic), the f16 / bf16 MFMA work actually issued beside it (mfma_issue_frac), the
                       matrix-pipe busy fraction and the vector-issue fraction from the PMC pass, the clock the kernel ran at
   roofline_hbm        k_gram: algorithmic bytes / rocprofv3 kernel duration, PMC traffic beside it
   roofline_streaming  SURVEY 8(d): algorithmic bytes of a generation / (bench step time - pair-sum kernel), and set 0
@@ -114,10 +115,15 @@ for c in cfgs:
         kde_ms = ns / 1e6
         pairs = float(K) * Kp
         mf = 6 * ((P + 15) // 16) + 3
-        tf = pairs * mf * 32.0 / (ns * 1e-9) / 1e12
+        tf = pairs * mf * 32.0 / (ns * 1e-9) / 1e12                      # matrix work ISSUED (limb products of the fp64 operands)
+        alg = pairs * (3.0 * P + 1.0)                                    # K K' (3 P + 1) algorithmic flops
+        atf = alg / (ns * 1e-9) / 1e12
         ent["roofline"] = {"kernel": kk[0], "bound": "mfma", "kernel_avg_ms": round(kde_ms, 4), "pairs_per_launch": pairs,
-                           "mfma_32x32x16_per_1024_pairs": mf, "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_PEAK_TF,
-                           "frac": round(tf / MFMA_PEAK_TF, 4), "traffic_hbm_bytes": traffic(c, 'k_kde_split')}
+                           "flops_algorithmic": alg, "achieved_TFLOPs": round(atf, 1), "peak_TFLOPs": MFMA_PEAK_TF,
+                           "frac": round(atf / MFMA_PEAK_TF, 4), "frac_algorithmic": round(atf / MFMA_PEAK_TF, 4),
+                           "algorithmic_vs_fp64_vector_peak": round(atf / 78.6, 3),
+                           "mfma_32x32x16_per_1024_pairs": mf, "achieved_issued_mfma_TFLOPs": round(tf, 1),
+                           "mfma_issue_frac": round(tf / MFMA_PEAK_TF, 4), "traffic_hbm_bytes": traffic(c, 'k_kde_split')}
         d = G + '%s_kde_c%d' % (pp, c)
         if os.path.isdir(d):
             cn = pmc(d, kernel='k_kde_split')
@@ -153,7 +159,7 @@ for c in cfgs:
 json.dump(roof, open('profiles/%s_roofline.json' % tag, 'w'), indent=1)
 for c in cfgs:
     e = roof["config%d" % c]
-    print("config", c, "step %.3f ms" % e["ms_per_step_bench"], "| kde", e.get("roofline", {}).get("kernel_avg_ms"), "ms frac",
-          e.get("roofline", {}).get("frac"), "clock", e.get("roofline", {}).get("clock_ghz"), "valu", e.get("roofline", {}).get("valu_active_frac_of_kernel_cycles"),
+    print("config", c, "step %.3f ms" % e["ms_per_step_bench"], "| kde", e.get("roofline", {}).get("kernel_avg_ms"), "ms frac (algorithmic / issued)",
+          e.get("roofline", {}).get("frac"), e.get("roofline", {}).get("mfma_issue_frac"), "clock", e.get("roofline", {}).get("clock_ghz"), "valu", e.get("roofline", {}).get("valu_active_frac_of_kernel_cycles"),
           "| gram", e.get("roofline_hbm", {}).get("frac"), "| streaming", e["roofline_streaming"]["frac"], "| set0",
           e.get("set0_roofline_streaming", {}).get("frac"))
