@@ -25,6 +25,8 @@
 // table with the oracle's entry by entry.
 // Ten launches (the verdict is published by the caller's next kernel), no host involvement, no device-scope fences (reductions across work-groups go through kernel boundaries: every
 // "apply" kernel re-derives its block's prefix from the per-block aggregates of the launch before).
+#include <stdlib.h>
+
 #include "abc_internal.h"
 
 namespace {
@@ -161,7 +163,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 // fp64 block sums (approximate prefix sums: they only place every partial sum in its binade)
-__global__ __launch_bounds__(AL_T) void k_al_bsum(const double* __restrict__ w, size_t K, double* __restrict__ bsum, AlHead* __restrict__ head) {
+__global__ __launch_bounds__(AL_T) void k_al_bsum(const double* __restrict__ w, size_t K, double* __restrict__ bsum, AlHead* __restrict__ head,
+                                                  int force_fail) {
     __shared__ double sm[4];
     const size_t base = (size_t)blockIdx.x * AL_B + (size_t)threadIdx.x * AL_I;
     double s = 0.0;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(AL_T) void k_al_bsum(const double* __restrict__ w, 
     if (threadIdx.x == 0) bsum[blockIdx.x] = bs;
     if (blockIdx.x == 0 && threadIdx.x == 0) {            // this build's header (nothing else writes it in this launch)
         head->approx_total = 0.0; head->total = 0.0; head->e0_sum = 0; head->e0 = 0; head->ns = 0; head->nb = 0; head->nsteps = 0;
-        head->fail = 0; head->MEAN = 0;
+        head->fail = force_fail; head->MEAN = 0;
     }
 }
 
@@ -600,7 +603,9 @@ int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, u
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "device alias build: workspace exhausted");
     const double mean = 1.0 / (double)K, dK = (double)K;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_al_bsum, dim3(nblk), dim3(AL_T), 0, st, w, K, bsum, head);
+    // ABC_ALIAS_FORCE_FAIL (tests): the build reports failure although it verified, so the callers' host fall-backs can be exercised
+    const int force_fail = getenv("ABC_ALIAS_FORCE_FAIL") ? 1 : 0;
+    hipLaunchKernelGGL(k_al_bsum, dim3(nblk), dim3(AL_T), 0, st, w, K, bsum, head, force_fail);
     hipLaunchKernelGGL(k_al_sum_reduce, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, agg, tpre, head);
     hipLaunchKernelGGL(k_al_sum_apply, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, (const RMap*)agg, (const RMap*)tpre, head);
     hipLaunchKernelGGL(k_al_classify, dim3(nblk), dim3(AL_T), 0, st, w, K, mean, head, E, cnt, F, A);

@@ -154,16 +154,16 @@ __device__ __forceinline__ double exp2_neg(double x) {
 
 // partial denominators: part[slice*kn + i] = sum_{j in slice} exp(a_i.b_j - 1/2|a_i|^2 - hb_j) [* zero-dv mask]
 template <int PP>
-__global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn x PP scaled rows */, size_t kn,
-                                             const double* __restrict__ b /* Kp x PP scaled rows */, size_t Kp,
-                                             const double* __restrict__ hb /* Kp */, const WConst* __restrict__ wc,
-                                             const double* __restrict__ theta_raw, size_t K, size_t k0,
-                                             const double* __restrict__ prev_raw, double* __restrict__ part,
-                                             int fallback_of_split) {
+__device__ __forceinline__ void kde_body(unsigned bx, unsigned by, unsigned ny, const double* __restrict__ a /* kn x PP scaled rows */, size_t kn,
+                                         const double* __restrict__ b /* Kp x PP scaled rows */, size_t Kp,
+                                         const double* __restrict__ hb /* Kp */, const WConst* __restrict__ wc,
+                                         const double* __restrict__ theta_raw, size_t K, size_t k0,
+                                         const double* __restrict__ prev_raw, double* __restrict__ part,
+                                         int fallback_of_split) {
     // launched behind k_kde_split: runs only when that kernel declined (converged parameters, too many far rows)
     if (fallback_of_split && ks_split_on(wc)) return;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t slices = gridDim.y, sl = blockIdx.y;
+    const size_t i = (size_t)bx * 256 + threadIdx.x;
+    const size_t slices = ny, sl = by;
     // wave-uniform bounds in SGPRs (Kp < 2^32, checked by the launcher): the loop test stays off the vector pipe
     const unsigned j0 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * sl / slices));
     const unsigned j1 = __builtin_amdgcn_readfirstlane((unsigned)(Kp * (sl + 1) / slices));
@@ -204,6 +204,13 @@ __global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a /* kn 
         }
     }
     if (active) part[sl * kn + i] = acc;
+}
+template <int PP>
+__global__ __launch_bounds__(256) void k_kde(const double* __restrict__ a, size_t kn, const double* __restrict__ b, size_t Kp,
+                                             const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                             const double* __restrict__ theta_raw, size_t K, size_t k0,
+                                             const double* __restrict__ prev_raw, double* __restrict__ part, int fallback_of_split) {
+    kde_body<PP>(blockIdx.x, blockIdx.y, gridDim.y, a, kn, b, Kp, hb, wc, theta_raw, K, k0, prev_raw, part, fallback_of_split);
 }
 
 // ---- optional Epanechnikov kernel (ABC_WEIGHT_EPANECHNIKOV; an extension, see include/abcsmc_hip.h) -------------------------
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256) void k_kde_gen(const double* __restrict__ a, s
 // weight against the oracle: tests/test_gpu_parity.py::test_weight_split_kernel_accuracy_and_zero_weights (bound 2e-7), budget 1e-6.
 // Rows outside the exact range (a |coordinate| > 8, |row|^2 > 400, a weight outside {0} U [2^-300, 2^100]) are "far": k_wrows
 // gives them all-zero limbs (a far previous row then contributes exactly 0 here), flags / lists them, and two fp64 fix-up
-// kernels add their pairs (k_kde_far: a far new particle against the whole previous set; the far previous
+// kernels add their pairs (k_kde_fixups: a far new particle against the whole previous set; the far previous
 // particles against every new one), k_wfinish picking per row.  With converged parameters, coordinates beyond the int32
 // exponent range, or too many far rows (> K/16 + 32 new, > 1024 previous) the fp64 kernel above takes the whole call: every
 // kernel is always launched and those whose turn it is not return at once, so no flag travels to the host.
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
     if (rfar2k && inrange && g == 0) atomicOr(&wc->far, 1);
     if (valid) far = far || rfar8 || !(nrow <= KS_NORM2);
     // a far row takes no part in the matrix work (all-zero limbs, and hb = KS_HB_ZERO on the previous side): the fp64
-    // fix-up kernel (k_kde_far) adds its pairs
+    // fix-up launch (k_kde_fixups) adds its pairs
     if (far) {
         if (g == 0) {
             if (is_prev) { const int pos = atomicAdd(&wc->nfar_j, 1); if (pos < KS_MAX_FAR_J) far_list[pos] = (unsigned)r; }
@@ -529,16 +536,16 @@ __device__ __forceinline__ double ks_pair_term(const double (&ai)[PP], double ha
 // work-groups [nat, nat + rb) the far PREVIOUS particles: their terms for every new particle (one per lane), in ascending row
 // order (the atomically appended list is sorted in LDS by every work-group: a fixed order makes the sums bit-reproducible).
 template <int PP>
-__global__ __launch_bounds__(256) void k_kde_far(const double* __restrict__ a, size_t kn, const double* __restrict__ b,
-                                                 size_t Kp, const double* __restrict__ hb, const WConst* __restrict__ wc,
-                                                 const unsigned char* __restrict__ far_flag, const unsigned* __restrict__ list,
-                                                 unsigned nat, double* __restrict__ fix_i, double* __restrict__ fix_j) {
+__device__ __forceinline__ void far_body(unsigned bx, const double* __restrict__ a, size_t kn, const double* __restrict__ b,
+                                         size_t Kp, const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                         const unsigned char* __restrict__ far_flag, const unsigned* __restrict__ list,
+                                         unsigned nat, double* __restrict__ fix_i, double* __restrict__ fix_j) {
     if (!ks_split_on(wc)) return;
     __shared__ double sm[4];
     __shared__ unsigned sl[KS_MAX_FAR_J];
-    if (blockIdx.x < nat) {
+    if (bx < nat) {
         if (wc->nfar_i == 0) return;
-        const size_t i0 = (size_t)blockIdx.x * 32;
+        const size_t i0 = (size_t)bx * 32;
         for (int r = 0; r < 32; r++) {
             const size_t i = i0 + r;
             if (i >= kn || !far_flag[i]) continue;               // work-group uniform
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256) void k_kde_far(const double* __restrict__ a, s
             }
         }
     __syncthreads();
-    const size_t i = (size_t)(blockIdx.x - nat) * 256 + t;
+    const size_t i = (size_t)(bx - nat) * 256 + t;
     if (i >= kn) return;
     double ai[PP], ha = 0.0;
 #pragma unroll
@@ -580,6 +587,20 @@ __global__ __launch_bounds__(256) void k_kde_far(const double* __restrict__ a, s
         s += ks_pair_term<PP>(ai, ha, b + j * PP, hb[j]);
     }
     fix_j[i] = s;
+}
+// ONE launch behind k_kde_split for everything that kernel may have left undone (round 2: two, 10 us of empty launches on the
+// critical path of every weighted generation): work-groups [0, nat + rb) the far rows' fix-ups, the rest the fp64 kernel's grid
+// for the case that the split kernel declined the whole call.  Whose turn it is not returns at once.
+template <int PP>
+__global__ __launch_bounds__(256) void k_kde_fixups(const double* __restrict__ a, size_t kn, const double* __restrict__ b, size_t Kp,
+                                                    const double* __restrict__ hb, const WConst* __restrict__ wc,
+                                                    const unsigned char* __restrict__ far_flag, const unsigned* __restrict__ list,
+                                                    unsigned nat, unsigned rb, unsigned slices, double* __restrict__ fix_i,
+                                                    double* __restrict__ fix_j, const double* __restrict__ theta_raw, size_t K, size_t k0,
+                                                    const double* __restrict__ prev_raw, double* __restrict__ part) {
+    if (blockIdx.x < nat + rb) { far_body<PP>(blockIdx.x, a, kn, b, Kp, hb, wc, far_flag, list, nat, fix_i, fix_j); return; }
+    const unsigned bid = blockIdx.x - (nat + rb);
+    kde_body<PP>(bid % rb, bid / rb, slices, a, kn, b, Kp, hb, wc, theta_raw, K, k0, prev_raw, part, 1);
 }
 
 // The limb products of one 16-parameter chunk: which operand of the previous (A) and of the new (B) particle.  Product 0 is the
@@ -815,11 +836,11 @@ __global__ __launch_bounds__(256) void k_wfinish(const abc_prior* __restrict__ p
     if (wq == 0 && active) {
         num = (sn[0][lane] * sn[1][lane]) * (sn[2][lane] * sn[3][lane]);
         if (far_row) {
-            den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_far
+            den = fix_i[i];                                      // a far new particle: summed in fp64 by k_kde_fixups
         } else {
             den = (sd[0][lane] + sd[1][lane]) + (sd[2][lane] + sd[3][lane]);
             if (split_on) den *= exp2(-ha_frac[i]);              // the fraction of 1/2|a_i|^2 the split kernel left out (k_wrows)
-            if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_far)
+            if (split_on && wc->nfar_j > 0) den += fix_j[i];     // + the far previous particles (k_kde_fixups)
         }
         if (epan) wv = (den > 0.0) ? num / den : 0.0;            // compact support: a particle nothing supports gets weight 0
         else wv = num / (wc->C * den);
@@ -1055,7 +1076,17 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         if (PP > 64)
             hipLaunchKernelGGL(k_kde_gen, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc, theta, K, k0,
                                theta_prev, part, PP, 0, (int)P, w_prev);
-        else
+        else if (split) {       // far rows + the fp64 kernel as the split kernel's stand-in: one launch, returns at once when not needed
+#define LAUNCH_FIX(PPV)                                                                                                       \
+    hipLaunchKernelGGL(k_kde_fixups<PPV>, dim3((unsigned)(nat + rb + rb * slices)), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc, \
+                       far_flag, far_list, (unsigned)nat, (unsigned)rb, (unsigned)slices, fix_i, fix_j, theta, K, k0, theta_prev, part)
+            switch (PP) {
+                case 8: LAUNCH_FIX(8); break;
+                case 16: LAUNCH_FIX(16); break;
+                default: LAUNCH_FIX(32); break;
+            }
+#undef LAUNCH_FIX
+        } else
         switch (PP) {
             case 2: LAUNCH_KDE(2); break;
             case 4: LAUNCH_KDE(4); break;
@@ -1066,17 +1097,6 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         }
     }
 #undef LAUNCH_KDE
-    if (split) {        // far rows (outside the split kernel's exact range): returns at once when there are none
-#define LAUNCH_FAR(PPV)                                                                                                  \
-    hipLaunchKernelGGL(k_kde_far<PPV>, dim3((unsigned)(nat + rb)), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc,      \
-                       far_flag, far_list, (unsigned)nat, fix_i, fix_j)
-        switch (PP) {
-            case 8: LAUNCH_FAR(8); break;
-            case 16: LAUNCH_FAR(16); break;
-            default: LAUNCH_FAR(32); break;
-        }
-#undef LAUNCH_FAR
-    }
     // the whole set in one call (k0 = 0, kn = K) and a caller that normalises next: the sum of squares comes out of k_wfinish
     const unsigned fb = (unsigned)((kn + 63) / 64);
     double* sq_part = nullptr;

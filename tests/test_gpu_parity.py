@@ -1069,6 +1069,38 @@ def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp):
             assert nxt[:, p].min() >= a and nxt[:, p].max() <= b
 
 
+def test_generation_repeats_its_proposals_when_the_device_alias_build_fails(gpu_ctx, oracle, monkeypatch):
+    """abc_generation_dev queues the draws and the proposals behind the device-built resampling table without waiting for the
+    build's verdict; when the verdict (read at the generation's final synchronisation) says the table is unusable, the draws and
+    the proposals are repeated with the host's table.  ABC_ALIAS_FORCE_FAIL makes a (correct) build report failure: parents,
+    weights and seeds must still be the oracle's, and the fallback must have been counted"""
+    from abcsmc_amd import device
+    monkeypatch.setenv("ABC_ALIAS_FORCE_FAIL", "1")
+    N, M, P, K, Kp, Nn, A = 3000, 32, 16, 400, 400, 3000, 8
+    ctx = gpu_ctx
+    ctx.alias_stats(reset=True)
+    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    builds, fallbacks = ctx.alias_stats(reset=True)
+    monkeypatch.delenv("ABC_ALIAS_FORCE_FAIL")
+    assert builds >= 1 and fallbacks == builds
+    o = oracle.rng(67890)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A, multivariate=True)
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    nxt = device.to_numpy(gen.next)
+    assert np.isfinite(nxt).all()
+    # the repeated proposals are the ones a host-table generation makes: same Philox keys, same parents
+    from abcsmc_amd import _lib
+    ctx.set_alias_mode(_lib.ALIAS_HOST)
+    try:
+        wl2, X2, Y2, obs2, spec2, prev2, gen2, r2 = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    finally:
+        ctx.set_alias_mode(_lib.ALIAS_DEVICE)
+    assert np.array_equal(device.to_numpy(gen2.next), nxt) and np.array_equal(gen2.parent.cpu().numpy(), gen.parent.cpu().numpy())
+    assert (r.s1, r.s2, r.s3) == (r2.s1, r2.s2, r2.s3)
+
+
 @pytest.mark.parametrize("N,M,P,K,Kp,A", [(20000, 32, 16, 2000, 2000, 8), (6000, 64, 32, 600, 600, 8), (4000, 128, 16, 400, 400, 32)])
 def test_generation_repeats_bit_identically(gpu_ctx, N, M, P, K, Kp, A):
     """two runs of the same generation (side stream, deferred moments, host alias build between them) give the same bits in
