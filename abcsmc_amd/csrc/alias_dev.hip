@@ -103,24 +103,36 @@ __device__ __forceinline__ double from_grid(i128 v, int e0, bool* ok) {
     return ldexp((double)top, sh + e0);
 }
 
-// inclusive scan of one RMap per thread over the work-group (Hillis-Steele through two LDS buffers); returns this thread's
-// inclusive value; *excl gets the exclusive one (identity for thread 0)
+__device__ __forceinline__ i128 shfl_up_i128(i128 v, int d) {
+    const u64 lo = (u64)__shfl_up((long long)(u64)v, d, 64), hi = (u64)__shfl_up((long long)(u64)((u128)v >> 64), d, 64);
+    return (i128)(((u128)hi << 64) | lo);
+}
+__device__ __forceinline__ RMap shfl_up_map(const RMap& m, int d) {
+    RMap r;
+    r.t0 = shfl_up_i128(m.t0, d); r.t1 = shfl_up_i128(m.t1, d); r.b = shfl_up_i128(m.b, d); r.k = __shfl_up(m.k, d, 64);
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+    return r;
+}
+// inclusive scan of one RMap per thread over the work-group: inside a wave by shuffles (six steps), the four wave totals through
+// LDS (first version: Hillis-Steele over all 256 threads through two LDS buffers, eight rounds with a barrier each); returns
+// this thread's inclusive value; *excl gets the exclusive one (identity for thread 0)
 __device__ __forceinline__ RMap block_scan_maps(RMap mine, RMap (*buf)[AL_T], RMap* excl) {
-    const int t = threadIdx.x;
-    int cur = 0;
-    buf[0][t] = mine;
-    __syncthreads();
-    for (int step = 1; step < AL_T; step <<= 1) {
-        RMap v = buf[cur][t];
-        if (t >= step) v = compose(buf[cur][t - step], v);
-        buf[cur ^ 1][t] = v;
-        __syncthreads();
-        cur ^= 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    RMap inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const RMap up = shfl_up_map(inc, d);
+        if (lane >= d) inc = compose(up, inc);
     }
-    const RMap inc = buf[cur][t];
-    *excl = t ? buf[cur][t - 1] : rmap_identity();
+    RMap exw = shfl_up_map(inc, 1);                       // exclusive inside the wave
+    if (lane == 0) exw = rmap_identity();
+    if (lane == 63) buf[0][wave] = inc;
     __syncthreads();
-    return inc;
+    RMap before = rmap_identity();                        // the waves in front of this one, in order
+    for (int w = 0; w < wave; w++) before = compose(before, buf[0][w]);
+    __syncthreads();
+    *excl = compose(before, exw);
+    return compose(before, inc);
 }
 // composition, in order, of the aggregates agg[0 .. nb): every thread takes a contiguous chunk, then the block scan
 __device__ __forceinline__ RMap prefix_of_blocks(const RMap* __restrict__ agg, int nb, RMap (*buf)[AL_T]) {
@@ -401,7 +413,8 @@ __global__ __launch_bounds__(AL_T) void k_al_psum_reduce(const u64* __restrict__
     if (threadIdx.x == 0) bs[(size_t)blockIdx.y * nblk + blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(AL_T) void k_al_psum_apply(const u64* __restrict__ dI, const i128* __restrict__ VI, const AlHead* __restrict__ head,
-                                                        const i128* __restrict__ bs, int nblk, i128* __restrict__ D, i128* __restrict__ X) {
+                                                        const i128* __restrict__ bs, int nblk, i128* __restrict__ D, i128* __restrict__ X,
+                                                        i128* __restrict__ Dc, i128* __restrict__ Xc /* last sum of every block: coarse index */) {
     __shared__ i128 sh[AL_T];
     const bool bigs = blockIdx.y == 1;
     const size_t n = bigs ? head->nb : head->ns;
@@ -426,6 +439,7 @@ __global__ __launch_bounds__(AL_T) void k_al_psum_apply(const u64* __restrict__ 
     i128* out = bigs ? X : D;
 #pragma unroll
     for (int j = 0; j < AL_I; j++) if (base + j < n) { run += v[j]; out[base + j] = run; }
+    if (t == AL_T - 1) (bigs ? Xc : Dc)[blockIdx.x] = run;           // (a partly filled last block: the sum of what it holds)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -433,35 +447,74 @@ __global__ __launch_bounds__(AL_T) void k_al_psum_apply(const u64* __restrict__ 
 //    mean (ns + 1: never), jof[i] = the big serving small i, and the position of every small-step / hand-over in the chain
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr unsigned AL_HAND = 0x80000000u;
-__global__ __launch_bounds__(AL_T) void k_al_structure(const i128* __restrict__ D, const i128* __restrict__ X, AlHead* __restrict__ head,
-                                                       uint32_t* __restrict__ z, uint32_t* __restrict__ jof, uint32_t* __restrict__ step) {
+// one step of the serving chain, everything its map needs (the scans then build maps without a dependent load): a small-step
+// subtracts val = the small's deficit at result level k1; a hand-over is -fl(mean - r) at level k1, then fl(val - .) with
+// val = E[b'] at level k2.  idx: the small (0-based) resp. AL_HAND | the big handing over (0-based)
+struct StepRec { i128 val; uint32_t idx; unsigned char k1, k2; unsigned char pad_[10]; };
+// number of elements of the sorted array a[0 .. n) that are < v (strict) resp. <= v: first over the coarse index c (the last
+// element of every AL_B block: a few hundred entries every thread probes -- cache hits), then inside one block (16 KB, shared
+// with the neighbouring threads' searches).  A plain binary search over 1.6 MB arrays was 17 dependent L2 / fabric round trips
+// per thread: 25 us of the build.
+template <bool STRICT>
+__device__ __forceinline__ unsigned rank_two_level(const i128* __restrict__ a, const i128* __restrict__ c, unsigned n, i128 v) {
+    const unsigned nblk = (n + AL_B - 1) / AL_B;
+    unsigned lo = 0, hi = nblk;                     // first block whose last element is not before v
+    while (lo < hi) { const unsigned mid = (lo + hi) >> 1; const i128 x = c[mid]; if (STRICT ? (x < v) : (x <= v)) lo = mid + 1; else hi = mid; }
+    if (lo >= nblk) return n;
+    unsigned l2 = lo * AL_B, h2 = l2 + AL_B;
+    if (h2 > n) h2 = n;
+    while (l2 < h2) { const unsigned mid = (l2 + h2) >> 1; const i128 x = a[mid]; if (STRICT ? (x < v) : (x <= v)) l2 = mid + 1; else h2 = mid; }
+    return l2;
+}
+
+__global__ __launch_bounds__(AL_T) void k_al_structure(const i128* __restrict__ D, const i128* __restrict__ X, const i128* __restrict__ Dc,
+                                                       const i128* __restrict__ Xc, const u64* __restrict__ dI, const i128* __restrict__ VI,
+                                                       AlHead* __restrict__ head, uint32_t* __restrict__ z, uint32_t* __restrict__ jof,
+                                                       StepRec* __restrict__ step) {
     const unsigned ns = head->ns, nb = head->nb;
     const size_t t = (size_t)blockIdx.x * AL_T + threadIdx.x;
-    if (ns == 0 || nb == 0 || t >= (size_t)ns + nb) return;
-    if (t < ns) {
-        const unsigned i = (unsigned)t + 1;                    // small i (1-based): served by big 1 + #{j : X_j < D_{i-1}}
-        const i128 dprev = (i >= 2) ? D[i - 2] : (i128)0;
-        unsigned lo = 0, hi = nb;                              // lower bound of dprev in X
-        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (X[mid] < dprev) lo = mid + 1; else hi = mid; }
-        const unsigned j = lo + 1;
-        jof[i - 1] = j;
-        if (j <= nb) {
-            const unsigned pos = i + j - 1;                    // 1-based position in the chain
-            step[pos - 1] = i - 1;
-            atomicMax(&head->nsteps, pos);
+    unsigned pos = 0;                                          // 1-based position of this thread's step in the chain (0: none)
+    if (ns != 0 && nb != 0 && t < (size_t)ns + nb) {
+        if (t < ns) {
+            const unsigned i = (unsigned)t + 1;                    // small i (1-based): served by big 1 + #{j : X_j < D_{i-1}}
+            const i128 dprev = (i >= 2) ? D[i - 2] : (i128)0;
+            const unsigned j = rank_two_level<true>(X, Xc, nb, dprev) + 1;      // lower bound of dprev in X
+            jof[i - 1] = j;
+            if (j <= nb) {
+                pos = i + j - 1;
+                const i128 star = head->MEAN + X[j - 1] - D[i - 1];               // exact value after the step: its binade is the level
+                StepRec r;
+                r.val = (i128)dI[i - 1]; r.idx = i - 1; r.k1 = (unsigned char)level_of(star < 0 ? (i128)0 : star); r.k2 = 0;
+                step[pos - 1] = r;
+            }
+        } else {
+            const unsigned j = (unsigned)(t - ns) + 1;             // big j (1-based): z = 1 + #{i : D_i <= X_j}
+            const i128 xj = X[j - 1];
+            const unsigned zz = rank_two_level<false>(D, Dc, ns, xj) + 1;       // upper bound of xj in D
+            z[j - 1] = zz;
+            if (zz <= ns && j < nb) {
+                pos = zz + j;
+                const i128 dz = D[zz - 1];
+                const i128 dd = dz - xj;                                          // mean - r, exact
+                const i128 star = head->MEAN + X[j] - dz;
+                StepRec r;
+                r.val = VI[j]; r.idx = AL_HAND | (j - 1);
+                r.k1 = (unsigned char)level_of(dd < 0 ? (i128)0 : dd); r.k2 = (unsigned char)level_of(star < 0 ? (i128)0 : star);
+                step[pos - 1] = r;
+            }
         }
-    } else {
-        const unsigned j = (unsigned)(t - ns) + 1;             // big j (1-based): z = 1 + #{i : D_i <= X_j}
-        const i128 xj = X[j - 1];
-        unsigned lo = 0, hi = ns;                              // upper bound of xj in D
-        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (D[mid] <= xj) lo = mid + 1; else hi = mid; }
-        const unsigned zz = lo + 1;
-        z[j - 1] = zz;
-        if (zz <= ns && j < nb) {
-            const unsigned pos = zz + j;
-            step[pos - 1] = AL_HAND | (j - 1);
-            atomicMax(&head->nsteps, pos);
-        }
+    }
+    // the chain's length = the largest position: one atomic per work-group (one per thread on a single word was most of this
+    // kernel's 25 us)
+    __shared__ unsigned smax[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned v = __shfl_xor(pos, o, 64); pos = v > pos ? v : pos; }
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = pos;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = smax[0];
+        for (int w = 1; w < 4; w++) m = smax[w] > m ? smax[w] : m;
+        if (m) atomicMax(&head->nsteps, m);
     }
 }
 
@@ -470,21 +523,12 @@ __global__ __launch_bounds__(AL_T) void k_al_structure(const i128* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------------
 struct ServeArgs {
     const double* E; const uint32_t* sidx; const uint32_t* bidx; const u64* dI; const i128* VI; const i128* D; const i128* X;
-    const uint32_t* z; const uint32_t* jof; const uint32_t* step;
+    const uint32_t* z; const uint32_t* jof; const StepRec* step;
 };
-__device__ __forceinline__ RMap serve_map(const ServeArgs& a, const AlHead* head, unsigned t) {
-    const uint32_t s = a.step[t];
-    const i128 MEAN = head->MEAN;
-    if (!(s & AL_HAND)) {
-        const unsigned ii = s, j = a.jof[ii];                              // small ii (0-based) on big j (1-based)
-        const i128 star = MEAN + a.X[j - 1] - a.D[ii];                     // exact value after the step
-        return rne_map(level_of(star < 0 ? (i128)0 : star), -(i128)a.dI[ii], false);
-    }
-    const unsigned j = (s & ~AL_HAND) + 1, zz = a.z[j - 1];                // hand-over from big j to big j + 1 after small zz
-    const i128 dd = a.D[zz - 1] - a.X[j - 1];                              // mean - r, exact
-    const RMap m1 = rne_map(level_of(dd < 0 ? (i128)0 : dd), -MEAN, false);     // r -> -fl(mean - r) (round-half-even is odd-symmetric)
-    const i128 star = MEAN + a.X[j] - a.D[zz - 1];
-    const RMap m2 = rne_map(level_of(star < 0 ? (i128)0 : star), a.VI[j], false);   // -> fl(E[b'] - fl(mean - r))
+__device__ __forceinline__ RMap serve_map(const StepRec& r, i128 MEAN) {
+    if (!(r.idx & AL_HAND)) return rne_map(r.k1, -r.val, false);
+    const RMap m1 = rne_map(r.k1, -MEAN, false);              // r -> -fl(mean - r) (round-half-even is odd-symmetric)
+    const RMap m2 = rne_map(r.k2, r.val, false);              // -> fl(E[b'] - fl(mean - r))
     return compose(m1, m2);
 }
 
@@ -494,9 +538,13 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_reduce(ServeArgs a, const AlH
     const unsigned n = head->nsteps;
     if ((size_t)blockIdx.x * AL_B >= n) { if (threadIdx.x == 0) agg[blockIdx.x] = rmap_identity(); return; }
     const size_t base = (size_t)blockIdx.x * AL_B + (size_t)threadIdx.x * AL_I;
+    const i128 MEAN = head->MEAN;
+    StepRec rec[AL_I];
+#pragma unroll
+    for (int j = 0; j < AL_I; j++) if (base + j < n) rec[j] = a.step[base + j];
     RMap m = rmap_identity();
 #pragma unroll
-    for (int j = 0; j < AL_I; j++) if (base + j < n) m = compose(m, serve_map(a, head, (unsigned)(base + j)));
+    for (int j = 0; j < AL_I; j++) if (base + j < n) m = compose(m, serve_map(rec[j], MEAN));
     RMap ex;
     const RMap inc = block_scan_maps(m, buf, &ex);
     tpre[(size_t)blockIdx.x * AL_T + threadIdx.x] = ex;
@@ -517,9 +565,14 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_apply(ServeArgs a, AlHead* __
     }
     const RMap pre = prefix_of_blocks(agg, blockIdx.x, buf);
     const size_t base = (size_t)blockIdx.x * AL_B + (size_t)threadIdx.x * AL_I;
+    const i128 MEAN = head->MEAN;
+    StepRec rec[AL_I];
     RMap mj[AL_I];
 #pragma unroll
-    for (int j = 0; j < AL_I; j++) mj[j] = (base + j < n) ? serve_map(a, head, (unsigned)(base + j)) : rmap_identity();
+    for (int j = 0; j < AL_I; j++) {
+        if (base + j < n) { rec[j] = a.step[base + j]; mj[j] = serve_map(rec[j], MEAN); }
+        else { rec[j].idx = 0; mj[j] = rmap_identity(); }
+    }
     const RMap ex = tpre[(size_t)blockIdx.x * AL_T + threadIdx.x];
     const int e0 = head->e0;
     i128 v = rapply(ex, rapply(pre, a.VI[0]));                     // the chain starts at E[b_1]
@@ -531,7 +584,7 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_apply(ServeArgs a, AlHead* __
         if (t >= n) break;
         v = rapply(mj[j], v);
         const double c = from_grid(v, e0, &ok);
-        const uint32_t s = a.step[t];
+        const uint32_t s = rec[j].idx;
         unsigned jcur;
         bool below, at_last_small;
         if (!(s & AL_HAND)) {
@@ -574,7 +627,7 @@ __global__ void k_al_flag(const AlHead* __restrict__ head, int* __restrict__ fai
 
 size_t abc_alias_dev_need(size_t K) {
     const size_t nblk = (K + AL_B - 1) / AL_B + 1, nblk2 = (2 * K + AL_B - 1) / AL_B + 1;
-    return K * (8 + 4 + 4 + 8 + 16 + 16 + 16 + 4 + 4 + 8) + nblk * (8 + 4 + 64 + 32) + nblk2 * 64 * (AL_T + 1) + sizeof(AlHead) + 64 * 256;
+    return K * (8 + 4 + 4 + 8 + 16 + 16 + 16 + 4 + 4 + 64) + nblk * (8 + 4 + 64 + 64) + nblk2 * 64 * (AL_T + 1) + sizeof(AlHead) + 64 * 256;
 }
 
 // F (K doubles, cut-off fractions WITHOUT the KNUTH_CONVENTION map, as alias_preproc(..., knuth = false)) and A (K uint32) on the
@@ -595,10 +648,12 @@ int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, u
     i128* VI = (i128*)abc_ws_alloc(ctx, K * 16);
     i128* D = (i128*)abc_ws_alloc(ctx, K * 16);
     i128* X = (i128*)abc_ws_alloc(ctx, K * 16);
-    i128* bs = (i128*)abc_ws_alloc(ctx, (size_t)2 * nblk * 16);
+    i128* bs = (i128*)abc_ws_alloc(ctx, (size_t)4 * nblk * 16);          // block sums of both arrays, then their coarse indices
+    i128* Dc = bs ? bs + (size_t)2 * nblk : nullptr;
+    i128* Xc = bs ? bs + (size_t)3 * nblk : nullptr;
     uint32_t* z = (uint32_t*)abc_ws_alloc(ctx, K * 4);
     uint32_t* jof = (uint32_t*)abc_ws_alloc(ctx, K * 4);
-    uint32_t* step = (uint32_t*)abc_ws_alloc(ctx, 2 * K * 4);
+    StepRec* step = (StepRec*)abc_ws_alloc(ctx, 2 * K * sizeof(StepRec));
     if (!head || !bsum || !agg || !tpre || !E || !cnt || !sidx || !bidx || !dI || !VI || !D || !X || !bs || !z || !jof || !step)
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "device alias build: workspace exhausted");
     const double mean = 1.0 / (double)K, dK = (double)K;
@@ -612,8 +667,8 @@ int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, u
     hipLaunchKernelGGL(k_al_lists, dim3(nblk), dim3(AL_T), 0, st, (const double*)E, K, mean, (const unsigned*)cnt, nblk, head, sidx, dI, bidx, VI);
     hipLaunchKernelGGL(k_al_psum_reduce, dim3(nblk, 2), dim3(AL_T), 0, st, (const u64*)dI, (const i128*)VI, (const AlHead*)head, bs, nblk);
     hipLaunchKernelGGL(k_al_psum_apply, dim3(nblk, 2), dim3(AL_T), 0, st, (const u64*)dI, (const i128*)VI, (const AlHead*)head,
-                       (const i128*)bs, nblk, D, X);
-    hipLaunchKernelGGL(k_al_structure, dim3((unsigned)((K + AL_T - 1) / AL_T)), dim3(AL_T), 0, st, (const i128*)D, (const i128*)X, head, z, jof, step);
+                       (const i128*)bs, nblk, D, X, Dc, Xc);
+    hipLaunchKernelGGL(k_al_structure, dim3((unsigned)((K + AL_T - 1) / AL_T)), dim3(AL_T), 0, st, (const i128*)D, (const i128*)X, (const i128*)Dc, (const i128*)Xc, (const u64*)dI, (const i128*)VI, head, z, jof, step);
     ServeArgs a = {E, sidx, bidx, dI, VI, D, X, z, jof, step};
     hipLaunchKernelGGL(k_al_serve_reduce, dim3(nblk2), dim3(AL_T), 0, st, a, (const AlHead*)head, agg, tpre);
     hipLaunchKernelGGL(k_al_serve_apply, dim3(nblk2), dim3(AL_T), 0, st, a, head, (const RMap*)agg, (const RMap*)tpre, mean, dK, F, A, fail_dev, fail_pin);
