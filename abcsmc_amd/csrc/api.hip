@@ -613,7 +613,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // (with proposals to draw the host builds the alias table of these weights next: the normalisation kernel stores them
         // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
         double* mirror = nullptr;
-        const bool alias_on_device = ctx->alias_mode == ABC_ALIAS_DEVICE && K >= 2 && K <= ABC_ALIAS_DEV_MAX_K;
+        const bool alias_on_device = ctx->alias_mode == ABC_ALIAS_DEVICE && K >= ABC_ALIAS_DEV_MIN_K && K <= ABC_ALIAS_DEV_MAX_K;
         if (Nn && !alias_on_device) {          // (the device build reads the weights where they are)
             ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;

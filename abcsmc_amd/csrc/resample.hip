@@ -668,7 +668,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     }
     ctx->alias_A = (uint32_t*)(ctx->alias_F + K);
     // ---- the table built on the device (alias_dev.hip): no copy of the weights to the host, no host wait ------------------------
-    if (ctx->alias_mode == ABC_ALIAS_DEVICE && K >= 2 && K <= ABC_ALIAS_DEV_MAX_K && ctx->ws_off + abc_alias_dev_need(K) <= ctx->ws_bytes) {
+    if (ctx->alias_mode == ABC_ALIAS_DEVICE && K >= ABC_ALIAS_DEV_MIN_K && K <= ABC_ALIAS_DEV_MAX_K && ctx->ws_off + abc_alias_dev_need(K) <= ctx->ws_bytes) {
         if (!ctx->alias_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->alias_fail_dev, sizeof(int)));
         int* fail_pin = (int*)(ctx->status_pin + 44);
         *fail_pin = 0;

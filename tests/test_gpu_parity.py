@@ -1076,7 +1076,7 @@ def test_generation_repeats_its_proposals_when_the_device_alias_build_fails(gpu_
     weights and seeds must still be the oracle's, and the fallback must have been counted"""
     from abcsmc_amd import device
     monkeypatch.setenv("ABC_ALIAS_FORCE_FAIL", "1")
-    N, M, P, K, Kp, Nn, A = 3000, 32, 16, 400, 400, 3000, 8
+    N, M, P, K, Kp, Nn, A = 220000, 32, 16, 22000, 500, 30000, 8          # (the device build takes tables from 20000 entries)
     ctx = gpu_ctx
     ctx.alias_stats(reset=True)
     wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
