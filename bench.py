@@ -138,6 +138,7 @@ def main():
     rng = abcutil.rng(67890)
 
     ctx = _lib.default_context(local_rank)
+    ctx.alias_stats(reset=True)
     ctx.set_kde_mode(_lib.KDE_FP64 if args.kde_mode == "fp64" else _lib.KDE_AUTO)
     comm_kind = None
     if world == 1:
@@ -453,7 +454,6 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
     # host's sequential build it replaces (host ms; the GPU idles behind it, plus two PCIe hops), on log-normal weights
     g = np.random.default_rng(5)
     r = abcutil.rng(3)
-    ctx.alias_stats(reset=True)
     for name, w in (("lognormal_sigma1.5", np.exp(1.5 * g.normal(size=K))), ("lognormal_sigma3", np.exp(3.0 * g.normal(size=K)))):
         dw = torch.from_numpy(w / np.linalg.norm(w)).to(dev)
         par = be.empty(1024, torch.int64)
@@ -470,7 +470,7 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
             ctx.timing_enable(False)
             out[key + name] = round(st["alias_host"][col] / max(st["alias_host"][2], 1), 5)
     ctx.set_alias_mode(_lib.ALIAS_DEVICE)
-    builds, fallbacks = ctx.alias_stats(reset=True)
+    builds, fallbacks = ctx.alias_stats(reset=True)           # over the WHOLE run: warm-up, timed region, sustained leg, these legs
     out["alias_device_builds"], out["alias_device_fallbacks"] = builds, fallbacks
     return out
 
