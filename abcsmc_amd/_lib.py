@@ -29,6 +29,13 @@ class AbcError(RuntimeError):
         self.code = code
 
 
+class AbcWarning(UserWarning):
+    pass
+
+
+WARN_GIVEUPS = 1
+
+
 class Prior(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
 
@@ -187,8 +194,13 @@ class Context:
         return self._h
 
     def check(self, rc):
-        if rc:
+        """negative status: AbcError; positive (ABC_WARN_GIVEUPS): a Python warning, the call's outputs are valid"""
+        if rc < 0:
             raise AbcError(rc, lib().abc_last_error(self._h).decode())
+        if rc > 0:
+            import warnings
+            self.last_warning = lib().abc_last_error(self._h).decode()
+            warnings.warn(AbcWarning(self.last_warning), stacklevel=2)
 
     def set_stream(self, stream_ptr):
         if getattr(self, "_stream", -1) != stream_ptr:      # abc_ctx_set_stream synchronises: only on change

@@ -59,6 +59,9 @@ struct abc_ctx {
     unsigned long long alias_dev_builds, alias_dev_fallbacks;   // device builds queued / found unusable (abc_alias_stats)
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
+    unsigned long long giveups_seen;   // device counter as of the last generation's end (abc_generation_dev warns when it grows)
+    int timers_open;                   // StageTimers between their two events (the ring is only drained when none is)
+    unsigned long long timing_dropped; // samples that found the ring full while a timer was open (abc_timing_read reports them)
     int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish
     int* sel_fail_dev;       // device: the sampled-range bin selection gave up (select.hip); read by abc_select_check
     bool sel_bins_ran;       // the last launch_select_smallest took the bin path and has not been checked yet
@@ -78,18 +81,26 @@ struct abc_ctx {
     long long stage_cnt[ABC_NSTAGE];
 };
 
+int abc_timing_flush(abc_ctx* ctx);
 // RAII marker: records an event pair around a stage when timing is on
 struct StageTimer {
     abc_ctx* ctx; int slot;
     StageTimer(abc_ctx* c, int stage) : ctx(c), slot(-1) {
-        if (!c->timing || c->nev >= 256 || stage < 0) return;
+        if (!c->timing || stage < 0) return;
         if (c->timing == 2 && stage != ST_GRAM && stage != ST_KDE) return;
+        // ring full: drain it (a stream synchronisation) unless an enclosing timer is still open -- then the sample is lost,
+        // counted, and abc_timing_read says so instead of handing out a short sum
+        if (c->nev >= 256) {
+            if (c->timers_open == 0) (void)abc_timing_flush(c);
+            if (c->nev >= 256) { c->timing_dropped++; return; }
+        }
+        c->timers_open++;
         slot = c->nev++;
         if (!c->ev[slot].a) { (void)hipEventCreate(&c->ev[slot].a); (void)hipEventCreate(&c->ev[slot].b); }
         c->ev[slot].stage = stage;
         (void)hipEventRecord(c->ev[slot].a, c->stream);
     }
-    ~StageTimer() { if (slot >= 0) (void)hipEventRecord(ctx->ev[slot].b, ctx->stream); }
+    ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(ctx->ev[slot].b, ctx->stream); ctx->timers_open--; } }
 };
 
 #define ABC_FAIL(ctx, code, ...)                                   \

@@ -176,6 +176,7 @@ extern "C" int abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset) {
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     *count = (uint64_t)dev + (uint64_t)ctx->giveups_host;
+    ctx->giveups_seen = reset ? 0 : (unsigned long long)*count;
     if (reset) ctx->giveups_host = 0;
     return ABC_OK;
 }
@@ -204,6 +205,8 @@ extern "C" int abc_timing_enable(abc_ctx* ctx, int on) {
     ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timing = (on == 2) ? 2 : (on != 0);
     ctx->nev = 0;
+    ctx->timers_open = 0;
+    ctx->timing_dropped = 0;
     return ABC_OK;
 }
 
@@ -225,6 +228,11 @@ extern "C" int abc_timing_read(abc_ctx* ctx, const char** names, double* ms, dou
                                int max_stages, int reset) {
     if (!ctx) return ABC_ERR_INVALID;
     ABC_TRY(abc_timing_flush(ctx));
+    if (ctx->timing_dropped) {
+        const unsigned long long d = ctx->timing_dropped;
+        ctx->timing_dropped = 0;
+        ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_timing_read: %llu stage samples were lost (event ring full inside an open stage); the sums are short", d);
+    }
     for (int i = 0; i < ABC_NSTAGE && i < max_stages; i++) {
         if (names) names[i] = kStageNames[i];
         if (ms) ms[i] = ctx->stage_ms[i];
@@ -450,11 +458,13 @@ extern "C" int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* t
 // the status words of a generation (model header with the component count, Cholesky status, selection flag) stored by the GPU
 // straight into the context's pinned, device-visible block
 __global__ void k_status_words(const double* __restrict__ model_hdr, const int* __restrict__ spd, const int* __restrict__ fail,
-                               double* __restrict__ hdr_out, int* __restrict__ spd_out, int* __restrict__ fail_out) {
+                               const unsigned long long* __restrict__ giveups, double* __restrict__ hdr_out, int* __restrict__ spd_out,
+                               int* __restrict__ fail_out, unsigned long long* __restrict__ giveups_out) {
     const int t = threadIdx.x;
     if (model_hdr && t < 4) hdr_out[t] = model_hdr[t];
     if (spd && t == 4) *spd_out = *spd;
     if (fail && t == 5) *fail_out = *fail;
+    if (t == 6) *giveups_out = giveups ? giveups[0] : 0ull;
 }
 
 static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const abc_generation_io* io, abc_rng* rng,
@@ -706,8 +716,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         hdr[0] = 0.0; *pspd = 0; *pfail = 0;
         // ONE tiny kernel stores the three words into the (device-visible) pinned block: three copies were three blit launches
         const int* fail_dev = (ctx->sel_bins_ran && ctx->sel_fail_dev) ? (const int*)ctx->sel_fail_dev : nullptr;
+        unsigned long long* pgive = (unsigned long long*)(ctx->status_pin + 48);
+        *pgive = 0;
         hipLaunchKernelGGL(k_status_words, dim3(1), dim3(64), 0, ctx->stream, simple ? (const double*)nullptr : (const double*)model,
-                           have_spd ? (const int*)spd_dev : (const int*)nullptr, fail_dev, hdr, pspd, pfail);
+                           have_spd ? (const int*)spd_dev : (const int*)nullptr, fail_dev, (const unsigned long long*)ctx->giveups_dev, hdr, pspd,
+                           pfail, pgive);
         ABC_HIP(ctx, hipGetLastError());
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
@@ -733,6 +746,17 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     }
     if (ctx->timing && ctx->nev > 128) ABC_TRY(abc_timing_flush(ctx));
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
+    // proposals the perturbation gave up on during THIS call (the reference never returns in that case, AbcUtil.cpp:132): the
+    // outputs are complete -- such a row is its (valid) parent, or the prior mean in INDEPENDENT mode -- and the caller is told
+    {
+        const unsigned long long gv = *(volatile unsigned long long*)(ctx->status_pin + 48) + ctx->giveups_host;
+        const unsigned long long before = ctx->giveups_seen;
+        ctx->giveups_seen = gv;
+        if (Nn && gv > before)
+            ABC_FAIL(ctx, ABC_WARN_GIVEUPS, "generation complete, but the perturbation gave up on %llu proposal(s): they are their parents "
+                     "(MULTIVARIATE, after %u rejected attempts) or prior means (INDEPENDENT, after 1000); abc_perturb_giveups has the total",
+                     gv - before, 16384u);
+    }
     return ABC_OK;
 }
 

@@ -16,7 +16,9 @@
  *   - functions WITHOUT the _dev suffix take HOST pointers (drop-in for the reference call
  *     sites); functions WITH _dev take DEVICE pointers (HBM-resident data, used by bench.py and
  *     the multi-GPU driver) and run asynchronously on the context's stream.
- *   - every function returns ABC_OK (0) or a negative abc_status; abc_last_error() gives text.
+ *   - every function returns ABC_OK (0) or a negative abc_status; abc_last_error() gives text.  One POSITIVE value exists:
+ *     abc_generation_dev returns ABC_WARN_GIVEUPS when its outputs are complete and valid but some proposals are their (valid)
+ *     parents or a prior mean because the perturbation gave up on them (the reference would still be retrying, AbcUtil.cpp:132).
  *     Nothing here calls exit() or throws (the reference exits/aborts).
  *   - one context per GPU and per host thread; calls on one context are serialised.
  */
@@ -33,6 +35,7 @@ extern "C" {
 typedef struct abc_ctx abc_ctx;
 
 typedef enum {
+    ABC_WARN_GIVEUPS = 1,       /* abc_generation_dev: done, but abc_perturb_giveups grew during this call (see there)       */
     ABC_OK = 0,
     ABC_ERR_INVALID = -1,       /* bad argument (reference: assert / exit)                   */
     ABC_ERR_HIP = -2,           /* HIP runtime failure                                        */
