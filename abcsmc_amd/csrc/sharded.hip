@@ -599,7 +599,38 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // ---- doubled variance, importance weights (pair sums: K / G rows per rank) ----------------------------------------------
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;
-    if (P <= 64 && K >= 2) {
+    const bool uniform_weights = (Kp == 0 || !io->theta_prev);
+    // As in the single-GPU driver: with proposals to draw behind a weight stage, the posterior's moments and everything that
+    // follows from them (doubled variance, proposal factor, the perturbation's row-major copy and padded factor) run on the SIDE
+    // stream beside the pair sums -- nothing waits for the host any more (the resampling table is built on the device).
+    double* L_early = nullptr;
+    abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool moments_on_side = false;
+    if (Nn && !uniform_weights && P <= 64 && K >= 2 && ctx->side) {
+        if (cfg->multivariate) {
+            L_early = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
+            if (!L_early) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        }
+        const int PPr = abc_perturb_pp(P);
+        side_out.dv = dv; side_out.L = L_early; side_out.spd = spd_dev;
+        side_out.rows = (double*)abc_ws_alloc(ctx, K * (size_t)PPr * sizeof(double));
+        if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
+        if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        if (!ctx->ev_theta) {
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, hipEventDisableTiming));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, hipEventDisableTiming));
+        }
+        ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_theta, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->side;
+        int rc = launch_theta_stats(ctx, theta, K, P, &theta_stats);
+        if (rc == ABC_OK) rc = launch_post_tail(ctx, theta, K, P, theta_stats, &side_out);
+        ctx->stream = main_stream;
+        ABC_TRY(rc);
+        ABC_HIP(ctx, hipEventRecord(ctx->ev_moments, ctx->side));
+        moments_on_side = true;
+    } else if (P <= 64 && K >= 2) {
         StageTimer tm(ctx, ST_GATHER_DV);
         ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats));
         ABC_TRY(launch_dv_from_stats(ctx, theta_stats, P, dv));
@@ -622,7 +653,8 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         }
         // (as in the single-GPU driver: the normalised weights go to the pinned scratch as they are written)
         double* mirror = nullptr;
-        if (Nn) {
+        const bool alias_on_device = ctx->alias_mode == ABC_ALIAS_DEVICE && K >= ABC_ALIAS_DEV_MIN_K && K <= ABC_ALIAS_DEV_MAX_K;
+        if (Nn && !alias_on_device) {          // (the device build reads the weights where they are)
             ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
             mirror = (double*)ctx->pin;
         }
@@ -633,20 +665,25 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // ---- proposals for this rank's slice of the next set --------------------------------------------------------------------
     int spd = 0;
     bool have_spd = false;
+    int alias_deferred = 0;
+    uint64_t* parent_used = nullptr;
+    double* L_used = nullptr;
+    abc_perturb_prep prep_used = {nullptr, 0, nullptr};
     if (Nn) {
         uint64_t* parent = io->parent ? io->parent : (uint64_t*)abc_ws_alloc(ctx, Nn * 8);
         if (!parent) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         double* L = nullptr;
         if (cfg->multivariate) {
-            L = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
+            L = L_early ? L_early : (io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8));
             have_spd = true;
         }
-        abc_perturb_prep prep = {nullptr, io->seeds ? 1 : 0, nullptr};
+        abc_perturb_prep prep = {moments_on_side ? side_out.rows : nullptr, io->seeds ? 1 : 0, moments_on_side ? side_out.Lpad : nullptr};
+        if (moments_on_side) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_moments, 0));
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t i0, seed_off; uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; const double* dv;
         };
-        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, cfg->next0, cfg->Nnext_total, io->seeds, &prep, L, spd_dev, dv};
+        PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, cfg->next0, cfg->Nnext_total, io->seeds, &prep, moments_on_side ? nullptr : L, spd_dev, dv};
         auto hook = [](void* a) -> int {          // GPU work that does not need the alias table runs while the host builds it
             PrepArg* q = (PrepArg*)a;
             if (q->L) {
@@ -662,12 +699,13 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         };
         {
             const int rc = launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host,
-                                           (fast_sel && !uniform_w) ? pfail_early : nullptr);
+                                           (fast_sel && !uniform_w) ? pfail_early : nullptr, false, &alias_deferred);
             if (rc == ABC_INTERNAL_RETRY) return repeat_with_radix();
             ABC_TRY(rc);
         }
         ABC_TRY(launch_perturb(ctx, rng, theta, K, P, io->priors, parent, cfg->next0, Nn, cfg->multivariate,
                                cfg->multivariate ? L : dv, io->next, io->seeds, cfg->Nnext_total, &prep));
+        parent_used = parent; L_used = L; prep_used = prep;
     } else if (cfg->multivariate && io->L) {
         have_spd = true;
         if (theta_stats) ABC_TRY(launch_mvn_from_stats(ctx, theta_stats, P, io->L, spd_dev));
@@ -683,7 +721,21 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
         spd = *pspd;
-        if (ds_fail_dev && pfail_early && *pfail_early) return repeat_with_radix();      // (set 0: no host wait before this one)
+        if (ds_fail_dev && pfail_early && *pfail_early) return repeat_with_radix();      // (no host wait before this one)
+        // the device build of the resampling table did not verify (every rank builds the same table from the same weights, so
+        // every rank lands here alike): this rank's draws and proposals once more, with the table from the host
+        if (alias_deferred && *(volatile int*)(ctx->status_pin + 44) && parent_used) {
+            ctx->alias_dev_fallbacks++;
+            const int mode = ctx->alias_mode;
+            ctx->alias_mode = ABC_ALIAS_HOST;
+            const int rc = launch_resample(ctx, &rng_entry, io->w, K, cfg->next0, Nn, parent_used);
+            ctx->alias_mode = mode;
+            ABC_TRY(rc);
+            prep_used.seeds_done = 1;
+            ABC_TRY(launch_perturb(ctx, &rng_entry, theta, K, P, io->priors, parent_used, cfg->next0, Nn, cfg->multivariate,
+                                   cfg->multivariate ? L_used : dv, io->next, nullptr, cfg->Nnext_total, &prep_used));
+            ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
     return ABC_OK;
