@@ -108,11 +108,19 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
+    # ABC_BENCH_BACKEND=gloo: a dry run of the N > 1 path on a box with ONE GPU (all ranks on cuda:0, the C++ driver's collectives
+    # forwarded to gloo as callbacks -- RCCL does not let two ranks share a device): exercises the sharded code path, not a measurement
+    backend = os.environ.get("ABC_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     cfg = CONFIGS[args.config]
     M, P, A = cfg["M"], cfg["P"], cfg["A"]
@@ -148,8 +156,10 @@ def main():
         # rank 0 broadcasts; if RCCL cannot be initialised from the library, the same C++ driver runs with torch.distributed's
         # (RCCL) collectives handed in as callbacks -- said loudly and recorded in the JSON line
         ctx.set_stream(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
-        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        ok = torch.ones(1, dtype=torch.int32, device="cpu" if backend == "gloo" else dev)
         try:
+            if backend == "gloo":
+                raise RuntimeError("dry run over gloo requested (ABC_BENCH_BACKEND)")
             sharded.attach_rccl(ctx, dev)
         except Exception as e:           # noqa: BLE001 -- any failure of the in-library communicator
             print("bench.py rank %d: in-library RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
@@ -194,7 +204,7 @@ def main():
     stages_all = ctx.timing_read(reset=True)
     ctx.timing_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
