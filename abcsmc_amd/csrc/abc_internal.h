@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/abcsmc_hip.h"
@@ -47,6 +48,7 @@ struct abc_ctx {
     hipEvent_t ev_fork, ev_side, ev_prev;
     hipEvent_t ev_theta, ev_moments;   // the posterior's moments on the side stream: start (rows gathered) and end
     bool side_forked;      // ev_fork of the current generation is recorded (abc_side_fork); cleared when the generation ends
+    bool side_early_waited; // the main stream already waits for everything queued early on the side stream (ev_prev implies ev_side)
     // jump-ahead matrices for taus2 (device), built once
     uint32_t* jump_tab;
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
@@ -82,6 +84,11 @@ struct abc_ctx {
 };
 
 int abc_timing_flush(abc_ctx* ctx);
+// Flags of the events that order the context's two streams: GPU-to-GPU dependencies on one device, so a device-scope release is
+// enough (the default, system scope, also makes the writes visible to the host: more cache maintenance per record)
+inline unsigned abc_xstream_event_flags() {
+    return hipEventDisableTiming | hipEventReleaseToDevice;
+}
 // RAII marker: records an event pair around a stage when timing is on
 struct StageTimer {
     abc_ctx* ctx; int slot;
@@ -234,10 +241,12 @@ int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* v
 int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
                     size_t A, size_t row_test, double* model);
 // sel_fail / sel_fail_pin (fused drivers): the bin selection's give-up flag is stored into the pinned status block by this
-// kernel, and the proposals' give-up counter is snapshotted into its second slot
+// kernel, and the proposals' give-up counter is snapshotted into its second slot.  done: an event bound to the kernel's OWN
+// completion signal (hipExtLaunchKernelGGL's stop event) -- a hipEventRecord behind it is one more packet in the queue, and the
+// next kernel waits for that packet: ~7 us of the main stream's critical path per record (rocprofv3 timeline)
 int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, size_t P,
                        const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt,
-                       const int* sel_fail = nullptr, int* sel_fail_pin = nullptr);
+                       const int* sel_fail = nullptr, int* sel_fail_pin = nullptr, hipEvent_t done = nullptr);
 #define ABC_INTERNAL_RETRY 1      // launch_resample: the caller's abort flag was set when the host looked (not an error code of the ABI)
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
 // K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor

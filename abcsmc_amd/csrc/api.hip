@@ -472,6 +472,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const size_t N = cfg->N, M = cfg->M, P = cfg->P, K = cfg->K, Kp = cfg->Kp, Nn = cfg->Nnext;
     if (!N || !M || K > N) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: bad sizes N=%zu M=%zu K=%zu", N, M, K);
     const size_t ws_entry = ctx->ws_off;              // a failed bin selection (select.hip) repeats the call from here
+    ctx->side_early_waited = false;
     abc_rng rng_entry;
     if (rng) rng_entry = *rng;
     if (!simple && !(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))      // AbcUtil.cpp:428
@@ -502,10 +503,16 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             if (!parent_early) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
         }
     }
+    // The side stream's work (taus2 streams, the previous set's share of the weight stage) depends on nothing this call queues:
+    // it is forked at the call's START -- the record is the first packet of an idle queue, processed while the host prepares the
+    // first launch -- and runs beside the Gram kernel; forked behind that kernel (rounds 2 and 3) the record sat between the
+    // reduce and the fit and cost the critical path ~6 us (rocprofv3 timeline).  Its launches still follow the fit's.
+    static const int fork_late = getenv("ABC_FORK_LATE") ? 1 : 0;
+    ctx->side_forked = false;
+    if (!fork_late) ABC_TRY(abc_side_fork(ctx));
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
-    ctx->side_forked = false;
-    ABC_TRY(abc_side_fork(ctx));             // the side stream's work starts behind the Gram kernel; its launches follow the fit's
+    if (fork_late) ABC_TRY(abc_side_fork(ctx));
     if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
     else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
     if (!simple && cfg->rule == ABC_RULE_WILCOXON)
@@ -542,7 +549,28 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     int* pfail_early = (int*)(ctx->status_pin + 40);
     *pfail_early = 0;
     const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
-    ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early));
+    // The main stream needs what the side stream queued early (the previous set's tiles, the taus2 outputs) only behind the
+    // gather, and those kernels ended long ago: the wait goes IN FRONT of the gather, where the event is certain to have fired
+    // (a wait that still has to be resolved between the gather and the new set's tiles cost ~12 us of the critical path there)
+    static const int wait_late = getenv("ABC_WAIT_LATE") ? 1 : 0;
+    ctx->side_early_waited = false;
+    if (wprev.ready && !wait_late) {
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
+        ctx->side_early_waited = true;                 // (ev_prev was recorded behind ev_side on the same stream)
+    }
+    // (weighted generations hand the gathered rows to the side stream, for the posterior's moments: the event that orders the two
+    // is the gather's own completion signal, not a record behind it)
+    static const int side_moments_on = getenv("ABC_MOMENTS_MAIN") ? 0 : 1;        // A/B switches for measurements
+    static const int ev_marker = getenv("ABC_EV_MARKER") ? 1 : 0;
+    const bool defer_moments = Nn && P <= 64 && K >= 2;
+    const bool moments_side_planned = defer_moments && !uniform_w && side_moments_on && ctx->side && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
+    if (moments_side_planned && !ctx->ev_theta) {
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, abc_xstream_event_flags()));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, abc_xstream_event_flags()));
+    }
+    const bool theta_ev_bound = moments_side_planned && !ev_marker;
+    ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
+                               theta_ev_bound ? ctx->ev_theta : nullptr));
     // A failed bin selection (degenerate distances) leaves placeholder winners: everything downstream of it is repeated with
     // the radix select.  Weighted generations learn of it at the host's wait for the weights (launch_resample's abort flag),
     // before the alias table, the draws and the proposals of the placeholder are queued; set 0 has no host wait before its
@@ -567,7 +595,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // they run in the GPU's idle time behind it (hook below) instead of in front of the pair sums.
     // (set 0 too: nothing in front of the proposals needs them, and up to 16 parameters ONE launch then delivers the moments,
     // the doubled variance, the proposal factor and the perturbation's row-major copy: k_theta_moments)
-    const bool defer_moments = Nn && P <= 64 && K >= 2;
     if (defer_moments) {
     } else if (P <= 64 && K >= 2) {
         StageTimer tm(ctx, ST_GATHER_DV);
@@ -584,8 +611,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool moments_on_side = false;
     // (set 0 has nothing to overlap them with: two cross-stream hand-overs for nothing, measured +35 us)
-    static const int side_moments_on = getenv("ABC_MOMENTS_MAIN") ? 0 : 1;        // A/B switch for measurements
-    if (defer_moments && !uniform_w && side_moments_on && ctx->side && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM) {
+    if (moments_side_planned) {
         if (cfg->multivariate) {
             L_early = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
             if (!L_early) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
@@ -595,11 +621,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         side_out.rows = (double*)abc_ws_alloc(ctx, K * (size_t)PPr * sizeof(double));
         if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
         if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
-        if (!ctx->ev_theta) {
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, hipEventDisableTiming));
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, hipEventDisableTiming));
-        }
-        ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));
+        if (!theta_ev_bound) ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));
         ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_theta, 0));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->side;                        // the launchers below queue on the context's stream
@@ -616,7 +638,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (Kp == 0 || !io->theta_prev) {
         if (!filled_early) ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
     } else {
-        if (wprev.ready) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
+        if (wprev.ready && !ctx->side_early_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
         const double* sumsq = nullptr;       // the normalisation's sum of squares comes out of the weight stage's last kernel
         ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
                                    io->w, &wprev, &sumsq));
@@ -722,6 +744,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                            have_spd ? (const int*)spd_dev : (const int*)nullptr, fail_dev, (const unsigned long long*)ctx->giveups_dev, hdr, pspd,
                            pfail, pgive);
         ABC_HIP(ctx, hipGetLastError());
+        ctx->side_early_waited = false;
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
         spd = *pspd;

@@ -591,8 +591,8 @@ static int launch_seeds(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n,
 int abc_side_fork(abc_ctx* ctx) {
     if (!ctx->side) {
         ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, abc_xstream_event_flags()));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side, abc_xstream_event_flags()));
     }
     ABC_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -628,7 +628,7 @@ int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t 
 int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                            const double* dv_prev, abc_wprev* out) {
     if (!ctx->side_forked) ABC_TRY(abc_side_fork(ctx));
-    if (!ctx->ev_prev) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_prev, hipEventDisableTiming));
+    if (!ctx->ev_prev) ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_prev, abc_xstream_event_flags()));
     ABC_TRY(launch_weights_prev(ctx, P, kn_max, theta_prev, Kp, w_prev, dv_prev, out, ctx->side));
     ABC_HIP(ctx, hipEventRecord(ctx->ev_prev, ctx->side));
     return ABC_OK;
@@ -679,7 +679,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
         abc_rng base = *rng;
         taus2_jump(&base, i0);
         if (raw_ready) {
-            ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+            if (!ctx->side_early_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
         } else {
             StageTimer tm(ctx, ST_RESAMPLE);
             ABC_TRY(taus_stream(ctx, base, n, raw));
@@ -725,7 +725,7 @@ int launch_resample(abc_ctx* ctx, const abc_rng* rng, const double* w, size_t K,
     abc_rng base = *rng;
     taus2_jump(&base, i0);
     if (raw_ready) {
-        if (wait_side) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+        if (wait_side && !ctx->side_early_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
     } else {
         StageTimer tm(ctx, ST_RESAMPLE);
         ABC_TRY(taus_stream(ctx, base, n, raw));

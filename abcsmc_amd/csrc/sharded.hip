@@ -419,6 +419,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, forked
     // behind the Gram kernel
     uint32_t* raw_early = nullptr;
+    ctx->side_early_waited = false;
     ctx->side_forked = false;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
     // ... and so does the previous set's share of the weight stage
@@ -617,8 +618,8 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
         if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         if (!ctx->ev_theta) {
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, hipEventDisableTiming));
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, hipEventDisableTiming));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, abc_xstream_event_flags()));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, abc_xstream_event_flags()));
         }
         ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));
         ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_theta, 0));

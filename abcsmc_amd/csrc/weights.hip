@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "abc_internal.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -93,19 +94,31 @@ __device__ __forceinline__ bool ks_split_on(const WConst* wc) {
     return !(wc->nzero | wc->far) && wc->nfar_i <= wc->lim_i && wc->nfar_j <= KS_MAX_FAR_J;
 }
 
-__global__ void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc, int lim_i) {
-    if (threadIdx.x != 0) return;
-    double C = 1.0; int nz = 0;
+// (one wave: the square roots and divisions of the parameters side by side, then lane 0 alone takes the product and the list of
+// converged parameters in parameter order -- the same operations in the same order as a single thread's loop, which took 34 us)
+__global__ __launch_bounds__(64) void k_wprep(const double* __restrict__ dv_prev, int P, WConst* __restrict__ wc, int lim_i) {
+    __shared__ double fac[64];
+    __shared__ int live[64];
     const int pmax = (P > 64) ? ((P + 63) / 64) * 64 : 64;
-    for (int p = 0; p < pmax; p++) {
-        double sc = 0.0;
+    double C = 1.0; int nz = 0;
+    for (int p0 = 0; p0 < pmax; p0 += 64) {
+        const int p = p0 + (int)threadIdx.x;
+        double sc = 0.0, f = 1.0;
+        int lv = 0;                                  // 0: converged (dv = 0) or padding
         if (p < P) {
             const double dv = dv_prev[p];
-            if (dv != 0.0) { const double sg = sqrt(dv); sc = 1.0 / sg; C *= 1.0 / (sqrt(2.0 * M_PI) * sg); }
-            else wc->zero_idx[nz++] = p;
+            if (dv != 0.0) { const double sg = sqrt(dv); sc = 1.0 / sg; f = 1.0 / (sqrt(2.0 * M_PI) * sg); lv = 1; }
         }
         wc->scale[p] = sc * W_SQRT_LOG2E;
+        fac[threadIdx.x] = f; live[threadIdx.x] = lv;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int q = 0; q < 64 && p0 + q < P; q++) {
+                if (live[q]) C *= fac[q]; else wc->zero_idx[nz++] = p0 + q;
+            }
+        __syncthreads();
     }
+    if (threadIdx.x != 0) return;
     wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0; wc->nfar_i = 0; wc->nfar_j = 0; wc->lim_i = lim_i;
 }
 
@@ -889,13 +902,19 @@ __global__ __launch_bounds__(256) void k_div_norm(double* __restrict__ w, size_t
 int abc_kde_words(abc_ctx* ctx);
 
 int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy, size_t P, const uint64_t* idx,
-                       size_t K, uint64_t idx_base, double* theta, size_t ldt, const int* sel_fail, int* sel_fail_pin) {
+                       size_t K, uint64_t idx_base, double* theta, size_t ldt, const int* sel_fail, int* sel_fail_pin,
+                       hipEvent_t done) {
     const size_t tot = K * P;
-    if (!tot) return ABC_OK;
+    if (!tot) { if (done) ABC_HIP(ctx, hipEventRecord(done, ctx->stream)); return ABC_OK; }
     StageTimer tm(ctx, ST_GATHER_DV);
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Y, n_local, ldy,
-                       (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt, sel_fail, sel_fail_pin,
-                       sel_fail ? ctx->giveups_dev : (unsigned long long*)nullptr);
+    if (done)
+        hipExtLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, nullptr, done, 0, Y, n_local, ldy,
+                              (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt, sel_fail, sel_fail_pin,
+                              sel_fail ? ctx->giveups_dev : (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Y, n_local, ldy,
+                           (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt, sel_fail, sel_fail_pin,
+                           sel_fail ? ctx->giveups_dev : (unsigned long long*)nullptr);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }

@@ -59,20 +59,29 @@ class Generation:
         self.parent = torch.empty(max(Nnext, 1), dtype=i64, device=d)
         self.seeds = torch.empty(max(Nnext, 1), dtype=i64, device=d)
         self.ncomp = C.c_int32(0)
+        self._io_key, self._io, self._args = None, None, None
+        self._call = lib().abc_generation_dev
 
     def run(self, X, Y, obs, priors_dev, rng, theta_prev=None, w_prev=None, dv_prev=None):
         """X: (M, N), Y: (P, N), obs: (M,), all float64 on self.device; rng: _lib.Rng (advanced)."""
         cfg = self.cfg
-        assert X.shape == (cfg.M, cfg.N) and Y.shape == (cfg.P, cfg.N) and X.is_contiguous() and Y.is_contiguous()
-        io = GenerationIO()
-        io.X, io.Y, io.obs, io.priors = X.data_ptr(), Y.data_ptr(), obs.data_ptr(), priors_dev.data_ptr()
-        if theta_prev is not None and cfg.Kp:
-            assert theta_prev.shape == (cfg.P, cfg.Kp)
-            io.theta_prev, io.w_prev, io.dv_prev = theta_prev.data_ptr(), w_prev.data_ptr(), dv_prev.data_ptr()
-        io.idx, io.dist, io.theta = self.idx.data_ptr(), self.dist.data_ptr(), self.theta.data_ptr()
-        io.w, io.dv, io.L = self.w.data_ptr(), self.dv.data_ptr(), self.L.data_ptr()
-        io.next, io.parent, io.seeds = self.next.data_ptr(), self.parent.data_ptr(), self.seeds.data_ptr()
-        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        self.ctx.check(lib().abc_generation_dev(self.ctx.handle, C.addressof(cfg), C.addressof(io),
-                                                C.addressof(rng), C.addressof(self.ncomp)))
+        weighted = theta_prev is not None and cfg.Kp
+        key = (X.data_ptr(), Y.data_ptr(), obs.data_ptr(), priors_dev.data_ptr(),
+               theta_prev.data_ptr() if weighted else 0, w_prev.data_ptr() if weighted else 0,
+               dv_prev.data_ptr() if weighted else 0)
+        if key != self._io_key:           # (the argument block of the C call is rebuilt only when a buffer moved)
+            assert X.shape == (cfg.M, cfg.N) and Y.shape == (cfg.P, cfg.N) and X.is_contiguous() and Y.is_contiguous()
+            io = GenerationIO()
+            io.X, io.Y, io.obs, io.priors = key[0], key[1], key[2], key[3]
+            if weighted:
+                assert theta_prev.shape == (cfg.P, cfg.Kp)
+                io.theta_prev, io.w_prev, io.dv_prev = key[4], key[5], key[6]
+            io.idx, io.dist, io.theta = self.idx.data_ptr(), self.dist.data_ptr(), self.theta.data_ptr()
+            io.w, io.dv, io.L = self.w.data_ptr(), self.dv.data_ptr(), self.L.data_ptr()
+            io.next, io.parent, io.seeds = self.next.data_ptr(), self.parent.data_ptr(), self.seeds.data_ptr()
+            self._io, self._io_key = io, key
+            self._args = (self.ctx.handle, C.addressof(cfg), C.addressof(io), None, C.addressof(self.ncomp))
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)      # (a no-op unless the stream changed)
+        a = self._args
+        self.ctx.check(self._call(a[0], a[1], a[2], C.addressof(rng), a[4]))
         return self
