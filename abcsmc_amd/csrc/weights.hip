@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_kde_gen(const double* __restrict__ a, s
 //   below 2^-14 an f16 SUBNORMAL, which v_mfma_f32_32x32x16_f16 takes at its value: scripts/mfma_f16_probe.hip),
 //   r2 = v - h0 - h1, |r2| <= 2^-19, entering as (h0 2^-11).(r2' 2^11) -- both factors f16-representable, the product unscaled,
 // and the dot product as the sum of the limb products, which the MFMA evaluates with the parameter index as its K
-// dimension (P <= 16: one chunk; P <= 32: two), 32 previous x 32 new particles per instruction.  One f32 accumulator, in this order:
+// dimension (P <= 16: one chunk; P <= 32: two; P <= 64: four), 32 previous x 32 new particles per instruction.  One f32 accumulator, in this order:
 //   X = h0.h0' - hbTop_j          every term a multiple of 2^-14, every partial sum below 2^10: EXACT in f32 whatever the
 //                                 order of accumulation (bound: KS_NORM2 below; probe: 0 inexact sums of 102400)
 //   - n                           n = floor(max X) of the 16 values a lane owns: still exact, and now small for the terms that matter
@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
             kz_reference(Z0, lane, n0, BN);
             kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
         }
+        if constexpr (NCH < 4) {
         for (unsigned t = t0; t < t1; t++) {
             uint4 An[OPB];
             const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass re-reads its own tile (no branch); unused
@@ -772,6 +773,32 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
             kz_slots<NCH, 0>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
             for (int q2 = 0; q2 < OPB; q2++) A[q2] = An[q2];
+        }
+        } else {
+        // 33..64 parameters: the two operand sets of the previous tiles (17 x 16 bytes per lane each) trade places every pass
+        // instead of being copied -- 68 register moves per 2048 pairs otherwise, on top of the accumulation-register traffic of a
+        // kernel that needs more than 256 registers (one wave per SIMD; the compiler parks operands in accumulation registers)
+        uint4 An[OPB];
+        for (unsigned t = t0; t < t1; t += 2) {
+            {
+                const unsigned tn = (t + 1 < t1) ? t + 1 : t;
+#pragma unroll
+                for (int q = 0; q < OPB; q++) An[q] = bt[((size_t)tn * OPB + q) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            KsRef q;
+            kz_slots<NCH, 0>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
+            kz_slots<NCH, 0>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
+            if (t + 1 >= t1) break;                                                   // (wave-uniform)
+            {
+                const unsigned tn = (t + 2 < t1) ? t + 2 : t + 1;
+#pragma unroll
+                for (int q2 = 0; q2 < OPB; q2++) A[q2] = bt[((size_t)tn * OPB + q2) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kz_slots<NCH, 0>(An, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);     // matrix: (t+1, columns 1); vector: (t+1, columns 0)
+            kz_slots<NCH, 0>(A, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);      // matrix: (t+2, columns 0); vector: (t+1, columns 1)
+        }
         }
     }
     {
@@ -945,9 +972,9 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     if (P > 64) PP = (int)((P + 63) / 64 * 64);
-    const int NCH = (P <= 16) ? 1 : 2;
+    const int NCH = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
-    const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
+    const bool split = (PP >= 8 && P <= 64 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32;
     const int opb = NCH * KS_NL + 1;
     WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
@@ -971,8 +998,11 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
         if (NCH == 1)
             hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((rbp / 32 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
                                w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
-        else
+        else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((rbp / 16 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+        else
+            hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((rbp / 8 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
                                w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
@@ -1005,10 +1035,11 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (slices > Kp / 64) slices = Kp / 64;
     if (slices < 1) slices = 1;
     if (slices > 1024) slices = 1024;
-    // split-operand kernel: 5 <= P <= 32 parameters (padded width 8, 16 or 32; below that the fp64 body is as short), unless the caller asked for fp64
-    const int NCH = (P <= 16) ? 1 : 2;
+    // split-operand kernel: 5 <= P <= 64 parameters (padded width 8, 16, 32 or 64: one, two or four 16-parameter chunks; below
+    // that the fp64 body is as short), unless the caller asked for fp64
+    const int NCH = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
-    const bool split = (PP >= 8 && P <= 32 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
+    const bool split = (PP >= 8 && P <= 64 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
     const int opa = NCH * KS_NL;
     if (split) {
@@ -1055,8 +1086,11 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         if (NCH == 1)
             hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((ra / 32 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
                                wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
-        else
+        else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((ra / 16 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
+        else
+            hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((ra / 8 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
                                wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
@@ -1085,11 +1119,15 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         StageTimer tk(ctx, ST_KDE);
         if (split) {
             // three waves per SIMD at 16 parameters (129 VGPRs; four, with two spills: no faster), two at 32 (192)
+            // ... one at 64 (more than 256 registers: the two resident column operand sets alone are 128)
             if (NCH == 1)
                 hipLaunchKernelGGL((k_kde_split<1, 3>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
-            else
+            else if (NCH == 2)
                 hipLaunchKernelGGL((k_kde_split<2, 2>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+            else
+                hipLaunchKernelGGL((k_kde_split<4, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
         }
         if (PP > 64)
@@ -1102,7 +1140,8 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             switch (PP) {
                 case 8: LAUNCH_FIX(8); break;
                 case 16: LAUNCH_FIX(16); break;
-                default: LAUNCH_FIX(32); break;
+                case 32: LAUNCH_FIX(32); break;
+                default: LAUNCH_FIX(64); break;
             }
 #undef LAUNCH_FIX
         } else
