@@ -725,7 +725,49 @@ __device__ __forceinline__ void kz_slots(const uint4* An, const uint4* Bn, const
     }
 }
 
-template <int NCH, int WPS>
+// The same step of a wave in SIXTEEN slots of one exponential: with few waves per SIMD (two at 32 parameters, one at 64) the
+// instruction stream of a wave is what fills the matrix pipe -- a wave issues in order, so vector work placed behind a run of
+// dependent MFMAs does not overlap with them; here at most ceil(steps / slots) MFMAs stand between two exponentials.  The exact
+// steps go first (one per slot), the reference one slot behind them, the remaining steps evenly over the slots that are left.
+template <int NCH, int RO, int R>
+__device__ __forceinline__ void kz_fine(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
+                                        const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
+    if constexpr (R < 16) {
+        constexpr int NS = kz_nsteps<NCH>(), NA = 1 + NCH, R0 = NA + RO, M = NS - NA, L = 16 - R0;
+        if constexpr (R < NA) kz_mfma_range<NCH, R, R + 1>(An, Bn, NB, BN, Zn);
+        if constexpr (R == R0) kz_reference(Zn, lane, nn, BN);
+        if constexpr (R >= R0) {
+            constexpr int r = R - R0;
+            constexpr int s0 = NA + (r * M) / L, s1 = NA + ((r + 1) * M) / L;
+            if constexpr (r > 0) asm volatile("" : "+v"(Zn));
+            kz_mfma_range<NCH, s0, s1>(An, Bn, NB, BN, Zn);
+        }
+        {
+            const float e = __builtin_amdgcn_exp2f(Zc[R]);
+            float& p = (R & 3) == 0 ? q.p0 : (R & 3) == 1 ? q.p1 : (R & 3) == 2 ? q.p2 : q.p3;
+            if (R < 4) p = e; else p += e;
+        }
+        if constexpr (R == 15) {
+            float t = q.p0 + q.p1;
+            asm volatile("" : "+v"(t));
+            t += q.p2 + q.p3;
+            s += ldexp((double)t, nc - hsub);
+            asm volatile("" : "+v"(s));
+        } else {
+            asm volatile("" : "+v"(q.p0), "+v"(q.p1), "+v"(q.p2), "+v"(q.p3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        kz_fine<NCH, RO, R + 1>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
+    }
+}
+template <int NCH, int FINE>
+__device__ __forceinline__ void kz_step(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
+                                        const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
+    if constexpr (FINE > 0) kz_fine<NCH, FINE, 0>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
+    else kz_slots<NCH, 0>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
+}
+
+template <int NCH, int WPS, bool PING = (NCH >= 4), int FINE = 0>
 __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict__ at, size_t kn,
                                                       const uint4* __restrict__ bt, unsigned nbt,
                                                       const WConst* __restrict__ wc, const int* __restrict__ ha_int,
@@ -761,7 +803,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
             kz_reference(Z0, lane, n0, BN);
             kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
         }
-        if constexpr (NCH < 4) {
+        if constexpr (!PING) {
         for (unsigned t = t0; t < t1; t++) {
             uint4 An[OPB];
             const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass re-reads its own tile (no branch); unused
@@ -769,14 +811,14 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
             for (int q = 0; q < OPB; q++) An[q] = bt[((size_t)tn * OPB + q) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
             KsRef q;
-            kz_slots<NCH, 0>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
-            kz_slots<NCH, 0>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
+            kz_step<NCH, FINE>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
+            kz_step<NCH, FINE>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
             for (int q2 = 0; q2 < OPB; q2++) A[q2] = An[q2];
         }
         } else {
         // 33..64 parameters: the two operand sets of the previous tiles (17 x 16 bytes per lane each) trade places every pass
-        // instead of being copied -- 68 register moves per 2048 pairs otherwise, on top of the accumulation-register traffic of a
+        // instead of being copied (at 16 and 32 parameters the same loop was measured 1-3 % SLOWER than the copying one: PING stays off there) -- 68 register moves per 2048 pairs otherwise, on top of the accumulation-register traffic of a
         // kernel that needs more than 256 registers (one wave per SIMD; the compiler parks operands in accumulation registers)
         uint4 An[OPB];
         for (unsigned t = t0; t < t1; t += 2) {
@@ -787,8 +829,8 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
             }
             __builtin_amdgcn_sched_barrier(0);
             KsRef q;
-            kz_slots<NCH, 0>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
-            kz_slots<NCH, 0>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
+            kz_step<NCH, FINE>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
+            kz_step<NCH, FINE>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
             if (t + 1 >= t1) break;                                                   // (wave-uniform)
             {
                 const unsigned tn = (t + 2 < t1) ? t + 2 : t + 1;
@@ -796,8 +838,8 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
                 for (int q2 = 0; q2 < OPB; q2++) A[q2] = bt[((size_t)tn * OPB + q2) * 64 + lane];
             }
             __builtin_amdgcn_sched_barrier(0);
-            kz_slots<NCH, 0>(An, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);     // matrix: (t+1, columns 1); vector: (t+1, columns 0)
-            kz_slots<NCH, 0>(A, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);      // matrix: (t+2, columns 0); vector: (t+1, columns 1)
+            kz_step<NCH, FINE>(An, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);     // matrix: (t+1, columns 1); vector: (t+1, columns 0)
+            kz_step<NCH, FINE>(A, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);      // matrix: (t+2, columns 0); vector: (t+1, columns 1)
         }
         }
     }
@@ -1120,8 +1162,13 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         if (split) {
             // three waves per SIMD at 16 parameters (129 VGPRs; four, with two spills: no faster), two at 32 (192)
             // ... one at 64 (more than 256 registers: the two resident column operand sets alone are 128)
+            // (16 parameters: the sixteen-slot interleave, reference one slot behind the exact steps: 2.244 -> 2.220 ms per 1e10 pairs,
+            // and ON TOP of it the operand sets trading places instead of being copied: -> 2.13-2.17 ms (without the finer interleave
+            // the same loop was 2 % slower than the copying one, rounds 2 and 3); at 32 parameters either change and both together are
+            // 0.7-2 % slower than the eight-slot copying loop, at 64 -- one wave per SIMD -- the finer interleave costs 50 %: they keep
+            // kz_slots; four waves per SIMD, the reference two slots behind: +0.5 %)
             if (NCH == 1)
-                hipLaunchKernelGGL((k_kde_split<1, 3>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL((k_kde_split<1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
             else if (NCH == 2)
                 hipLaunchKernelGGL((k_kde_split<2, 2>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
