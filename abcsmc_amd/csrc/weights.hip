@@ -520,12 +520,12 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
             unsigned pc[6];
             unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
             ks_pieces(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
-            // K-slots 6,7 = 1 for the rows an MFMA result holds in its lanes 0..31 (bit 2 of the row clear), 8,9 = 1 for the others:
-            // against a B operand whose slots 6,7 / 8,9 carry the pieces of -n, the lane's own batch reference is subtracted from
-            // exactly its rows (k_kde_split)
-            const unsigned ones = KS_ONE | (KS_ONE << 16);
+            // K-slots 6,7 = -1 for the rows an MFMA result holds in its lanes 0..31 (bit 2 of the row clear), 14,15 = -1 for the others:
+            // against a B operand whose slots 6,7 / 14,15 carry the pieces of n -- the LAST four bytes of every lane's sixteen, so the
+            // kernel builds that operand without a lane select --, the lane's own batch reference is subtracted from exactly its rows
+            const unsigned ones = KS_MONE | (KS_MONE << 16);            // (-1: the kernel hands over +n, not -n: one negation less per batch)
             *(uint4*)(ob + r32 * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), (r32 & 4) ? 0u : ones);
-            *(uint4*)(ob + (32 + r32) * 8) = make_uint4((r32 & 4) ? ones : 0u, 0u, 0u, 0u);
+            *(uint4*)(ob + (32 + r32) * 8) = make_uint4(0u, 0u, 0u, (r32 & 4) ? ones : 0u);
         } else {
             const double ha = valid ? 0.5 * nrow : 0.0, hi = floor(ha);          // 0 for a far / padded row
             ha_int[r] = (int)hi;
@@ -629,9 +629,9 @@ __device__ __forceinline__ float ks_max3(float a, float b, float c) {
 struct KsRef { float p0, p1, p2, p3; };        // the four running f32 sums of a batch
 // ---- one accumulator per batch ----------------------------------------------------------------------------------------------
 // Z = X - n + Y in ONE f32 accumulator.  The chain starts with the exact part X (norm top, h0.h0'); the vector pipe takes
-// n = floor(max X) over the 16 values a lane owns of the 32 x 32 block (8 v_max3_f32) and hands -n back to the matrix pipe as
-// the B operand of one more bf16 step -- its two bf16 pieces in K-slots 6,7 of lanes 0..31 and 8,9 of lanes 32..63, against the
-// ones k_wrows put in the previous set's norm operand, so each lane's n lands on exactly the rows that lane holds -- which is
+// n = floor(max X) over the 16 values a lane owns of the 32 x 32 block (8 v_max3_f32) and hands n back to the matrix pipe as
+// the B operand of one more bf16 step -- its two bf16 pieces in K-slots 6,7 of lanes 0..31 and 14,15 of lanes 32..63, against the
+// -1 entries k_wrows put in the previous set's norm operand, so each lane's -n lands on exactly the rows that lane holds -- which is
 // still exact (multiples of 2^-14 below 2^11); then -hbLow and the five small products follow into the SAME accumulator, which
 // by then is small (< 1.3 for the terms that carry the sum), so their roundings are 2^-25 |Z| each.  The vector pipe is left with
 // v_exp_f32 (measured on gfx950 over every float of [-0.3, 1.3], scripts/exp2_hw_accuracy.hip: max 8.2e-8, rms 2.6e-8 relative)
@@ -673,18 +673,25 @@ __device__ __forceinline__ void kz_mfma_range(const uint4* A, const uint4* B, co
 // n = floor(max of the lane's 16 values) and the B operand that subtracts it (see above); |n| < 2048: two bf16 pieces
 __device__ __forceinline__ void kz_reference(const f32x16& Z, unsigned lane, int& n, uint4& BN) {
     // The first read of the freshly written accumulator is an instruction the compiler knows (it places the wait states a VALU
-    // read of an MFMA result needs; it does not look inside inline assembly), the v_max3_f32 tree follows behind a barrier.
-    const float f01 = __builtin_fmaxf(Z[0], Z[1]);
+    // read of an MFMA result needs; it does not look inside inline assembly): ONE v_max_f32 of Z[0] with itself (fmaxf of two
+    // accumulator values is three instructions: each input is quieted first); the v_max3_f32 tree follows.
+    const float f0 = __builtin_canonicalizef(Z[0]);
     __builtin_amdgcn_sched_barrier(0);
-    const float m0 = ks_max3(f01, Z[2], Z[3]), m1 = ks_max3(Z[4], Z[5], Z[6]), m2 = ks_max3(Z[7], Z[8], Z[9]),
-                m3 = ks_max3(Z[10], Z[11], Z[12]), m4 = ks_max3(Z[13], Z[14], Z[15]);
-    const float m = ks_max3(ks_max3(m0, m1, m2), m3, m4);
+    const float m0 = ks_max3(f0, Z[1], Z[2]), m1 = ks_max3(Z[3], Z[4], Z[5]), m2 = ks_max3(Z[6], Z[7], Z[8]),
+                m3 = ks_max3(Z[9], Z[10], Z[11]), m4 = ks_max3(Z[12], Z[13], Z[14]);
+    const float ma = ks_max3(m0, m1, m2), mb = ks_max3(m3, m4, Z[15]);
+    const float m = ks_max3(ma, mb, mb);
     const float nf = __builtin_floorf(m);
     n = (int)nf;
-    const unsigned u = __float_as_uint(nf), t1 = u & 0xffff0000u;                 // leading eight bits: a bf16
-    const float r = nf - __uint_as_float(t1);                                      // at most three more bits: a bf16 too
-    const unsigned pack = ((t1 ^ 0x80000000u) >> 16) | ((__float_as_uint(r) ^ 0x80000000u) & 0xffff0000u);   // (-t1, -r)
-    BN = (lane < 32) ? make_uint4(0u, 0u, 0u, pack) : make_uint4(pack, 0u, 0u, 0u);
+    // n = p1 + p2, two bf16 pieces against the -1 entries of the previous set's norm operand: p1 = n rounded to bf16 (eight
+    // significant bits), p2 = n - p1 (|n| < 2048: at most three bits, exact); v_cvt_pk_bf16_f32 packs both
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const bf16x2_ h1 = __builtin_convertvector((f32x2_){nf, 0.f}, bf16x2_);
+    const float p1 = __uint_as_float(__builtin_bit_cast(unsigned, h1) << 16);
+    const bf16x2_ pk = __builtin_convertvector((f32x2_){nf, nf - p1}, bf16x2_);
+    (void)lane;
+    BN.w = __builtin_bit_cast(unsigned, pk);      // K-slots 6,7 (lanes 0..31) / 14,15 (lanes 32..63), the rest stays zero: see k_wrows
 }
 // One step of a wave: the vector work of the finished batch (Zc, reference nc) interleaved with the whole chain of the next one
 // (An x Bn -> Zn, reference nn).  Eight slots of two exponentials; the next batch's exact part goes first, its reference is taken
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
         for (int q = 0; q < OPB; q++) A[q] = bt[((size_t)t0 * OPB + q) * 64 + lane];
         f32x16 Z0, Z1;
         int n0 = 0, n1 = 0;
-        uint4 BN;
+        uint4 BN = make_uint4(0u, 0u, 0u, 0u);                   // (kz_reference only ever writes its last component)
         {   // (t0, columns 0): the whole chain up front
             constexpr int NA = 1 + NCH;
             kz_mfma_range<NCH, 0, NA>(A, B0, NB, BN, Z0);
