@@ -227,7 +227,7 @@ def main():
     # How it is done: k_kde_split takes the pair dot products as exact f16 limb products on the matrix
     # pipe -- 6 ceil(P/16) + 3 v_mfma_f32_32x32x16_{f16,bf16} per 32 x 32 pairs = 32 ISSUED flop per pair and MFMA
     # (`mfma_issue_frac`) -- and 2 vector instructions per pair (v_exp_f32 [8 issue cycles], f32 add) + 18 per batch of 16
-    # pairs = 4.1 issue slots per pair.  k_kde (fp64 fallback): 1 add + PP FMAs + 13 for 2^x per pair, no matrix work.
+    # pairs = 4.3 issue slots per pair.  k_kde (fp64 fallback): 1 add + PP FMAs + 13 for 2^x per pair, no matrix work.
     kde_bracket_ms, kde_launches = per_launch_ms("k_kde") if Kp else (0.0, 0)
     kde_ms = max(kde_bracket_ms - event_overhead_ms, 0.0)
     pairs = float(split(K, world, rank)[1]) * Kp
@@ -241,7 +241,9 @@ def main():
     if which == _lib.KDE_RAN_SPLIT:
         mfma_per_block = 6 * ((P + 15) // 16) + 3
         flops_issued = pairs * mfma_per_block * 32.0   # 32 x 32 x 16 x 2 flop per MFMA over 1024 pairs
-        slots_per_pair = 4.125
+        # vector issue slots of 4 cycles per pair besides the MFMAs, counted in the kernel's ISA at 16 parameters: 52.5 vector
+        # instructions per 1024 pairs (16 v_exp_f32 at two slots each, 15 f32 adds, 8 v_max3_f32, 13.5 others) = 68.5 slots / 16
+        slots_per_pair = 4.28
         issued_tf = flops_issued / (kde_ms * 1e-3) / 1e12 if kde_ms > 0 else 0.0
         roofline = {"kernel": "k_kde_split", "bound": "mfma", "achieved": round(alg_tf, 1), "peak": MFMA_F16_PEAK_TF,
                     "unit": "TFLOP/s", "frac": round(alg_tf / MFMA_F16_PEAK_TF, 4),
