@@ -413,14 +413,16 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     ABC_TRY(abc_pin_reserve(ctx, (size_t)(2 * W) * sizeof(long long) + 64));
 
     // ---- 1-2: sufficient statistics, replicated model fit -----------------------------------------------------------------
+    // (the side stream is forked at the call's start, as in the single-GPU driver: a record between two kernels of the main
+    // stream costs its critical path 6-7 us, the first packet of an idle queue nothing)
+    ctx->side_early_waited = false;
+    ctx->side_forked = false;
+    ABC_TRY(abc_side_fork(ctx));
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
     ABC_TRY(comm_broadcast(ctx, stats + SL.off_shift, SL.C16 * 8, 0));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
-    // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream, forked
-    // behind the Gram kernel
+    // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream
     uint32_t* raw_early = nullptr;
-    ctx->side_early_waited = false;
-    ctx->side_forked = false;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
     // ... and so does the previous set's share of the weight stage
     abc_wprev wprev;

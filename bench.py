@@ -45,6 +45,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0     # same guide: dense f16 / bf16 MFMA peak (v_mfma_f32_32x32x16_f16: 32 cycles per SIMD at 2.4 GHz)
+MFMA_SUSTAINED_TF = 1247.0    # same guide, 'DVFS give-back' (1): a bare bf16 MFMA loop on RANDOM operands (the chip holds 1.90-1.95 GHz)
 FP64_VALU_PEAK_TF = 78.6      # same guide: fp64 vector peak
 
 
@@ -252,6 +253,10 @@ def main():
                     "flops_issued_mfma": flops_issued, "achieved_issued_mfma": round(issued_tf, 1),
                     "mfma_issue_frac": round(issued_tf / MFMA_F16_PEAK_TF, 4),
                     "issued_per_algorithmic_flop": round(flops_issued / flops_alg, 2),
+                    # what bare bf16 MFMA loops sustain on random operands on this chip (the clock gives way under matrix load:
+                    # /opt/skills/guides/MI355X_MICROARCH.md, 'DVFS give-back' item 1): the practical ceiling of issued matrix work
+                    "mfma_sustained_random_data_TFLOPs": MFMA_SUSTAINED_TF,
+                    "mfma_issue_vs_sustained": round(issued_tf / MFMA_SUSTAINED_TF, 4),
                     "algorithmic_vs_fp64_vector_peak": round(alg_tf / FP64_VALU_PEAK_TF, 3),
                     "mfma_32x32x16_per_1024_pairs": mfma_per_block,
                     "pairs_per_launch": pairs, "pairs_per_s": pairs / (kde_ms * 1e-3) if kde_ms > 0 else 0.0,
