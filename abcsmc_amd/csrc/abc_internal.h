@@ -346,6 +346,7 @@ constexpr size_t ABC_ALIAS_DEV_MAX_K = (size_t)2 << 20;
 // below this the ten launches of the device build (~90 us, latency-bound) lose to the host's round trip (K = 1e4: 26 us of host
 // work + two PCIe hops); measured break-even between 1e4 and 1e5
 constexpr size_t ABC_ALIAS_DEV_MIN_K = 20000;
+constexpr size_t ABC_ALIAS_DEV_SMALL_K = 300000;   // up to here the build runs with two elements per thread, beyond with four (alias_dev.hip)
 
 // arena bound shared by api.hip and sharded.hip
 size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext);

@@ -35,10 +35,20 @@ typedef __int128 i128;
 typedef unsigned __int128 u128;
 typedef unsigned long long u64;
 
+// Elements per thread: this file is compiled TWICE (Makefile: alias_dev.o with four, alias_dev_i2.o with -DABC_AL_I=2).  Every
+// kernel of the build is latency-bound on a nearly empty chip, a thread's serial work (compositions of 128-bit step maps) grows
+// with its elements and every work-group re-scans the aggregates of all work-groups in its prologue: two elements per thread win
+// up to a few hundred thousand entries (0.099 -> 0.086 ms at 1e5), four beyond (0.225 against 0.278 ms at 1e6; one: 0.090 / 0.45).
+#ifndef ABC_AL_I
+#define ABC_AL_I 4
+#endif
+#define ABC_AL_CAT2(a, b) a##b
+#define ABC_AL_CAT(a, b) ABC_AL_CAT2(a, b)
+#define ABC_AL_FN(name) ABC_AL_CAT(name##_i, ABC_AL_I)
 constexpr int AL_T = 256;                 // threads per work-group
-constexpr int AL_I = 4;                   // consecutive elements per thread
+constexpr int AL_I = ABC_AL_I;            // consecutive elements per thread
 constexpr int AL_B = AL_T * AL_I;         // elements per work-group
-constexpr int AL_MAXBLK = 4096;           // work-groups whose aggregates one work-group re-scans in its prologue (K <= 4.19e6)
+constexpr int AL_MAXBLK = 8192;           // work-groups whose aggregates one work-group re-scans in its prologue (K <= 4.19e6 / 2.1e6)
 constexpr int AL_SUM_BITS = 44;           // the total's grid lies this many bits below its ulp
 
 struct RMap { i128 t0, t1, b; int k; int pad_[3]; };      // 64 bytes
@@ -625,15 +635,31 @@ __global__ void k_al_flag(const AlHead* __restrict__ head, int* __restrict__ fai
 
 }  // namespace
 
-size_t abc_alias_dev_need(size_t K) {
-    const size_t nblk = (K + AL_B - 1) / AL_B + 1, nblk2 = (2 * K + AL_B - 1) / AL_B + 1;
+#if ABC_AL_I == 4
+int launch_alias_build_dev_i2(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
+                              const int** verdict_src);
+int launch_alias_build_dev_i4(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
+                              const int** verdict_src);
+static size_t alias_small_k() {             // tables up to this size: two elements per thread
+    static const size_t k = getenv("ABC_ALIAS_SMALL_K") ? (size_t)atoll(getenv("ABC_ALIAS_SMALL_K")) : ABC_ALIAS_DEV_SMALL_K;
+    return k;
+}
+size_t abc_alias_dev_need(size_t K) {       // (the larger of the two variants' needs: the smaller work-groups')
+    constexpr size_t B = AL_T * 2;
+    const size_t nblk = (K + B - 1) / B + 1, nblk2 = (2 * K + B - 1) / B + 1;
     return K * (8 + 4 + 4 + 8 + 16 + 16 + 16 + 4 + 4 + 64) + nblk * (8 + 4 + 64 + 64) + nblk2 * 64 * (AL_T + 1) + sizeof(AlHead) + 64 * 256;
 }
+int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
+                           const int** verdict_src) {
+    if (K <= alias_small_k()) return launch_alias_build_dev_i2(ctx, w, K, F, A, fail_dev, fail_pin, verdict_src);
+    return launch_alias_build_dev_i4(ctx, w, K, F, A, fail_dev, fail_pin, verdict_src);
+}
+#endif
 
 // F (K doubles, cut-off fractions WITHOUT the KNUTH_CONVENTION map, as alias_preproc(..., knuth = false)) and A (K uint32) on the
 // device; *fail_dev (and *fail_pin, optional, pinned) = 1 when the table must not be used (the caller builds it on the host)
-int launch_alias_build_dev(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
-                           const int** verdict_src) {
+int ABC_AL_FN(launch_alias_build_dev)(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
+                                      const int** verdict_src) {
     if (K == 0 || K > (size_t)AL_MAXBLK * AL_B / 2) ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "device alias build: K = %zu", K);
     const int nblk = (int)((K + AL_B - 1) / AL_B), nblk2 = (int)((2 * K + AL_B - 1) / AL_B);
     AlHead* head = (AlHead*)abc_ws_alloc(ctx, sizeof(AlHead));
