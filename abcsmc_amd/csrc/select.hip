@@ -279,9 +279,17 @@ __global__ __launch_bounds__(256) void k_bs_hist(const double* __restrict__ dist
     __syncthreads();
     const unsigned long long lo = bs->lo, hi = bs->hi;
     const int shift = bs->shift;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned long long k = key_of(dist[i]);
-        if (k <= hi) atomicAdd(&lh[bs_bin(k, lo, shift)], 1u);
+    // eight keys in flight per thread (a load directly in front of the LDS atomic that depends on it is one memory latency per key)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 8 * stride) {
+        double d[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const size_t i = i0 + u * stride; d[u] = dist[i < n ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned long long k = key_of(d[u]);
+            if (i0 + u * stride < n && k <= hi) atomicAdd(&lh[bs_bin(k, lo, shift)], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < BS_NB; i += 256) {
