@@ -16,7 +16,9 @@ SHAPES = {"small": "1500,12,5,4,500,300,1000", "wx": "2100,10,3,6,400,300,900", 
           # large enough for the gathered-sample selection of the C++ driver (N / W >= 4096): 2 x 40000 rows, 8000 kept
           "big": "40000,32,16,8,8000,3000,20000", "big0": "40000,32,16,8,8000,0,20000",
           # ... and for the resampling table to be built on the device (from 20000 entries) on every rank
-          "huge": "120000,32,16,8,24000,1000,20000"}
+          "huge": "120000,32,16,8,24000,1000,20000",
+          # 40 parameters: each rank's row slice of the pair sums on the four-chunk split-operand kernel (33..64 parameters)
+          "p40": "1600,48,40,6,450,380,1100"}
 
 
 def _launch(backend, tmp_path, port, shape="small", rule="press", data="plain"):
@@ -50,7 +52,7 @@ def test_sharded_world2_gloo_hip(tmp_path, shape, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,port", [("small", 29616), ("config4", 29617), ("config5", 29618)])
+@pytest.mark.parametrize("shape,port", [("small", 29616), ("config4", 29617), ("config5", 29618), ("p40", 29619)])
 def test_sharded_world2_cabi_driver(tmp_path, shape, port):
     """abc_generation_sharded_dev (the C++ driver behind the C ABI) on two ranks sharing cuda:0, its collectives forwarded to
     gloo through abc_comm_init_callbacks: the same checks against the single-process oracle as the Python driver"""
