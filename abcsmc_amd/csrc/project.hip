@@ -8,6 +8,8 @@
 // The operation order is FIXED and shared with the oracle (orc_project_distance): for each
 // metric m ascending, z = (x - mean)/sd (true division), s_k = fma(z, R[m,k], s_k); then
 // d2 = fma(s_k - o_k, s_k - o_k, d2) for k ascending; dist = sqrt(d2).  HBM-bound: 8*M B/particle.
+#include <stdlib.h>
+
 #include "abc_internal.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -147,6 +149,106 @@ __global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restr
     }
 }
 
+// 17..32 components (two 16-component tiles) on the fp64 MATRIX pipe.  v_mfma_f64_16x16x4_f64 chained through its accumulator IS the ascending fma chain
+// s = fma(z_m, R[m,k], s), bit for bit (scripts/mfma_f64_probe.hip: 0 of 51200 results differ over K = 128, mixed magnitudes), so the
+// scores -- and with them the distances and the ranking -- keep the bits of the vector kernels and of the oracle.  A wave takes 64
+// particles as four groups of 16 and 4 metrics per step: lane (r, q) z-scores metric 4j + q of particle 16g + r (the A operand: one
+// true division per lane and group, where the vector kernel divides twice per metric and lane), reads loading R[4j + q, 16t + r] from
+// LDS (the B operand: one 8-byte read per lane and tile, where the vector kernel needs a broadcast 16-byte read per two fmas -- at 32
+// components that LDS traffic, not the fp64 rate, bound it: 0.38 ms at N = 1e6 x 128 metrics), 4 x KT MFMAs per step.  Epilogue: the scores
+// go through LDS (over the loadings, which nobody needs any more) so that every lane holds one particle's components in order
+// for the distance's own fma chain.
+typedef double pd4 __attribute__((ext_vector_type(4)));
+// (n: an EVEN number of rows, 16-byte aligned columns: lane (r, q) loads the row pair 32 h + 2 r, + 1 of metric 4 j + q with one
+// 16-byte load -- 256 contiguous bytes per 16 lanes -- and feeds group 2 h with the even row, group 2 h + 1 with the odd one;
+// the loads run PF steps ahead of the step that consumes them)
+template <int KT>
+__global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__ X, size_t n, size_t ldx, int M,
+                                                      const double* __restrict__ mean, const double* __restrict__ sd,
+                                                      const double* __restrict__ model, size_t off_R, size_t off_oscore,
+                                                      double* __restrict__ dist, int lds_main /* doubles in front of the observed scores */) {
+    constexpr int KC = 16 * KT, SROW = KC + 1, PF = 8;
+    extern __shared__ double lds[];
+    const int M4 = (M + 3) & ~3;
+    double* const Rl = lds;                              // M4 x KC, rows beyond M zero
+    double* const mu = Rl + (size_t)M4 * KC;             // M4
+    double* const sg = mu + M4;                          // M4 (0: the metric takes no part -- zero variance or padding)
+    double* const op = lds + lds_main;                   // KC observed scores, behind everything the epilogue overlays
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
+    const int ncomp = (int)model[0];
+    for (int e = t; e < M4 * KC; e += 256) {
+        const int m = e / KC, k = e % KC;
+        Rl[e] = (m < M && k < ncomp) ? model[off_R + m + (size_t)M * k] : 0.0;
+    }
+    for (int m = t; m < M4; m += 256) { mu[m] = (m < M) ? mean[m] : 0.0; sg[m] = (m < M) ? sd[m] : 0.0; }
+    if (t < KC) op[t] = (t < ncomp) ? model[off_oscore + t] : 0.0;
+    __syncthreads();
+    const size_t base = ((size_t)blockIdx.x * 4 + wave) * 64;
+    const double* xr[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        size_t row = base + 32 * h + 2 * r;
+        if (row + 1 >= n) row = n - 2;                   // a legal, aligned address; the result is not stored
+        xr[h] = X + row;
+    }
+    pd4 acc[4][KT];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int tt = 0; tt < KT; tt++) acc[g][tt] = (pd4){0.0, 0.0, 0.0, 0.0};
+    d2 xb[PF][2];
+    auto loadx = [&](d2 (&x)[2], int j) {
+        int m = 4 * j + q;
+        if (m >= M) m = M - 1;                           // padding metric of the last step: in range, and its sd entry is 0
+#pragma unroll
+        for (int h = 0; h < 2; h++) x[h] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xr[h] + (size_t)m * ldx));
+    };
+    const int steps = M4 / 4;
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        if (u < steps) loadx(xb[u], u);
+    for (int j0 = 0; j0 < steps; j0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int j = j0 + u;
+            if (j < steps) {                             // (uniform)
+                const int m = 4 * j + q;
+                const double mm = mu[m], ss = sg[m];
+                double b[KT];
+#pragma unroll
+                for (int tt = 0; tt < KT; tt++) b[tt] = Rl[(size_t)m * KC + 16 * tt + r];
+                const double xv[4] = {xb[u][0].x, xb[u][0].y, xb[u][1].x, xb[u][1].y};
+                if (j + PF < steps) loadx(xb[u], j + PF);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const double z = (ss == 0.0) ? 0.0 : (xv[g] - mm) / ss;
+#pragma unroll
+                    for (int tt = 0; tt < KT; tt++) acc[g][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(z, b[tt], acc[g][tt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                     // every wave is done with the loadings: the scores go over them
+    double* const stage = lds + (size_t)wave * 64 * SROW;
+    // group g = 2 h + e holds rows 32 h + 2 row16 + e of the wave's 64
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int tt = 0; tt < KT; tt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                stage[(size_t)(32 * (g >> 1) + 2 * (q + 4 * i) + (g & 1)) * SROW + 16 * tt + r] = acc[g][tt][i];
+    __syncthreads();
+    double d2v = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < KC; k++) {
+        const double tt = stage[(size_t)lane * SROW + k] - op[k];
+        d2v = fma(tt, tt, d2v);
+    }
+    const size_t p = base + lane;
+    if (p < n) dist[p] = sqrt(d2v);
+}
+
 template <int KC>
 __global__ __launch_bounds__(256) void k_project_dist(const double* __restrict__ X, size_t n, size_t ldx, int M,
                                                       const double* __restrict__ mean,
@@ -284,6 +386,30 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     if (pblocks > 256 * 16) pblocks = 256 * 16;
     blocks = (ntail + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    // 17..32 components: the score contraction on the fp64 matrix pipe, while its LDS fits (aligned row pairs; an odd last row
+    // goes through the scalar kernel below)
+    bool mfma_kernel = false;
+    size_t mfma_lb = 0, mfma_main = 0;
+    if (KC == 32 && npairs && !getenv("ABC_PROJECT_VALU")) {       // (16 components: the vector kernel is 5-10 % faster, measured)
+        const size_t M4 = (M + 3) & ~(size_t)3;
+        mfma_main = (M4 * KC + 2 * M4 > (size_t)4 * 64 * (KC + 1)) ? M4 * KC + 2 * M4 : (size_t)4 * 64 * (KC + 1);
+        mfma_lb = (mfma_main + KC) * sizeof(double);
+        mfma_kernel = mfma_lb <= 150 * 1024;
+    }
+    if (mfma_kernel) {
+        const unsigned gb = (unsigned)((2 * npairs + 255) / 256);
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_project_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lb));
+        hipLaunchKernelGGL(k_project_mfma<2>, dim3(gb), dim3(256), mfma_lb, ctx->stream, X, 2 * npairs, ldx, (int)M, model + ML.off_mean,
+                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, (int)mfma_main);
+        ABC_HIP(ctx, hipGetLastError());
+        if (ntail) {
+            hipLaunchKernelGGL(k_pad_model, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, KC, Rpad, opad);
+            hipLaunchKernelGGL(k_project_dist<32>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X + 2 * npairs, ntail, ldx, (int)M,
+                                   model + ML.off_mean, model + ML.off_sd, Rpad, opad, dist + 2 * npairs);
+            ABC_HIP(ctx, hipGetLastError());
+        }
+        return ABC_OK;
+    }
     // the LDS kernel pads the loadings itself; the others read the padded copy k_pad_model leaves in the workspace
     const bool lds_kernel = (KC == 8 || KC == 16 || KC == 32) && (M * KC + KC) * sizeof(double) <= 64 * 1024 && npairs;
     if (!lds_kernel || ntail) {

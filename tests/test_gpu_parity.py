@@ -67,6 +67,9 @@ def _near_tie_ok(idx_a, idx_b, dist_full, tol=1e-9):
     (1500, 127, 16, 12, 0.45),   # ... odd leading dimension just below the register limit
     (1500, 129, 5, 9, 0.5),      # ... just above it: X'X read from global memory
     (700, 40, 16, 40, 0.5),      # as many components as metrics (XY exhausted after 16: the rest are rounding-level directions)
+    (2502, 37, 20, 20, 0.5),     # 17..32 components: the projection on the fp64 matrix pipe; metrics not a multiple of four, rows not of 64
+    (1111, 50, 24, 24, 0.5),     # ... odd row count: the last row through the scalar kernel
+    (130, 128, 30, 30, 0.5),     # ... fewer rows than one work-group, 128 metrics
 ])
 def test_particle_ranking_pls(gpu_ctx, oracle, N, M, P, A, f):
     from abcsmc_amd import abcutil
