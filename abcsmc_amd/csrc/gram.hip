@@ -686,17 +686,19 @@ __global__ __launch_bounds__(512) void k_gram_wide(const double* __restrict__ X,
 }
 
 // Sum the per-work-group partial records in a fixed order and scatter into the stats record.
+constexpr int SR_SL = 16;          // slices of the G partial records per work-group (64 elements x SR_SL slices = 1024 threads)
 template <int C, int CY>
-__global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__ partial, int G,
+__global__ __launch_bounds__(64 * SR_SL) void k_stats_reduce(const double* __restrict__ partial, int G,
                                                       double* __restrict__ stats, long long n_train,
                                                       long long n_test) {
     using D = GramDims<C, CY>;
     const StatsLayout L = stats_layout(D::C16, 0);
     const int part = blockIdx.y;
-    // 64 consecutive record elements x 4 slices of the G partial records per block: a wave reads 512 contiguous bytes of one
+    // 64 consecutive record elements x SR_SL slices of the G partial records per block: a wave reads 512 contiguous bytes of one
     // record per instruction (16 elements x 16 slices read 128-byte pieces of four records: 30 us for the 23 MB of a 144-column
-    // set); slices are combined in a fixed order, each slice as four interleaved running sums (four loads in flight per thread)
-    __shared__ double red[4][64];
+    // set); slices are combined in a fixed order, each slice as four interleaved running sums (four loads in flight per thread).
+    // Sixteen slices on 1024 threads (four on 256 until round 3): the kernel is a chain of dependent loads on a nearly empty chip
+    __shared__ double red[SR_SL][64];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
     if (blockIdx.x == 0 && threadIdx.x == 0 && part == 0) { stats[L.off_n] = (double)n_train; stats[L.off_n + 1] = (double)n_test; }
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__
         // the skipped pure-Y blocks: zero off their diagonal (a memset of the whole record used to do this: one launch more)
         constexpr int y0 = 16 * (C - CY), ny = 16 * CY;
         double* Gz = stats + L.off_G[part];
-        for (int i = threadIdx.x; i < ny * ny; i += 256) {
+        for (int i = threadIdx.x; i < ny * ny; i += 64 * SR_SL) {
             const int r = y0 + i % ny, c = y0 + i / ny;
             if (r != c) Gz[r + (size_t)D::C16 * c] = 0.0;
         }
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__
     double ps = 0.0;
     if (e < D::PSZ) {
         const double* p = partial + (size_t)part * G * D::PSZ + e;
-        const int g0 = (int)((long long)G * sl / 4), g1 = (int)((long long)G * (sl + 1) / 4);
+        const int g0 = (int)((long long)G * sl / SR_SL), g1 = (int)((long long)G * (sl + 1) / SR_SL);
         double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
         int g = g0;
         for (; g + 3 < g1; g += 4) {
@@ -727,7 +729,9 @@ __global__ __launch_bounds__(256) void k_stats_reduce(const double* __restrict__
     red[sl][el] = ps;
     __syncthreads();
     if (sl != 0 || e >= D::PSZ) return;
-    const double s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    double s = 0.0;
+#pragma unroll
+    for (int q4 = 0; q4 < SR_SL; q4 += 4) s += (red[q4][el] + red[q4 + 1][el]) + (red[q4 + 2][el] + red[q4 + 3][el]);
     if (e >= D::NBLK * 256) {
         const int c = e - D::NBLK * 256;
         if (c < D::C16) stats[L.off_sum[part] + c] = s;
@@ -791,7 +795,7 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
-    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(256), 0, ctx->stream, partial, (int)G,
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(64 * SR_SL), 0, ctx->stream, partial, (int)G,
                        stats, ntr, nte);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -828,7 +832,7 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
-    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(256), 0, ctx->stream, partial, (int)G,
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(64 * SR_SL), 0, ctx->stream, partial, (int)G,
                        stats, ntr, nte);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -861,7 +865,7 @@ int run_gram_dma8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
-    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(256), 0, ctx->stream, partial, (int)G, stats, ntr,
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(64 * SR_SL), 0, ctx->stream, partial, (int)G, stats, ntr,
                        nte);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -890,7 +894,7 @@ int run_gram_wide(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
-    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(256), 0, ctx->stream, partial, (int)G,
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(64 * SR_SL), 0, ctx->stream, partial, (int)G,
                        stats, ntr, nte);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
@@ -968,7 +972,7 @@ int run_gram_grouped(abc_ctx* ctx, const double* X, const double* Y, size_t n, s
                                    (const double*)tab, (const double*)nullptr, ldx, ldy, 96, 0, (long long)n, split,
                                    loc + LL.off_shift, partial, vec_ok);
             }
-            hipLaunchKernelGGL((k_stats_reduce<6, 0>), dim3((D::PSZ + 63) / 64, 2), dim3(256), 0, ctx->stream, partial,
+            hipLaunchKernelGGL((k_stats_reduce<6, 0>), dim3((D::PSZ + 63) / 64, 2), dim3(64 * SR_SL), 0, ctx->stream, partial,
                                (int)G, loc, ntr, nte);
             }
             hipLaunchKernelGGL(k_group_scatter, dim3((96 * 96 + 255) / 256), dim3(256), 0, ctx->stream, loc, 96, gmap, stats,
