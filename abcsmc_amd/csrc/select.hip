@@ -305,9 +305,10 @@ __global__ __launch_bounds__(1024) void k_bs_scan(BinSel* __restrict__ bs, unsig
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_fail = 0;
-    unsigned int c[4], sum = 0;
+    constexpr int BPT = BS_NB / 1024;        // bins per thread
+    unsigned int c[BPT], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { c[j] = hist[4 * t + j]; sum += c[j]; }
+    for (int j = 0; j < BPT; j++) { c[j] = hist[BPT * t + j]; sum += c[j]; }
     unsigned int inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
@@ -319,10 +320,10 @@ __global__ __launch_bounds__(1024) void k_bs_scan(BinSel* __restrict__ bs, unsig
     for (int w = 0; w < 16; w++) tot += wsum[w];
     // keys of bins <= b* are sorted by one work-group each: none may exceed BS_CAP
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < BPT; j++) {
         const unsigned int off = run;
-        hist[4 * t + j] = off;
-        if ((unsigned long long)off < K && K <= (unsigned long long)off + c[j]) { bs->bstar = 4 * t + j; bs->need = K - off; }
+        hist[BPT * t + j] = off;
+        if ((unsigned long long)off < K && K <= (unsigned long long)off + c[j]) { bs->bstar = BPT * t + j; bs->need = K - off; }
         if ((unsigned long long)off < K && c[j] > (unsigned int)BS_CAP) s_fail = 1;
         run += c[j];
     }
