@@ -389,6 +389,21 @@ __device__ __forceinline__ unsigned f16_bits(double x) {
     if (m == 2048u) { m = 1024u; e++; }
     return sg | ((unsigned)(e + 15) << 10) | (m - 1024u);
 }
+// value of IEEE binary16 bits (finite)
+__device__ __forceinline__ double f16_value(unsigned b) {
+    const int e = (int)((b >> 10) & 31u), m = (int)(b & 0x3ffu);
+    const double v = e ? ldexp((double)(1024 + m), e - 25) : ldexp((double)m, -24);
+    return (b & 0x8000u) ? -v : v;
+}
+// KS_FOLD: h = top + low as f16 pieces for the spare K-slots of the limb operands -- top (a multiple of 2^-14 below 2^11: 11 + 11 + 3
+// bits, exact) and low scaled by 2^24 (|low| <= 2^-15: three pieces carry it to 2^-48)
+__device__ __forceinline__ void ks_pieces_f16(double h, double unit_inv, unsigned top_pc[3], unsigned low_pc[3]) {
+    const double top = rint(h * unit_inv) / unit_inv;
+    double rem = top;
+    for (int k = 0; k < 3; k++) { top_pc[k] = f16_bits(rem); rem -= f16_value(top_pc[k]); }
+    rem = (h - top) * 0x1p24;
+    for (int k = 0; k < 3; k++) { low_pc[k] = f16_bits(rem); rem -= f16_value(low_pc[k]); }
+}
 // h = top (a multiple of 1/unit_inv = 2^-14, <= 24 significant bits: three bf16 pieces hold it exactly) + low (three more pieces)
 __device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc[6]) {
     const double top = rint(h * unit_inv) / unit_inv;
@@ -432,7 +447,8 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
                                                WConst* __restrict__ wc, const double* __restrict__ w, int is_prev,
                                                double* __restrict__ out, double* __restrict__ hb,
                                                unsigned short* __restrict__ tiles, int ops, unsigned char* __restrict__ far_flag,
-                                               unsigned* __restrict__ far_list, int* __restrict__ ha_int, double* __restrict__ ha_frac) {
+                                               unsigned* __restrict__ far_list, int* __restrict__ ha_int, double* __restrict__ ha_frac,
+                                               int fold /* KS_FOLD: norm pieces in K-slots 13..15 of the limb operands, no norm operand */) {
     constexpr int G = 2 * NCH, RW = 64 / G;
     const int lane = threadIdx.x & 63, g = lane / RW, rr = lane % RW;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -495,6 +511,9 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
     const unsigned r32 = (unsigned)(r & 31);
     const int c = g >> 1, h = g & 1;
     unsigned pk[KS_NL][4];
+    unsigned top_pc[3] = {0u, 0u, 0u}, low_pc[3] = {0u, 0u, 0u};
+    const bool fold_lane = (NCH == 1) && fold && g == 1;              // the lane that holds K-slots 8..15 of its row
+    if (fold_lane && is_prev) ks_pieces_f16(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, top_pc, low_pc);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const double x = valid ? v[j] : 0.0;
@@ -507,6 +526,10 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
         b[1] = f16_of_int(n1, 18);
         b[2] = f16_of_int(n0, 18);                                   // h0 2^-11
         b[3] = f16_bits(r2 * 0x1p11);                                // |.| <= 2^-8, rounded to eleven significant bits
+        if (fold_lane && j >= 5) {                                   // K-slots 13..15 (parameters 13..15 do not exist: P <= 13)
+            if (is_prev) { b[0] = top_pc[j - 5]; b[2] = low_pc[j - 5]; }      // against -1 in the new set's h0 operand, -2^-24 in its r2 operand
+            else { b[0] = 0xBC00u; b[3] = 0x8001u; }
+        }
 #pragma unroll
         for (int k = 0; k < KS_NL; k++) {
             if (j & 1) pk[k][j >> 1] |= b[k] << 16; else pk[k][j >> 1] = b[k];
@@ -516,7 +539,7 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
     for (int k = 0; k < KS_NL; k++)
         *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + r32) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
     if (g == 0) {
-        if (is_prev) {
+        if (is_prev && !fold) {
             unsigned pc[6];
             unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
             ks_pieces(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
@@ -526,7 +549,7 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
             const unsigned ones = KS_MONE | (KS_MONE << 16);            // (-1: the kernel hands over +n, not -n: one negation less per batch)
             *(uint4*)(ob + r32 * 8) = make_uint4(pc[0] | (pc[1] << 16), pc[2] | (pc[3] << 16), pc[4] | (pc[5] << 16), (r32 & 4) ? 0u : ones);
             *(uint4*)(ob + (32 + r32) * 8) = make_uint4(0u, 0u, 0u, (r32 & 4) ? ones : 0u);
-        } else {
+        } else if (!is_prev) {
             const double ha = valid ? 0.5 * nrow : 0.0, hi = floor(ha);          // 0 for a far / padded row
             ha_int[r] = (int)hi;
             ha_frac[r] = ha - hi;
@@ -642,13 +665,34 @@ struct KsRef { float p0, p1, p2, p3; };        // the four running f32 sums of a
 // parameters).  Error of a batch sum (emulation, scripts/split_precision.py): rms 4.8e-8 / max 2.0e-7 (4.6e-8 / 2.0e-7 with two
 // accumulators).  Measured at 1e10 pairs, P = 16: 2.38 -> 2.24 ms -- the chip clocks 6 % lower under the ninth MFMA (1.78 against
 // 1.90 GHz, PMC), which eats most of what the 26 % shorter instruction stream buys.
+// The kernel's variants, by their first template argument: 1, 2, 4 = 16-parameter chunks; KS_FOLD = ONE chunk of at most 13
+// parameters with the norm pieces in the three spare K-slots of its limb operands -- hbTop (three f16 pieces against -1) in the
+// exact h0.h0' step, hbLow (scaled by 2^24, three f16 pieces against -2^-24: f16 has no exponent for it otherwise) in the
+// (h0 2^-11).(r2' 2^11) step, which only ever meets its own partner operand: SEVEN MFMAs per 1024 pairs instead of nine (the -n
+// step stays an instruction of its own: scripts/mfma_merge_probe.hip), and no norm operand to stream (the -1 entries the -n step
+// needs are a per-lane constant).  The matrix pipe's energy is what bounds this kernel.
+constexpr int KS_FOLD = 101;
+constexpr int KS_FOLD_MAXP = 13;
+template <int V> __host__ __device__ constexpr int kz_nch() { return V == KS_FOLD ? 1 : V; }
+template <int V> __host__ __device__ constexpr bool kz_fold() { return V == KS_FOLD; }
+template <int V> __host__ __device__ constexpr int kz_nexact() { return V == KS_FOLD ? 1 : 1 + V; }
 template <int NCH>
-__host__ __device__ constexpr int kz_nsteps() { return 3 + 6 * NCH; }
+__host__ __device__ constexpr int kz_nsteps() { return NCH == KS_FOLD ? 7 : 3 + 6 * NCH; }
 // step S of a batch: 0 norm top; 1..NCH h0.h0'; [vector: n]; NCH+1: -n; NCH+2: norm low; then 5 products per chunk
+// (KS_FOLD: 0 h0.h0' with the norm top; [vector: n]; 1: -n; then the 5 products, the last but one with the norm low)
 template <int NCH, int S>
 __device__ __forceinline__ void kz_mfma(const uint4* A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
     const f32x16 Z0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (S == 0) {
+    if constexpr (NCH == KS_FOLD) {
+        if constexpr (S == 0) {
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), __builtin_bit_cast(f16x8, B[0]), Z0, 0, 0, 0);
+        } else if constexpr (S == 1) {
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, NB[0]), __builtin_bit_cast(bf16x8, BN), Z, 0, 0, 0);
+        } else {
+            constexpr int l = S - 1;                                             // products 1..5 of KS_LA / KS_LB
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[KS_LA[l]]), __builtin_bit_cast(f16x8, B[KS_LB[l]]), Z, 0, 0, 0);
+        }
+    } else if constexpr (S == 0) {
         Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[0]), Z0, 0, 0, 0);
     } else if constexpr (S <= NCH) {
         constexpr int c = S - 1;
@@ -700,7 +744,7 @@ template <int NCH, int R>
 __device__ __forceinline__ void kz_slots(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
                                          const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
     if constexpr (R < 8) {
-        constexpr int NS = kz_nsteps<NCH>(), NA = 1 + NCH;            // NA exact steps, then the reference, then NS - NA more
+        constexpr int NS = kz_nsteps<NCH>(), NA = kz_nexact<NCH>();   // NA exact steps, then the reference, then NS - NA more
         if constexpr (R == 0) kz_mfma_range<NCH, 0, NA>(An, Bn, NB, BN, Zn);
         if constexpr (R == 3) {
             kz_reference(Zn, lane, nn, BN);
@@ -740,7 +784,7 @@ template <int NCH, int RO, int R>
 __device__ __forceinline__ void kz_fine(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
                                         const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
     if constexpr (R < 16) {
-        constexpr int NS = kz_nsteps<NCH>(), NA = 1 + NCH, R0 = NA + RO, M = NS - NA, L = 16 - R0;
+        constexpr int NS = kz_nsteps<NCH>(), NA = kz_nexact<NCH>(), R0 = NA + RO, M = NS - NA, L = 16 - R0;
         if constexpr (R < NA) kz_mfma_range<NCH, R, R + 1>(An, Bn, NB, BN, Zn);
         if constexpr (R == R0) kz_reference(Zn, lane, nn, BN);
         if constexpr (R >= R0) {
@@ -780,7 +824,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
                                                       const WConst* __restrict__ wc, const int* __restrict__ ha_int,
                                                       double* __restrict__ part) {
     if (!ks_split_on(wc)) return;                             // the fp64 kernel's turn
-    constexpr int OPA = NCH * KS_NL, OPB = NCH * KS_NL + 1;
+    constexpr int OPA = kz_nch<NCH>() * KS_NL, OPB = OPA + (kz_fold<NCH>() ? 0 : 1);
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
     const unsigned slices = gridDim.y, sl = blockIdx.y;
@@ -795,6 +839,12 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
     uint4 NB[2];
     NB[0] = (lane < 32) ? make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
     NB[1] = (lane < 32) ? make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u) : make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (kz_fold<NCH>()) {
+        // the A operand of the -n step: -1 in K-slots 6,7 for the rows an MFMA result holds in lanes 0..31 (bit 2 of the row clear),
+        // in 14,15 for the others (what k_wrows writes into the norm operand of the other variants), nothing else
+        const bool mine = (lane < 32) == (((lane & 31u) & 4u) == 0u);
+        NB[0] = make_uint4(0u, 0u, 0u, mine ? (KS_MONE | (KS_MONE << 16)) : 0u);
+    }
     const int hs0 = ha_int[(it0 + 0) * 32 + (lane & 31)], hs1 = ha_int[(it0 + 1) * 32 + (lane & 31)];
     double acc0 = 0.0, acc1 = 0.0;
     if (t0 < t1) {
@@ -805,7 +855,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
         int n0 = 0, n1 = 0;
         uint4 BN = make_uint4(0u, 0u, 0u, 0u);                   // (kz_reference only ever writes its last component)
         {   // (t0, columns 0): the whole chain up front
-            constexpr int NA = 1 + NCH;
+            constexpr int NA = kz_nexact<NCH>();
             kz_mfma_range<NCH, 0, NA>(A, B0, NB, BN, Z0);
             kz_reference(Z0, lane, n0, BN);
             kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
@@ -1012,6 +1062,12 @@ int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t 
 // row-major copy b with hb, the limb tiles of the split kernel.  The fused drivers queue it on the side stream at the start of a
 // generation (it runs beside the ranking); st == NULL: the context's stream.  kn_max: the most rows a later launch_weights_raw
 // will handle (its far-row budget).
+// up to 13 parameters: the seven-MFMA variant of the split kernel (norm pieces in the spare K-slots: KS_FOLD)
+static bool ks_fold_on(size_t P, bool split) {
+    static const bool off = getenv("ABC_KDE_NOFOLD") != nullptr;              // A/B switch for measurements
+    return split && P <= (size_t)KS_FOLD_MAXP && !off;
+}
+
 int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
                         const double* dv_prev, abc_wprev* out, hipStream_t st) {
     memset(out, 0, sizeof(*out));
@@ -1025,7 +1081,8 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
     const bool split = (PP >= 8 && P <= 64 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32;
-    const int opb = NCH * KS_NL + 1;
+    const bool fold = ks_fold_on(P, split);
+    const int opb = NCH * KS_NL + (fold ? 0 : 1);
     WConst* wc = (WConst*)abc_ws_alloc(ctx, sizeof(WConst));
     double* b = (double*)abc_ws_alloc(ctx, Kp * PP * sizeof(double));
     double* hb = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
@@ -1046,13 +1103,13 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
         const size_t rbp = nbt * 32;
         if (NCH == 1)
             hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((rbp / 32 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((rbp / 16 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, 0);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((rbp / 8 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, 0);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
                            (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
@@ -1091,6 +1148,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     const bool split = (PP >= 8 && P <= 64 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
     const int opa = NCH * KS_NL;
+    const bool fold = ks_fold_on(P, split);
     if (split) {
         // Every work-group of the split kernel loads its 32-64 KB of resident operands once per slice: with the 65 slices
         // the fp64 kernel likes that was 1.2 GB of fabric traffic per launch at K = K' = 1e5 (PMC).  Its time is flat between
@@ -1134,13 +1192,13 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         const size_t ra = nat * 32;
         if (NCH == 1)
             hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((ra / 32 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((ra / 16 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, 0);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((ra / 8 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, 0);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
                            (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
@@ -1174,7 +1232,10 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             // the same loop was 2 % slower than the copying one, rounds 2 and 3); at 32 parameters either change and both together are
             // 0.7-2 % slower than the eight-slot copying loop, at 64 -- one wave per SIMD -- the finer interleave costs 50 %: they keep
             // kz_slots; four waves per SIMD, the reference two slots behind: +0.5 %)
-            if (NCH == 1)
+            if (fold)           // (up to 13 parameters: seven MFMAs per 1024 pairs, no norm operand)
+                hipLaunchKernelGGL((k_kde_split<KS_FOLD, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+            else if (NCH == 1)
                 hipLaunchKernelGGL((k_kde_split<1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
             else if (NCH == 2)

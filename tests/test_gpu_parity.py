@@ -467,11 +467,13 @@ def test_weight_epanechnikov_extension(gpu_ctx, oracle, K, Kp, P):
         assert not np.allclose(w, w_gauss, rtol=1e-3)                   # it is a different kernel
 
 
-def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle):
+@pytest.mark.parametrize("P", [16, 13, 12, 7])
+def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle, P):
     """the split-operand kernel on a set large enough for many column slices and tiles: against the oracle and against
-    the fp64 kernel; previous particles of weight exactly 0 (inside the exact range) contribute exactly nothing"""
+    the fp64 kernel; previous particles of weight exactly 0 (inside the exact range) contribute exactly nothing.  Up to 13
+    parameters run the seven-MFMA variant (norm pieces in the spare K-slots of the limb operands), 14..16 the nine-MFMA one"""
     from abcsmc_amd import abcutil, _lib
-    P, K, Kp = 16, 3000, 5000
+    K, Kp = 3000, 5000
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 4242)
     wp = wp.copy()
     wp[::97] = 0.0
@@ -517,13 +519,14 @@ def test_weight_split_kernel_accuracy_at_33_to_64_parameters(gpu_ctx, oracle, P,
     assert np.array_equal(w == 0, ref == 0)
 
 
-def test_weight_split_kernel_range_edges(gpu_ctx, oracle):
+@pytest.mark.parametrize("P", [16, 11])
+def test_weight_split_kernel_range_edges(gpu_ctx, oracle, P):
     """edges of the range the split-operand kernel is exact on: particles up to ~9.5 scaled units from the centre and
     previous weights down to 1e-150 are inside it; one coordinate past 10 units, or a weight of 1e-200, makes that ROW
     'far': it leaves the matrix work and its pairs are added in fp64 by the fix-up kernels -- the call stays on the split
     kernel and still matches the oracle"""
     from abcsmc_amd import abcutil, _lib
-    P, K, Kp = 16, 400, 600
+    K, Kp = 400, 600
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 99)
     spec = [(_lib.PRIOR_GAUSS, 0.0, 1e9)] * P
     pri, opri = _lib.make_priors(spec), oracle.make_priors(spec)
@@ -554,13 +557,14 @@ def test_weight_split_kernel_range_edges(gpu_ctx, oracle):
     assert np.max(np.abs(w3 - ref3) / ref3) < KDE_TOL["auto"]
 
 
-def test_weight_far_rows_are_fixed_up_row_by_row(gpu_ctx, oracle):
+@pytest.mark.parametrize("P", [16, 10])
+def test_weight_far_rows_are_fixed_up_row_by_row(gpu_ctx, oracle, P):
     """particles outside the split-operand kernel's exact range on BOTH sides, scattered over tiles and slices: far new
     particles next to far previous ones (their mutual term dominates both sums), a far previous particle next to ordinary
     new ones, previous particles of weight 0 among the far ones.  Everything stays on the split kernel + fix-ups and
     matches the oracle; the result is bit-reproducible; with more far rows than the fix-ups take, the fp64 kernel runs."""
     from abcsmc_amd import abcutil, _lib
-    P, K, Kp = 16, 1500, 2100
+    K, Kp = 1500, 2100
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 1234)
     spec = [(_lib.PRIOR_GAUSS, 0.0, 1e9)] * P
     pri, opri = _lib.make_priors(spec), oracle.make_priors(spec)
@@ -1112,10 +1116,10 @@ def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=6789
     return wl, X, Y, obs, spec, prev, gen, r
 
 
-@pytest.mark.parametrize("multivariate,Kp", [(True, 400), (False, 400), (True, 0)])
-def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp):
+@pytest.mark.parametrize("multivariate,Kp,P", [(True, 400, 16), (False, 400, 16), (True, 0, 16), (True, 400, 12), (False, 400, 7)])
+def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp, P):
     from abcsmc_amd import device
-    N, M, P, K, Nn, A = 3000, 32, 16, 400, 3000, 8
+    N, M, K, Nn, A = 3000, 32, 400, 3000, 8
     wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, multivariate)
     o = oracle.rng(67890)
     ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A,
