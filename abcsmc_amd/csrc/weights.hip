@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
     const int c = g >> 1, h = g & 1;
     unsigned pk[KS_NL][4];
     unsigned top_pc[3] = {0u, 0u, 0u}, low_pc[3] = {0u, 0u, 0u};
-    const bool fold_lane = (NCH == 1) && fold && g == 1;              // the lane that holds K-slots 8..15 of its row
+    const bool fold_lane = fold && g == G - 1;                        // the lane that holds K-slots 8..15 of its row's LAST chunk
     if (fold_lane && is_prev) ks_pieces_f16(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, top_pc, low_pc);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
         b[1] = f16_of_int(n1, 18);
         b[2] = f16_of_int(n0, 18);                                   // h0 2^-11
         b[3] = f16_bits(r2 * 0x1p11);                                // |.| <= 2^-8, rounded to eleven significant bits
-        if (fold_lane && j >= 5) {                                   // K-slots 13..15 (parameters 13..15 do not exist: P <= 13)
+        if (fold_lane && j >= 5) {                                   // K-slots 13..15 of the last chunk (its parameters 13..15 do not exist)
             if (is_prev) { b[0] = top_pc[j - 5]; b[2] = low_pc[j - 5]; }      // against -1 in the new set's h0 operand, -2^-24 in its r2 operand
             else { b[0] = 0xBC00u; b[3] = 0x8001u; }
         }
@@ -665,32 +665,36 @@ struct KsRef { float p0, p1, p2, p3; };        // the four running f32 sums of a
 // parameters).  Error of a batch sum (emulation, scripts/split_precision.py): rms 4.8e-8 / max 2.0e-7 (4.6e-8 / 2.0e-7 with two
 // accumulators).  Measured at 1e10 pairs, P = 16: 2.38 -> 2.24 ms -- the chip clocks 6 % lower under the ninth MFMA (1.78 against
 // 1.90 GHz, PMC), which eats most of what the 26 % shorter instruction stream buys.
-// The kernel's variants, by their first template argument: 1, 2, 4 = 16-parameter chunks; KS_FOLD = ONE chunk of at most 13
-// parameters with the norm pieces in the three spare K-slots of its limb operands -- hbTop (three f16 pieces against -1) in the
+// The kernel's variants, by their first template argument: 1, 2, 4 = 16-parameter chunks; KS_FOLD + 1, 2, 4 = as many chunks
+// holding at most 13 / 29 / 61 parameters with the norm pieces in the three spare K-slots of the LAST chunk's limb operands -- hbTop (three f16 pieces against -1) in the
 // exact h0.h0' step, hbLow (scaled by 2^24, three f16 pieces against -2^-24: f16 has no exponent for it otherwise) in the
-// (h0 2^-11).(r2' 2^11) step, which only ever meets its own partner operand: SEVEN MFMAs per 1024 pairs instead of nine (the -n
+// (h0 2^-11).(r2' 2^11) step, which only ever meets its own partner operand: 7 / 13 / 25 MFMAs per 1024 pairs instead of 9 / 15 / 27 (the -n
 // step stays an instruction of its own: scripts/mfma_merge_probe.hip), and no norm operand to stream (the -1 entries the -n step
 // needs are a per-lane constant).  The matrix pipe's energy is what bounds this kernel.
-constexpr int KS_FOLD = 101;
-constexpr int KS_FOLD_MAXP = 13;
-template <int V> __host__ __device__ constexpr int kz_nch() { return V == KS_FOLD ? 1 : V; }
-template <int V> __host__ __device__ constexpr bool kz_fold() { return V == KS_FOLD; }
-template <int V> __host__ __device__ constexpr int kz_nexact() { return V == KS_FOLD ? 1 : 1 + V; }
+constexpr int KS_FOLD = 100;               // variant tag KS_FOLD + chunks: 101, 102, 104
+template <int V> __host__ __device__ constexpr int kz_nch() { return V > KS_FOLD ? V - KS_FOLD : V; }
+template <int V> __host__ __device__ constexpr bool kz_fold() { return V > KS_FOLD; }
+template <int V> __host__ __device__ constexpr int kz_nexact() { return V > KS_FOLD ? V - KS_FOLD : 1 + V; }
 template <int NCH>
-__host__ __device__ constexpr int kz_nsteps() { return NCH == KS_FOLD ? 7 : 3 + 6 * NCH; }
+__host__ __device__ constexpr int kz_nsteps() { return NCH > KS_FOLD ? 1 + 6 * (NCH - KS_FOLD) : 3 + 6 * NCH; }
 // step S of a batch: 0 norm top; 1..NCH h0.h0'; [vector: n]; NCH+1: -n; NCH+2: norm low; then 5 products per chunk
-// (KS_FOLD: 0 h0.h0' with the norm top; [vector: n]; 1: -n; then the 5 products, the last but one with the norm low)
+// (folded: 0..NCH-1 h0.h0', the last chunk's with the norm top; [vector: n]; NCH: -n; then 5 products per chunk, the last chunk's
+// (h0 2^-11).(r2' 2^11) with the norm low)
 template <int NCH, int S>
 __device__ __forceinline__ void kz_mfma(const uint4* A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
     const f32x16 Z0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (NCH == KS_FOLD) {
+    if constexpr (kz_fold<NCH>()) {
+        constexpr int C = kz_nch<NCH>();
         if constexpr (S == 0) {
             Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), __builtin_bit_cast(f16x8, B[0]), Z0, 0, 0, 0);
-        } else if constexpr (S == 1) {
+        } else if constexpr (S < C) {
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[S * KS_NL]), __builtin_bit_cast(f16x8, B[S * KS_NL]), Z, 0, 0, 0);
+        } else if constexpr (S == C) {
             Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, NB[0]), __builtin_bit_cast(bf16x8, BN), Z, 0, 0, 0);
         } else {
-            constexpr int l = S - 1;                                             // products 1..5 of KS_LA / KS_LB
-            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[KS_LA[l]]), __builtin_bit_cast(f16x8, B[KS_LB[l]]), Z, 0, 0, 0);
+            constexpr int q = S - (C + 1), c = q / 5, l = 1 + q % 5;             // products 1..5 of KS_LA / KS_LB
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c * KS_NL + KS_LA[l]]),
+                                                       __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]), Z, 0, 0, 0);
         }
     } else if constexpr (S == 0) {
         Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[NCH * KS_NL]), __builtin_bit_cast(bf16x8, NB[0]), Z0, 0, 0, 0);
@@ -1062,10 +1066,11 @@ int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t 
 // row-major copy b with hb, the limb tiles of the split kernel.  The fused drivers queue it on the side stream at the start of a
 // generation (it runs beside the ranking); st == NULL: the context's stream.  kn_max: the most rows a later launch_weights_raw
 // will handle (its far-row budget).
-// up to 13 parameters: the seven-MFMA variant of the split kernel (norm pieces in the spare K-slots: KS_FOLD)
+// up to 13 / 17..29 / 33..61 parameters: the variants of the split kernel with two MFMAs fewer (norm pieces in the spare K-slots: KS_FOLD)
 static bool ks_fold_on(size_t P, bool split) {
     static const bool off = getenv("ABC_KDE_NOFOLD") != nullptr;              // A/B switch for measurements
-    return split && P <= (size_t)KS_FOLD_MAXP && !off;
+    const size_t nch = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
+    return split && P + 3 <= 16 * nch && !off;                                // three spare K-slots in the last chunk
 }
 
 int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
@@ -1106,10 +1111,10 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
                                w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((rbp / 16 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, 0);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((rbp / 8 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, 0);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
                            (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
@@ -1195,10 +1200,10 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
                                wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((ra / 16 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, 0);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((ra / 8 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, 0);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
                            (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
@@ -1232,8 +1237,14 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             // the same loop was 2 % slower than the copying one, rounds 2 and 3); at 32 parameters either change and both together are
             // 0.7-2 % slower than the eight-slot copying loop, at 64 -- one wave per SIMD -- the finer interleave costs 50 %: they keep
             // kz_slots; four waves per SIMD, the reference two slots behind: +0.5 %)
-            if (fold)           // (up to 13 parameters: seven MFMAs per 1024 pairs, no norm operand)
-                hipLaunchKernelGGL((k_kde_split<KS_FOLD, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+            if (fold && NCH == 1)           // (up to 13 parameters: seven MFMAs per 1024 pairs, no norm operand)
+                hipLaunchKernelGGL((k_kde_split<KS_FOLD + 1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+            else if (fold && NCH == 2)      // (17..29: thirteen instead of fifteen)
+                hipLaunchKernelGGL((k_kde_split<KS_FOLD + 2, 2, false, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+            else if (fold)                  // (33..61: twenty-five instead of twenty-seven)
+                hipLaunchKernelGGL((k_kde_split<KS_FOLD + 4, 1, true, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
             else if (NCH == 1)
                 hipLaunchKernelGGL((k_kde_split<1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,

@@ -420,7 +420,9 @@ class _kde_mode:
 @pytest.mark.parametrize("mode", ["auto", "fp64"])
 @pytest.mark.parametrize("P,K,Kp", [(16, 700, 900), (2, 100, 64), (5, 1, 130), (32, 300, 257), (3, 2500, 70), (48, 200, 150),
                                     (9, 513, 31), (20, 65, 1000), (13, 1, 40), (33, 130, 97), (64, 257, 300), (57, 64, 1030),
-                                    (70, 90, 80)])
+                                    (70, 90, 80),
+                                    # either side of the parameter counts up to which the norm pieces ride in spare K-slots (13, 29, 61)
+                                    (13, 200, 333), (14, 200, 333), (29, 150, 260), (30, 150, 260), (61, 100, 140), (62, 100, 140)])
 def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp, mode):
     from abcsmc_amd import abcutil, _lib
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 77 + P)
