@@ -259,6 +259,7 @@ int launch_mvn_from_stats(abc_ctx*, const double* stats, size_t P, double* L, in
 // the previous set's share of the weight stage (weights.hip: launch_weights_prev), prepared ahead of launch_weights_raw
 struct abc_wprev {
     void* wc /* WConst */; double* b; double* hb; unsigned short* bt; unsigned* far_list;
+    unsigned* tmin;        // KS_TOPN (tiles in the order of the rows' norm tops): the smallest top of every tile, f32 bits; else NULL
     size_t Kp, P, kn_max; int split, ready;
 };
 int launch_weights_prev(abc_ctx*, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,

@@ -94,9 +94,9 @@ __device__ __forceinline__ uint32_t d_apply(const uint32_t* __restrict__ col, ui
 __global__ __launch_bounds__(256) void k_taus_stream(abc_rng base, size_t n, const uint32_t* __restrict__ jt,
                                                      uint32_t* __restrict__ out) {
     __shared__ uint32_t sjt[24 * 96];          // T^(RUN*2^k), k < 24 (16 M lanes x 64 outputs = 2^30 draws)
-    for (int e = threadIdx.x; e < 24 * 96; e += 256) sjt[e] = jt[e];
+    for (int e = threadIdx.x; e < 24 * 96; e += blockDim.x) sjt[e] = jt[e];
     __syncthreads();
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t first = t * RUN;
     if (first >= n) return;
     uint32_t s1 = base.s1, s2 = base.s2, s3 = base.s3;
@@ -538,7 +538,10 @@ int ensure_jump_tab(abc_ctx* ctx) {
 int taus_stream(abc_ctx* ctx, abc_rng base, size_t n, uint32_t* out, hipStream_t st = nullptr) {
     ABC_TRY(ensure_jump_tab(ctx));
     const size_t threads = (n + RUN - 1) / RUN;
-    hipLaunchKernelGGL(k_taus_stream, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st ? st : ctx->stream, base, n,
+    // every thread pays ~3000 instructions (its jump ahead, then 64 outputs): work-groups of ONE wave while they do not fill the
+    // chip four waves each (1e6 outputs: 62 groups of four waves on 62 of 256 CUs took 27 us; 245 single waves take a third)
+    const unsigned bs = (threads <= (size_t)256 * 64 * 4) ? 64u : 256u;
+    hipLaunchKernelGGL(k_taus_stream, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st ? st : ctx->stream, base, n,
                        ctx->jump_tab, out);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;

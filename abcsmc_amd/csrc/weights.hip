@@ -82,6 +82,7 @@ struct WConst {           // per-parameter constants, built on the device by k_w
     int nfar_i, nfar_j;   // rows of the new / previous set outside the range the split-operand kernel is exact on (k_wrows)
     int lim_i;            // more far new rows than this: the fp64 kernel takes the whole call
     double centre[W_MAXP]; // robust column centre of the previous set (k_wcentre): both sets are centred here
+    unsigned long long hb_lo, hb_hi;   // KS_TOPN: smallest / largest norm hb of the previous rows that take part, as order-preserving integers (k_whb)
 };
 
 constexpr double W_SQRT_LOG2E = 1.2011224087864497825;     // sqrt(log2 e): a.b then comes out in base 2
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64) void k_wprep(const double* __restrict__ dv_prev
     }
     if (threadIdx.x != 0) return;
     wc->C = C; wc->nzero = nz; wc->logC = 0.0; wc->far = 0; wc->nfar_i = 0; wc->nfar_j = 0; wc->lim_i = lim_i;
+    wc->hb_lo = ~0ull; wc->hb_hi = 0ull;
 }
 
 // scaled copies: out[row*PP + p] = (in[row + ld*p] - centre[p]) * scale[p]   (row-major, zero padded to PP);
@@ -448,7 +450,9 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
                                                double* __restrict__ out, double* __restrict__ hb,
                                                unsigned short* __restrict__ tiles, int ops, unsigned char* __restrict__ far_flag,
                                                unsigned* __restrict__ far_list, int* __restrict__ ha_int, double* __restrict__ ha_frac,
-                                               int fold /* KS_FOLD: norm pieces in K-slots 13..15 of the limb operands, no norm operand */) {
+                                               int fold /* KS_FOLD: norm pieces in K-slots 13..15 of the limb operands, no norm operand */,
+                                               const unsigned* __restrict__ rank /* KS_TOPN: the tile position of every row (its rank by norm top), or NULL */,
+                                               float* __restrict__ topf /* ... and the tops as f32, by tile position */) {
     constexpr int G = 2 * NCH, RW = 64 / G;
     const int lane = threadIdx.x & 63, g = lane / RW, rr = lane % RW;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -507,8 +511,9 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
         valid = false;
     }
     if (!is_prev && g == 0) far_flag[r] = far ? 1 : 0;
-    unsigned short* tb = tiles + (r >> 5) * (size_t)ops * 512;
-    const unsigned r32 = (unsigned)(r & 31);
+    const size_t spos = (rank && inrange) ? (size_t)rank[r] : r;      // where the row sits in the tiles (padding rows: behind all others either way)
+    unsigned short* tb = tiles + (spos >> 5) * (size_t)ops * 512;
+    const unsigned r32 = (unsigned)(spos & 31);
     const int c = g >> 1, h = g & 1;
     unsigned pk[KS_NL][4];
     unsigned top_pc[3] = {0u, 0u, 0u}, low_pc[3] = {0u, 0u, 0u};
@@ -542,7 +547,9 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
         if (is_prev && !fold) {
             unsigned pc[6];
             unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
-            ks_pieces(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, pc);
+            const double hbv = valid ? 0.5 * nrow + lw : KS_HB_ZERO;
+            ks_pieces(hbv, KS_XUNIT_INV, pc);
+            if (topf) topf[spos] = (float)(rint(hbv * KS_XUNIT_INV) / KS_XUNIT_INV);     // (the top ks_pieces splits off)
             // K-slots 6,7 = -1 for the rows an MFMA result holds in its lanes 0..31 (bit 2 of the row clear), 14,15 = -1 for the others:
             // against a B operand whose slots 6,7 / 14,15 carry the pieces of n -- the LAST four bytes of every lane's sixteen, so the
             // kernel builds that operand without a lane select --, the lane's own batch reference is subtracted from exactly its rows
@@ -672,11 +679,23 @@ struct KsRef { float p0, p1, p2, p3; };        // the four running f32 sums of a
 // step stays an instruction of its own: scripts/mfma_merge_probe.hip), and no norm operand to stream (the -1 entries the -n step
 // needs are a per-lane constant).  The matrix pipe's energy is what bounds this kernel.
 constexpr int KS_FOLD = 100;               // variant tag KS_FOLD + chunks: 101, 102, 104
-template <int V> __host__ __device__ constexpr int kz_nch() { return V > KS_FOLD ? V - KS_FOLD : V; }
-template <int V> __host__ __device__ constexpr bool kz_fold() { return V > KS_FOLD; }
-template <int V> __host__ __device__ constexpr int kz_nexact() { return V > KS_FOLD ? V - KS_FOLD : 1 + V; }
+// KS_TOPN + 1, 2, 4 = full chunks (14..16, 30..32, 62..64 parameters: no spare K-slot) with ONE MFMA less than the plain variants:
+// the norm top is not subtracted by a step of its own in front of the batch reference but TOGETHER with the reference, in one
+// bf16 step (-1 against the top pieces, the pieces of n against the -1 entries): X' - top - n is exact for every result within
+// 2^-128 of the batch's largest (scripts/mfma_topn_probe.hip: 0 of 2 048 000 such results inexact), the others flush to zero
+// anyway.  The reference has to come from X' = h0.h0' alone then: n = floor(max X' - tmin) with tmin the smallest top of the
+// tile, which is only close to the largest X' - top if the tile's tops are close to one another -- so the previous set's tiles
+// are filled in the ORDER OF THE ROWS' TOPS (launch_weights_prev: k_whb, a stable sort, k_wrows writing every row to its rank;
+// pair sums do not care about the order of their terms): the spread inside a tile is the set's range / its tiles.  Taking the
+// maximum of X' - top row by row instead (16 subtractions per lane and tile) cost more than the MFMA saved (+5.7 % at 16
+// parameters); this way the vector pipe gets one subtraction per batch.
+constexpr int KS_TOPN = 200;
+template <int V> __host__ __device__ constexpr int kz_nch() { return V > KS_TOPN ? V - KS_TOPN : V > KS_FOLD ? V - KS_FOLD : V; }
+template <int V> __host__ __device__ constexpr bool kz_fold() { return V > KS_FOLD && V < KS_TOPN; }
+template <int V> __host__ __device__ constexpr bool kz_topn() { return V > KS_TOPN; }
+template <int V> __host__ __device__ constexpr int kz_nexact() { return V > KS_FOLD ? kz_nch<V>() : 1 + V; }
 template <int NCH>
-__host__ __device__ constexpr int kz_nsteps() { return NCH > KS_FOLD ? 1 + 6 * (NCH - KS_FOLD) : 3 + 6 * NCH; }
+__host__ __device__ constexpr int kz_nsteps() { return kz_fold<NCH>() ? 1 + 6 * kz_nch<NCH>() : kz_topn<NCH>() ? 2 + 6 * kz_nch<NCH>() : 3 + 6 * NCH; }
 // step S of a batch: 0 norm top; 1..NCH h0.h0'; [vector: n]; NCH+1: -n; NCH+2: norm low; then 5 products per chunk
 // (folded: 0..NCH-1 h0.h0', the last chunk's with the norm top; [vector: n]; NCH: -n; then 5 products per chunk, the last chunk's
 // (h0 2^-11).(r2' 2^11) with the norm low)
@@ -693,6 +712,29 @@ __device__ __forceinline__ void kz_mfma(const uint4* A, const uint4* B, const ui
             Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, NB[0]), __builtin_bit_cast(bf16x8, BN), Z, 0, 0, 0);
         } else {
             constexpr int q = S - (C + 1), c = q / 5, l = 1 + q % 5;             // products 1..5 of KS_LA / KS_LB
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c * KS_NL + KS_LA[l]]),
+                                                       __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]), Z, 0, 0, 0);
+        }
+    } else if constexpr (kz_topn<NCH>()) {
+        constexpr int C = kz_nch<NCH>();
+        if constexpr (S == 0) {
+            // a WIDE tile (its tops spread over more than KS_TOPN_SPREAD: the sparse tail of the set) takes the plain variant's
+            // route -- the norm top in a step of its own, in front of everything -- so that its reference is the maximum of X' - top
+            // itself; the tile's info word says so (mask 0), and the reference step below then leaves the top out of its operand
+            if (__builtin_amdgcn_readfirstlane(A[C * KS_NL + 1].y) == 0u) {
+                Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[C * KS_NL]), __builtin_bit_cast(bf16x8, NB[0]), Z0, 0, 0, 0);
+                Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), __builtin_bit_cast(f16x8, B[0]), Z, 0, 0, 0);
+            } else {
+                Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), __builtin_bit_cast(f16x8, B[0]), Z0, 0, 0, 0);
+            }
+        } else if constexpr (S < C) {
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[S * KS_NL]), __builtin_bit_cast(f16x8, B[S * KS_NL]), Z, 0, 0, 0);
+        } else if constexpr (S == C) {          // - top - n
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[C * KS_NL]), __builtin_bit_cast(bf16x8, BN), Z, 0, 0, 0);
+        } else if constexpr (S == C + 1) {      // - low
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[C * KS_NL]), __builtin_bit_cast(bf16x8, NB[1]), Z, 0, 0, 0);
+        } else {
+            constexpr int q = S - (C + 2), c = q / 5, l = 1 + q % 5;
             Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c * KS_NL + KS_LA[l]]),
                                                        __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]), Z, 0, 0, 0);
         }
@@ -719,7 +761,8 @@ __device__ __forceinline__ void kz_mfma_range(const uint4* A, const uint4* B, co
     }
 }
 // n = floor(max of the lane's 16 values) and the B operand that subtracts it (see above); |n| < 2048: two bf16 pieces
-__device__ __forceinline__ void kz_reference(const f32x16& Z, unsigned lane, int& n, uint4& BN) {
+template <int V>
+__device__ __forceinline__ void kz_reference(const f32x16& Z, const uint4* A, const uint4& NB0, unsigned lane, int& n, uint4& BN) {
     // The first read of the freshly written accumulator is an instruction the compiler knows (it places the wait states a VALU
     // read of an MFMA result needs; it does not look inside inline assembly): ONE v_max_f32 of Z[0] with itself (fmaxf of two
     // accumulator values is three instructions: each input is quieted first); the v_max3_f32 tree follows.
@@ -728,7 +771,15 @@ __device__ __forceinline__ void kz_reference(const f32x16& Z, unsigned lane, int
     const float m0 = ks_max3(f0, Z[1], Z[2]), m1 = ks_max3(Z[3], Z[4], Z[5]), m2 = ks_max3(Z[6], Z[7], Z[8]),
                 m3 = ks_max3(Z[9], Z[10], Z[11]), m4 = ks_max3(Z[12], Z[13], Z[14]);
     const float ma = ks_max3(m0, m1, m2), mb = ks_max3(m3, m4, Z[15]);
-    const float m = ks_max3(ma, mb, mb);
+    float m = ks_max3(ma, mb, mb);
+    if constexpr (kz_topn<V>()) {
+        // the tile's info words (behind its operands): its smallest top and an all-ones mask, or 0 and 0 for a wide tile (whose
+        // top is in the accumulator already: kz_mfma, step 0)
+        const uint4 ti = A[kz_nch<V>() * KS_NL + 1];
+        m -= __uint_as_float(ti.x);
+        BN.x = NB0.x & ti.y;
+        BN.y = NB0.y & ti.y;
+    }
     const float nf = __builtin_floorf(m);
     n = (int)nf;
     // n = p1 + p2, two bf16 pieces against the -1 entries of the previous set's norm operand: p1 = n rounded to bf16 (eight
@@ -751,7 +802,7 @@ __device__ __forceinline__ void kz_slots(const uint4* An, const uint4* Bn, const
         constexpr int NS = kz_nsteps<NCH>(), NA = kz_nexact<NCH>();   // NA exact steps, then the reference, then NS - NA more
         if constexpr (R == 0) kz_mfma_range<NCH, 0, NA>(An, Bn, NB, BN, Zn);
         if constexpr (R == 3) {
-            kz_reference(Zn, lane, nn, BN);
+            kz_reference<NCH>(Zn, An, NB[0], lane, nn, BN);
         }
         if constexpr (R >= 3 && R < 7) {
             constexpr int r = R - 3, M = NS - NA;                        // spread the remaining M steps over slots 3..6
@@ -790,7 +841,7 @@ __device__ __forceinline__ void kz_fine(const uint4* An, const uint4* Bn, const 
     if constexpr (R < 16) {
         constexpr int NS = kz_nsteps<NCH>(), NA = kz_nexact<NCH>(), R0 = NA + RO, M = NS - NA, L = 16 - R0;
         if constexpr (R < NA) kz_mfma_range<NCH, R, R + 1>(An, Bn, NB, BN, Zn);
-        if constexpr (R == R0) kz_reference(Zn, lane, nn, BN);
+        if constexpr (R == R0) kz_reference<NCH>(Zn, An, NB[0], lane, nn, BN);
         if constexpr (R >= R0) {
             constexpr int r = R - R0;
             constexpr int s0 = NA + (r * M) / L, s1 = NA + ((r + 1) * M) / L;
@@ -826,9 +877,10 @@ template <int NCH, int WPS, bool PING = (NCH >= 4), int FINE = 0>
 __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict__ at, size_t kn,
                                                       const uint4* __restrict__ bt, unsigned nbt,
                                                       const WConst* __restrict__ wc, const int* __restrict__ ha_int,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ part, const uint2* __restrict__ tmin /* KS_TOPN: two info words per tile */) {
     if (!ks_split_on(wc)) return;                             // the fp64 kernel's turn
     constexpr int OPA = kz_nch<NCH>() * KS_NL, OPB = OPA + (kz_fold<NCH>() ? 0 : 1);
+    constexpr int OPT = kz_topn<NCH>() ? 1 : 0;            // one more register behind a tile's operands: its smallest top (KS_TOPN)
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
     const unsigned slices = gridDim.y, sl = blockIdx.y;
@@ -852,41 +904,45 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
     const int hs0 = ha_int[(it0 + 0) * 32 + (lane & 31)], hs1 = ha_int[(it0 + 1) * 32 + (lane & 31)];
     double acc0 = 0.0, acc1 = 0.0;
     if (t0 < t1) {
-        uint4 A[OPB];
+        uint4 A[OPB + OPT];
 #pragma unroll
         for (int q = 0; q < OPB; q++) A[q] = bt[((size_t)t0 * OPB + q) * 64 + lane];
+        if constexpr (OPT) { const uint2 ti = tmin[t0]; A[OPB] = make_uint4(ti.x, ti.y, 0u, 0u); }
         f32x16 Z0, Z1;
         int n0 = 0, n1 = 0;
         uint4 BN = make_uint4(0u, 0u, 0u, 0u);                   // (kz_reference only ever writes its last component)
         {   // (t0, columns 0): the whole chain up front
             constexpr int NA = kz_nexact<NCH>();
             kz_mfma_range<NCH, 0, NA>(A, B0, NB, BN, Z0);
-            kz_reference(Z0, lane, n0, BN);
+            kz_reference<NCH>(Z0, A, NB[0], lane, n0, BN);
             kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
         }
         if constexpr (!PING) {
         for (unsigned t = t0; t < t1; t++) {
-            uint4 An[OPB];
+            uint4 An[OPB + OPT];
             const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass re-reads its own tile (no branch); unused
 #pragma unroll
             for (int q = 0; q < OPB; q++) An[q] = bt[((size_t)tn * OPB + q) * 64 + lane];
+            if constexpr (OPT) { const uint2 ti = tmin[tn]; An[OPB] = make_uint4(ti.x, ti.y, 0u, 0u); }
             __builtin_amdgcn_sched_barrier(0);
             KsRef q;
             kz_step<NCH, FINE>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
             kz_step<NCH, FINE>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
 #pragma unroll
             for (int q2 = 0; q2 < OPB; q2++) A[q2] = An[q2];
+            if constexpr (OPT) { A[OPB].x = An[OPB].x; A[OPB].y = An[OPB].y; }
         }
         } else {
         // 33..64 parameters: the two operand sets of the previous tiles (17 x 16 bytes per lane each) trade places every pass
         // instead of being copied (at 16 and 32 parameters the same loop was measured 1-3 % SLOWER than the copying one: PING stays off there) -- 68 register moves per 2048 pairs otherwise, on top of the accumulation-register traffic of a
         // kernel that needs more than 256 registers (one wave per SIMD; the compiler parks operands in accumulation registers)
-        uint4 An[OPB];
+        uint4 An[OPB + OPT];
         for (unsigned t = t0; t < t1; t += 2) {
             {
                 const unsigned tn = (t + 1 < t1) ? t + 1 : t;
 #pragma unroll
                 for (int q = 0; q < OPB; q++) An[q] = bt[((size_t)tn * OPB + q) * 64 + lane];
+                if constexpr (OPT) { const uint2 ti = tmin[tn]; An[OPB] = make_uint4(ti.x, ti.y, 0u, 0u); }
             }
             __builtin_amdgcn_sched_barrier(0);
             KsRef q;
@@ -897,6 +953,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
                 const unsigned tn = (t + 2 < t1) ? t + 2 : t + 1;
 #pragma unroll
                 for (int q2 = 0; q2 < OPB; q2++) A[q2] = bt[((size_t)tn * OPB + q2) * 64 + lane];
+                if constexpr (OPT) { const uint2 ti = tmin[tn]; A[OPB] = make_uint4(ti.x, ti.y, 0u, 0u); }
             }
             __builtin_amdgcn_sched_barrier(0);
             kz_step<NCH, FINE>(An, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);     // matrix: (t+1, columns 1); vector: (t+1, columns 0)
@@ -1066,6 +1123,146 @@ int launch_doubled_variance(abc_ctx* ctx, const double* theta, size_t K, size_t 
 // row-major copy b with hb, the limb tiles of the split kernel.  The fused drivers queue it on the side stream at the start of a
 // generation (it runs beside the ranking); st == NULL: the context's stream.  kn_max: the most rows a later launch_weights_raw
 // will handle (its far-row budget).
+// ---- KS_TOPN: the previous set's tiles in the order of the rows' norm tops ------------------------------------------------
+// grouping key of a previous row, step 1: its hb = 1/2 |b|^2 - log2 w' as k_wrows will see it (KS_HB_ZERO for a row that takes no
+// part in the matrix work: weight 0, far), and the smallest / largest hb of the rows that do (exact, order-independent: atomics on
+// order-preserving integers)
+__device__ __forceinline__ unsigned long long ks_okey(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ks_okey_inv(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__global__ __launch_bounds__(256) void k_whb(const double* __restrict__ prev, size_t Kp, int P, WConst* __restrict__ wc,
+                                             const double* __restrict__ w, double* __restrict__ hbk) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= Kp) return;
+    double nn = 0.0;
+    bool far8 = false;
+    for (int p = 0; p < P; p++) {
+        const double v = (prev[r + Kp * (size_t)p] - wc->centre[p]) * wc->scale[p];
+        nn = fma(v, v, nn);
+        far8 = far8 || !(fabs(v) <= KS_BOUND);
+    }
+    const double wr = w[r];
+    double k = KS_HB_ZERO;
+    if (wr != 0.0) {
+        const double lw = -log2(wr);
+        if ((lw >= KS_LW_MIN && lw <= KS_LW_CAP) && !far8 && (nn <= KS_NORM2)) k = 0.5 * nn + lw;
+    }
+    hbk[r] = k;
+    if (k < KS_HB_ZERO) { const unsigned long long o = ks_okey(k); atomicMin(&wc->hb_lo, o); atomicMax(&wc->hb_hi, o); }
+}
+// ... step 2: 255 equal bins between the two (bin 255: the rows that take no part -- they go behind all others) and ONE stable
+// counting pass on that bin (per-block histograms, a scan, ranks by wave ballots: the scheme of select.hip's radix passes, here with
+// the bin computed on the fly and the row's RANK as the only output).  Tiles only need rows of SIMILAR tops -- a tile's spread is a
+// bin or two, 1/255 of the set's range (0.14 at the bench's sets) --, and where the set is sparse the kernel handles a tile the
+// plain way (k_tile_tmin).  (A full 64-bit sort of 1e5 keys took 0.12 ms on the side stream, two generic 8-bit passes 0.11.)
+constexpr int WQ_ITEMS = 8, WQ_CHUNK = 256 * WQ_ITEMS;      // rows per work-group; each wave owns WQ_CHUNK / 4 of them, in order
+__device__ __forceinline__ unsigned ks_qbin(double k, double lo, double hi) {
+    if (!(k < KS_HB_ZERO)) return 255u;
+    const double t = (hi > lo) ? (k - lo) / (hi - lo) * 255.0 : 0.0;
+    return (t >= 254.0) ? 254u : (t <= 0.0 ? 0u : (unsigned)t);
+}
+__global__ __launch_bounds__(256) void k_wq_hist(const double* __restrict__ hbk, size_t Kp, const WConst* __restrict__ wc,
+                                                 unsigned* __restrict__ bh /* [256][nb] */, int nb) {
+    __shared__ unsigned lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const double lo = ks_okey_inv(wc->hb_lo), hi = ks_okey_inv(wc->hb_hi);
+    const size_t base = (size_t)blockIdx.x * WQ_CHUNK;
+#pragma unroll
+    for (int j = 0; j < WQ_ITEMS; j++) {
+        const size_t i = base + (size_t)j * 256 + threadIdx.x;
+        if (i < Kp) atomicAdd(&lh[ks_qbin(hbk[i], lo, hi)], 1u);
+    }
+    __syncthreads();
+    bh[(size_t)threadIdx.x * nb + blockIdx.x] = lh[threadIdx.x];
+}
+// exclusive scan of the bin-major [256][nb] histogram = of the array as it lies in memory; one work-group, through LDS
+__global__ __launch_bounds__(1024) void k_wq_scan(unsigned* __restrict__ bh, int total) {
+    __shared__ unsigned wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (total + 1023) / 1024, i0 = t * per;
+    unsigned sum = 0;
+    for (int i = i0; i < i0 + per && i < total; i++) sum += bh[i];
+    unsigned inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned run = inc - sum;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+    for (int i = i0; i < i0 + per && i < total; i++) { const unsigned v = bh[i]; bh[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_wq_rank(const double* __restrict__ hbk, size_t Kp, const WConst* __restrict__ wc,
+                                                 const unsigned* __restrict__ bh, int nb, unsigned* __restrict__ rank) {
+    __shared__ unsigned whist[4][256];
+    __shared__ volatile unsigned woff[4][256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) whist[w][t] = 0;
+    __syncthreads();
+    const double lo = ks_okey_inv(wc->hb_lo), hi = ks_okey_inv(wc->hb_hi);
+    const size_t seg = (size_t)blockIdx.x * WQ_CHUNK + (size_t)wave * (WQ_CHUNK / 4);
+    unsigned q[WQ_ITEMS];
+#pragma unroll
+    for (int j = 0; j < WQ_ITEMS; j++) {
+        const size_t i = seg + (size_t)j * 64 + lane;
+        q[j] = (i < Kp) ? ks_qbin(hbk[i], lo, hi) : 0u;
+        if (i < Kp) atomicAdd(&whist[wave][q[j]], 1u);
+    }
+    __syncthreads();
+    {
+        unsigned run = bh[(size_t)t * nb + blockIdx.x];          // scanned: the first position of (bin t, this block)
+#pragma unroll
+        for (int w = 0; w < 4; w++) { woff[w][t] = run; run += whist[w][t]; }
+    }
+    __syncthreads();
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < WQ_ITEMS; j++) {
+        const size_t i = seg + (size_t)j * 64 + lane;
+        const bool valid = i < Kp;
+        const unsigned d = q[j];
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        if (valid) rank[i] = woff[wave][d] + (unsigned)__popcll(peers & lt_mask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0) woff[wave][d] += (unsigned)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// a tile's info words: (smallest top, all ones), or (0, 0) if the tops of its rows that take part (below KS_HB_ZERO) spread over
+// more than KS_TOPN_SPREAD -- then the kernel handles the tile as the plain variant would
+constexpr float KS_TOPN_SPREAD = 0.75f;
+__global__ __launch_bounds__(256) void k_tile_tmin(const float* __restrict__ topf, size_t ntiles, uint2* __restrict__ tinfo) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int j = 0; j < 32; j++) {
+        const float v = topf[t * 32 + j];
+        if (v < (float)KS_HB_ZERO) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    }
+    if (mx < mn) { mn = (float)KS_HB_ZERO; mx = mn; }              // no row of the tile takes part
+    const bool wide = !(mx - mn <= KS_TOPN_SPREAD);
+    tinfo[t] = wide ? make_uint2(0u, 0u) : make_uint2(__float_as_uint(mn), 0xffffffffu);
+}
+// full chunks (no spare K-slot) and enough pairs for the sort to pay (it runs on the side stream of the fused drivers, in front of a
+// stage-level call): the variants with one MFMA less
+static bool ks_topn_on(size_t P, bool split, bool fold, size_t pairs) {
+    if (!split || fold) return false;
+    const char* e = getenv("ABC_KDE_TOPN_MIN_PAIRS");                       // (tests: 0 = always; A/B: a huge number = never)
+    const double minp = e ? atof(e) : 4.0e9;
+    return (double)pairs >= minp;
+}
+
 // up to 13 / 17..29 / 33..61 parameters: the variants of the split kernel with two MFMAs fewer (norm pieces in the spare K-slots: KS_FOLD)
 static bool ks_fold_on(size_t P, bool split) {
     static const bool off = getenv("ABC_KDE_NOFOLD") != nullptr;              // A/B switch for measurements
@@ -1094,33 +1291,56 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     double* cpart = (double*)abc_ws_alloc(ctx, (P > 64 ? P : 64) * WC_NB * sizeof(double));
     unsigned short* bt = nullptr;
     unsigned* far_list = nullptr;
+    const bool topn = ks_topn_on(P, split, fold, Kp * kn_max);
+    unsigned* rank = nullptr;
+    uint2* tmin = nullptr;
+    float* topf = nullptr;
+    double* hbk = nullptr;
+    unsigned* qh = nullptr;
     if (split) {
         bt = (unsigned short*)abc_ws_alloc(ctx, nbt * opb * 1024);
         far_list = (unsigned*)abc_ws_alloc(ctx, KS_MAX_FAR_J * sizeof(unsigned));
         if (!bt || !far_list) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+        if (topn) {
+            rank = (unsigned*)abc_ws_alloc(ctx, Kp * sizeof(unsigned));
+            tmin = (uint2*)abc_ws_alloc(ctx, nbt * sizeof(uint2));
+            topf = (float*)abc_ws_alloc(ctx, nbt * 32 * sizeof(float));
+            hbk = (double*)abc_ws_alloc(ctx, Kp * sizeof(double));
+            qh = (unsigned*)abc_ws_alloc(ctx, (size_t)256 * ((Kp + WQ_CHUNK - 1) / WQ_CHUNK) * sizeof(unsigned));
+            if (!rank || !tmin || !topf || !hbk || !qh) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
+        }
     }
     if (!wc || !b || !hb || !cpart) ABC_FAIL(ctx, ABC_ERR_NOMEM, "weights: workspace exhausted");
     const double* centre = (const double*)((const char*)wc + offsetof(WConst, centre));
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(64), 0, s, dv_prev, (int)P, wc, (int)(kn_max / 16 + 32));
     hipLaunchKernelGGL(k_wcentre, dim3((unsigned)P, WC_NB), dim3(256), 0, s, theta_prev, Kp, wc, cpart);
     hipLaunchKernelGGL(k_wcentre_finish, dim3(1), dim3(P > 64 ? 1024 : 64), 0, s, theta_prev, Kp, (int)P, cpart, wc);
+    if (topn) {          // the rows' ranks by norm top (KS_TOPN): keys, a stable sort, the inverse permutation
+        const int nbq = (int)((Kp + WQ_CHUNK - 1) / WQ_CHUNK);
+        hipLaunchKernelGGL(k_whb, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, (int)P, wc, w_prev, hbk);
+        hipLaunchKernelGGL(k_wq_hist, dim3(nbq), dim3(256), 0, s, (const double*)hbk, Kp, (const WConst*)wc, qh, nbq);
+        hipLaunchKernelGGL(k_wq_scan, dim3(1), dim3(1024), 0, s, qh, 256 * nbq);
+        hipLaunchKernelGGL(k_wq_rank, dim3(nbq), dim3(256), 0, s, (const double*)hbk, Kp, (const WConst*)wc, (const unsigned*)qh, nbq, rank);
+        ABC_HIP(ctx, hipGetLastError());
+    }
     if (split) {         // scaled copy, hb and the limb tiles in one pass (k_wrows)
         const size_t rbp = nbt * 32;
         if (NCH == 1)
             hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((rbp / 32 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0, (const unsigned*)rank, topf);
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((rbp / 16 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0, (const unsigned*)rank, topf);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((rbp / 8 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
-                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0);
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0, (const unsigned*)rank, topf);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, s, theta_prev, Kp, Kp,
                            (int)P, PP, wc, centre, (size_t)1, w_prev, b, hb);
     }
+    if (topn) hipLaunchKernelGGL(k_tile_tmin, dim3((unsigned)((nbt + 255) / 256)), dim3(256), 0, s, (const float*)topf, nbt, tmin);
     ABC_HIP(ctx, hipGetLastError());
-    out->wc = wc; out->b = b; out->hb = hb; out->bt = bt; out->far_list = far_list;
+    out->wc = wc; out->b = b; out->hb = hb; out->bt = bt; out->far_list = far_list; out->tmin = (unsigned*)tmin;
     out->Kp = Kp; out->P = P; out->kn_max = kn_max; out->split = split ? 1 : 0; out->ready = 1;
     return ABC_OK;
 }
@@ -1197,13 +1417,13 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         const size_t ra = nat * 32;
         if (NCH == 1)
             hipLaunchKernelGGL(k_wrows<1>, dim3((unsigned)((ra / 32 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0, (const unsigned*)nullptr, (float*)nullptr);
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((ra / 16 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0, (const unsigned*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((ra / 8 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
-                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0);
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0, (const unsigned*)nullptr, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(k_wscale, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, ctx->stream, theta + k0, kn, K,
                            (int)P, PP, wc, centre, (size_t)1, (const double*)nullptr, a, (double*)nullptr);
@@ -1239,22 +1459,31 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             // kz_slots; four waves per SIMD, the reference two slots behind: +0.5 %)
             if (fold && NCH == 1)           // (up to 13 parameters: seven MFMAs per 1024 pairs, no norm operand)
                 hipLaunchKernelGGL((k_kde_split<KS_FOLD + 1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
-                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (fold && NCH == 2)      // (17..29: thirteen instead of fifteen)
                 hipLaunchKernelGGL((k_kde_split<KS_FOLD + 2, 2, false, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
-                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (fold)                  // (33..61: twenty-five instead of twenty-seven)
                 hipLaunchKernelGGL((k_kde_split<KS_FOLD + 4, 1, true, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
-                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (prev->tmin && NCH == 1)      // (14..16 parameters, tiles in the order of the norm tops: eight MFMAs instead of nine)
+                hipLaunchKernelGGL((k_kde_split<KS_TOPN + 1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (prev->tmin && NCH == 2)      // (30..32: fourteen instead of fifteen)
+                hipLaunchKernelGGL((k_kde_split<KS_TOPN + 2, 2, false, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (prev->tmin)                  // (62..64: twenty-six instead of twenty-seven)
+                hipLaunchKernelGGL((k_kde_split<KS_TOPN + 4, 1, true, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (NCH == 1)
                 hipLaunchKernelGGL((k_kde_split<1, 3, true, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
-                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (NCH == 2)
                 hipLaunchKernelGGL((k_kde_split<2, 2>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
-                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else
                 hipLaunchKernelGGL((k_kde_split<4, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
-                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part);
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
         }
         if (PP > 64)
             hipLaunchKernelGGL(k_kde_gen, dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream, a, kn, b, Kp, hb, wc, theta, K, k0,

@@ -494,6 +494,41 @@ def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle, P):
     assert np.max(np.abs(w2 - w) / w) < KDE_TOL["auto"]
 
 
+@pytest.mark.parametrize("P,K,Kp,heavy", [(16, 2500, 6000, False), (14, 1300, 4000, True), (32, 1500, 5000, False), (64, 700, 3000, True)])
+def test_weight_split_kernel_with_tiles_in_the_order_of_the_norm_tops(gpu_ctx, oracle, monkeypatch, P, K, Kp, heavy):
+    """full 16-parameter chunks and enough pairs: the previous set's tiles are filled in the order of the rows' norm tops and the
+    kernel subtracts top and batch reference in one MFMA step (KS_TOPN; forced here at a test's size).  Against the oracle and the fp64
+    kernel, with zero weights and far rows; `heavy`: previous weights over 60 binades, so that the sparse ends of the order make
+    wide tiles (handled the plain way inside the same kernel); bit-identical when repeated; equal to the plain variant's
+    weights to the kernel's tolerance"""
+    from abcsmc_amd import abcutil, _lib
+    wl, th, tp, wp, dv = _weights_case(P, K, Kp, 77 + P)
+    wp = wp.copy()
+    if heavy:
+        wp *= np.exp2(np.random.default_rng(3).uniform(-60, 0, Kp))
+    wp[::101] = 0.0
+    th, tp = th.copy(), tp.copy()
+    unit = np.sqrt(dv) / np.sqrt(np.log2(np.e))
+    th[5, 2] += 12.0 * unit[2]
+    tp[9, P - 1] -= 11.0 * unit[P - 1]
+    pri = _lib.make_priors(wl.prior_spec())
+    ref = oracle.weights_importance(oracle.make_priors(wl.prior_spec()), th, tp, wp, dv)
+    monkeypatch.setenv("ABC_KDE_TOPN_MIN_PAIRS", "1e30")
+    w_plain = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    monkeypatch.setenv("ABC_KDE_TOPN_MIN_PAIRS", "0")
+    w = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    assert gpu_ctx.kde_last_kernel() == _lib.KDE_RAN_SPLIT
+    w2 = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=gpu_ctx)
+    monkeypatch.delenv("ABC_KDE_TOPN_MIN_PAIRS")
+    ok = ref > 0
+    err = np.abs(w - ref)[ok] / ref[ok]
+    print("P = %d tiles by norm top: max rel err %.2e (rms %.2e); against the plain variant %.2e" %
+          (P, err.max(), np.sqrt((err ** 2).mean()), np.max(np.abs(w - w_plain)[ok] / ref[ok])))
+    assert ok.sum() >= K - 1 and err.max() < _kde_tol("auto", P) and np.array_equal(w == 0, ref == 0)
+    assert np.array_equal(w, w2)
+    assert np.max(np.abs(w - w_plain)[ok] / ref[ok]) < 2 * _kde_tol("auto", P)
+
+
 @pytest.mark.parametrize("P,K,Kp", [(40, 2100, 3000), (64, 1500, 4100)])
 def test_weight_split_kernel_accuracy_at_33_to_64_parameters(gpu_ctx, oracle, P, K, Kp):
     """33..64 parameters: four 16-parameter chunks per pair (27 matrix instructions per 1024 pairs, one wave per SIMD, the two
