@@ -241,7 +241,9 @@ def main():
     alg_tf = flops_alg / (kde_ms * 1e-3) / 1e12 if kde_ms > 0 else 0.0
     if which == _lib.KDE_RAN_SPLIT:
         nch_ = 1 if P <= 16 else (2 if P <= 32 else 4)          # 16-parameter chunks of the split kernel
-        mfma_per_block = 6 * nch_ + (1 if P + 3 <= 16 * nch_ else 3)       # (norm steps folded into spare K-slots where the last chunk has three)
+        # (norm steps folded into spare K-slots where the last chunk has three; else, from 4e9 pairs, tiles in the order of the norm
+        # tops and one step for top and batch reference)
+        mfma_per_block = 6 * nch_ + (1 if P + 3 <= 16 * nch_ else (2 if pairs >= 4.0e9 else 3))
         flops_issued = pairs * mfma_per_block * 32.0   # 32 x 32 x 16 x 2 flop per MFMA over 1024 pairs
         # vector issue slots of 4 cycles per pair besides the MFMAs, counted in the kernel's ISA at 16 parameters: 52.5 vector
         # instructions per 1024 pairs (16 v_exp_f32 at two slots each, 15 f32 adds, 8 v_max3_f32, 13.5 others) = 68.5 slots / 16

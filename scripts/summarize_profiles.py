@@ -115,7 +115,9 @@ for c in cfgs:
         kde_ms = ns / 1e6
         pairs = float(K) * Kp
         nch_ = 1 if P <= 16 else (2 if P <= 32 else 4)          # 16-parameter chunks of the split kernel
-        mf = 6 * nch_ + (1 if P + 3 <= 16 * nch_ else 3)       # (norm steps folded into spare K-slots where the last chunk has three)
+        # (norm steps folded into spare K-slots where the last chunk has three; else, from 4e9 pairs, tiles in the order of the norm
+        # tops and one step for top and batch reference)
+        mf = 6 * nch_ + (1 if P + 3 <= 16 * nch_ else (2 if pairs >= 4.0e9 else 3))
         tf = pairs * mf * 32.0 / (ns * 1e-9) / 1e12                      # matrix work ISSUED (limb products of the fp64 operands)
         alg = pairs * (3.0 * P + 1.0)                                    # K K' (3 P + 1) algorithmic flops
         atf = alg / (ns * 1e-9) / 1e12
