@@ -59,6 +59,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     b += (K + Kp) * PPw * 8 + 1024 * 8 + 64 * PPw * 8 + 32768;    // weights: scaled copies of both sets, centre partials, constants
     b += (K + Kp + 512) * (9 * 32 + 8 + 12) + 8192;               // ... and their f16 limb tiles (<= 9 operands of 32 B a row), 1/2|a|^2 parts
     b += (K + 512) * 17 + 16384;                                   // far-row flags, list and fix-up sums
+    b += (Kp + 64) * (8 + 4 + 4 + 1) + (Kp / 2048 + 2) * 256 * 4 + 4096;   // tiles in the order of the norm tops: keys, ranks, tops, tile info, bin counts
     if (K && Kp) b += ((size_t)64 << 20) + 64 * K + ((size_t)16 << 20);   // ... and the per-slice partial sums (abc_kde_slices)
     b += K * 8 + P * P * 8 + P * 8;
     b += Nnext * (8 + 8 + 4 + 4);                                 // parent, seeds, raw streams
