@@ -303,6 +303,7 @@ int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t 
                           uint32_t** raw, uint64_t* parent_uniform = nullptr, size_t K_uniform = 0);
 // parent_uniform (set 0): the weights will be K_uniform copies of 1 / K_uniform whatever the ranking says, their alias table is
 // on the device already (abc_uniform_alias, called BEFORE the fork), so the parents are drawn here too, beside the ranking
+int abc_rng_seeds_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset);
 int abc_side_fork(abc_ctx* ctx);      // records where on the main stream the side stream's work of this generation may start
 // Alias table of K equal weights: gsl_ran_discrete_preproc on K copies of 1.0 / K (bit-identical to the table of the filled
 // weight vector), built on the host on first use for this K and kept in HBM.  The fused drivers call it right after queueing

@@ -526,12 +526,21 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K, ctx->side));
         filled_early = true;
     }
-    if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, io->seeds, Nn, &raw_early, parent_early, K));
-    // ... and so does everything the weight stage needs of the PREVIOUS set (scales, centre, scaled copy, limb tiles)
+    // ... and so does everything the weight stage needs of the PREVIOUS set (scales, centre, scaled copy, limb tiles -- in the
+    // order of the rows' norm tops where that saves the pair sums an MFMA).  Order on the side stream: the draws' taus2 outputs (pure
+    // arithmetic: they run beside the Gram kernel without touching its memory system), the previous set's prologue (the pair sums
+    // need it ~0.3 ms into the generation), THEN the seeds (an output nobody reads before the call returns): the moments' event,
+    // which the main stream waits for in front of the resampling table, is recorded behind all of them on the same stream
+    const bool weighted = io->w && K && Kp && io->theta_prev;
+    const bool moments_side_possible = Nn && P <= 64 && K >= 2 && !uniform_w && !getenv("ABC_MOMENTS_MAIN") && ctx->side;
+    static const int seeds_first = getenv("ABC_SEEDS_FIRST") ? 1 : 0;              // A/B switch for measurements
+    const bool seeds_late = early && weighted && !seeds_first && moments_side_possible;
+    if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, seeds_late ? nullptr : io->seeds, Nn, &raw_early, parent_early, K));
     abc_wprev wprev;
     memset(&wprev, 0, sizeof(wprev));
-    if (io->w && K && Kp && io->theta_prev)
+    if (weighted)
         ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
+    if (seeds_late) ABC_TRY(abc_rng_seeds_early(ctx, rng, 0, Nn, io->seeds, Nn));
     ctx->side_forked = false;
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
@@ -610,7 +619,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // them (round 2 hid them behind the host's alias build).
     double* L_early = nullptr;
     abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool moments_on_side = false;
+    bool moments_on_side = false, seeds_waited = false;
     // (set 0 has nothing to overlap them with: two cross-stream hand-overs for nothing, measured +35 us)
     if (moments_side_planned) {
         if (cfg->multivariate) {
@@ -672,7 +681,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // meanwhile: the MVN factor (covariance + Cholesky), the row-major posterior copy and the seed stream of the
         // perturbation.
         abc_perturb_prep prep = {moments_on_side ? side_out.rows : nullptr, (early && io->seeds) ? 1 : 0, moments_on_side ? side_out.Lpad : nullptr};
-        if (moments_on_side) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_moments, 0));
+        if (moments_on_side) { ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_moments, 0)); seeds_waited = true; }   // (recorded behind the seeds)
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
             uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments;
@@ -737,6 +746,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         int* pspd = (int*)(ctx->status_pin + 32);
         int* pfail = (int*)(ctx->status_pin + 36);
         hdr[0] = 0.0; *pspd = 0; *pfail = 0;
+        if (seeds_late && !seeds_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));     // (never in practice: see below)
         // ONE tiny kernel stores the three words into the (device-visible) pinned block: three copies were three blit launches
         const int* fail_dev = (ctx->sel_bins_ran && ctx->sel_fail_dev) ? (const int*)ctx->sel_fail_dev : nullptr;
         unsigned long long* pgive = (unsigned long long*)(ctx->status_pin + 48);

@@ -626,6 +626,16 @@ int abc_rng_streams_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t 
     return ABC_OK;
 }
 
+// the simulator seeds alone, on the side stream BEHIND whatever is queued there (the fused driver queues them behind the previous
+// set's prologue, which the main stream needs much earlier); ev_side is recorded again behind them
+int abc_rng_seeds_early(abc_ctx* ctx, const abc_rng* rng, uint64_t i0, size_t n, uint64_t* seeds, uint64_t seed_stream_offset) {
+    if (n == 0 || !seeds) return ABC_OK;
+    if (!ctx->side_forked) ABC_TRY(abc_side_fork(ctx));
+    ABC_TRY(launch_seeds(ctx, rng, i0, n, seeds, seed_stream_offset, ctx->side));
+    ABC_HIP(ctx, hipEventRecord(ctx->ev_side, ctx->side));
+    return ABC_OK;
+}
+
 // the previous set's share of the weight stage on the side stream (behind whatever abc_rng_streams_early queued there, or
 // forked here); the main stream waits for ev_prev before launch_weights_raw
 int abc_weights_prev_early(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
