@@ -532,7 +532,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // need it ~0.3 ms into the generation), THEN the seeds (an output nobody reads before the call returns): the moments' event,
     // which the main stream waits for in front of the resampling table, is recorded behind all of them on the same stream
     const bool weighted = io->w && K && Kp && io->theta_prev;
-    const bool moments_side_possible = Nn && P <= 64 && K >= 2 && !uniform_w && !getenv("ABC_MOMENTS_MAIN") && ctx->side;
+    static const int moments_main = getenv("ABC_MOMENTS_MAIN") ? 1 : 0;             // A/B switches for measurements
+    const bool moments_side_possible = Nn && P <= 64 && K >= 2 && !uniform_w && !moments_main && ctx->side;
     static const int seeds_first = getenv("ABC_SEEDS_FIRST") ? 1 : 0;              // A/B switch for measurements
     const bool seeds_late = early && weighted && !seeds_first && moments_side_possible;
     if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, seeds_late ? nullptr : io->seeds, Nn, &raw_early, parent_early, K));
