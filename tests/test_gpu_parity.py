@@ -1167,6 +1167,12 @@ def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp, P):
     assert np.allclose(gen.dv.cpu().numpy(), ref["dv"], rtol=1e-9)
     assert np.array_equal(device.to_numpy(gen.theta), Y[ref["idx"].astype(int)])
     assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    # seeds (device noise): the taus2 outputs right behind the Nn resampling draws -- queued on the side stream BEHIND the previous
+    # set's prologue in weighted generations, complete when the call returns all the same
+    o2 = oracle.rng(67890)
+    for _ in range(Nn):
+        oracle.rng_get(o2)
+    assert np.array_equal(gen.seeds.cpu().numpy().astype(np.uint64), np.array([oracle.rng_get(o2) for _ in range(Nn)], dtype=np.uint64))
     if multivariate:
         L = device.to_numpy(gen.L)
         assert np.allclose(np.tril(L), np.tril(ref["L"]), rtol=1e-7, atol=1e-12)
