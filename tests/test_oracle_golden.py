@@ -273,7 +273,7 @@ def test_split_operand_arithmetic_emulation(P, bound_rms, bound_max):
     line = [l for l in out.stdout.splitlines() if l.startswith("shipped")][0]
     rms, mx = (float(x) for x in re.findall(r"with the f32 accumulator: rms (\S+) max (\S+)", line)[0])
     assert rms < bound_rms and mx < bound_max, line
-    # the f32 evaluation of a batch of 16 terms (ks_slots): what a weight inherits at worst (a row one batch dominates); budget 1e-6, the GPU tests hold 2e-7
+    # the f32 evaluation of a batch of 16 terms (ks_slots): what a weight inherits at worst (a row one batch dominates); budget 1e-6, the GPU tests hold 2.5e-7
     tline = [l for l in out.stdout.splitlines() if "f32 term" in l][0]
     trms, tmax = (float(x) for x in re.findall(r"relative error rms (\S+) max (\S+)", tline)[0])
     assert trms < 6e-8 and tmax < 3e-7, tline
