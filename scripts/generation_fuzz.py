@@ -1,0 +1,113 @@
+"""Whole generations (abc_generation_dev) at random shapes against the CPU oracle: every parameter count from 1 up, metric counts
+that are not multiples of anything, K and K' off the 32-row tiles, first sets and weighted sets, both noise kinds, training
+fractions, component caps.  What must hold: component count equal, the selection identical up to near-ties (same index SET and
+the same order wherever the oracle's distances differ by more than 1e-12 relative), weights within the kernel's bound for the
+parameter count (against the oracle's weights of the oracle's selection when the selections agree), doubled variance 1e-9,
+parents bit for bit when the weights are the oracle's to the last bit (first sets) -- else the parents' distribution is the
+weights', not checked here --, proposals finite and inside the priors' support.
+    python scripts/generation_fuzz.py [out.json] [cases] [seed]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from abcsmc_amd import _lib, abcutil, device, synthetic
+from oracle import pyoracle as oracle
+
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/generation_fuzz.json"
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 2026
+dev = "cuda:0"
+g = np.random.default_rng(seed0)
+rows, fails = [], []
+for case in range(cases):
+    P = int(g.integers(1, 41)) if case % 4 else int(g.choice([1, 2, 4, 5, 8, 13, 14, 16, 17, 29, 30, 32, 33, 48, 61, 62, 64]))
+    M = int(g.integers(max(2, P // 2), 70))
+    N = int(g.integers(600, 6000))
+    K = int(g.integers(max(40, 2 * P + 8), max(50, N // 4)))
+    Kp = 0 if case % 5 == 0 else int(g.integers(max(40, 2 * P + 8), 1500))
+    Nn = int(g.integers(200, 5000))
+    A = int(g.integers(1, min(M, 12) + 1))
+    mv = bool(g.integers(0, 2))
+    tf = float(g.choice([0.5, 0.5, 0.3, 0.8]))
+    sd = int(g.integers(1, 1 << 30))
+    tag = dict(case=case, N=N, M=M, P=P, K=K, Kp=Kp, Nn=Nn, A=A, multivariate=mv, train_frac=tf, seed=sd)
+    try:
+        wl = synthetic.Workload(M, P, sd)
+        dX, dY = wl.rows_device(0, N, dev)
+        obs, spec = wl.observed(), wl.prior_spec()
+        dprev = wl.previous_set_device(Kp, dev) if Kp else ()
+        X, Y = dX.cpu().numpy().T, dY.cpu().numpy().T
+        prev = tuple((dprev[0].cpu().numpy().T, dprev[1].cpu().numpy(), dprev[2].cpu().numpy())) if Kp else ()
+        gen = device.Generation(N, M, P, K, Kp, Nn, tf, A, multivariate=mv, device=dev)
+        r = abcutil.rng(sd)
+        gen.run(dX, dY, device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
+        torch.cuda.synchronize()
+        o = oracle.rng(sd)
+        ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=tf, max_comp=A, multivariate=mv)
+        problems = []
+        if gen.ncomp.value != ref["ncomp"]:
+            problems.append("ncomp %d != %d" % (gen.ncomp.value, ref["ncomp"]))
+        idx = gen.idx.cpu().numpy().astype(np.uint64)
+        same_sel = np.array_equal(idx, ref["idx"])
+        same_set = np.array_equal(np.sort(idx), np.sort(ref["idx"]))
+        if not same_sel:
+            # near-ties: positions that differ must hold distances equal to 1e-12 (the device's own distances)
+            d = gen.dist.cpu().numpy() if hasattr(gen, "dist") else None
+            bad = np.nonzero(idx != ref["idx"])[0]
+            if d is None or not same_set:
+                problems.append("selection differs at %d positions (same set: %s)" % (bad.size, same_set))
+            else:
+                pos = {int(v): i for i, v in enumerate(idx)}
+                worst = max(abs(d[i] - d[pos[int(ref["idx"][i])]]) / max(d[i], 1e-300) for i in bad)
+                if worst > 1e-10:
+                    problems.append("selection order differs beyond near-ties (%.2e)" % worst)
+        w = gen.w.cpu().numpy()
+        tol = 1e-12 if not Kp else (1e-9 if (P < 5 or P > 64) else 7e-7 if P > 32 else 3e-7 if P > 16 else 2.5e-7)
+        werr = None
+        if same_sel:
+            ok = ref["w"] > 0
+            if not np.array_equal(w == 0, ref["w"] == 0):
+                problems.append("zero pattern of the weights differs")
+            elif ok.any():
+                werr = float(np.max(np.abs(w - ref["w"])[ok] / ref["w"][ok]))
+                if werr > tol:
+                    problems.append("weights %.2e > %.1e" % (werr, tol))
+            dverr = float(np.max(np.abs(gen.dv.cpu().numpy() - ref["dv"]) / np.maximum(np.abs(ref["dv"]), 1e-300)))
+            if dverr > 1e-9:
+                problems.append("dv %.2e" % dverr)
+            if not np.array_equal(device.to_numpy(gen.theta), Y[ref["idx"].astype(int)]):
+                problems.append("gathered rows differ")
+            if not Kp and not np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"]):
+                problems.append("parents differ (first set)")
+            if mv and K > P + 1:
+                L = device.to_numpy(gen.L)
+                if not np.allclose(np.tril(L), np.tril(ref["L"]), rtol=1e-6, atol=1e-10):
+                    problems.append("L differs")
+        o2 = oracle.rng(sd)
+        for _ in range(Nn):
+            oracle.rng_get(o2)
+        if not np.array_equal(gen.seeds.cpu().numpy().astype(np.uint64)[:Nn], np.array([oracle.rng_get(o2) for _ in range(Nn)], dtype=np.uint64)):
+            problems.append("seeds differ")
+        nxt = device.to_numpy(gen.next)
+        if nxt.shape != (Nn, P) or not np.isfinite(nxt).all():
+            problems.append("proposals not finite")
+        else:
+            for p in range(P):
+                k, a, b = spec[p]
+                if k == 2 and (nxt[:, p].min() < a or nxt[:, p].max() > b):
+                    problems.append("proposal outside the support of parameter %d" % p)
+                if k == 1 and (np.any(nxt[:, p] != np.round(nxt[:, p])) or nxt[:, p].min() < a or nxt[:, p].max() > b):
+                    problems.append("integer parameter %d off its grid / range" % p)
+        tag.update(ncomp=int(ref["ncomp"]), same_selection=bool(same_sel), weight_err=werr, problems=problems)
+    except Exception as e:        # noqa: BLE001 -- a crash of one case is a finding, the sweep goes on
+        tag.update(problems=["exception: %r" % (e,)])
+    rows.append(tag)
+    if tag["problems"]:
+        fails.append(tag)
+    print(("FAIL " if tag["problems"] else "ok   ") + json.dumps(tag), flush=True)
+json.dump({"cases": len(rows), "failed": len(fails), "failures": fails, "rows": rows}, open(out, "w"), indent=1)
+print("%d cases, %d with problems" % (len(rows), len(fails)))
