@@ -1,0 +1,33 @@
+"""Randomised differential tests: the fuzzers under scripts/ (each a stand-alone program that replays random shapes and unfriendly
+data against the CPU oracle and prints one verdict line) at a small number of cases with fixed seeds.  Their long runs are
+summarised under profiles/r03_*_fuzz.json; the far-row bug of round 3 (weights.hip, k_wrows: a far coordinate beyond the first
+eight parameters) was found by the first of them."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,cases,seed", [
+    ("kde_accuracy_sweep.py", 1, None),          # every parameter count 5..64, one set each, both orders of the previous tiles
+    ("weights_fuzz.py", 150, 21),
+    ("generation_fuzz.py", 60, 22),
+    ("ranking_fuzz.py", 60, 23),
+    ("resample_fuzz.py", 80, 24),
+    ("sharded_fuzz.py", 6, 25),
+])
+def test_fuzzer_finds_nothing(tmp_path, script, cases, seed):
+    out = str(tmp_path / (script + ".json"))
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", script), out, str(cases)] + ([str(seed)] if seed is not None else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    tail = (p.stdout[-3000:] + p.stderr[-2000:])
+    assert p.returncode == 0, tail
+    last = p.stdout.strip().splitlines()[-1]
+    if script == "kde_accuracy_sweep.py":
+        assert last.endswith("over the asserted bound: none"), tail
+    else:
+        assert " 0 with problems" in last, "\n".join(l for l in p.stdout.splitlines() if l.startswith("FAIL"))[:4000] + "\n" + last
