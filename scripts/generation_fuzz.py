@@ -34,6 +34,14 @@ for case in range(cases):
     A = int(g.integers(1, min(M, 12) + 1))
     mv = bool(g.integers(0, 2))
     tf = float(g.choice([0.5, 0.5, 0.3, 0.8]))
+    if os.environ.get("FUZZ_LARGE"):        # sizes at which the other code paths run: sorts beyond 2^18 keys, the radix select (2 K > N), the device alias build
+        P = int(g.choice([3, 8, 12, 16, 20, 32, 40]))
+        M = int(g.integers(max(4, P // 2), 40))
+        N = int(g.choice([70000, 150000, 270000, 400000]))
+        K = int(g.choice([N // 10, N // 3, (N * 3) // 5, 20000, 33333]))
+        Kp = 0 if case % 4 == 0 else int(g.integers(200, 1500))
+        Nn = int(g.choice([5000, 100000, 270000]))
+        A = int(g.integers(1, min(M, 10) + 1))
     sd = int(g.integers(1, 1 << 30))
     wilcoxon = bool(g.integers(0, 4) == 0) and P <= 40
     dups = bool(g.integers(0, 5) == 0)                    # duplicated rows: exact distance ties, broken by the row index
