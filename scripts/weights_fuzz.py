@@ -83,7 +83,9 @@ for case in range(cases):
             continue
         spec = [(_lib.PRIOR_GAUSS, 0.0, 30.0)] * P
         pri, opri = _lib.make_priors(spec), oracle.make_priors(spec)
-        ref = oracle.weights_importance(opri, th, tp, wp, dv)
+        epan = bool(os.environ.get("FUZZ_EPAN"))         # the Epanechnikov extension instead of the reference's Gaussian kernel
+        ctx.set_weight_kernel(_lib.WEIGHT_EPANECHNIKOV if epan else _lib.WEIGHT_GAUSSIAN)
+        ref = (oracle.weights_epanechnikov if epan else oracle.weights_importance)(opri, th, tp, wp, dv)
         w = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=ctx)
         ran = ctx.kde_last_kernel()
         w2 = abcutil.weight_predictive_prior(pri, th, tp, wp, dv, ctx=ctx)
@@ -125,6 +127,7 @@ for case in range(cases):
         tag.update(kernel="split" if ran == _lib.KDE_RAN_SPLIT else "fp64", problems=problems)
     except Exception as e:        # noqa: BLE001
         tag.update(problems=["exception: %r" % (e,)])
+    ctx.set_weight_kernel(_lib.WEIGHT_GAUSSIAN)
     rows.append(tag)
     if tag["problems"]:
         fails.append(tag)
