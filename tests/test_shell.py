@@ -22,7 +22,10 @@ LIBDIR = os.path.join(ROOT, "abcsmc_amd")
 
 
 def _compile(src, exe):
-    subprocess.check_call(["g++", "-std=c++17", "-O1", src, "-o", exe, "-L" + LIBDIR, "-labcsmc_hip", "-ldl",
+    # ABC_TEST_CXXFLAGS: extra flags for the host programs, e.g. "-fsanitize=address,undefined -g" (with ASAN_OPTIONS=detect_leaks=0:
+    # the HIP runtime the library links keeps its allocations) -- how the shell was run under the sanitizers on the CPU
+    extra = os.environ.get("ABC_TEST_CXXFLAGS", "").split()
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + extra + [src, "-o", exe, "-L" + LIBDIR, "-labcsmc_hip", "-ldl",
                            "-Wl,-rpath," + LIBDIR])
     return exe
 
