@@ -17,6 +17,11 @@ int abc_ws_reserve(abc_ctx* ctx, size_t bytes) {
         ctx->ws_bytes = bytes;
     }
     ctx->ws_off = 0;
+    // ABC_WS_POISON=<byte> (debugging): every entry point starts from a workspace filled with that byte (ff: NaNs and huge
+    // integers), so that a kernel which reads a word nobody wrote in THIS call shows up in the tests instead of inheriting
+    // whatever the previous call left there
+    static const char* poison = getenv("ABC_WS_POISON");
+    if (poison && ctx->ws) ABC_HIP(ctx, hipMemsetAsync(ctx->ws, (int)strtol(poison, nullptr, 16), ctx->ws_bytes, ctx->stream));
     return ABC_OK;
 }
 void* abc_ws_alloc(abc_ctx* ctx, size_t bytes) {
