@@ -45,6 +45,58 @@ __device__ __forceinline__ void cov_chol_wave(const double* __restrict__ stats, 
     CH_SYNC();
 }
 
+// The same factorisation with the matrix in REGISTERS (up to 32 parameters): lane i holds row i, the entries of row j that
+// column j's update needs come through v_readlane as scalar operands -- no LDS round trip per product, no barrier per column
+// (the LDS version: ~120 dependent load-multiply-add steps and 48 wave barriers at 16 parameters, most of k_post_tail's 17 us on
+// the critical path of a first set).  Same operations in the same order as above (GSL's cholesky_decomp1: temp += a * b with
+// separate multiply and add, A_ij -= temp, the column scaled by 1 / sqrt(A_jj)).  Rows and columns beyond P: identity.
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int PP>
+__device__ __forceinline__ void cov_chol_regs(const double* __restrict__ stats, int P, double* __restrict__ Lout, int* __restrict__ status,
+                                              double* __restrict__ Lpad, int lane) {
+    const StatsLayout SL = stats_layout(P, 0);
+    const double n = stats[SL.off_n] + stats[SL.off_n + 1];
+    const bool row = lane < P;
+    const double di = row ? (stats[SL.off_sum[0] + lane] + stats[SL.off_sum[1] + lane]) / n : 0.0;
+    double a[PP];
+#pragma unroll
+    for (int b = 0; b < PP; b++) {
+        const double db = lane_bcast(di, b);                       // (lanes >= P hold 0; columns >= P are not used below)
+        double c = (lane == b) ? 1.0 : 0.0;
+        if (row && b < P) {
+            const double g = stats[SL.off_G[0] + lane + SL.C16 * b] + stats[SL.off_G[1] + lane + SL.C16 * b];
+            c = (g - n * di * db) / (n - 1.0);
+            if (lane == b) c = 2.0 * c;                            // AbcUtil.cpp:475-479
+        }
+        a[b] = c;
+    }
+    int ok = 1;
+#pragma unroll
+    for (int j = 0; j < PP; j++) {
+        double temp = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) temp += lane_bcast(a[k], j) * a[k];
+        if (lane >= j) a[j] += -1.0 * temp;
+        const double ajj = lane_bcast(a[j], j);
+        if (j < P && !(ajj > 0.0)) { ok = 0; break; }              // GSL_EDOM in the reference (process abort); wave-uniform
+        const double inv = 1.0 / sqrt(ajj);
+        if (lane >= j) a[j] *= inv;
+    }
+    if (row) {
+#pragma unroll
+        for (int b = 0; b < PP; b++) if (b < P) Lout[lane + P * b] = a[b];
+    }
+    if (Lpad && lane < PP) {
+#pragma unroll
+        for (int b = 0; b < PP; b++) Lpad[lane + PP * b] = (row && b < P && b <= lane) ? a[b] : 0.0;
+    }
+    if (lane == 0) *status = ok ? 0 : -1;
+}
+
 // gA != NULL (more than 128 parameters: P x P doubles exceed the LDS): the work matrix lives there instead
 __global__ __launch_bounds__(64) void k_cov_chol(const double* __restrict__ stats, int P, double* __restrict__ Lout,
                                                  int* __restrict__ status, double* __restrict__ gA) {
@@ -81,6 +133,10 @@ __global__ __launch_bounds__(256) void k_post_tail(const double* __restrict__ th
         if (dv) for (int p = threadIdx.x; p < P; p += 256) dv[p] = dv_of_stats(stats, P, p);
         if (Lout && threadIdx.x < 64) {
             const int lane = threadIdx.x;
+            if constexpr (PP <= 32) {
+                cov_chol_regs<PP>(stats, P, Lout, spd, Lpad, lane);
+                return;
+            }
             cov_chol_wave(stats, P, sA, sA + P * P, Lout, spd, lane);
             if (Lpad) {
                 for (int e = lane; e < PP * PP; e += 64) {
