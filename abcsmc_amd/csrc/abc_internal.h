@@ -60,6 +60,8 @@ struct abc_ctx {
     int* alias_fail_dev;               // device flag of the last device build
     unsigned long long alias_dev_builds, alias_dev_fallbacks;   // device builds queued / found unusable (abc_alias_stats)
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
+    const double* gram_shift_override; // launch_theta_stats inside a generation: the Gram kernel centres the winners' columns with the shift of the
+                                       // generation's own statistics pass (no pilot launch for 5 us of kernel in front of the moments); NULL otherwise
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
     unsigned long long giveups_seen;   // device counter as of the last generation's end (abc_generation_dev warns when it grows)
     int timers_open;                   // StageTimers between their two events (the ring is only drained when none is)
@@ -250,7 +252,9 @@ int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, si
 #define ABC_INTERNAL_RETRY 1      // launch_resample: the caller's abort flag was set when the host looked (not an error code of the ABI)
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
 // K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor
-int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);
+// shift (optional, device, P doubles): centres of the columns good enough for the one-pass sums (no pilot launch then; the record's
+// own shift slot stays unwritten: covariance and doubled variance do not read it)
+int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out, const double* shift = nullptr);
 // everything that follows from the posterior's statistics record in ONE launch (mvn.hip: k_post_tail; P <= 64; fields optional)
 struct abc_theta_fused { double* dv; double* L; int* spd; double* rows /* K x PP row-major, zero padded */; double* Lpad /* PP x PP */; };
 int launch_post_tail(abc_ctx*, const double* theta, size_t K, size_t P, const double* stats, const abc_theta_fused* f);

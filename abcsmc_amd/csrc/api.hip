@@ -604,6 +604,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ctx->sel_force_radix = false;
         return rc;
     };
+    // (the winners' columns are centred with the shift the generation's statistics pass took for the parameter columns: the mean of
+    // the first 256 particles is as good a centre for the one-pass sums of the winners as a pilot of their own)
+    const double* theta_shift = (io->Y && Pstat == P) ? stats + SL.off_shift + M : nullptr;
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;        // moments of the posterior: shared by dv and the MVN factor
     // Weighted generations with proposals: the kernel density of the weights uses the PREVIOUS set's variance, so the new set's
@@ -614,7 +617,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (defer_moments) {
     } else if (P <= 64 && K >= 2) {
         StageTimer tm(ctx, ST_GATHER_DV);
-        ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats));
+        ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats, theta_shift));
         ABC_TRY(launch_dv_from_stats(ctx, theta_stats, P, dv));
     } else {
         ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
@@ -642,7 +645,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->side;                        // the launchers below queue on the context's stream
         double* st = nullptr;
-        int rc = launch_theta_stats(ctx, theta, K, P, &st);
+        int rc = launch_theta_stats(ctx, theta, K, P, &st, theta_shift);
         if (rc == ABC_OK) rc = launch_post_tail(ctx, theta, K, P, st, &side_out);
         ctx->stream = main_stream;
         ABC_TRY(rc);
@@ -690,17 +693,17 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         if (moments_on_side) { ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_moments, 0)); seeds_waited = true; }   // (recorded behind the seeds)
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
-            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments;
+            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments; const double* theta_shift;
         };
         PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, moments_on_side ? nullptr : L, spd_dev, dv,
-                      defer_moments && !moments_on_side};
+                      defer_moments && !moments_on_side, theta_shift};
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
             int fused_done = 0;
             if (q->moments) {
                 StageTimer tm(q->ctx, ST_GATHER_DV);
                 double* st = nullptr;
-                ABC_TRY(launch_theta_stats(q->ctx, q->theta, q->K, q->P, &st));
+                ABC_TRY(launch_theta_stats(q->ctx, q->theta, q->K, q->P, &st, q->theta_shift));
                 q->theta_stats = st;
                 // doubled variance, proposal factor and the perturbation's inputs (row-major copy, padded factor) in ONE launch
                 abc_theta_fused f = {q->dv, q->L, q->spd_dev, nullptr, nullptr};

@@ -4,6 +4,8 @@
 // place, strict upper triangle keeps the covariance entries).
 // The K x P cross-products come from the same one-pass MFMA Gram kernel as the PLS statistics
 // (gram.hip, theta treated as a P-column matrix); the P x P factorisation is one wavefront in LDS.
+#include <stdlib.h>
+
 #include "abc_internal.h"
 
 namespace {
@@ -170,13 +172,17 @@ __global__ void k_dv_from_stats(const double* __restrict__ stats, int P, double*
 }  // namespace
 
 // one pass over the K x P posterior: pilot shift + Gram (k_gram<.,0>) -> statistics record in the arena
-int launch_theta_stats(abc_ctx* ctx, const double* theta, size_t K, size_t P, double** stats_out) {
+int launch_theta_stats(abc_ctx* ctx, const double* theta, size_t K, size_t P, double** stats_out, const double* shift) {
     const StatsLayout SL = stats_layout(P, 0);
     double* stats = (double*)abc_ws_alloc(ctx, SL.len * sizeof(double));
     if (!stats) ABC_FAIL(ctx, ABC_ERR_NOMEM, "theta stats: workspace exhausted");
-    ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
+    static const int pilot_always = getenv("ABC_THETA_PILOT") ? 1 : 0;          // A/B switch for measurements
+    if (pilot_always) shift = nullptr;
+    if (!shift) ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
     ctx->in_mvn = true;
+    ctx->gram_shift_override = shift;
     const int rc_acc = launch_stats_accumulate(ctx, theta, theta, K, K, K, P, 0, 0, K, stats);
+    ctx->gram_shift_override = nullptr;
     ctx->in_mvn = false;
     ABC_TRY(rc_acc);
     *stats_out = stats;
