@@ -60,10 +60,9 @@ struct abc_ctx {
     int* alias_fail_dev;               // device flag of the last device build
     unsigned long long alias_dev_builds, alias_dev_fallbacks;   // device builds queued / found unusable (abc_alias_stats)
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
-    const double* gram_shift_override; // launch_theta_stats inside a generation: the Gram kernel centres the winners' columns with the shift of the
-                                       // generation's own statistics pass (no pilot launch for 5 us of kernel in front of the moments); NULL otherwise
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
     unsigned long long giveups_seen;   // device counter as of the last generation's end (abc_generation_dev warns when it grows)
+    unsigned long long giveups_dev_known;   // the device counter as the host last read it (re-read only when the pinned flag word says it moved)
     int timers_open;                   // StageTimers between their two events (the ring is only drained when none is)
     unsigned long long timing_dropped; // samples that found the ring full while a timer was open (abc_timing_read reports them)
     int* kde_which;  // device: which weight kernel produced the last sums (ABC_KDE_RAN_*), written by k_wfinish
@@ -252,11 +251,14 @@ int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, si
 #define ABC_INTERNAL_RETRY 1      // launch_resample: the caller's abort flag was set when the host looked (not an error code of the ABI)
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
 // K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor
-// shift (optional, device, P doubles): centres of the columns good enough for the one-pass sums (no pilot launch then; the record's
-// own shift slot stays unwritten: covariance and doubled variance do not read it)
-int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out, const double* shift = nullptr);
+int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);
 // everything that follows from the posterior's statistics record in ONE launch (mvn.hip: k_post_tail; P <= 64; fields optional)
-struct abc_theta_fused { double* dv; double* L; int* spd; double* rows /* K x PP row-major, zero padded */; double* Lpad /* PP x PP */; };
+struct abc_theta_fused {
+    double* dv; double* L; int* spd; double* rows /* K x PP row-major, zero padded */; double* Lpad /* PP x PP */;
+    // (fused drivers) the generation's status words straight into the pinned block, by the work-group that has the Cholesky status
+    // anyway: the model header (component count; NULL: none) and the status -- no copy kernel behind the proposals then
+    const double* model_hdr; double* hdr_pin; int* spd_pin;
+};
 int launch_post_tail(abc_ctx*, const double* theta, size_t K, size_t P, const double* stats, const abc_theta_fused* f);
 int launch_dv_from_stats(abc_ctx*, const double* stats, size_t P, double* dv);
 int launch_mvn_from_stats(abc_ctx*, const double* stats, size_t P, double* L, int* status_dev);

@@ -182,6 +182,7 @@ extern "C" int abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset) {
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     *count = (uint64_t)dev + (uint64_t)ctx->giveups_host;
+    ctx->giveups_dev_known = reset ? 0ull : dev;
     ctx->giveups_seen = reset ? 0 : (unsigned long long)*count;
     if (reset) ctx->giveups_host = 0;
     return ABC_OK;
@@ -564,6 +565,15 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // (the gather is the first kernel behind the selection: it also stores the selection's give-up flag into the pinned block)
     int* pfail_early = (int*)(ctx->status_pin + 40);
     *pfail_early = 0;
+    volatile unsigned* pgaveup = (volatile unsigned*)(ctx->status_pin + 56);       // raised by a proposal kernel that gives up (note_giveup)
+    *pgaveup = 0u;
+    // the status words the host reads at the generation's end (model header, Cholesky status): zeroed here, written by the
+    // posterior's k_post_tail where that kernel runs -- the copy kernel behind the proposals is then not launched
+    double* const hdr_pin = (double*)ctx->status_pin;
+    int* const spd_pin = (int*)(ctx->status_pin + 32);
+    hdr_pin[0] = 0.0; *spd_pin = 0;
+    bool status_early = false;
+    static const int status_late = getenv("ABC_STATUS_KERNEL") ? 1 : 0;           // A/B switch for measurements
     const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
     // The main stream needs what the side stream queued early (the previous set's tiles, the taus2 outputs) only behind the
     // gather, and those kernels ended long ago: the wait goes IN FRONT of the gather, where the event is certain to have fired
@@ -604,9 +614,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ctx->sel_force_radix = false;
         return rc;
     };
-    // (the winners' columns are centred with the shift the generation's statistics pass took for the parameter columns: the mean of
-    // the first 256 particles is as good a centre for the one-pass sums of the winners as a pilot of their own)
-    const double* theta_shift = (io->Y && Pstat == P) ? stats + SL.off_shift + M : nullptr;
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;        // moments of the posterior: shared by dv and the MVN factor
     // Weighted generations with proposals: the kernel density of the weights uses the PREVIOUS set's variance, so the new set's
@@ -617,7 +624,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (defer_moments) {
     } else if (P <= 64 && K >= 2) {
         StageTimer tm(ctx, ST_GATHER_DV);
-        ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats, theta_shift));
+        ABC_TRY(launch_theta_stats(ctx, theta, K, P, &theta_stats));
         ABC_TRY(launch_dv_from_stats(ctx, theta_stats, P, dv));
     } else {
         ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
@@ -637,6 +644,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         }
         const int PPr = abc_perturb_pp(P);
         side_out.dv = dv; side_out.L = L_early; side_out.spd = spd_dev;
+        if (!status_late) { side_out.model_hdr = simple ? nullptr : model; side_out.hdr_pin = hdr_pin; side_out.spd_pin = L_early ? spd_pin : nullptr; status_early = true; }
         side_out.rows = (double*)abc_ws_alloc(ctx, K * (size_t)PPr * sizeof(double));
         if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
         if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
@@ -645,7 +653,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->side;                        // the launchers below queue on the context's stream
         double* st = nullptr;
-        int rc = launch_theta_stats(ctx, theta, K, P, &st, theta_shift);
+        int rc = launch_theta_stats(ctx, theta, K, P, &st);
         if (rc == ABC_OK) rc = launch_post_tail(ctx, theta, K, P, st, &side_out);
         ctx->stream = main_stream;
         ABC_TRY(rc);
@@ -693,20 +701,26 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         if (moments_on_side) { ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_moments, 0)); seeds_waited = true; }   // (recorded behind the seeds)
         struct PrepArg {
             abc_ctx* ctx; const abc_rng* rng; const double* theta; const double* theta_stats; size_t K, P, Nn;
-            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments; const double* theta_shift;
+            uint64_t* seeds; abc_perturb_prep* prep; double* L; int* spd_dev; double* dv; bool moments;
+            const double* model_hdr; double* hdr_pin; int* spd_pin;
         };
+        const bool hook_moments = defer_moments && !moments_on_side;
         PrepArg pa = {ctx, rng, theta, theta_stats, K, P, Nn, io->seeds, &prep, moments_on_side ? nullptr : L, spd_dev, dv,
-                      defer_moments && !moments_on_side, theta_shift};
+                      hook_moments, nullptr, nullptr, nullptr};
+        if (hook_moments && !status_late) {
+            pa.model_hdr = simple ? nullptr : model; pa.hdr_pin = hdr_pin; pa.spd_pin = L ? spd_pin : nullptr;
+            status_early = true;
+        }
         auto hook = [](void* a) -> int {
             PrepArg* q = (PrepArg*)a;
             int fused_done = 0;
             if (q->moments) {
                 StageTimer tm(q->ctx, ST_GATHER_DV);
                 double* st = nullptr;
-                ABC_TRY(launch_theta_stats(q->ctx, q->theta, q->K, q->P, &st, q->theta_shift));
+                ABC_TRY(launch_theta_stats(q->ctx, q->theta, q->K, q->P, &st));
                 q->theta_stats = st;
                 // doubled variance, proposal factor and the perturbation's inputs (row-major copy, padded factor) in ONE launch
-                abc_theta_fused f = {q->dv, q->L, q->spd_dev, nullptr, nullptr};
+                abc_theta_fused f = {q->dv, q->L, q->spd_dev, nullptr, nullptr, q->model_hdr, q->hdr_pin, q->spd_pin};
                 if (q->ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM) {
                     const int PP = abc_perturb_pp(q->P);
                     f.rows = (double*)abc_ws_alloc(q->ctx, q->K * (size_t)PP * sizeof(double));
@@ -754,18 +768,28 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         double* hdr = (double*)ctx->status_pin;
         int* pspd = (int*)(ctx->status_pin + 32);
         int* pfail = (int*)(ctx->status_pin + 36);
-        hdr[0] = 0.0; *pspd = 0; *pfail = 0;
+        if (!status_early) { hdr[0] = 0.0; *pspd = 0; }
+        *pfail = 0;
         if (seeds_late && !seeds_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));     // (never in practice: see below)
         // ONE tiny kernel stores the three words into the (device-visible) pinned block: three copies were three blit launches
         const int* fail_dev = (ctx->sel_bins_ran && ctx->sel_fail_dev) ? (const int*)ctx->sel_fail_dev : nullptr;
         unsigned long long* pgive = (unsigned long long*)(ctx->status_pin + 48);
         *pgive = 0;
-        hipLaunchKernelGGL(k_status_words, dim3(1), dim3(64), 0, ctx->stream, simple ? (const double*)nullptr : (const double*)model,
-                           have_spd ? (const int*)spd_dev : (const int*)nullptr, fail_dev, (const unsigned long long*)ctx->giveups_dev, hdr, pspd,
-                           pfail, pgive);
-        ABC_HIP(ctx, hipGetLastError());
+        if (!status_early) {
+            hipLaunchKernelGGL(k_status_words, dim3(1), dim3(64), 0, ctx->stream, simple ? (const double*)nullptr : (const double*)model,
+                               have_spd ? (const int*)spd_dev : (const int*)nullptr, fail_dev, (const unsigned long long*)ctx->giveups_dev, hdr, pspd,
+                               pfail, pgive);
+            ABC_HIP(ctx, hipGetLastError());
+        }
         ctx->side_early_waited = false;
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (status_early) {
+            // header and Cholesky status came from k_post_tail, the selection's flag from the gather (bins_deferred), the proposals'
+            // give-up counter is read only when a proposal kernel raised the flag word
+            *pfail = fail_dev ? *(volatile int*)pfail_early : 0;
+        } else {
+            ctx->giveups_dev_known = *(volatile unsigned long long*)pgive;
+        }
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
         spd = *pspd;
         // the sampled-range bin selection gave up (degenerate distances, an atypical sample): everything downstream of it
@@ -792,6 +816,15 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // proposals the perturbation gave up on during THIS call (the reference never returns in that case, AbcUtil.cpp:132): the
     // outputs are complete -- such a row is its (valid) parent, or the prior mean in INDEPENDENT mode -- and the caller is told
     {
+        if (status_early) {
+            if (*pgaveup && ctx->giveups_dev) {           // (rare) a proposal kernel gave up: fetch the counter
+                unsigned long long now = 0;
+                ABC_HIP(ctx, hipMemcpyAsync(&now, ctx->giveups_dev, sizeof(now), hipMemcpyDeviceToHost, ctx->stream));
+                ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ctx->giveups_dev_known = now;
+            }
+            *(volatile unsigned long long*)(ctx->status_pin + 48) = ctx->giveups_dev_known;
+        }
         const unsigned long long gv = *(volatile unsigned long long*)(ctx->status_pin + 48) + ctx->giveups_host;
         const unsigned long long before = ctx->giveups_seen;
         ctx->giveups_seen = gv;

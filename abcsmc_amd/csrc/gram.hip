@@ -13,10 +13,6 @@
 
 #include "abc_internal.h"
 
-// the shift a Gram launch centres its columns with: the record's own (k_pilot_shift), or -- the posterior's moments inside a
-// generation -- one the caller supplies (abc_internal.h: gram_shift_override)
-static inline const double* abc_gram_shift(const abc_ctx* ctx, const double* own) { return ctx->gram_shift_override ? ctx->gram_shift_override : own; }
-
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -795,7 +791,7 @@ int run_gram(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ld
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
-                           (int)P, (long long)n, split, abc_gram_shift(ctx, stats + L.off_shift), partial, vec_ok);
+                           (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
@@ -832,7 +828,7 @@ int run_gram_dma(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram_dma<C, CY, NW, PRIV, R, TABLE>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx,
-                           ldy, (int)M, (int)P, (long long)n, split, abc_gram_shift(ctx, stats + L.off_shift), partial);
+                           ldy, (int)M, (int)P, (long long)n, split, stats + L.off_shift, partial);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
@@ -865,7 +861,7 @@ int run_gram_dma8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram_dma8<C, CY>), dim3((unsigned)G, 2), dim3(512), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
-                           (long long)n, split, abc_gram_shift(ctx, stats + L.off_shift), partial);
+                           (long long)n, split, stats + L.off_shift, partial);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
@@ -894,7 +890,7 @@ int run_gram_wide(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL((k_gram_wide<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M,
-                           (int)P, (long long)n, split, abc_gram_shift(ctx, stats + L.off_shift), partial, vec_ok);
+                           (int)P, (long long)n, split, stats + L.off_shift, partial, vec_ok);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);

@@ -128,24 +128,27 @@ __device__ __forceinline__ double dv_of_stats(const double* __restrict__ stats, 
 template <int PP>
 __global__ __launch_bounds__(256) void k_post_tail(const double* __restrict__ theta, size_t K, int P, const double* __restrict__ stats,
                                                    double* __restrict__ dv, double* __restrict__ Lout, int* __restrict__ spd,
-                                                   double* __restrict__ rows, double* __restrict__ Lpad) {
+                                                   double* __restrict__ rows, double* __restrict__ Lpad,
+                                                   const double* __restrict__ model_hdr, double* __restrict__ hdr_pin, int* __restrict__ spd_pin) {
     __shared__ double t[PP][65];                    // group 0: the P x P work matrix + P means; others: the transposed tile
     if (blockIdx.x == 0) {
         double* sA = &t[0][0];
         if (dv) for (int p = threadIdx.x; p < P; p += 256) dv[p] = dv_of_stats(stats, P, p);
+        if (model_hdr && hdr_pin && threadIdx.x >= 64 && threadIdx.x < 68) hdr_pin[threadIdx.x - 64] = model_hdr[threadIdx.x - 64];
         if (Lout && threadIdx.x < 64) {
             const int lane = threadIdx.x;
             if constexpr (PP <= 32) {
                 cov_chol_regs<PP>(stats, P, Lout, spd, Lpad, lane);
-                return;
-            }
-            cov_chol_wave(stats, P, sA, sA + P * P, Lout, spd, lane);
-            if (Lpad) {
-                for (int e = lane; e < PP * PP; e += 64) {
-                    const int a = e % PP, b = e / PP;
-                    Lpad[e] = (a < P && b < P && b <= a) ? sA[a + P * b] : 0.0;
+            } else {
+                cov_chol_wave(stats, P, sA, sA + P * P, Lout, spd, lane);
+                if (Lpad) {
+                    for (int e = lane; e < PP * PP; e += 64) {
+                        const int a = e % PP, b = e / PP;
+                        Lpad[e] = (a < P && b < P && b <= a) ? sA[a + P * b] : 0.0;
+                    }
                 }
             }
+            if (spd_pin && lane == 0) *spd_pin = *spd;          // (lane 0 wrote it itself)
         }
         return;
     }
@@ -172,17 +175,13 @@ __global__ void k_dv_from_stats(const double* __restrict__ stats, int P, double*
 }  // namespace
 
 // one pass over the K x P posterior: pilot shift + Gram (k_gram<.,0>) -> statistics record in the arena
-int launch_theta_stats(abc_ctx* ctx, const double* theta, size_t K, size_t P, double** stats_out, const double* shift) {
+int launch_theta_stats(abc_ctx* ctx, const double* theta, size_t K, size_t P, double** stats_out) {
     const StatsLayout SL = stats_layout(P, 0);
     double* stats = (double*)abc_ws_alloc(ctx, SL.len * sizeof(double));
     if (!stats) ABC_FAIL(ctx, ABC_ERR_NOMEM, "theta stats: workspace exhausted");
-    static const int pilot_always = getenv("ABC_THETA_PILOT") ? 1 : 0;          // A/B switch for measurements
-    if (pilot_always) shift = nullptr;
-    if (!shift) ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
+    ABC_TRY(launch_stats_shift(ctx, theta, theta, K, K, K, P, 0, stats));
     ctx->in_mvn = true;
-    ctx->gram_shift_override = shift;
     const int rc_acc = launch_stats_accumulate(ctx, theta, theta, K, K, K, P, 0, 0, K, stats);
-    ctx->gram_shift_override = nullptr;
     ctx->in_mvn = false;
     ABC_TRY(rc_acc);
     *stats_out = stats;
@@ -195,7 +194,7 @@ int launch_post_tail(abc_ctx* ctx, const double* theta, size_t K, size_t P, cons
     const int PP = abc_perturb_pp(P);
     const unsigned grid = 1u + (f->rows ? (unsigned)((K + 63) / 64) : 0u);
 #define PT_LAUNCH(PPV) hipLaunchKernelGGL(k_post_tail<PPV>, dim3(grid), dim3(256), 0, ctx->stream, theta, K, (int)P, stats, f->dv, f->L, f->spd, \
-                                          f->rows, f->Lpad)
+                                          f->rows, f->Lpad, f->model_hdr, f->hdr_pin, f->spd_pin)
     switch (PP) {
         case 2: PT_LAUNCH(2); break;
         case 4: PT_LAUNCH(4); break;

@@ -208,6 +208,15 @@ __device__ __forceinline__ double d_prior_mean(const abc_prior& pr) {           
     return (pr.kind == ABC_PRIOR_GAUSS) ? pr.a : (pr.b + pr.a) / 2.0;
 }
 
+// a proposal the perturbation gives up on: counted on the device, and -- rare path -- a flag word in the context's pinned block is
+// raised (its address travels in slot 2 of the counter array), so that the host learns of give-ups at its next synchronisation
+// without a kernel that copies the counter behind every generation
+__device__ __forceinline__ void note_giveup(unsigned long long* __restrict__ g) {
+    atomicAdd(g, 1ull);
+    unsigned* f = (unsigned*)(size_t)g[2];
+    if (f) *f = 1u;
+}
+
 constexpr unsigned MVN_MAX_TRIES = 1u << 14;   // the reference retries for ever (AbcUtil.cpp:132); bounded here
 
 // theta (K x P column-major) -> row-major K x PP, zero padded: a parent row is then one contiguous PP*8-byte line
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256, (MV && PP <= 16) ? 3 : (PP <= 16 ? 2 : 1)) voi
             if (attempt + 1 == MVN_MAX_TRIES) {
 #pragma unroll
                 for (int a = 0; a < PP; a++) x[a] = mrow[a];   // give up: keep the (valid) parent, and say so (abc_perturb_giveups)
-                atomicAdd(giveups, 1ull);
+                note_giveup(giveups);
             }
         }
     } else {
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, (MV && PP <= 16) ? 3 : (PP <= 16 ? 2 : 1)) voi
                     ok = d_valid(sp[p], v);
                 }
                 x[p] = ok ? v : d_prior_mean(sp[p]);
-                if (!ok) atomicAdd(giveups, 1ull);       // the reference prints an error line per fallback (Priors.h:27-29)
+                if (!ok) note_giveup(giveups);       // the reference prints an error line per fallback (Priors.h:27-29)
             }
         }
     }
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
         }
         if (!ok) {
             for (int p = 0; p < P; p++) out[i + n * (size_t)p] = mu[p];      // give up: keep the (valid) parent
-            atomicAdd(giveups, 1ull);
+            note_giveup(giveups);
         }
     } else {
         for (int p = 0; p < P; p++) {
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const doubl
                 ok = d_valid(sp[p], v);
             }
             out[i + n * (size_t)p] = ok ? v : d_prior_mean(sp[p]);
-            if (!ok) atomicAdd(giveups, 1ull);
+            if (!ok) note_giveup(giveups);
         }
     }
 }
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(256) void k_perturb_gen(abc_rng key, const double* 
         }
         if (!ok) {
             for (int p = 0; p < P; p++) out[i + n * (size_t)p] = mu[p];      // give up: keep the (valid) parent
-            atomicAdd(giveups, 1ull);
+            note_giveup(giveups);
         }
     } else {
         for (int p = 0; p < P; p++) {
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(256) void k_perturb_gen(abc_rng key, const double* 
                 ok = d_valid(spg[p], v);
             }
             out[i + n * (size_t)p] = ok ? v : d_prior_mean(spg[p]);
-            if (!ok) atomicAdd(giveups, 1ull);
+            if (!ok) note_giveup(giveups);
         }
     }
 }
@@ -832,8 +841,10 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     while (PP < (int)P) PP *= 2;
     if (P > 64) PP = (int)((P + 63) / 64 * 64);
     if (!ctx->giveups_dev) {
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, 2 * sizeof(unsigned long long)));      // [0] the counter, [1] its snapshot
-        ABC_HIP(ctx, hipMemsetAsync(ctx->giveups_dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        // [0] the counter, [1] its snapshot, [2] the address of the pinned flag word (note_giveup)
+        ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, 3 * sizeof(unsigned long long)));
+        const unsigned long long init[3] = {0ull, 0ull, (unsigned long long)(size_t)(ctx->status_pin + 56)};
+        ABC_HIP(ctx, hipMemcpy(ctx->giveups_dev, init, sizeof(init), hipMemcpyHostToDevice));
     }
     StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);
