@@ -65,7 +65,7 @@ for case in range(cases):
             X[:, c] += off; obs[c] += off
         if "constant" in mods and M > 2:
             X[:, int(g.integers(0, M))] = 3.25
-            A = min(A, M - 1)            # (components beyond the rank of X are rounding noise, and so is the count that minimises PRESS among them)
+            A = min(A if A > 0 else min(M, P), M - 1)   # (components beyond the rank of X are rounding noise, and so is the count that minimises PRESS among them; 0 = as many as fit)
             tag["A"] = A
         if "collinear" in mods and M > 3:
             a, b = g.choice(M, 2, replace=False)
