@@ -1,6 +1,8 @@
 """The same generation many times over (inputs resident, outputs hashed each time): every output must be bit-identical from run
 to run -- the two streams of a generation, the side stream's early work and the events between them leave room for races that a
-single comparison against the oracle would not show.  Also once with the streams' orchestration switches flipped.
+single comparison against the oracle would not show.  The printed hash must also be the same with the streams' orchestration
+switches flipped (ABC_FORK_ALWAYS, ABC_WAIT_LATE, ABC_SEEDS_FIRST, ABC_MOMENTS_MAIN, ABC_STATUS_KERNEL) and with the runtime serialising
+every launch (AMD_SERIALIZE_KERNEL=3): a dependency the streams' events do not express would show as a different hash there.
     python scripts/repeat_check.py [repeats]"""
 import hashlib
 import os
@@ -34,5 +36,5 @@ for (N, M, P, K, Kp, Nn, A, mv) in [(100000, 32, 16, 10000, 10000, 100000, 8, Tr
         seen[h.hexdigest()] = seen.get(h.hexdigest(), 0) + 1
     ok = len(seen) == 1
     bad += 0 if ok else 1
-    print("%s N=%d P=%d K=%d K'=%d N+=%d %s: %d runs, %d distinct output sets %s" % ("ok  " if ok else "FAIL", N, P, K, Kp, Nn, "MVN" if mv else "independent", reps, len(seen), "" if ok else sorted(seen.values())), flush=True)
+    print("%s N=%d P=%d K=%d K'=%d N+=%d %s: %d runs, %d distinct output sets %s sha1 %s" % ("ok  " if ok else "FAIL", N, P, K, Kp, Nn, "MVN" if mv else "independent", reps, len(seen), "" if ok else sorted(seen.values()), sorted(seen)[0][:16]), flush=True)
 print("%d shapes, %d not reproducible" % (5, bad))
