@@ -162,38 +162,38 @@ class AbcSmc {
     AbcSmc() {}
 
     // ---- AbcSmc.h:41-107 ------------------------------------------------------------------------------------
-    size_t get_smc_iterations() { return _num_smc_sets; }
+    size_t get_smc_iterations() { return n_sets_; }
     size_t get_smc_size_at(const size_t set_num) {
-        if (set_num >= _num_smc_sets) throw std::out_of_range("set_num out of range");
-        return (set_num < _smc_set_sizes.size()) ? _smc_set_sizes[set_num] : _smc_set_sizes.back();
+        if (set_num >= n_sets_) throw std::out_of_range("set_num out of range");
+        return (set_num < particles_per_set_.size()) ? particles_per_set_[set_num] : particles_per_set_.back();
     }
     size_t get_pred_prior_size_at(const size_t set_num) {
-        if (set_num >= _num_smc_sets || _predictive_prior_sizes.empty()) throw std::out_of_range("set_num out of range");
-        return (set_num < _predictive_prior_sizes.size()) ? _predictive_prior_sizes[set_num] : _predictive_prior_sizes.back();
+        if (set_num >= n_sets_ || kept_per_set_.empty()) throw std::out_of_range("set_num out of range");
+        return (set_num < kept_per_set_.size()) ? kept_per_set_[set_num] : kept_per_set_.back();
     }
-    void set_smc_iterations(const size_t n) { _num_smc_sets = n; }
-    void set_smc_set_sizes(const std::vector<size_t>& v) { _smc_set_sizes = v; }                 // manual configuration
-    void set_predictive_prior_sizes(const std::vector<size_t>& v) { _predictive_prior_sizes = v; }
+    void set_smc_iterations(const size_t n) { n_sets_ = n; }
+    void set_smc_set_sizes(const std::vector<size_t>& v) { particles_per_set_ = v; }                 // manual configuration
+    void set_predictive_prior_sizes(const std::vector<size_t>& v) { kept_per_set_ = v; }
     void set_pls_validation_training_fraction(const float_type f) {
         if (!((0 < f) && (f <= 1))) throw std::invalid_argument("pls training fraction must be in (0, 1]");
-        _pls_training_fraction = f;
+        train_frac_ = f;
     }
-    void set_simulation(AbcSimFun* abcsf) { _simulator = abcsf; }
+    void set_simulation(AbcSimFun* abcsf) { sim_ = abcsf; }
     void set_executable(std::string cmd) { set_simulation(new AbcExec(cmd)); }
     void set_simulator(AbcSimBase* simulator) { set_simulation(new AbcFPtrBase(simulator)); }
     void set_simulator(std::string soname) { set_simulation(new AbcFPtrBase(soname.c_str())); }
-    void set_database_filename(std::string name) { _database_filename = name; }
-    void set_retain_posterior_rank(const bool retain_rank) { _retain_posterior_rank = retain_rank; }
-    void set_filtering_type(const ABC::FILTER& ft) { _filtering = ft; }
-    void set_noise_type(const ABC::NOISE& nt) { _noise = nt; }
+    void set_database_filename(std::string name) { db_path_ = name; }
+    void set_retain_posterior_rank(const bool retain_rank) { keep_posterior_rank_ = retain_rank; }
+    void set_filtering_type(const ABC::FILTER& ft) { ranking_kind_ = ft; }
+    void set_noise_type(const ABC::NOISE& nt) { noise_kind_ = nt; }
     const ABC::Metric* add_next_metric(const ABC::Metric* m) {
-        _model_mets.push_back(m);
-        _met_vals.push_back(m->get_obs_val());
+        mets_.push_back(m);
+        observed_.push_back(m->get_obs_val());
         return m;
     }
-    const ABC::Parameter* add_next_parameter(const ABC::Parameter* p) { _model_pars.push_back(p); return p; }
-    void add_modification_map(const ABC::Parameter* par, const ABC::ParXform* xform) { _par_modification_map[par] = xform; }
-    void add_par_rescale(const ABC::Parameter* par, const ABC::ParRescale* r) { _par_rescale_map[par] = r; }
+    const ABC::Parameter* add_next_parameter(const ABC::Parameter* p) { pars_.push_back(p); return p; }
+    void add_modification_map(const ABC::Parameter* par, const ABC::ParXform* xform) { xform_of_par_[par] = xform; }
+    void add_par_rescale(const ABC::Parameter* par, const ABC::ParRescale* r) { rescale_of_par_[par] = r; }
 
     bool parse_config(const std::string& conf_filename);
     bool build_database(const ABC::RNG* RNG);
@@ -210,13 +210,13 @@ class AbcSmc {
     bool run(const ABC::RNG* RNG, const std::function<unsigned long(size_t)>& reseed = nullptr);
     bool run(const std::string& executable, const ABC::RNG* RNG) { set_executable(executable); return run(RNG); }
 
-    size_t npar() { return _model_pars.size(); }
-    size_t nmet() { return _model_mets.size(); }
-    std::vector<Mat2D> get_particle_parameters() { return _particle_parameters; }
-    std::vector<Mat2D> get_particle_metrics() { return _particle_metrics; }
+    size_t npar() { return pars_.size(); }
+    size_t nmet() { return mets_.size(); }
+    std::vector<Mat2D> get_particle_parameters() { return set_params_; }
+    std::vector<Mat2D> get_particle_metrics() { return set_metrics_; }
     // extras for tests / drivers
-    const std::vector<std::vector<size_t>>& get_predictive_priors() const { return _predictive_prior; }
-    const std::vector<Col>& get_weights() const { return _weights; }
+    const std::vector<std::vector<size_t>>& get_predictive_priors() const { return kept_rows_; }
+    const std::vector<Col>& get_weights() const { return set_weights_; }
     std::ostream* log_stream = &std::cerr;      // the reference writes its reports to std::cerr
 
    private:
@@ -226,28 +226,28 @@ class AbcSmc {
     static constexpr const char* PAR_TABLE = "par";
     static constexpr const char* UPAR_TABLE = "upar";
 
-    std::vector<const ABC::Parameter*> _model_pars;
-    std::map<const ABC::Parameter*, const ABC::ParXform*> _par_modification_map;
-    std::map<const ABC::Parameter*, const ABC::ParRescale*> _par_rescale_map;
-    Mat2D _posterior;
-    AbcSimFun* _simulator = new AbcSimUnset();
-    std::vector<const ABC::Metric*> _model_mets;
-    Row _met_vals;
-    bool _retain_posterior_rank = false;
-    ABC::FILTER _filtering = ABC::FILTER::PLS;
-    ABC::NOISE _noise = ABC::NOISE::INDEPENDENT;
-    size_t _num_smc_sets = 0;
-    std::vector<size_t> _smc_set_sizes, _predictive_prior_sizes;
-    float_type _pls_training_fraction = 0.5;
-    std::vector<std::vector<size_t>> _predictive_prior;
-    std::vector<Mat2D> _particle_metrics, _particle_parameters;
-    std::vector<Col> _weights;
-    std::vector<Row> _doubled_variance;
-    std::string _database_filename;
-    std::optional<std::string> _resume_directory;
+    std::vector<const ABC::Parameter*> pars_;
+    std::map<const ABC::Parameter*, const ABC::ParXform*> xform_of_par_;
+    std::map<const ABC::Parameter*, const ABC::ParRescale*> rescale_of_par_;
+    Mat2D posterior_path_;
+    AbcSimFun* sim_ = new AbcSimUnset();
+    std::vector<const ABC::Metric*> mets_;
+    Row observed_;
+    bool keep_posterior_rank_ = false;
+    ABC::FILTER ranking_kind_ = ABC::FILTER::PLS;
+    ABC::NOISE noise_kind_ = ABC::NOISE::INDEPENDENT;
+    size_t n_sets_ = 0;
+    std::vector<size_t> particles_per_set_, kept_per_set_;
+    float_type train_frac_ = 0.5;
+    std::vector<std::vector<size_t>> kept_rows_;
+    std::vector<Mat2D> set_metrics_, set_params_;
+    std::vector<Col> set_weights_;
+    std::vector<Row> set_dv_;
+    std::string db_path_;
+    std::optional<std::string> resume_dir_;
 
     Row _to_model_space(const Row& pars);
-    bool _run_simulator(Row& par, Row& met, const size_t rng_seed, const size_t serial);
+    bool run_sim_(Row& par, Row& met, const size_t rng_seed, const size_t serial);
     void calculate_predictive_prior_weights(const size_t set_num);
     std::string _column_list(const char* prefix, bool pars, const char* suffix);
     void _insert_particles(sqdyn::Db& db, size_t set_num, long long first_serial, const Mat2D& pars,
@@ -459,30 +459,30 @@ inline bool AbcSmc::parse_config(const std::string& conf_filename) {          //
         pseudosize *= posterior_size;
         if (!par.isMember("posterior_database_filename"))
             die(-204, "Parameter specfied as type POSTERIOR, without previously specifying a posterior_database_filename.  Aborting.");
-        if (_num_smc_sets > 1) die(-203, "Cannot use posterior parameters with multiple SMC sets.  Aborting.");
-        _posterior = abcsmc_slurp_posterior(par["posterior_database_filename"].asString(), _model_pars);
+        if (n_sets_ > 1) die(-203, "Cannot use posterior parameters with multiple SMC sets.  Aborting.");
+        posterior_path_ = abcsmc_slurp_posterior(par["posterior_database_filename"].asString(), pars_);
     }
     for (const mjson::Value& mmet : par["metrics"]) add_next_metric(parse_metric(mmet));
 
-    parse_iterations(par, pseudosize, &_num_smc_sets, &_pls_training_fraction, &_smc_set_sizes, &_predictive_prior_sizes);
+    parse_iterations(par, pseudosize, &n_sets_, &train_frac_, &particles_per_set_, &kept_per_set_);
 
     const std::string executable = par.get("executable", "").asString();
     if (executable != "") set_executable(executable);
     const std::string sharedobj = par.get("shared", "").asString();
     if (sharedobj != "") set_simulator(sharedobj);
     const std::string resume_dir = par.get("resume_directory", "").asString();
-    if (resume_dir != "") { std::cerr << "Resuming in directory: " << resume_dir << std::endl; _resume_directory.emplace(resume_dir); }
+    if (resume_dir != "") { std::cerr << "Resuming in directory: " << resume_dir << std::endl; resume_dir_.emplace(resume_dir); }
     set_database_filename(par["database_filename"].asString());
 
     const std::string noise = par.get("noise", "INDEPENDENT").asString();
-    if (noise == "INDEPENDENT") _noise = ABC::NOISE::INDEPENDENT;
-    else if (noise == "MULTIVARIATE") _noise = ABC::NOISE::MULTIVARIATE;
+    if (noise == "INDEPENDENT") noise_kind_ = ABC::NOISE::INDEPENDENT;
+    else if (noise == "MULTIVARIATE") noise_kind_ = ABC::NOISE::MULTIVARIATE;
     else die(-210, "Unknown parameter noise type specified: " + noise + ". Aborting.");
     // not in the reference's JSON: lets a configuration ask for the simple (non-PLS) ranking that upstream only
     // reaches through set_filtering_type()
     const std::string filtering = par.get("filtering", "PLS").asString();
-    if (filtering == "PLS") _filtering = ABC::FILTER::PLS;
-    else if (filtering == "SIMPLE") _filtering = ABC::FILTER::SIMPLE;
+    if (filtering == "PLS") ranking_kind_ = ABC::FILTER::PLS;
+    else if (filtering == "SIMPLE") ranking_kind_ = ABC::FILTER::SIMPLE;
     else die(-210, "Unknown filtering type specified: " + filtering + ". Aborting.");
     return true;
 }
@@ -490,9 +490,9 @@ inline bool AbcSmc::parse_config(const std::string& conf_filename) {          //
 inline Row AbcSmc::_to_model_space(const Row& fitting) {                       // AbcSmc.cpp:432-447
     Row model = fitting;
     for (size_t j = 0; j < fitting.size(); j++) {
-        const ABC::Parameter* mpar = _model_pars[j];
-        auto it = _par_modification_map.find(mpar);
-        if (it != _par_modification_map.end()) model[j] = _par_rescale_map[mpar]->rescale(it->second->transform(fitting[j], fitting));
+        const ABC::Parameter* mpar = pars_[j];
+        auto it = xform_of_par_.find(mpar);
+        if (it != xform_of_par_.end()) model[j] = rescale_of_par_[mpar]->rescale(it->second->transform(fitting[j], fitting));
     }
     return model;
 }
@@ -504,7 +504,7 @@ inline std::string AbcSmc::_column_list(const char* prefix, bool pars, const cha
     std::string out;
     const size_t n = pars ? npar() : nmet();
     for (size_t i = 0; i < n; i++) {
-        out += prefix + (pars ? _model_pars[i]->get_short_name() : _model_mets[i]->get_short_name()) + suffix;
+        out += prefix + (pars ? pars_[i]->get_short_name() : mets_[i]->get_short_name()) + suffix;
         out += (i + 1 < n) ? ", " : " ";
     }
     return out;
@@ -527,7 +527,7 @@ template <typename F> bool AbcSmc::_transaction(sqdyn::Db& db, const char* what,
 inline void AbcSmc::_insert_particles(sqdyn::Db& db, size_t set_num, long long first_serial, const Mat2D& pars,
                                       const std::vector<unsigned long>& seeds, const std::vector<long long>& posterior_ranks) {
     using abcsmc_detail::num;
-    const bool upar = !_par_modification_map.empty();
+    const bool upar = !xform_of_par_.empty();
     std::string null_mets;
     for (size_t j = 0; j < nmet(); j++) null_mets += ", NULL";
     for (size_t i = 0; i < pars.rows(); i++) {
@@ -552,27 +552,27 @@ inline void AbcSmc::_insert_particles(sqdyn::Db& db, size_t set_num, long long f
 }
 
 inline bool AbcSmc::build_database(const ABC::RNG* RNG) {                      // AbcSmc.cpp:810-873
-    sqdyn::Db db(_database_filename);
+    sqdyn::Db db(db_path_);
     if (db.table_exists(JOB_TABLE) || db.table_exists(PAR_TABLE) || db.table_exists(MET_TABLE)) return false;
     // the tables first; the priors and seeds are drawn (and the RNG stream consumed) only once they exist
     const bool created = _transaction(db, "creating tables", [&] {
         db.exec(std::string("create table ") + JOB_TABLE + " ( serial int primary key asc, smcSet int, particleIdx int, startTime int, duration real, status text, posterior int, attempts int );");
         db.exec(std::string("create index idx1 on ") + JOB_TABLE + " (status, attempts);");
         db.exec(std::string("create table ") + PAR_TABLE + " ( serial int primary key, seed blob, " + _column_list("", true, " real") + ");");
-        if (!_par_modification_map.empty())
+        if (!xform_of_par_.empty())
             db.exec(std::string("create table ") + UPAR_TABLE + " ( serial int primary key, seed blob, " + _column_list("", true, " real") + ");");
         db.exec(std::string("create table ") + MET_TABLE + " ( serial int primary key, " + _column_list("", false, " real") + ");");
     });
-    if (!created) { std::cerr << "ERROR: could not create the tables of " << _database_filename << std::endl; return false; }
+    if (!created) { std::cerr << "ERROR: could not create the tables of " << db_path_ << std::endl; return false; }
     const size_t num_particles = get_smc_size_at(0);
     std::vector<size_t> posterior_ranks;
-    const Mat2D pars = ABC::sample_priors(RNG, num_particles, _posterior, _model_pars, posterior_ranks);
+    const Mat2D pars = ABC::sample_priors(RNG, num_particles, posterior_path_, pars_, posterior_ranks);
     std::vector<unsigned long> seeds(num_particles);
     for (size_t i = 0; i < num_particles; i++) seeds[i] = ABC::rng_get(RNG);     // after all samples (:843, 859)
     std::vector<long long> ranks;
-    if (_retain_posterior_rank) ranks.assign(posterior_ranks.begin(), posterior_ranks.end());
+    if (keep_posterior_rank_) ranks.assign(posterior_ranks.begin(), posterior_ranks.end());
     if (!_transaction(db, "inserting the first set", [&] { _insert_particles(db, 0, 0, pars, seeds, ranks); })) {
-        std::cerr << "ERROR: could not store the first set in " << _database_filename << std::endl;
+        std::cerr << "ERROR: could not store the first set in " << db_path_ << std::endl;
         return false;
     }
     return true;
@@ -593,17 +593,17 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
         while (s.next()) sets.push_back({(int)s.i64(0), (int)s.i64(1), (int)s.i64(2)});
     }
     serials.clear();
-    _particle_parameters.clear();
-    _particle_metrics.clear();
+    set_params_.clear();
+    set_metrics_.clear();
     for (const SetRow& sr : sets) {
         const int t = sr.t;
         if (sr.size != sr.done) {
             std::cerr << "ERROR: Failed to read SMC set from database because not all particles are complete in set " << t << "\n";
             return false;
         }
-        if ((size_t)t >= _num_smc_sets || sr.size != (int)get_smc_size_at(t)) {
+        if ((size_t)t >= n_sets_ || sr.size != (int)get_smc_size_at(t)) {
             std::cerr << "ERROR:\tSet size for one or more sets does not agree between configuration file and database:" << std::endl
-                      << "\tSet " << t << " in configuration file has size " << ((size_t)t < _num_smc_sets ? (long)get_smc_size_at(t) : -1L)
+                      << "\tSet " << t << " in configuration file has size " << ((size_t)t < n_sets_ ? (long)get_smc_size_at(t) : -1L)
                       << " vs size " << sr.size << " in database." << std::endl
                       << "\tNB: You may want to edit the configuration file to have an array of set sizes that reflect what is already in the database." << std::endl
                       << "\t    Sizes of sets currently in database: [";
@@ -612,8 +612,8 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
             exit(1);
         }
         const size_t n = (size_t)sr.size;
-        _particle_parameters.push_back(Mat2D(n, npar()));
-        _particle_metrics.push_back(Mat2D(n, nmet()));
+        set_params_.push_back(Mat2D(n, npar()));
+        set_metrics_.push_back(Mat2D(n, nmet()));
         serials.push_back(std::vector<int>(n));
         std::vector<std::pair<int, int>> posterior_pairs;
         {
@@ -629,50 +629,50 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
                 }
                 serials[t][counter] = serial;
                 if (rank > -1) posterior_pairs.push_back({rank, particle_idx});
-                for (size_t j = 0; j < npar(); j++) _particle_parameters[t](counter, j) = s2.f64(3 + (int)j);
-                for (size_t j = 0; j < nmet(); j++) _particle_metrics[t](counter, j) = s2.f64(3 + (int)npar() + (int)j);
+                for (size_t j = 0; j < npar(); j++) set_params_[t](counter, j) = s2.f64(3 + (int)j);
+                for (size_t j = 0; j < nmet(); j++) set_metrics_[t](counter, j) = s2.f64(3 + (int)npar() + (int)j);
                 counter++;
             }
         }
         if (!posterior_pairs.empty()) {          // already filtered and ranked
-            _predictive_prior.push_back(std::vector<size_t>(posterior_pairs.size()));
-            for (const auto& pr : posterior_pairs) _predictive_prior.back()[pr.first] = (size_t)pr.second;
-        } else if (ABC::multi_device() && _filtering == ABC::FILTER::PLS) {
+            kept_rows_.push_back(std::vector<size_t>(posterior_pairs.size()));
+            for (const auto& pr : posterior_pairs) kept_rows_.back()[pr.first] = (size_t)pr.second;
+        } else if (ABC::multi_device() && ranking_kind_ == ABC::FILTER::PLS) {
             // several GPUs (ABC::use_devices): rank + truncate + doubled variance + weights of this set in one row-sharded call
             const size_t K = get_pred_prior_size_at(t);
             Mat2D prev_post;
-            if (t > 0) prev_post = ABC::select_rows(_particle_parameters[t - 1], _predictive_prior[t - 1]);
-            ABC::RankedSet rs = ABC::rank_and_weight(_particle_metrics[t], _particle_parameters[t], _met_vals, _pls_training_fraction, K,
-                                                     _model_pars, t > 0 ? &prev_post : nullptr, t > 0 ? &_weights[t - 1] : nullptr,
-                                                     t > 0 ? &_doubled_variance[t - 1] : nullptr);
-            _predictive_prior.push_back(rs.idx);
-            AbcLog::filtering_report(this, t, rs.theta, ABC::select_rows(_particle_metrics[t], _predictive_prior[t]), *log_stream);
+            if (t > 0) prev_post = ABC::select_rows(set_params_[t - 1], kept_rows_[t - 1]);
+            ABC::RankedSet rs = ABC::rank_and_weight(set_metrics_[t], set_params_[t], observed_, train_frac_, K,
+                                                     pars_, t > 0 ? &prev_post : nullptr, t > 0 ? &set_weights_[t - 1] : nullptr,
+                                                     t > 0 ? &set_dv_[t - 1] : nullptr);
+            kept_rows_.push_back(rs.idx);
+            AbcLog::filtering_report(this, t, rs.theta, ABC::select_rows(set_metrics_[t], kept_rows_[t]), *log_stream);
             _transaction(db, "recording posterior ranks", [&] {
                 for (size_t i = 0; i < K; i++)
                     db.exec(std::string("update ") + JOB_TABLE + " set posterior = " + std::to_string(i) + " where serial = " +
-                            std::to_string(serials[t][_predictive_prior[t][i]]) + ";");
+                            std::to_string(serials[t][kept_rows_[t][i]]) + ";");
             });
-            _doubled_variance.push_back(rs.doubled_variance);
-            _weights.push_back(rs.weights);
+            set_dv_.push_back(rs.doubled_variance);
+            set_weights_.push_back(rs.weights);
             continue;
         } else {                                 // rank on the GPU, keep the best K, record the ranks
-            switch (_filtering) {
+            switch (ranking_kind_) {
                 case ABC::FILTER::PLS:
-                    _predictive_prior.push_back(ABC::particle_ranking_PLS(_particle_metrics[t], _particle_parameters[t], _met_vals, _pls_training_fraction));
+                    kept_rows_.push_back(ABC::particle_ranking_PLS(set_metrics_[t], set_params_[t], observed_, train_frac_));
                     break;
                 case ABC::FILTER::SIMPLE:
-                    _predictive_prior.push_back(ABC::particle_ranking_simple(_particle_metrics[t], _particle_parameters[t], _met_vals));
+                    kept_rows_.push_back(ABC::particle_ranking_simple(set_metrics_[t], set_params_[t], observed_));
                     break;
-                default: std::cerr << "ERROR: Unsupported filtering method: " << _filtering << std::endl; return false;
+                default: std::cerr << "ERROR: Unsupported filtering method: " << ranking_kind_ << std::endl; return false;
             }
             const size_t K = get_pred_prior_size_at(t);
-            _predictive_prior.back().resize(K);
-            AbcLog::filtering_report(this, t, ABC::select_rows(_particle_parameters[t], _predictive_prior[t]),
-                                     ABC::select_rows(_particle_metrics[t], _predictive_prior[t]), *log_stream);
+            kept_rows_.back().resize(K);
+            AbcLog::filtering_report(this, t, ABC::select_rows(set_params_[t], kept_rows_[t]),
+                                     ABC::select_rows(set_metrics_[t], kept_rows_[t]), *log_stream);
             _transaction(db, "recording posterior ranks", [&] {
                 for (size_t i = 0; i < K; i++)
                     db.exec(std::string("update ") + JOB_TABLE + " set posterior = " + std::to_string(i) + " where serial = " +
-                            std::to_string(serials[t][_predictive_prior[t][i]]) + ";");
+                            std::to_string(serials[t][kept_rows_[t][i]]) + ";");
             });
         }
         calculate_predictive_prior_weights(t);
@@ -681,13 +681,13 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
 }
 
 inline void AbcSmc::calculate_predictive_prior_weights(const size_t t) {      // AbcSmc.cpp:1041-1066
-    const Mat2D post = ABC::select_rows(_particle_parameters[t], _predictive_prior[t]);
-    _doubled_variance.push_back(ABC::calculate_doubled_variance(post));
+    const Mat2D post = ABC::select_rows(set_params_[t], kept_rows_[t]);
+    set_dv_.push_back(ABC::calculate_doubled_variance(post));
     if (t == 0) {
-        _weights.push_back(ABC::weight_predictive_prior(_model_pars, post));
+        set_weights_.push_back(ABC::weight_predictive_prior(pars_, post));
     } else {
-        _weights.push_back(ABC::weight_predictive_prior(_model_pars, post, ABC::select_rows(_particle_parameters[t - 1], _predictive_prior[t - 1]),
-                                                        _weights[t - 1], _doubled_variance[t - 1]));
+        set_weights_.push_back(ABC::weight_predictive_prior(pars_, post, ABC::select_rows(set_params_[t - 1], kept_rows_[t - 1]),
+                                                        set_weights_[t - 1], set_dv_[t - 1]));
     }
 }
 
@@ -705,12 +705,12 @@ inline bool AbcSmc::run(const ABC::RNG* RNG, const std::function<unsigned long(s
 
 inline bool AbcSmc::process_database(const ABC::RNG* RNG, const bool verbose) {   // AbcSmc.cpp:452-559
     if (build_database(RNG)) return true;
-    sqdyn::Db db(_database_filename);
-    _particle_parameters.clear();
-    _particle_metrics.clear();
-    _weights.clear();
-    _predictive_prior.clear();
-    _doubled_variance.clear();
+    sqdyn::Db db(db_path_);
+    set_params_.clear();
+    set_metrics_.clear();
+    set_weights_.clear();
+    kept_rows_.clear();
+    set_dv_.clear();
     *log_stream << std::setprecision(5);
     std::vector<std::vector<int>> serials;
     if (!read_SMC_sets_from_database(db, serials)) return false;
@@ -718,23 +718,23 @@ inline bool AbcSmc::process_database(const ABC::RNG* RNG, const bool verbose) { 
     if (next_set == 0) return false;
     AbcLog::report_convergence_data(this, next_set - 1, *log_stream);
     *log_stream << std::endl << std::endl;
-    if (_num_smc_sets > next_set) {
+    if (n_sets_ > next_set) {
         const size_t num_particles = get_smc_size_at(next_set);
-        const Mat2D prior = ABC::select_rows(_particle_parameters[next_set - 1], _predictive_prior[next_set - 1]);
+        const Mat2D prior = ABC::select_rows(set_params_[next_set - 1], kept_rows_[next_set - 1]);
         std::vector<unsigned long> seeds;
         Mat2D noised;
-        if (_noise == ABC::NOISE::MULTIVARIATE) {
+        if (noise_kind_ == ABC::NOISE::MULTIVARIATE) {
             const Mat2D L = ABC::setup_mvn_sampler(prior);
-            noised = ABC::sample_mvn_predictive_priors(RNG, num_particles, _weights[next_set - 1], prior, _model_pars, L, &seeds);
+            noised = ABC::sample_mvn_predictive_priors(RNG, num_particles, set_weights_[next_set - 1], prior, pars_, L, &seeds);
             if (verbose) std::cerr << "Populating next set using MULTIVARIATE noising of parameters." << std::endl;
         } else {
-            noised = ABC::sample_predictive_priors(RNG, num_particles, _weights[next_set - 1], prior, _model_pars, _doubled_variance[next_set - 1], &seeds);
+            noised = ABC::sample_predictive_priors(RNG, num_particles, set_weights_[next_set - 1], prior, pars_, set_dv_[next_set - 1], &seeds);
             if (verbose) std::cerr << "Populating next set using INDEPENDENT noising of parameters." << std::endl;
         }
         const long long last_serial = serials.back().back();
         _transaction(db, "inserting the next set", [&] { _insert_particles(db, next_set, last_serial + 1, noised, seeds, {}); });
     } else {
-        std::cerr << "Database already contains " << _num_smc_sets << " complete sets.\n";
+        std::cerr << "Database already contains " << n_sets_ << " complete sets.\n";
     }
     return true;
 }
@@ -742,8 +742,8 @@ inline bool AbcSmc::process_database(const ABC::RNG* RNG, const bool verbose) { 
 // =============================================================================================================
 // simulation (AbcSmc.cpp:681-689, 876-1039)
 // =============================================================================================================
-inline bool AbcSmc::_run_simulator(Row& par, Row& met, const size_t rng_seed, const size_t serial) {
-    std::vector<float_type> met_vec = (*_simulator)(par, rng_seed, serial);
+inline bool AbcSmc::run_sim_(Row& par, Row& met, const size_t rng_seed, const size_t serial) {
+    std::vector<float_type> met_vec = (*sim_)(par, rng_seed, serial);
     const bool ok = (met_vec.size() == nmet());
     if (!ok) std::cerr << "ERROR: simulator function returned the wrong number of metrics: expected " << nmet() << ", received " << met_vec.size() << std::endl;
     met = met_vec;
@@ -756,7 +756,7 @@ inline bool AbcSmc::simulate_next_particles(const int n, const int serial_req, c
     const bool verbose = (n == 1);
     if (!(n == 1 || (serial_req == -1 && posterior_req == -1)) || !(serial_req == -1 || posterior_req == -1))
         throw std::invalid_argument("simulate_next_particles: a serial or posterior request is for exactly one particle");
-    sqdyn::Db db(_database_filename);
+    sqdyn::Db db(db_path_);
     const std::string model_par_table = db.table_exists(UPAR_TABLE) ? UPAR_TABLE : PAR_TABLE;
     std::ostringstream select_ss;
     select_ss << "select J.serial, P.seed, " << _column_list("P.", true, "") << "from " << model_par_table << " P, " << JOB_TABLE
@@ -791,9 +791,9 @@ inline bool AbcSmc::simulate_next_particles(const int n, const int serial_req, c
     for (size_t i = 0; i < par_mat.size(); i++) {
         const auto start = system_clock::now();
         Row met(nmet());
-        if (!_run_simulator(par_mat[i], met, seeds[i], (size_t)serials[i])) exit(-211);
+        if (!run_sim_(par_mat[i], met, seeds[i], (size_t)serials[i])) exit(-211);
         std::string sets;
-        for (size_t j = 0; j < nmet(); j++) sets += _model_mets[j]->get_short_name() + "=" + num(met[j]) + (j + 1 < nmet() ? ", " : " ");
+        for (size_t j = 0; j < nmet(); j++) sets += mets_[j]->get_short_name() + "=" + num(met[j]) + (j + 1 < nmet() ? ", " : " ");
         // only while the job is still running, queued or paused (AbcSmc.cpp:1006-1008)
         met_updates.push_back(std::string("update ") + MET_TABLE + " set " + sets + "where serial = " + std::to_string(serials[i]) +
                               " and (select (status is 'R' or status is 'Q' or status is 'P') from " + JOB_TABLE + " J where J.serial=" +
@@ -813,26 +813,26 @@ inline bool AbcSmc::simulate_next_particles(const int n, const int serial_req, c
 // reports
 // =============================================================================================================
 inline void AbcLog::table_header(AbcSmc* abc, std::ostream& os) {
-    for (size_t i = 0; i < abc->npar(); i++) os << std::setw(WIDTH) << abc->_model_pars[i]->get_short_name();
+    for (size_t i = 0; i < abc->npar(); i++) os << std::setw(WIDTH) << abc->pars_[i]->get_short_name();
     os << " | ";
-    for (size_t i = 0; i < abc->nmet(); i++) os << std::setw(WIDTH) << abc->_model_mets[i]->get_short_name();
+    for (size_t i = 0; i < abc->nmet(); i++) os << std::setw(WIDTH) << abc->mets_[i]->get_short_name();
     os << std::endl;
 }
 
 inline void AbcLog::report_convergence_data(AbcSmc* abc, const size_t set_t, std::ostream& os) {   // AbcLog.cpp:24-77
-    if (abc->_predictive_prior.size() <= set_t) {
+    if (abc->kept_rows_.size() <= set_t) {
         os << "ERROR: attempting to report stats for set " << set_t << ", but data aren't available. " << std::endl
            << "       This can happen if --process is called on a database that is not ready to be processed." << std::endl;
         exit(-214);
     }
-    const Row current_means = ABC::col_means(ABC::select_rows(abc->_particle_parameters[set_t], abc->_predictive_prior[set_t]));
+    const Row current_means = ABC::col_means(ABC::select_rows(abc->set_params_[set_t], abc->kept_rows_[set_t]));
     Row last_means;
-    if (set_t > 0) last_means = ABC::col_means(ABC::select_rows(abc->_particle_parameters[set_t - 1], abc->_predictive_prior[set_t - 1]));
+    if (set_t > 0) last_means = ABC::col_means(ABC::select_rows(abc->set_params_[set_t - 1], abc->kept_rows_[set_t - 1]));
     os << double_bar() << std::endl << (set_t == 0 ? "Predictive prior summary statistics:\n" : "Convergence data for predictive priors:\n");
     auto pct = [](double delta, double base) { return base != 0 ? 100 * delta / base : INFINITY; };
-    for (size_t j = 0; j < abc->_model_pars.size(); j++) {
-        const ABC::Parameter* par = abc->_model_pars[j];
-        const double cur_sd = std::sqrt(abc->_doubled_variance[set_t][j] / 2.0);
+    for (size_t j = 0; j < abc->pars_.size(); j++) {
+        const ABC::Parameter* par = abc->pars_[j];
+        const double cur_sd = std::sqrt(abc->set_dv_[set_t][j] / 2.0);
         const double pm = par->get_mean(), ps = par->get_sd();
         os << "  Par " << j << ": \"" << par->get_name() << "\"\n" << "  Means:\n";
         print_stats("Prior", "current", pm, current_means[j], current_means[j] - pm, pct(current_means[j] - pm, pm), "", os);
@@ -841,7 +841,7 @@ inline void AbcLog::report_convergence_data(AbcSmc* abc, const size_t set_t, std
         os << "  Standard deviations:\n";
         print_stats("Prior", "current", ps, cur_sd, cur_sd - ps, pct(cur_sd - ps, ps), "\n", os);
         if (set_t != 0) {
-            const double last_sd = std::sqrt(abc->_doubled_variance[set_t - 1][j] / 2.0);
+            const double last_sd = std::sqrt(abc->set_dv_[set_t - 1][j] / 2.0);
             print_stats("Last", " current", last_sd, cur_sd, cur_sd - last_sd, pct(cur_sd - last_sd, last_sd), "\n", os);
         }
     }
@@ -853,9 +853,9 @@ inline void AbcLog::filtering_report(AbcSmc* abc, const size_t t, const Mat2D& p
     table_header(abc, os);
     for (size_t i = 0; i < ppars.cols(); i++) os << std::setw(WIDTH) << "---";
     os << " | ";
-    for (auto m : abc->_model_mets) os << std::setw(WIDTH) << m->get_obs_val();
+    for (auto m : abc->mets_) os << std::setw(WIDTH) << m->get_obs_val();
     os << std::endl;
-    os << "Normalized RMSE for metric means (lower is better):  " << ABC::calculate_nrmse(pmets, abc->_met_vals) << std::endl;
+    os << "Normalized RMSE for metric means (lower is better):  " << ABC::calculate_nrmse(pmets, abc->observed_) << std::endl;
     auto medians = [](const Mat2D& m) {
         Row out(m.cols());
         for (size_t j = 0; j < m.cols(); j++) out[j] = ABC::median(Col(m.data() + j * m.rows(), m.data() + (j + 1) * m.rows()));
