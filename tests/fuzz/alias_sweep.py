@@ -1,7 +1,7 @@
 """Measured mismatch / fallback rate of the DEVICE build of the resampling table (csrc/alias_dev.hip) on an MI355X: many random
 weight vectors of several kinds and sizes through abc_alias_table, every table compared entry by entry (bit patterns of F, values
 of A) with the CPU oracle's sequential gsl_ran_discrete_preproc.  Writes one JSON record.
-    python scripts/alias_sweep.py [tables per (kind, size)] [out.json]"""
+    python tests/fuzz/alias_sweep.py [tables per (kind, size)] [out.json]"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from abcsmc_amd import _lib          # noqa: E402
 from oracle import pyoracle as O     # noqa: E402  (the checker)

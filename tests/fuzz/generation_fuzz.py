@@ -6,12 +6,12 @@ parameter count (5e-7 up to 16 parameters, 5.5e-7 up to 32, 8e-7 up to 64: expon
 sixteen-term partial sum, all at their worst, for a weight that one term dominates; the north star allows 1e-6) (against the oracle's weights of the oracle's selection when the selections agree), doubled variance 1e-9,
 parents bit for bit when the weights are the oracle's to the last bit (first sets) -- else the parents' distribution is the
 weights', not checked here --, proposals finite and inside the priors' support.
-    python scripts/generation_fuzz.py [out.json] [cases] [seed]"""
+    python tests/fuzz/generation_fuzz.py [out.json] [cases] [seed]"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

@@ -2,13 +2,13 @@
 (itself held to <= 1e-9 of the oracle by tests/test_gpu_parity.py): random set sizes with ragged tiles, previous weights over a
 few or over sixty binades, zero weights, one far row on each side; every variant of the kernel (plain / norm pieces folded into
 spare K-slots / tiles in the order of the norm tops, the last one forced at these sizes).
-    python scripts/kde_accuracy_sweep.py [out.json] [cases per parameter count]
+    python tests/fuzz/kde_accuracy_sweep.py [out.json] [cases per parameter count]
 Writes, per parameter count: the largest and the rms relative error of a weight, the number of weights compared."""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from abcsmc_amd import _lib, abcutil, synthetic

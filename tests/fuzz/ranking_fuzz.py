@@ -5,12 +5,12 @@ of the one-pass statistics is for), a constant column, nearly collinear columns.
 What must hold (tests/test_gpu_parity.py::test_particle_ranking_pls): component count equal; means 1e-12, standard deviations
 1e-10; the distances and the order are BIT-EXACT given the device's model (the oracle's projection fed that model); against the
 oracle's own model distances to 1e-6 and the order up to near-ties.
-    python scripts/ranking_fuzz.py [out.json] [cases] [seed]"""
+    python tests/fuzz/ranking_fuzz.py [out.json] [cases] [seed]"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from abcsmc_amd import _lib, abcutil, synthetic

@@ -4,12 +4,12 @@ entries, the device build (alias_dev.hip) from there --, parents bit for bit (ab
 then abc_sample_mvn_predictive_priors / abc_sample_predictive_priors: parents and seeds bit for bit in the default noise mode,
 every proposal inside its prior's support and on the integer grid where the prior is one, and -- reference-stream mode, small
 sizes -- the proposals themselves, the seeds and the final rng state bit for bit.
-    python scripts/resample_fuzz.py [out.json] [cases] [seed]"""
+    python tests/fuzz/resample_fuzz.py [out.json] [cases] [seed]"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from abcsmc_amd import _lib, abcutil

@@ -3,7 +3,7 @@ cuda:0, at random shapes, against the single-process oracle: tests/_sharded_work
 (tests/test_sharded.py::_check) applied here.  Shapes cover parameter counts on every weight kernel (fp64, one / two / four
 chunks), first sets, the Wilcoxon rule, massively tied distances, local row counts below and above the gathered-sample
 selection's threshold.
-    python scripts/sharded_fuzz.py [out.json] [cases] [seed]"""
+    python tests/fuzz/sharded_fuzz.py [out.json] [cases] [seed]"""
 import json
 import os
 import subprocess
@@ -12,7 +12,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sharded_fuzz.json"
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 11

@@ -5,12 +5,12 @@ every parameter count from 1 to 70.  (Far means 8.5 to 18 proposal widths in one
 the sums enter double precision's subnormal range -- 2^-1060 carries fourteen bits -- and device and oracle, both right to that
 precision, differ by 1e-5: seen with rows 40 widths out, not a finding.)  Zero patterns must agree, every positive weight within the error budget of the kernel that
 ran (fp64: 1e-9; split: 5e-7 / 5.5e-7 / 8e-7 by chunk count), repeated calls bit-identical.
-    python scripts/weights_fuzz.py [out.json] [cases] [seed]"""
+    python tests/fuzz/weights_fuzz.py [out.json] [cases] [seed]"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from abcsmc_amd import _lib, abcutil, synthetic

@@ -84,12 +84,18 @@ def test_no_gpu_fails_loudly(L):
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "abcsmc_amd")
-    for dp, _, fns in os.walk(pkg):
-        for fn in fns:
-            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
-                txt = open(os.path.join(dp, fn)).read()
-                assert "pyoracle" not in txt and "abc_oracle" not in txt and "liboracle" not in txt, fn
+    """the oracle is test infrastructure: nothing in the package, the examples, the public header or the measurement / diagnostic
+    scripts loads it (the fuzzers that do live under tests/fuzz/); bench.py may, in its cpu_baseline leg only"""
+    for top in ("abcsmc_amd", "examples", "include", "scripts"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, top)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".sh")):
+                    txt = open(os.path.join(dp, fn)).read()
+                    assert "pyoracle" not in txt and "abc_oracle" not in txt and "liboracle" not in txt, os.path.join(top, fn)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("pyoracle") >= 1 and "def cpu_baseline" in bench
+    before = bench.split("def cpu_baseline")[0]
+    assert "import pyoracle" not in before and "from oracle" not in before, "bench.py loads the oracle outside its cpu_baseline leg"
 
 
 def test_header_is_plain_c_and_links(tmp_path, L):

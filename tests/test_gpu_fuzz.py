@@ -1,4 +1,4 @@
-"""Randomised differential tests: the fuzzers under scripts/ (each a stand-alone program that replays random shapes and unfriendly
+"""Randomised differential tests: the fuzzers under tests/fuzz/ (each a stand-alone program that replays random shapes and unfriendly
 data against the CPU oracle and prints one verdict line) at a small number of cases with fixed seeds.  Their long runs are
 summarised under profiles/r03_*_fuzz.json; the far-row bug of round 3 (weights.hip, k_wrows: a far coordinate beyond the first
 eight parameters) was found by the first of them."""
@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ])
 def test_fuzzer_finds_nothing(tmp_path, script, cases, seed):
     out = str(tmp_path / (script + ".json"))
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", script), out, str(cases)] + ([str(seed)] if seed is not None else [])
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "fuzz", script), out, str(cases)] + ([str(seed)] if seed is not None else [])
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     tail = (p.stdout[-3000:] + p.stderr[-2000:])
     assert p.returncode == 0, tail
