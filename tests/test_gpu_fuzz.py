@@ -31,3 +31,16 @@ def test_fuzzer_finds_nothing(tmp_path, script, cases, seed):
         assert last.endswith("over the asserted bound: none"), tail
     else:
         assert " 0 with problems" in last, "\n".join(l for l in p.stdout.splitlines() if l.startswith("FAIL"))[:4000] + "\n" + last
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_what_the_workspace_held():
+    """a slice of the parity suite with every entry point starting from a NaN-filled workspace (ABC_WS_POISON=ff): a kernel that
+    reads a workspace word nobody wrote in the same call would inherit the poison instead of the previous call's leftovers"""
+    env = dict(os.environ)
+    env["ABC_WS_POISON"] = "ff"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "generation_matches or generation_with_40 or weight_split_kernel or weight_far or particle_ranking_pls or resample_bit_exact "
+                        "or device_alias or perturb"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
+    assert " passed" in p.stdout and "failed" not in p.stdout.splitlines()[-1], p.stdout[-500:]
