@@ -44,3 +44,13 @@ def test_results_do_not_depend_on_what_the_workspace_held():
                         "or device_alias or perturb"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
     assert " passed" in p.stdout and "failed" not in p.stdout.splitlines()[-1], p.stdout[-500:]
+
+
+def test_fuzzers_compile():
+    """(CPU) the stand-alone fuzzers are valid Python: a syntax error in one would otherwise surface only on the GPU box"""
+    import glob
+    import py_compile
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "fuzz", "*.py")))
+    assert len(files) >= 7
+    for f in files:
+        py_compile.compile(f, doraise=True)
