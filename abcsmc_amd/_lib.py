@@ -33,7 +33,6 @@ class AbcWarning(UserWarning):
     pass
 
 
-WARN_GIVEUPS = 1
 
 
 class Prior(C.Structure):
@@ -96,6 +95,7 @@ SIGNATURES = {
     "abc_ctx_set_noise_mode": (_i, [_vp, _i]),
     "abc_ctx_set_weight_kernel": (_i, [_vp, _i]),
     "abc_perturb_giveups": (_i, [_vp, _vp, _i]),
+    "abc_generation_giveups": (_i, [_vp, _vp]),
     "abc_ctx_set_alias_mode": (_i, [_vp, _i]),
     "abc_alias_stats": (_i, [_vp, _vp, _vp, _i]),
     "abc_alias_table": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
@@ -194,13 +194,22 @@ class Context:
         return self._h
 
     def check(self, rc):
-        """negative status: AbcError; positive (ABC_WARN_GIVEUPS): a Python warning, the call's outputs are valid"""
-        if rc < 0:
+        """non-zero status: AbcError (the ABI has no positive status)"""
+        if rc:
             raise AbcError(rc, lib().abc_last_error(self._h).decode())
-        if rc > 0:
+
+    def warn_generation_giveups(self):
+        """after abc_generation_dev: a Python warning when the perturbation gave up on proposals during that call (they are
+        their valid parents / prior means; the reference would still be retrying, AbcUtil.cpp:132).  No synchronisation."""
+        n = C.c_uint64(0)
+        lib().abc_generation_giveups(self._h, C.byref(n))
+        if n.value:
             import warnings
-            self.last_warning = lib().abc_last_error(self._h).decode()
-            warnings.warn(AbcWarning(self.last_warning), stacklevel=2)
+            self.last_warning = ("generation complete, but the perturbation gave up on %d proposal(s): they are their parents "
+                                 "(MULTIVARIATE, after 16384 rejected attempts) or prior means (INDEPENDENT, after 1000); "
+                                 "abc_perturb_giveups has the total" % n.value)
+            warnings.warn(AbcWarning(self.last_warning), stacklevel=3)
+        return n.value
 
     def set_stream(self, stream_ptr):
         if getattr(self, "_stream", -1) != stream_ptr:      # abc_ctx_set_stream synchronises: only on change

@@ -12,6 +12,14 @@
 
 #define ABC_WAVE 64
 
+// Diagnostic switches (include/abcsmc_hip.h, "Diagnostic environment switches"): an environment variable steers the library
+// ONLY when ABC_DIAG=1 is set beside it -- a production process that happens to inherit ABC_WS_POISON or ABC_ALIAS_FORCE_FAIL
+// from somebody's shell is not affected.  Every getenv of the library goes through here.
+inline const char* abc_diag_env(const char* name) {
+    static const bool on = [] { const char* d = getenv("ABC_DIAG"); return d && d[0] == '1'; }();
+    return on ? getenv(name) : nullptr;
+}
+
 // timed stages (abc_timing_names in api.hip must match)
 enum { ST_GRAM = 0, ST_STATS_REDUCE, ST_PLS_MODEL, ST_PROJECT, ST_SELECT, ST_SORT, ST_GATHER_DV, ST_KDE,
        ST_WEIGHTS_MISC, ST_MVN, ST_ALIAS_HOST, ST_RESAMPLE, ST_PERTURB, ST_COMM, ABC_NSTAGE };
@@ -61,7 +69,8 @@ struct abc_ctx {
     unsigned long long alias_dev_builds, alias_dev_fallbacks;   // device builds queued / found unusable (abc_alias_stats)
     unsigned long long* giveups_dev;   // proposals the perturbation gave up on (device counter, abc_perturb_giveups)
     unsigned long long giveups_host;   // ... and in the reference-stream host loop
-    unsigned long long giveups_seen;   // device counter as of the last generation's end (abc_generation_dev warns when it grows)
+    unsigned long long giveups_seen;   // device counter as of the last generation's end
+    unsigned long long giveups_last_call;   // what the most recent generation added to it (abc_generation_giveups)
     unsigned long long giveups_dev_known;   // the device counter as the host last read it (re-read only when the pinned flag word says it moved)
     int timers_open;                   // StageTimers between their two events (the ring is only drained when none is)
     unsigned long long timing_dropped; // samples that found the ring full while a timer was open (abc_timing_read reports them)
@@ -245,10 +254,11 @@ int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t
 // kernel, and the proposals' give-up counter is snapshotted into its second slot.  done: an event bound to the kernel's OWN
 // completion signal (hipExtLaunchKernelGGL's stop event) -- a hipEventRecord behind it is one more packet in the queue, and the
 // next kernel waits for that packet: ~7 us of the main stream's critical path per record (rocprofv3 timeline)
+int abc_giveups_ensure(abc_ctx* ctx);
 int launch_gather_rows(abc_ctx*, const double* Y, size_t n_local, size_t ldy, size_t P,
                        const uint64_t* idx, size_t K, uint64_t idx_base, double* theta, size_t ldt,
                        const int* sel_fail = nullptr, int* sel_fail_pin = nullptr, hipEvent_t done = nullptr);
-#define ABC_INTERNAL_RETRY 1      // launch_resample: the caller's abort flag was set when the host looked (not an error code of the ABI)
+#define ABC_INTERNAL_RETRY (-2147483647)      // launch_resample: the caller's abort flag was set when the host looked (not an error code of the ABI)
 int launch_doubled_variance(abc_ctx*, const double* theta, size_t K, size_t P, double* dv);
 // K x P posterior moments computed once (Gram kernel) and shared by the doubled variance and the MVN factor
 int launch_theta_stats(abc_ctx*, const double* theta, size_t K, size_t P, double** stats_out);

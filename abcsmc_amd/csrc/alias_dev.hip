@@ -481,6 +481,11 @@ __global__ __launch_bounds__(AL_T) void k_al_structure(const i128* __restrict__ 
                                                        const i128* __restrict__ Xc, const u64* __restrict__ dI, const i128* __restrict__ VI,
                                                        AlHead* __restrict__ head, uint32_t* __restrict__ z, uint32_t* __restrict__ jof,
                                                        StepRec* __restrict__ step) {
+    // weights the earlier launches flagged (non-finite, negative, off the grid): the exact sums are then not sums of what the
+    // rank searches assume (a non-finite big has VI = 0: X decreases), slots of `step` would stay unwritten and the serving
+    // kernels would follow garbage indices -- nothing below this point runs, the caller builds the table on the host.
+    // (the flag was written by earlier LAUNCHES: visible here; nothing in this launch or the next sets it before they read it)
+    if (head->fail) return;
     const unsigned ns = head->ns, nb = head->nb;
     const size_t t = (size_t)blockIdx.x * AL_T + threadIdx.x;
     unsigned pos = 0;                                          // 1-based position of this thread's step in the chain (0: none)
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_reduce(ServeArgs a, const AlH
                                                           RMap* __restrict__ tpre) {
     __shared__ RMap buf[2][AL_T];
     const unsigned n = head->nsteps;
+    if (head->fail) return;                                        // (see k_al_structure)
     if ((size_t)blockIdx.x * AL_B >= n) { if (threadIdx.x == 0) agg[blockIdx.x] = rmap_identity(); return; }
     const size_t base = (size_t)blockIdx.x * AL_B + (size_t)threadIdx.x * AL_I;
     const i128 MEAN = head->MEAN;
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(AL_T) void k_al_serve_apply(ServeArgs a, AlHead* __
     const unsigned n = head->nsteps, ns = head->ns, nb = head->nb;
     const bool last_block = ((size_t)(blockIdx.x + 1) * AL_B >= n);
     if ((size_t)blockIdx.x * AL_B >= n && blockIdx.x != 0) return;
-    if (n == 0) {                                                  // no small or no big: the defaults are the table
+    if (n == 0 || head->fail) {              // no small or no big: the defaults are the table; or a build flagged before this launch
         if (blockIdx.x == 0 && threadIdx.x == 0) { *fail_out = head->fail; if (fail_pin) *fail_pin = head->fail; }
         return;
     }
@@ -641,7 +647,7 @@ int launch_alias_build_dev_i2(abc_ctx* ctx, const double* w, size_t K, double* F
 int launch_alias_build_dev_i4(abc_ctx* ctx, const double* w, size_t K, double* F, uint32_t* A, int* fail_dev, int* fail_pin,
                               const int** verdict_src);
 static size_t alias_small_k() {             // tables up to this size: two elements per thread
-    static const size_t k = getenv("ABC_ALIAS_SMALL_K") ? (size_t)atoll(getenv("ABC_ALIAS_SMALL_K")) : ABC_ALIAS_DEV_SMALL_K;
+    static const size_t k = abc_diag_env("ABC_ALIAS_SMALL_K") ? (size_t)atoll(abc_diag_env("ABC_ALIAS_SMALL_K")) : ABC_ALIAS_DEV_SMALL_K;
     return k;
 }
 size_t abc_alias_dev_need(size_t K) {       // (the larger of the two variants' needs: the smaller work-groups')
@@ -685,7 +691,7 @@ int ABC_AL_FN(launch_alias_build_dev)(abc_ctx* ctx, const double* w, size_t K, d
     const double mean = 1.0 / (double)K, dK = (double)K;
     hipStream_t st = ctx->stream;
     // ABC_ALIAS_FORCE_FAIL (tests): the build reports failure although it verified, so the callers' host fall-backs can be exercised
-    const int force_fail = getenv("ABC_ALIAS_FORCE_FAIL") ? 1 : 0;
+    const int force_fail = abc_diag_env("ABC_ALIAS_FORCE_FAIL") ? 1 : 0;
     hipLaunchKernelGGL(k_al_bsum, dim3(nblk), dim3(AL_T), 0, st, w, K, bsum, head, force_fail);
     hipLaunchKernelGGL(k_al_sum_reduce, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, agg, tpre, head);
     hipLaunchKernelGGL(k_al_sum_apply, dim3(nblk), dim3(AL_T), 0, st, w, K, (const double*)bsum, nblk, (const RMap*)agg, (const RMap*)tpre, head);

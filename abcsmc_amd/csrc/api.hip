@@ -20,7 +20,7 @@ int abc_ws_reserve(abc_ctx* ctx, size_t bytes) {
     // ABC_WS_POISON=<byte> (debugging): every entry point starts from a workspace filled with that byte (ff: NaNs and huge
     // integers), so that a kernel which reads a word nobody wrote in THIS call shows up in the tests instead of inheriting
     // whatever the previous call left there
-    static const char* poison = getenv("ABC_WS_POISON");
+    static const char* poison = abc_diag_env("ABC_WS_POISON");
     if (poison && ctx->ws) ABC_HIP(ctx, hipMemsetAsync(ctx->ws, (int)strtol(poison, nullptr, 16), ctx->ws_bytes, ctx->stream));
     return ABC_OK;
 }
@@ -185,6 +185,12 @@ extern "C" int abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset) {
     ctx->giveups_dev_known = reset ? 0ull : dev;
     ctx->giveups_seen = reset ? 0 : (unsigned long long)*count;
     if (reset) ctx->giveups_host = 0;
+    return ABC_OK;
+}
+
+extern "C" int abc_generation_giveups(const abc_ctx* ctx, uint64_t* count) {
+    if (!ctx || !count) return ABC_ERR_INVALID;
+    *count = (uint64_t)ctx->giveups_last_call;
     return ABC_OK;
 }
 
@@ -480,6 +486,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (!N || !M || K > N) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: bad sizes N=%zu M=%zu K=%zu", N, M, K);
     const size_t ws_entry = ctx->ws_off;              // a failed bin selection (select.hip) repeats the call from here
     ctx->side_early_waited = false;
+    ctx->giveups_last_call = 0;
+    if (Nn) ABC_TRY(abc_giveups_ensure(ctx));         // (the gather snapshots the counter: it has to exist before the first proposals)
     abc_rng rng_entry;
     if (rng) rng_entry = *rng;
     if (!simple && !(0.0 < cfg->train_frac && cfg->train_frac <= 1.0))      // AbcUtil.cpp:428
@@ -514,7 +522,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // it is forked at the call's START -- the record is the first packet of an idle queue, processed while the host prepares the
     // first launch -- and runs beside the Gram kernel; forked behind that kernel (rounds 2 and 3) the record sat between the
     // reduce and the fit and cost the critical path ~6 us (rocprofv3 timeline).  Its launches still follow the fit's.
-    static const int fork_late = getenv("ABC_FORK_LATE") ? 1 : 0;
+    static const int fork_late = abc_diag_env("ABC_FORK_LATE") ? 1 : 0;
     ctx->side_forked = false;
     if (!fork_late) ABC_TRY(abc_side_fork(ctx));
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
@@ -538,9 +546,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // need it ~0.3 ms into the generation), THEN the seeds (an output nobody reads before the call returns): the moments' event,
     // which the main stream waits for in front of the resampling table, is recorded behind all of them on the same stream
     const bool weighted = io->w && K && Kp && io->theta_prev;
-    static const int moments_main = getenv("ABC_MOMENTS_MAIN") ? 1 : 0;             // A/B switches for measurements
+    static const int moments_main = abc_diag_env("ABC_MOMENTS_MAIN") ? 1 : 0;             // A/B switches for measurements
     const bool moments_side_possible = Nn && P <= 64 && K >= 2 && !uniform_w && !moments_main && ctx->side;
-    static const int seeds_first = getenv("ABC_SEEDS_FIRST") ? 1 : 0;              // A/B switch for measurements
+    static const int seeds_first = abc_diag_env("ABC_SEEDS_FIRST") ? 1 : 0;              // A/B switch for measurements
     const bool seeds_late = early && weighted && !seeds_first && moments_side_possible;
     if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, seeds_late ? nullptr : io->seeds, Nn, &raw_early, parent_early, K));
     abc_wprev wprev;
@@ -573,12 +581,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     int* const spd_pin = (int*)(ctx->status_pin + 32);
     hdr_pin[0] = 0.0; *spd_pin = 0;
     bool status_early = false;
-    static const int status_late = getenv("ABC_STATUS_KERNEL") ? 1 : 0;           // A/B switch for measurements
+    static const int status_late = abc_diag_env("ABC_STATUS_KERNEL") ? 1 : 0;           // A/B switch for measurements
     const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
     // The main stream needs what the side stream queued early (the previous set's tiles, the taus2 outputs) only behind the
     // gather, and those kernels ended long ago: the wait goes IN FRONT of the gather, where the event is certain to have fired
     // (a wait that still has to be resolved between the gather and the new set's tiles cost ~12 us of the critical path there)
-    static const int wait_late = getenv("ABC_WAIT_LATE") ? 1 : 0;
+    static const int wait_late = abc_diag_env("ABC_WAIT_LATE") ? 1 : 0;
     ctx->side_early_waited = false;
     if (wprev.ready && !wait_late) {
         ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
@@ -586,8 +594,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     }
     // (weighted generations hand the gathered rows to the side stream, for the posterior's moments: the event that orders the two
     // is the gather's own completion signal, not a record behind it)
-    static const int side_moments_on = getenv("ABC_MOMENTS_MAIN") ? 0 : 1;        // A/B switches for measurements
-    static const int ev_marker = getenv("ABC_EV_MARKER") ? 1 : 0;
+    static const int side_moments_on = abc_diag_env("ABC_MOMENTS_MAIN") ? 0 : 1;        // A/B switches for measurements
+    static const int ev_marker = abc_diag_env("ABC_EV_MARKER") ? 1 : 0;
     const bool defer_moments = Nn && P <= 64 && K >= 2;
     const bool moments_side_planned = defer_moments && !uniform_w && side_moments_on && ctx->side && ctx->noise_mode != ABC_NOISE_REFERENCE_STREAM;
     if (moments_side_planned && !ctx->ev_theta) {
@@ -806,6 +814,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             ctx->alias_mode = mode;
             ABC_TRY(rc);
             prep_used.seeds_done = 1;
+            // (the first pass's give-ups belong to proposals that are being replaced: counter back to the generation's snapshot)
+            if (ctx->giveups_dev)
+                ABC_HIP(ctx, hipMemcpyAsync(ctx->giveups_dev, ctx->giveups_dev + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
             ABC_TRY(launch_perturb(ctx, &rng_entry, theta, K, P, io->priors, parent_used, 0, Nn, cfg->multivariate,
                                    cfg->multivariate ? L_used : dv, io->next, nullptr, Nn, &prep_used));
             ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -828,10 +839,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         const unsigned long long gv = *(volatile unsigned long long*)(ctx->status_pin + 48) + ctx->giveups_host;
         const unsigned long long before = ctx->giveups_seen;
         ctx->giveups_seen = gv;
-        if (Nn && gv > before)
-            ABC_FAIL(ctx, ABC_WARN_GIVEUPS, "generation complete, but the perturbation gave up on %llu proposal(s): they are their parents "
-                     "(MULTIVARIATE, after %u rejected attempts) or prior means (INDEPENDENT, after 1000); abc_perturb_giveups has the total",
-                     gv - before, 16384u);
+        // (status stays ABC_OK: a C caller's `if (rc)` must not read a finished generation as a failure; abc_generation_giveups)
+        ctx->giveups_last_call = (Nn && gv > before) ? gv - before : 0ull;
     }
     return ABC_OK;
 }

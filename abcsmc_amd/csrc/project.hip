@@ -390,7 +390,7 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
     // goes through the scalar kernel below)
     bool mfma_kernel = false;
     size_t mfma_lb = 0, mfma_main = 0;
-    static const bool valu_only = getenv("ABC_PROJECT_VALU") != nullptr;          // A/B switch for measurements
+    static const bool valu_only = abc_diag_env("ABC_PROJECT_VALU") != nullptr;          // A/B switch for measurements
     if (KC == 32 && npairs && !valu_only) {       // (16 components: the vector kernel is 5-10 % faster, measured)
         const size_t M4 = (M + 3) & ~(size_t)3;
         mfma_main = (M4 * KC + 2 * M4 > (size_t)4 * 64 * (KC + 1)) ? M4 * KC + 2 * M4 : (size_t)4 * 64 * (KC + 1);

@@ -609,7 +609,7 @@ int abc_side_fork(abc_ctx* ctx) {
     // The side stream must start behind everything queued on the main one so far.  When the main stream is idle -- the usual
     // case at the start of a generation: the previous call ended with a synchronisation -- that holds without an event, and the
     // record + wait pair (~15 us of host time in front of the generation's first launch, the GPU idle meanwhile) is skipped.
-    static const int always = getenv("ABC_FORK_ALWAYS") ? 1 : 0;           // A/B switch for measurements
+    static const int always = abc_diag_env("ABC_FORK_ALWAYS") ? 1 : 0;           // A/B switch for measurements
     if (always || hipStreamQuery(ctx->stream) != hipSuccess) {
         (void)hipGetLastError();                                           // (hipErrorNotReady is not an error here)
         ABC_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -833,6 +833,16 @@ int launch_perturb_prepare(abc_ctx* ctx, const abc_rng* rng, const double* theta
     return ABC_OK;
 }
 
+// the proposals' give-up counter: [0] the counter, [1] its snapshot (taken by the gather in front of a generation's weight stage:
+// a repeated perturbation starts from it), [2] the address of the pinned flag word (note_giveup)
+int abc_giveups_ensure(abc_ctx* ctx) {
+    if (ctx->giveups_dev) return ABC_OK;
+    ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, 3 * sizeof(unsigned long long)));
+    const unsigned long long init[3] = {0ull, 0ull, (unsigned long long)(size_t)(ctx->status_pin + 56)};
+    ABC_HIP(ctx, hipMemcpy(ctx->giveups_dev, init, sizeof(init), hipMemcpyHostToDevice));
+    return ABC_OK;
+}
+
 int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t K, size_t P, const abc_prior* priors,
                    const uint64_t* parent, uint64_t i0, size_t n, int multivariate, const double* L_or_dv, double* out,
                    uint64_t* seeds, uint64_t seed_stream_offset, const abc_perturb_prep* prep) {
@@ -840,12 +850,7 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     if (P > 64) PP = (int)((P + 63) / 64 * 64);
-    if (!ctx->giveups_dev) {
-        // [0] the counter, [1] its snapshot, [2] the address of the pinned flag word (note_giveup)
-        ABC_HIP(ctx, hipMalloc((void**)&ctx->giveups_dev, 3 * sizeof(unsigned long long)));
-        const unsigned long long init[3] = {0ull, 0ull, (unsigned long long)(size_t)(ctx->status_pin + 56)};
-        ABC_HIP(ctx, hipMemcpy(ctx->giveups_dev, init, sizeof(init), hipMemcpyHostToDevice));
-    }
+    ABC_TRY(abc_giveups_ensure(ctx));
     StageTimer tm(ctx, ST_PERTURB);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     double* rows = (prep && prep->rows) ? prep->rows : (double*)abc_ws_alloc(ctx, K * (size_t)PP * sizeof(double));

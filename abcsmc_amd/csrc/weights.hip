@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ 
     // (fused drivers) the first kernel behind the selection: the selection's give-up flag goes to the pinned status block
     // now, so the host sees it at its next synchronisation -- before it builds an alias table of placeholder weights --, and the
     // give-up counter of the proposals is snapshotted (a repeated generation restores it)
-    if (e == 0 && sel_fail) { *sel_fail_pin = *sel_fail; if (giveups) giveups[1] = giveups[0]; }
+    if (e == 0) { if (sel_fail) *sel_fail_pin = *sel_fail; if (giveups) giveups[1] = giveups[0]; }
     if (e >= K * (size_t)P) return;
     const size_t i = e % K, p = e / K;
     const unsigned long long g = idx[i];
@@ -1100,11 +1100,11 @@ int launch_gather_rows(abc_ctx* ctx, const double* Y, size_t n_local, size_t ldy
     if (done)
         hipExtLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, nullptr, done, 0, Y, n_local, ldy,
                               (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt, sel_fail, sel_fail_pin,
-                              sel_fail ? ctx->giveups_dev : (unsigned long long*)nullptr);
+                              ctx->giveups_dev);
     else
         hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Y, n_local, ldy,
                            (int)P, (const unsigned long long*)idx, K, (unsigned long long)idx_base, theta, ldt, sel_fail, sel_fail_pin,
-                           sel_fail ? ctx->giveups_dev : (unsigned long long*)nullptr);
+                           ctx->giveups_dev);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
@@ -1261,14 +1261,14 @@ __global__ __launch_bounds__(256) void k_tile_tmin(const float* __restrict__ top
 // stage-level call): the variants with one MFMA less
 static bool ks_topn_on(size_t P, bool split, bool fold, size_t pairs) {
     if (!split || fold) return false;
-    const char* e = getenv("ABC_KDE_TOPN_MIN_PAIRS");                       // (tests: 0 = always; A/B: a huge number = never)
+    const char* e = abc_diag_env("ABC_KDE_TOPN_MIN_PAIRS");                       // (tests: 0 = always; A/B: a huge number = never)
     const double minp = e ? atof(e) : 4.0e9;
     return (double)pairs >= minp;
 }
 
 // up to 13 / 17..29 / 33..61 parameters: the variants of the split kernel with two MFMAs fewer (norm pieces in the spare K-slots: KS_FOLD)
 static bool ks_fold_on(size_t P, bool split) {
-    static const bool off = getenv("ABC_KDE_NOFOLD") != nullptr;              // A/B switch for measurements
+    static const bool off = abc_diag_env("ABC_KDE_NOFOLD") != nullptr;              // A/B switch for measurements
     const size_t nch = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
     return split && P + 3 <= 16 * nch && !off;                                // three spare K-slots in the last chunk
 }

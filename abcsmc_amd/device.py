@@ -66,15 +66,20 @@ class Generation:
         """X: (M, N), Y: (P, N), obs: (M,), all float64 on self.device; rng: _lib.Rng (advanced)."""
         cfg = self.cfg
         weighted = theta_prev is not None and cfg.Kp
+        # (addresses AND shapes: torch's caching allocator hands the same address to a differently shaped tensor)
         key = (X.data_ptr(), Y.data_ptr(), obs.data_ptr(), priors_dev.data_ptr(),
                theta_prev.data_ptr() if weighted else 0, w_prev.data_ptr() if weighted else 0,
-               dv_prev.data_ptr() if weighted else 0)
+               dv_prev.data_ptr() if weighted else 0, X.shape, Y.shape, X.stride(), Y.stride(), obs.shape, priors_dev.shape,
+               theta_prev.shape if weighted else None, theta_prev.stride() if weighted else None,
+               w_prev.shape if weighted else None, dv_prev.shape if weighted else None)
         if key != self._io_key:           # (the argument block of the C call is rebuilt only when a buffer moved)
             assert X.shape == (cfg.M, cfg.N) and Y.shape == (cfg.P, cfg.N) and X.is_contiguous() and Y.is_contiguous()
+            assert obs.numel() == cfg.M and obs.is_contiguous() and priors_dev.numel() >= 24 * cfg.P
             io = GenerationIO()
             io.X, io.Y, io.obs, io.priors = key[0], key[1], key[2], key[3]
             if weighted:
-                assert theta_prev.shape == (cfg.P, cfg.Kp)
+                assert theta_prev.shape == (cfg.P, cfg.Kp) and theta_prev.is_contiguous()
+                assert w_prev.numel() == cfg.Kp and dv_prev.numel() == cfg.P and w_prev.is_contiguous() and dv_prev.is_contiguous()
                 io.theta_prev, io.w_prev, io.dv_prev = key[4], key[5], key[6]
             io.idx, io.dist, io.theta = self.idx.data_ptr(), self.dist.data_ptr(), self.theta.data_ptr()
             io.w, io.dv, io.L = self.w.data_ptr(), self.dv.data_ptr(), self.L.data_ptr()
@@ -84,4 +89,6 @@ class Generation:
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)      # (a no-op unless the stream changed)
         a = self._args
         self.ctx.check(self._call(a[0], a[1], a[2], C.addressof(rng), a[4]))
+        if cfg.Nnext:
+            self.ctx.warn_generation_giveups()
         return self

@@ -16,11 +16,16 @@
  *   - functions WITHOUT the _dev suffix take HOST pointers (drop-in for the reference call
  *     sites); functions WITH _dev take DEVICE pointers (HBM-resident data, used by bench.py and
  *     the multi-GPU driver) and run asynchronously on the context's stream.
- *   - every function returns ABC_OK (0) or a negative abc_status; abc_last_error() gives text.  One POSITIVE value exists:
- *     abc_generation_dev returns ABC_WARN_GIVEUPS when its outputs are complete and valid but some proposals are their (valid)
- *     parents or a prior mean because the perturbation gave up on them (the reference would still be retrying, AbcUtil.cpp:132).
+ *   - every function returns ABC_OK (0) or a negative abc_status; abc_last_error() gives text; there is no positive status
+ *     (`if (rc)` is a valid failure test).  A generation whose outputs are complete and valid but in which the perturbation gave
+ *     up on some proposals -- they are their (valid) parents or a prior mean; the reference would still be retrying,
+ *     AbcUtil.cpp:132 -- returns ABC_OK and says so through abc_generation_giveups / abc_perturb_giveups.
  *     Nothing here calls exit() or throws (the reference exits/aborts).
  *   - one context per GPU and per host thread; calls on one context are serialised.
+ *   - Diagnostic environment switches: the library reads NO environment variable unless ABC_DIAG=1 is set; beside it, the
+ *     test / A-B switches listed in INTEGRATION.md section 6 act (ABC_WS_POISON: workspace pre-filled with a byte;
+ *     ABC_ALIAS_FORCE_FAIL: the device alias build reports failure; kernel-variant and stream-orchestration A/B switches).
+ *     None changes a result except by forcing a documented fall-back path.
  */
 #ifndef ABCSMC_HIP_H
 #define ABCSMC_HIP_H
@@ -35,7 +40,6 @@ extern "C" {
 typedef struct abc_ctx abc_ctx;
 
 typedef enum {
-    ABC_WARN_GIVEUPS = 1,       /* abc_generation_dev: done, but abc_perturb_giveups grew during this call (see there)       */
     ABC_OK = 0,
     ABC_ERR_INVALID = -1,       /* bad argument (reference: assert / exit)                   */
     ABC_ERR_HIP = -2,           /* HIP runtime failure                                        */
@@ -119,6 +123,8 @@ int  abc_alias_table(abc_ctx* ctx, const double* w, size_t K, double* F, uint64_
  * AbcUtil.cpp:132) plus independent-noise coordinates that fell back to the prior mean after 1000 tries (the reference prints
  * an error line per fallback, Priors.h:27-29).  Synchronises. */
 int  abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset);
+/* ... and how many of them the most recent abc_generation_dev call on this context added (0 after a clean generation; the value the host already holds at the call's end: no synchronisation). */
+int  abc_generation_giveups(const abc_ctx* ctx, uint64_t* count);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
  * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]

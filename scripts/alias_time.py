@@ -1,6 +1,7 @@
 """Device time of the resampling table's build (HIP-event bracket of its launches) at a given size, log-normal weights.
     python scripts/alias_time.py K [K ...]        (ABC_ALIAS_SMALL_K overrides the size up to which two elements per thread are used)"""
 import os
+os.environ.setdefault("ABC_DIAG", "1")     # the library reads its diagnostic switches only beside this
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

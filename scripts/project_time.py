@@ -1,6 +1,7 @@
 """Times the PLS ranking (device resident) at a given shape; the stage timers give the projection kernel's share.
     python scripts/project_time.py N M P A        (ABC_PROJECT_VALU=1: the vector-pipe projection for 16 / 32 components)"""
 import os
+os.environ.setdefault("ABC_DIAG", "1")     # the library reads its diagnostic switches only beside this
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

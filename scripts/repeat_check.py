@@ -6,6 +6,7 @@ every launch (AMD_SERIALIZE_KERNEL=3): a dependency the streams' events do not e
     python scripts/repeat_check.py [repeats]"""
 import hashlib
 import os
+os.environ.setdefault("ABC_DIAG", "1")     # the library reads its diagnostic switches only beside this
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library honours its diagnostic switches (ABC_WS_POISON, ABC_ALIAS_FORCE_FAIL, ABC_KDE_TOPN_MIN_PAIRS, ...) only beside
+# ABC_DIAG=1, read once at its first call: the tests that flip them need it set before the library loads
+os.environ.setdefault("ABC_DIAG", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -6,6 +6,7 @@ spare K-slots / tiles in the order of the norm tops, the last one forced at thes
 Writes, per parameter count: the largest and the rms relative error of a weight, the number of weights compared."""
 import json
 import os
+os.environ.setdefault("ABC_DIAG", "1")     # the library reads its diagnostic switches only beside this
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -33,6 +33,16 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
 
 
+def test_nothing_but_the_abi_is_exported(L):
+    """-Wl,--version-script (csrc/exports.map): the dynamic symbol table of the library is the header's list, nothing else --
+    no mangled C++ helpers, no kernels' host stubs"""
+    import subprocess
+    from abcsmc_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared(), set(exported) ^ set(_declared())
+
+
 def test_version_and_layout_helpers(L):
     assert L.abc_version() >= 100
     assert L.abc_stats_len(32, 16) == 2 + 3 * 48 + 2 * 48 * 48

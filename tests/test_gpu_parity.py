@@ -889,6 +889,47 @@ def test_device_alias_table_falls_back_outside_its_grid(gpu_ctx, oracle):
         gpu_ctx.set_alias_mode(_lib.ALIAS_DEVICE)
 
 
+@pytest.mark.parametrize("K", [5000, 30000])
+@pytest.mark.parametrize("bad", ["two_inf", "nan", "negative", "inf_and_nan"])
+def test_device_alias_table_with_unusable_weights_goes_to_the_host(gpu_ctx, bad, K):
+    """non-finite / negative weights: the first launches of the device build flag them, and NOTHING behind the flag
+    may run on them -- a non-finite "big" has grid value 0, the excess sums then decrease, the rank searches stop being a
+    bijection onto the chain's steps and the serving kernels would follow unwritten indices out of bounds.  The kernels now
+    return at the flag; the table comes from the host's sequential build, the same bytes as with ABC_ALIAS_HOST.  (Also part of
+    the poisoned-workspace slice of tests/test_gpu_fuzz.py, where unwritten step records are 0xff..ff indices.)"""
+    from abcsmc_amd import _lib
+    rng = np.random.default_rng(11)
+    w = rng.random(K)
+    if bad == "two_inf":
+        w[[7, K // 2]] = np.inf
+    elif bad == "nan":
+        w[K // 3] = np.nan
+    elif bad == "negative":
+        w[K - 2] = -0.25
+    else:
+        w[3], w[K - 1] = np.inf, np.nan
+    gpu_ctx.alias_stats(reset=True)
+    F, A, on_device = gpu_ctx.alias_table(w)
+    assert on_device == 0 and gpu_ctx.alias_stats() == (1, 1)
+    gpu_ctx.set_alias_mode(_lib.ALIAS_HOST)
+    try:
+        hF, hA, _ = gpu_ctx.alias_table(w)
+    finally:
+        gpu_ctx.set_alias_mode(_lib.ALIAS_DEVICE)
+        gpu_ctx.alias_stats(reset=True)
+    assert np.array_equal(A, hA) and np.array_equal(F.view(np.uint64), hF.view(np.uint64))
+    # ... and the context is fine afterwards: a well-posed table right behind it is built on the device and is GSL's
+    w2 = rng.random(K)
+    F2, A2, on2 = gpu_ctx.alias_table(w2)
+    gpu_ctx.set_alias_mode(_lib.ALIAS_HOST)
+    try:
+        hF2, hA2, _ = gpu_ctx.alias_table(w2)
+    finally:
+        gpu_ctx.set_alias_mode(_lib.ALIAS_DEVICE)
+        gpu_ctx.alias_stats(reset=True)
+    assert on2 == 1 and np.array_equal(A2, hA2) and np.array_equal(F2.view(np.uint64), hF2.view(np.uint64))
+
+
 def test_sample_mvn_predictive_priors(gpu_ctx, oracle):
     from abcsmc_amd import abcutil, _lib
     rng = np.random.default_rng(21)
@@ -1082,7 +1123,8 @@ def test_perturb_giveups_are_counted(gpu_ctx):
 
 def test_generation_reports_giveups_as_a_warning_status(gpu_ctx):
     """abc_generation_dev with a prior no proposal can land in: the call completes -- every proposal is its (valid) parent --
-    and returns ABC_WARN_GIVEUPS (positive: a warning, not an error) with the count in its message; the next, well-posed
+    and returns ABC_OK (the ABI has no positive status: `if (rc)` stays a valid failure test); abc_generation_giveups holds the
+    count of THAT call, which the Python driver turns into a warning; the next, well-posed
     generation returns ABC_OK again (the reference would never return, AbcUtil.cpp:132)"""
     import torch
     from abcsmc_amd import abcutil, device, _lib
@@ -1098,6 +1140,9 @@ def test_generation_reports_giveups_as_a_warning_status(gpu_ctx):
     with pytest.warns(_lib.AbcWarning, match="gave up on %d proposal" % Nn):
         gen.run(*args, device.priors_to_device(_lib.make_priors(spec), dev), abcutil.rng(3))
     torch.cuda.synchronize()
+    import ctypes as C
+    last = C.c_uint64(0)
+    assert _lib.lib().abc_generation_giveups(gpu_ctx.handle, C.byref(last)) == 0 and last.value == Nn
     assert gpu_ctx.perturb_giveups() == Nn
     nxt = device.to_numpy(gen.next)
     assert np.all(nxt[:, 0] == a0) and np.isfinite(nxt).all()        # the prior mean of the zero-width prior (Priors.h:23-31)
@@ -1105,6 +1150,7 @@ def test_generation_reports_giveups_as_a_warning_status(gpu_ctx):
     with warnings.catch_warnings():
         warnings.simplefilter("error")                               # a well-posed generation: no warning
         gen.run(*args, device.priors_to_device(_lib.make_priors(wl.prior_spec()), dev), abcutil.rng(3))
+    assert _lib.lib().abc_generation_giveups(gpu_ctx.handle, C.byref(last)) == 0 and last.value == 0
     assert gpu_ctx.perturb_giveups(reset=True) == Nn
 
 
