@@ -189,6 +189,15 @@ class Context:
             raise AbcError(rc, "abc_ctx_create(device=%d) failed: no usable GPU (HIP path is mandatory)" % device)
         self.device = device
 
+    @classmethod
+    def from_handle(cls, handle, device):
+        """a view of a context somebody else owns (MultiContext.context): not destroyed with this object"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(handle)
+        self.device = int(device)
+        self._borrowed = True
+        return self
+
     @property
     def handle(self):
         return self._h
@@ -324,9 +333,9 @@ class Context:
         self.check(lib().abc_comm_destroy(self._h))
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             lib().abc_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -354,6 +363,11 @@ class MultiContext:
         rc = lib().abc_ctx_create_multi((C.c_int * n)(*self.devices), n, self._arr)
         if rc:
             raise AbcError(rc, "abc_ctx_create_multi(%r) failed" % (self.devices,))
+
+    def context(self, i):
+        """the context of device i as a Context (a view: the MultiContext keeps the ownership); each is driven from its own
+        host thread (abc_generation_sharded_dev is collective over the ndev contexts)"""
+        return Context.from_handle(self._arr[i], self.devices[i])
 
     def generation(self, cfg, io, rng):
         """host-pointer generation over all devices (abc_generation_multi); -> ncomp"""

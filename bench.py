@@ -74,7 +74,7 @@ def split(total, world, rank):
     return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -85,43 +85,256 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default): the stated total whatever --gpus is; weak: particles per GPU fixed at the "
                          "configuration's per-GPU share (its total / the GPU count it is stated for)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N > 1 inside THIS process: abc_ctx_create_multi (ncclCommInitAll) and one host thread per GPU, each "
+                         "driving abc_generation_sharded_dev on its device-resident shard; the fallback of a bare `--gpus N` when "
+                         "torch.distributed.run is not available")
+    ap.add_argument("--rule", choices=["press", "wilcoxon"], default="press",
+                    help="PLS component rule of the timed generation (AbcUtil.cpp:447-449): press = argmin PRESS (default), "
+                         "wilcoxon = its Wilcoxon signed-rank reduction (SURVEY A.2); the other rule is timed in `extra`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the timed region (sustained run, fp64 "
-                    "kernel, INDEPENDENT noise, simple ranking, host-pointer call, log-normal alias build)")
+                    "kernel, INDEPENDENT noise, Wilcoxon rule, simple ranking, host-pointer call, log-normal alias build, scaling model)")
     ap.add_argument("--kde-mode", choices=["auto", "fp64"], default="auto",
                     help="weight kernel: auto = split-operand kernel where it applies (default), fp64 = the fp64 vector kernel (A/B runs)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--sustained-s", type=float, default=2.0)
     ap.add_argument("--prev-size", type=int, default=0,
                     help="size K' of the previous predictive prior (default: K = 0.1 x all particles, the stated configuration)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from abcsmc_amd import _lib, abcutil, device, sharded, synthetic
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
-        sys.exit(2)
-    # ABC_BENCH_BACKEND=gloo: a dry run of the N > 1 path on a box with ONE GPU (all ranks on cuda:0, the C++ driver's collectives
-    # forwarded to gloo as callbacks -- RCCL does not let two ranks share a device): exercises the sharded code path, not a measurement
-    backend = os.environ.get("ABC_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
-    if world > 1:
+# ---- how a rank talks to the others ---------------------------------------------------------------------------------------
+class SoloEnv:
+    """--gpus 1"""
+    world, rank, local_rank, launcher = 1, 0, 0, "single GPU"
+
+    def __init__(self):
+        self.dev = "cuda:0"
+
+    def context(self):
+        from abcsmc_amd import _lib
+        return _lib.default_context(0)
+
+    def attach(self, ctx):
+        return None
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        return float(x)
+
+    def finish(self):
+        pass
+
+
+class TorchrunEnv:
+    """one process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment)"""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ["WORLD_SIZE"])
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # ABC_BENCH_BACKEND=gloo: a dry run of the N > 1 path on a box with ONE GPU (all ranks on cuda:0, the C++ driver's collectives
+        # forwarded to gloo as callbacks -- RCCL does not let two ranks share a device): exercises the sharded code path, not a measurement
+        self.backend = os.environ.get("ABC_BENCH_BACKEND", "nccl")
+        if self.backend == "gloo":
+            self.local_rank = 0
+        self.dev = "cuda:%d" % self.local_rank
+        self.launcher = ("torch.distributed.run (started by bench.py itself)" if os.environ.get("ABC_BENCH_SELF_LAUNCHED")
+                         else "torch.distributed.run")
+        torch.cuda.set_device(self.local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "gloo":
+        if self.backend == "gloo":
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            dist.init_process_group("nccl", device_id=torch.device(self.dev))
+        self._dist, self._torch = dist, torch
+
+    def context(self):
+        from abcsmc_amd import _lib
+        return _lib.default_context(self.local_rank)
+
+    def attach(self, ctx):
+        """the row-sharded driver inside the C ABI (abc_generation_sharded_dev): RCCL communicator created from an id that rank 0
+        broadcasts; if RCCL cannot be initialised from the library, the same C++ driver runs with torch.distributed's (RCCL)
+        collectives handed in as callbacks -- said loudly and recorded in the JSON line"""
+        from abcsmc_amd import sharded
+        dist, torch = self._dist, self._torch
+        ctx.set_stream(torch.cuda.current_stream(torch.device(self.dev)).cuda_stream)
+        ok = torch.ones(1, dtype=torch.int32, device="cpu" if self.backend == "gloo" else self.dev)
+        try:
+            if self.backend == "gloo":
+                raise RuntimeError("dry run over gloo requested (ABC_BENCH_BACKEND)")
+            sharded.attach_rccl(ctx, self.dev)
+        except Exception as e:           # noqa: BLE001 -- any failure of the in-library communicator
+            print("bench.py rank %d: in-library RCCL communicator failed (%s)" % (self.rank, e), file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # the choice is collective: every rank runs the same transport
+        if int(ok.item()) == 1:
+            return "rccl (C ABI, abc_comm_init_rank)"
+        if self.rank == 0:
+            print("bench.py: using torch.distributed collectives as callbacks of the C++ driver", file=sys.stderr)
+        sharded.attach_torch_distributed(ctx, self.dev)
+        return "torch.distributed callbacks (%s)" % self.backend
+
+    def barrier(self):
+        self._dist.barrier()
+        self._torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        t = self._torch.tensor([x], dtype=self._torch.float64, device="cpu" if self.backend == "gloo" else self.dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        self._dist.destroy_process_group()
+
+
+class ThreadEnv:
+    """--single-process: rank r is host thread r of this process, its context one of abc_ctx_create_multi's (joined by
+    ncclCommInitAll); barriers and the max over ranks go through the threads' shared memory"""
+    launcher = "one process, one host thread per GPU (abc_ctx_create_multi)"
+
+    def __init__(self, shared, rank):
+        import torch
+        self.shared, self.rank, self.world, self.local_rank = shared, rank, shared["world"], rank
+        self.dev = "cuda:%d" % rank
+        torch.cuda.set_device(rank)
+        self._torch = torch
+
+    def context(self):
+        return self.shared["multi"].context(self.rank)
+
+    def attach(self, ctx):
+        ctx.set_stream(self._torch.cuda.current_stream(self._torch.device(self.dev)).cuda_stream)
+        return "rccl (C ABI, abc_ctx_create_multi / ncclCommInitAll)"
+
+    def barrier(self):
+        self._torch.cuda.synchronize()
+        self.shared["barrier"].wait()
+
+    def max_over_ranks(self, x):
+        self.shared["vals"][self.rank] = float(x)
+        self.shared["barrier"].wait()
+        m = max(self.shared["vals"])
+        self.shared["barrier"].wait()
+        return m
+
+    def finish(self):
+        pass
+
+
+def launcher_command(args_list, gpus, port):
+    """what a bare `python bench.py --gpus N` starts (the driver's own N > 1 command line, with our arguments)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE): start the N ranks from here, BEFORE this process
+    makes any GPU call (a child process, never an exec), relay the one JSON line and the exit status.  Returns the exit status."""
+    import importlib.util
+    import socket
+    import subprocess
+    if importlib.util.find_spec("torch.distributed.run") is None:
+        print("bench.py: torch.distributed.run is not available -- running the %d ranks as host threads of this process "
+              "(--single-process)" % args.gpus, file=sys.stderr)
+        return run_threads(args)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env["ABC_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = launcher_command(argv, args.gpus, port)
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)          # (stderr goes straight through)
+    except OSError as e:
+        print("bench.py: could not start %s: %s" % (" ".join(cmd[:4]), e), file=sys.stderr)
+        return 2
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    other = [ln for ln in p.stdout.splitlines() if not ln.startswith('{"metric"')]
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if p.returncode == 0 and len(lines) == 1:
+        print(lines[0])
+        return 0
+    print("bench.py: the %d-rank run failed (exit status %d, %d JSON line(s)); command: %s"
+          % (args.gpus, p.returncode, len(lines), " ".join(cmd)), file=sys.stderr)
+    return p.returncode if p.returncode else 1
+
+
+def run_threads(args):
+    """--single-process: N host threads, one per GPU, each running the body of a rank (run_rank) on a context of
+    abc_ctx_create_multi.  ctypes releases the GIL inside the library, so the ranks' generations overlap like those of N processes."""
+    import threading
+    import traceback
+    import torch
+    from abcsmc_amd import _lib
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        print("bench.py: --single-process --gpus %d, but this process sees %d GPU(s)" % (n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    try:
+        multi = _lib.MultiContext(list(range(n)))
+    except Exception as e:           # noqa: BLE001
+        print("bench.py: abc_ctx_create_multi failed: %s" % e, file=sys.stderr)
+        return 3
+    shared = {"world": n, "multi": multi, "barrier": threading.Barrier(n), "vals": [0.0] * n}
+    failed = []
+
+    def body(r):
+        try:
+            run_rank(args, ThreadEnv(shared, r))
+        except BaseException:        # noqa: BLE001 -- a rank that dies would leave the others inside a collective for ever
+            traceback.print_exc()
+            failed.append(r)
+            sys.stderr.flush()
+            sys.stdout.flush()
+            os._exit(4)
+    th = [threading.Thread(target=body, args=(r,), name="rank%d" % r) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    multi.close()
+    return 4 if failed else 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.single_process:
+        return run_threads(args)
+    if world_env is None and args.gpus > 1:
+        # a bare `python bench.py --gpus N`: nothing has touched the GPU yet
+        return self_launch(args, argv)
+    if world_env is not None and int(world_env) != args.gpus:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s (the launcher's rank count and --gpus must agree)" % (args.gpus, world_env),
+                  file=sys.stderr)
+        return 2
+    env = TorchrunEnv() if (world_env is not None and args.gpus > 1) else SoloEnv()
+    run_rank(args, env)
+    return 0
+
+
+def run_rank(args, env):
+    import numpy as np
+    import torch
+    from abcsmc_amd import _lib, abcutil, device, sharded, synthetic
+
+    world, rank, dev = env.world, env.rank, env.dev
+    RULE = _lib.RULE_WILCOXON if args.rule == "wilcoxon" else _lib.RULE_MIN_PRESS
 
     cfg = CONFIGS[args.config]
     M, P, A = cfg["M"], cfg["P"], cfg["A"]
@@ -146,43 +359,24 @@ def main():
     dtp, dwp, ddvp = wl.previous_set_device(Kp, dev)
     rng = abcutil.rng(67890)
 
-    ctx = _lib.default_context(local_rank)
+    ctx = env.context()
     ctx.alias_stats(reset=True)
     ctx.set_kde_mode(_lib.KDE_FP64 if args.kde_mode == "fp64" else _lib.KDE_AUTO)
     comm_kind = None
-    if world == 1:
-        gen = device.Generation(N, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
+    # (--single-process --gpus 1 still goes through the sharded driver and a one-rank RCCL communicator: the thread plumbing and
+    # abc_ctx_create_multi can then be exercised on a one-GPU box)
+    use_sharded = world > 1 or isinstance(env, ThreadEnv)
+    if not use_sharded:
+        gen = device.Generation(N, M, P, K, Kp, nn_loc, 0.5, A, rule=RULE, multivariate=True, device=dev, ctx=ctx)
     else:
-        # the row-sharded driver inside the C ABI (abc_generation_sharded_dev): RCCL communicator created from an id that
-        # rank 0 broadcasts; if RCCL cannot be initialised from the library, the same C++ driver runs with torch.distributed's
-        # (RCCL) collectives handed in as callbacks -- said loudly and recorded in the JSON line
-        ctx.set_stream(torch.cuda.current_stream(torch.device(dev)).cuda_stream)
-        ok = torch.ones(1, dtype=torch.int32, device="cpu" if backend == "gloo" else dev)
-        try:
-            if backend == "gloo":
-                raise RuntimeError("dry run over gloo requested (ABC_BENCH_BACKEND)")
-            sharded.attach_rccl(ctx, dev)
-        except Exception as e:           # noqa: BLE001 -- any failure of the in-library communicator
-            print("bench.py rank %d: in-library RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # the choice is collective: every rank runs the same transport
-        if int(ok.item()) == 1:
-            comm_kind = "rccl (C ABI)"
-        else:
-            if rank == 0:
-                print("bench.py: using torch.distributed collectives as callbacks of the C++ driver", file=sys.stderr)
-            sharded.attach_torch_distributed(ctx, dev)
-            comm_kind = "torch.distributed callbacks"
-        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True,
+        comm_kind = env.attach(ctx)
+        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, rule=RULE, multivariate=True,
                                             row0=row0, N_total=N, next0=next0, Nnext_total=N)
 
     def step():
         gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = env.barrier
 
     for _ in range(args.warmup):
         step()
@@ -204,10 +398,7 @@ def main():
     barrier()
     stages_all = ctx.timing_read(reset=True)
     ctx.timing_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = env.max_over_ranks(elapsed)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = N / (elapsed / args.steps)
@@ -311,6 +502,7 @@ def main():
     set0 = None
     sustained = None
     extra = None
+    scaling_model = None
     if world == 1:
         rng0 = abcutil.rng(67890)
         gen0 = device.Generation(N, M, P, K, 0, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
@@ -354,6 +546,8 @@ def main():
                      "note": "same step, run back to back for >= %.1f s right after the timed region; the ratio of the pair-sum "
                              "brackets is the clock the chip holds under sustained load relative to the timed region" % args.sustained_s}
         extra = extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, event_overhead_ms)
+        scaling_model = scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, RULE,
+                                          ms_per_step, kde_ms * kde_launches, stage_ms, stage_launches, event_overhead_ms)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -375,22 +569,23 @@ def main():
                        "particles_per_gpu": n_loc, "particles_total": N, "metrics": M,
                        "params": P, "pls_components": A, "pred_prior_size": K, "prev_pred_prior_size": Kp,
                        "next_set_size": N, "noise": "MULTIVARIATE", "train_fraction": 0.5,
-                       "ncomp_chosen": int(gen.ncomp.value if world == 1 else gen.ncomp),
-                       "parallelism": "row-sharded x%d" % world, "collectives": comm_kind,
-                       "collectives_per_step": stage_launches.get("collectives", 0) if world > 1 else 0,
-                       "collectives_ms_per_step": stage_ms.get("collectives", 0.0) if world > 1 else 0.0},
+                       "ncomp_chosen": int(gen.ncomp if use_sharded else gen.ncomp.value),
+                       "pls_component_rule": "wilcoxon" if args.rule == "wilcoxon" else "min_press",
+                       "parallelism": "row-sharded x%d" % world, "launcher": env.launcher, "collectives": comm_kind,
+                       "collectives_per_step": stage_launches.get("collectives", 0) if use_sharded else 0,
+                       "collectives_ms_per_step": stage_ms.get("collectives", 0.0) if use_sharded else 0.0},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "roofline_streaming": roofline_streaming,
             "set0": set0,
             "sustained": sustained,
             "extra": extra,
+            "scaling_model": scaling_model,
             "cpu_baseline": cpu,
             "stage_ms_per_step": stage_ms,
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    env.finish()
 
 
 def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, event_overhead_ms):
@@ -435,6 +630,17 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
         # (2) noise = INDEPENDENT, the reference's default (AbcSmc.cpp:419, AbcSmc.h:159)
         geni = device.Generation(N, M, P, K, Kp, N, 0.5, A, multivariate=False, device=dev, ctx=ctx)
         out["independent_noise_step_ms"] = round(timed(lambda: geni.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)), 5)
+    # (2b) the OTHER component rule (AbcUtil.cpp:447-449; SURVEY A.2: argmin PRESS reduced by a Wilcoxon signed-rank test): the whole
+    # generation and the PLS ranking alone under it -- `wilcoxon_*` when the timed region ran argmin PRESS, `min_press_*` otherwise
+    other = _lib.RULE_MIN_PRESS if args.rule == "wilcoxon" else _lib.RULE_WILCOXON
+    oname = "min_press" if args.rule == "wilcoxon" else "wilcoxon"
+    rngo = abcutil.rng(67890)
+    geno = device.Generation(N, M, P, K, Kp, N, 0.5, A, rule=other, multivariate=True, device=dev, ctx=ctx)
+    out[oname + "_rule_step_ms"] = round(timed(lambda: geno.run(dX, dY, dobs, dpri, rngo, dtp, dwp, ddvp)), 5)
+    out[oname + "_rule_ncomp"] = int(geno.ncomp.value)
+    genor = device.Generation(N, M, P, K, 0, 0, 0.5, A, rule=other, multivariate=True, device=dev, ctx=ctx)
+    out["ranking_pls_" + oname + "_ms"] = round(timed(lambda: genor.run(dX, dY, dobs, dpri, rngo)), 5)
+    del geno, genor
     # (3) particle_ranking_simple (AbcUtil.cpp:408-421), device resident, through the staged entry points: moments of the
     # metrics, z-scored distance to the observation, the K smallest
     be = sharded.HipBackend(dev, ctx)
@@ -453,7 +659,8 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
     out["ranking_simple_ms"] = round(timed(simple), 5)
     out["ranking_simple_particles_per_s"] = N / (out["ranking_simple_ms"] * 1e-3)
     # ... and the PLS ranking alone (no weights, no proposals), device resident
-    genr = device.Generation(N, M, P, K, 0, 0, 0.5, A, multivariate=True, device=dev, ctx=ctx)
+    this = _lib.RULE_WILCOXON if args.rule == "wilcoxon" else _lib.RULE_MIN_PRESS
+    genr = device.Generation(N, M, P, K, 0, 0, 0.5, A, rule=this, multivariate=True, device=dev, ctx=ctx)
     rngr = abcutil.rng(1)
     out["ranking_pls_ms"] = round(timed(lambda: genr.run(dX, dY, dobs, dpri, rngr)), 5)
     # (4) the drop-in call as the reference makes it (AbcUtil.h:149-153): host matrices in, host index vector out
@@ -504,6 +711,78 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
     return out
 
 
+def predict_scaling(ms_per_step, kde_ms, sharded_ms, collectives, collective_ms, gpus=(2, 4, 8)):
+    """STRONG scaling of one generation over G GPUs from single-GPU measurements (pure arithmetic, unit-tested on the CPU):
+         t(G) = kde_ms / G                     the pair sums of the weight stage: K / G rows per rank
+              + sharded_ms / G                 the row-proportional streaming kernels (Gram, projection, draws + proposals)
+              + (ms_per_step - kde_ms - sharded_ms)      everything else is REPLICATED on every rank (model fit, selection,
+                                                         gather, weight prologue / epilogue, alias table, host gaps)
+              + collectives * collective_ms    the exchange steps, each priced at the measured world-1 latency of an RCCL call
+                                               (a floor: real xGMI hops add to it)"""
+    repl = ms_per_step - kde_ms - sharded_ms
+    out = {}
+    for g in gpus:
+        t = kde_ms / g + sharded_ms / g + repl + collectives * collective_ms
+        out[str(g)] = {"ms_per_step": round(t, 5), "speedup": round(ms_per_step / t, 3), "efficiency": round(ms_per_step / t / g, 4)}
+    return out
+
+
+def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, rule, ms_per_step, kde_ms, stage_ms,
+                      stage_launches, event_overhead_ms):
+    """The N = 1 line's PREDICTION of the strong-scaling curve, so that the first real multi-GPU run can be held against a
+    stated number: stage times from this run + the latency of the sharded driver's collectives measured on a ONE-rank RCCL
+    communicator (abc_comm_init_rank at world 1: every collective of the protocol is a real RCCL call on this GPU)."""
+    import torch
+    from abcsmc_amd import _lib, abcutil, sharded
+    # row-proportional kernels, from the per-stage pass (each stage bracket carries one event pair of overhead)
+    def st(name):
+        return max(stage_ms.get(name, 0.0) - event_overhead_ms * stage_launches.get(name, 0), 0.0)
+    sharded_ms = st("k_gram") + st("project_distance") + st("perturb")
+    coll_ms, ncoll, note, step1 = None, 5 if Kp else 4, None, None
+    c1 = None
+    try:
+        c1 = _lib.Context(int(torch.device(dev).index or 0))
+        c1.comm_init_rccl(1, 0, _lib.comm_unique_id())
+        g1 = sharded.CabiShardedGeneration(c1, dev, N, M, P, K, Kp, N, 0.5, A, rule=rule, multivariate=True)
+        r1 = abcutil.rng(67890)
+        for _ in range(2):
+            g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
+        torch.cuda.synchronize()
+        step1 = 1e3 * (time.perf_counter() - t) / 5
+        c1.timing_enable(1)
+        c1.timing_read(reset=True)
+        for _ in range(5):
+            g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
+        torch.cuda.synchronize()
+        stc = c1.timing_read(reset=True)
+        c1.timing_enable(False)
+        ms, _, cnt = stc["collectives"]
+        if cnt:
+            ncoll = cnt // 5
+            coll_ms = max(ms / cnt - event_overhead_ms, 0.0)
+        c1.comm_destroy()
+    except Exception as e:           # noqa: BLE001 -- RCCL not loadable on this box: the model is then quoted without the collectives
+        note = "world-1 RCCL communicator unavailable (%s): collectives priced at 0" % e
+    finally:
+        if c1 is not None:
+            c1.close()
+    pred = predict_scaling(ms_per_step, kde_ms, sharded_ms, ncoll, coll_ms or 0.0)
+    return {"scaling": "strong", "from": {"ms_per_step": round(ms_per_step, 5), "pair_sums_ms": round(kde_ms, 5),
+                                          "row_sharded_streaming_ms": round(sharded_ms, 5),
+                                          "replicated_ms": round(ms_per_step - kde_ms - sharded_ms, 5),
+                                          "collectives_per_step": ncoll,
+                                          "rccl_world1_collective_ms": None if coll_ms is None else round(coll_ms, 5),
+                                          "sharded_driver_world1_step_ms": None if step1 is None else round(step1, 5)},
+            "predicted": pred,
+            "formula": "t(G) = pair_sums/G + row_sharded_streaming/G + replicated + collectives_per_step x rccl_world1_collective_ms",
+            "note": note or "a prediction to hold the first measured curve against, not a measurement; the replicated chain (model fit, "
+                            "selection, alias table, weight prologue / epilogue) is the Amdahl term"}
+
+
 def cpu_baseline(cfg, wl, X, Y, obs, spec, th_prev, w_prev, dv_prev, K, A, budget_s):
     """Single-threaded CPU oracle (oracle/, a restatement of the reference path: the reference itself
     cannot be built here) timed on a bounded sample of the same workload."""
@@ -544,4 +823,4 @@ def cpu_baseline(cfg, wl, X, Y, obs, spec, th_prev, w_prev, dv_prev, K, A, budge
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,126 @@
+"""bench.py's launch paths.  north_star asks for numbers at 1/2/4/8 GPUs: `python bench.py --gpus N` has to start its own ranks
+when nothing has started them, fail with a non-zero status on every failure path, and carry a stated
+prediction of the scaling curve in its N = 1 line.
+CPU: the launcher plumbing, its failure paths, the prediction's arithmetic.  GPU: a bare two-rank launch sharing cuda:0
+(collectives through gloo callbacks: RCCL does not let two ranks share a device) and the one-process / one-thread-per-GPU route
+on the one GPU of the box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(argv, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ABC_BENCH_SELF_LAUNCHED")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + argv, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def _json_lines(stdout):
+    return [json.loads(ln) for ln in stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launcher_command_is_the_drivers_own():
+    """what a bare `--gpus N` starts is the command line the driver itself uses for N > 1 (one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1), with bench.py's own arguments handed through"""
+    b = _bench_module()
+    cmd = b.launcher_command(["--gpus", "4", "--steps", "7"], 4, 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5] == BENCH and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+
+
+def test_predicted_scaling_is_amdahl_on_the_measured_stages():
+    b = _bench_module()
+    # 2.7 ms step: 2.1 pair sums, 0.2 row-proportional streaming, 0.4 replicated; five collectives of 0.02 ms
+    pred = b.predict_scaling(2.7, 2.1, 0.2, 5, 0.02)
+    assert set(pred) == {"2", "4", "8"}
+    for g in (2, 4, 8):
+        t = 2.1 / g + 0.2 / g + 0.4 + 5 * 0.02
+        assert abs(pred[str(g)]["ms_per_step"] - t) < 1e-4
+        assert abs(pred[str(g)]["speedup"] - 2.7 / t) < 1e-3
+        assert abs(pred[str(g)]["efficiency"] - 2.7 / t / g) < 1e-3
+    assert pred["8"]["efficiency"] < pred["2"]["efficiency"] < 1.0      # the replicated chain is the Amdahl term
+
+
+def test_argument_errors_exit_non_zero_without_a_json_line():
+    p = _run(["--gpus", "0"])
+    assert p.returncode == 2 and not _json_lines(p.stdout)
+    # a launcher that started a different number of ranks than --gpus says
+    p = _run(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode == 2 and not _json_lines(p.stdout) and "WORLD_SIZE" in p.stderr
+
+
+def test_bare_multi_gpu_launch_starts_its_ranks_and_fails_loudly_without_a_gpu():
+    """no GPU in this container: the bare launch must get as far as starting both ranks (it used to exit with status 2 at once),
+    every rank must fail at its first GPU call, and the parent must relay that as a non-zero status and no JSON line"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the two-rank launch is tested for real below")
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"], {"ABC_BENCH_BACKEND": "gloo"}, timeout=300)
+    assert p.returncode != 0 and not _json_lines(p.stdout)
+    assert "2-rank run failed" in p.stderr and "torch.distributed.run" in p.stderr
+    # ... and so must the one-process route
+    p = _run(["--gpus", "2", "--single-process", "--steps", "2", "--no-extra", "--no-cpu-baseline"], timeout=300)
+    assert p.returncode != 0 and not _json_lines(p.stdout)
+
+
+@pytest.mark.gpu
+def test_bare_two_rank_launch_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself (a child process, before
+    any GPU call), both ranks share cuda:0 and the C++ sharded driver's collectives go through gloo callbacks; ONE JSON line with
+    n_gpus == 2 comes back through the parent, exit status 0"""
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "2", "--no-extra", "--no-cpu-baseline"],
+             {"ABC_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "strong"
+    assert "started by bench.py itself" in j["config"]["launcher"]
+    assert j["config"]["collectives"].startswith("torch.distributed callbacks") and j["config"]["collectives_per_step"] >= 4
+    assert j["config"]["particles_per_gpu"] * 2 == j["config"]["particles_total"]
+    assert j["roofline"]["frac"] > 0 and j["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_single_process_route_on_one_gpu():
+    """--single-process: abc_ctx_create_multi (ncclCommInitAll) + one host thread per GPU driving abc_generation_sharded_dev on
+    its device-resident shard -- with the one GPU of this box: one thread, a one-rank RCCL communicator, every collective of the
+    protocol a real RCCL call"""
+    p = _run(["--gpus", "1", "--single-process", "--steps", "2", "--warmup", "1", "--config", "2", "--no-extra", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 1 and "one host thread per GPU" in j["config"]["launcher"]
+    assert "ncclCommInitAll" in j["config"]["collectives"] and j["config"]["collectives_per_step"] >= 4
+
+
+@pytest.mark.gpu
+def test_n1_line_carries_both_component_rules_and_a_scaling_prediction():
+    """the default N = 1 run at the small configuration: `extra` times the Wilcoxon rule (whole generation and ranking alone),
+    `scaling_model` predicts 2 / 4 / 8 GPUs from the measured stages and the world-1 RCCL collective latency"""
+    p = _run(["--config", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained-s", "0.2"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    j = _json_lines(p.stdout)[0]
+    ex = j["extra"]
+    assert ex["wilcoxon_rule_step_ms"] > 0 and ex["ranking_pls_wilcoxon_ms"] > 0 and ex["wilcoxon_rule_ncomp"] >= 1
+    sm = j["scaling_model"]
+    assert set(sm["predicted"]) == {"2", "4", "8"} and sm["from"]["collectives_per_step"] in (4, 5)
+    assert sm["from"]["rccl_world1_collective_ms"] is None or sm["from"]["rccl_world1_collective_ms"] >= 0
+    assert sm["predicted"]["8"]["ms_per_step"] < j["ms_per_step"]

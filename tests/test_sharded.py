@@ -81,10 +81,12 @@ def test_sharded_world2_cabi_driver_gathered_sample_selection(tmp_path, shape, d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,port", [("small", 29641), ("big", 29642)])
+@pytest.mark.parametrize("shape,port", [("small", 29641), ("big", 29642), ("config4", 29643), ("config5", 29644), ("huge", 29645)])
 def test_sharded_world2_rccl_two_gpus(tmp_path, shape, port):
     """abc_comm_init_rank at world size 2, one GPU per rank: every collective of the sharded generation through RCCL itself
-    (the callbacks tests share one GPU, which RCCL does not allow).  Skipped on a one-GPU box; runs on any box with two."""
+    (the callbacks tests share one GPU, which RCCL does not allow) -- the radix protocol (small), the gathered-sample selection
+    (big), the BASELINE configs[3] / configs[4] column shapes (64 metrics x 32 parameters; 128 metrics, 32 components) and a set
+    whose resampling table is built on the device on every rank (huge).  Skipped on a one-GPU box; runs on any box with two."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (found %d)" % torch.cuda.device_count())
