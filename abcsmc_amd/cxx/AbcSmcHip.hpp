@@ -484,6 +484,15 @@ inline bool AbcSmc::parse_config(const std::string& conf_filename) {          //
     if (filtering == "PLS") ranking_kind_ = ABC::FILTER::PLS;
     else if (filtering == "SIMPLE") ranking_kind_ = ABC::FILTER::SIMPLE;
     else die(-210, "Unknown filtering type specified: " + filtering + ". Aborting.");
+    // not in the reference's JSON either: the PLS component rule (ABC::set_component_rule; default = upstream's Wilcoxon
+    // reduction as SURVEY A.2 describes it) and a cap on the number of components
+    if (par.isMember("pls_component_rule")) {
+        const std::string rule = par["pls_component_rule"].asString();
+        if (rule == "wilcoxon" || rule == "WILCOXON") ABC::set_component_rule(ABC_RULE_WILCOXON);
+        else if (rule == "min_press" || rule == "MIN_PRESS" || rule == "press") ABC::set_component_rule(ABC_RULE_MIN_PRESS);
+        else die(-210, "Unknown pls_component_rule specified: " + rule + ". Aborting.");
+    }
+    if (par.isMember("pls_max_components")) ABC::set_max_components(par["pls_max_components"].asInt());
     return true;
 }
 

@@ -225,6 +225,20 @@ inline uint64_t perturb_giveups(bool reset = false) {
     check(abc_perturb_giveups(context(), &n, reset ? 1 : 0));
     return n;
 }
+// How many PLS components particle_ranking_PLS keeps (AbcUtil.cpp:447-449: `PLS::optimal_num_components(em).maxCoeff()`; the PLS
+// library is not in the reference tree).  SURVEY A.2, the only specification of it at hand, describes upstream as: per response
+// the component count of least PRESS, REDUCED to the smallest count whose validation errors a two-sided Wilcoxon signed-rank
+// test (alpha = 0.1) cannot tell from it.  That is the drop-in default here (ABC_RULE_WILCOXON); ABC_RULE_MIN_PRESS keeps the
+// plain argmin (about 1 ms less per million particles; never fewer components).  `max_components` = 0 means min(#metrics,
+// #parameters), the unverifiable default of `PLS::Model plsm(X, Y)` (AbcUtil.cpp:443).
+inline int& component_rule_ref() { static int r = ABC_RULE_WILCOXON; return r; }
+inline int& max_components_ref() { static int a = 0; return a; }
+inline void set_component_rule(int rule) {
+    if (rule != ABC_RULE_MIN_PRESS && rule != ABC_RULE_WILCOXON) throw HipError(ABC_ERR_INVALID, "set_component_rule: unknown rule");
+    component_rule_ref() = rule;
+}
+inline int component_rule() { return component_rule_ref(); }
+inline void set_max_components(int a) { max_components_ref() = a < 0 ? 0 : a; }
 inline std::vector<abc_prior> to_pod(const std::vector<const Parameter*>& pars) {
     std::vector<abc_prior> p;
     for (const Parameter* q : pars) p.push_back(q->pod());
@@ -265,7 +279,7 @@ inline RankedSet rank_and_weight(const Mat2D& X, const Mat2D& Y, const Row& obs,
     abc_generation_cfg cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.N = N; cfg.M = M; cfg.P = P; cfg.K = K; cfg.Kp = prev_params ? prev_params->rows() : 0; cfg.Nnext = 0;
-    cfg.train_frac = training_fraction; cfg.max_comp = 0; cfg.rule = ABC_RULE_MIN_PRESS; cfg.multivariate = 0;
+    cfg.train_frac = training_fraction; cfg.max_comp = max_components_ref(); cfg.rule = component_rule(); cfg.multivariate = 0;
     abc_generation_io io;
     memset(&io, 0, sizeof(io));
     io.X = X.data(); io.Y = Y.data(); io.obs = obs.data(); io.priors = pr.data();
@@ -288,7 +302,7 @@ inline std::vector<size_t> particle_ranking_PLS(const Mat2D& X_orig, const Mat2D
     const size_t N = X_orig.rows();
     std::vector<uint64_t> idx(N);
     check(abc_particle_ranking_pls(context(), X_orig.data(), Y_orig.data(), target_values.data(), N, X_orig.cols(),
-                                   Y_orig.cols(), training_fraction, 0, ABC_RULE_MIN_PRESS, N, idx.data(), nullptr,
+                                   Y_orig.cols(), training_fraction, max_components_ref(), component_rule(), N, idx.data(), nullptr,
                                    nullptr, nullptr, nullptr, nullptr));
     return std::vector<size_t>(idx.begin(), idx.end());
 }

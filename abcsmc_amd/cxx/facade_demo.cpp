@@ -35,6 +35,21 @@ int main() {
         std::printf("facade ok: best particle %zu, posterior mean[0]=%.3f, dv[0]=%.3f, next(0,0)=%.3f, w1[0]=%.3e\n",
                     rank[0], mean0, dv[0], next(0, 0), w1[0]);
         if (!(mean0 > 3.5 && mean0 < 6.5)) return 2;   // observed metrics correspond to parameters near 5
+        // the component rule of particle_ranking_PLS (AbcUtil.cpp:447-449): default = upstream's Wilcoxon reduction, switchable
+        const int dflt = component_rule();
+        set_component_rule(ABC_RULE_MIN_PRESS);
+        const std::vector<size_t> r_press = particle_ranking_PLS(X, Y, obs, 0.5);
+        set_component_rule(ABC_RULE_WILCOXON);
+        const std::vector<size_t> r_wx = particle_ranking_PLS(X, Y, obs, 0.5);
+        bool rejected = false;
+        try { set_component_rule(7); } catch (const HipError&) { rejected = true; }
+        std::printf("rules: default %d invalid_rejected %d same_as_default %d\n", dflt, (int)rejected, (int)(r_wx == std::vector<size_t>(particle_ranking_PLS(X, Y, obs, 0.5))));
+        std::printf("press:");
+        for (size_t i = 0; i < 12; i++) std::printf(" %zu", r_press[i]);
+        std::printf("\nwilcoxon:");
+        for (size_t i = 0; i < 12; i++) std::printf(" %zu", r_wx[i]);
+        std::printf("\n");
+        if (dflt != ABC_RULE_WILCOXON || !rejected) return 3;
     } catch (const HipError& e) {
         std::printf("HipError %d: %s\n", e.code, e.what());
         return 1;

@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 MFMA_F16_PEAK_TF = 2500.0     # same guide: dense f16 / bf16 MFMA peak (v_mfma_f32_32x32x16_f16: 32 cycles per SIMD at 2.4 GHz)
 MFMA_SUSTAINED_TF = 1247.0    # same guide, 'DVFS give-back' (1): a bare bf16 MFMA loop on RANDOM operands (the chip holds 1.90-1.95 GHz)
 FP64_VALU_PEAK_TF = 78.6      # same guide: fp64 vector peak
+ASSUMED_XGMI_COLLECTIVE_MS = 0.02   # scaling_model: a small RCCL collective over xGMI, ASSUMED (not measurable on one GPU)
 
 
 def pmc_traffic(kernel_prefix, config, world):
@@ -738,7 +739,9 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     def st(name):
         return max(stage_ms.get(name, 0.0) - event_overhead_ms * stage_launches.get(name, 0), 0.0)
     sharded_ms = st("k_gram") + st("project_distance") + st("perturb")
-    coll_ms, ncoll, note, step1 = None, 5 if Kp else 4, None, None
+    # collectives of one generation at world > 1 (broadcast of the pilot shift, packed all-reduce of the
+    # statistics, sample all-gather, candidates-with-rows all-gather, and for weighted sets the all-gather of the weight slices)
+    coll_ms, ncoll, note, step1, measured = None, 5 if Kp else 4, None, None, 0
     c1 = None
     try:
         c1 = _lib.Context(int(torch.device(dev).index or 0))
@@ -761,8 +764,8 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
         stc = c1.timing_read(reset=True)
         c1.timing_enable(False)
         ms, _, cnt = stc["collectives"]
-        if cnt:
-            ncoll = cnt // 5
+        if cnt:          # (at world 1 the driver skips the exchanges that have nobody to talk to: what runs is the pilot broadcast)
+            measured = cnt // 5
             coll_ms = max(ms / cnt - event_overhead_ms, 0.0)
         c1.comm_destroy()
     except Exception as e:           # noqa: BLE001 -- RCCL not loadable on this box: the model is then quoted without the collectives
@@ -770,15 +773,26 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     finally:
         if c1 is not None:
             c1.close()
-    pred = predict_scaling(ms_per_step, kde_ms, sharded_ms, ncoll, coll_ms or 0.0)
+    # the code that runs at G > 1 is the sharded driver: its own world-1 step (fewer overlaps than the fused single-GPU driver) is
+    # the base of the prediction when it could be measured; a collective is priced at the larger of the measured world-1 RCCL call
+    # and ASSUMED_XGMI_COLLECTIVE_MS (a one-GPU box cannot measure a hop over xGMI: world-1 RCCL calls return in ~0 us)
+    base = step1 if step1 is not None else ms_per_step
+    price = max(coll_ms or 0.0, ASSUMED_XGMI_COLLECTIVE_MS)
+    pred = predict_scaling(base, kde_ms, sharded_ms, ncoll, price)
+    for g, v in pred.items():              # speed-up and efficiency against the fused single-GPU step (what --gpus 1 measures)
+        v["speedup"] = round(ms_per_step / v["ms_per_step"], 3)
+        v["efficiency"] = round(ms_per_step / v["ms_per_step"] / int(g), 4)
     return {"scaling": "strong", "from": {"ms_per_step": round(ms_per_step, 5), "pair_sums_ms": round(kde_ms, 5),
                                           "row_sharded_streaming_ms": round(sharded_ms, 5),
-                                          "replicated_ms": round(ms_per_step - kde_ms - sharded_ms, 5),
+                                          "replicated_ms": round(base - kde_ms - sharded_ms, 5),
+                                          "collective_price_ms": round(price, 5),
                                           "collectives_per_step": ncoll,
                                           "rccl_world1_collective_ms": None if coll_ms is None else round(coll_ms, 5),
+                                          "rccl_world1_collectives_measured_per_step": measured,
                                           "sharded_driver_world1_step_ms": None if step1 is None else round(step1, 5)},
             "predicted": pred,
-            "formula": "t(G) = pair_sums/G + row_sharded_streaming/G + replicated + collectives_per_step x rccl_world1_collective_ms",
+            "formula": "t(G) = pair_sums/G + row_sharded_streaming/G + replicated + collectives_per_step x collective_price_ms; "
+                       "replicated = sharded_driver_world1_step_ms - pair_sums - row_sharded_streaming",
             "note": note or "a prediction to hold the first measured curve against, not a measurement; the replicated chain (model fit, "
                             "selection, alias table, weight prologue / epilogue) is the Amdahl term"}
 

@@ -30,7 +30,7 @@ static std::vector<double> simulator(std::vector<double> parameters, const unsig
 static void usage() {
     std::cerr << "\n\tUsage: ./abc_dice config.json --process\n\n"
               << "\t       ./abc_dice config.json --simulate [-n <simulations per database write>]\n\n"
-              << "\t       ./abc_dice config.json --process --simulate [-n <...>] [--all] [--seed <s>] [--configured-simulator] [--devices 0,1,...] [--reference-stream]\n\n";
+              << "\t       ./abc_dice config.json --process --simulate [-n <...>] [--all] [--seed <s>] [--configured-simulator] [--devices 0,1,...] [--reference-stream] [--component-rule wilcoxon|press]\n\n";
 }
 
 int main(int argc, char* argv[]) {
@@ -40,6 +40,7 @@ int main(int argc, char* argv[]) {
     int buffer_size = 1;
     std::vector<int> devices;
     bool reference_stream = false;
+    int component_rule = -1;                 // -1: the configuration's / the facade's default (ABC_RULE_WILCOXON)
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--process")) process_db = true;
         else if (!strcmp(argv[i], "--simulate")) simulate_db = true;
@@ -47,6 +48,12 @@ int main(int argc, char* argv[]) {
         else if (!strcmp(argv[i], "--configured-simulator")) configured = true;   // use the "shared" / "executable" of the configuration
         else if (!strcmp(argv[i], "-n") && i + 1 < argc) buffer_size = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--reference-stream")) reference_stream = true;   // proposals from the reference's own taus2 stream
+        else if (!strcmp(argv[i], "--component-rule") && i + 1 < argc) {       // PLS component rule (ABC::set_component_rule)
+            const char* r = argv[++i];
+            if (!strcmp(r, "wilcoxon")) component_rule = ABC_RULE_WILCOXON;
+            else if (!strcmp(r, "press") || !strcmp(r, "min_press")) component_rule = ABC_RULE_MIN_PRESS;
+            else { usage(); return 101; }
+        }
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {              // e.g. --devices 0,1,2,3: rows sharded over these GPUs
             for (char* tok = strtok(argv[++i], ","); tok; tok = strtok(nullptr, ",")) devices.push_back(atoi(tok));
         }
@@ -55,6 +62,7 @@ int main(int argc, char* argv[]) {
     }
     AbcSmc* abc = new AbcSmc();
     abc->parse_config(argv[1]);
+    if (component_rule >= 0) ABC::set_component_rule(component_rule);          // (the command line overrides the configuration)
     try {
         if (!devices.empty()) ABC::use_devices(devices);
         if (reference_stream && process_db) ABC::set_reference_stream(true);

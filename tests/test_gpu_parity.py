@@ -1385,6 +1385,22 @@ def test_cxx_facade_demo(gpu_ctx, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "facade ok" in out.stdout
+    # ABC::set_component_rule: the facade's default is the Wilcoxon reduction; both rules rank as the oracle does under them
+    # (the demo's data regenerated here from the same taus2 stream)
+    from oracle import pyoracle as O
+    assert "rules: default 1 invalid_rejected 1 same_as_default 1" in out.stdout
+    N, M, P = 2000, 6, 3
+    g = O.rng(42)
+    X, Y = np.empty((N, M)), np.empty((N, P))
+    for i in range(N):
+        for p in range(P):
+            Y[i, p] = O.rng_get(g) / 4294967296.0 * 10.0
+        for m in range(M):
+            X[i, m] = Y[i, m % P] * (1.0 + m) + O.rng_get(g) / 4294967296.0
+    obs = np.array([5.0 * (1.0 + m) + 0.5 for m in range(M)])
+    lines = {ln.split(":")[0]: [int(v) for v in ln.split(":")[1].split()] for ln in out.stdout.splitlines() if ln.startswith(("press:", "wilcoxon:"))}
+    assert lines["press"] == [int(v) for v in O.particle_ranking_pls(X, Y, obs, 0.5, rule=O.RULE_MIN_PRESS)["idx"][:12]]
+    assert lines["wilcoxon"] == [int(v) for v in O.particle_ranking_pls(X, Y, obs, 0.5, rule=O.RULE_WILCOXON)["idx"][:12]]
 
 
 # ---------------------------------------------------------------------------------------------------

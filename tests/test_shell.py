@@ -469,7 +469,8 @@ def test_dice_fit_end_to_end(dice, tmp_path):
         # proposals are valid under the integer priors (recast + rejection on the device)
         assert np.all(pars == np.round(pars)) and pars.min() >= 1 and pars.max() <= 1000
         # the stored ranks are the oracle's ranking of exactly what is in the database (bit-exact indices)
-        want = orc.particle_ranking_pls(mets, pars, np.array([44.0, 2.39925]), 0.5)["idx"][:K[t]]
+        # (the shell's default component rule is the facade's: upstream's Wilcoxon reduction)
+        want = orc.particle_ranking_pls(mets, pars, np.array([44.0, 2.39925]), 0.5, rule=orc.RULE_WILCOXON)["idx"][:K[t]]
         got = sorted((r[1], r[0]) for r in rows if r[1] > -1)
         assert [g[0] for g in got] == list(range(K[t]))
         assert [g[1] for g in got] == [int(i) for i in want], "set %d" % t
@@ -508,6 +509,31 @@ def test_dice_fit_end_to_end(dice, tmp_path):
     r = run(dice, cfg, "--process", "--seed", "1")
     assert "Database already contains 4 complete sets." in r.stderr
     assert c.execute("select count(*) from job").fetchone()[0] == sum(sizes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["flag", "json"])
+def test_dice_fit_component_rule_switch(dice, tmp_path, how):
+    """ABC::set_component_rule through the shell: `--component-rule press` / "pls_component_rule": "min_press" rank every set by
+    the plain PRESS argmin (the facade's default is the Wilcoxon reduction); an unknown rule is a configuration error"""
+    over = {"pls_component_rule": "min_press"} if how == "json" else {}
+    cfg, db = write_cfg(tmp_path, DICE, **over)
+    extra = ["--component-rule", "press"] if how == "flag" else []
+    run(dice, cfg, "--process", "--simulate", "--all", "--seed", "17", *extra)
+    c = sqlite3.connect(db)
+    sizes, K = [300, 400, 400, 400], [75, 100, 100, 100]
+    for t, n in enumerate(sizes):
+        rows = c.execute("select J.particleIdx, J.posterior, ndice, sides, sum, sd from job J, par P, met M where J.serial = P.serial "
+                         "and J.serial = M.serial and smcSet = ? order by particleIdx", (t,)).fetchall()
+        pars = np.array([[r[2], r[3]] for r in rows])
+        mets = np.array([[r[4], r[5]] for r in rows])
+        want = orc.particle_ranking_pls(mets, pars, np.array([44.0, 2.39925]), 0.5, rule=orc.RULE_MIN_PRESS)["idx"][:K[t]]
+        got = sorted((r[1], r[0]) for r in rows if r[1] > -1)
+        assert [g[1] for g in got] == [int(i) for i in want], "set %d" % t
+    if how == "json":
+        bad, _ = write_cfg(tmp_path, DICE, name="bad.json", pls_component_rule="median")
+        r = run(dice, bad, "--process", check=False)
+        assert r.returncode != 0 and "pls_component_rule" in r.stderr
 
 
 @pytest.mark.gpu
@@ -551,7 +577,7 @@ def test_dice_fit_reference_stream_reproduces_an_oracle_driven_fit(dice, tmp_pat
         mets = np.array([[six(v) for v in dice_metrics(int(a), int(b), int(sd))] for (a, b), sd in zip(pars, seeds)])
         assert np.allclose(mets, np.array([[q[5], q[6]] for q in rows]), rtol=1e-5)
         mets = np.array([[q[5], q[6]] for q in rows])                       # what the next --process reads back
-        idx = orc.particle_ranking_pls(mets, pars, obs, 0.5)["idx"][:K[t]].astype(int)
+        idx = orc.particle_ranking_pls(mets, pars, obs, 0.5, rule=orc.RULE_WILCOXON)["idx"][:K[t]].astype(int)
         assert [q[0] for q in sorted((q for q in rows if q[1] > -1), key=lambda q: q[1])] == [int(i) for i in idx]
         theta = np.asfortranarray(pars[idx])
         dv = orc.doubled_variance(theta)
