@@ -40,12 +40,6 @@ int abc_pin_reserve(abc_ctx* ctx, size_t bytes) {
     return ABC_OK;
 }
 
-// arena needed by the Wilcoxon reduction: scores + 4 key/value buffers over (segments x validation rows)
-size_t abc_wx_need(size_t nt, size_t P, size_t A) {
-    const size_t seg = P * (A > 0 ? A - 1 : 0);
-    return nt * A * 8 + 4 * seg * nt * 8 + 256 * ((seg * nt) / 2048 + 2) * 4 + seg * 32 + P * 8 + (1u << 20);
-}
-
 // generous upper bound of the arena needed by any single API call on these sizes
 size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, size_t Nnext) {
     const size_t Call = (M + P + 15) / 16, C = Call > 6 ? 6 : Call;      // wider sets go through 96-column group pairs

@@ -1198,14 +1198,14 @@ def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate, P):
 # ---------------------------------------------------------------------------------------------------
 # whole generation, device resident (AbcSmc.cpp:634-664, 1041-1066, 490-518)
 # ---------------------------------------------------------------------------------------------------
-def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890):
+def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=0):
     import torch
     from abcsmc_amd import abcutil, device, _lib
     wl, X, Y, obs = _wl(M, P, N)
     spec = wl.prior_spec()
     prev = wl.previous_set(Kp) if Kp else (None, None, None)
     dev = "cuda:0"
-    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, multivariate=multivariate, device=dev)
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=rule, multivariate=multivariate, device=dev)
     r = abcutil.rng(seed)
     gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev),
             device.priors_to_device(_lib.make_priors(spec), dev), r,
@@ -1214,7 +1214,7 @@ def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890):
     return wl, X, Y, obs, spec, prev, gen, r
 
 
-def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=67890):
+def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=0):
     """_run_generation with the synthetic set generated ON the GPU (synthetic.Workload.rows_device: numpy takes minutes at
     1e7 rows) and downloaded for the oracle: both sides see the same bits"""
     import torch
@@ -1227,7 +1227,7 @@ def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=6789
     dprev = wl.previous_set_device(Kp, dev)
     X, Y = dX.cpu().numpy().T, dY.cpu().numpy().T                  # (N, c) column-major views of the downloads
     prev = (dprev[0].cpu().numpy().T, dprev[1].cpu().numpy(), dprev[2].cpu().numpy())
-    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, multivariate=multivariate, device=dev)
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=rule, multivariate=multivariate, device=dev)
     r = abcutil.rng(seed)
     gen.run(dX, dY, device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
     torch.cuda.synchronize()
@@ -1438,7 +1438,110 @@ def test_wilcoxon_rule_reduces_somewhere(oracle):
     assert hit >= 1
 
 
-def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol, device_inputs=False, oracle_model=True):
+def _wilcoxon_per_response(gpu_ctx, oracle, X, Y, obs, A, f=0.5):
+    """The Wilcoxon reduction alone, through the staged entry points: statistics -> model under argmin PRESS -> abc_pls_wilcoxon_dev;
+    the per-response component counts it leaves in the model record against the oracle's reduction RUN ON THE DEVICE'S OWN MODEL
+    (its loadings, means and deviations: the residuals are then the same bits on both sides, and so is every rank sum)."""
+    import torch
+    from abcsmc_amd import _lib, device, sharded
+    lib = _lib.lib()
+    N, M = X.shape
+    P = Y.shape[1]
+    dev = "cuda:0"
+    be = sharded.HipBackend(dev, gpu_ctx)
+    dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev)
+    ntrain = int(round(N * f))
+    stats = be.zeros(be.stats_len(M, P))
+    L = be.model_len(M, P, A)
+    model = be.zeros(L + 8)
+    be.stats_shift(dX, dY, stats)
+    be.stats_accumulate(dX, dY, 0, ntrain, stats)
+    be.pls_model(stats, dobs, M, P, A, _lib.RULE_MIN_PRESS, model)
+    torch.cuda.synchronize()
+    m0 = model.cpu().numpy().copy()
+    gpu_ctx.check(lib.abc_pls_wilcoxon_dev(gpu_ctx.handle, dX.data_ptr(), dY.data_ptr(), N, N, N, M, P, A, ntrain, model.data_ptr()))
+    torch.cuda.synchronize()
+    m1 = model.cpu().numpy()
+    off_mean, off_sd = 4, 4 + M + P
+    off_R = off_sd + (M + P) + M + A
+    off_Q = off_R + M * A
+    off_per = L - P
+    per_press, per_wx = m0[off_per:L].astype(int), m1[off_per:L].astype(int)
+    mean, sd = m0[off_mean:off_mean + M + P], m0[off_sd:off_sd + M + P]
+    R = np.asfortranarray(m0[off_R:off_R + M * A].reshape(A, M).T)
+    Q = np.asfortranarray(m0[off_Q:off_Q + P * A].reshape(A, P).T)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Zx = np.where(sd[:M] == 0, 0.0, (X[ntrain:] - mean[:M]) / sd[:M])
+        Zy = np.where(sd[M:] == 0, 0.0, (Y[ntrain:] - mean[M:]) / sd[M:])
+    _, o_press = oracle.pls_optimal_components(Zx, Zy, R, Q, oracle.RULE_MIN_PRESS)
+    _, o_wx = oracle.pls_optimal_components(Zx, Zy, R, Q, oracle.RULE_WILCOXON)
+    return per_press, per_wx, o_press.astype(int), o_wx.astype(int), int(m1[0])
+
+
+@pytest.mark.parametrize("N,M,P,A,kind", [
+    (6000, 10, 4, 4, "plain"),             # 3000 validation rows: one bin, sorted as a whole in LDS
+    (6000, 10, 4, 4, "pairs"),             # every validation row twice: tie groups of two, average ranks
+    (6000, 12, 5, 5, "zeros"),             # responses the model predicts equally well at several counts: zero differences dropped
+    (40_000, 16, 6, 8, "plain"),           # 2e4 validation rows: 16 bins
+    (40_000, 16, 6, 8, "pairs"),
+    (300_000, 32, 16, 8, "plain"),         # 1.5e5 rows, 128 bins, up to 112 tests
+    (300_000, 24, 8, 16, "plain"),         # two rows per thread (9..16 components)
+    (200_000, 40, 6, 24, "plain"),         # one row per thread (17..32 components)
+    (300_000, 16, 4, 6, "copies50"),       # 50 distinct validation rows: tie groups of 3000, a few values per bin
+    (300_000, 16, 4, 6, "copies8"),        # 8 distinct rows: groups of 18750 outgrow a bin -> the build repeats on the sorted path
+])
+def test_wilcoxon_reduction_per_response_binned_path(gpu_ctx, oracle, N, M, P, A, kind):
+    """Round 4's binned rank sums (wilcoxon.hip): per response the reduced component count equals the oracle's, on plain data, on
+    tie-heavy data (average ranks across tie groups that fill whole bins) and where a bin outgrows LDS (the reduction then repeats
+    itself on the sorted path)"""
+    wl, X, Y, obs = _wl(M, P, N, 11)
+    rng = np.random.default_rng(7)
+    Y = np.asfortranarray(Y + rng.normal(size=Y.shape) * Y.std(0) * 1.5)      # noisy responses: later components insignificant
+    nt0 = N // 2
+    if kind == "pairs":
+        X[nt0 + 1:N:2], Y[nt0 + 1:N:2] = X[nt0:N - 1:2], Y[nt0:N - 1:2]
+    elif kind == "zeros":
+        Y[:, 0] = Y[:, 0].mean() + 1e-9 * rng.normal(size=N)                   # a response nothing predicts
+        Y[nt0:, 1] = Y[nt0, 1]                                                  # ... and one that is constant on the validation rows
+    elif kind.startswith("copies"):
+        c = int(kind[6:])
+        src = nt0 + (np.arange(N - nt0) % c)
+        X[nt0:], Y[nt0:] = X[src], Y[src]
+    X, Y = np.asfortranarray(X), np.asfortranarray(Y)
+    gpu_ctx.alias_stats(reset=True)
+    per_press, per_wx, o_press, o_wx, ncomp = _wilcoxon_per_response(gpu_ctx, oracle, X, Y, obs, A)
+    assert np.array_equal(per_press, o_press), (per_press, o_press)           # (same argmin: else the tests below compare different things)
+    assert np.array_equal(per_wx, o_wx), (per_wx, o_wx, per_press)
+    assert ncomp == o_wx.max() and np.all(per_wx <= per_press)
+    print("wilcoxon %s N=%d: PRESS optima %s -> %s" % (kind, N, per_press.tolist(), per_wx.tolist()))
+
+
+def test_wilcoxon_paths_agree(gpu_ctx, oracle, tmp_path):
+    """the binned path, the sorted path (ABC_WX_SORTED) and a binned reduction forced to repeat itself on the sorted path
+    (ABC_WX_FORCE_FAIL) leave the same component counts -- each in a process of its own (the switches are read once)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_parity as T\nfrom oracle import pyoracle as O\nfrom abcsmc_amd import _lib\n"
+            "wl, X, Y, obs = T._wl(24, 8, 120000, 11)\nrng = np.random.default_rng(7)\n"
+            "Y = np.asfortranarray(Y + rng.normal(size=Y.shape) * Y.std(0) * 1.5)\n"
+            "r = T._wilcoxon_per_response(_lib.default_context(0), O, np.asfortranarray(X), Y, obs, 8)\n"
+            "print('RESULT', r[1].tolist(), r[3].tolist(), r[4])\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    for extra in ({}, {"ABC_WX_SORTED": "1"}, {"ABC_WX_FORCE_FAIL": "1"}):
+        env = dict(os.environ, ABC_DIAG="1", **extra)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        outs.append([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0])
+    assert outs[0] == outs[1] == outs[2], outs
+    got, want = eval(outs[0].split(" ", 1)[1].split("] ")[0] + "]"), eval("[" + outs[0].split("] [")[1].split("]")[0] + "]")
+    assert got == want, (got, want)
+
+
+def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol, device_inputs=False, oracle_model=True,
+                                rule=0, multivariate=True):
     """A full generation at a BASELINE size.  (1) The PLS model at size: the oracle's own ranking of the same set (its
     independent algorithm) -- component count equal, every loading column within 1e-6 of the oracle's, the K winners the
     oracle's up to near-ties, their distances within 1e-6.  (2) Invariants that do not need the O(K K' P) oracle --
@@ -1447,11 +1550,11 @@ def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol,
     (bit-exact), finite proposals inside the prior support, MVN factor against numpy."""
     from abcsmc_amd import abcutil, device
     run = _run_generation_device_inputs if device_inputs else _run_generation
-    wl, X, Y, obs, spec, prev, gen, r = run(N, M, P, K, Kp, Nn, A, True)
+    wl, X, Y, obs, spec, prev, gen, r = run(N, M, P, K, Kp, Nn, A, multivariate, rule=rule)
     idx, dist = gen.idx.cpu().numpy(), gen.dist.cpu().numpy()
     assert np.all(np.diff(dist) >= 0) and len(np.unique(idx)) == K
     # full distance vector through the staged entry point, then the oracle's argsort on those exact values
-    g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=N, max_comp=A, details=True, ctx=gpu_ctx)
+    g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=N, max_comp=A, rule=rule, details=True, ctx=gpu_ctx)
     assert g["ncomp"] == gen.ncomp.value and 1 <= g["ncomp"] <= A
     full = np.empty(N)
     full[g["idx"].astype(np.int64)] = g["dist"]
@@ -1460,8 +1563,9 @@ def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol,
     assert np.array_equal(dist, full[ref.astype(np.int64)])
     if oracle_model:
         # the model against the oracle's independent fit of the same N rows (AbcUtil.cpp:423-458)
-        o = oracle.particle_ranking_pls(X, Y, obs, 0.5, A)
-        assert g["ncomp"] == o["ncomp"]
+        # (under the Wilcoxon rule the oracle sorts the validation rows once per (response, candidate) test: ~0.1 s each at 5e5 rows)
+        o = oracle.particle_ranking_pls(X, Y, obs, 0.5, A, rule=rule)
+        assert g["ncomp"] == o["ncomp"], (g["ncomp"], o["ncomp"])
         assert np.allclose(g["mean"], o["mean"], rtol=1e-12) and np.allclose(g["sd"], o["sd"], rtol=1e-11)
         worst = max(np.linalg.norm(g["R"][:, k] - o["R"][:, k]) / np.linalg.norm(o["R"][:, k]) for k in range(o["ncomp"]))
         assert worst <= RTOL, worst                                         # loadings: 1e-6 of the column norm
@@ -1485,18 +1589,31 @@ def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol,
     theta = Y[idx]
     assert np.array_equal(device.to_numpy(gen.theta), theta)
     assert np.allclose(gen.dv.cpu().numpy(), 2.0 * theta.var(axis=0, ddof=1), rtol=1e-9)
-    rows = np.array([0, 1, 777, K // 2, K - 1])
+    # weights at size: 64+ STRATIFIED rows -- the 16 heaviest, the 16 lightest non-zero, the 16 farthest
+    # from the previous set's centre in units of its kernel width (where the split-operand kernel's far-row fix-ups live), 16
+    # random ones and the five of earlier rounds -- against the oracle's formula on exactly those rows.  The device normalises by
+    # the L2 norm of ALL K raw weights, which the oracle cannot afford (O(K K' P)): the constant is taken as the median ratio over
+    # the sample, and EVERY sampled row has to agree with it to the kernel's tolerance (absolute relative error, not ratios to one row)
+    order = np.argsort(w, kind="stable")
+    nzw = order[w[order] > 0]
+    far = np.argsort(-np.max(np.abs(theta - prev[0].mean(axis=0)) / np.sqrt(np.where(prev[2] > 0, prev[2], 1.0)), axis=1), kind="stable")[:16]
+    rows = np.unique(np.concatenate([order[-16:], nzw[:16], far, np.random.default_rng(5).integers(0, K, 16), [0, 1, 777 % K, K // 2, K - 1]]))
     raw = oracle.weights_importance(oracle.make_priors(spec), theta[rows], prev[0], prev[1], prev[2])
-    ratio = (w[rows] / w[rows[0]]) / (raw / raw[0])                          # normalisation cancels in ratios
-    assert np.allclose(ratio, 1.0, rtol=2 * kde_tol)
+    ok = (raw > 0) & (w[rows] > 0)
+    assert np.array_equal(raw > 0, w[rows] > 0) and ok.sum() >= 48
+    c = np.median(raw[ok] / w[rows][ok])
+    werr = float(np.max(np.abs(raw[ok] / (c * w[rows][ok]) - 1.0)))
+    print("weights at size: %d stratified rows, largest relative error %.2e (tolerance %.1e)" % (len(rows), werr, 2 * kde_tol))
+    assert werr <= 2 * kde_tol, werr
     parent = gen.parent.cpu().numpy()
     assert np.bincount(parent, minlength=K).sum() == Nn and parent.max() < K
     # the resampled parents are exactly the oracle's for the device's own weights
     o = oracle.rng(67890)
     assert np.array_equal(parent.astype(np.uint64), oracle.resample(o, w, Nn))
-    cov = np.cov(theta, rowvar=False, ddof=1)
-    cov[np.diag_indices(P)] *= 2.0                                           # AbcUtil.cpp:475-479
-    assert np.allclose(np.tril(device.to_numpy(gen.L)), np.linalg.cholesky(cov), rtol=1e-7, atol=1e-12 * np.abs(cov).max() ** 0.5)
+    if multivariate:
+        cov = np.cov(theta, rowvar=False, ddof=1)
+        cov[np.diag_indices(P)] *= 2.0                                       # AbcUtil.cpp:475-479
+        assert np.allclose(np.tril(device.to_numpy(gen.L)), np.linalg.cholesky(cov), rtol=1e-7, atol=1e-12 * np.abs(cov).max() ** 0.5)
     nxt = device.to_numpy(gen.next)
     assert np.isfinite(nxt).all()
     for p in range(P):
@@ -1506,6 +1623,33 @@ def _generation_size_properties(gpu_ctx, oracle, N, M, P, K, Kp, Nn, A, kde_tol,
     # a proposal is its parent plus noise of the doubled posterior variance (distributional: Philox stream)
     d = nxt - theta[parent]
     assert np.allclose(d.std(axis=0) / np.sqrt(gen.dv.cpu().numpy()), 1.0, atol=0.05)
+    if not multivariate:
+        # INDEPENDENT noise (the reference's default, AbcSmc.cpp:419; Priors.h:19-33): per-coordinate truncated normals -- the
+        # coordinates' noise is uncorrelated although the posterior's coordinates are not
+        cc = np.corrcoef(d[:200_000].T)
+        assert np.max(np.abs(cc - np.eye(P))) < 0.02, np.max(np.abs(cc - np.eye(P)))
+
+
+def test_generation_config3_size_independent_noise(gpu_ctx, oracle):
+    """BASELINE configs[2] with noise = INDEPENDENT, the reference's default (AbcSmc.cpp:419): the at-size properties of the
+    MULTIVARIATE test (selection bit-exact, stratified weights, parents bit-exact, support) plus uncorrelated per-coordinate noise"""
+    _generation_size_properties(gpu_ctx, oracle, 1_000_000, 32, 16, 100_000, 100_000, 1_000_000, 8, KDE_TOL["auto"],
+                                multivariate=False, oracle_model=False)
+
+
+def test_generation_config3_size_wilcoxon_rule(gpu_ctx, oracle):
+    """BASELINE configs[2] under the Wilcoxon component rule (the drop-in default of the C++ facade): up to 112 tests
+    over 5e5 validation rows each on the binned path; the oracle sorts each test's rows (about ten seconds in all)"""
+    from abcsmc_amd import _lib
+    _generation_size_properties(gpu_ctx, oracle, 1_000_000, 32, 16, 100_000, 100_000, 1_000_000, 8, KDE_TOL["auto"],
+                                rule=_lib.RULE_WILCOXON)
+
+
+def test_generation_config5_size_wilcoxon_rule(gpu_ctx, oracle):
+    """BASELINE configs[4] (128 metrics, 32 components: up to 496 tests over 5e5 validation rows) under the Wilcoxon rule"""
+    from abcsmc_amd import _lib
+    _generation_size_properties(gpu_ctx, oracle, 1_000_000, 128, 16, 100_000, 100_000, 1_000_000, 32, KDE_TOL["auto"],
+                                device_inputs=True, rule=_lib.RULE_WILCOXON)
 
 
 def test_generation_config3_size_properties(gpu_ctx, oracle):
