@@ -215,6 +215,11 @@ class AbcSmc {
     std::vector<Mat2D> get_particle_parameters() { return set_params_; }
     std::vector<Mat2D> get_particle_metrics() { return set_metrics_; }
     // extras for tests / drivers
+    const std::vector<const ABC::Parameter*>& parameters() const { return pars_; }
+    const std::vector<const ABC::Metric*>& metrics() const { return mets_; }
+    const Row& observed_metrics() const { return observed_; }
+    ABC::NOISE noise_type() const { return noise_kind_; }
+    ABC::FILTER filtering_type() const { return ranking_kind_; }
     const std::vector<std::vector<size_t>>& get_predictive_priors() const { return kept_rows_; }
     const std::vector<Col>& get_weights() const { return set_weights_; }
     std::ostream* log_stream = &std::cerr;      // the reference writes its reports to std::cerr

@@ -28,7 +28,31 @@ static int report_mode(const char* cfg, int K) {
     return 0;
 }
 
+// --describe cfg: everything parse_config took from the file, one line per item (tests/test_shell.py feeds it the content of the
+// reference's own examples/reference.json merged with examples/shared/partial.json)
+static int describe_mode(const char* cfg) {
+    AbcSmc abc;
+    abc.parse_config(cfg);
+    std::cout << "iterations " << abc.get_smc_iterations() << "\n";
+    std::cout << "noise " << (abc.noise_type() == ABC::NOISE::MULTIVARIATE ? "MULTIVARIATE" : "INDEPENDENT") << "\n";
+    std::cout << "filtering " << (abc.filtering_type() == ABC::FILTER::PLS ? "PLS" : "SIMPLE") << "\n";
+    std::cout << "component_rule " << (ABC::component_rule() == ABC_RULE_WILCOXON ? "wilcoxon" : "min_press") << "\n";
+    std::cout << "set_sizes";
+    for (size_t t = 0; t < abc.get_smc_iterations(); t++) std::cout << " " << abc.get_smc_size_at(t);
+    std::cout << "\npred_prior_sizes";
+    for (size_t t = 0; t < abc.get_smc_iterations(); t++) std::cout << " " << abc.get_pred_prior_size_at(t);
+    std::cout << "\n";
+    for (const ABC::Parameter* p : abc.parameters()) {
+        const abc_prior pod = p->pod();
+        std::cout << "parameter " << p->get_short_name() << " kind " << pod.kind << " a " << pod.a << " b " << pod.b << " name " << p->get_name() << "\n";
+    }
+    for (size_t j = 0; j < abc.metrics().size(); j++)
+        std::cout << "metric " << abc.metrics()[j]->get_short_name() << " obs " << std::setprecision(17) << abc.observed_metrics()[j] << "\n";
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 3 && std::string(argv[1]) == "--describe") return describe_mode(argv[2]);
     if (argc >= 7 && std::string(argv[1]) == "--gauss") return gauss_mode(argv + 2);
     if (argc >= 4 && std::string(argv[1]) == "--filter-report") return report_mode(argv[2], atoi(argv[3]));
     if (argc < 2) return 2;

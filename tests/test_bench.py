@@ -124,4 +124,8 @@ def test_n1_line_carries_both_component_rules_and_a_scaling_prediction():
     sm = j["scaling_model"]
     assert set(sm["predicted"]) == {"2", "4", "8"} and sm["from"]["collectives_per_step"] in (4, 5)
     assert sm["from"]["rccl_world1_collective_ms"] is None or sm["from"]["rccl_world1_collective_ms"] >= 0
-    assert sm["predicted"]["8"]["ms_per_step"] < j["ms_per_step"]
+    # (at this small configuration the replicated chain and the collectives outweigh what sharding saves: the prediction may well be
+    # SLOWER than one GPU -- it has to be self-consistent, not flattering)
+    f = sm["from"]
+    t8 = f["pair_sums_ms"] / 8 + f["row_sharded_streaming_ms"] / 8 + f["replicated_ms"] + f["collectives_per_step"] * f["collective_price_ms"]
+    assert abs(sm["predicted"]["8"]["ms_per_step"] - t8) < 2e-3 and sm["predicted"]["8"]["ms_per_step"] > 0

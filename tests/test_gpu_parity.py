@@ -1265,6 +1265,59 @@ def test_generation_matches_oracle(gpu_ctx, oracle, multivariate, Kp, P):
             assert nxt[:, p].min() >= a and nxt[:, p].max() <= b
 
 
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("multivariate", [True, False])
+def test_reference_posterior_rows_ranking_and_generation(gpu_ctx, oracle, rule, multivariate):
+    """The one real data set the reference ships: the 1000 posterior rows of examples/scratch/posterior.sqlite (5 parameters x 7
+    metrics of a dengue model fit; tests/golden/posterior_rows.npz, exported by tests/golden/make_reference_fixtures.py).  Ranking
+    (PLS under both component rules, and the simple ranking) and a whole weighted generation on it against the oracle: component
+    count, selection, parents and seeds bit for bit, distances / weights / doubled variance / proposal factor to 1e-6 or better.
+    The database holds no observed metrics: the mean metrics of its fifty best-ranked rows stand in for them; the previous
+    predictive prior is the rows ranked 200..349 with uniform weights."""
+    import os
+    import torch
+    from abcsmc_amd import abcutil, device, _lib
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_rows.npz"))
+    X, Y, rank = np.asfortranarray(d["metrics"]), np.asfortranarray(d["parameters"]), d["posterior_rank"]
+    N, M = X.shape
+    P = Y.shape[1]
+    assert (N, M, P) == (1000, 7, 5) and sorted(rank) == list(range(1000))
+    obs = X[rank < 50].mean(axis=0)
+    g = abcutil.particle_ranking_PLS(X, Y, obs, 0.5, rule=rule, details=True, ctx=gpu_ctx)
+    o = oracle.particle_ranking_pls(X, Y, obs, 0.5, rule=rule)
+    assert g["ncomp"] == o["ncomp"]
+    assert np.allclose(g["dist"], o["dist"][g["idx"].astype(int)], rtol=RTOL) and _near_tie_ok(g["idx"], o["idx"], o["dist"])
+    gs = abcutil.particle_ranking_simple(X, Y, obs, details=True, ctx=gpu_ctx)
+    os_idx, os_dist = oracle.particle_ranking_simple(X, obs)
+    assert np.allclose(gs["dist"], os_dist[gs["idx"].astype(int)], rtol=1e-12) and _near_tie_ok(gs["idx"], os_idx, os_dist)
+    # a weighted generation: 200 kept, 150 previous rows, 1000 proposals
+    K, Nn = 200, 1000
+    prev_rows = np.argsort(rank, kind="stable")[200:350]
+    th_prev = np.asfortranarray(Y[prev_rows])
+    w_prev = np.full(len(prev_rows), 1.0 / len(prev_rows))
+    dv_prev = 2.0 * th_prev.var(axis=0, ddof=1)
+    spec = [(_lib.PRIOR_UNIF_REAL, float(Y[:, p].min() - Y[:, p].std()), float(Y[:, p].max() + Y[:, p].std())) for p in range(P)]
+    dev = "cuda:0"
+    gen = device.Generation(N, M, P, K, len(prev_rows), Nn, 0.5, 0, rule=rule, multivariate=multivariate, device=dev, ctx=gpu_ctx)
+    r = abcutil.rng(424242)
+    gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r,
+            device.colmajor(th_prev, dev), device.colmajor(w_prev, dev), device.colmajor(dv_prev, dev))
+    torch.cuda.synchronize()
+    orng = oracle.rng(424242)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, orng, th_prev, w_prev, dv_prev, train_frac=0.5, max_comp=0, rule=rule,
+                            multivariate=multivariate)
+    assert gen.ncomp.value == ref["ncomp"]
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL) and np.allclose(gen.dv.cpu().numpy(), ref["dv"], rtol=1e-9)
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+    if multivariate:
+        assert np.allclose(np.tril(device.to_numpy(gen.L)), np.tril(ref["L"]), rtol=1e-7, atol=1e-12)
+    nxt = device.to_numpy(gen.next)
+    assert np.isfinite(nxt).all()
+    for p in range(P):
+        assert nxt[:, p].min() >= spec[p][1] and nxt[:, p].max() <= spec[p][2]
+
+
 def test_generation_with_40_parameters_matches_oracle(gpu_ctx, oracle):
     """a whole weighted, MULTIVARIATE generation at 40 parameters / 48 metrics: the model fit beyond 32 responses, the pair sums
     on the four-chunk split kernel, 64-wide perturbation -- selection, parents bit for bit, weights to the 33..64-parameter bound"""

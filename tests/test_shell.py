@@ -172,6 +172,58 @@ def test_process_needs_the_gpu(dice, tmp_path):
     assert c.execute("select count(*) from job where posterior > -1").fetchone()[0] == 0
 
 
+def test_reference_shipped_configuration(dice, probe, tmp_path):
+    """the CONTENT of the reference's own configuration -- examples/reference.json merged with examples/shared/partial.json, what
+    `make run_shared` runs (examples/Makefile:38-39), committed as the data fixture tests/golden/reference_shared_config.json by
+    tests/golden/make_reference_fixtures.py -- through the shell's parser: thirty sets growing 300 / 500 / 500 / 750 / 1000 / 1000 ...,
+    half of each kept, two integer uniform priors on [1, 1000], the observed sum 44 and sd 2.39925 of 13 eight-sided dice
+    (examples/README.md:29-34), MULTIVARIATE noise, the simulator a shared object with the `simulator` symbol (AbcSim.h:57-76).
+    Then the first steps of the fit on it: set 0 sampled into `shared.sqlite`, particles simulated through libdice.so."""
+    fixture = os.path.join(ROOT, "tests", "golden", "reference_shared_config.json")
+    ref = json.load(open(fixture))
+    assert ref["shared"] == "libdice.so" and ref["database_filename"] == "shared.sqlite" and ref["smc_iterations"] == 30
+    # a libdice.so with the reference's plugin signature: sum and sample sd of `ndice` dice with `sides` sides (examples/include/dice.h:14-45
+    # does the same with the example's own static RNG; here the particle's seed drives a taus2 stream so the test can re-derive it)
+    src = tmp_path / "dice_plugin.cpp"
+    src.write_text('#include <cmath>\n#include <vector>\n#include "%s"\n'
+                   'extern "C" std::vector<double> simulator(std::vector<double> p, const unsigned long seed, const unsigned long) {\n'
+                   '    ABC::RNG r(seed); const int n = (int)p[0], m = (int)p[1]; double s = 0; std::vector<double> x;\n'
+                   '    for (int i = 0; i < n; i++) { x.push_back(1.0 + ABC::rng_uniform_int(&r, (unsigned long)m)); s += x.back(); }\n'
+                   '    double q = 0; for (double v : x) q += (v - s / n) * (v - s / n);\n'
+                   '    return {s, n > 1 ? std::sqrt(q / (n - 1)) : 0.0};\n}\n' % os.path.join(ROOT, "abcsmc_amd", "cxx", "AbcUtilHip.hpp"))
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), str(src), "-o",
+                           str(tmp_path / "libdice.so"), "-L" + LIBDIR, "-labcsmc_hip", "-Wl,-rpath," + LIBDIR])
+    cfg = tmp_path / "shared.json"
+    cfg.write_text(open(fixture).read())                           # (the file as committed: relative names resolve in the run directory)
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([probe, "--describe", str(cfg)], capture_output=True, text=True, timeout=60, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    got = {}
+    for ln in out.stdout.splitlines():
+        k, _, v = ln.partition(" ")
+        got.setdefault(k, []).append(v)
+    sizes = [300, 500, 500, 750] + [1000] * 26
+    assert got["iterations"] == ["30"] and got["noise"] == ["MULTIVARIATE"] and got["filtering"] == ["PLS"]
+    assert got["component_rule"] == ["wilcoxon"]                    # the facade's default (INTEGRATION.md section 1)
+    assert [int(v) for v in got["set_sizes"][0].split()] == sizes
+    assert [int(v) for v in got["pred_prior_sizes"][0].split()] == [round(0.5 * n) for n in sizes]
+    assert got["parameter"] == ["ndice kind 1 a 1 b 1000 name number of dice", "sides kind 1 a 1 b 1000 name number of sides"]
+    assert [m.split()[0] for m in got["metric"]] == ["sum", "sd"]
+    assert [float(m.split()[2]) for m in got["metric"]] == [44.0, 2.39925]
+    # set 0 into shared.sqlite, twenty particles through the configured shared object
+    for args in (["--process", "--seed", "5", "--configured-simulator"], ["--simulate", "-n", "20", "--configured-simulator"]):
+        r = subprocess.run([dice, str(cfg)] + args, capture_output=True, text=True, timeout=120, cwd=str(tmp_path), env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+    c = sqlite3.connect(str(tmp_path / "shared.sqlite"))
+    assert c.execute("select count(*) from job where smcSet = 0").fetchone()[0] == 300
+    rows = c.execute("select P.seed, ndice, sides, sum, sd from par P, met M where P.serial = M.serial and sum is not null").fetchall()
+    assert len(rows) == 20
+    for seed, nd, sd_, s_, d in rows:
+        assert 1 <= nd <= 1000 and 1 <= sd_ <= 1000 and nd == int(nd) and sd_ == int(sd_)
+        es, esd = dice_metrics(int(nd), int(sd_), int(seed))
+        assert s_ == six(es) and d == pytest.approx(six(esd), rel=1e-12)
+
+
 def test_iteration_rules(probe, tmp_path):
     def sizes(**over):
         base = {k: v for k, v in DICE.items() if k not in ("predictive_prior_fraction", "smc_iterations", "num_samples")}
