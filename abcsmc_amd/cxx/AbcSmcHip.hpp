@@ -72,25 +72,38 @@ struct AbcFPtrBase : AbcSimFun {     // AbcSim.h:106-117
 };
 struct AbcExec : AbcSimFun {         // AbcSim.h:122-157: parameters as command-line arguments, metrics on stdout
     const std::string command;
-    AbcExec(std::string c) : command(c) {}
+    AbcExec(std::string c) : command(std::move(c)) {}
+    // the command line: the configured command, then every parameter as the reference's ostream prints a double (6 significant digits)
+    std::string command_line(const std::vector<float_type>& pars) const {
+        std::ostringstream line;
+        line << command;
+        for (size_t i = 0; i < pars.size(); i++) line << ' ' << pars[i];
+        return line.str();
+    }
+    // everything the child wrote to its standard output (RAII on the pipe: closed on every path)
+    static bool slurp(const std::string& line, std::string* out) {
+        struct Pipe {
+            FILE* f;
+            explicit Pipe(const std::string& l) : f(popen(l.c_str(), "r")) {}
+            ~Pipe() { if (f) pclose(f); }
+        } pipe(line);
+        if (!pipe.f) return false;
+        char chunk[4096];
+        for (size_t got; (got = fread(chunk, 1, sizeof chunk, pipe.f)) > 0;) out->append(chunk, got);
+        return true;
+    }
     std::vector<float_type> operator()(std::vector<float_type> pars, const unsigned long int, const unsigned long int) const override {
-        std::ostringstream execcom(command, std::ios_base::ate);
-        for (const float_type par : pars) execcom << " " << par;
+        const std::string line = command_line(pars);
+        std::string reply;
+        if (!slurp(line, &reply)) { std::cerr << "ERROR: Unable to create pipe to " << line << std::endl; exit(103); }
         std::vector<float_type> mets;
-        FILE* pipe = popen(execcom.str().c_str(), "r");
-        if (!pipe) { std::cerr << "ERROR: Unable to create pipe to " << execcom.str() << std::endl; exit(103); }
-        char buffer[512];
-        std::string retval;
-        while (fgets(buffer, sizeof buffer, pipe) != NULL) retval += buffer;
-        pclose(pipe);
-        if (retval == "ERROR" || retval == "") {
+        if (reply.empty() || reply == "ERROR") {                            // (the caller counts the metrics: AbcSmc.cpp:998, exit -211)
             std::cerr << command << " does not exist or appears to be an invalid simulator." << std::endl;
-            std::cerr << "Attempted: " << execcom.str() << std::endl;
-        } else {
-            std::istringstream ss(retval);
-            float_type met;
-            while (ss >> met) mets.push_back(met);
+            std::cerr << "Attempted: " << line << std::endl;
+            return mets;
         }
+        std::istringstream numbers(reply);
+        for (float_type m; numbers >> m;) mets.push_back(m);
         return mets;
     }
 };
