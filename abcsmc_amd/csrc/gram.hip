@@ -11,6 +11,8 @@
 // 16x16 blocks (fp64 in, fp64 accumulate).  HBM-bound: 8*(M+P) bytes per particle, read once.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "abc_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -685,6 +687,354 @@ __global__ __launch_bounds__(512) void k_gram_wide(const double* __restrict__ X,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the Gram of wide sets OFF the fp64 matrix pipe.  k_gram_wide is bound by v_mfma_f64_16x16x4_f64 (44 blocks x 64 cycles
+// per 4 rows: 0.61 ms at 1e6 rows x 144 columns, 0.235 of the HBM roofline).  Here every shifted value travels as a 32-bit
+// FIXED-POINT number on a per-column grid -- q = rint(v 2^(31 - e_c)), |v| < 2^e_c -- cut into four balanced signed bytes
+// (q = sum_b l_b 2^(8b), -128 <= l_b <= 127), and the cross products run as exact integer arithmetic on
+// v_mfma_i32_32x32x32_i8 (the 16-bit pipe's rate at twice the depth): G_ab 2^(62 - e_a - e_b) = sum_rows q_a q_b =
+// sum_{b,b'} 2^(8(b+b')) sum_rows l_b l'_b', of which the thirteen byte pairs with b + b' >= 2 are kept -- one i32 accumulator per
+// order b + b' (exact: <= 2^21 per 32-row step, flushed to fp64 every 16384 rows), 13 MFMAs per 32 x 32 tile and step, 14 tiles at
+// 144 columns: 46 MFMA-cycles per row against 704 on the fp64 pipe.  The dropped pairs (b + b' <= 1) are products of the low bytes:
+// zero-mean noise below 1e-11 of sigma_a sigma_b rows off the diagonal (with b + b' = 2 dropped as well it was 3e-9, and the 32nd
+// loading of a 128-metric model moved by 4e-6) -- and a BIAS on the diagonal (l l' >= 0 there), so column sums and sums of squares are taken in fp64 on the
+// vector pipe while the tile is staged (exact as before: means to 1e-12, deviations to 1e-11) and the diagonal of the result is
+// theirs.  Conversion is three instructions per value: v + 1.5 2^(21 + e_c) leaves q in the low word of the double, and
+// (q + 0x80808080) ^ 0x80808080 are its four balanced bytes.
+// A tile is one 32-row step; the eight waves of a work-group work in two roles (GramI8 below).
+// Range: e_c = ceil(log2(4 max |x - shift|)) over 4096 rows spread over the set (k_pilot_scale).  A row with a value outside its
+// column's range ("far": a spike 4 times beyond anything in the sample) is left out of the byte products as a whole -- its bytes
+// are zeroed in LDS -- and listed; k_gram_far adds the far rows' products in fp64.
+// Partial records in k_gram's format (k_stats_reduce unchanged): a 32 x 32 tile is written as its 16 x 16 blocks.
+template <int C, int CY>
+struct GramI8 {
+    static constexpr int C16 = 16 * C;
+    static constexpr int CB = (C + 1) / 2;                       // 32-column super-blocks
+    static constexpr int C32 = 32 * CB;
+    static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
+    static constexpr int PSZ = NBLK * 256 + 2 * C16;             // the partial record of k_gram
+    static constexpr int NT = 512, NW = 8, TRW = 32;             // a tile = one 32-row step of the i8 MFMA
+    static constexpr int NI = CB;                                // columns per thread and tile in the conversion (column 32 i + t / 16, row pair t % 16)
+    static constexpr int NDMA = C32 * 16 * 16 / 1024;            // LDS-DMA instructions per tile (1 KB each: 4 columns x 16 row pairs)
+    static constexpr int DPW = (NDMA + NW - 1) / NW;             // ... per wave
+    static constexpr int RAW = C32 * 256;                        // bytes of a raw tile in LDS: [column][32 rows] doubles
+    static constexpr int CS = 48;                                // bytes of a (byte plane, column) in LDS: 32 rows + 16 (b128 reads conflict-free)
+    static constexpr int PLANE = C32 * CS;
+    static constexpr bool skip_last = (2 * (CB - 1) >= C - CY);  // the last diagonal tile holds Y'Y / padding only
+    static constexpr int NTILE = CB * (CB + 1) / 2 - (skip_last ? 1 : 0);
+    static constexpr int TPW = (NTILE + NW - 1) / NW;            // tiles per wave
+    // two raw tiles (LDS-DMA targets), one set of byte planes, the running column sums and sums of squares of every (column, row
+    // pair), (shift, magic, limit) per column, two sets of far flags (32 rows + any)
+    static constexpr int SUMS = C32 * 16 * 8;
+    static constexpr int LDS_B = 2 * RAW + 4 * PLANE + 2 * SUMS + C32 * 24 + 2 * 48;
+    static constexpr int FLUSH = 512;                            // tiles (32-row steps) between two flushes of the i32 accumulators
+};
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// e[c]: the binade of the column's fixed-point range = 4 x a ROBUST size of |x - shift| among 4096 rows spread evenly over the n rows:
+// the median of the 64 maxima of 64 samples each (for a Gaussian column 4 x 2.4 sigma, rounded up to a power of two: 10 .. 19 sigma; a spike in the sample moves one of the 64
+// maxima, not their median -- with the plain maximum one sampled outlier of 1e4 sigma cost the column thirteen bits of resolution)
+__global__ __launch_bounds__(1024) void k_pilot_scale(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy,
+                                                      int M, int P, long long n, const double* __restrict__ shift, int* __restrict__ e) {
+    const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ double gmax[64];
+    const bool real = c < M + P;
+    const double* p = (c < M) ? X + (size_t)c * ldx : Y + (size_t)((real ? c : M) - M) * ldy;
+    const double sh = real ? shift[c] : 0.0;
+    const long long S = n < 4096 ? n : 4096;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const long long q = (long long)t + 1024 * j;
+        double a = 0.0;
+        if (real && q < S) {
+            const long long r = (long long)(((unsigned long long)q * (unsigned long long)n) / (unsigned long long)S);
+            a = fabs(p[r] - sh);
+            a = (a == a) ? a : 0.0;                                          // (a NaN never counts: such a row is far in the main pass)
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const double b = __shfl_xor(a, o, 64); a = b > a ? b : a; }
+        if (lane == 0) gmax[wave * 4 + j] = a;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const double mine = gmax[lane];
+        int below = 0;
+        for (int i = 0; i < 64; i++) { const double o = gmax[i]; below += (o < mine || (o == mine && i < lane)) ? 1 : 0; }
+        const unsigned long long pick = __ballot(below == 32);                // the 33rd smallest of the 64 (ties broken by position)
+        const double med = __shfl(mine, __ffsll((long long)pick) - 1, 64);
+        if (lane == 0) {
+            int ex = -1000;
+            if (med > 0.0 && med < 1.0e300) { (void)frexp(med, &ex); ex += 2; }      // med < 2^(ex - 2): range 2^ex >= 4 med
+            e[c] = ex < -1000 ? -1000 : ex;
+        }
+    }
+}
+
+// Staging by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without a register round trip), TWO raw tiles in flight behind the one
+// being multiplied (80 KB per CU: HBM at 6 TB/s with ~2.5 us of latency wants ~60 KB per CU in flight).  What was measured on the way
+// (1e6 rows x 144 columns): the next tile prefetched in registers, one tile ahead -- 336 us, the kernel ran at the latency of its
+// loads (41 KB in flight per CU), and the ~250 registers a thread then needs spill, each scratch reload being a vmcnt wait that also
+// waits for the prefetch; three converter waves feeding five multiplier waves (roles as separate code paths) -- 450 us with one tile
+// ahead, 930 us with two (the compiler spilled the converters' second tile).  The running column sums live in LDS for the same
+// reason (every (column, row pair) slot has one owner: plain read-add-write, a fixed order): with them in registers the conversion
+// spilled accumulators around itself.  Per tile: wait for the own DMAs of tile i, barrier, convert it (raw -> byte planes, column
+// sums and squares in fp64, far flags), barrier, refill its raw slot with tile i + 2, the MFMAs of tile i.
+template <int C, int CY>
+__global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M,
+                                                 int P, long long n, long long split, const double* __restrict__ shift,
+                                                 const int* __restrict__ escale, double* __restrict__ partial,
+                                                 unsigned long long* __restrict__ far_mask /* [2][tmax]: far rows of every 32-row tile */,
+                                                 unsigned long long* __restrict__ far_sum /* [2][(tmax + 63) / 64]: tiles with any; then one word: any at all */,
+                                                 long long tmax) {
+    using D = GramI8<C, CY>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    unsigned char* raw0 = lds8;                                               // [2][C32][32 rows] doubles
+    unsigned char* planes = lds8 + 2 * D::RAW;                                // [4][C32][CS]
+    double* lsum = reinterpret_cast<double*>(lds8 + 2 * D::RAW + 4 * D::PLANE);             // [C32][16] column sums per row pair
+    double* lsq = lsum + D::C32 * 16;                                                       // [C32][16] sums of squares
+    double* colc = lsq + D::C32 * 16;                                                       // [C32][3]: shift, magic, range limit
+    unsigned char* rowfar0 = reinterpret_cast<unsigned char*>(colc + D::C32 * 3);           // [2][48]: 32 row flags + the any-flag word
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
+    const long long r_begin = part ? split : 0, r_end = part ? n : split;
+    const long long t0 = r_begin & ~1LL;
+    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + D::TRW - 1) / D::TRW : 0;
+    const long long nmine = (ntiles > g) ? (ntiles - g + G - 1) / G : 0;      // this work-group's tiles: g, g + G, ...
+    const long long rmax = (n - 2) & ~1LL;                                    // last in-bounds 16-B row pair (n is even on this path)
+    double* out = partial + ((size_t)part * (G + 1) + g) * D::PSZ;           // (record G of a partition: k_gram_far's)
+    auto blk_index = [&](int bi, int bj) -> int {                               // (bi, bj >= bi, bi < C - CY) enumeration of k_gram
+        int b = 0;
+        for (int i2 = 0; i2 < bi; i2++) b += C - i2;
+        return b + (bj - bi);
+    };
+    // per-column constants: shift, magic = 1.5 2^(21 + e) (v + magic has q = rint(v 2^(31 - e)) in its low word), and the range
+    // limit (1 - 2^-6) 2^e (so that the balanced bytes of q never carry out of the top one)
+    for (int c = t; c < D::C32; c += D::NT) {
+        const bool real = c < M + P;
+        const int e = real ? escale[c] : 0;
+        colc[3 * c] = real ? shift[c] : 0.0;
+        colc[3 * c + 1] = ldexp(1.5, 21 + e);
+        colc[3 * c + 2] = ldexp(0.984375, e);
+    }
+    for (int e2 = t; e2 < 2 * D::C32 * 16; e2 += D::NT) lsum[e2] = 0.0;     // (lsum and lsq are adjacent)
+    if (t < 24) reinterpret_cast<unsigned int*>(rowfar0)[t] = 0u;            // both sets of far flags
+    for (int e2 = t; e2 < D::NBLK * 256; e2 += D::NT) out[e2] = 0.0;       // the flushes ADD into the record
+    // this wave's tiles: the b-th (I, J >= I) super-block pair in row-major order, b = wave + 8 k
+    int wI[D::TPW], wJ[D::TPW];
+#pragma unroll
+    for (int k = 0; k < D::TPW; k++) {
+        int rem = wave + 8 * k, I = 0;
+        while (I < D::CB && rem >= D::CB - I) { rem -= D::CB - I; I++; }
+        const bool ok = I < D::CB && !(D::skip_last && I == D::CB - 1);
+        wI[k] = ok ? I : -1;
+        wJ[k] = I + rem;
+    }
+    v16i acc[D::TPW][5];                                                      // orders b + b' = 2 .. 6
+#pragma unroll
+    for (int k = 0; k < D::TPW; k++)
+#pragma unroll
+        for (int o = 0; o < 5; o++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[k][o][r] = 0;
+    // LDS-DMA: instruction d of a tile moves columns 4 d .. 4 d + 3 (lane = 16 (column & 3) + row pair); wave w issues d = w, w + 8, ...
+    auto stage = [&](long long k) {                                             // the k-th tile of this work-group -> raw slot k & 1
+        const long long r = t0 + (g + k * G) * D::TRW + 2 * (lane & 15);
+        const long long rr = r > rmax ? rmax : r;                               // (a legal address for rows past the end: masked later)
+        unsigned char* dst = raw0 + (size_t)(k & 1) * D::RAW;
+#pragma unroll
+        for (int j = 0; j < D::DPW; j++) {
+            const int d = wave + D::NW * j, c = 4 * d + (lane >> 4);
+            if (d < D::NDMA) {
+                const double* p = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+                dma16(p + rr, reinterpret_cast<double*>(dst + (size_t)d * 1024));
+            }
+        }
+    };
+    // conversion: thread -> (column 32 i + t / 16, row pair t % 16)
+    const int cq = t >> 4, rp = t & 15;
+    auto convert = [&](long long k) {                                           // raw slot k & 1 -> the byte planes, far flags k & 1
+        const unsigned char* raw = raw0 + (size_t)(k & 1) * D::RAW;
+        unsigned char* rowfar = rowfar0 + (int)(k & 1) * 48;
+        const long long r = t0 + (g + k * G) * D::TRW + 2 * rp;
+        const bool oka = (r >= r_begin) && (r < r_end), okb = (r + 1 >= r_begin) && (r + 1 < r_end);
+        bool farx = false, fary = false;
+#pragma unroll 1
+        for (int i = 0; i < D::NI; i++) {                                      // (one column after the other: the accumulators leave few registers)
+            const int c = 32 * i + cq;
+            const d2 v = *reinterpret_cast<const d2*>(raw + (size_t)c * 256 + 16 * rp);
+            const double sh = colc[3 * c], magic = colc[3 * c + 1], lim = colc[3 * c + 2];
+            const bool real = c < M + P;
+            const double zx = (real && oka) ? v.x - sh : 0.0, zy = (real && okb) ? v.y - sh : 0.0;   // (rows outside the partition: 0)
+            lsum[c * 16 + rp] += zx + zy;                                      // (this thread's slot: no other thread touches it)
+            lsq[c * 16 + rp] = fma(zy, zy, fma(zx, zx, lsq[c * 16 + rp]));
+            farx = farx || !(fabs(zx) <= lim);                                 // (NaN: not in range)
+            fary = fary || !(fabs(zy) <= lim);
+            const unsigned int qx = (unsigned int)__double_as_longlong(zx + magic), qy = (unsigned int)__double_as_longlong(zy + magic);
+            const unsigned int bx = (qx + 0x80808080u) ^ 0x80808080u, by = (qy + 0x80808080u) ^ 0x80808080u;
+            unsigned char* dst = planes + (size_t)c * D::CS + 2 * rp;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                *reinterpret_cast<unsigned short*>(dst + (size_t)b * D::PLANE) = (unsigned short)(((bx >> (8 * b)) & 0xffu) | (((by >> (8 * b)) & 0xffu) << 8));
+        }
+        if (farx) rowfar[2 * rp] = 1;
+        if (fary) rowfar[2 * rp + 1] = 1;
+        if (farx || fary) rowfar[32] = 1;
+    };
+    // flush of the i32 accumulators into this work-group's partial record (fp64): tile (I, J), order o = b + b' - 3 carries weight
+    // 2^(8 o) 2^(e_a + e_b - 62 + 24); a 32 x 32 tile is up to four 16 x 16 blocks of the record, stored in the f64 MFMA's C layout
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < D::TPW; k++) {
+            if (wI[k] < 0) continue;
+            const int I = wI[k], J = wJ[k];
+            const int ncol = 32 * J + (lane & 31);                            // this lane's column of the tile
+            const int eb = (ncol < M + P) ? escale[ncol] : 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mrow = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ea = (mrow < M + P) ? escale[mrow] : 0;
+                const double val = ldexp(((double)acc[k][4][r] * 4294967296.0 + (double)acc[k][3][r] * 16777216.0) +
+                                         ((double)acc[k][2][r] * 65536.0 + ((double)acc[k][1][r] * 256.0 + (double)acc[k][0][r])), ea + eb - 62 + 16);
+                const int bi = mrow >> 4, bj = ncol >> 4;
+                if (bi > bj || bi >= C - CY || bj >= C || mrow == ncol) continue;   // lower triangle, pure Y'Y / padding, the diagonal
+                // C/D layout of v_mfma_f64_16x16x4_f64: element (row, col) of a block sits at lane' = 16 (row & 3) + col, register row >> 2
+                const int rr = mrow & 15, cc = ncol & 15;
+                out[(size_t)blk_index(bi, bj) * 256 + (rr >> 2) * 64 + 16 * (rr & 3) + cc] += val;     // (one owner per element)
+            }
+#pragma unroll
+            for (int o = 0; o < 5; o++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[k][o][r] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the record's loads and stores out of the DMA count)
+    };
+    __syncthreads();
+    if (nmine > 0) stage(0);
+    if (nmine > 1) stage(1);
+    // (two loops: the accumulators are flushed between runs of FLUSH tiles -- the flush stays out of the inner loop's register budget)
+    for (long long i0 = 0; i0 < nmine; i0 += D::FLUSH) {
+        const long long i1 = (i0 + D::FLUSH < nmine) ? i0 + D::FLUSH : nmine;
+#pragma unroll 1
+        for (long long i = i0; i < i1; i++) {
+            // (1) the own DMAs of tile i have landed (those of tile i + 1 may stay in flight), then everybody's
+            if (i + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::DPW) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                   // (also: every wave is done with the MFMAs of tile i - 1)
+            // (2) tile i -> bytes
+            unsigned char* rowfar = rowfar0 + (int)(i & 1) * 48;
+            const long long tile = g + i * G, row0 = t0 + tile * D::TRW;
+            convert(i);
+            __syncthreads();                                                   // the planes are complete, tile i's raw slot is free
+            // (3) refill the slot with tile i + 2; far rows; the byte products of tile i
+            if (i + 2 < nmine) stage(i + 2);
+            if (wave == 0) {                                                   // tile i's far rows as a mask (always written: no memset)
+                const unsigned long long m = __ballot(lane < 32 && rowfar[lane & 31] != 0 && row0 + lane >= r_begin && row0 + lane < r_end);
+                if (lane == 0) {
+                    far_mask[(size_t)part * tmax + tile] = m;
+                    if (m) {
+                        atomicOr(&far_sum[(size_t)part * ((tmax + 63) / 64) + (tile >> 6)], 1ull << (tile & 63));
+                        far_sum[(size_t)2 * ((tmax + 63) / 64)] = 1ull;        // (k_gram_far's way out when nothing is far)
+                    }
+                }
+                // the other set of flags, for tile i + 1: its readers (tile i - 1) passed this iteration's first barrier, its writers
+                // have to pass the next iteration's
+                if (lane < 12) reinterpret_cast<unsigned int*>(rowfar0 + (int)((i + 1) & 1) * 48)[lane] = 0u;
+            }
+            if (rowfar[32]) {                                                  // (uniform) rare: zero the far rows' bytes
+                for (int e2 = t; e2 < 4 * D::C32 * 32; e2 += D::NT) {
+                    const int r = e2 & 31, c = (e2 >> 5) % D::C32, b = e2 / (32 * D::C32);
+                    if (rowfar[r]) planes[(size_t)b * D::PLANE + (size_t)c * D::CS + r] = 0;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < D::TPW; k++) {
+                if (wI[k] < 0) continue;                                       // (wave-uniform)
+                v4i fa[4];
+                const unsigned char* pa = planes + (size_t)(32 * wI[k] + (lane & 31)) * D::CS + 16 * (lane >> 5);
+                const unsigned char* pb = planes + (size_t)(32 * wJ[k] + (lane & 31)) * D::CS + 16 * (lane >> 5);
+#pragma unroll
+                for (int b = 0; b < 4; b++) fa[b] = *reinterpret_cast<const v4i*>(pa + (size_t)b * D::PLANE);
+                // order o = b + b' - 2: (2,0)(1,1)(0,2) | (3,0)(2,1)(1,2)(0,3) | (3,1)(2,2)(1,3) | (3,2)(2,3) | (3,3)
+#pragma unroll
+                for (int b2 = 0; b2 < 4; b2++) {
+                    const v4i fb = *reinterpret_cast<const v4i*>(pb + (size_t)b2 * D::PLANE);
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b + b2 >= 2) acc[k][b + b2 - 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[b], fb, acc[k][b + b2 - 2], 0, 0, 0);
+                }
+            }
+        }
+        if (i1 < nmine) flush();                                               // (rare: more than FLUSH tiles in this work-group)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    flush();
+    // column sums / sums of squares (16 slots per column) and the exact diagonal
+    if (t < D::C16) {
+        for (int half = 0; half < 2; half++) {
+            const double* src = half ? lsq : lsum;
+            double sacc = 0.0;
+            for (int l = 0; l < 16; l++) sacc += src[t * 16 + l];
+            out[D::NBLK * 256 + half * D::C16 + t] = sacc;
+            if (half == 1 && (t >> 4) < C - CY) {                              // the diagonal element of block (t / 16, t / 16)
+                const int rr = t & 15;
+                out[(size_t)blk_index(t >> 4, t >> 4) * 256 + (rr >> 2) * 64 + 16 * (rr & 3) + rr] = sacc;
+            }
+        }
+    }
+}
+
+// the far rows of k_gram_i8 (a value outside its column's fixed-point range): their products in fp64, as one more partial record per
+// partition (index G).  One work-group per 16 x 16 block of the record, a thread per element, the rows in ASCENDING order whatever
+// order the tiles were processed in (the masks are walked, not a list: repeats are bit-identical); the sums of the record stay zero
+// (k_gram_i8 counted the far rows in its column sums and squares), and so does the diagonal.
+template <int C, int CY>
+__global__ __launch_bounds__(256) void k_gram_far(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M,
+                                                  int P, long long n, long long split, const double* __restrict__ shift,
+                                                  double* __restrict__ partial, int G, const unsigned long long* __restrict__ far_mask,
+                                                  const unsigned long long* __restrict__ far_sum, long long tmax) {
+    using D = GramI8<C, CY>;
+    const int part = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    double* out = partial + ((size_t)part * (G + 1) + G) * D::PSZ;
+    if (b == D::NBLK) {                                                        // the sums part of the record
+        for (int e = t; e < 2 * D::C16; e += 256) out[D::NBLK * 256 + e] = 0.0;
+        return;
+    }
+    int blk = b, bi = 0;
+    while (blk >= C - bi) { blk -= C - bi; bi++; }
+    const int bj = bi + blk;
+    // element t of the block in the f64 MFMA's C layout: row = (lane >> 4) + 4 reg, col = lane & 15 with t = 64 reg + lane
+    const int row = 16 * bi + ((t & 63) >> 4) + 4 * (t >> 6), col = 16 * bj + (t & 15);
+    const bool live = row != col && row < M + P && col < M + P;
+    const double* pr = (row < M) ? X + (size_t)row * ldx : Y + (size_t)((row < M + P ? row : M) - M) * ldy;
+    const double* pc = (col < M) ? X + (size_t)col * ldx : Y + (size_t)((col < M + P ? col : M) - M) * ldy;
+    const double sr = live ? shift[row] : 0.0, sc = live ? shift[col] : 0.0;
+    const long long r_begin = part ? split : 0, r_end = part ? n : split;
+    const long long t0 = r_begin & ~1LL;
+    const long long ntiles = (r_end > r_begin) ? (r_end - t0 + D::TRW - 1) / D::TRW : 0;
+    const unsigned long long* fs = far_sum + (size_t)part * ((tmax + 63) / 64);
+    const unsigned long long* fm = far_mask + (size_t)part * tmax;
+    double s = 0.0;
+    const bool any = far_sum[(size_t)2 * ((tmax + 63) / 64)] != 0ull;
+    for (long long w = 0; any && w < (ntiles + 63) / 64; w++) {
+        unsigned long long tiles = fs[w];
+        while (tiles) {
+            const int tb = __ffsll((long long)tiles) - 1;
+            tiles &= tiles - 1;
+            unsigned long long rows = fm[w * 64 + tb];
+            while (rows) {
+                const int rb = __ffsll((long long)rows) - 1;
+                rows &= rows - 1;
+                const long long r = t0 + (w * 64 + tb) * D::TRW + rb;
+                if (live) s = fma(pr[r] - sr, pc[r] - sc, s);
+            }
+        }
+    }
+    out[(size_t)b * 256 + t] = s;
+}
+
 // Sum the per-work-group partial records in a fixed order and scatter into the stats record.
 constexpr int SR_SL = 16;          // slices of the G partial records per work-group (64 elements x SR_SL slices = 1024 threads)
 template <int C, int CY>
@@ -900,6 +1250,50 @@ int run_gram_wide(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     return ABC_OK;
 }
 
+template <int C, int CY>
+int run_gram_i8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
+                long long split, double* stats) {
+    using D = GramI8<C, CY>;
+    const StatsLayout L = stats_layout(M, P);
+    const long long ntr = split, nte = (long long)n - split;
+    const long long tmax = ((ntr > nte ? ntr : nte) + D::TRW - 1) / D::TRW + 2;      // tiles of a partition (t0 may start a row early)
+    long long G = tmax / 2;
+    if (G < 1) G = 1;
+    if (G > 127) G = 127;              // 154 KB of LDS, 512 threads with ~250 registers: one work-group per CU; with k_gram_far's record
+                                       // 128 records per partition (k_stats_reduce splits them evenly over its 16 slices)
+    const size_t pbytes = (size_t)2 * (G + 1) * D::PSZ * sizeof(double);
+    double* partial = (double*)abc_ws_alloc(ctx, pbytes);
+    int* escale = (int*)abc_ws_alloc(ctx, (size_t)D::C32 * sizeof(int));
+    const size_t sumw = (size_t)((tmax + 63) / 64);
+    unsigned long long* far_mask = (unsigned long long*)abc_ws_alloc(ctx, (size_t)2 * tmax * 8);
+    unsigned long long* far_sum = (unsigned long long*)abc_ws_alloc(ctx, (2 * sumw + 1) * 8);
+    if (!partial || !escale || !far_mask || !far_sum) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_i8<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D::LDS_B));
+    {
+        StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
+        hipLaunchKernelGGL(k_pilot_scale, dim3((unsigned)D::C16), dim3(1024), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P, (long long)n,
+                           (const double*)(stats + L.off_shift), escale);
+        ABC_HIP(ctx, hipMemsetAsync(far_sum, 0, (2 * sumw + 1) * 8, ctx->stream));
+        hipLaunchKernelGGL((k_gram_i8<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), (size_t)D::LDS_B, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
+                           (long long)n, split, (const double*)(stats + L.off_shift), (const int*)escale, partial, far_mask, far_sum, tmax);
+        hipLaunchKernelGGL((k_gram_far<C, CY>), dim3((unsigned)(D::NBLK + 1), 2), dim3(256), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
+                           (long long)n, split, (const double*)(stats + L.off_shift), partial, (int)G, (const unsigned long long*)far_mask,
+                           (const unsigned long long*)far_sum, tmax);
+    }
+    ABC_HIP(ctx, hipGetLastError());
+    if (abc_diag_env("ABC_GRAM_DEBUG")) {        // (diagnostic: the columns' fixed-point binades)
+        std::vector<int> he(D::C32);
+        ABC_HIP(ctx, hipMemcpy(he.data(), escale, D::C16 * sizeof(int), hipMemcpyDeviceToHost));
+        for (int c = 0; c < (int)(M + P); c++) fprintf(stderr, "%d%s", he[c], (c + 1) % 32 ? " " : "\n");
+        fprintf(stderr, "\n");
+    }
+    StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);
+    hipLaunchKernelGGL((k_stats_reduce<C, CY>), dim3((D::PSZ + 63) / 64, 2), dim3(64 * SR_SL), 0, ctx->stream, partial, (int)(G + 1),
+                       stats, ntr, nte);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}
+
 // ---- wide sets (M+P > 96): column groups of <= 48, one k_gram<.,0,TABLE> launch per pair of groups ------------
 __global__ void k_group_table(const double* X, const double* Y, size_t ldx, size_t ldy, int M, int P, int ga0, int gan,
                               int gb0, int gbn, const double* __restrict__ shift_big, const double** __restrict__ tab,
@@ -1021,7 +1415,15 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
 #undef GRAM_CASE
     // 8..10 column blocks: one launch, the Gram blocks dealt out to the waves of a work-group (7 blocks: the compiler spills
     // that instantiation; it stays on the grouped path)
-#define GRAM_WIDE_CASE(c, cy) if (C == c && CY == cy) return run_gram_wide<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+    // ... large sets on the byte-limb kernel on the i8 matrix pipe (k_gram_i8: sums and the diagonal exact, off-diagonal products
+    // to ~1e-10 of sqrt(G_aa G_bb)); small ones, and all with ABC_GRAM_FP64 (A/B runs, tests), on the fp64 matrix pipe
+    static const bool gram_fp64 = abc_diag_env("ABC_GRAM_FP64") != nullptr;
+    // (LDS-DMA staging: 16-byte aligned columns, an even row count; from 200000 rows: the values are rounded to a 32-bit grid of
+    // 10 .. 19 sigma, noise of 3e-9 sigma per value that averages out with the square root of the rows -- 1e-10 of sqrt(G_aa G_bb) at
+    // 35000 rows per partition, which the 32nd loading of a 128-metric model amplifies to 2e-7; 4e-8 at 1e6 rows)
+    const bool i8_ok = !gram_fp64 && n >= 200000 && dma_ok;
+#define GRAM_WIDE_CASE(c, cy) if (C == c && CY == cy) return i8_ok ? run_gram_i8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats) \
+                                                                    : run_gram_wide<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_WIDE_CASE(8, 0); GRAM_WIDE_CASE(8, 1); GRAM_WIDE_CASE(8, 2);
     GRAM_WIDE_CASE(9, 0); GRAM_WIDE_CASE(9, 1); GRAM_WIDE_CASE(9, 2); GRAM_WIDE_CASE(10, 0); GRAM_WIDE_CASE(10, 1); GRAM_WIDE_CASE(10, 2);
 #undef GRAM_WIDE_CASE

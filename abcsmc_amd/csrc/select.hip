@@ -553,14 +553,25 @@ __global__ __launch_bounds__(256) void k_sort_hist(const unsigned long long* __r
 __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned long long* __restrict__ key,
                                                       const unsigned long long* __restrict__ idx, size_t n,
                                                       int shift, const unsigned int* __restrict__ bh, int nb,
+                                                      const unsigned int* __restrict__ dtot,
                                                       unsigned long long* __restrict__ okey,
                                                       unsigned long long* __restrict__ oidx) {
     __shared__ unsigned int whist[4][256];
     __shared__ volatile unsigned int woff[4][256];
+    __shared__ unsigned int dsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) whist[w][t] = 0;
+    // keys with smaller digits (all work-groups): exclusive scan of the 256 digit totals, one per thread
+    const unsigned int mytot = dtot[t];
+    unsigned int dinc = mytot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int a = __shfl_up(dinc, o, 64); if (lane >= o) dinc += a; }
+    if (lane == 63) dsum[wave] = dinc;
     __syncthreads();
+    unsigned int dbase = dinc - mytot;
+#pragma unroll
+    for (int w = 0; w < 4; w++) if (w < wave) dbase += dsum[w];
     const size_t seg = (size_t)blockIdx.x * ST_CHUNK + (size_t)wave * (ST_CHUNK / 4);
     unsigned long long k[ST_ITEMS];
 #pragma unroll
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned long long* 
     }
     __syncthreads();
     {
-        unsigned int run = bh[(size_t)t * nb + blockIdx.x];   // scanned: global base of (digit t, this block)
+        unsigned int run = dbase + bh[(size_t)t * nb + blockIdx.x];   // keys of smaller digits + digit t's keys in earlier work-groups
 #pragma unroll
         for (int w = 0; w < 4; w++) { woff[w][t] = run; run += whist[w][t]; }
     }
@@ -600,42 +611,28 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned long long* 
     }
 }
 
-// exclusive scan of the digit-major [256][nb] block histogram, one work-group of 1024 threads:
-// 4 threads per digit, each owning a quarter of the blocks
-__global__ __launch_bounds__(1024) void k_sort_scan(unsigned int* __restrict__ bh, int nb) {
-    __shared__ unsigned int part[4][256];
-    __shared__ unsigned int tot[256];
-    const int d = threadIdx.x & 255, p = threadIdx.x >> 8;
-    const int b0 = (int)((long long)nb * p / 4), b1 = (int)((long long)nb * (p + 1) / 4);
-    unsigned int s = 0;
-#pragma unroll 4
-    for (int b = b0; b < b1; b++) s += bh[(size_t)d * nb + b];
-    part[p][d] = s;
+// exclusive scan of the digit-major [256][nb] block histogram in two levels: ONE WORK-GROUP PER DIGIT scans its row of nb block
+// counts (its own prefix only) and leaves the digit's total in dtot[d]; k_sort_scatter adds the digits in front of its own -- an
+// exclusive scan of 256 totals in its prologue.  (Rounds 1-3: one work-group of 1024 threads for the whole table, four threads
+// per digit each walking a quarter of the row: 178 us per pass at 1e6 keys, eight passes per sort.)
+__global__ __launch_bounds__(256) void k_sort_scan(unsigned int* __restrict__ bh, int nb, unsigned int* __restrict__ dtot) {
+    __shared__ unsigned int wsum[4];
+    const int d = blockIdx.x, t = threadIdx.x;
+    unsigned int* row = bh + (size_t)d * nb;
+    const int per = (nb + 255) / 256, i0 = t * per;
+    unsigned int loc = 0;
+    for (int c = 0; c < per; c++) if (i0 + c < nb) loc += row[i0 + c];
+    unsigned int inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int a = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += a; }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
     __syncthreads();
-    if (threadIdx.x < 64) {       // exclusive scan of the 256 digit totals: 4 per lane + wave scan
-        const int lane = threadIdx.x;
-        unsigned int v[4], sum = 0;
+    unsigned int run = inc - loc;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int dd = 4 * lane + q;
-            v[q] = part[0][dd] + part[1][dd] + part[2][dd] + part[3][dd];
-            sum += v[q];
-        }
-        unsigned int inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned int a = __shfl_up(inc, o, 64); if (lane >= o) inc += a; }
-        unsigned int run = inc - sum;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { tot[4 * lane + q] = run; run += v[q]; }
-    }
-    __syncthreads();
-    unsigned int run = tot[d];
-    for (int q = 0; q < p; q++) run += part[q][d];
-    for (int b = b0; b < b1; b++) {
-        const unsigned int v = bh[(size_t)d * nb + b];
-        bh[(size_t)d * nb + b] = run;
-        run += v;
-    }
+    for (int w = 0; w < 4; w++) if (w < (t >> 6)) run += wsum[w];
+    for (int c = 0; c < per; c++)
+        if (i0 + c < nb) { const unsigned int v = row[i0 + c]; row[i0 + c] = run; run += v; }
+    if (t == 255) dtot[d] = run;
 }
 
 // ---- small sets: LDS chunk sort + rank merge (2 launches instead of 24) -----------------------------------------
@@ -748,14 +745,15 @@ int sort_pairs_u64(abc_ctx* ctx, unsigned long long* key0, unsigned long long* i
         return ABC_OK;
     }
     const int nb = (int)((n + ST_CHUNK - 1) / ST_CHUNK);
-    unsigned int* bh = (unsigned int*)abc_ws_alloc(ctx, (size_t)256 * nb * sizeof(unsigned int));
+    unsigned int* bh = (unsigned int*)abc_ws_alloc(ctx, ((size_t)256 * nb + 256) * sizeof(unsigned int));
     if (!bh) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sort: workspace exhausted");
+    unsigned int* dtot = bh + (size_t)256 * nb;
     unsigned long long *ka = key0, *ia = idx0, *kb = key1, *ib = idx1;
     for (int pass = byte_lo; pass < byte_hi; pass++) {   // an even number of passes ends in (key0, idx0)
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(256), 0, ctx->stream, ka, n, shift, bh, nb);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ctx->stream, bh, nb);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, ctx->stream, ka, ia, n, shift, bh, nb, kb, ib);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, ctx->stream, bh, nb, dtot);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(256), 0, ctx->stream, ka, ia, n, shift, bh, nb, (const unsigned int*)dtot, kb, ib);
         unsigned long long* tk = ka; ka = kb; kb = tk;
         unsigned long long* ti = ia; ia = ib; ib = ti;
     }

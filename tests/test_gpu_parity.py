@@ -1491,6 +1491,77 @@ def test_wilcoxon_rule_reduces_somewhere(oracle):
     assert hit >= 1
 
 
+def _stats_record(gpu_ctx, X, Y, ntrain):
+    """the sufficient-statistics record of [X | Y] through the staged entry points -> (shift, sums[2], G[2]) as numpy"""
+    import torch
+    from abcsmc_amd import device, sharded
+    dev = "cuda:0"
+    be = sharded.HipBackend(dev, gpu_ctx)
+    N, M = X.shape
+    P = Y.shape[1]
+    dX, dY = device.colmajor(X, dev), device.colmajor(Y, dev)
+    stats = be.zeros(be.stats_len(M, P))
+    be.stats_shift(dX, dY, stats)
+    be.stats_accumulate(dX, dY, 0, ntrain, stats)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    C16 = 16 * ((M + P + 15) // 16)
+    shift = st[2:2 + C16]
+    sums = [st[2 + C16:2 + 2 * C16], st[2 + 2 * C16:2 + 3 * C16]]
+    G = [st[2 + 3 * C16:2 + 3 * C16 + C16 * C16].reshape(C16, C16).T, st[2 + 3 * C16 + C16 * C16:2 + 3 * C16 + 2 * C16 * C16].reshape(C16, C16).T]
+    return shift, sums, G
+
+
+@pytest.mark.parametrize("N,M,P,kind", [(200_000, 128, 16, "plain"), (400_000, 120, 8, "plain"), (231_073, 140, 20, "plain"),
+                                        (240_000, 128, 16, "spikes"), (240_000, 128, 16, "heavy"), (220_000, 113, 16, "constant")])
+def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
+    """k_gram_i8 (round 4): the Gram of 113..160 columns (from 200000 rows) from four signed bytes per value on v_mfma_i32_32x32x32_i8.
+    Against numpy on the same shifted data: column sums and the diagonal (fp64 on the vector pipe) to rounding, the off-diagonal
+    products -- exact integer arithmetic on values rounded to a 32-bit grid of 4 x a robust sample range, byte pairs below 2^-32 of the
+    top pair dropped -- to 5e-10 of sqrt(G_aa G_bb) (it falls with the square root of the rows); with values far outside the sampled
+    range (their rows go through k_gram_far in fp64), heavy tails, a column of tiny variance and a constant one; an odd row count
+    (no 16-byte row pairs for the LDS-DMA staging) stays on the fp64 matrix pipe"""
+    wl, X, Y, obs = _wl(M, P, N, 21)
+    rng = np.random.default_rng(3)
+    if kind == "spikes":                      # a handful of values hundreds of times beyond anything the 4096 sampled rows hold
+        for r, c, f in ((5, 3, 900.0), (N // 2 + 1, 77, -2000.0), (N - 2, M - 1, 1e6), (12345, 0, 50.0), (N // 2, 100, 1e4)):
+            X[r, c] = X[:, c].mean() + f * X[:, c].std()
+        Y[777, 2] = Y[:, 2].mean() - 300.0 * Y[:, 2].std()
+    elif kind == "heavy":                     # Cauchy-tailed metrics: hundreds of far rows
+        X[:, :8] = X[:, :8].mean(axis=0) + X[:, :8].std(axis=0) * rng.standard_cauchy(size=(N, 8))
+    elif kind == "constant":                  # constant wherever the sample looks (every 19th row of the 4096 samples' stride), not elsewhere
+        X[:, 5] = 3.25
+        X[1::7, 5] = 3.25 + rng.normal(size=len(X[1::7, 5])) * 1e-3
+        X[:, 9] = -1.0                       # ... and one that is constant throughout
+    X, Y = np.asfortranarray(X), np.asfortranarray(Y)
+    ntrain = N // 2
+    shift, sums, G = _stats_record(gpu_ctx, X, Y, ntrain)
+    Z = np.hstack([X, Y])
+    C = M + P
+    worst, where = 0.0, ""
+    for part, (a, b) in enumerate(((0, ntrain), (ntrain, N))):
+        V = Z[a:b] - shift[:C]
+        ref = V.T @ V
+        sref = V.sum(axis=0)
+        scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300
+        assert np.allclose(sums[part][:C], sref, rtol=1e-10, atol=1e-13 * np.abs(V).sum(axis=0).max())
+        assert np.allclose(np.diag(G[part])[:M], np.diag(ref)[:M], rtol=1e-12)                       # X'X diagonal: fp64
+        assert np.allclose(np.diag(G[part])[M:C], np.diag(ref)[M:C], rtol=1e-12)                     # Y'Y diagonal
+        blockXX = np.abs(G[part][:M, :M] - ref[:M, :M]) / scale[:M, :M]
+        blockXY = np.abs(G[part][:M, M:C] - ref[:M, M:C]) / scale[:M, M:C]
+        if max(blockXX.max(), blockXY.max()) > worst:
+            worst = max(blockXX.max(), blockXY.max())
+            full = np.abs(G[part][:M, :C] - ref[:M, :C]) / scale[:M, :C]
+            wa, wb = np.unravel_index(np.argmax(full), full.shape)
+            where = "partition %d, columns (%d, %d): %.17g against %.17g" % (part, wa, wb, G[part][wa, wb], ref[wa, wb])
+            if kind == "spikes":
+                rows = [r for r in (5, 12345, 777, N // 2 + 1, N - 2, N // 2) if a <= r < b]
+                where += "; diff %.6g, products of the spike rows %s" % (G[part][wa, wb] - ref[wa, wb], [float(V[r - a, wa] * V[r - a, wb]) for r in rows])
+        assert np.allclose(G[part][:M, :C], G[part][:C, :M].T)                                       # symmetric where both halves exist
+    print("wide Gram %s N=%d: worst off-diagonal error %.2e of sqrt(G_aa G_bb) (%s)" % (kind, N, worst, where))
+    assert worst <= 5e-10, worst
+
+
 def _wilcoxon_per_response(gpu_ctx, oracle, X, Y, obs, A, f=0.5):
     """The Wilcoxon reduction alone, through the staged entry points: statistics -> model under argmin PRESS -> abc_pls_wilcoxon_dev;
     the per-response component counts it leaves in the model record against the oracle's reduction RUN ON THE DEVICE'S OWN MODEL
