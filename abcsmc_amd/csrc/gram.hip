@@ -694,8 +694,8 @@ __global__ __launch_bounds__(512) void k_gram_wide(const double* __restrict__ X,
 // (q = sum_b l_b 2^(8b), -128 <= l_b <= 127), and the cross products run as exact integer arithmetic on
 // v_mfma_i32_32x32x32_i8 (the 16-bit pipe's rate at twice the depth): G_ab 2^(62 - e_a - e_b) = sum_rows q_a q_b =
 // sum_{b,b'} 2^(8(b+b')) sum_rows l_b l'_b', of which the thirteen byte pairs with b + b' >= 2 are kept -- one i32 accumulator per
-// order b + b' (exact: <= 2^21 per 32-row step, flushed to fp64 every 16384 rows), 13 MFMAs per 32 x 32 tile and step, 14 tiles at
-// 144 columns: 46 MFMA-cycles per row against 704 on the fp64 pipe.  The dropped pairs (b + b' <= 1) are products of the low bytes:
+// order b + b' (exact: <= 2^21 per 32-row step, flushed to fp64 every 512 steps), 13 MFMAs per 32 x 32 tile and step, 14 tiles at
+// 144 columns: 182 matrix-pipe cycles per row (14 x 13 MFMAs of 32 cycles per 32 rows) against 704 on the fp64 pipe.  The dropped pairs (b + b' <= 1) are products of the low bytes:
 // zero-mean noise below 1e-11 of sigma_a sigma_b rows off the diagonal (with b + b' = 2 dropped as well it was 3e-9, and the 32nd
 // loading of a 128-metric model moved by 4e-6) -- and a BIAS on the diagonal (l l' >= 0 there), so column sums and sums of squares are taken in fp64 on the
 // vector pipe while the tile is staged (exact as before: means to 1e-12, deviations to 1e-11) and the diagonal of the result is

@@ -55,7 +55,7 @@ def pmc_traffic(kernel_prefix, config, world):
     written by scripts/summarize_profiles.py); only for the exact single-GPU configuration profiled, else None"""
     if world != 1:
         return None
-    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r04_pmc_hbm_traffic.json", "history/r03_pmc_hbm_traffic.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(prof):
             continue
@@ -642,6 +642,19 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
     genor = device.Generation(N, M, P, K, 0, 0, 0.5, A, rule=other, multivariate=True, device=dev, ctx=ctx)
     out["ranking_pls_" + oname + "_ms"] = round(timed(lambda: genor.run(dX, dY, dobs, dpri, rngo)), 5)
     del geno, genor
+    # (the Wilcoxon rule's work: one signed-rank test per (response j, candidate a' < a*_j) over the n - n_train validation rows;
+    # the PRESS optima a*_j are read from a model record fitted under argmin PRESS through the staged entry points)
+    bew = sharded.HipBackend(dev, ctx)
+    wstats, wmodel = bew.zeros(bew.stats_len(M, P)), bew.zeros(bew.model_len(M, P, A) + 8)
+    bew.stats_shift(dX, dY, wstats)
+    bew.stats_accumulate(dX, dY, 0, int(round(N * 0.5)), wstats)
+    bew.pls_model(wstats, dobs, M, P, A, _lib.RULE_MIN_PRESS, wmodel)
+    torch.cuda.synchronize()
+    Lm = bew.model_len(M, P, A)
+    per = wmodel[Lm - P:Lm].cpu().numpy().astype(int)
+    out["wilcoxon_tests"] = int(np.maximum(per - 1, 0).sum())
+    out["wilcoxon_validation_rows"] = N - int(round(N * 0.5))
+    del bew, wstats, wmodel
     # (3) particle_ranking_simple (AbcUtil.cpp:408-421), device resident, through the staged entry points: moments of the
     # metrics, z-scored distance to the observation, the K smallest
     be = sharded.HipBackend(dev, ctx)

@@ -59,8 +59,8 @@ res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE pas
                 "--warmup 1 --no-cpu-baseline`; per-dispatch averages in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                 "(gfx950: FETCH_SIZE counts 64 B per 128-B request).", "configs": {}}
 rows = []
-for cfg in (2, 3):
-    if not os.path.isdir(G + '%s_fetch_c%d' % (pp, cfg)):
+for cfg in (2, 3, 4, 5):
+    if not os.path.isdir(G + '%s_fetch_c%d' % (pp, cfg)) or not os.path.isdir(G + '%s_write_c%d' % (pp, cfg)):
         continue
     fe, wr = pmc(G + '%s_fetch_c%d' % (pp, cfg), 'FETCH_SIZE'), pmc(G + '%s_write_c%d' % (pp, cfg), 'WRITE_SIZE')
     ent = {}
@@ -159,6 +159,95 @@ for c in cfgs:
         ent["set0_roofline_streaming"] = {"algorithmic_bytes_per_step": alg(0), "ms": round(s0, 5),
                                           "achieved_GBs": round(alg(0) / s0 / 1e6, 1), "frac": round(alg(0) / s0 / 1e6 / HBM_PEAK, 4)}
     roof["config%d" % c] = ent
+# ---- the matrix-pipe kernels of the ranking: busy cycles of the pipe against the kernel's cycles -------
+MFMA_F64_PEAK_TF, MFMA_I8_PEAK_TOPS = 78.6, 5000.0       # MI355X_MICROARCH.md: fp64 matrix = fp64 vector peak; dense i8 = fp8 peak
+
+
+def mfma_entry(cfg, d, st, kernel, work, peak, unit, note):
+    """one kernel of one configuration: rocprofv3 duration (stats pass), the PMC pass's busy cycles, the ISSUED matrix work"""
+    names = [k for k in st if k.startswith(kernel)]
+    if not names or not os.path.isdir(d):
+        return None
+    name = max(names, key=lambda k: st[k][1])
+    calls, ns = st[name]
+    cn = pmc(d, kernel=kernel)
+    cyc = cn.get('GRBM_GUI_ACTIVE', 0) / 8
+    rate = work / (ns * 1e-9) / 1e12
+    return {"kernel": name, "kernel_avg_ms": round(ns / 1e6, 4), "issued_matrix_work": work, "achieved": round(rate, 1), "peak": peak, "unit": unit,
+            "frac": round(rate / peak, 4), "pmc": {k: round(v) for k, v in cn.items()}, "cycles_per_xcd_in_the_pmc_pass": round(cyc),
+            "mfma_busy_frac": round(cn.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / NSIMD / cyc, 3) if cyc else None,
+            "valu_active_frac": round(4 * cn.get('SQ_ACTIVE_INST_VALU', 0) / NSIMD / cyc, 3) if cyc else None, "note": note}
+
+
+for c, sfx in ((4, ''), (5, ''), (5, 'f')):
+    if c not in cfgs or not os.path.isdir(G + '%s_c%d%s' % (sp, c, sfx)):
+        continue
+    b = bench(c)
+    cfgd = b["config"]
+    n, M, P, A = cfgd["particles_per_gpu"], cfgd["metrics"], cfgd["params"], cfgd["pls_components"]
+    stc = {short(r['Name']): (int(r['Calls']), float(r['AverageNs'])) for r in csv.DictReader(open(find(G + '%s_c%d%s' % (sp, c, sfx), 'kernel_stats.csv')))}
+    if sfx:
+        shutil.copy(find(G + '%s_c%d%s' % (sp, c, sfx), 'kernel_stats.csv'), 'profiles/%s_kernel_stats_config%d_fp64gram.csv' % (tag, c))
+    d = G + '%s_mfma_c%d%s' % (pp, c, sfx)
+    C16 = 16 * ((M + P + 15) // 16)
+    nb = C16 // 16
+    blocks = nb * (nb + 1) // 2 - (P // 16) * (P // 16 + 1) // 2 + P // 16        # upper-triangular 16 x 16 blocks, Y'Y only its diagonal blocks
+    ents = {}
+    e = mfma_entry(c, d, stc, 'k_gram_dma8', 2.0 * n * blocks * 256, MFMA_F64_PEAK_TF, "TFLOP/s",
+                   "v_mfma_f64_16x16x4_f64 on the upper-triangular 16 x 16 blocks of [X|Y]'[X|Y]: 2 n 256 flops per block")
+    if e: ents['k_gram_dma8'] = e
+    e = mfma_entry(c, d, stc, 'k_gram_wide', 2.0 * n * blocks * 256, MFMA_F64_PEAK_TF, "TFLOP/s", "as k_gram_dma8 (ABC_GRAM_FP64 run)")
+    if e: ents['k_gram_wide'] = e
+    C32 = 32 * ((M + P + 31) // 32)
+    t32 = (C32 // 32) * (C32 // 32 + 1) // 2
+    e = mfma_entry(c, d, stc, 'k_gram_i8', 2.0 * n * t32 * 1024 * 13, MFMA_I8_PEAK_TOPS, "TOP/s",
+                   "v_mfma_i32_32x32x32_i8: 13 byte-limb products (b + b' >= 2 of four balanced bytes per operand) on the upper-triangular 32 x 32 "
+                   "tiles; the limb conversion (fp64 -> fixed point -> balanced bytes, per element) runs on the vector pipe beside it")
+    if e: ents['k_gram_i8'] = e
+    e = mfma_entry(c, d, stc, 'k_project_mfma', 2.0 * n * M * 16 * ((A + 15) // 16), MFMA_F64_PEAK_TF, "TFLOP/s",
+                   "scores of all particles on v_mfma_f64_16x16x4_f64 (chained accumulator = the oracle's fma order)")
+    if e: ents['k_project_mfma'] = e
+    if ents:
+        roof.setdefault("config%d" % c, {})["roofline_mfma" + ("_fp64gram" if sfx else "")] = ents
+
+# ---- the Wilcoxon rule's kernels (VERDICT round 3, item 2c): algorithmic bytes and achieved GB/s --------------------------------
+for c in cfgs:
+    dw = G + '%s_w%d' % (sp, c)
+    if not os.path.isdir(dw):
+        continue
+    shutil.copy(find(dw, 'kernel_stats.csv'), 'profiles/%s_kernel_stats_config%d_wilcoxon.csv' % (tag, c))
+    b = bench(c)
+    ex, cfgd = b.get("extra", {}), b["config"]
+    if "wilcoxon_tests" not in ex:
+        continue
+    T, nv, M, P, A = ex["wilcoxon_tests"], ex["wilcoxon_validation_rows"], cfgd["metrics"], cfgd["params"], cfgd["pls_components"]
+    stw = {short(r['Name']): (int(r['Calls']), float(r['AverageNs'])) for r in csv.DictReader(open(find(dw, 'kernel_stats.csv')))}
+    gens = max(v[0] for k, v in stw.items() if k.startswith('k_wx_decide'))
+    alg = {'k_wx_scores': 8.0 * nv * (M + A), 'k_wx_bin<.., false>': 8.0 * nv * (A + P), 'k_wx_bin<.., true>': 8.0 * nv * (A + P) + 8.0 * T * nv,
+           'k_wx_ranks': 8.0 * T * nv}
+    rows, tot_ns = [], 0.0
+    for k, (calls, ns) in sorted(stw.items()):
+        if not k.startswith('k_wx_'):
+            continue
+        per_gen = calls / gens
+        tot_ns += ns * per_gen
+        key = k.split('<')[0]
+        if key == 'k_wx_bin':
+            key = 'k_wx_bin<.., true>' if k.rstrip('>').endswith('true') else 'k_wx_bin<.., false>'
+        a = alg.get(key)
+        rows.append({"kernel": k, "launches_per_generation": per_gen, "avg_us": round(ns / 1e3, 2), "algorithmic_bytes": a,
+                     "achieved_GBs": round(a / ns, 1) if a else None, "frac_of_hbm_peak": round(a / ns / HBM_PEAK, 4) if a else None})
+    total_alg = 8.0 * nv * (M + A) + 2 * 8.0 * nv * (A + P) + 16.0 * T * nv
+    roof.setdefault("config%d" % c, {})["wilcoxon_rule"] = {
+        "tests": T, "validation_rows": nv, "kernels": rows, "kernel_us_per_generation": round(tot_ns / 1e3, 1),
+        "algorithmic_bytes_per_generation": total_alg, "achieved_GBs": round(total_alg / tot_ns, 1), "frac_of_hbm_peak": round(total_alg / tot_ns / HBM_PEAK, 4),
+        "bench": {k: v for k, v in ex.items() if 'wilcoxon' in k or k == 'ranking_pls_ms'},
+        "note": "algorithmic bytes: the validation rows' metrics read once for the scores (8 nv (M + A) with the scores' write), scores and responses "
+                "read by the counting and by the placing sweep (2 x 8 nv (A + P)), every test's key written once and read once (16 T nv)"}
+    with open('profiles/%s_wilcoxon_kernels_config%d.csv' % (tag, c), 'w') as f:
+        f.write("kernel,launches_per_generation,avg_us,algorithmic_bytes,achieved_GBs,frac_of_hbm_peak\n")
+        for r in rows:
+            f.write('"%s",%g,%.2f,%s,%s,%s\n' % (r["kernel"], r["launches_per_generation"], r["avg_us"], r["algorithmic_bytes"], r["achieved_GBs"], r["frac_of_hbm_peak"]))
 json.dump(roof, open('profiles/%s_roofline.json' % tag, 'w'), indent=1)
 for c in cfgs:
     e = roof["config%d" % c]

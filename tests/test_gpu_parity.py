@@ -1121,7 +1121,7 @@ def test_perturb_giveups_are_counted(gpu_ctx):
     assert gpu_ctx.perturb_giveups(reset=True) == n and gpu_ctx.perturb_giveups() == 0
 
 
-def test_generation_reports_giveups_as_a_warning_status(gpu_ctx):
+def test_generation_reports_giveups_through_a_count_not_a_status(gpu_ctx):
     """abc_generation_dev with a prior no proposal can land in: the call completes -- every proposal is its (valid) parent --
     and returns ABC_OK (the ABI has no positive status: `if (rc)` stays a valid failure test); abc_generation_giveups holds the
     count of THAT call, which the Python driver turns into a warning; the next, well-posed
