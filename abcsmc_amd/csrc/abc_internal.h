@@ -233,6 +233,8 @@ inline size_t abc_kde_slices(size_t kn, size_t Kp, int PP) {
 int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx,
                       uint64_t* osrc = nullptr);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
+bool launch_select_bounded(abc_ctx*, const double* dist, size_t n, size_t K, const long long* state, uint64_t* pos_out, double* dist_out,
+                           int* fail_dev, int* rc);
 // distributed radix select stages (state: 8 x int64, hist: 2048 x int32, all-reduced by the caller between hist and pick)
 int launch_select_begin(abc_ctx*, uint64_t K, long long* state, int* hist);
 int launch_select_hist(abc_ctx*, const double* dist, size_t n, const long long* state, int pass, int* hist);

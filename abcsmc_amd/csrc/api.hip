@@ -51,7 +51,7 @@ size_t abc_ws_need(size_t N, size_t M, size_t P, size_t A, size_t K, size_t Kp, 
     b += (M * P + 3 * P * P + 2 * P + 8 * M + 2 * M * A + A + 64 + 2048) * 8 + 3 * 96 * 96 * 8 * 2;   // PLS work arrays beyond the LDS; group-pair records
     b += N * 8;                                                   // distances
     b += 4 * K * 8 + (N / 2048 + 2) * 8 + 2048 * 4 + 256 * (K / 2048 + 2) * 4 + 4096;   // select + sort
-    b += 2 * (K + 1024) * 8 + 34 * 4096 * 4 + 4096;               // ... or the bin selection's pair buffer, counts and cursors
+    b += 2 * (K + 1024) * 8 + 34 * 16384 * 4 + 4096;              // ... or the bin selection's pair buffer, counts and cursors
     b += 3 * N * 8 + 256 * (N / 2048 + 2) * 4;                    // full-sort case K == N
     const size_t PPw = P <= 64 ? 64 : (P + 63) / 64 * 64;         // padded row width of the row-major copies
     b += K * P * 8 + K * PPw * 8;                                 // theta, and its row-major copy for the perturb gather

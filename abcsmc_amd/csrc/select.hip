@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) void k_sel_hist_fused(const double* __restrict
 // The result is the same array the radix select + stable sort produce (ascending (key, index) is a total order).
 // `fail` (any bin above BS_CAP keys, or fewer than K keys at or below hi): k_bs_sort writes a harmless result (indices
 // idx_base .. idx_base + K - 1) and the host, when it next synchronises, repeats the selection with the radix path.
-constexpr int BS_NB = 4096;          // bins
+constexpr int BS_NB = 4096;          // bins up to K = 2^18 ...
+constexpr int BS_NB_BIG = 16384;     // ... and beyond, up to 2^20 (round 4: K = 1e6 of configs[3] took the radix select and eight LSD sort
+                                     // passes, 2.7 ms; the same average bin filling -- 64 of the 1024 keys a bin may hold -- here)
 constexpr int BS_S = 4096;           // sampled keys
 constexpr int BS_CAP = 1024;         // keys one work-group sorts
 constexpr int BS_CSTRIDE = 32;       // the scatter's per-bin cursors sit 128 bytes apart: neighbouring (equally busy) bins on the
@@ -201,22 +203,25 @@ struct BinSel {
     int pad_;
 };
 
+// hi_in (optional): the caller knows an upper bound of the K-th key (state of the distributed selection: keys < hi_in->prefix); the
+// sample then only yields the smallest key, and keys above the bound (the padding of the candidate lists) are left out of it
 __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ dist, size_t n, unsigned long long K,
-                                                    BinSel* __restrict__ bs, unsigned int* __restrict__ hist /* BS_NB + 1 */,
-                                                    int* __restrict__ fail_flag) {
+                                                    BinSel* __restrict__ bs, unsigned int* __restrict__ hist /* nbins + 1 */,
+                                                    int* __restrict__ fail_flag, int nbins, const SelState* __restrict__ hi_in) {
     __shared__ unsigned long long sk[BS_S];
     __shared__ unsigned int h[256];
     __shared__ unsigned long long red[16];
     __shared__ unsigned long long s_prefix;
     __shared__ unsigned int s_rank;
     const int t = threadIdx.x;
-    for (int i = t; i < BS_NB + 1; i += 1024) hist[i] = 0;
+    for (int i = t; i < nbins + 1; i += 1024) hist[i] = 0;
     const size_t stride = n / BS_S;
     unsigned long long mn = ~0ull;
+    const unsigned long long bound = hi_in ? hi_in->prefix - 1ull : ~0ull;        // (prefix = bound + 1, or all ones)
     for (int i = t; i < BS_S; i += 1024) {
         const unsigned long long k = key_of(dist[(size_t)i * stride + stride / 2]);
         sk[i] = k;
-        mn = k < mn ? k : mn;
+        mn = (k < mn && k <= bound) ? k : mn;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const unsigned long long v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ d
     // LDS radix select of the sample's q-th key, most significant bits first.  hi only has to lie at or above it: three passes
     // decide its top 24 bits (sign, exponent, 12 mantissa bits), the rest is filled with ones
     unsigned long long mask = 0;
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < (hi_in ? 0 : 3); pass++) {
         const int shift = 56 - 8 * pass;
         if (t < 256) h[t] = 0;
         __syncthreads();
@@ -258,10 +263,11 @@ __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ d
         __syncthreads();
     }
     if (t == 0) {
-        const unsigned long long lo = mn, hi = s_prefix | ~mask;
+        const unsigned long long hi = hi_in ? bound : (s_prefix | ~mask);
+        const unsigned long long lo = mn < hi ? mn : hi;               // (no sampled key at or below a given bound: one bin takes all)
         const unsigned long long span = hi - lo;
         int shift = 0;
-        while (shift < 63 && (span >> shift) >= (unsigned long long)(BS_NB - 1)) shift++;
+        while (shift < 63 && (span >> shift) >= (unsigned long long)(nbins - 1)) shift++;
         bs->lo = lo; bs->hi = hi; bs->shift = shift; bs->bstar = 0; bs->need = 0; bs->fail = 0; bs->pad_ = 0;
         *fail_flag = 0;
     }
@@ -272,10 +278,10 @@ __device__ __forceinline__ int bs_bin(unsigned long long k, unsigned long long l
 }
 
 __global__ __launch_bounds__(256) void k_bs_hist(const double* __restrict__ dist, size_t n, const BinSel* __restrict__ bs,
-                                                 unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor) {
-    __shared__ unsigned int lh[BS_NB];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)BS_NB * BS_CSTRIDE; i += (size_t)gridDim.x * 256) cursor[i] = 0;
-    for (int i = threadIdx.x; i < BS_NB; i += 256) lh[i] = 0;
+                                                 unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor, int nbins) {
+    extern __shared__ unsigned int lh[];              // nbins
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)nbins * BS_CSTRIDE; i += (size_t)gridDim.x * 256) cursor[i] = 0;
+    for (int i = threadIdx.x; i < nbins; i += 256) lh[i] = 0;
     __syncthreads();
     const unsigned long long lo = bs->lo, hi = bs->hi;
     const int shift = bs->shift;
@@ -292,20 +298,20 @@ __global__ __launch_bounds__(256) void k_bs_hist(const double* __restrict__ dist
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < BS_NB; i += 256) {
+    for (int i = threadIdx.x; i < nbins; i += 256) {
         const unsigned int c = lh[i];
         if (c) atomicAdd(&hist[i], c);
     }
 }
 
-// hist[b] -> exclusive offsets in place (hist[BS_NB] = total); b*, need, fail
+// hist[b] -> exclusive offsets in place (hist[nbins] = total); b*, need, fail
+template <int BPT>                           // bins per thread: nbins / 1024
 __global__ __launch_bounds__(1024) void k_bs_scan(BinSel* __restrict__ bs, unsigned int* __restrict__ hist, unsigned long long K,
                                                   int* __restrict__ fail_flag) {
     __shared__ unsigned int wsum[16];
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_fail = 0;
-    constexpr int BPT = BS_NB / 1024;        // bins per thread
     unsigned int c[BPT], sum = 0;
 #pragma unroll
     for (int j = 0; j < BPT; j++) { c[j] = hist[BPT * t + j]; sum += c[j]; }
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_bs_scan(BinSel* __restrict__ bs, unsig
         if ((unsigned long long)off < K && c[j] > (unsigned int)BS_CAP) s_fail = 1;
         run += c[j];
     }
-    if (t == 0) hist[BS_NB] = tot;
+    if (t == 0) hist[BPT * 1024] = tot;
     __syncthreads();
     if (t == 0) {
         const int fail = (s_fail || (unsigned long long)tot < K) ? 1 : 0;
@@ -974,23 +980,32 @@ int launch_select_candidates(abc_ctx* ctx, const double* dist, size_t n, const l
 }
 
 // bin path: the caller (defer_check) or this function reads ctx->sel_fail_dev afterwards; see abc_select_check
-static int select_by_bins(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx, double* dist_out) {
-    if (!ctx->sel_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->sel_fail_dev, sizeof(int)));
+static int select_by_bins(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx, double* dist_out,
+                          const long long* hi_state = nullptr, int* fail_dev = nullptr) {
+    if (!fail_dev) {
+        if (!ctx->sel_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->sel_fail_dev, sizeof(int)));
+        fail_dev = ctx->sel_fail_dev;
+    }
+    const int nbins = K <= ((size_t)1 << 18) ? BS_NB : BS_NB_BIG;
     BinSel* bs = (BinSel*)abc_ws_alloc(ctx, sizeof(BinSel));
-    unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, (BS_NB + 1) * sizeof(unsigned int));
-    unsigned int* cursor = (unsigned int*)abc_ws_alloc(ctx, (size_t)BS_NB * BS_CSTRIDE * sizeof(unsigned int));
+    unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, ((size_t)nbins + 1) * sizeof(unsigned int));
+    unsigned int* cursor = (unsigned int*)abc_ws_alloc(ctx, (size_t)nbins * BS_CSTRIDE * sizeof(unsigned int));
     unsigned long long* tkey = (unsigned long long*)abc_ws_alloc(ctx, (K + BS_CAP) * 8);
     unsigned long long* tidx = (unsigned long long*)abc_ws_alloc(ctx, (K + BS_CAP) * 8);
     if (!bs || !hist || !cursor || !tkey || !tidx) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
     StageTimer tm(ctx, ST_SELECT);
-    hipLaunchKernelGGL(k_bs_sample, dim3(1), dim3(1024), 0, ctx->stream, dist, n, (unsigned long long)K, bs, hist, ctx->sel_fail_dev);
+    hipLaunchKernelGGL(k_bs_sample, dim3(1), dim3(1024), 0, ctx->stream, dist, n, (unsigned long long)K, bs, hist, fail_dev, nbins,
+                       (const SelState*)hi_state);
     size_t hb = (n + 255) / 256;
     if (hb > 512) hb = 512;
-    hipLaunchKernelGGL(k_bs_hist, dim3((unsigned)hb), dim3(256), 0, ctx->stream, dist, n, (const BinSel*)bs, hist, cursor);
-    hipLaunchKernelGGL(k_bs_scan, dim3(1), dim3(1024), 0, ctx->stream, bs, hist, (unsigned long long)K, ctx->sel_fail_dev);
+    const size_t hl = (size_t)nbins * sizeof(unsigned int);
+    if (hl > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_bs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+    hipLaunchKernelGGL(k_bs_hist, dim3((unsigned)hb), dim3(256), hl, ctx->stream, dist, n, (const BinSel*)bs, hist, cursor, nbins);
+    if (nbins == BS_NB) hipLaunchKernelGGL(k_bs_scan<BS_NB / 1024>, dim3(1), dim3(1024), 0, ctx->stream, bs, hist, (unsigned long long)K, fail_dev);
+    else hipLaunchKernelGGL(k_bs_scan<BS_NB_BIG / 1024>, dim3(1), dim3(1024), 0, ctx->stream, bs, hist, (unsigned long long)K, fail_dev);
     hipLaunchKernelGGL(k_bs_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dist, n, (const BinSel*)bs,
                        (const unsigned int*)hist, cursor, (unsigned long long)idx_base, tkey, tidx);
-    hipLaunchKernelGGL(k_bs_sort, dim3(BS_NB), dim3(256), 0, ctx->stream, (const BinSel*)bs, (const unsigned int*)hist,
+    hipLaunchKernelGGL(k_bs_sort, dim3((unsigned)nbins), dim3(256), 0, ctx->stream, (const BinSel*)bs, (const unsigned int*)hist,
                        (const unsigned long long*)tkey, (const unsigned long long*)tidx, (unsigned long long)K,
                        (unsigned long long)idx_base, (unsigned long long*)idx, dist_out);
     ABC_HIP(ctx, hipGetLastError());
@@ -1046,7 +1061,7 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
                            double* dist_out, bool defer_check) {
     if (K == 0) return ABC_OK;
     if (K > n) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: K = %zu > n = %zu", K, n);
-    const bool bins = !ctx->sel_force_radix && n >= 4 * (size_t)BS_S && 2 * K <= n && K <= ((size_t)1 << 18);
+    const bool bins = !ctx->sel_force_radix && n >= 4 * (size_t)BS_S && 2 * K <= n && K <= ((size_t)1 << 20);
     ctx->sel_bins_ran = bins;
     if (!bins) return select_by_radix(ctx, dist, n, K, idx_base, idx, dist_out);
     const size_t mark = ctx->ws_off;
@@ -1057,6 +1072,18 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
     if (!failed) return ABC_OK;
     ctx->ws_off = mark;
     return select_by_radix(ctx, dist, n, K, idx_base, idx, dist_out);
+}
+
+// the K smallest of n keys of which the caller knows a bound (state->prefix: keys below it are candidates, the others -- the
+// padding of the distributed selection's candidate lists -- are not looked at), as (position, distance) in ascending (distance,
+// position) order: what a stable sort of all n by distance would put first.  *fail_dev = 1 (and a harmless placeholder result) when
+// a bin outgrows a work-group or fewer than K keys lie below the bound: the caller falls back.  false: shape not taken.
+bool launch_select_bounded(abc_ctx* ctx, const double* dist, size_t n, size_t K, const long long* state, uint64_t* pos_out, double* dist_out,
+                           int* fail_dev, int* rc) {
+    *rc = ABC_OK;
+    if (ctx->sel_force_radix || n < 4 * (size_t)BS_S || K == 0 || K > n || K > ((size_t)1 << 20)) return false;
+    *rc = select_by_bins(ctx, dist, n, K, 0, pos_out, dist_out, state, fail_dev);
+    return true;
 }
 
 int abc_select_check_queue(abc_ctx* ctx, int* slot) {

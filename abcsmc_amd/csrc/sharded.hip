@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void k_ds_unpack(const char* __restrict__ all,
     cand_dist[e] = R.dist(all, q)[j];
     cand_pos[e] = e;
 }
+// the bin selection among the candidates gave up: the generation repeats with the radix protocol, as for a truncated list
+__global__ void k_ds_join_fail(const int* __restrict__ bin_fail, int* __restrict__ fail, int* __restrict__ fail_pin) {
+    if (threadIdx.x == 0 && *bin_fail) { *fail = 1; if (fail_pin) *fail_pin = 1; }
+}
 // the K winners in ascending (distance, global row) order = the first K of the sorted candidates: their rows and parameters
 __global__ __launch_bounds__(256) void k_ds_place(const char* __restrict__ all, CandRec R, const double* __restrict__ sdist,
                                                   const unsigned long long* __restrict__ spos, size_t K, const int* __restrict__ fail,
@@ -525,9 +529,29 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         hipLaunchKernelGGL(k_ds_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R, W,
                            (unsigned long long)K, cand_dist, (unsigned long long*)cand_pos, ds_fail, pfail_early);
         ABC_HIP(ctx, hipGetLastError());
-        ABC_TRY(launch_sort_pairs(ctx, cand_dist, cand_pos, tot));      // stable: equal distances stay in global row order
+        // the first K of the candidates in (distance, global row) order.  Large lists (round 4; K = 1e6 of configs[3]: 1.2e6
+        // candidates were an eight-pass LSD sort on every rank): the single-GPU bin selection with the bound every rank already has
+        // -- the padding lies above it --, whose give-up (a bin of massively tied distances) joins the lists' own: same fallback.
+        // Small ones: a stable sort by distance.
+        const double* sdist = cand_dist;
+        const uint64_t* spos = cand_pos;
+        {
+            uint64_t* bpos = (uint64_t*)abc_ws_alloc(ctx, K * 8);
+            double* bdist = (double*)abc_ws_alloc(ctx, K * 8);
+            int* bfail = (int*)abc_ws_alloc(ctx, sizeof(int));
+            if (!bpos || !bdist || !bfail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+            int rc = ABC_OK;
+            if (launch_select_bounded(ctx, cand_dist, tot, K, sel_state, bpos, bdist, bfail, &rc)) {
+                ABC_TRY(rc);
+                hipLaunchKernelGGL(k_ds_join_fail, dim3(1), dim3(64), 0, ctx->stream, (const int*)bfail, ds_fail, pfail_early);
+                sdist = bdist;
+                spos = bpos;
+            } else {
+                ABC_TRY(launch_sort_pairs(ctx, cand_dist, cand_pos, tot));      // stable: equal distances stay in global row order
+            }
+        }
         hipLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R,
-                           (const double*)cand_dist, (const unsigned long long*)cand_pos, K, (const int*)ds_fail,
+                           sdist, (const unsigned long long*)spos, K, (const int*)ds_fail,
                            (unsigned long long*)io->idx, io->dist, theta);
         ABC_HIP(ctx, hipGetLastError());
     } else {

@@ -27,9 +27,7 @@
 // reduction on the SORTED path of rounds 1-3 (one stable LSD radix sort of all (key, segment) pairs), which also takes the
 // shapes the binned path is not built for (more than 32 components, more than ~7e6 validation rows).
 #include "abc_internal.h"
-#ifdef WX_STAMPS
 #include <vector>
-#endif
 
 // (k_wx_sample<32>'s sorting network is too long for the unroller's budget: it stays a loop there, which is correct, only slower)
 #pragma clang diagnostic ignored "-Wpass-failed"
@@ -50,8 +48,8 @@ struct WxPlan {            // built on the device from the model record; the arr
 __global__ void k_wx_plan(const double* __restrict__ model, int M, int P, int A, WxPlan* __restrict__ plan,
                           int* __restrict__ seg_j, int* __restrict__ seg_a, int* __restrict__ astar, int nseg_max,
                           unsigned long long* __restrict__ nz, double* __restrict__ W, int* __restrict__ segbase,
-                          int* __restrict__ fail) {
-    for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; }
+                          int* __restrict__ fail, int* __restrict__ v3 = nullptr) {
+    for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; if (v3) v3[s] = 2; }
     if (threadIdx.x != 0) return;
     if (fail) *fail = 0;
     const ModelLayout ML = model_layout(M, P, A);
@@ -179,7 +177,8 @@ __global__ __launch_bounds__(256) void k_wx_ranksum(const unsigned long long* __
 // ===========================================================================================================================
 constexpr int WXT = 256;                         // threads of the sweep kernels
 constexpr int WX_CAP = 16384;                    // keys one bin may hold (k_wx_ranks_big: the bin in 128 KB of LDS)
-constexpr int WX_NBMAX = 2048;                   // bins per segment
+constexpr int WX_NBMAX = 4096;                   // bins per segment
+constexpr int WX_TAB = 512;                      // cells of the bounds sweep's key -> fine bin table
 constexpr unsigned long long WX_SIGN = 1ull << 63;
 constexpr unsigned long long WX_MASK = ~WX_SIGN;
 
@@ -191,6 +190,10 @@ struct WxGeo {                 // geometry of one binned reduction (computed on 
     int tps;
     int G;                     // segments of one response whose splitters / counters share LDS (the sweep loops over groups)
     int nseg_max;
+    // the BOUNDS sweep (k_wx_bin<.., 2>): F linear sub-bins per bin (a power of two; 0: no bounds sweep), its own partition of the
+    // tiles (a work-group's rows stay below 2^16: its per-bin counters are two 16-bit halves) and its own group size
+    int F;
+    int STb, tpsb, Gb;
 };
 
 // -DWX_STAMPS (diagnostic build, scripts/wx_stamps.sh): thread 0 of every work-group of the kernel WX_STAMPS names (1: k_wx_ranks, 2 / 3: the counting / placing
@@ -204,19 +207,7 @@ __device__ unsigned long long* wx_stamp_buf = nullptr;
 #define WX_STAMP(i) do { } while (0)
 #endif
 
-// key of validation row i in test (j, a1): |d| = ||e_as| - |e_a1|| as its IEEE pattern, the sign of d in bit 63; false: d == 0
-__device__ __forceinline__ bool wx_row_key(const double* __restrict__ S, size_t nt, size_t i, double zy, const double* __restrict__ Qj,
-                                           int P, int a1, int as, unsigned long long* key) {
-    double pred = 0.0, e_small = 0.0;
-    for (int k = 0; k < as; k++) {
-        pred = fma(S[i + nt * k], Qj[(size_t)P * k], pred);
-        if (k + 1 == a1) e_small = zy - pred;
-    }
-    const double d = fabs(zy - pred) - fabs(e_small);
-    if (d == 0.0) return false;
-    *key = (unsigned long long)__double_as_longlong(fabs(d)) | (d > 0.0 ? WX_SIGN : 0ull);
-    return true;
-}
+// key of validation row i in test (j, a1): |d| = ||e_as| - |e_a1|| as its IEEE pattern, the sign of d in bit 63; d == 0: no key
 __device__ __forceinline__ double wx_zy(const double* __restrict__ Y, size_t ldy, size_t row, int j, const double* __restrict__ model,
                                         const ModelLayout& ML, int M) {
     const double sdy = model[ML.off_sd + M + j];
@@ -271,7 +262,8 @@ __device__ __forceinline__ void wx_sort_regs(unsigned int (&v)[EPT], unsigned in
 template <int EPT>
 __global__ __launch_bounds__(1024) void k_wx_sample(const double* __restrict__ Y, size_t ldy, size_t row_test, WxGeo g, int M, int P,
                                                     int A, const double* __restrict__ model, const double* __restrict__ S,
-                                                    const WxPlan* __restrict__ plan, unsigned long long* __restrict__ spl) {
+                                                    const WxPlan* __restrict__ plan, unsigned long long* __restrict__ spl,
+                                                    unsigned int* __restrict__ tab) {
     extern __shared__ unsigned int wx_sk[];
     __shared__ unsigned int s_m;
     const int seg = blockIdx.x;
@@ -283,14 +275,36 @@ __global__ __launch_bounds__(1024) void k_wx_sample(const double* __restrict__ Y
     if (t == 0) s_m = 0;
     __syncthreads();
     unsigned int v[EPT], mine = 0;
+    {
+        // the rows' chains side by side, component by component: EPT independent loads per step (row after row, every load of a
+        // chain waited for the one before)
+        size_t ri[EPT];
+        double zy[EPT], pred[EPT], esm[EPT];
+        const double* Qj = model + ML.off_Q + j;
+        const size_t nt = (size_t)g.nt;
 #pragma unroll
-    for (int u = 0; u < EPT; u++) {
-        const unsigned long long q = (unsigned long long)u * 1024 + t;
-        const size_t i = (size_t)((q * g.nt) / (unsigned long long)SAMP);
-        unsigned long long key;
-        const bool nzr = wx_row_key(S, (size_t)g.nt, i, wx_zy(Y, ldy, row_test + i, j, model, ML, M), model + ML.off_Q + j, P, a1, as, &key);
-        v[u] = nzr ? (unsigned int)((key & WX_MASK) >> 31) : 0xffffffffu;
-        mine += nzr ? 1u : 0u;
+        for (int u = 0; u < EPT; u++) {
+            const unsigned long long q = (unsigned long long)u * 1024 + t;
+            ri[u] = (size_t)((q * g.nt) / (unsigned long long)SAMP);
+            zy[u] = wx_zy(Y, ldy, row_test + ri[u], j, model, ML, M);
+            pred[u] = 0.0;
+            esm[u] = 0.0;
+        }
+        for (int k = 0; k < as; k++) {
+            const double qk = Qj[(size_t)P * k];
+#pragma unroll
+            for (int u = 0; u < EPT; u++) {
+                pred[u] = fma(S[ri[u] + nt * k], qk, pred[u]);
+                if (k + 1 == a1) esm[u] = zy[u] - pred[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const double d = fabs(zy[u] - pred[u]) - fabs(esm[u]);
+            const bool nzr = d != 0.0;
+            v[u] = nzr ? (unsigned int)((unsigned long long)__double_as_longlong(fabs(d)) >> 31) : 0xffffffffu;
+            mine += nzr ? 1u : 0u;
+        }
     }
     if (mine) atomicAdd(&s_m, mine);
     wx_sort_regs<1024, EPT>(v, wx_sk);
@@ -306,6 +320,35 @@ __global__ __launch_bounds__(1024) void k_wx_sample(const double* __restrict__ Y
             sv = ((unsigned long long)wx_sk[idx] << 31) | 0x7fffffffull;
         }
         spl[(size_t)seg * g.NB + b] = sv;
+    }
+    // the bounds sweep's fine bins, without a search: WX_TAB cells, linear in the key prefix between the sample's extremes; a cell
+    // starts at fine bin (sample keys below it) NBF / m and spreads its keys linearly over the fine bins up to the next cell's start
+    // -- a non-decreasing function of the key (any such function makes bins the bounds hold for; the sample only makes them
+    // evenly filled).  tab[seg]: WX_TAB x (start | span << 16), the first prefix, the cell width's shift
+    if (tab && g.F) {
+        unsigned int* tb = tab + (size_t)seg * (WX_TAB + 2);
+        const unsigned int NBF = (unsigned int)(g.NB * g.F);
+        if (m == 0) {
+            for (int c = t; c < WX_TAB + 2; c += 1024) tb[c] = 0u;
+        } else {
+            const unsigned int kmin = wx_sk[0], kmax = wx_sk[m - 1];
+            unsigned int sh = 0;
+            while (((kmax - kmin) >> sh) >= (unsigned int)WX_TAB) sh++;
+            auto below = [&](unsigned long long bound) -> unsigned int {          // sample keys < bound
+                if (bound > 0xffffffffull) return m;
+                unsigned int lo = 0, hi = m;
+                while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if ((unsigned long long)wx_sk[mid] < bound) lo = mid + 1; else hi = mid; }
+                return lo;
+            };
+            for (int c = t; c < WX_TAB; c += 1024) {
+                const unsigned int c0 = below((unsigned long long)kmin + ((unsigned long long)c << sh));
+                const unsigned int c1 = below((unsigned long long)kmin + ((unsigned long long)(c + 1) << sh));
+                const unsigned int s0 = (unsigned int)(((unsigned long long)c0 * NBF) / m);
+                const unsigned int s1 = (c == WX_TAB - 1) ? NBF : (unsigned int)(((unsigned long long)c1 * NBF) / m);
+                tb[c] = s0 | ((s1 - s0) << 16);
+            }
+            if (t == 0) { tb[WX_TAB] = kmin; tb[WX_TAB + 1] = sh; }
+        }
     }
 }
 
@@ -340,76 +383,113 @@ __device__ __forceinline__ unsigned int wx_block_scan(const unsigned int* in, un
 //                     NOT kept: no staging -- the LDS counter of a (segment, bin) as the work-group's write cursor, a returning
 //                     LDS atomic hands every key its place, no barrier in the loop: 0.56 ms against 0.44 ms; the 64 lanes of
 //                     a store then hit 64 different lines.)
-template <int AM, int R, bool SCATTER>
+//   MODE 2 (the bounds sweep, before the other two): counts per FINE bin = (bin, one of F linear sub-bins of the bin's key range),
+//                     all keys in the low and the positive differences in the high half of one 32-bit counter -> blockfine
+// MODE 0 / 1 skip the tests whose verdict the bounds have settled (v3, wx_need): mostly all of them.
+template <int AM, int R, int MODE>
 __global__ __launch_bounds__(WXT) void k_wx_bin(const double* __restrict__ Y, size_t ldy, size_t row_test, WxGeo g, int M, int P, int A,
                                                 const double* __restrict__ model, const double* __restrict__ S,
                                                 const WxPlan* __restrict__ plan, const int* __restrict__ segbase,
                                                 const unsigned long long* __restrict__ spl, unsigned int* __restrict__ blockhist,
-                                                const unsigned int* __restrict__ binbase, unsigned long long* __restrict__ keys) {
+                                                const unsigned int* __restrict__ binbase, unsigned long long* __restrict__ keys,
+                                                const int* __restrict__ v3, const unsigned int* __restrict__ tab) {
     constexpr int TR = WXT * R;
+    constexpr bool SCATTER = MODE == 1, FINE = MODE == 2;
     extern __shared__ unsigned long long wx_smem[];
-    const int j = blockIdx.y;
+    const int ST = FINE ? g.STb : g.ST, tps = FINE ? g.tpsb : g.tps;
+    // MODE 0 / 1: work-groups that share an XCD (blockIdx % 8) take neighbouring runs of tiles: the pieces they write into a bin
+    // are neighbours in memory and meet in that XCD's L2.
+    // MODE 2 (one-dimensional grid): the P work-groups of one run of tiles -- one per response, all reading the same scores, once
+    // per group of tests -- follow each other on ONE XCD, so the scores come from HBM once per group and from that XCD's L2 for
+    // the other responses (with the response in grid.y they were fetched P times: 41 GB at 1e7 rows x 32 responses)
+    const int per_x = (ST + 7) / 8;
+    const int j = FINE ? (int)((blockIdx.x / 8) % (unsigned)P) : (int)blockIdx.y;
+    const int st = FINE ? (int)(blockIdx.x / (8u * (unsigned)P)) * 8 + (int)(blockIdx.x % 8) : (int)(blockIdx.x % 8) * per_x + (int)(blockIdx.x / 8);
+    if (st >= ST) return;
     const int as = plan->astar[j];
     if (as <= 1) return;
-    // work-groups that share an XCD (blockIdx % 8) take neighbouring runs of tiles: the pieces they write into a bin are
-    // neighbours in memory and meet in that XCD's L2
-    const int per_x = (g.ST + 7) / 8;
-    const int st = (int)(blockIdx.x % 8) * per_x + (int)(blockIdx.x / 8);
-    if (st >= g.ST) return;
     const ModelLayout ML = model_layout(M, P, A);
-    const int NB = g.NB, G = g.G, t = threadIdx.x;
+    const int NB = g.NB, G = FINE ? g.Gb : g.G, t = threadIdx.x;
+    const int F = FINE ? g.F : 1, NBF = NB * F;
     const size_t nt = (size_t)g.nt;
+    const int seg0 = segbase[j], nsj = as - 1;
+    // tests of this response that still need their exact rank sum (bit a1 - 1): undecided by the bounds, no smaller a' has passed
+    unsigned int needmask = 0xffffffffu;
+    if (!FINE) {
+        needmask = 0;
+        bool passed = false;
+        for (int a1 = 1; a1 <= nsj; a1++) {
+            const int v = v3[seg0 + a1 - 1];
+            if (v == 2 && !passed) needmask |= 1u << (a1 - 1);
+            passed = passed || v == 1;
+        }
+        if (!needmask) return;
+    }
     // a splitter is a 32-bit prefix followed by 31 ones (k_wx_sample): splitter < key <=> prefix < key >> 31 -- the search compares
     // 32-bit words (half the LDS traffic and half the compare instructions of the 64-bit one)
-    unsigned int* spl_s = (unsigned int*)wx_smem;                          // [G][NB] splitter prefixes
-    unsigned int* acc = spl_s + (size_t)G * NB;                            // [G][NB]: counts (false) / running global offsets (true)
-    unsigned int* lh = acc + (size_t)G * NB;                               // [NB] keys of the current (tile, segment) per bin
+    unsigned int* spl_s = (unsigned int*)wx_smem;                          // [G][NB] splitter prefixes; FINE: [G][WX_TAB + 2], the tables
+    const int SPW = FINE ? WX_TAB + 2 : NB;
+    unsigned int* acc = spl_s + (size_t)G * SPW;                           // [G][NB F]: counts (0, 2) / running global offsets (1)
+    unsigned int* lh = acc + (size_t)G * NBF;                              // [NB] keys of the current (tile, segment) per bin
     unsigned int* cst = lh + NB;                                           // [NB] their exclusive scan
     unsigned long long* skey = (unsigned long long*)(((size_t)(cst + NB) + 7) & ~(size_t)7);   // [TR] staged keys (SCATTER)
     unsigned int* sdst = (unsigned int*)(skey + TR);                       // [TR] their places in the bin
     __shared__ unsigned int wsum[WXT / 64 + 1];
-    const int seg0 = segbase[j], nsj = as - 1;
-    const size_t tile0 = (size_t)st * g.tps;
+    const size_t tile0 = (size_t)st * tps;
     const double* Qj = model + ML.off_Q + j;
     WX_STAMP_K(SCATTER ? 3 : 2, 0);
     for (int grp = 0; grp * G < nsj; grp++) {
         const int gn = (nsj - grp * G < G) ? nsj - grp * G : G;            // segments of this group: a1 = grp G + 1 .. grp G + gn
-        for (int e = t; e < gn * NB; e += WXT) {
-            const int gs = e / NB, b = e - gs * NB, seg = seg0 + grp * G + gs;
-            spl_s[e] = (b < NB - 1) ? (unsigned int)(spl[(size_t)seg * NB + b] >> 31) : 0xffffffffu;
-            acc[e] = SCATTER ? binbase[(size_t)seg * NB + b] + blockhist[((size_t)st * g.nseg_max + seg) * NB + b] : 0u;
-        }
+        if (!FINE && ((needmask >> (grp * G)) & ((gn >= 32) ? 0xffffffffu : ((1u << gn) - 1u))) == 0) continue;      // (uniform)
+        if (FINE) {
+            for (int e = t; e < gn * SPW; e += WXT) spl_s[e] = tab[(size_t)(seg0 + grp * G) * SPW + e];
+            for (int e = t; e < gn * NBF; e += WXT) acc[e] = 0u;
+        } else
+            for (int e = t; e < gn * NB; e += WXT) {
+                const int gs = e / NB, b = e - gs * NB, seg = seg0 + grp * G + gs;
+                spl_s[e] = (b < NB - 1) ? (unsigned int)(spl[(size_t)seg * NB + b] >> 31) : 0xffffffffu;
+                acc[e] = SCATTER ? binbase[(size_t)seg * NB + b] + blockhist[((size_t)st * g.nseg_max + seg) * NB + b] : 0u;
+            }
         __syncthreads();
         if (grp == 0) WX_STAMP_K(SCATTER ? 3 : 2, 1);
-        for (int tt = 0; tt < g.tps; tt++) {
+        for (int tt = 0; tt < tps; tt++) {
             const size_t row_t = (tile0 + tt) * TR;
             if (row_t >= nt) break;
             // residuals of this thread's R rows at 1 .. as components (pred: the k-ascending fma chain of the oracle)
-            double e[R][AM], estar[R];
+            // All loads first, unconditionally (clamped rows and columns): with the loads inside the `k < as` branches of the chain
+            // every one waited for the one before -- R AM memory latencies in a row were 70-90 % of all three sweeps (in-kernel stamps).
+            double e[R][AM], estar[R], yv[R];
             bool in[R];
+            const double sdy = model[ML.off_sd + M + j], muy = model[ML.off_mean + M + j];
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const size_t i = row_t + (size_t)r * WXT + t;
                 in[r] = i < nt;
-                estar[r] = 0.0;
-                if (in[r]) {
-                    const double zy = wx_zy(Y, ldy, row_test + i, j, model, ML, M);
-                    double pred = 0.0;
+                const size_t ic = in[r] ? i : nt - 1;
+                yv[r] = Y[row_test + ic + ldy * (size_t)j];
 #pragma unroll
-                    for (int k = 0; k < AM; k++)
-                        if (k < as) {
-                            pred = fma(S[i + nt * k], Qj[(size_t)P * k], pred);
-                            e[r][k] = zy - pred;
-                            if (k == as - 1) estar[r] = fabs(zy - pred);
-                        }
-                }
+                for (int k = 0; k < AM; k++) e[r][k] = S[ic + nt * (size_t)(k < A ? k : A - 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                estar[r] = 0.0;
+                const double zy = (sdy == 0.0) ? 0.0 : (yv[r] - muy) / sdy;        // (wx_zy)
+                double pred = 0.0;
+#pragma unroll
+                for (int k = 0; k < AM; k++)
+                    if (k < as) {
+                        pred = fma(e[r][k], Qj[(size_t)P * k], pred);
+                        e[r][k] = zy - pred;
+                        if (k == as - 1) estar[r] = fabs(zy - pred);
+                    }
             }
             if (grp == 0 && tt == 0) WX_STAMP_K(SCATTER ? 3 : 2, 2);
 #pragma unroll
             for (int a1 = 1; a1 < AM; a1++) {
                 if (a1 >= as || (a1 - 1) / G != grp) continue;            // (uniform over the work-group)
+                if (!FINE && !((needmask >> (a1 - 1)) & 1u)) continue;
                 const int gs = (a1 - 1) - grp * G;
-                const unsigned int* sp = spl_s + (size_t)gs * NB;
+                const unsigned int* sp = spl_s + (size_t)gs * SPW;
                 if (SCATTER) { for (int b = t; b < NB; b += WXT) lh[b] = 0; __syncthreads(); }
                 unsigned long long key[R];
                 unsigned int k32[R];
@@ -428,6 +508,26 @@ __global__ __launch_bounds__(WXT) void k_wx_bin(const double* __restrict__ Y, si
                 // bin = #{splitters < key}: NB is a power of two, so the search is log2(NB) steps for every row -- no data-dependent
                 // trip count, and the R chains of dependent LDS reads run interleaved (a `while (lo < hi)` per row ran them one
                 // after the other: 8 LDS round trips per key were most of this kernel)
+                if (FINE) {          // fine bin from the table: one LDS read and one LDS atomic per key, no dependent chain
+                    const unsigned int kmin = sp[WX_TAB], sh = sp[WX_TAB + 1];
+                    unsigned int* ac = acc + (size_t)gs * NBF;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (!nzr[r]) continue;
+                        unsigned int fine = 0;
+                        if (k32[r] >= kmin) {
+                            const unsigned int off = k32[r] - kmin, cell = off >> sh;
+                            if (cell >= (unsigned int)WX_TAB) fine = (unsigned int)NBF - 1u;
+                            else {
+                                const unsigned int e2 = sp[cell];
+                                fine = (e2 & 0xffffu) + (unsigned int)(((unsigned long long)(off & ((1u << sh) - 1u)) * (e2 >> 16)) >> sh);
+                                fine = fine < (unsigned int)NBF - 1u ? fine : (unsigned int)NBF - 1u;
+                            }
+                        }
+                        atomicAdd(&ac[fine], 1u + ((key[r] & WX_SIGN) ? 65536u : 0u));
+                    }
+                    continue;
+                }
                 for (int step = NB >> 1; step >= 1; step >>= 1) {
 #pragma unroll
                     for (int r = 0; r < R; r++) bin[r] += (sp[bin[r] + step - 1] < k32[r]) ? step : 0;
@@ -463,13 +563,99 @@ __global__ __launch_bounds__(WXT) void k_wx_bin(const double* __restrict__ Y, si
         __syncthreads();
         if (grp == 0) WX_STAMP_K(SCATTER ? 3 : 2, 5);
         if (!SCATTER)
-            for (int e2 = t; e2 < gn * NB; e2 += WXT) {
-                const int gs = e2 / NB, b = e2 - gs * NB, seg = seg0 + grp * G + gs;
-                blockhist[((size_t)st * g.nseg_max + seg) * NB + b] = acc[e2];
+            for (int e2 = t; e2 < gn * NBF; e2 += WXT) {
+                const int gs = e2 / NBF, b = e2 - gs * NBF, seg = seg0 + grp * G + gs;
+                blockhist[((size_t)st * g.nseg_max + seg) * NBF + b] = acc[e2];
             }
         __syncthreads();
     }
     WX_STAMP_K(SCATTER ? 3 : 2, 6);
+}
+
+// does test `seg` (of a response whose tests start at seg_first) still need its exact rank sum?  v3: 0 rejected / 1 passed by the
+// bounds, 2 undecided; a test behind a smaller a' that passed is never looked at (k_wx_decide stops there)
+__device__ __forceinline__ bool wx_need(const int* __restrict__ v3, int seg_first, int seg) {
+    if (v3[seg] != 2) return false;
+    for (int s = seg_first; s < seg; s++)
+        if (v3[s] == 1) return false;
+    return true;
+}
+// the verdict of a test at |W| / sigma = x, exactly as k_wx_decide takes it
+__device__ double normalcdf_poly(double z);
+__device__ __forceinline__ bool wx_passes(double x) { return 2.0 * (1.0 - normalcdf_poly(x)) > 0.1; }
+
+// BOUNDS on the signed rank sum from counts alone.  Fine bin b of a test holds c_b keys, p_b of them positive differences, B_b keys
+// lie below it: whatever the order inside the bin, its ranks are B_b + 1 .. B_b + c_b (average ranks of ties: a doubly stochastic
+// mix of those, which moves no subset sum beyond the extremes), so the positives' rank sum lies between the p_b lowest and the p_b
+// highest of them and   2 W_b in [4 p B + 2 p (p + 1), 4 p B + 4 p c - 2 p (p - 1)] - (2 c B + c (c + 1)).
+// Integers below 2^50, summed exactly.  The interval of |W| / sigma, widened by 1e-12 against the roundings of the division, is put
+// through the decision function of k_wx_decide at both ends: equal answers = THE answer (the function is monotone but for the last
+// bits next to its threshold); else the test stays undecided (2) and goes through the exact sweeps.  With ~3 sqrt(n) fine bins the
+// interval is ~0.3 sigma wide: a test is undecided when its statistic lies within that of the threshold.
+__global__ __launch_bounds__(1024) void k_wx_bounds(WxGeo g, const WxPlan* __restrict__ plan, const unsigned int* __restrict__ blockfine,
+                                                    unsigned long long* __restrict__ nz, int* __restrict__ v3) {
+    extern __shared__ unsigned int wxb_cp[];              // [NBF] packed (all keys, positive keys) of the test's fine bins
+    __shared__ long long red[3][16];
+    __shared__ unsigned int wtot[16];
+    const int seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (seg >= plan->nseg) return;
+    const int NBF = g.NB * g.F;
+    const size_t stride = (size_t)g.nseg_max * NBF;
+    for (int b = t; b < NBF; b += 1024) {
+        const unsigned int* src = blockfine + (size_t)seg * NBF + b;
+        unsigned int c = 0, p = 0;
+        int st = 0;
+        for (; st + 8 <= g.STb; st += 8) {
+            unsigned int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(st + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { c += v[u] & 0xffffu; p += v[u] >> 16; }
+        }
+        for (; st < g.STb; st++) { const unsigned int v = src[(size_t)st * stride]; c += v & 0xffffu; p += v >> 16; }
+        wxb_cp[2 * b] = c;
+        wxb_cp[2 * b + 1] = p;
+    }
+    __syncthreads();
+    // thread t owns the consecutive fine bins [t per, (t + 1) per): keys below them by a work-group scan of the threads' totals
+    const int per = (NBF + 1023) / 1024, b0 = t * per;
+    unsigned int loc = 0;
+    for (int i = 0; i < per; i++) if (b0 + i < NBF) loc += wxb_cp[2 * (b0 + i)];
+    unsigned int inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    unsigned int below = inc - loc;
+    for (int w = 0; w < wave; w++) below += wtot[w];
+    long long lo2 = 0, hi2 = 0, m = loc;
+    for (int i = 0; i < per; i++)
+        if (b0 + i < NBF) {
+            const long long c = wxb_cp[2 * (b0 + i)], p = wxb_cp[2 * (b0 + i) + 1], B = below;
+            const long long all2 = 2 * c * B + c * (c + 1);
+            lo2 += 4 * p * B + 2 * p * (p + 1) - all2;
+            hi2 += 4 * p * B + 4 * p * c - 2 * p * (p - 1) - all2;
+            below += (unsigned int)c;
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lo2 += __shfl_xor(lo2, o, 64); hi2 += __shfl_xor(hi2, o, 64); m += __shfl_xor(m, o, 64); }
+    if (lane == 0) { red[0][wave] = lo2; red[1][wave] = hi2; red[2][wave] = m; }
+    __syncthreads();
+    if (t == 0) {
+        lo2 = hi2 = m = 0;
+        for (int w = 0; w < 16; w++) { lo2 += red[0][w]; hi2 += red[1][w]; m += red[2][w]; }
+        nz[seg] = (unsigned long long)m;
+        int v = 1;                                         // no non-zero difference: p = 1, the test passes (k_wx_decide)
+        if (m > 0) {
+            const double md = (double)m, sigma = sqrt(md * (md + 1.0) * (2.0 * md + 1.0) / 6.0);
+            const long long alo = lo2 < 0 ? -lo2 : lo2, ahi = hi2 < 0 ? -hi2 : hi2;
+            const long long mx2 = alo > ahi ? alo : ahi, mn2 = (lo2 <= 0 && hi2 >= 0) ? 0 : (alo < ahi ? alo : ahi);
+            const double x_lo = 0.5 * (double)mn2 / sigma * (1.0 - 1e-12), x_hi = 0.5 * (double)mx2 / sigma * (1.0 + 1e-12);
+            const bool p_lo = wx_passes(x_lo), p_hi = wx_passes(x_hi);
+            v = (p_lo == p_hi) ? (p_lo ? 1 : 0) : 2;
+        }
+        v3[seg] = v;
+    }
 }
 
 // per segment: blockhist[st][seg][b] -> the work-group's offset inside bin b (exclusive over st), hist[seg][b] = the bin's size,
@@ -477,11 +663,13 @@ __global__ __launch_bounds__(WXT) void k_wx_bin(const double* __restrict__ Y, si
 // the work-groups: partial sums per quarter (independent loads, eight in flight), then the offsets in a second sweep
 __global__ __launch_bounds__(1024) void k_wx_offsets(WxGeo g, const WxPlan* __restrict__ plan, unsigned int* __restrict__ blockhist,
                                                      unsigned int* __restrict__ hist, unsigned int* __restrict__ binbase,
-                                                     unsigned long long* __restrict__ nz) {
+                                                     unsigned long long* __restrict__ nz, const int* __restrict__ v3,
+                                                     const int* __restrict__ segbase) {
     __shared__ unsigned int tot[WX_NBMAX];
     __shared__ unsigned int part[4][256];
     const int seg = blockIdx.x, NB = g.NB;
     if (seg >= plan->nseg) return;
+    if (!wx_need(v3, segbase[plan->seg_j[seg]], seg)) return;          // (uniform: settled by the bounds)
     const int bl = threadIdx.x & 255, q = threadIdx.x >> 8;
     const int per = (g.ST + 3) / 4, s0 = q * per, s1 = (s0 + per < g.ST) ? s0 + per : g.ST;
     const size_t stride = (size_t)g.nseg_max * NB;
@@ -649,7 +837,8 @@ constexpr int WX_NS = 1024;                     // linear sub-bins
 constexpr int WX_WALK = 48;                     // longest sub-bin it walks
 __global__ __launch_bounds__(256) void k_wx_ranks(WxGeo g, const WxPlan* __restrict__ plan, const unsigned long long* __restrict__ keys,
                                                   const unsigned int* __restrict__ hist, const unsigned int* __restrict__ binbase,
-                                                  double* __restrict__ W, unsigned int* __restrict__ big /* [0] count, then (seg, bin) pairs */) {
+                                                  double* __restrict__ W, unsigned int* __restrict__ big /* [0] count, then (seg, bin) pairs */,
+                                                  const int* __restrict__ v3, const int* __restrict__ segbase) {
     constexpr int T = 256, KPT = WX_CAP_S / T;
     __shared__ unsigned long long ks[WX_CAP_S + 1];
     __shared__ unsigned int cnt[WX_NS + 2], start[WX_NS + 2];
@@ -658,6 +847,7 @@ __global__ __launch_bounds__(256) void k_wx_ranks(WxGeo g, const WxPlan* __restr
     __shared__ unsigned int s_max[T / 64];
     const int seg = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     if (seg >= plan->nseg) return;
+    if (!wx_need(v3, segbase[plan->seg_j[seg]], seg)) return;
     const unsigned int n = hist[(size_t)seg * g.NB + b];
     if (n == 0) return;
     auto to_big = [&]() { if (t == 0) { const unsigned int e = atomicAdd(&big[0], 1u); big[1 + 2 * e] = (unsigned int)seg; big[2 + 2 * e] = (unsigned int)b; } };
@@ -821,9 +1011,11 @@ __device__ double normalcdf_poly(double z) {        // [PLS] normalcdf, Abramowi
 // pass[s] (optional scratch of nseg_max bytes): the test's verdict, computed by one thread per test; thread 0 then walks the
 // responses (single-threaded it was 50 us of square roots and divisions in a row at 112 tests)
 __global__ void k_wx_decide(double* __restrict__ model, int M, int P, int A, const WxPlan* __restrict__ plan,
-                            const unsigned long long* __restrict__ nz, const double* __restrict__ W, unsigned char* __restrict__ pass) {
+                            const unsigned long long* __restrict__ nz, const double* __restrict__ W, unsigned char* __restrict__ pass,
+                            const int* __restrict__ v3) {
     const int nseg = plan->nseg;
     auto verdict = [&](int s) -> bool {
+        if (v3 && v3[s] != 2) return v3[s] == 1;           // settled by the bounds (k_wx_bounds): the exact sum was never taken
         const double m = (double)nz[s];
         double p = 1.0;
         if (m > 0.0) {
@@ -917,7 +1109,7 @@ static int launch_wilcoxon_sorted(abc_ctx* ctx, const double* X, const double* Y
     ABC_TRY(abc_sort_u64_bytes(ctx, key0, val0, key1, val1, tot, 0, 8));
     ABC_TRY(abc_sort_u64_bytes(ctx, val0, key0, val1, key1, tot, 4, 6));
     hipLaunchKernelGGL(k_wx_ranksum, dim3(rb, nseg_host), dim3(256), 0, ctx->stream, key0, val0, nt, plan, nz, W);
-    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(64), 0, ctx->stream, model, (int)M, (int)P, (int)A, plan, nz, W, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(64), 0, ctx->stream, model, (int)M, (int)P, (int)A, plan, nz, W, (unsigned char*)nullptr, (const int*)nullptr);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
 }
@@ -928,6 +1120,10 @@ static size_t wx_sorted_need(size_t nt, size_t P, size_t A) {
     return nt * A * 8 + 4 * seg * nt * 8 + 2 * 256 * ((seg * nt) / 1024 + 2) * 4 + seg * 32 + P * 8 + (2u << 20);
 }
 
+static bool wx_no_bounds() {            // A/B runs and tests (ABC_DIAG=1 ABC_WX_NOBOUNDS=1): every test through the exact sweeps
+    static const bool on = abc_diag_env("ABC_WX_NOBOUNDS") != nullptr;
+    return on;
+}
 // geometry of the binned path; false: the shape goes to the sorted path
 static bool wx_geometry(size_t nt, size_t P, size_t A, WxGeo* g, int* R_out) {
     if (A > 32 || A < 2 || nt == 0 || P * (A - 1) > MAXSEG) return false;
@@ -949,6 +1145,24 @@ static bool wx_geometry(size_t nt, size_t P, size_t A, WxGeo* g, int* R_out) {
     if (G > (int)A - 1) G = (int)A - 1;
     g->G = G;
     g->nseg_max = (int)(P * (A - 1));
+    // the bounds sweep: ~2.5 sqrt(nt) fine bins and up (an interval of <= 0.35 sigma), at most 8192; a work-group's rows below 2^16
+    g->F = 0; g->STb = 0; g->tpsb = 0; g->Gb = 0;
+    if (NB > 1 && !wx_no_bounds()) {
+        size_t nbf = (size_t)NB;
+        while (nbf < 8192 && (double)nbf < 2.5 * sqrt((double)nt)) nbf *= 2;
+        g->F = (int)(nbf / (size_t)NB);
+        size_t stb = (1024 + P - 1) / P;
+        if (stb > tiles) stb = tiles;
+        size_t tpsb = (tiles + stb - 1) / stb;
+        const size_t tmax = 61440 / TR;
+        if (tpsb > tmax) tpsb = tmax;
+        g->tpsb = (int)tpsb;
+        g->STb = (int)((tiles + tpsb - 1) / tpsb);
+        int Gb = (int)((72u << 10) / ((size_t)(WX_TAB + 2) * 4 + nbf * 4));
+        if (Gb < 1) Gb = 1;
+        if (Gb > (int)A - 1) Gb = (int)A - 1;
+        g->Gb = Gb;
+    }
     *R_out = R;
     return true;
 }
@@ -957,7 +1171,8 @@ static size_t wx_binned_need(size_t nt, size_t P, size_t A) {
     int R;
     if (!wx_geometry(nt, P, A, &g, &R)) return 0;
     const size_t seg = P * (A - 1);
-    return nt * A * 8 + seg * nt * 8 + (size_t)g.ST * seg * g.NB * 4 + seg * g.NB * (8 + 4 + 4 + 8) + seg * 32 + P * 16 + (1u << 20);
+    return nt * A * 8 + seg * nt * 8 + (size_t)g.ST * seg * g.NB * 4 + (size_t)g.STb * seg * g.NB * g.F * 4 + seg * g.NB * (8 + 4 + 4 + 8) +
+           seg * (40 + (size_t)(WX_TAB + 2) * 4) + P * 16 + (1u << 20);
 }
 static bool wx_force_sorted() {          // A/B runs and tests (ABC_DIAG=1 ABC_WX_SORTED=1): the sorted path only
     static const bool on = abc_diag_env("ABC_WX_SORTED") != nullptr;
@@ -968,21 +1183,30 @@ size_t abc_wx_need(size_t nt, size_t P, size_t A) {
     return b ? b : wx_sorted_need(nt, P, A);       // (a binned reduction that has to be repeated on the sorted path allocates its own arena)
 }
 
+// mode 0: the counting sweep, 1: the placing sweep (blockhist: per-bin counts / offsets of the work-groups), 2: the bounds sweep
+// (blockhist: the fine-bin counters)
 template <int AM, int R>
-static void wx_launch_bins(abc_ctx* ctx, bool scatter, const WxGeo& g, const double* Y, size_t ldy, size_t row_test, size_t M, size_t P,
+static void wx_launch_bins(abc_ctx* ctx, int mode, const WxGeo& g, const double* Y, size_t ldy, size_t row_test, size_t M, size_t P,
                            size_t A, const double* model, const double* S, const WxPlan* plan, const int* segbase,
-                           const unsigned long long* spl, unsigned int* blockhist, const unsigned int* binbase, unsigned long long* keys) {
-    const dim3 grid((unsigned)(8 * ((g.ST + 7) / 8)), (unsigned)P);
+                           const unsigned long long* spl, unsigned int* blockhist, const unsigned int* binbase, unsigned long long* keys,
+                           const int* v3, const unsigned int* tab) {
+    const int ST = mode == 2 ? g.STb : g.ST;
+    const dim3 grid = mode == 2 ? dim3((unsigned)(8 * ((ST + 7) / 8) * P), 1u) : dim3((unsigned)(8 * ((ST + 7) / 8)), (unsigned)P);
     size_t lds = (size_t)g.G * g.NB * 8 + (size_t)g.NB * 8 + 8;
-    if (scatter) {
+    if (mode == 1) {
         lds += (size_t)WXT * R * 12 + 16;
-        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_wx_bin<AM, R, true>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
-                           plan, segbase, spl, blockhist, binbase, keys);
+        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_wx_bin<AM, R, 1>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
+                           plan, segbase, spl, blockhist, binbase, keys, v3, tab);
+    } else if (mode == 0) {
+        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_wx_bin<AM, R, 0>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
+                           plan, segbase, spl, blockhist, binbase, keys, v3, tab);
     } else {
-        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_wx_bin<AM, R, false>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
-                           plan, segbase, spl, blockhist, binbase, keys);
+        lds = (size_t)g.Gb * ((size_t)(WX_TAB + 2) * 4 + (size_t)g.NB * g.F * 4) + 64;
+        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_wx_bin<AM, R, 2>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
+                           plan, segbase, spl, blockhist, binbase, keys, v3, tab);
     }
 }
 
@@ -1004,7 +1228,11 @@ static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const dou
     unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, nseg_max * NB * 4);
     unsigned int* binbase = (unsigned int*)abc_ws_alloc(ctx, nseg_max * NB * 4);
     unsigned int* blockhist = (unsigned int*)abc_ws_alloc(ctx, (size_t)g.ST * nseg_max * NB * 4);
+    unsigned int* blockfine = (unsigned int*)abc_ws_alloc(ctx, (size_t)g.STb * nseg_max * NB * g.F * 4 + 4);
+    int* v3 = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    unsigned int* tab = (unsigned int*)abc_ws_alloc(ctx, nseg_max * (size_t)(WX_TAB + 2) * 4);
     unsigned long long* keys = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
+    if (!blockfine || !v3 || !tab) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu segments x %zu rows)", nseg_max, nt);
     if (!plan || !seg_j || !seg_a || !astar || !segbase || !fail || !big || !nz || !W || !S || !spl || !hist || !binbase || !blockhist || !keys)
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu segments x %zu rows)", nseg_max, nt);
     hipStream_t st = ctx->stream;
@@ -1018,7 +1246,7 @@ static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const dou
     ABC_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(wx_stamp_buf), &stamp_dev, sizeof(stamp_dev), 0, hipMemcpyHostToDevice, st));
 #endif
     hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
-                       segbase, fail);
+                       segbase, fail, v3);
     ABC_HIP(ctx, hipMemsetAsync(big, 0, 4, st));
     const unsigned rb = (unsigned)((nt + 255) / 256);
     int KC = 1;
@@ -1040,33 +1268,52 @@ static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const dou
         if ((size_t)g.SAMP * 4 > (48u << 10))                                                                                        \
             ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_sample<EPTV>, hipFuncAttributeMaxDynamicSharedMemorySize, g.SAMP * 4)); \
         hipLaunchKernelGGL(k_wx_sample<EPTV>, dim3((unsigned)nseg_max), dim3(1024), (size_t)g.SAMP * 4, st, Y, ldy, row_test, g, (int)M, \
-                           (int)P, (int)A, (const double*)model, (const double*)S, (const WxPlan*)plan, spl);                      \
+                           (int)P, (int)A, (const double*)model, (const double*)S, (const WxPlan*)plan, spl, tab);                 \
     } while (0)
         if (g.SAMP == 4096) WX_SAMPLE(4);
         else if (g.SAMP == 16384) WX_SAMPLE(16);
         else WX_SAMPLE(32);
 #undef WX_SAMPLE
     }
-#define WX_BINS(AMV, RV, SC) wx_launch_bins<AMV, RV>(ctx, SC, g, Y, ldy, row_test, M, P, A, model, S, plan, segbase, spl, blockhist, binbase, keys)
-    for (int pass = 0; pass < 2; pass++) {
-        if (R == 4) WX_BINS(8, 4, pass == 1);
-        else if (R == 2) WX_BINS(16, 2, pass == 1);
-        else WX_BINS(32, 1, pass == 1);
+#define WX_BINS(AMV, RV, MODE, BH) wx_launch_bins<AMV, RV>(ctx, MODE, g, Y, ldy, row_test, M, P, A, model, S, plan, segbase, spl, BH, binbase, keys, v3, tab)
+    // the bounds sweep first: it settles every test whose statistic is not next to the threshold (v3); the counting, placing and
+    // ranking launches behind it then only work on the undecided ones (their work-groups look at v3 and leave)
+    for (int pass = g.F ? -1 : 0; pass < 2; pass++) {
+        const int mode = pass < 0 ? 2 : pass;
+        unsigned int* bh = pass < 0 ? blockfine : blockhist;
+        if (R == 4) WX_BINS(8, 4, mode, bh);
+        else if (R == 2) WX_BINS(16, 2, mode, bh);
+        else WX_BINS(32, 1, mode, bh);
+        if (pass < 0)
+            hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)nseg_max), dim3(1024), (size_t)NB * g.F * 8, st, g, (const WxPlan*)plan,
+                               (const unsigned int*)blockfine, nz, v3);
         if (pass == 0)
-            hipLaunchKernelGGL(k_wx_offsets, dim3((unsigned)nseg_max), dim3(1024), 0, st, g, (const WxPlan*)plan, blockhist, hist, binbase, nz);
+            hipLaunchKernelGGL(k_wx_offsets, dim3((unsigned)nseg_max), dim3(1024), 0, st, g, (const WxPlan*)plan, blockhist, hist, binbase, nz,
+                               (const int*)v3, (const int*)segbase);
     }
 #undef WX_BINS
     hipLaunchKernelGGL(k_wx_ranks, dim3((unsigned)NB, (unsigned)nseg_max), dim3(256), 0, st, g, (const WxPlan*)plan,
-                       (const unsigned long long*)keys, (const unsigned int*)hist, (const unsigned int*)binbase, W, big);
+                       (const unsigned long long*)keys, (const unsigned int*)hist, (const unsigned int*)binbase, W, big, (const int*)v3,
+                       (const int*)segbase);
     ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_ranks_big, hipFuncAttributeMaxDynamicSharedMemorySize, WX_CAP * 8));
     hipLaunchKernelGGL(k_wx_ranks_big, dim3(256), dim3(1024), (size_t)WX_CAP * 8, st, g, (const unsigned long long*)keys, (const unsigned int*)hist,
                        (const unsigned int*)binbase, W, (const unsigned int*)big, fail);
-    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, (unsigned char*)hist);
+    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, (unsigned char*)hist, (const int*)v3);
     ABC_HIP(ctx, hipGetLastError());
     // the one host visit of the reduction: did every bin fit?  (k_wx_decide has then written a count from incomplete sums: the
     // sorted path overwrites it)
     ABC_HIP(ctx, hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, st));
     ABC_HIP(ctx, hipStreamSynchronize(st));
+    if (abc_diag_env("ABC_WX_DEBUG")) {          // (diagnostic: how the tests were settled)
+        std::vector<int> hv(nseg_max);
+        WxPlan hp;
+        ABC_HIP(ctx, hipMemcpy(&hp, plan, sizeof(WxPlan), hipMemcpyDeviceToHost));
+        ABC_HIP(ctx, hipMemcpy(hv.data(), v3, nseg_max * sizeof(int), hipMemcpyDeviceToHost));
+        int cnt[3] = {0, 0, 0};
+        for (int i = 0; i < hp.nseg; i++) cnt[hv[i] < 0 || hv[i] > 2 ? 2 : hv[i]]++;
+        fprintf(stderr, "WX_DEBUG: %d tests over %zu rows, %d bins x %d fine: bounds rejected %d, passed %d, undecided %d%s\n", hp.nseg, nt, g.NB,
+                g.F, cnt[0], cnt[1], cnt[2], *fail_host ? " (a bin outgrew LDS: repeat on the sorted path)" : "");
+    }
 #ifdef WX_STAMPS
     {
         std::vector<unsigned long long> h(nstamp);

@@ -7,6 +7,8 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("ABC_DIAG", "1")
+if len(sys.argv) > 6:
+    os.environ["ABC_WX_DEBUG"] = "1"
 import torch
 
 from abcsmc_amd import _lib, abcutil, device, synthetic

@@ -201,9 +201,11 @@ def test_select_smallest_random(gpu_ctx, oracle, n, K):
 
 @pytest.mark.parametrize("n,K,kind", [(200000, 20000, "chi"), (200000, 1, "chi"), (50000, 25000, "lognormal"),
                                       (1000000, 100000, "chi"), (65536, 300, "ties_at_threshold"), (100000, 5000, "outliers"),
-                                      (16384, 8192, "chi"), (300000, 150000, "binades")])
+                                      (16384, 8192, "chi"), (300000, 150000, "binades"),
+                                      (10_000_000, 1_000_000, "chi"), (4_000_000, 1 << 20, "lognormal"), (3_000_000, 300_000, "binades")])
 def test_select_smallest_sampled_bins(gpu_ctx, oracle, n, K, kind):
-    """large sets, at most half kept: the sampled-range bin selection (k_bs_*) instead of radix select + sort; same array"""
+    """large sets, at most half kept: the sampled-range bin selection (k_bs_*) instead of radix select + sort; same array.
+    Round 4: up to 2^20 winners (16384 bins beyond 2^18: the 1e6 winners of configs[3] at its stated size)"""
     rng = np.random.default_rng(n + 7 * K)
     if kind == "chi":
         d = np.sqrt((rng.normal(size=(n, 8)) ** 2).sum(axis=1))            # distances in an 8-dimensional score space
@@ -1613,6 +1615,7 @@ def _wilcoxon_per_response(gpu_ctx, oracle, X, Y, obs, A, f=0.5):
     (200_000, 40, 6, 24, "plain"),         # one row per thread (17..32 components)
     (300_000, 16, 4, 6, "copies50"),       # 50 distinct validation rows: tie groups of 3000, a few values per bin
     (300_000, 16, 4, 6, "copies8"),        # 8 distinct rows: groups of 18750 outgrow a bin -> the build repeats on the sorted path
+    (10_000_000, 8, 2, 4, "plain"),        # 5e6 validation rows (configs[3]'s count): 4096 bins, 8192 fine bins of the bounds sweep
 ])
 def test_wilcoxon_reduction_per_response_binned_path(gpu_ctx, oracle, N, M, P, A, kind):
     """Round 4's binned rank sums (wilcoxon.hip): per response the reduced component count equals the oracle's, on plain data, on
@@ -1641,7 +1644,8 @@ def test_wilcoxon_reduction_per_response_binned_path(gpu_ctx, oracle, N, M, P, A
 
 
 def test_wilcoxon_paths_agree(gpu_ctx, oracle, tmp_path):
-    """the binned path, the sorted path (ABC_WX_SORTED) and a binned reduction forced to repeat itself on the sorted path
+    """the binned path (tests settled by the bounds sweep where they can be), the same with every test through the exact sweeps
+    (ABC_WX_NOBOUNDS), the sorted path (ABC_WX_SORTED) and a binned reduction forced to repeat itself on the sorted path
     (ABC_WX_FORCE_FAIL) leave the same component counts -- each in a process of its own (the switches are read once)"""
     import os
     import subprocess
@@ -1653,13 +1657,22 @@ def test_wilcoxon_paths_agree(gpu_ctx, oracle, tmp_path):
             "Y = np.asfortranarray(Y + rng.normal(size=Y.shape) * Y.std(0) * 1.5)\n"
             "r = T._wilcoxon_per_response(_lib.default_context(0), O, np.asfortranarray(X), Y, obs, 8)\n"
             "print('RESULT', r[1].tolist(), r[3].tolist(), r[4])\n") % (root, os.path.join(root, "tests"))
-    outs = []
-    for extra in ({}, {"ABC_WX_SORTED": "1"}, {"ABC_WX_FORCE_FAIL": "1"}):
-        env = dict(os.environ, ABC_DIAG="1", **extra)
+    outs, dbg = [], []
+    for extra in ({}, {"ABC_WX_NOBOUNDS": "1"}, {"ABC_WX_SORTED": "1"}, {"ABC_WX_FORCE_FAIL": "1"}):
+        env = dict(os.environ, ABC_DIAG="1", ABC_WX_DEBUG="1", **extra)
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
         outs.append([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0])
-    assert outs[0] == outs[1] == outs[2], outs
+        dbg.append([ln for ln in p.stderr.splitlines() if ln.startswith("WX_DEBUG")])
+    assert outs[0] == outs[1] == outs[2] == outs[3], outs
+    # the default run settled tests by their bounds and left some to the exact sweeps (noisy responses: statistics near the
+    # threshold exist); with the switch every test is undecided
+    import re
+    m0 = re.search(r"rejected (\d+), passed (\d+), undecided (\d+)", dbg[0][0])
+    m1 = re.search(r"rejected (\d+), passed (\d+), undecided (\d+)", dbg[1][0])
+    print(dbg[0][0], "|", dbg[1][0])
+    assert int(m0.group(1)) + int(m0.group(2)) > 0
+    assert int(m1.group(1)) + int(m1.group(2)) == 0 and int(m1.group(3)) > 0
     got, want = eval(outs[0].split(" ", 1)[1].split("] ")[0] + "]"), eval("[" + outs[0].split("] [")[1].split("]")[0] + "]")
     assert got == want, (got, want)
 

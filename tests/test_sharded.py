@@ -61,7 +61,7 @@ def test_sharded_world2_cabi_driver(tmp_path, shape, port):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,data,port", [("big", "plain", 29631), ("big0", "plain", 29632), ("big", "ties", 29633), ("big0", "ties", 29634),
-                                             ("huge", "plain", 29635)])
+                                             ("huge", "plain", 29635), ("huge", "ties", 29636)])
 def test_sharded_world2_cabi_driver_gathered_sample_selection(tmp_path, shape, data, port):
     """sets large enough for the C++ driver's gathered-sample selection (sample all-gather, bound of the K-th key, candidate
     lists with their rows in one all-gather, exact pick of the K smallest on every rank): weighted and first-set generations
