@@ -229,12 +229,14 @@ struct GramDimsDma {
 // buffer being refilled from the one being read, puts s_waitcnt vmcnt(0) in front of the next LDS operand read, i.e. it
 // waits for the prefetch it has just issued and nothing overlaps (seen in the ISA; the kernel then ran at the SUM of
 // its memory and MFMA times).  All waits for these loads are the explicit counted s_waitcnt in the loop.
+template <bool NT = true>
 __device__ __forceinline__ void dma16(const double* gsrc, double* dst) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
     // nt: every byte of X and Y is read exactly once -- streamed past L2 / Infinity Cache instead of allocated there.  Without
     // it the kernel's time depended on what the previous kernels had left in the caches (1 GB flushed between launches:
     // 134 us; behind a generation's 128 MB of freshly written proposals: 95 us); with it 84-86 us in every state.
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"(gsrc) : "memory");
+    if constexpr (NT) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"(gsrc) : "memory");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
 }
 
 // PRIV = true (NW == 8): every wave stages and consumes its OWN 16 rows of each tile (8 columns x 16 rows per DMA
@@ -423,10 +425,10 @@ __global__ __launch_bounds__((GramDimsDma<C, CY, NW>::NT)) void k_gram_dma(
 // waves per SIMD need rings of at most 18 KB per wave: wave-private chunks of EIGHT rows (64-row tiles, three-chunk rings of
 // 6 KB per wave at 96 columns).  DMA instruction i of a chunk brings the 16 columns of MFMA block i: lane l fetches rows
 // 2 (l >> 4), +1 of column 16 i + (l & 15), 64-byte pieces of a column (the other half of the 128-byte line goes to the
-// neighbouring wave of the same work-group at the same time); in LDS that is element (column c, row r) of block i at
+// neighbouring wave of the same work-group at the same time: the loads are therefore NOT non-temporal, see run_gram_dma8); in LDS that is element (column c, row r) of block i at
 // 128 i + 2 c + 32 (r >> 1) + (r & 1), so the operand read of k-step s (lane (cl, q) -> row 4 s + q) covers 64 consecutive
 // doubles: conflict-free without a swizzle.  Everything else (shift at operand read, masks, column sums, epilogue) as above.
-template <int C, int CY>
+template <int C, int CY, bool NTL = true>
 __global__ __launch_bounds__(512) void k_gram_dma8(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy,
                                                   int M, int P, long long n, long long split, const double* __restrict__ shift,
                                                   double* __restrict__ partial) {
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(512) void k_gram_dma8(const double* __restrict__ X,
         long long r = t0 + tile * TRK + 8 * wave + 2 * (lane >> 4);
         r = r > rmax ? rmax : r;                         // rows past the end are masked later; keep the address legal
 #pragma unroll
-        for (int i = 0; i < C; i++) dma16(cptr[i] + r, wring + slot * CH + i * 128);
+        for (int i = 0; i < C; i++) dma16<NTL>(cptr[i] + r, wring + slot * CH + i * 128);
     };
     const int cl = lane & 15, q = lane >> 4;
     double sh[C], keep[C];
@@ -1207,11 +1209,22 @@ int run_gram_dma8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size
     constexpr size_t lds_max = lds_ring > lds_epi ? (lds_ring > lds_cs ? lds_ring : lds_cs) : (lds_epi > lds_cs ? lds_epi : lds_cs);
     static_assert(lds_max * sizeof(double) <= 160 * 1024, "k_gram_dma8: ring / epilogue exceed the 160 KB of LDS");
     const size_t lds_bytes = lds_max * sizeof(double);
-    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma8<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // This kernel's loads go WITHOUT the non-temporal hint (round 4).  Its DMA pieces are 64 bytes of a column -- half a 128-byte
+    // line, the other half going to the neighbouring wave at about the same time --, and a line fetched with the hint is not kept
+    // for the neighbour: FETCH_SIZE showed 13.5 GB for the 7.68 GB of configs[3]'s set (1.76 x), 8.25 GB without the hint, and the
+    // kernel 2.25 -> 2.09 ms (it is bound by the fp64 matrix pipe first, so the doubled traffic cost 7 %, not 76 %).  The kernels
+    // whose pieces are whole lines (k_gram_dma: 16 rows, k_gram_i8: 32 rows of a column) keep the hint.  ABC_GRAM_DMA8_NT: A/B.
+    static const bool nont = abc_diag_env("ABC_GRAM_DMA8_NT") == nullptr;
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma8<C, CY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dma8<C, CY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
-        hipLaunchKernelGGL((k_gram_dma8<C, CY>), dim3((unsigned)G, 2), dim3(512), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
-                           (long long)n, split, stats + L.off_shift, partial);
+        if (nont)
+            hipLaunchKernelGGL((k_gram_dma8<C, CY, false>), dim3((unsigned)G, 2), dim3(512), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
+                               (long long)n, split, stats + L.off_shift, partial);
+        else
+            hipLaunchKernelGGL((k_gram_dma8<C, CY, true>), dim3((unsigned)G, 2), dim3(512), lds_bytes, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
+                               (long long)n, split, stats + L.off_shift, partial);
     }
     ABC_HIP(ctx, hipGetLastError());
     StageTimer tm2(ctx, ctx->in_mvn ? -1 : ST_STATS_REDUCE);

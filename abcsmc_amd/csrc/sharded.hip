@@ -380,6 +380,11 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     int DSL = 4096;
     while (DSL > 1 && (size_t)DSL * 16 > N / (size_t)W) DSL >>= 1;
     while ((size_t)DSL * (size_t)W > 16384) DSL >>= 1;
+    // (the sample has to fit the device's LDS beside the kernel's own 1.1 KB: a build for a 64 KB part halves it, and below 256 keys
+    // per rank the radix protocol runs -- the same decision on every rank, all of them being the same device type)
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess) lds_max = 64 << 10;
+    while (DSL > 1 && (size_t)DSL * (size_t)W * 8 + 2048 > (size_t)lds_max) DSL >>= 1;
     const bool fast_sel = W > 1 && !ctx->sel_force_radix && 2 * K <= N && DSL >= 256;
     size_t ds_cap = 0;
     if (fast_sel) {

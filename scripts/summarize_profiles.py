@@ -139,8 +139,8 @@ for c in cfgs:
                 "valu_active_frac_of_kernel_cycles": round(4 * cn.get('SQ_ACTIVE_INST_VALU', 0) / NSIMD / cyc, 3),
                 "valu_active_frac_of_2.4GHz_issue_peak": round(cn.get('SQ_ACTIVE_INST_VALU', 0) / (ns * 1e-9) / (NSIMD * 2.4e9 / 4), 3)})
     # the wide Gram of the ranking: every k_gram* launch except the K x P moment pass of the posterior (k_gram<1, 0, ...>)
-    gk = [k for k in st if k.startswith('k_gram') and not k.startswith('k_gram<1, 0')]
-    ngen = sum(st[k][0] for k in st if k.startswith('k_project_dist'))          # one projection per generation
+    gk = [k for k in st if (k.startswith('k_gram') and not k.startswith('k_gram<1, 0')) or k.startswith('k_pilot_scale')]
+    ngen = sum(st[k][0] for k in st if k.startswith('k_project_'))          # one projection per generation
     if gk and ngen:
         gb = 8.0 * n * (M + P)
         tot_ns = sum(st[k][1] * st[k][0] for k in gk) / ngen
@@ -223,8 +223,9 @@ for c in cfgs:
     T, nv, M, P, A = ex["wilcoxon_tests"], ex["wilcoxon_validation_rows"], cfgd["metrics"], cfgd["params"], cfgd["pls_components"]
     stw = {short(r['Name']): (int(r['Calls']), float(r['AverageNs'])) for r in csv.DictReader(open(find(dw, 'kernel_stats.csv')))}
     gens = max(v[0] for k, v in stw.items() if k.startswith('k_wx_decide'))
-    alg = {'k_wx_scores': 8.0 * nv * (M + A), 'k_wx_bin<.., false>': 8.0 * nv * (A + P), 'k_wx_bin<.., true>': 8.0 * nv * (A + P) + 8.0 * T * nv,
-           'k_wx_ranks': 8.0 * T * nv}
+    # (the bounds sweep settles most tests: the counting / placing / ranking launches behind it only work on the undecided ones, so
+    # no byte count is attached to them; the bounds sweep reads scores and responses once and is bound by its per-key work: keys/s)
+    alg = {'k_wx_scores': 8.0 * nv * (M + A), 'k_wx_bin<.., 2>': 8.0 * nv * (A + P)}
     rows, tot_ns = [], 0.0
     for k, (calls, ns) in sorted(stw.items()):
         if not k.startswith('k_wx_'):
@@ -233,21 +234,23 @@ for c in cfgs:
         tot_ns += ns * per_gen
         key = k.split('<')[0]
         if key == 'k_wx_bin':
-            key = 'k_wx_bin<.., true>' if k.rstrip('>').endswith('true') else 'k_wx_bin<.., false>'
+            key = 'k_wx_bin<.., %s>' % k.rstrip('>').split(',')[-1].strip()
         a = alg.get(key)
         rows.append({"kernel": k, "launches_per_generation": per_gen, "avg_us": round(ns / 1e3, 2), "algorithmic_bytes": a,
-                     "achieved_GBs": round(a / ns, 1) if a else None, "frac_of_hbm_peak": round(a / ns / HBM_PEAK, 4) if a else None})
-    total_alg = 8.0 * nv * (M + A) + 2 * 8.0 * nv * (A + P) + 16.0 * T * nv
+                     "achieved_GBs": round(a / ns, 1) if a else None, "frac_of_hbm_peak": round(a / ns / HBM_PEAK, 4) if a else None,
+                     "keys_per_s": round(T * nv / (ns * 1e-9), -6) if key == 'k_wx_bin<.., 2>' else None})
+    total_alg = 8.0 * nv * (M + A) + 8.0 * nv * (A + P)
     roof.setdefault("config%d" % c, {})["wilcoxon_rule"] = {
         "tests": T, "validation_rows": nv, "kernels": rows, "kernel_us_per_generation": round(tot_ns / 1e3, 1),
         "algorithmic_bytes_per_generation": total_alg, "achieved_GBs": round(total_alg / tot_ns, 1), "frac_of_hbm_peak": round(total_alg / tot_ns / HBM_PEAK, 4),
         "bench": {k: v for k, v in ex.items() if 'wilcoxon' in k or k == 'ranking_pls_ms'},
         "note": "algorithmic bytes: the validation rows' metrics read once for the scores (8 nv (M + A) with the scores' write), scores and responses "
-                "read by the counting and by the placing sweep (2 x 8 nv (A + P)), every test's key written once and read once (16 T nv)"}
+                "read once by the bounds sweep (8 nv (A + P)); the exact sweeps behind it (a key written once and read once per undecided test) "
+                "carry no byte count: how many tests stay undecided is data"}
     with open('profiles/%s_wilcoxon_kernels_config%d.csv' % (tag, c), 'w') as f:
-        f.write("kernel,launches_per_generation,avg_us,algorithmic_bytes,achieved_GBs,frac_of_hbm_peak\n")
+        f.write("kernel,launches_per_generation,avg_us,algorithmic_bytes,achieved_GBs,frac_of_hbm_peak,keys_per_s\n")
         for r in rows:
-            f.write('"%s",%g,%.2f,%s,%s,%s\n' % (r["kernel"], r["launches_per_generation"], r["avg_us"], r["algorithmic_bytes"], r["achieved_GBs"], r["frac_of_hbm_peak"]))
+            f.write('"%s",%g,%.2f,%s,%s,%s,%s\n' % (r["kernel"], r["launches_per_generation"], r["avg_us"], r["algorithmic_bytes"], r["achieved_GBs"], r["frac_of_hbm_peak"], r["keys_per_s"]))
 json.dump(roof, open('profiles/%s_roofline.json' % tag, 'w'), indent=1)
 for c in cfgs:
     e = roof["config%d" % c]
