@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("ranking_fuzz.py", 60, 23),
     ("resample_fuzz.py", 80, 24),
     ("sharded_fuzz.py", 6, 25),
+    ("wilcoxon_fuzz.py", 12, 26),
 ])
 def test_fuzzer_finds_nothing(tmp_path, script, cases, seed):
     out = str(tmp_path / (script + ".json"))
