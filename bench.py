@@ -461,7 +461,7 @@ def run_rank(args, env):
                     "note": "achieved / frac = ALGORITHMIC flops K K' (3P + 1) (SURVEY 8d) against the dense f16 MFMA peak, the pipe "
                             "the dot products run on; the fp64 operands travel as three f16 limbs, so the matrix pipe ISSUES "
                             "issued_per_algorithmic_flop times that (mfma_issue_frac); the exponentials run as v_exp_f32 on the "
-                            "vector pipe (valu_issue_frac); weights within 5e-7 of the fp64 oracle by the kernel's error budget, largest seen 3.1e-7 (profiles/r03_kde_accuracy.json, r03_generation_fuzz.json).  The chip clocks down "
+                            "vector pipe (valu_issue_frac); weights within 5e-7 of the fp64 oracle by the kernel's error budget, largest seen 3.1e-7 (profiles/history/r03_kde_accuracy.json, r03_generation_fuzz.json).  The chip clocks down "
                             "under this kernel (profiles/: clock from GRBM_GUI_ACTIVE)"}
     else:
         instr_pair = 1 + PPad + 13

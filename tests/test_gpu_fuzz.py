@@ -1,6 +1,6 @@
 """Randomised differential tests: the fuzzers under tests/fuzz/ (each a stand-alone program that replays random shapes and unfriendly
 data against the CPU oracle and prints one verdict line) at a small number of cases with fixed seeds.  Their long runs are
-summarised under profiles/r03_*_fuzz.json; the far-row bug of round 3 (weights.hip, k_wrows: a far coordinate beyond the first
+summarised under profiles/history/r03_*_fuzz.json; the far-row bug of round 3 (weights.hip, k_wrows: a far coordinate beyond the first
 eight parameters) was found by the first of them."""
 import os
 import subprocess

@@ -401,8 +401,8 @@ def _weights_case(P, K, Kp, seed):
 #   ... at 17..32 parameters (two chunks)    3e-7 } (the limb products left out, h1.r2' + r2.h1', grow with sqrt(P))
 #   ... at 33..64 parameters (four chunks)   7e-7 }
 # Largest error over ~15 000 weights per parameter count, every count from 5 to 64, far rows, zero and sixty-binade weights
-# (tests/fuzz/kde_accuracy_sweep.py -> profiles/r03_kde_accuracy.json): 2.15e-7 up to 16 parameters, 2.43e-7 at 17..32, 4.1e-7 at 33..64;
-# over 980 whole generations at random shapes (tests/fuzz/generation_fuzz.py -> profiles/r03_generation_fuzz.json): 3.1e-7 / 3.1e-7 / 5.2e-7.
+# (tests/fuzz/kde_accuracy_sweep.py -> profiles/history/r03_kde_accuracy.json): 2.15e-7 up to 16 parameters, 2.43e-7 at 17..32, 4.1e-7 at 33..64;
+# over 980 whole generations at random shapes (tests/fuzz/generation_fuzz.py -> profiles/history/r03_generation_fuzz.json): 3.1e-7 / 3.1e-7 / 5.2e-7.
 # (the bounds below are for THESE tests' fixed seeds; the kernel's error budget for a weight that one term dominates is 5e-7 / 5.5e-7 / 8e-7)
 KDE_TOL = {"fp64": 1e-9, "auto": 2.5e-7}
 
