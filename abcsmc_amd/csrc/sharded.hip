@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "abc_internal.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -395,8 +396,6 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ds_cap = (size_t)(1.10 * expect + 8.0 * sqrt(expect) + 256.0);
         ds_cap = (ds_cap + 31) / 32 * 32;
     }
-    int* pfail_early = nullptr;          // pinned: the candidate rule's verdict, seen by the host at its wait for the weights
-    int* ds_fail_dev = nullptr;
     const abc_rng rng_entry = *rng;
     size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20) + 8 * (size_t)W * ds_cap * 8;
     const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
@@ -502,9 +501,29 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // ---- 3-5: the K smallest distances of the whole set, their rows ---------------------------------------------------------
     double* theta = io->theta ? io->theta : (double*)abc_ws_alloc(ctx, K * P * 8);
     if (!theta) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+    // The posterior's moments go to the side stream beside the pair sums (below); the event that hands theta over is the completion
+    // signal of the kernel that writes it, not a record behind it (a record between two kernels of the main stream cost ~35 us of
+    // this driver's critical path in the world-1 timeline: scripts/trace_sharded.py)
+    const bool moments_planned = Nn && !uniform_w && P <= 64 && K >= 2 && ctx->side;
+    if (moments_planned && !ctx->ev_theta) {
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, abc_xstream_event_flags()));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, abc_xstream_event_flags()));
+    }
+    bool theta_ev_bound = false;
+    int* pfail_early = nullptr;          // pinned: the selection's verdict, seen by the host at its wait for the weights / at the end
+    int* ds_fail_dev = nullptr;
     if (W == 1) {
-        ABC_TRY(launch_select_smallest(ctx, dist, n, K, row0, io->idx, io->dist));
-        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, io->idx, K, row0, theta, K));
+        // as abc_generation_dev: a bin selection that gave up (degenerate distances) is noticed at the generation's next host visit
+        // and the generation repeats itself with the radix select -- no synchronisation in the middle of the ranking
+        ABC_TRY(launch_select_smallest(ctx, dist, n, K, row0, io->idx, io->dist, true));
+        const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
+        ctx->sel_bins_ran = false;
+        pfail_early = (int*)(ctx->status_pin + 40);
+        *pfail_early = 0;
+        if (bins_deferred) ds_fail_dev = ctx->sel_fail_dev;
+        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, io->idx, K, row0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
+                                   moments_planned ? ctx->ev_theta : nullptr));
+        theta_ev_bound = moments_planned;
     } else if (fast_sel) {
         // gathered sample -> bound of the K-th key -> fixed-capacity candidate lists with their rows, ONE all-gather -> the exact K
         // smallest of the union, picked locally (select.hip: "distributed selection by a gathered sample")
@@ -555,9 +574,15 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
                 ABC_TRY(launch_sort_pairs(ctx, cand_dist, cand_pos, tot));      // stable: equal distances stay in global row order
             }
         }
-        hipLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R,
-                           sdist, (const unsigned long long*)spos, K, (const int*)ds_fail,
-                           (unsigned long long*)io->idx, io->dist, theta);
+        if (moments_planned) {
+            hipExtLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, nullptr, ctx->ev_theta, 0,
+                                  (const char*)rec_all, R, sdist, (const unsigned long long*)spos, K, (const int*)ds_fail,
+                                  (unsigned long long*)io->idx, io->dist, theta);
+            theta_ev_bound = true;
+        } else
+            hipLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R,
+                               sdist, (const unsigned long long*)spos, K, (const int*)ds_fail,
+                               (unsigned long long*)io->idx, io->dist, theta);
         ABC_HIP(ctx, hipGetLastError());
     } else {
         ABC_TRY(launch_select_begin(ctx, K, sel_state, sel_hist));
@@ -638,7 +663,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     double* L_early = nullptr;
     abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool moments_on_side = false;
-    if (Nn && !uniform_weights && P <= 64 && K >= 2 && ctx->side) {
+    if (moments_planned) {
         if (cfg->multivariate) {
             L_early = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
             if (!L_early) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
@@ -648,11 +673,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         side_out.rows = (double*)abc_ws_alloc(ctx, K * (size_t)PPr * sizeof(double));
         if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
         if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
-        if (!ctx->ev_theta) {
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_theta, abc_xstream_event_flags()));
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_moments, abc_xstream_event_flags()));
-        }
-        ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));
+        if (!theta_ev_bound) ABC_HIP(ctx, hipEventRecord(ctx->ev_theta, ctx->stream));      // (the radix protocol's k_place_rows)
         ABC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_theta, 0));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->side;
@@ -731,7 +752,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         };
         {
             const int rc = launch_resample(ctx, rng, io->w, K, cfg->next0, Nn, parent, hook, &pa, uniform_w, raw_early, w_on_host,
-                                           (fast_sel && !uniform_w) ? pfail_early : nullptr, false, &alias_deferred);
+                                           (ds_fail_dev && !uniform_w) ? pfail_early : nullptr, false, &alias_deferred);
             if (rc == ABC_INTERNAL_RETRY) return repeat_with_radix();
             ABC_TRY(rc);
         }
