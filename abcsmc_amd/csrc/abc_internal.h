@@ -233,8 +233,6 @@ inline size_t abc_kde_slices(size_t kn, size_t Kp, int PP) {
 int launch_merge_runs(abc_ctx* ctx, const double* key, const uint64_t* idx, int W, size_t len, double* okey, uint64_t* oidx,
                       uint64_t* osrc = nullptr);
 int launch_sort_pairs(abc_ctx*, double* key, uint64_t* idx, size_t n);
-bool launch_select_bounded(abc_ctx*, const double* dist, size_t n, size_t K, const long long* state, uint64_t* pos_out, double* dist_out,
-                           int* fail_dev, int* rc);
 // distributed radix select stages (state: 8 x int64, hist: 2048 x int32, all-reduced by the caller between hist and pick)
 int launch_select_begin(abc_ctx*, uint64_t K, long long* state, int* hist);
 int launch_select_hist(abc_ctx*, const double* dist, size_t n, const long long* state, int pass, int* hist);
@@ -242,11 +240,6 @@ int launch_select_pick(abc_ctx*, long long* state, int pass, int* hist, uint64_t
 int launch_select_count(abc_ctx*, const double* dist, size_t n, const long long* state, long long* counts);
 int launch_select_compact(abc_ctx*, const double* dist, size_t n, const long long* state, uint64_t n_less,
                           uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out);
-// distributed selection by a gathered sample (select.hip, "distributed selection by a gathered sample")
-int launch_select_sample(abc_ctx*, const double* dist, size_t n, int SL, double* out);
-int launch_select_threshold(abc_ctx*, const double* sample, int S, uint64_t K, uint64_t N, long long* state);
-int launch_select_candidates(abc_ctx*, const double* dist, size_t n, const long long* state, uint64_t idx_base, size_t cap,
-                             uint64_t* idx_out, double* dist_out, uint64_t* hdr);
 int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
                        unsigned long long* val1, size_t n, int byte_lo, int byte_hi);
 // Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n)

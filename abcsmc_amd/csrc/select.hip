@@ -203,11 +203,9 @@ struct BinSel {
     int pad_;
 };
 
-// hi_in (optional): the caller knows an upper bound of the K-th key (state of the distributed selection: keys < hi_in->prefix); the
-// sample then only yields the smallest key, and keys above the bound (the padding of the candidate lists) are left out of it
 __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ dist, size_t n, unsigned long long K,
                                                     BinSel* __restrict__ bs, unsigned int* __restrict__ hist /* nbins + 1 */,
-                                                    int* __restrict__ fail_flag, int nbins, const SelState* __restrict__ hi_in) {
+                                                    int* __restrict__ fail_flag, int nbins) {
     __shared__ unsigned long long sk[BS_S];
     __shared__ unsigned int h[256];
     __shared__ unsigned long long red[16];
@@ -217,11 +215,10 @@ __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ d
     for (int i = t; i < nbins + 1; i += 1024) hist[i] = 0;
     const size_t stride = n / BS_S;
     unsigned long long mn = ~0ull;
-    const unsigned long long bound = hi_in ? hi_in->prefix - 1ull : ~0ull;        // (prefix = bound + 1, or all ones)
     for (int i = t; i < BS_S; i += 1024) {
         const unsigned long long k = key_of(dist[(size_t)i * stride + stride / 2]);
         sk[i] = k;
-        mn = (k < mn && k <= bound) ? k : mn;
+        mn = k < mn ? k : mn;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const unsigned long long v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
@@ -236,7 +233,7 @@ __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ d
     // LDS radix select of the sample's q-th key, most significant bits first.  hi only has to lie at or above it: three passes
     // decide its top 24 bits (sign, exponent, 12 mantissa bits), the rest is filled with ones
     unsigned long long mask = 0;
-    for (int pass = 0; pass < (hi_in ? 0 : 3); pass++) {
+    for (int pass = 0; pass < 3; pass++) {
         const int shift = 56 - 8 * pass;
         if (t < 256) h[t] = 0;
         __syncthreads();
@@ -263,8 +260,7 @@ __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ d
         __syncthreads();
     }
     if (t == 0) {
-        const unsigned long long hi = hi_in ? bound : (s_prefix | ~mask);
-        const unsigned long long lo = mn < hi ? mn : hi;               // (no sampled key at or below a given bound: one bin takes all)
+        const unsigned long long lo = mn, hi = s_prefix | ~mask;
         const unsigned long long span = hi - lo;
         int shift = 0;
         while (shift < 63 && (span >> shift) >= (unsigned long long)(nbins - 1)) shift++;
@@ -841,151 +837,10 @@ int launch_select_compact(abc_ctx* ctx, const double* dist, size_t n, const long
     return ABC_OK;
 }
 
-// ---- distributed selection by a gathered sample (sharded driver, round 3) -----------------------------------------------------
-// Round 2 walked to the global K-th key with six all-reduced radix histograms, a count exchange with a host round trip and three
-// all-gathers.  Here every rank contributes SL evenly spaced local distances (launch_select_sample; ONE all-gather), every rank
-// runs the same LDS radix select on the gathered sample for an upper bound of the K-th key (the sample key of rank
-// K/N S + 4 sigma + 8, its low 40 bits filled with ones: launch_select_threshold), compacts its keys at or below the bound in row
-// order into a fixed-capacity list (launch_select_candidates) and the lists travel, with their rows, in ONE more all-gather; the
-// exact K smallest of the union are then picked locally, the same on every rank.  The candidates' total must reach K and no
-// list may overflow: every rank sees all counts, so all take the same decision to fall back to the radix protocol.
-namespace {
-
-__global__ __launch_bounds__(256) void k_ds_sample(const double* __restrict__ dist, size_t n, int SL, double* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= SL) return;
-    if (n == 0) { out[i] = INFINITY; return; }
-    // evenly spaced over the shard (a shard shorter than the sample repeats rows: harmless)
-    size_t r = (size_t)(((double)i + 0.5) * (double)n / (double)SL);
-    if (r >= n) r = n - 1;
-    out[i] = dist[r];
-}
-
-// one work-group: the gathered sample (S keys, dynamic LDS) -> st->prefix = T with "key < T" <=> "key <= bound" (SelState as
-// the compaction kernels read it: no ties to hand out); q = rank of the bound among the samples
-__global__ __launch_bounds__(1024) void k_ds_threshold(const double* __restrict__ sample, int S, unsigned long long K,
-                                                       unsigned long long N, SelState* __restrict__ st) {
-    extern __shared__ unsigned long long dsk[];
-    __shared__ unsigned int h[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ unsigned int s_rank;
-    const int t = threadIdx.x;
-    for (int i = t; i < S; i += 1024) dsk[i] = key_of(sample[i]);
-    const double f = (double)K / (double)N;
-    double qd = f * S + 4.0 * sqrt(S * f * (1.0 - f)) + 8.0;
-    const unsigned int q = (qd >= (double)(S - 1)) ? (unsigned)(S - 1) : (unsigned int)qd;
-    if (t == 0) { s_prefix = 0; s_rank = q; }
-    __syncthreads();
-    unsigned long long mask = 0;
-    const int lane = t & 63;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int pass = 0; pass < 3; pass++) {
-        const int shift = 56 - 8 * pass;
-        if (t < 256) h[t] = 0;
-        __syncthreads();
-        const unsigned long long prefix = s_prefix;
-        // distances share their leading bits: equal digits are aggregated inside the wave, one LDS add per distinct digit
-        for (int i0 = 0; i0 < S; i0 += 1024) {
-            const int i = i0 + t;
-            const unsigned long long k = (i < S) ? dsk[i] : 0ull;
-            const bool in = (i < S) && ((k & mask) == prefix);
-            const unsigned int d = (unsigned int)(k >> shift) & 255u;
-            unsigned long long peers = __ballot(in);
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const unsigned long long m = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? m : ~m;
-            }
-            if (in && (peers & lt_mask) == 0) atomicAdd(&h[d], (unsigned int)__popcll(peers));
-        }
-        __syncthreads();
-        if (t < 64) {
-            unsigned int c[4], sum = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { c[j] = h[4 * t + j]; sum += c[j]; }
-            unsigned int inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o, 64); if (t >= o) inc += u; }
-            unsigned int run = inc - sum;
-            const unsigned int r = s_rank;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (run <= r && r < run + c[j]) { s_prefix = prefix | ((unsigned long long)(4 * t + j) << shift); s_rank = r - run; }
-                run += c[j];
-            }
-        }
-        mask |= 255ull << shift;
-        __syncthreads();
-    }
-    if (t == 0) {
-        const unsigned long long hi = s_prefix | ~mask;
-        st->prefix = (hi == ~0ull) ? hi : hi + 1;       // keys < prefix <=> keys <= hi
-        st->mask = ~0ull; st->krem = 0; st->n_less = 0; st->ties = 0;
-    }
-}
-
-// header of a candidate list: [0] = the local number of keys at or below the bound (may exceed the capacity)
-__global__ void k_ds_header(const unsigned long long* __restrict__ totals, unsigned long long* __restrict__ hdr) {
-    if (threadIdx.x == 0) hdr[0] = totals[0];
-}
-// entries [count, cap) of a list: sentinels that sort last; keys -> distances for the others
-__global__ __launch_bounds__(256) void k_ds_finish_list(const unsigned long long* __restrict__ totals, size_t cap,
-                                                         const unsigned long long* __restrict__ key, double* __restrict__ dist,
-                                                         unsigned long long* __restrict__ idx) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= cap) return;
-    const unsigned long long cnt = totals[0] < cap ? totals[0] : cap;
-    if (i < cnt) dist[i] = dist_of(key[i]);
-    else { dist[i] = INFINITY; idx[i] = 1ull << 62; }
-}
-
-}  // namespace
-
-int launch_select_sample(abc_ctx* ctx, const double* dist, size_t n, int SL, double* out) {
-    StageTimer tm(ctx, ST_SELECT);
-    hipLaunchKernelGGL(k_ds_sample, dim3((unsigned)((SL + 255) / 256)), dim3(256), 0, ctx->stream, dist, n, SL, out);
-    ABC_HIP(ctx, hipGetLastError());
-    return ABC_OK;
-}
-int launch_select_threshold(abc_ctx* ctx, const double* sample, int S, uint64_t K, uint64_t N, long long* state) {
-    if (S < 1 || (size_t)S * 8 > 128 * 1024) ABC_FAIL(ctx, ABC_ERR_INVALID, "select: sample of %d keys", S);
-    StageTimer tm(ctx, ST_SELECT);
-    const size_t lds = (size_t)S * 8;
-    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_ds_threshold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ds_threshold, dim3(1), dim3(1024), lds, ctx->stream, sample, S, (unsigned long long)K, (unsigned long long)N,
-                       (SelState*)state);
-    ABC_HIP(ctx, hipGetLastError());
-    return ABC_OK;
-}
-// the local keys below state->prefix in row order: at most cap of them -> (dist_out, idx_out) padded with sentinels to cap;
-// hdr[0] = how many there are (more than cap: the list is truncated and the caller's overflow rule applies)
-int launch_select_candidates(abc_ctx* ctx, const double* dist, size_t n, const long long* state, uint64_t idx_base, size_t cap,
-                             uint64_t* idx_out, double* dist_out, uint64_t* hdr) {
-    StageTimer tm(ctx, ST_SELECT);
-    const int nb = (int)((n + CP_CHUNK - 1) / CP_CHUNK);
-    unsigned int* cnt = (unsigned int*)abc_ws_alloc(ctx, (size_t)2 * (nb + 1) * sizeof(unsigned int));
-    unsigned long long* totals = (unsigned long long*)abc_ws_alloc(ctx, 2 * sizeof(unsigned long long));
-    unsigned long long* key = (unsigned long long*)abc_ws_alloc(ctx, (cap ? cap : 1) * 8);
-    if (!cnt || !totals || !key) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
-    if (nb) hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (SelState*)state, cnt, nb);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, ctx->stream, cnt, nb, nb, totals);
-    if (nb) hipLaunchKernelGGL(k_cp_write, dim3(nb), dim3(256), 0, ctx->stream, dist, n, (const SelState*)state, cnt, nb,
-                               (unsigned long long)idx_base, key, (unsigned long long*)idx_out, (const unsigned long long*)nullptr,
-                               (unsigned long long)cap);
-    hipLaunchKernelGGL(k_ds_header, dim3(1), dim3(64), 0, ctx->stream, totals, (unsigned long long*)hdr);
-    if (cap) hipLaunchKernelGGL(k_ds_finish_list, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->stream, totals, cap, key, dist_out,
-                                (unsigned long long*)idx_out);
-    ABC_HIP(ctx, hipGetLastError());
-    return ABC_OK;
-}
-
 // bin path: the caller (defer_check) or this function reads ctx->sel_fail_dev afterwards; see abc_select_check
-static int select_by_bins(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx, double* dist_out,
-                          const long long* hi_state = nullptr, int* fail_dev = nullptr) {
-    if (!fail_dev) {
-        if (!ctx->sel_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->sel_fail_dev, sizeof(int)));
-        fail_dev = ctx->sel_fail_dev;
-    }
+static int select_by_bins(abc_ctx* ctx, const double* dist, size_t n, size_t K, uint64_t idx_base, uint64_t* idx, double* dist_out) {
+    if (!ctx->sel_fail_dev) ABC_HIP(ctx, hipMalloc((void**)&ctx->sel_fail_dev, sizeof(int)));
+    int* const fail_dev = ctx->sel_fail_dev;
     const int nbins = K <= ((size_t)1 << 18) ? BS_NB : BS_NB_BIG;
     BinSel* bs = (BinSel*)abc_ws_alloc(ctx, sizeof(BinSel));
     unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, ((size_t)nbins + 1) * sizeof(unsigned int));
@@ -994,8 +849,7 @@ static int select_by_bins(abc_ctx* ctx, const double* dist, size_t n, size_t K, 
     unsigned long long* tidx = (unsigned long long*)abc_ws_alloc(ctx, (K + BS_CAP) * 8);
     if (!bs || !hist || !cursor || !tkey || !tidx) ABC_FAIL(ctx, ABC_ERR_NOMEM, "select: workspace exhausted");
     StageTimer tm(ctx, ST_SELECT);
-    hipLaunchKernelGGL(k_bs_sample, dim3(1), dim3(1024), 0, ctx->stream, dist, n, (unsigned long long)K, bs, hist, fail_dev, nbins,
-                       (const SelState*)hi_state);
+    hipLaunchKernelGGL(k_bs_sample, dim3(1), dim3(1024), 0, ctx->stream, dist, n, (unsigned long long)K, bs, hist, fail_dev, nbins);
     size_t hb = (n + 255) / 256;
     if (hb > 512) hb = 512;
     const size_t hl = (size_t)nbins * sizeof(unsigned int);
@@ -1072,18 +926,6 @@ int launch_select_smallest(abc_ctx* ctx, const double* dist, size_t n, size_t K,
     if (!failed) return ABC_OK;
     ctx->ws_off = mark;
     return select_by_radix(ctx, dist, n, K, idx_base, idx, dist_out);
-}
-
-// the K smallest of n keys of which the caller knows a bound (state->prefix: keys below it are candidates, the others -- the
-// padding of the distributed selection's candidate lists -- are not looked at), as (position, distance) in ascending (distance,
-// position) order: what a stable sort of all n by distance would put first.  *fail_dev = 1 (and a harmless placeholder result) when
-// a bin outgrows a work-group or fewer than K keys lie below the bound: the caller falls back.  false: shape not taken.
-bool launch_select_bounded(abc_ctx* ctx, const double* dist, size_t n, size_t K, const long long* state, uint64_t* pos_out, double* dist_out,
-                           int* fail_dev, int* rc) {
-    *rc = ABC_OK;
-    if (ctx->sel_force_radix || n < 4 * (size_t)BS_S || K == 0 || K > n || K > ((size_t)1 << 20)) return false;
-    *rc = select_by_bins(ctx, dist, n, K, 0, pos_out, dist_out, state, fail_dev);
-    return true;
 }
 
 int abc_select_check_queue(abc_ctx* ctx, int* slot) {

@@ -189,17 +189,17 @@ struct CandRec {
     __host__ __device__ const unsigned long long* idx(const char* all, int q) const { return (const unsigned long long*)(all + (size_t)q * rec_bytes + 256 + cap * 8); }
     __host__ __device__ const double* rows(const char* all, int q) const { return (const double*)(all + (size_t)q * rec_bytes + 256 + cap * 16); }
 };
-// the candidates' distances as ONE array in (rank, row) = global row order with their positions as payload; thread 0 applies the
-// rule every rank applies alike: the lists must hold the K smallest (their total reaches K) and none may be truncated
-__global__ __launch_bounds__(256) void k_ds_unpack(const char* __restrict__ all, CandRec R, int W, unsigned long long K,
-                                                   double* __restrict__ cand_dist, unsigned long long* __restrict__ cand_pos,
-                                                   int* __restrict__ fail, int* __restrict__ fail_pin) {
+// header of a rank's list: [0] entries, [1] its selection gave up (placeholder entries), [2] the rank's rows
+__global__ void k_ls_header(unsigned long long* __restrict__ hdr, unsigned long long count, unsigned long long n_local, const int* __restrict__ sel_fail) {
+    if (threadIdx.x == 0) { hdr[0] = count; hdr[1] = (sel_fail && *sel_fail) ? 1ull : 0ull; hdr[2] = n_local; }
+}
+// the gathered lists as W contiguous sorted runs (distance, global row); thread 0: did any rank's selection give up?
+__global__ __launch_bounds__(256) void k_ls_unpack(const char* __restrict__ all, CandRec R, int W, double* __restrict__ cand_dist,
+                                                   unsigned long long* __restrict__ cand_idx, int* __restrict__ fail, int* __restrict__ fail_pin) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e == 0) {
-        unsigned long long tot = 0;
         int bad = 0;
-        for (int q = 0; q < W; q++) { const unsigned long long c = R.hdr(all, q)[0]; tot += c; if (c > R.cap) bad = 1; }
-        if (tot < K) bad = 1;
+        for (int q = 0; q < W; q++) if (R.hdr(all, q)[1] != 0ull || R.hdr(all, q)[0] != (unsigned long long)R.cap) bad = 1;
         *fail = bad;
         if (fail_pin) *fail_pin = bad;
     }
@@ -207,11 +207,20 @@ __global__ __launch_bounds__(256) void k_ds_unpack(const char* __restrict__ all,
     const int q = (int)(e / R.cap);
     const size_t j = e % R.cap;
     cand_dist[e] = R.dist(all, q)[j];
-    cand_pos[e] = e;
+    cand_idx[e] = R.idx(all, q)[j];
 }
-// the bin selection among the candidates gave up: the generation repeats with the radix protocol, as for a truncated list
-__global__ void k_ds_join_fail(const int* __restrict__ bin_fail, int* __restrict__ fail, int* __restrict__ fail_pin) {
-    if (threadIdx.x == 0 && *bin_fail) { *fail = 1; if (fail_pin) *fail_pin = 1; }
+// the rule of the local-top protocol: the first K of the merge are the K smallest of the whole set unless some rank may hold an
+// unlisted key at or below the K-th -- i.e. unless its list is not exhaustive and its last key does not lie ABOVE the K-th (an
+// unlisted key EQUAL to it could precede a chosen one of a higher rank in global row order).  NaN compares false: fails, safely.
+__global__ void k_ls_check(const char* __restrict__ all, CandRec R, int W, const double* __restrict__ merged, size_t K, int* __restrict__ fail,
+                           int* __restrict__ fail_pin) {
+    const double kth = merged[K - 1];
+    int bad = 0;
+    for (int q = threadIdx.x; q < W; q += blockDim.x) {
+        const bool exhaustive = R.hdr(all, q)[2] <= (unsigned long long)R.cap;
+        if (!exhaustive && !(R.dist(all, q)[R.cap - 1] > kth)) bad = 1;
+    }
+    if (__any(bad) && threadIdx.x == 0) { *fail = 1; if (fail_pin) *fail_pin = 1; }
 }
 // the K winners in ascending (distance, global row) order = the first K of the sorted candidates: their rows and parameters
 __global__ __launch_bounds__(256) void k_ds_place(const char* __restrict__ all, CandRec R, const double* __restrict__ sdist,
@@ -374,28 +383,24 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     const size_t kbase = K / (size_t)W, krem = K % (size_t)W, kmax = kbase + (krem ? 1 : 0);
     const size_t k0 = (size_t)r * kbase + ((size_t)r < krem ? (size_t)r : krem), kn = kbase + ((size_t)r < krem ? 1 : 0);
 
-    // Selection over the ranks: by a gathered sample (two all-gathers) when the set is large and at most half of it is kept,
-    // else -- and as the fallback when the sample's bound turns out too low or a list overflows -- the radix protocol (six
-    // all-reduced histograms).  The sample: DSL evenly spaced local distances per rank, a power of two <= N / (16 W), S = DSL W
-    // <= 16384 keys in all (128 KB of LDS in launch_select_threshold); the lists' common capacity follows from N, K, S alone.
-    int DSL = 4096;
-    while (DSL > 1 && (size_t)DSL * 16 > N / (size_t)W) DSL >>= 1;
-    while ((size_t)DSL * (size_t)W > 16384) DSL >>= 1;
-    // (the sample has to fit the device's LDS beside the kernel's own 1.1 KB: a build for a 64 KB part halves it, and below 256 keys
-    // per rank the radix protocol runs -- the same decision on every rank, all of them being the same device type)
-    int lds_max = 0;
-    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess) lds_max = 64 << 10;
-    while (DSL > 1 && (size_t)DSL * (size_t)W * 8 + 2048 > (size_t)lds_max) DSL >>= 1;
-    const bool fast_sel = W > 1 && !ctx->sel_force_radix && 2 * K <= N && DSL >= 256;
-    size_t ds_cap = 0;
-    if (fast_sel) {
-        const double f = (double)K / (double)N, S = (double)DSL * W;
-        double q = f * S + 4.0 * sqrt(S * f * (1.0 - f)) + 8.0;      // rank of the bound among the samples (k_ds_threshold)
-        if (q > S - 1) q = S - 1;
-        const double expect = (q + 1.0) / S * (double)N / (double)W;  // keys below it per rank
-        ds_cap = (size_t)(1.10 * expect + 8.0 * sqrt(expect) + 256.0);
-        ds_cap = (ds_cap + 31) / 32 * 32;
+    // Selection over the ranks (round 4, second half): every rank takes the ls_cap smallest of ITS OWN distances in ascending (distance,
+    // row) order -- the single-GPU bin selection on the local shard --, ONE all-gather carries these lists with their parameter rows,
+    // and every rank merges the W sorted runs: the first K of the merge are the K smallest of the whole set in the single-GPU order,
+    // PROVIDED no rank holds an unlisted key below the K-th (every list's last key lies above it).  Rows are dealt to ranks without
+    // regard to their distance, so a rank's share of the K smallest is Binomial(K, 1 / W): ls_cap = K / W + 8 sigma + 64 fails
+    // once in ~1e15 sets on continuous data; massively tied distances (or a rank's bin selection giving up) fail the rule, every rank
+    // sees that in the gathered lists alike, and the generation repeats itself with the radix protocol (six all-reduced histograms),
+    // which also takes small sets (fewer than 4096 rows per rank) and K > N / 2.  (The first half of the round and round 3 gathered
+    // a SAMPLE of the distances first, for a common bound: one collective and six launches more, and the candidates unsorted.)
+    size_t ls_cap = 0;
+    bool local_sel = W > 1 && !ctx->sel_force_radix && 2 * K <= N && N / (size_t)W >= 4096;
+    if (local_sel) {
+        const double mean = (double)K / (double)W, sd = sqrt(mean * (1.0 - 1.0 / (double)W));
+        ls_cap = (size_t)(mean + 8.0 * sd + 64.0);
+        ls_cap = (ls_cap + 31) / 32 * 32;
+        if (ls_cap > N / (size_t)W) local_sel = false;            // (the smallest shard could not fill its list)
     }
+    const size_t ds_cap = ls_cap;
     const abc_rng rng_entry = *rng;
     size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20) + 8 * (size_t)W * ds_cap * 8;
     const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
@@ -524,64 +529,46 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, io->idx, K, row0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
                                    moments_planned ? ctx->ev_theta : nullptr));
         theta_ev_bound = moments_planned;
-    } else if (fast_sel) {
-        // gathered sample -> bound of the K-th key -> fixed-capacity candidate lists with their rows, ONE all-gather -> the exact K
-        // smallest of the union, picked locally (select.hip: "distributed selection by a gathered sample")
-        const int S = DSL * W;
-        double* samp_mine = (double*)abc_ws_alloc(ctx, (size_t)DSL * 8);
-        double* samp_all = (double*)abc_ws_alloc(ctx, (size_t)S * 8);
-        int* ds_fail = (int*)abc_ws_alloc(ctx, sizeof(int));
-        if (!samp_mine || !samp_all || !ds_fail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
-        ABC_TRY(launch_select_sample(ctx, dist, n, DSL, samp_mine));
-        ABC_TRY(comm_all_gather(ctx, samp_mine, samp_all, (size_t)DSL * 8));
-        ABC_TRY(launch_select_threshold(ctx, samp_all, S, K, N, sel_state));
+    } else if (local_sel) {
         CandRec R;
-        R.cap = ds_cap; R.P = P; R.rec_bytes = abc_align(256 + ds_cap * (16 + 8 * P), 256);
-        const size_t tot = (size_t)W * ds_cap;
-        ABC_TRY(xbuf_reserve(ctx, (size_t)(W + 1) * R.rec_bytes + tot * 16 + 4096));
+        R.cap = ls_cap; R.P = P; R.rec_bytes = abc_align(256 + ls_cap * (16 + 8 * P), 256);
+        const size_t tot = (size_t)W * ls_cap;
+        ABC_TRY(xbuf_reserve(ctx, (size_t)(W + 1) * R.rec_bytes + tot * 40 + 4096));
         char* rec_mine = ctx->xbuf;
         char* rec_all = rec_mine + R.rec_bytes;
         double* cand_dist = (double*)(rec_all + (size_t)W * R.rec_bytes);
-        uint64_t* cand_pos = (uint64_t*)(cand_dist + tot);
-        ABC_TRY(launch_select_candidates(ctx, dist, n, sel_state, row0, ds_cap, (uint64_t*)R.idx(rec_mine, 0), (double*)R.dist(rec_mine, 0),
-                                         (uint64_t*)R.hdr(rec_mine, 0)));
-        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, (const uint64_t*)R.idx(rec_mine, 0), ds_cap, row0, (double*)R.rows(rec_mine, 0), ds_cap));
+        uint64_t* cand_idx = (uint64_t*)(cand_dist + tot);
+        double* mrg_dist = (double*)(cand_idx + tot);
+        uint64_t* mrg_idx = (uint64_t*)(mrg_dist + tot);
+        uint64_t* mrg_src = mrg_idx + tot;
+        int* ds_fail = (int*)abc_ws_alloc(ctx, sizeof(int));
+        if (!ds_fail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        // this rank's ls_cap smallest, ascending (distance, global row), straight into its record; a bin selection that gives up
+        // leaves a placeholder and says so in the record's header
+        ABC_TRY(launch_select_smallest(ctx, dist, n, ls_cap, row0, (uint64_t*)R.idx(rec_mine, 0), (double*)R.dist(rec_mine, 0), true));
+        const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
+        ctx->sel_bins_ran = false;
+        hipLaunchKernelGGL(k_ls_header, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long*)R.hdr(rec_mine, 0), (unsigned long long)ls_cap,
+                           (unsigned long long)n, bins_deferred ? (const int*)ctx->sel_fail_dev : (const int*)nullptr);
+        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, (const uint64_t*)R.idx(rec_mine, 0), ls_cap, row0, (double*)R.rows(rec_mine, 0), ls_cap));
         ABC_TRY(comm_all_gather(ctx, rec_mine, rec_all, R.rec_bytes));
         pfail_early = (int*)(ctx->status_pin + 40);
         *pfail_early = 0;
         ds_fail_dev = ds_fail;
-        hipLaunchKernelGGL(k_ds_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R, W,
-                           (unsigned long long)K, cand_dist, (unsigned long long*)cand_pos, ds_fail, pfail_early);
+        hipLaunchKernelGGL(k_ls_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R, W, cand_dist,
+                           (unsigned long long*)cand_idx, ds_fail, pfail_early);
         ABC_HIP(ctx, hipGetLastError());
-        // the first K of the candidates in (distance, global row) order.  Large lists (round 4; K = 1e6 of configs[3]: 1.2e6
-        // candidates were an eight-pass LSD sort on every rank): the single-GPU bin selection with the bound every rank already has
-        // -- the padding lies above it --, whose give-up (a bin of massively tied distances) joins the lists' own: same fallback.
-        // Small ones: a stable sort by distance.
-        const double* sdist = cand_dist;
-        const uint64_t* spos = cand_pos;
-        {
-            uint64_t* bpos = (uint64_t*)abc_ws_alloc(ctx, K * 8);
-            double* bdist = (double*)abc_ws_alloc(ctx, K * 8);
-            int* bfail = (int*)abc_ws_alloc(ctx, sizeof(int));
-            if (!bpos || !bdist || !bfail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
-            int rc = ABC_OK;
-            if (launch_select_bounded(ctx, cand_dist, tot, K, sel_state, bpos, bdist, bfail, &rc)) {
-                ABC_TRY(rc);
-                hipLaunchKernelGGL(k_ds_join_fail, dim3(1), dim3(64), 0, ctx->stream, (const int*)bfail, ds_fail, pfail_early);
-                sdist = bdist;
-                spos = bpos;
-            } else {
-                ABC_TRY(launch_sort_pairs(ctx, cand_dist, cand_pos, tot));      // stable: equal distances stay in global row order
-            }
-        }
+        // W sorted runs -> one sequence; equal distances: lower rank (= lower global rows) first
+        ABC_TRY(launch_merge_runs(ctx, cand_dist, cand_idx, W, ls_cap, mrg_dist, mrg_idx, mrg_src));
+        hipLaunchKernelGGL(k_ls_check, dim3(1), dim3(64), 0, ctx->stream, (const char*)rec_all, R, W, (const double*)mrg_dist, K, ds_fail, pfail_early);
         if (moments_planned) {
             hipExtLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, nullptr, ctx->ev_theta, 0,
-                                  (const char*)rec_all, R, sdist, (const unsigned long long*)spos, K, (const int*)ds_fail,
+                                  (const char*)rec_all, R, (const double*)mrg_dist, (const unsigned long long*)mrg_src, K, (const int*)ds_fail,
                                   (unsigned long long*)io->idx, io->dist, theta);
             theta_ev_bound = true;
         } else
             hipLaunchKernelGGL(k_ds_place, dim3((unsigned)((K * (P + 1) + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)rec_all, R,
-                               sdist, (const unsigned long long*)spos, K, (const int*)ds_fail,
+                               (const double*)mrg_dist, (const unsigned long long*)mrg_src, K, (const int*)ds_fail,
                                (unsigned long long*)io->idx, io->dist, theta);
         ABC_HIP(ctx, hipGetLastError());
     } else {
@@ -643,7 +630,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_HIP(ctx, hipGetLastError());
     }
 
-    // the gathered-sample selection gave up (every rank alike): once more, from the top, with the radix protocol
+    // the local-top selection failed its rule (every rank alike): once more, from the top, with the radix protocol
     auto repeat_with_radix = [&]() -> int {
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->side) ABC_HIP(ctx, hipStreamSynchronize(ctx->side));
@@ -656,7 +643,6 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // ---- doubled variance, importance weights (pair sums: K / G rows per rank) ----------------------------------------------
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;
-    const bool uniform_weights = (Kp == 0 || !io->theta_prev);
     // As in the single-GPU driver: with proposals to draw behind a weight stage, the posterior's moments and everything that
     // follows from them (doubled variance, proposal factor, the perturbation's row-major copy and padded factor) run on the SIDE
     // stream beside the pair sums -- nothing waits for the host any more (the resampling table is built on the device).

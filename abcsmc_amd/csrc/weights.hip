@@ -414,7 +414,7 @@ __device__ __forceinline__ void ks_pieces(double h, double unit_inv, unsigned pc
     rem = h - top;
     for (int k = 3; k < 6; k++) { pc[k] = bf16_bits(rem, &back); rem -= back; }
 }
-constexpr unsigned KS_ONE = 0x3F80u, KS_MONE = 0xBF80u;      // bf16 +1, -1
+constexpr unsigned KS_MONE = 0xBF80u;                       // bf16 -1
 
 // Limb tiles of one set (written by k_wrows below).
 // Output, per tile of 32 rows: `ops` operands of 1 KiB in MFMA fragment order [half h][row r][8 x 16 bit] (lane 32h + r

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # BASELINE configs[3] / configs[4] column shapes (64 metrics x 32 parameters, 8 components; 128 metrics, 32 components)
 SHAPES = {"small": "1500,12,5,4,500,300,1000", "wx": "2100,10,3,6,400,300,900", "config4": "1500,64,32,8,400,300,1200", "config5": "1400,128,16,32,300,250,1000",
-          # large enough for the gathered-sample selection of the C++ driver (N / W >= 4096): 2 x 40000 rows, 8000 kept
+          # large enough for the local-top selection of the C++ driver (N / W >= 4096): 2 x 40000 rows, 8000 kept
           "big": "40000,32,16,8,8000,3000,20000", "big0": "40000,32,16,8,8000,0,20000",
           # ... and for the resampling table to be built on the device (from 20000 entries) on every rank
           "huge": "120000,32,16,8,24000,1000,20000",
@@ -63,19 +63,19 @@ def test_sharded_world2_cabi_driver(tmp_path, shape, port):
 @pytest.mark.parametrize("shape,data,port", [("big", "plain", 29631), ("big0", "plain", 29632), ("big", "ties", 29633), ("big0", "ties", 29634),
                                              ("huge", "plain", 29635), ("huge", "ties", 29636)])
 def test_sharded_world2_cabi_driver_gathered_sample_selection(tmp_path, shape, data, port):
-    """sets large enough for the C++ driver's gathered-sample selection (sample all-gather, bound of the K-th key, candidate
-    lists with their rows in one all-gather, exact pick of the K smallest on every rank): weighted and first-set generations
-    against the single-process oracle; with massively tied distances the candidate lists overflow, every rank takes the same
-    decision and the generation repeats itself with the radix protocol (weighted: at the host's wait for the weights; set 0:
-    at its end) -- same results"""
+    """sets large enough for the C++ driver's local-top selection (every rank's K / W + 8 sigma smallest distances, sorted, with
+    their rows in ONE all-gather; the merge of the W runs on every rank; the rule that no rank may hold an unlisted key at or below
+    the K-th): weighted and first-set generations against the single-process oracle; with massively tied distances the rule
+    fails, every rank takes the same decision and the generation repeats itself with the radix protocol (weighted: at the host's
+    wait for the weights; set 0: at its end) -- same results"""
     res = _launch("cabi", tmp_path, port, shape, "press", data)
     _check(res)
     calls = res["comm_calls"]
     total = sum(calls.values())
     if data == "plain":
-        # broadcast of the pilot shift, packed all-reduce of the statistics, sample all-gather, candidates-with-rows all-gather,
-        # and (weighted generations) the all-gather of the raw weight slices: 5 collectives, 4 in the first set
-        assert calls == {"broadcast": 1, "all_reduce": 1, "all_gather": 2 if shape == "big0" else 3}, calls
+        # broadcast of the pilot shift, packed all-reduce of the statistics, the all-gather of the ranks' sorted lists with their rows,
+        # and (weighted generations) the all-gather of the raw weight slices: 4 collectives, 3 in the first set
+        assert calls == {"broadcast": 1, "all_reduce": 1, "all_gather": 1 if shape == "big0" else 2}, calls
     else:
         assert total > 10 and calls["all_reduce"] >= 7, calls           # ... + the whole radix protocol of the repeat
 
