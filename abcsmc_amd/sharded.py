@@ -358,20 +358,36 @@ class CabiShardedGeneration:
         self.parent = torch.empty(max(nnext_local, 1), dtype=i64, device=d)
         self.seeds = torch.empty(max(nnext_local, 1), dtype=i64, device=d)
         self.ncomp = 0
+        self._nc = C.c_int32(0)
+        self._io_key, self._io, self._args = None, None, None
+        self._call = lib().abc_generation_sharded_dev
 
     def run(self, X, Y, obs, priors, rng, theta_prev=None, w_prev=None, dv_prev=None):
         cfg = self.cfg
-        assert X.shape == (cfg.M, cfg.n_local) and Y.shape == (cfg.P, cfg.n_local) and X.is_contiguous() and Y.is_contiguous()
-        io = _lib.GenerationIO()
-        io.X, io.Y, io.obs, io.priors = X.data_ptr(), Y.data_ptr(), obs.data_ptr(), priors.data_ptr()
-        if theta_prev is not None and cfg.Kp:
-            io.theta_prev, io.w_prev, io.dv_prev = theta_prev.data_ptr(), w_prev.data_ptr(), dv_prev.data_ptr()
-        io.idx, io.dist, io.theta = self.idx.data_ptr(), self.dist.data_ptr(), self.theta.data_ptr()
-        io.w, io.dv, io.L = self.w.data_ptr(), self.dv.data_ptr(), self.L.data_ptr()
-        io.next, io.parent, io.seeds = self.next.data_ptr(), self.parent.data_ptr(), self.seeds.data_ptr()
+        weighted = theta_prev is not None and cfg.Kp
+        # (as device.Generation.run: the argument block of the C call is rebuilt, and the shapes checked, only when a buffer moved
+        # or changed shape -- at a millisecond per generation on eight GPUs a rebuilt ctypes structure per call is several percent)
+        key = (X.data_ptr(), Y.data_ptr(), obs.data_ptr(), priors.data_ptr(),
+               theta_prev.data_ptr() if weighted else 0, w_prev.data_ptr() if weighted else 0,
+               dv_prev.data_ptr() if weighted else 0, X.shape, Y.shape, X.stride(), Y.stride(), obs.shape, priors.shape,
+               theta_prev.shape if weighted else None, theta_prev.stride() if weighted else None,
+               w_prev.shape if weighted else None, dv_prev.shape if weighted else None)
+        if key != self._io_key:
+            assert X.shape == (cfg.M, cfg.n_local) and Y.shape == (cfg.P, cfg.n_local) and X.is_contiguous() and Y.is_contiguous()
+            assert obs.numel() == cfg.M and obs.is_contiguous() and priors.numel() >= 24 * cfg.P
+            io = _lib.GenerationIO()
+            io.X, io.Y, io.obs, io.priors = key[0], key[1], key[2], key[3]
+            if weighted:
+                assert theta_prev.shape == (cfg.P, cfg.Kp) and theta_prev.is_contiguous()
+                assert w_prev.numel() == cfg.Kp and dv_prev.numel() == cfg.P and w_prev.is_contiguous() and dv_prev.is_contiguous()
+                io.theta_prev, io.w_prev, io.dv_prev = key[4], key[5], key[6]
+            io.idx, io.dist, io.theta = self.idx.data_ptr(), self.dist.data_ptr(), self.theta.data_ptr()
+            io.w, io.dv, io.L = self.w.data_ptr(), self.dv.data_ptr(), self.L.data_ptr()
+            io.next, io.parent, io.seeds = self.next.data_ptr(), self.parent.data_ptr(), self.seeds.data_ptr()
+            self._io, self._io_key = io, key
+            self._args = (self.ctx.handle, C.addressof(cfg), C.addressof(io), None, C.addressof(self._nc))
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        nc = C.c_int32(0)
-        self.ctx.check(lib().abc_generation_sharded_dev(self.ctx.handle, C.addressof(cfg), C.addressof(io), C.addressof(rng),
-                                                        C.addressof(nc)))
-        self.ncomp = nc.value
+        a = self._args
+        self.ctx.check(self._call(a[0], a[1], a[2], C.addressof(rng), a[4]))
+        self.ncomp = self._nc.value
         return self

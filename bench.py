@@ -48,6 +48,7 @@ MFMA_F16_PEAK_TF = 2500.0     # same guide: dense f16 / bf16 MFMA peak (v_mfma_f
 MFMA_SUSTAINED_TF = 1247.0    # same guide, 'DVFS give-back' (1): a bare bf16 MFMA loop on RANDOM operands (the chip holds 1.90-1.95 GHz)
 FP64_VALU_PEAK_TF = 78.6      # same guide: fp64 vector peak
 ASSUMED_XGMI_COLLECTIVE_MS = 0.02   # scaling_model: a small RCCL collective over xGMI, ASSUMED (not measurable on one GPU)
+ASSUMED_EXCHANGE_KERNELS_MS = 0.03  # scaling_model: the kernels around the exchanges that a one-GPU run does not launch, ASSUMED
 
 
 def pmc_traffic(kernel_prefix, config, world):
@@ -548,7 +549,7 @@ def run_rank(args, env):
                              "brackets is the clock the chip holds under sustained load relative to the timed region" % args.sustained_s}
         extra = extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, event_overhead_ms)
         scaling_model = scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, RULE,
-                                          ms_per_step, kde_ms * kde_launches, stage_ms, stage_launches, event_overhead_ms)
+                                          ms_per_step, kde_ms * kde_launches, stage_ms, stage_launches, event_overhead_ms, step)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -742,7 +743,7 @@ def predict_scaling(ms_per_step, kde_ms, sharded_ms, collectives, collective_ms,
 
 
 def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, rule, ms_per_step, kde_ms, stage_ms,
-                      stage_launches, event_overhead_ms):
+                      stage_launches, event_overhead_ms, fused_step=None):
     """The N = 1 line's PREDICTION of the strong-scaling curve, so that the first real multi-GPU run can be held against a
     stated number: stage times from this run + the latency of the sharded driver's collectives measured on a ONE-rank RCCL
     communicator (abc_comm_init_rank at world 1: every collective of the protocol is a real RCCL call on this GPU)."""
@@ -755,20 +756,35 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     # collectives of one generation at world > 1 (broadcast of the pilot shift, packed all-reduce of the
     # statistics, the all-gather of the ranks' sorted lists with their rows, and for weighted sets the all-gather of the weight slices)
     coll_ms, ncoll, note, step1, measured = None, 4 if Kp else 3, None, None, 0
+    ratios = []
     c1 = None
     try:
         c1 = _lib.Context(int(torch.device(dev).index or 0))
         c1.comm_init_rccl(1, 0, _lib.comm_unique_id())
         g1 = sharded.CabiShardedGeneration(c1, dev, N, M, P, K, Kp, N, 0.5, A, rule=rule, multivariate=True)
         r1 = abcutil.rng(67890)
-        for _ in range(2):
-            g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(5):
-            g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
-        torch.cuda.synchronize()
-        step1 = 1e3 * (time.perf_counter() - t) / 5
+
+        def block(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t) / reps
+        sharded_step = lambda: g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
+        block(sharded_step, 2)
+        # The sharded driver against the fused one in INTERLEAVED blocks: the pair sums run at a power-limited clock that sags under
+        # sustained load (this leg runs behind the sustained one), so a block measured here is not comparable with the timed
+        # region's step -- the RATIO of neighbouring blocks is (a lone block made the sharded driver look 0.2 ms slower than it is)
+        s_blocks = []
+        for _ in range(3):
+            sb = block(sharded_step)
+            s_blocks.append(sb)
+            if fused_step is not None:
+                ratios.append(sb / block(fused_step))
+        ratios.sort()
+        step1 = min(s_blocks)
         c1.timing_enable(1)
         c1.timing_read(reset=True)
         for _ in range(5):
@@ -789,7 +805,12 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     # the code that runs at G > 1 is the sharded driver: its own world-1 step (fewer overlaps than the fused single-GPU driver) is
     # the base of the prediction when it could be measured; a collective is priced at the larger of the measured world-1 RCCL call
     # and ASSUMED_XGMI_COLLECTIVE_MS (a one-GPU box cannot measure a hop over xGMI: world-1 RCCL calls return in ~0 us)
-    base = step1 if step1 is not None else ms_per_step
+    # The base of the prediction is the timed region's own step plus the exchange steps' kernels that only exist at G > 1 (the list
+    # header, unpack, merge, check and placement, the weight slices' unpadding: six launches at ~5 us, ASSUMED_EXCHANGE_KERNELS_MS).
+    # The sharded driver's world-1 step is reported beside it but NOT used: on one GPU it runs the fused driver's kernels (same
+    # timeline, scripts/trace_sharded.py), and interleaved blocks of the two differ by +-7 % in either direction from run to run
+    # -- the spread of the power-limited pair sums, not a property of either driver.
+    base = ms_per_step + ASSUMED_EXCHANGE_KERNELS_MS
     price = max(coll_ms or 0.0, ASSUMED_XGMI_COLLECTIVE_MS)
     pred = predict_scaling(base, kde_ms, sharded_ms, ncoll, price)
     for g, v in pred.items():              # speed-up and efficiency against the fused single-GPU step (what --gpus 1 measures)
@@ -802,10 +823,11 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
                                           "collectives_per_step": ncoll,
                                           "rccl_world1_collective_ms": None if coll_ms is None else round(coll_ms, 5),
                                           "rccl_world1_collectives_measured_per_step": measured,
-                                          "sharded_driver_world1_step_ms": None if step1 is None else round(step1, 5)},
+                                          "sharded_driver_world1_step_ms": None if step1 is None else round(step1, 5),
+                                          "sharded_over_fused_step_ratio": (round(ratios[len(ratios) // 2], 4) if ratios else None)},
             "predicted": pred,
             "formula": "t(G) = pair_sums/G + row_sharded_streaming/G + replicated + collectives_per_step x collective_price_ms; "
-                       "replicated = sharded_driver_world1_step_ms - pair_sums - row_sharded_streaming",
+                       "replicated = ms_per_step + %.2f ms of exchange kernels (assumed) - pair_sums - row_sharded_streaming" % ASSUMED_EXCHANGE_KERNELS_MS,
             "note": note or "a prediction to hold the first measured curve against, not a measurement; the replicated chain (model fit, "
                             "selection, alias table, weight prologue / epilogue) is the Amdahl term"}
 
