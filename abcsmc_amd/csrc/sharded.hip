@@ -647,8 +647,8 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // follows from them (doubled variance, proposal factor, the perturbation's row-major copy and padded factor) run on the SIDE
     // stream beside the pair sums -- nothing waits for the host any more (the resampling table is built on the device).
     double* L_early = nullptr;
-    abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool moments_on_side = false;
+    abc_theta_fused side_out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool moments_on_side = false, status_early = false;
     if (moments_planned) {
         if (cfg->multivariate) {
             L_early = io->L ? io->L : (double*)abc_ws_alloc(ctx, P * P * 8);
@@ -656,6 +656,11 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         }
         const int PPr = abc_perturb_pp(P);
         side_out.dv = dv; side_out.L = L_early; side_out.spd = spd_dev;
+        // (as the fused driver: the generation's status words go straight into the pinned block from k_post_tail -- no copies behind
+        // the proposals)
+        side_out.model_hdr = model; side_out.hdr_pin = (double*)ctx->status_pin; side_out.spd_pin = L_early ? (int*)(ctx->status_pin + 32) : nullptr;
+        ((double*)ctx->status_pin)[0] = 0.0; *(int*)(ctx->status_pin + 32) = 0;
+        status_early = true;
         side_out.rows = (double*)abc_ws_alloc(ctx, K * (size_t)PPr * sizeof(double));
         if (L_early) side_out.Lpad = (double*)abc_ws_alloc(ctx, (size_t)PPr * PPr * sizeof(double));
         if (!side_out.rows || (L_early && !side_out.Lpad)) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
@@ -752,11 +757,13 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     }
     taus2_jump(rng, 2 * (uint64_t)cfg->Nnext_total);          // Nnext resampling draws + Nnext seeds of the whole set
     {
-        double* hdr = (double*)ctx->status_pin;             // pinned: the two copies queue behind one synchronisation
+        double* hdr = (double*)ctx->status_pin;             // pinned, device-visible
         int* pspd = (int*)(ctx->status_pin + 32);
-        hdr[0] = 0.0; *pspd = 0;
-        ABC_HIP(ctx, hipMemcpyAsync(hdr, model, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(pspd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (!status_early) {                                // (first sets, generations without proposals: the two words by copies)
+            hdr[0] = 0.0; *pspd = 0;
+            ABC_HIP(ctx, hipMemcpyAsync(hdr, model, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (have_spd) ABC_HIP(ctx, hipMemcpyAsync(pspd, spd_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        }
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ncomp_host) *ncomp_host = (int32_t)hdr[0];
         spd = *pspd;

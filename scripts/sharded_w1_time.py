@@ -1,6 +1,6 @@
 """Wall time per generation of the three ways to run configs[2] on one GPU: abc_generation_dev, the sharded driver without a
 communicator, the sharded driver over a one-rank RCCL communicator (what bench.py's scaling_model takes as its base).
-    python scripts/sharded_w1_time.py [steps]"""
+    python scripts/sharded_w1_time.py [steps] [config]"""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ import bench
 from abcsmc_amd import _lib, abcutil, device, sharded, synthetic
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-cfg = bench.CONFIGS[3]
+cfg_id = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cfg = bench.CONFIGS[cfg_id]
 N, M, P, A = cfg["N"], cfg["M"], cfg["P"], cfg["A"]
 K = N // 10
 dev = "cuda:0"
