@@ -774,9 +774,7 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
             return 1e3 * (time.perf_counter() - t) / reps
         sharded_step = lambda: g1.run(dX, dY, dobs, dpri, r1, dtp, dwp, ddvp)
         block(sharded_step, 2)
-        # The sharded driver against the fused one in INTERLEAVED blocks: the pair sums run at a power-limited clock that sags under
-        # sustained load (this leg runs behind the sustained one), so a block measured here is not comparable with the timed
-        # region's step -- the RATIO of neighbouring blocks is (a lone block made the sharded driver look 0.2 ms slower than it is)
+        # The sharded driver against the fused one in INTERLEAVED blocks (reported, not used: see below)
         s_blocks = []
         for _ in range(3):
             sb = block(sharded_step)
@@ -808,8 +806,9 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     # The base of the prediction is the timed region's own step plus the exchange steps' kernels that only exist at G > 1 (the list
     # header, unpack, merge, check and placement, the weight slices' unpadding: six launches at ~5 us, ASSUMED_EXCHANGE_KERNELS_MS).
     # The sharded driver's world-1 step is reported beside it but NOT used: on one GPU it runs the fused driver's kernels (same
-    # timeline, scripts/trace_sharded.py), and interleaved blocks of the two differ by +-7 % in either direction from run to run
-    # -- the spread of the power-limited pair sums, not a property of either driver.
+    # timeline, scripts/trace_sharded.py), and which of two contexts of one process is faster depends on the hardware queues their
+    # streams land on (four by default: a second context's side stream can share its main stream's queue and lose the overlap,
+    # +0.09 .. 0.18 ms per generation; with GPU_MAX_HW_QUEUES=8 the routes agree: scripts/sharded_w1_time.py) -- not on the driver.
     base = ms_per_step + ASSUMED_EXCHANGE_KERNELS_MS
     price = max(coll_ms or 0.0, ASSUMED_XGMI_COLLECTIVE_MS)
     pred = predict_scaling(base, kde_ms, sharded_ms, ncoll, price)
