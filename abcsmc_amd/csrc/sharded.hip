@@ -189,6 +189,52 @@ struct CandRec {
     __host__ __device__ const unsigned long long* idx(const char* all, int q) const { return (const unsigned long long*)(all + (size_t)q * rec_bytes + 256 + cap * 8); }
     __host__ __device__ const double* rows(const char* all, int q) const { return (const double*)(all + (size_t)q * rec_bytes + 256 + cap * 16); }
 };
+// The ranks' statistics records -- each about its own pilot shift t_r: counts n_r, sums s_r = sum (x - t_r), products
+// G_r = sum (x - t_r)(x - t_r)' per partition -- as ONE record about rank 0's shift: with d_r = t_r - t_0,
+//   sum (x - t_0) = s_r + n_r d_r,   sum (x - t_0)(x - t_0)' = G_r + d_r s_r' + s_r d_r' + n_r d_r d_r',
+// added up in rank order (the same bits on every rank).  The shifts are all near the column means, so the corrections are small
+// against G_r: nothing of the one-pass statistics' accuracy is lost.  Entries no rank has computed (the pure Y'Y blocks off their
+// diagonal, padding) stay zero.
+__global__ __launch_bounds__(256) void k_stats_merge(const double* __restrict__ all, int W, StatsLayout L, double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, C = L.C16;
+    if (e < 2) {                                             // the counts
+        double n = 0.0;
+        for (int r = 0; r < W; r++) n += all[(size_t)r * L.len + L.off_n + e];
+        out[L.off_n + e] = n;
+        return;
+    }
+    size_t q = e - 2;
+    if (q < C) { out[L.off_shift + q] = all[L.off_shift + q]; return; }          // rank 0's shift
+    q -= C;
+    if (q < 2 * C) {                                         // the column sums of a partition
+        const int p = (int)(q / C);
+        const size_t i = q % C;
+        double acc = 0.0;
+        for (int r = 0; r < W; r++) {
+            const double* rec = all + (size_t)r * L.len;
+            const double d = rec[L.off_shift + i] - all[L.off_shift + i];
+            acc += fma(rec[L.off_n + p], d, rec[L.off_sum[p] + i]);
+        }
+        out[L.off_sum[p] + i] = acc;
+        return;
+    }
+    q -= 2 * C;
+    if (q >= 2 * C * C) return;
+    const int p = (int)(q / (C * C));
+    const size_t ij = q % (C * C), i = ij % C, j = ij / C;
+    double acc = 0.0;
+    bool any = false;
+    for (int r = 0; r < W; r++) {
+        const double* rec = all + (size_t)r * L.len;
+        const double g = rec[L.off_G[p] + ij];
+        any = any || g != 0.0;
+        const double di = rec[L.off_shift + i] - all[L.off_shift + i], dj = rec[L.off_shift + j] - all[L.off_shift + j];
+        const double si = rec[L.off_sum[p] + i], sj = rec[L.off_sum[p] + j], nr = rec[L.off_n + p];
+        acc += g + fma(di, sj, fma(si, dj, nr * di * dj));
+    }
+    out[L.off_G[p] + ij] = (any || i == j) ? acc : 0.0;
+}
+
 // header of a rank's list: [0] entries, [1] its selection gave up (placeholder entries), [2] the rank's rows
 __global__ void k_ls_header(unsigned long long* __restrict__ hdr, unsigned long long count, unsigned long long n_local, const int* __restrict__ sel_fail) {
     if (threadIdx.x == 0) { hdr[0] = count; hdr[1] = (sel_fail && *sel_fail) ? 1ull : 0ull; hdr[2] = n_local; }
@@ -402,7 +448,8 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     }
     const size_t ds_cap = ls_cap;
     const abc_rng rng_entry = *rng;
-    size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20) + 8 * (size_t)W * ds_cap * 8;
+    size_t need = abc_ws_need(n, M, P, A, K, Kp, Nn) + (size_t)W * kmax * 8 + 4 * kloc * 8 + (1u << 20) + 8 * (size_t)W * ds_cap * 8 +
+                  (size_t)(W + 1) * stats_layout(M, P).len * 8;
     const uint64_t ntrain = (uint64_t)llround((double)N * cfg->train_frac);                  // AbcUtil.cpp:438, global rows
     if (cfg->rule == ABC_RULE_WILCOXON) {
         // the validation rows of the whole set are assembled on every rank (all-gather of the shards' validation rows)
@@ -431,8 +478,9 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     ctx->side_early_waited = false;
     ctx->side_forked = false;
     ABC_TRY(abc_side_fork(ctx));
+    // Every rank takes its statistics about ITS OWN pilot shift (round 4: no broadcast of rank 0's in front of the pass over the
+    // rows); the records are all-gathered and every rank re-centres them on rank 0's shift while it adds them up (k_stats_merge).
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
-    ABC_TRY(comm_broadcast(ctx, stats + SL.off_shift, SL.C16 * 8, 0));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
     // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream
     uint32_t* raw_early = nullptr;
@@ -444,8 +492,12 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     ctx->side_forked = false;
     if (W > 1) {
-        if (r != 0) ABC_HIP(ctx, hipMemsetAsync(stats + SL.off_shift, 0, SL.C16 * 8, ctx->stream));    // the sum keeps rank 0's shift
-        ABC_TRY(comm_all_reduce(ctx, stats, SL.len, ABC_DT_F64));
+        double* stats_all = (double*)abc_ws_alloc(ctx, (size_t)W * SL.len * 8);
+        if (!stats_all) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+        ABC_TRY(comm_all_gather(ctx, stats, stats_all, SL.len * 8));
+        const size_t ne = 2 * SL.C16 * SL.C16 + 3 * SL.C16 + 2;
+        hipLaunchKernelGGL(k_stats_merge, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)stats_all, W, SL, stats);
+        ABC_HIP(ctx, hipGetLastError());
     }
     ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
     if (cfg->rule == ABC_RULE_WILCOXON && W == 1)

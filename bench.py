@@ -761,9 +761,9 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     def st(name):
         return max(stage_ms.get(name, 0.0) - event_overhead_ms * stage_launches.get(name, 0), 0.0)
     sharded_ms = st("k_gram") + st("project_distance") + st("perturb")
-    # collectives of one generation at world > 1 (broadcast of the pilot shift, packed all-reduce of the
-    # statistics, the all-gather of the ranks' sorted lists with their rows, and for weighted sets the all-gather of the weight slices)
-    coll_ms, ncoll, note, step1, measured = None, 4 if Kp else 3, None, None, 0
+    # collectives of one generation at world > 1 (the all-gathers of the ranks' statistics records, of their sorted
+    # lists with their rows, and for weighted sets of the weight slices)
+    coll_ms, ncoll, note, step1, measured = None, 3 if Kp else 2, None, None, 0
     ratios = []
     c1 = None
     try:

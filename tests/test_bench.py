@@ -92,7 +92,7 @@ def test_bare_two_rank_launch_on_one_gpu():
     j = lines[0]
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "strong"
     assert "started by bench.py itself" in j["config"]["launcher"]
-    assert j["config"]["collectives"].startswith("torch.distributed callbacks") and j["config"]["collectives_per_step"] >= 3
+    assert j["config"]["collectives"].startswith("torch.distributed callbacks") and j["config"]["collectives_per_step"] >= 2
     assert j["config"]["particles_per_gpu"] * 2 == j["config"]["particles_total"]
     assert j["roofline"]["frac"] > 0 and j["cpu_baseline"] is None
 
@@ -108,7 +108,7 @@ def test_single_process_route_on_one_gpu():
     assert len(lines) == 1
     j = lines[0]
     assert j["n_gpus"] == 1 and "one host thread per GPU" in j["config"]["launcher"]
-    assert "ncclCommInitAll" in j["config"]["collectives"] and j["config"]["collectives_per_step"] >= 1
+    assert "ncclCommInitAll" in j["config"]["collectives"] and j["config"]["collectives_per_step"] == 0          # (none has a peer at world 1)
     assert j["value"] > 0 and j["config"]["particles_per_gpu"] == j["config"]["particles_total"]
 
 
@@ -122,7 +122,7 @@ def test_n1_line_carries_both_component_rules_and_a_scaling_prediction():
     ex = j["extra"]
     assert ex["wilcoxon_rule_step_ms"] > 0 and ex["ranking_pls_wilcoxon_ms"] > 0 and ex["wilcoxon_rule_ncomp"] >= 1
     sm = j["scaling_model"]
-    assert set(sm["predicted"]) == {"2", "4", "8"} and sm["from"]["collectives_per_step"] in (3, 4)
+    assert set(sm["predicted"]) == {"2", "4", "8"} and sm["from"]["collectives_per_step"] in (2, 3)
     assert sm["from"]["rccl_world1_collective_ms"] is None or sm["from"]["rccl_world1_collective_ms"] >= 0
     # (at this small configuration the replicated chain and the collectives outweigh what sharding saves: the prediction may well be
     # SLOWER than one GPU -- it has to be self-consistent, not flattering)

@@ -73,11 +73,11 @@ def test_sharded_world2_cabi_driver_gathered_sample_selection(tmp_path, shape, d
     calls = res["comm_calls"]
     total = sum(calls.values())
     if data == "plain":
-        # broadcast of the pilot shift, packed all-reduce of the statistics, the all-gather of the ranks' sorted lists with their rows,
-        # and (weighted generations) the all-gather of the raw weight slices: 4 collectives, 3 in the first set
-        assert calls == {"broadcast": 1, "all_reduce": 1, "all_gather": 1 if shape == "big0" else 2}, calls
+        # the all-gather of the ranks' statistics records (each about its own pilot shift), the all-gather of the ranks' sorted lists
+        # with their rows, and (weighted generations) the all-gather of the raw weight slices: 3 collectives, 2 in the first set
+        assert {k: v for k, v in calls.items() if v} == {"all_gather": 2 if shape == "big0" else 3}, calls
     else:
-        assert total > 10 and calls["all_reduce"] >= 7, calls           # ... + the whole radix protocol of the repeat
+        assert total > 10 and calls["all_reduce"] >= 6, calls           # ... + the whole radix protocol of the repeat
 
 
 @pytest.mark.gpu
@@ -209,19 +209,20 @@ def test_a_raising_collective_callback_fails_the_generation():
         calls.append("reduce")
         return 0
 
-    def ok_gather(send, recv, nbytes, stream):
+    def bad_gather(send, recv, nbytes, stream):
         calls.append("gather")
-        return 0
-
-    def bad_broadcast(buf, nbytes, root, stream):
-        calls.append("broadcast")
         raise TimeoutError("peer did not answer")
 
-    ctx.comm_init_callbacks(1, 0, ok_reduce, ok_gather, bad_broadcast)
+    def ok_broadcast(buf, nbytes, root, stream):
+        calls.append("broadcast")
+        return 0
+
+    # rank 0 of a world of two: the first exchange of a generation is the all-gather of the statistics records
+    ctx.comm_init_callbacks(2, 0, ok_reduce, bad_gather, ok_broadcast)
     g = sharded.CabiShardedGeneration(ctx, dev, N, M, P, K, Kp, Nn, 0.5, A)
     with pytest.raises(_lib.AbcError) as e:
         g.run(*args, pri, abcutil.rng(5), *prev)
-    assert e.value.code == -6 and "broadcast" in str(e.value)                   # ABC_ERR_COMM
-    assert isinstance(ctx.comm_callback_error, TimeoutError) and calls == ["broadcast"]
+    assert e.value.code == -6 and "all_gather" in str(e.value)                  # ABC_ERR_COMM
+    assert isinstance(ctx.comm_callback_error, TimeoutError) and calls == ["gather"]
     torch.cuda.synchronize()
     ctx.close()
