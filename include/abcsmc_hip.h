@@ -238,10 +238,10 @@ int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, const abc_ge
 /* Doubles needed for one sufficient-statistics record for (M,P):
  *   [ n_train, n_test, shift[C16], sum_train[C16], sum_test[C16], G_train[C16*C16], G_test[C16*C16] ]
  * with C16 = 16*ceil((M+P)/16).  Records from different row shards that used the same shift are
- * combined by plain addition of everything after shift[] (that is the packed all-reduce). */
+ * combined by plain addition of everything after shift[]; records about different shifts are re-centred first
+ * (abc_generation_sharded_dev all-gathers the ranks' records, each about its own pilot shift, and merges them). */
 size_t abc_stats_len(size_t M, size_t P);
-/* pilot shift (mean of the first min(n,256) local rows) -> stats record's shift[]; rank 0's
- * record is broadcast before abc_stats_accumulate_dev in the sharded driver. */
+/* pilot shift (mean of the first min(n,256) local rows) -> stats record's shift[] */
 int abc_stats_shift_dev(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx,
                         size_t ldy, size_t M, size_t P, double* stats);
 /* one pass over the local rows: column sums + Gram of the shifted [X|Y], train rows =
@@ -313,9 +313,11 @@ int abc_perturb_dev(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_
 /* The reference has no multi-device path (its MPI farm distributes simulator calls, AbcMPI.cpp:28-143, and is compiled
  * out); this is the particle sharding BASELINE.json's north_star asks for.  One context per GPU; a communicator is attached
  * to each context and the sharded entry points below run the same protocol on every rank:
- *   broadcast of the pilot shift, ONE packed all-reduce of the sufficient statistics (<= 0.35 MB), six all-reduces of a
- *   2048-bin radix histogram (exact global K-th distance), all-gathers of the per-rank winner lists and of the winners'
- *   parameter rows, all-gather of the per-rank weight slices; resampling / perturbation need no exchange.
+ *   all-gather of the ranks' sufficient-statistics records (<= 0.35 MB each, merged on every rank), all-gather of the ranks'
+ *   sorted local-top lists with their parameter rows (merged on every rank: the K smallest of the whole set), all-gather of the
+ *   per-rank weight slices; resampling / perturbation need no exchange.  Small sets, K > N / 2 and massively tied distances take
+ *   the radix protocol instead of the lists: six all-reduces of a 2048-bin histogram (exact global K-th distance) and
+ *   all-gathers of the per-rank winner lists and rows.
  * Communicators: RCCL over xGMI (one process per GPU: abc_comm_unique_id + abc_comm_init_rank; or one process driving
  * several GPUs: abc_ctx_create_multi), or collectives supplied by the caller (abc_comm_init_callbacks: any transport; used
  * by the tests to run two ranks over gloo on one GPU). */
