@@ -32,11 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # A context drives a generation on TWO streams (ranking / weights beside the rng streams, the previous set's tiles, the posterior's
-# moments).  The runtime maps streams onto four hardware queues by default; in a process that holds more streams than that -- a rank
-# under torch.distributed has PyTorch's and RCCL's as well -- a context's two streams can land on ONE queue and run one after the
-# other: +0.1 .. 0.2 ms per generation (measured: scripts/sharded_w1_time.py).  Eight queues give every stream
-# of such a process its own; the one-context timed region of an N = 1 run is the same with four and with eight.  (Set before
-# anything initialises the GPU; a value already in the environment wins.)
+# moments).  The runtime maps a process's streams onto four hardware queues by default; in a process that holds more streams than
+# that (several contexts; a rank under torch.distributed has PyTorch's and RCCL's as well) a generation was measured 0.1 .. 0.2 ms
+# slower on one of the contexts (scripts/sharded_w1_time.py), and with eight queues it is not; the one-context
+# timed region of an N = 1 run is the same with four and with eight.  (Set before anything initialises the GPU; a value already in
+# the environment wins.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # BASELINE.json configs: TOTAL sizes as stated (K = K' = 0.1 N, N_next = N, train fraction 0.5, MULTIVARIATE); `gpus` = the
