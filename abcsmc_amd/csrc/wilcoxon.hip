@@ -1301,6 +1301,8 @@ static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const dou
         else if (R == 2) WX_BINS(16, 2, mode, bh);
         else WX_BINS(32, 1, mode, bh);
         if (pass < 0) {
+            if ((size_t)NB * g.F * 8 > (48u << 10))
+                ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NB * g.F * 8)));
             hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)nseg_max), dim3(1024), (size_t)NB * g.F * 8, st, g, (const WxPlan*)plan,
                                (const unsigned int*)blockfine, nz, v3, fail + 1);
             // the reduction's host visit, here rather than at its end: with every test settled (the usual case) nothing else is

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("resample_fuzz.py", 80, 24),
     ("sharded_fuzz.py", 6, 25),
     ("wilcoxon_fuzz.py", 12, 26),
+    ("wide_gram_fuzz.py", 4, 27),
 ])
 def test_fuzzer_finds_nothing(tmp_path, script, cases, seed):
     out = str(tmp_path / (script + ".json"))

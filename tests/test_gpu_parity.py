@@ -1556,9 +1556,6 @@ def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
             full = np.abs(G[part][:M, :C] - ref[:M, :C]) / scale[:M, :C]
             wa, wb = np.unravel_index(np.argmax(full), full.shape)
             where = "partition %d, columns (%d, %d): %.17g against %.17g" % (part, wa, wb, G[part][wa, wb], ref[wa, wb])
-            if kind == "spikes":
-                rows = [r for r in (5, 12345, 777, N // 2 + 1, N - 2, N // 2) if a <= r < b]
-                where += "; diff %.6g, products of the spike rows %s" % (G[part][wa, wb] - ref[wa, wb], [float(V[r - a, wa] * V[r - a, wb]) for r in rows])
         assert np.allclose(G[part][:M, :C], G[part][:C, :M].T)                                       # symmetric where both halves exist
     print("wide Gram %s N=%d: worst off-diagonal error %.2e of sqrt(G_aa G_bb) (%s)" % (kind, N, worst, where))
     assert worst <= 5e-10, worst

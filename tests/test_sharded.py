@@ -62,7 +62,7 @@ def test_sharded_world2_cabi_driver(tmp_path, shape, port):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,data,port", [("big", "plain", 29631), ("big0", "plain", 29632), ("big", "ties", 29633), ("big0", "ties", 29634),
                                              ("huge", "plain", 29635), ("huge", "ties", 29636)])
-def test_sharded_world2_cabi_driver_gathered_sample_selection(tmp_path, shape, data, port):
+def test_sharded_world2_cabi_driver_local_top_selection(tmp_path, shape, data, port):
     """sets large enough for the C++ driver's local-top selection (every rank's K / W + 8 sigma smallest distances, sorted, with
     their rows in ONE all-gather; the merge of the W runs on every rank; the rule that no rank may hold an unlisted key at or below
     the K-th): weighted and first-set generations against the single-process oracle; with massively tied distances the rule
