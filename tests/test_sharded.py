@@ -84,7 +84,7 @@ def test_sharded_world2_cabi_driver_local_top_selection(tmp_path, shape, data, p
 @pytest.mark.parametrize("shape,port", [("small", 29641), ("big", 29642), ("config4", 29643), ("config5", 29644), ("huge", 29645)])
 def test_sharded_world2_rccl_two_gpus(tmp_path, shape, port):
     """abc_comm_init_rank at world size 2, one GPU per rank: every collective of the sharded generation through RCCL itself
-    (the callbacks tests share one GPU, which RCCL does not allow) -- the radix protocol (small), the gathered-sample selection
+    (the callbacks tests share one GPU, which RCCL does not allow) -- the radix protocol (small), the local-top selection
     (big), the BASELINE configs[3] / configs[4] column shapes (64 metrics x 32 parameters; 128 metrics, 32 components) and a set
     whose resampling table is built on the device on every rank (huge).  Skipped on a one-GPU box; runs on any box with two."""
     import torch
