@@ -9,6 +9,9 @@ SO_PATH = os.environ.get("ABCSMC_HIP_SO") or os.path.join(_HERE, "libabcsmc_hip.
 
 PRIOR_GAUSS, PRIOR_UNIF_INT, PRIOR_UNIF_REAL = 0, 1, 2
 RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
+# the drop-in's default everywhere (C++ facade ABC::component_rule, the shell's "pls_component_rule", these mirrors, bench.py): SURVEY A.2's
+# best knowledge of upstream's optimal_num_components -- argmin PRESS reduced by the Wilcoxon signed-rank test
+RULE_DEFAULT = RULE_WILCOXON
 KDE_AUTO, KDE_FP64 = 0, 1
 KDE_RAN_NONE, KDE_RAN_FP64, KDE_RAN_SPLIT = 0, 1, 2
 DT_F64, DT_I32, DT_I64 = 0, 1, 2

@@ -37,7 +37,7 @@ def rng_get(r):
 
 
 def particle_ranking_PLS(X_orig, Y_orig, target_values, training_fraction, K=None, max_comp=0,
-                         rule=_lib.RULE_MIN_PRESS, details=False, ctx=None):
+                         rule=_lib.RULE_DEFAULT, details=False, ctx=None):
     """ABC::particle_ranking_PLS (AbcUtil.cpp:423-458).  Returns the ascending-distance particle
     indices (first K; K=None -> all N as the reference)."""
     ctx = _ctx(ctx)

@@ -36,9 +36,10 @@ struct abc_ctx {
     // pinned host scratch
     char* pin;
     size_t pin_bytes;
-    // 64 pinned bytes for the status words a generation reads back at its end (component count, Cholesky status, selection
+    // 128 pinned bytes.  [0, 64): the status words a generation reads back at its end (component count, Cholesky status, selection
     // flag): into pinned memory the three small copies are queued back to back behind ONE synchronisation; into pageable
-    // memory each one is a blocking round trip (17 + 50 us of gaps at the end of a generation, rocprofv3 timeline)
+    // memory each one is a blocking round trip (17 + 50 us of gaps at the end of a generation, rocprofv3 timeline).
+    // [64, 128): the words of the Wilcoxon cascade (tests left after a level, the largest validation-row count of a rank: wilcoxon.hip)
     char* status_pin;
     // cached alias table (device) for the last weights vector handed to abc_resample_dev
     double* alias_F;
@@ -78,6 +79,8 @@ struct abc_ctx {
     int* sel_fail_dev;       // device: the sampled-range bin selection gave up (select.hip); read by abc_select_check
     bool sel_bins_ran;       // the last launch_select_smallest took the bin path and has not been checked yet
     bool sel_force_radix;    // set by a caller that repeats its work after a failed bin selection
+    bool wx_gather_rows;     // diagnostic (ABC_DIAG=1 ABC_WX_GATHER=1, set at context creation): the sharded generation's Wilcoxon rule by
+                             // gathering the validation rows on every rank (rounds 1-4) instead of the sharded cascade
     bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
     int nev;
     struct { hipEvent_t a, b; int stage; } ev[256];
@@ -171,9 +174,11 @@ __host__ __device__ static inline StatsLayout stats_layout(size_t M, size_t P) {
 
 // ---- model record layout ---------------------------------------------------------------
 // [ ncomp, A, n_total, pad, mean[M+P], sd[M+P], zobs[M], obs_scores[A], R[M*A], Q[P*A], W[M*A],
-//   Pl[M*A], press[A*P], per_response[P] ]
+//   Pl[M*A], H[A*A], press[A*P], per_response[P] ]
+// H = R' (X'X of the z-scored validation rows) R: the second moments of the validation scores, a by-product of PRESS (round 5: the
+// Wilcoxon reduction takes the scale of every test's paired differences from it, wilcoxon.hip)
 struct ModelLayout {
-    size_t off_hdr, off_mean, off_sd, off_zobs, off_oscore, off_R, off_Q, off_W, off_P, off_press,
+    size_t off_hdr, off_mean, off_sd, off_zobs, off_oscore, off_R, off_Q, off_W, off_P, off_H, off_press,
         off_per, len;
 };
 __host__ __device__ static inline ModelLayout model_layout(size_t M, size_t P, size_t A) {
@@ -187,7 +192,8 @@ __host__ __device__ static inline ModelLayout model_layout(size_t M, size_t P, s
     m.off_Q = m.off_R + M * A;
     m.off_W = m.off_Q + P * A;
     m.off_P = m.off_W + M * A;
-    m.off_press = m.off_P + M * A;
+    m.off_H = m.off_P + M * A;
+    m.off_press = m.off_H + A * A;
     m.off_per = m.off_press + A * P;
     m.len = m.off_per + P;
     return m;
@@ -205,6 +211,8 @@ int launch_simple_model(abc_ctx*, const double* stats, const double* obs, size_t
                         double* model);
 int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P,
                             size_t A, const double* model, int simple, double* dist);
+// scores of n rows (all A components) by the projection kernels: S[i + n k]; returns the rows taken (an even count, 0: not their shape)
+size_t launch_project_scores(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model, double* S);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out, bool defer_check = false);
 int abc_select_check(abc_ctx* ctx, int* failed);
@@ -242,9 +250,23 @@ int launch_select_compact(abc_ctx*, const double* dist, size_t n, const long lon
                           uint64_t ties_take, uint64_t idx_base, uint64_t* idx_out, double* dist_out);
 int abc_sort_u64_bytes(abc_ctx*, unsigned long long* key0, unsigned long long* val0, unsigned long long* key1,
                        unsigned long long* val1, size_t n, int byte_lo, int byte_hi);
-// Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n)
+// Wilcoxon reduction of the per-response component counts (rule ABC_RULE_WILCOXON); test rows = [row_test, n).
+// sh (row-sharded sets, sharded.hip): X / Y are THIS rank's rows; the counts of every level of the bounds cascade are all-reduced
+// over the context's communicator, the keys of the tests the bounds leave undecided are all-gathered (wilcoxon.hip).  Returns
+// ABC_INTERNAL_RETRY when the set is not one the cascade takes (abc_wx_cascade_applies) or a bin of its exact step outgrew LDS:
+// the caller then gathers the validation rows and calls again without sh.
+struct abc_wx_shard {
+    size_t nv_total;          // validation rows of the whole set
+    const double* nv_ranks;   // device: nv_ranks[q * nv_stride] = validation rows of rank q (the n_test word of its statistics record)
+    size_t nv_stride;
+};
+bool abc_wx_cascade_applies(size_t nv_total, size_t P, size_t A);
 int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
-                    size_t A, size_t row_test, double* model);
+                    size_t A, size_t row_test, double* model, const abc_wx_shard* sh = nullptr);
+// collectives on the context's stream and the exchange buffer (sharded.hip)
+int abc_comm_all_reduce(abc_ctx* ctx, void* buf, size_t count, int dtype);
+int abc_comm_all_gather(abc_ctx* ctx, const void* send, void* recv, size_t bytes);
+int abc_xbuf_reserve(abc_ctx* ctx, size_t bytes);
 // sel_fail / sel_fail_pin (fused drivers): the bin selection's give-up flag is stored into the pinned status block by this
 // kernel, and the proposals' give-up counter is snapshotted into its second slot.  done: an event bound to the kernel's OWN
 // completion signal (hipExtLaunchKernelGGL's stop event) -- a hipEventRecord behind it is one more packet in the queue, and the

@@ -82,8 +82,9 @@ extern "C" int abc_ctx_create(int device, abc_ctx** out) {
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ABC_ERR_HIP; }
-    if (hipHostMalloc((void**)&ctx->status_pin, 64, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ABC_ERR_HIP; }
+    if (hipHostMalloc((void**)&ctx->status_pin, 128, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ABC_ERR_HIP; }
     ctx->stream = ctx->own_stream;
+    ctx->wx_gather_rows = abc_diag_env("ABC_WX_GATHER") != nullptr;
     *out = ctx;
     return ABC_OK;
 }

@@ -689,6 +689,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit(const double* __restrict__ 
         }
     }
     PLS_SYNC();
+    for (int e = lane; e < A * A; e += NT) model[ML.off_H + e] = H[e];          // (the Wilcoxon reduction's scales)
     double* press = model + ML.off_press;   // A x P, column-major
     for (int j = lane; j < P; j += NT) {
         double lin = 0.0, quad = 0.0;
@@ -1199,6 +1200,7 @@ __global__ __launch_bounds__(64 * NW) void k_pls_fit16(const double* zwork, cons
         addm[e] = dot_ahead<16>(Ql + j, P, H + a, A, a, 0.0);
     }
     for (int k = tid; k < A; k += NT) model[ML.off_oscore + k] = dot_ahead<16>(wv, 1, Rl + (size_t)M * k, 1, M, 0.0);
+    for (int e = tid; e < A * A; e += NT) model[ML.off_H + e] = H[e];           // (the Wilcoxon reduction's scales)
     __syncthreads();
     double* press = model + ML.off_press;   // A x P, column-major
     double* perl = qp;                      // P: per-response component counts

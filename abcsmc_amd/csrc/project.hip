@@ -63,11 +63,14 @@ template <int KC>
 __global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restrict__ X, size_t npairs, size_t ldx, int M,
                                                            const double* __restrict__ mean, const double* __restrict__ sd,
                                                            const double* __restrict__ model, size_t off_R, size_t off_oscore,
-                                                           double* __restrict__ dist) {
+                                                           double* __restrict__ dist, double* __restrict__ Sout = nullptr, size_t sld = 0,
+                                                           int nc_force = 0) {
+    // Sout (round 5, the Wilcoxon reduction's validation scores): instead of the distance, the first nc_force scores of every row
+    // go to Sout[row + sld k] -- the same fma chains, hence the bits the distances are made of
     extern __shared__ double Rl[];                                       // M*KC + KC
     double* const opad = Rl + (size_t)M * KC;
     {   // the zero-padded loadings and observed scores straight from the model (what k_pad_model writes for the other kernels)
-        const int ncomp = (int)model[0];
+        const int ncomp = Sout ? nc_force : (int)model[0];
         for (int e = threadIdx.x; e < M * KC; e += 256) {
             const int m = e / KC, k = e % KC;
             Rl[e] = (k < ncomp) ? model[off_R + m + (size_t)M * k] : 0.0;
@@ -138,6 +141,12 @@ __global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restr
             __builtin_amdgcn_sched_barrier(0);
             chunk(xb, m0 + PF);
         }
+        if (Sout) {
+#pragma unroll
+            for (int k = 0; k < KC; k++)
+                if (k < nc_force) *reinterpret_cast<d2*>(Sout + 2 * i + sld * (size_t)k) = (d2){s0[k], s1[k]};
+            continue;
+        }
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll
         for (int k = 0; k < KC; k++) {
@@ -166,7 +175,8 @@ template <int KT>
 __global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__ X, size_t n, size_t ldx, int M,
                                                       const double* __restrict__ mean, const double* __restrict__ sd,
                                                       const double* __restrict__ model, size_t off_R, size_t off_oscore,
-                                                      double* __restrict__ dist, int lds_main /* doubles in front of the observed scores */) {
+                                                      double* __restrict__ dist, int lds_main /* doubles in front of the observed scores */,
+                                                      double* __restrict__ Sout = nullptr, size_t sld = 0, int nc_force = 0) {
     constexpr int KC = 16 * KT, SROW = KC + 1, PF = 8;
     extern __shared__ double lds[];
     const int M4 = (M + 3) & ~3;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__
     double* const sg = mu + M4;                          // M4 (0: the metric takes no part -- zero variance or padding)
     double* const op = lds + lds_main;                   // KC observed scores, behind everything the epilogue overlays
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
-    const int ncomp = (int)model[0];
+    const int ncomp = Sout ? nc_force : (int)model[0];          // (Sout: the scores themselves, as k_project_dist2_lds)
     for (int e = t; e < M4 * KC; e += 256) {
         const int m = e / KC, k = e % KC;
         Rl[e] = (m < M && k < ncomp) ? model[off_R + m + (size_t)M * k] : 0.0;
@@ -239,6 +249,12 @@ __global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__
             for (int i = 0; i < 4; i++)
                 stage[(size_t)(32 * (g >> 1) + 2 * (q + 4 * i) + (g & 1)) * SROW + 16 * tt + r] = acc[g][tt][i];
     __syncthreads();
+    if (Sout) {
+        const size_t p = base + lane;
+        if (p < n)
+            for (int k = 0; k < nc_force; k++) Sout[p + sld * (size_t)k] = stage[(size_t)lane * SROW + k];
+        return;
+    }
     double d2v = 0.0;
 #pragma unroll 8
     for (int k = 0; k < KC; k++) {
@@ -454,4 +470,39 @@ int launch_project_distance(abc_ctx* ctx, const double* X, size_t n, size_t ldx,
 #undef LAUNCH_PD_LDS
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
+}
+
+// The validation scores of the Wilcoxon reduction (wilcoxon.hip): S[i + n k] = score k of row i of X (n rows from X on), all A components, by
+// the projection kernels above (row pairs with 16-byte loads; 8 / 16 components with the loadings in LDS, 17..32 on the fp64 matrix
+// pipe).  Returns the number of rows it took (an even number; 0: the shape or the alignment is not theirs) -- the caller scores the rest.
+size_t launch_project_scores(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model, double* S) {
+    const ModelLayout ML = model_layout(M, P, A);
+    int KC = 1;
+    while (KC < (int)A) KC *= 2;
+    if (KC < 8) KC = 8;
+    const bool vec_ok = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)S & 15) == 0) && n >= 2;
+    if (!vec_ok || KC > 32) return 0;
+    const size_t npairs = n / 2;
+    if (KC == 32) {
+        const size_t M4 = (M + 3) & ~(size_t)3;
+        const size_t mfma_main = (M4 * KC + 2 * M4 > (size_t)4 * 64 * (KC + 1)) ? M4 * KC + 2 * M4 : (size_t)4 * 64 * (KC + 1);
+        const size_t lb = (mfma_main + KC) * sizeof(double);
+        if (lb > 150 * 1024) return 0;
+        const unsigned gb = (unsigned)((2 * npairs + 255) / 256);
+        if (hipFuncSetAttribute((const void*)k_project_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb) != hipSuccess) return 0;
+        hipLaunchKernelGGL(k_project_mfma<2>, dim3(gb), dim3(256), lb, ctx->stream, X, 2 * npairs, ldx, (int)M, model + ML.off_mean, model + ML.off_sd,
+                           model, ML.off_R, ML.off_oscore, (double*)nullptr, (int)mfma_main, S, n, (int)A);
+        return 2 * npairs;
+    }
+    if ((M * KC + KC) * sizeof(double) > 64 * 1024 || (n & 1)) return 0;      // (16-byte stores into columns of n rows: an even n)
+    size_t pblocks = (npairs + 255) / 256;
+    if (pblocks > 1024) pblocks = 1024;
+    const int lb = (int)((M * KC + KC) * sizeof(double));
+    if (KC == 8)
+        hipLaunchKernelGGL(k_project_dist2_lds<8>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
+                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, (double*)nullptr, S, n, (int)A);
+    else
+        hipLaunchKernelGGL(k_project_dist2_lds<16>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
+                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, (double*)nullptr, S, n, (int)A);
+    return 2 * npairs;
 }

@@ -290,6 +290,10 @@ size_t default_A(size_t M, size_t P, int max_comp) { return (max_comp > 0) ? (si
 
 }  // namespace
 
+int abc_comm_all_reduce(abc_ctx* ctx, void* buf, size_t count, int dtype) { return comm_all_reduce(ctx, buf, count, dtype); }
+int abc_comm_all_gather(abc_ctx* ctx, const void* send, void* recv, size_t bytes) { return comm_all_gather(ctx, send, recv, bytes); }
+int abc_xbuf_reserve(abc_ctx* ctx, size_t bytes) { return xbuf_reserve(ctx, bytes); }
+
 // ---- communicators ------------------------------------------------------------------------------------------------------------
 extern "C" int abc_comm_unique_id(void* id128) {
     if (!id128) return ABC_ERR_INVALID;
@@ -454,7 +458,8 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     if (cfg->rule == ABC_RULE_WILCOXON) {
         // the validation rows of the whole set are assembled on every rank (all-gather of the shards' validation rows)
         const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
-        need += abc_wx_need(NvT, P, A) + (1u << 20);      // (the gathered rows themselves live in the exchange buffer)
+        need += 2 * abc_wx_need(NvT, P, A) + (2u << 20);  // (the cascade over the shards and, should its exact step give up, the
+                                                          // reduction once more on the gathered rows; those live in the exchange buffer)
     }
     ABC_TRY(abc_ws_reserve(ctx, need));
     const StatsLayout SL = stats_layout(M, P);
@@ -491,8 +496,9 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     if (Kp && io->theta_prev && kn)
         ABC_TRY(abc_weights_prev_early(ctx, P, W == 1 ? K : kn, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     ctx->side_forked = false;
+    double* stats_all = nullptr;           // the ranks' records as gathered (k_stats_merge leaves them as they came)
     if (W > 1) {
-        double* stats_all = (double*)abc_ws_alloc(ctx, (size_t)W * SL.len * 8);
+        stats_all = (double*)abc_ws_alloc(ctx, (size_t)W * SL.len * 8);
         if (!stats_all) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         ABC_TRY(comm_all_gather(ctx, stats, stats_all, SL.len * 8));
         const size_t ne = 2 * SL.C16 * SL.C16 + 3 * SL.C16 + 2;
@@ -502,12 +508,28 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
     if (cfg->rule == ABC_RULE_WILCOXON && W == 1)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, (size_t)ntrain, model));
+    // The rank sums rank the paired differences of ALL validation rows (global rows >= ntrain, AbcUtil.cpp:438-446) together.
+    // Round 5: nothing of the rows travels.  The reduction is a cascade of bounds on the rank sums from per-bin counts, and counts
+    // are additive over rows: every rank sweeps ITS validation rows, the counts of a level are all-reduced (192 cells x 8 bytes a
+    // test, then the fine bins of the tests still undecided), bounds and verdicts are computed from the same numbers on every
+    // rank -- the (replicated) model stays identical everywhere without a broadcast; only the keys of the tests the bounds leave
+    // undecided (8 bytes a validation row each) are all-gathered for their exact rank sums (wilcoxon.hip).
+    int wx_rc = ABC_INTERNAL_RETRY;
+    const size_t wx_v0 = (ntrain > row0) ? (size_t)((ntrain - row0) < n ? (ntrain - row0) : n) : 0;
     if (cfg->rule == ABC_RULE_WILCOXON && W > 1) {
-        // The rank sums need the paired differences of ALL validation rows ranked together: every rank gathers the shards'
-        // validation rows (global rows >= ntrain, AbcUtil.cpp:438-446), rebuilds the validation block in global row order and
-        // runs the single-device reduction on it -- the same code on the same numbers on every rank, so the (replicated)
-        // model stays identical everywhere without a broadcast.
-        const size_t v0 = (ntrain > row0) ? (size_t)((ntrain - row0) < n ? (ntrain - row0) : n) : 0, nv = n - v0;
+        const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
+        if (NvT && abc_wx_cascade_applies(NvT, P, A) && !ctx->wx_gather_rows) {
+            const abc_wx_shard sh = {NvT, stats_all + SL.off_n + 1, SL.len};
+            wx_rc = launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, wx_v0, model, &sh);
+            if (wx_rc != ABC_OK && wx_rc != ABC_INTERNAL_RETRY) return wx_rc;
+        }
+    }
+    if (cfg->rule == ABC_RULE_WILCOXON && W > 1 && wx_rc == ABC_INTERNAL_RETRY) {
+        // Small sets (fewer than 16384 validation rows), more than 32 components, or a bin of the cascade's exact step that
+        // outgrew LDS (massive ties; every rank sees it alike): every rank gathers the shards' validation rows, rebuilds the
+        // validation block in global row order and runs the single-device reduction on it -- the same code on the same
+        // numbers on every rank.
+        const size_t v0 = wx_v0, nv = n - v0;
         long long* vcnt = (long long*)abc_ws_alloc(ctx, (size_t)(2 * W + 2) * sizeof(long long));
         if (!vcnt) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         const long long mine = (long long)nv;

@@ -6,35 +6,36 @@
 // All (j, a') tests ("segments") are batched.  Rank sums are sums of half-integers (< 2^52), hence exact and order-independent,
 // so integer / double atomics stay bit-reproducible; residuals use the same fixed fma order as the oracle.
 //
-// Round 4 -- the BINNED path (launch_wilcoxon_binned; 134 ms -> see DESIGN.md section 5 at 1e6 particles x 16 responses x 8
-// components: this rule is the drop-in default of the C++ facade).  A rank is "elements below" + "position among the
-// equal-or-close ones", so nothing has to be sorted globally:
-//   k_wx_sample   per segment: |d| of evenly spaced validation rows, sorted in LDS (leading 32 key bits) -> NB - 1 splitters
-//                 (equi-depth bins; a bin is a function of the key alone, so tied values share a bin);
-//   k_wx_bin<.., false>   counting pass: a work-group takes a run of 256 R-row tiles of ONE response, keeps the residuals of all
-//                 component counts of its rows in registers (the scores of a row are read once for all of the response's
-//                 segments), bins every segment's keys through the splitters in LDS and leaves its per-bin counts;
-//   k_wx_offsets  per segment: running offsets of the work-groups inside every bin, bin sizes, bin starts, the number of
-//                 non-zero differences;
-//   k_wx_bin<.., true>    the same sweep again, now placing the keys (sign in bit 63) bin by bin -- staged through LDS so that
-//                 a work-group writes its share of a bin as one contiguous piece;
-//   k_wx_ranks    one work-group per (segment, bin), the bin (<= 8192 keys) in LDS: 1024 linear sub-bins by counting, then
-//                 every key counts the smaller and the equal keys of its sub-bin -> average rank = keys below the bin + below
-//                 the sub-bin + smaller in it + (equal + 1) / 2; signed sum -> W[segment] (exact);
-//   k_wx_decide   unchanged.
-// Second half of round 4 -- MOST TESTS NEVER GET THAT FAR.  Before the sweeps above, one sweep (k_wx_bin<.., 2>) counts every test's
-// keys, all and positive, in ~2.5 sqrt(n) fine bins (a sampled table key -> bin: one LDS read, one LDS atomic per key), and
-// k_wx_bounds turns the counts into exact bounds on the signed rank sum: a test whose interval of |W| / sigma lies on one side of the
-// decision threshold is settled; the sweeps above then only work on the undecided tests (their work-groups read the verdicts and
-// leave).  Same component counts -- the bounds are rigorous --, a third of the time at 112 tests x 5e5 rows.
-// 24 bytes of traffic per (row, test) instead of ~500 (ten 16-byte LSD radix passes), no host round trip in the middle.  A
-// bin that outgrows LDS (massive ties, a degenerate sample) raises a flag: launch_wilcoxon reads it at the end and repeats the
-// reduction on the SORTED path of rounds 1-3 (one stable LSD radix sort of all (key, segment) pairs), which also takes the
-// shapes the binned path is not built for (more than 32 components, more than ~1.4e7 validation rows).
+// Round 5 -- a CASCADE OF BOUNDS, additive over rows (so that row shards only exchange counts).  A test's statistic is
+//   W = sum over the non-zero paired differences d_i of sign(d_i) rank(|d_i|),
+// and ANY non-decreasing map key -> bin gives exact bounds on W from two counts per bin (all keys, positive keys): the ranks of
+// a bin's keys are the integers between the keys below the bin and the keys up to its end, whatever their order (k_wx_bounds).
+// Nothing is sampled and nothing is sorted:
+//   level 0   every test at once, 192 cells that are LOGARITHMIC in |d| (sixteen to the binade, the leading bits of the IEEE
+//             pattern: three integer operations per key), anchored at eight standard deviations of the test's paired
+//             differences -- known before any row is read: |d| <= |e_a' - e_a*| and that increment is a combination of the
+//             validation scores, whose second moments R' X'X R the model fit has anyway (ModelLayout::off_H).  A work-group of
+//             1024 threads keeps the scores of its rows in registers and goes through ALL responses (the scores are read once
+//             per group of ~190 tests, not once per response), one LDS atomic per key.  ~13 sigma of resolution: settles every
+//             test whose statistic is far from the threshold -- at 1e6 particles x 16 responses x 8 components all 112 of them
+//             but one;
+//   level 1+  only the undecided tests, 2048 .. 16384 bins that are EQUI-DEPTH by construction: a cell of level 0 takes the
+//             share of the bins its count asks for and spreads its keys over them linearly (a cell is a sixteenth of a
+//             binade: the density hardly moves across it), one table read and one LDS atomic per key.  0.08 - 0.3 sigma;
+//   exact     what is still undecided (statistic within that of the threshold): the keys themselves, placed into bins that are
+//             unions of the last level's fine bins (their sizes and the keys below them are known from its counts), ranked
+//             bin by bin in LDS (k_wx_ranks, k_wx_ranks_big: as round 4).
+// Between the levels the host reads ONE word (how many tests are left; a spin on a pinned word the last work-group of the
+// bounds kernel writes) and sizes the next launch.  Row-sharded sets (sharded.hip): every rank sweeps ITS validation rows, the
+// counts of a level are all-reduced (T x 192 x 8 bytes, then (tests left) x bins x 8 bytes), bounds and verdicts are
+// replicated; for the exact step the keys of the undecided tests are all-gathered (8 bytes x validation rows each).
+// Round 4's path (a sorted sample per test for the splitters, one sweep per response, every test through ~2.5 sqrt(n) fine
+// bins) is gone: 1.54 ms of its 3.1 at 1e6 x 128 metrics x 32 components were that sweep re-reading the scores 80 times from L2.
+// The SORTED path of rounds 1-3 (one stable LSD radix sort of all (key, test) pairs) stays for small sets, for more than
+// 32 components and as the fallback when a bin of the exact step outgrows LDS (massive ties).
 #include "abc_internal.h"
 #include <vector>
 
-// (k_wx_sample<32>'s sorting network is too long for the unroller's budget: it stays a loop there, which is correct, only slower)
 #pragma clang diagnostic ignored "-Wpass-failed"
 
 namespace {
@@ -50,33 +51,71 @@ struct WxPlan {            // built on the device from the model record; the arr
     int* astar;            // PRESS optimum per response
 };
 
-__global__ void k_wx_plan(const double* __restrict__ model, int M, int P, int A, WxPlan* __restrict__ plan,
-                          int* __restrict__ seg_j, int* __restrict__ seg_a, int* __restrict__ astar, int nseg_max,
-                          unsigned long long* __restrict__ nz, double* __restrict__ W, int* __restrict__ segbase,
-                          int* __restrict__ fail, int* __restrict__ v3 = nullptr) {
-    for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; if (v3) v3[s] = 2; }
-    if (threadIdx.x != 0) return;
-    if (fail) { fail[0] = 0; fail[1] = 0; }           // [1]: tests the bounds leave undecided (k_wx_bounds)
+constexpr int WX_T = 1024;                       // threads of the sweep kernels
+constexpr int WX_NC0 = 192;                      // cells of level 0: 12 binades, 16 cells each
+constexpr int WX_CSH = 17;                       // a cell = 2^17 key prefixes (prefix = the leading 32 of the 63 key bits: 2^21 to the binade)
+constexpr int WX_LDS = 144 << 10;                // LDS of a sweep work-group's counters and tables
+constexpr int WX_NBFMAX = 16384;                 // most fine bins of a level (start and span of a cell travel in 16 bits each)
+constexpr unsigned long long WX_SIGN = 1ull << 63;
+constexpr unsigned long long WX_MASK = ~WX_SIGN;
+constexpr unsigned long long WX_NOKEY = ~0ull;   // a row without a key (zero difference, padding)
+
+// plan of the tests and, for the cascade (kbase != nullptr), the anchor of every test's level-0 cells: cell(key) =
+// min((max(prefix, kbase) - kbase) >> WX_CSH, WX_NC0 - 1) with kbase = prefix(8 sd) - (WX_NC0 - 1) cells, sd^2 = the mean
+// square of e_a' - e_a* = sum_k q_jk S_ik over the components k between a' and a*, taken from the diagonal of H (the validation
+// scores of different components are close to orthogonal; the anchor only decides how evenly the cells are filled)
+__global__ __launch_bounds__(256) void k_wx_plan(const double* __restrict__ model, int M, int P, int A, WxPlan* __restrict__ plan,
+                                                 int* __restrict__ seg_j, int* __restrict__ seg_a, int* __restrict__ astar, int nseg_max,
+                                                 unsigned long long* __restrict__ nz, double* __restrict__ W, int* __restrict__ segbase,
+                                                 int* __restrict__ fail, int* __restrict__ v3, unsigned int* __restrict__ kbase,
+                                                 int* __restrict__ act, int* __restrict__ nact, unsigned int* __restrict__ tickets,
+                                                 double nv_total) {
+    __shared__ int s_ns;
+    for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; if (v3) v3[s] = 2; if (act) act[s] = s; }
     const ModelLayout ML = model_layout(M, P, A);
-    int ns = 0;
-    for (int j = 0; j < P; j++) {
-        const int as = (int)model[ML.off_per + j];
-        astar[j] = as;
-        if (segbase) segbase[j] = ns;            // the tests of response j are segments segbase[j] .. segbase[j] + as - 2
-        for (int a = 1; a < as && ns < nseg_max; a++) { seg_j[ns] = j; seg_a[ns] = a; ns++; }
+    if (threadIdx.x == 0) {
+        if (fail) { fail[0] = 0; fail[1] = 0; }
+        if (tickets) { tickets[0] = 0; tickets[1] = 0; tickets[2] = 0; tickets[3] = 0; }
+        int ns = 0;
+        for (int j = 0; j < P; j++) {
+            const int as = (int)model[ML.off_per + j];
+            astar[j] = as;
+            if (segbase) segbase[j] = ns;            // the tests of response j are segments segbase[j] .. segbase[j] + as - 2
+            for (int a = 1; a < as && ns < nseg_max; a++) { seg_j[ns] = j; seg_a[ns] = a; ns++; }
+        }
+        plan->nseg = ns;
+        plan->pad_ = 0;
+        plan->seg_j = seg_j;
+        plan->seg_a = seg_a;
+        plan->astar = astar;
+        if (nact) nact[0] = ns;
+        s_ns = ns;
     }
-    plan->nseg = ns;
-    plan->pad_ = 0;
-    plan->seg_j = seg_j;
-    plan->seg_a = seg_a;
-    plan->astar = astar;
+    __syncthreads();
+    if (!kbase) return;
+    const int ns = s_ns;
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+        const int j = seg_j[s], a1 = seg_a[s], as = astar[j];
+        double var = 0.0;
+        for (int k = a1; k < as; k++) {
+            const double q = model[ML.off_Q + j + (size_t)P * k];
+            var = fma(q * q, model[ML.off_H + k + (size_t)A * k], var);
+        }
+        var /= nv_total;
+        if (!(var > 0.0) || !(var < 1e300)) var = model[ML.off_press + (a1 - 1) + (size_t)A * j] / nv_total;      // (degenerate scores)
+        if (!(var > 0.0) || !(var < 1e300)) var = 1.0;
+        const double top = 8.0 * sqrt(var);
+        const unsigned int ktop = (unsigned int)((unsigned long long)__double_as_longlong(top) >> 31);
+        const unsigned int span = (unsigned int)(WX_NC0 - 1) << WX_CSH;
+        kbase[s] = ktop > span ? ktop - span : 0u;
+    }
 }
 
 // scores of the validation rows: S[i + nt*k] = sum_m z(x_im) R[m,k]  (m ascending fma chain, as the oracle)
 template <int KC>
 __global__ __launch_bounds__(256) void k_wx_scores(const double* __restrict__ X, size_t ldx, size_t row_test, size_t nt,
                                                    int M, int P, int A, const double* __restrict__ model,
-                                                   double* __restrict__ S) {
+                                                   double* __restrict__ S, size_t sld /* rows of S (>= nt) */) {
     const ModelLayout ML = model_layout(M, P, A);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nt) return;
@@ -100,7 +139,7 @@ __global__ __launch_bounds__(256) void k_wx_scores(const double* __restrict__ X,
     }
 #pragma unroll
     for (int k = 0; k < KC; k++)
-        if (k < A) S[i + nt * k] = s[k];
+        if (k < A) S[i + sld * k] = s[k];
 }
 
 // more than 32 components: chunks of 32 (the row's metrics re-read per chunk; same fma chain per component)
@@ -186,406 +225,232 @@ __global__ __launch_bounds__(256) void k_wx_ranksum(const unsigned long long* __
 
 
 // ===========================================================================================================================
-// the binned path
+// the cascade of bounds
 // ===========================================================================================================================
-constexpr int WXT = 256;                         // threads of the sweep kernels
-constexpr int WX_CAP = 16384;                    // keys one bin may hold (k_wx_ranks_big: the bin in 128 KB of LDS)
-constexpr int WX_NBMAX = 4096;                   // bins per segment
-constexpr int WX_TAB = 512;                      // cells of the bounds sweep's key -> fine bin table
-constexpr unsigned long long WX_SIGN = 1ull << 63;
-constexpr unsigned long long WX_MASK = ~WX_SIGN;
-
-struct WxGeo {                 // geometry of one binned reduction (computed on the host, passed by value)
-    unsigned long long nt;     // validation rows
-    int NB;                    // bins per segment (a power of two, 1 .. WX_NBMAX)
-    int SAMP;                  // sampled rows per segment (a power of two <= nt; unused when NB == 1)
-    int ST;                    // work-groups per response in the sweeps, each taking `tps` consecutive tiles of 256 R rows
-    int tps;
-    int G;                     // segments of one response whose splitters / counters share LDS (the sweep loops over groups)
-    int nseg_max;
-    // the BOUNDS sweep (k_wx_bin<.., 2>): F linear sub-bins per bin (a power of two; 0: no bounds sweep), its own partition of the
-    // tiles (a work-group's rows stay below 2^16: its per-bin counters are two 16-bit halves) and its own group size
-    int F;
-    int STb, tpsb, Gb;
-};
-
-// -DWX_STAMPS (diagnostic build, scripts/wx_stamps.sh): thread 0 of every work-group of the kernel WX_STAMPS names (1: k_wx_ranks, 2 / 3: the counting / placing
-// sweep k_wx_bin) leaves s_memtime at its phase boundaries in a buffer of its own; the product build has no stamp
-#ifdef WX_STAMPS
-__device__ unsigned long long* wx_stamp_buf = nullptr;
-#define WX_STAMP_K(kern, i) do { if (WX_STAMPS == (kern) && threadIdx.x == 0 && wx_stamp_buf) wx_stamp_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define WX_STAMP(i) WX_STAMP_K(1, i)
-#else
-#define WX_STAMP_K(kern, i) do { } while (0)
+// (the phase stamps of round 4's diagnostic build of k_wx_ranks: no-ops)
 #define WX_STAMP(i) do { } while (0)
-#endif
 
-// key of validation row i in test (j, a1): |d| = ||e_as| - |e_a1|| as its IEEE pattern, the sign of d in bit 63; d == 0: no key
-__device__ __forceinline__ double wx_zy(const double* __restrict__ Y, size_t ldy, size_t row, int j, const double* __restrict__ model,
-                                        const ModelLayout& ML, int M) {
-    const double sdy = model[ML.off_sd + M + j];
-    return (sdy == 0.0) ? 0.0 : (Y[row + ldy * j] - model[ML.off_mean + M + j]) / sdy;
+// cell of level 0: logarithmic in |d|, a non-decreasing function of the key prefix
+__device__ __forceinline__ unsigned int wx_cell(unsigned int k32, unsigned int kb) {
+    const unsigned int off = (k32 > kb ? k32 : kb) - kb, c = off >> WX_CSH;
+    return c < (unsigned int)(WX_NC0 - 1) ? c : (unsigned int)(WX_NC0 - 1);
 }
-
-// bitonic sort of T EPT keys, EPT per thread in registers (element t EPT + u): compare-exchanges inside a thread stay in
-// registers, inside a wave they are shuffles, only the strides across waves go through LDS (10 of the 78 stages at 4096 keys; all
-// 78 through LDS with a barrier each were 80 us of this kernel's 90).  lds: T EPT words.
-template <int T, int EPT>
-__device__ __forceinline__ void wx_sort_regs(unsigned int (&v)[EPT], unsigned int* lds) {
-    constexpr int N = T * EPT;
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j < EPT) {
-#pragma unroll
-                for (int u = 0; u < EPT; u++) {
-                    const int x = u ^ j;
-                    if (x > u) {
-                        const bool asc = ((t * EPT + u) & k) == 0;
-                        const unsigned int a = v[u], b = v[x];
-                        if ((a > b) == asc) { v[u] = b; v[x] = a; }
-                    }
-                }
-            } else {
-                const int m = j / EPT;                                      // the partner thread is t ^ m
-                const bool lower = (t & m) == 0;
-                if (m >= 64) {
-#pragma unroll
-                    for (int u = 0; u < EPT; u++) lds[u * T + t] = v[u];
-                    __syncthreads();
-                }
-#pragma unroll
-                for (int u = 0; u < EPT; u++) {
-                    const unsigned int o = (m >= 64) ? lds[u * T + (t ^ m)] : (unsigned int)__shfl_xor((int)v[u], m, 64);
-                    const bool asc = ((t * EPT + u) & k) == 0;
-                    const unsigned int lo = v[u] < o ? v[u] : o, hi = v[u] < o ? o : v[u];
-                    v[u] = (lower == asc) ? lo : hi;
-                }
-                if (m >= 64) __syncthreads();
-            }
-        }
-    }
+// fine bin of a level: cell c owns the bins [start_c, start_c + span_c) (tab[c] = start | span << 16) and spreads its prefixes
+// linearly over them; non-decreasing in the prefix (starts are non-decreasing, a cell's last bin lies below the next start)
+__device__ __forceinline__ unsigned int wx_fine(unsigned int k32, unsigned int kb, const unsigned int* __restrict__ tab) {
+    const unsigned int off = (k32 > kb ? k32 : kb) - kb;
+    unsigned int c = off >> WX_CSH;
+    c = c < (unsigned int)(WX_NC0 - 1) ? c : (unsigned int)(WX_NC0 - 1);
+    unsigned int r = off - (c << WX_CSH);
+    r = r < (1u << WX_CSH) - 1u ? r : (1u << WX_CSH) - 1u;                // (the last cell takes everything above)
+    const unsigned int e = tab[c];
+    return (e & 0xffffu) + (__umul24(r, e >> 16) >> WX_CSH);              // r < 2^17, span <= 2^14: the product fits
 }
-
-// splitters of every segment from a sample of its keys: the leading 32 of the 63 key bits of SAMP = 1024 EPT evenly spaced rows,
-// sorted; splitter b = the sample's ((b + 1) / NB)-quantile with its low 31 bits set, so bin(key) = #{splitters < key} puts equal
-// keys (and keys equal in their leading 32 bits) in one bin
-template <int EPT>
-__global__ __launch_bounds__(1024) void k_wx_sample(const double* __restrict__ Y, size_t ldy, size_t row_test, WxGeo g, int M, int P,
-                                                    int A, const double* __restrict__ model, const double* __restrict__ S,
-                                                    const WxPlan* __restrict__ plan, unsigned long long* __restrict__ spl,
-                                                    unsigned int* __restrict__ tab) {
-    extern __shared__ unsigned int wx_sk[];
-    __shared__ unsigned int s_m;
-    const int seg = blockIdx.x;
-    if (seg >= plan->nseg) return;
-    const ModelLayout ML = model_layout(M, P, A);
-    const int j = plan->seg_j[seg], a1 = plan->seg_a[seg], as = plan->astar[j];
-    const int t = threadIdx.x;
-    constexpr int SAMP = 1024 * EPT;
-    if (t == 0) s_m = 0;
-    __syncthreads();
-    unsigned int v[EPT], mine = 0;
-    {
-        // the rows' chains side by side, component by component: EPT independent loads per step (row after row, every load of a
-        // chain waited for the one before)
-        size_t ri[EPT];
-        double zy[EPT], pred[EPT], esm[EPT];
-        const double* Qj = model + ML.off_Q + j;
-        const size_t nt = (size_t)g.nt;
+// the table of a level with NBX fine bins from a test's level-0 counts, by ONE wave: cell c starts at bin floor(keys below c * NBX / m)
+__device__ __forceinline__ void wx_wave_table(const unsigned int* __restrict__ c0row, int NBX, unsigned int* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    static_assert(WX_NC0 == 3 * 64, "three cells per lane");
+    unsigned int c[3], loc = 0;
 #pragma unroll
-        for (int u = 0; u < EPT; u++) {
-            const unsigned long long q = (unsigned long long)u * 1024 + t;
-            ri[u] = (size_t)((q * g.nt) / (unsigned long long)SAMP);
-            zy[u] = wx_zy(Y, ldy, row_test + ri[u], j, model, ML, M);
-            pred[u] = 0.0;
-            esm[u] = 0.0;
-        }
-        for (int k = 0; k < as; k++) {
-            const double qk = Qj[(size_t)P * k];
-#pragma unroll
-            for (int u = 0; u < EPT; u++) {
-                pred[u] = fma(S[ri[u] + nt * k], qk, pred[u]);
-                if (k + 1 == a1) esm[u] = zy[u] - pred[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < EPT; u++) {
-            const double d = fabs(zy[u] - pred[u]) - fabs(esm[u]);
-            const bool nzr = d != 0.0;
-            v[u] = nzr ? (unsigned int)((unsigned long long)__double_as_longlong(fabs(d)) >> 31) : 0xffffffffu;
-            mine += nzr ? 1u : 0u;
-        }
-    }
-    if (mine) atomicAdd(&s_m, mine);
-    wx_sort_regs<1024, EPT>(v, wx_sk);
-#pragma unroll
-    for (int u = 0; u < EPT; u++) wx_sk[t * EPT + u] = v[u];
-    __syncthreads();
-    const unsigned int m = s_m;                     // non-zero differences of the sample: the first m entries
-    for (int b = t; b < g.NB - 1; b += 1024) {
-        unsigned long long sv = ~0ull >> 1;          // an empty sample: everything in bin 0
-        if (m) {
-            unsigned long long idx = ((unsigned long long)(b + 1) * m) / (unsigned long long)g.NB;
-            if (idx >= m) idx = m - 1;
-            sv = ((unsigned long long)wx_sk[idx] << 31) | 0x7fffffffull;
-        }
-        spl[(size_t)seg * g.NB + b] = sv;
-    }
-    // the bounds sweep's fine bins, without a search: WX_TAB cells, linear in the key prefix between the sample's extremes; a cell
-    // starts at fine bin (sample keys below it) NBF / m and spreads its keys linearly over the fine bins up to the next cell's start
-    // -- a non-decreasing function of the key (any such function makes bins the bounds hold for; the sample only makes them
-    // evenly filled).  tab[seg]: WX_TAB x (start | span << 16), the first prefix, the cell width's shift
-    if (tab && g.F) {
-        unsigned int* tb = tab + (size_t)seg * (WX_TAB + 2);
-        const unsigned int NBF = (unsigned int)(g.NB * g.F);
-        if (m == 0) {
-            for (int c = t; c < WX_TAB + 2; c += 1024) tb[c] = 0u;
-        } else {
-            const unsigned int kmin = wx_sk[0], kmax = wx_sk[m - 1];
-            unsigned int sh = 0;
-            while (((kmax - kmin) >> sh) >= (unsigned int)WX_TAB) sh++;
-            auto below = [&](unsigned long long bound) -> unsigned int {          // sample keys < bound
-                if (bound > 0xffffffffull) return m;
-                unsigned int lo = 0, hi = m;
-                while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if ((unsigned long long)wx_sk[mid] < bound) lo = mid + 1; else hi = mid; }
-                return lo;
-            };
-            for (int c = t; c < WX_TAB; c += 1024) {
-                const unsigned int c0 = below((unsigned long long)kmin + ((unsigned long long)c << sh));
-                const unsigned int c1 = below((unsigned long long)kmin + ((unsigned long long)(c + 1) << sh));
-                const unsigned int s0 = (unsigned int)(((unsigned long long)c0 * NBF) / m);
-                const unsigned int s1 = (c == WX_TAB - 1) ? NBF : (unsigned int)(((unsigned long long)c1 * NBF) / m);
-                tb[c] = s0 | ((s1 - s0) << 16);
-            }
-            if (t == 0) { tb[WX_TAB] = kmin; tb[WX_TAB + 1] = sh; }
-        }
-    }
-}
-
-// exclusive scan of n <= WX_NBMAX counters by the WXT threads of a work-group (in -> out; in and out may be the same array);
-// returns the total.  wsum: WXT / 64 + 1 words of LDS.  Barriers inside: call it from uniform control flow.
-__device__ __forceinline__ unsigned int wx_block_scan(const unsigned int* in, unsigned int* out, int n, unsigned int* wsum) {
-    const int t = threadIdx.x, per = (n + WXT - 1) / WXT, i0 = t * per;
-    unsigned int loc = 0;
-    for (int c = 0; c < per; c++) if (i0 + c < n) loc += in[i0 + c];
+    for (int i = 0; i < 3; i++) { c[i] = c0row[3 * lane + i]; loc += c[i]; }
     unsigned int inc = loc;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned int up = __shfl_up(inc, d, 64); if ((t & 63) >= d) inc += up; }
-    __syncthreads();                                  // (every read of `in` is done: `out` may alias it)
-    if ((t & 63) == 63) wsum[t >> 6] = inc;
-    __syncthreads();
-    unsigned int before = 0, total = 0;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
+    const unsigned int m = __shfl(inc, 63, 64);
+    unsigned int cum = inc - loc;
 #pragma unroll
-    for (int w = 0; w < WXT / 64; w++) { const unsigned int v = wsum[w]; if (w < (t >> 6)) before += v; total += v; }
-    unsigned int run = before + inc - loc;
-    for (int c = 0; c < per; c++)
-        if (i0 + c < n) { const unsigned int v = in[i0 + c]; out[i0 + c] = run; run += v; }
-    __syncthreads();
-    return total;
+    for (int i = 0; i < 3; i++) {
+        const int cell = 3 * lane + i;
+        unsigned int s0 = 0, s1 = 0;
+        if (m) {
+            s0 = (unsigned int)(((unsigned long long)cum * (unsigned int)NBX) / m);
+            s1 = (cell == WX_NC0 - 1) ? (unsigned int)NBX : (unsigned int)(((unsigned long long)(cum + c[i]) * (unsigned int)NBX) / m);
+            if (s0 >= (unsigned int)NBX) { s0 = (unsigned int)NBX - 1u; s1 = s0; }
+        }
+        out[cell] = s0 | ((s1 - s0) << 16);
+        cum += c[i];
+    }
 }
 
-// The two sweeps over the validation rows.  A work-group = (run of tiles, response j): its threads keep the residuals of R rows
-// for all component counts in registers (the scores of a row are read once for all segments of the response) and go through
-// the response's segments in groups of G (splitters and per-bin counters of a group live in LDS).
-//   SCATTER == false: blockhist[st][seg][bin] = this work-group's keys of that bin
-//   SCATTER == true : blockhist holds the work-group's offset inside the bin (k_wx_offsets), binbase the bin's start: the keys
-//                     of a (tile, segment) are staged in LDS in bin order and written out as contiguous pieces.  (Measured and
-//                     NOT kept: no staging -- the LDS counter of a (segment, bin) as the work-group's write cursor, a returning
-//                     LDS atomic hands every key its place, no barrier in the loop: 0.56 ms against 0.44 ms; the 64 lanes of
-//                     a store then hit 64 different lines.)
-//   MODE 2 (the bounds sweep, before the other two): counts per FINE bin = (bin, one of F linear sub-bins of the bin's key range),
-//                     all keys in the low and the positive differences in the high half of one 32-bit counter -> blockfine
-// MODE 0 / 1 skip the tests whose verdict the bounds have settled (v3, wx_need): mostly all of them.
+// The sweep over the validation rows.  A work-group = (a run of tiles of 1024 R rows, a group of <= G tests of the list `act`): a
+// thread keeps the scores of its R rows in registers for the whole tile and goes through the group's tests response by response
+// -- per (row, response) the prediction chain once for |e_a*| and once more for the |e_a'| of the group's tests of that response
+// (pred: the k-ascending fma chain of the oracle), per (row, test) the key and
+//   MODE 0: one LDS atomic on the test's level-0 cell        MODE 1: a table read and one LDS atomic on its fine bin
+//   (all keys in the low, positive differences in the high half of a 32-bit counter: a work-group's rows stay below 2^16)
+//   MODE 2: the key itself (sign of d in bit 63) to keys[slot][row] -- the exact step.
+// The work-groups of one run of tiles (one per group of tests) follow each other on ONE XCD (blockIdx % 8), so the scores come
+// from HBM once and from that XCD's L2 for the other groups.
 template <int AM, int R, int MODE>
-__global__ __launch_bounds__(WXT) void k_wx_bin(const double* __restrict__ Y, size_t ldy, size_t row_test, WxGeo g, int M, int P, int A,
-                                                const double* __restrict__ model, const double* __restrict__ S,
-                                                const WxPlan* __restrict__ plan, const int* __restrict__ segbase,
-                                                const unsigned long long* __restrict__ spl, unsigned int* __restrict__ blockhist,
-                                                const unsigned int* __restrict__ binbase, unsigned long long* __restrict__ keys,
-                                                const int* __restrict__ v3, const unsigned int* __restrict__ tab) {
-    constexpr int TR = WXT * R;
-    constexpr bool SCATTER = MODE == 1, FINE = MODE == 2;
-    extern __shared__ unsigned long long wx_smem[];
-    const int ST = FINE ? g.STb : g.ST, tps = FINE ? g.tpsb : g.tps;
-    // MODE 0 / 1: work-groups that share an XCD (blockIdx % 8) take neighbouring runs of tiles: the pieces they write into a bin
-    // are neighbours in memory and meet in that XCD's L2.
-    // MODE 2 (one-dimensional grid): the P work-groups of one run of tiles -- one per response, all reading the same scores, once
-    // per group of tests -- follow each other on ONE XCD, so the scores come from HBM once per group and from that XCD's L2 for
-    // the other responses (with the response in grid.y they were fetched P times: 41 GB at 1e7 rows x 32 responses)
-    const int per_x = (ST + 7) / 8;
-    const int j = FINE ? (int)((blockIdx.x / 8) % (unsigned)P) : (int)blockIdx.y;
-    const int st = FINE ? (int)(blockIdx.x / (8u * (unsigned)P)) * 8 + (int)(blockIdx.x % 8) : (int)(blockIdx.x % 8) * per_x + (int)(blockIdx.x / 8);
-    if (st >= ST) return;
-    const int as = plan->astar[j];
-    if (as <= 1) return;
-    const ModelLayout ML = model_layout(M, P, A);
-    const int NB = g.NB, G = FINE ? g.Gb : g.G, t = threadIdx.x;
-    const int F = FINE ? g.F : 1, NBF = NB * F;
-    const size_t nt = (size_t)g.nt;
-    const int seg0 = segbase[j], nsj = as - 1;
-    // tests of this response that still need their exact rank sum (bit a1 - 1): undecided by the bounds, no smaller a' has passed
-    unsigned int needmask = 0xffffffffu;
-    if (!FINE) {
-        needmask = 0;
-        bool passed = false;
-        for (int a1 = 1; a1 <= nsj; a1++) {
-            const int v = v3[seg0 + a1 - 1];
-            if (v == 2 && !passed) needmask |= 1u << (a1 - 1);
-            passed = passed || v == 1;
+__global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y, size_t ldy, size_t row_test, size_t nt, int M, int P, int A,
+                                                   const double* __restrict__ model, const double* __restrict__ S,
+                                                   const int* __restrict__ seg_j, const int* __restrict__ seg_a, const int* __restrict__ astar,
+                                                   const int* __restrict__ act, const int* __restrict__ nact_p, int act_lo, int act_n, int G,
+                                                   int TG, int RR, int tpw, const unsigned int* __restrict__ kbase,
+                                                   const unsigned int* __restrict__ c0, int NBX, unsigned int* __restrict__ blockcnt,
+                                                   unsigned long long* __restrict__ keys, size_t kld) {
+    constexpr int TR = WX_T * R;
+    extern __shared__ unsigned int wx_lds[];
+    const int q = (int)(blockIdx.x >> 3), rr = (q / TG) * 8 + (int)(blockIdx.x & 7), tg = q % TG;
+    if (rr >= RR) return;
+    int end = act_lo + act_n;
+    { const int na = *nact_p; end = end < na ? end : na; }
+    const int lo = act_lo + tg * G;
+    if (lo >= end) return;
+    const int ng = (end - lo < G) ? end - lo : G, t = threadIdx.x;
+    unsigned int* cnt = wx_lds;                                           // [G][NBX]  (MODE 0 / 1)
+    unsigned int* tab_s = cnt + (MODE == 2 ? 0 : (size_t)G * NBX);        // [G][WX_NC0]  (MODE 1)
+    int* kb_s = (int*)(tab_s + (MODE == 1 ? (size_t)G * WX_NC0 : 0));     // [G] anchors
+    int* sj = kb_s + G;                                                   // [G] response, [G] candidate of the group's tests
+    int* sa = sj + G;
+    int* ej = sa + G;                                                     // entries: one per response present in the group
+    int* em = ej + G;                                                     //   mask of its candidates a' (bit a' - 1)
+    int* es = em + G;                                                     //   slot of its first test
+    __shared__ int s_nent;
+    if (MODE != 2) for (int e = t; e < ng * NBX; e += WX_T) cnt[e] = 0u;
+    if (t < ng) { const int s = act[lo + t]; kb_s[t] = (int)kbase[s]; sj[t] = seg_j[s]; sa[t] = seg_a[s]; }
+    if (MODE == 1)
+        for (int slot = t >> 6; slot < ng; slot += WX_T / 64) wx_wave_table(c0 + (size_t)act[lo + slot] * WX_NC0, NBX, tab_s + (size_t)slot * WX_NC0);
+    __syncthreads();
+    if (t == 0) {
+        int ne = 0, e = 0;
+        while (e < ng) {
+            const int j = sj[e];
+            unsigned int mask = 0;
+            int e2 = e;
+            while (e2 < ng && sj[e2] == j) { mask |= 1u << (sa[e2] - 1); e2++; }
+            ej[ne] = j; em[ne] = (int)mask; es[ne] = e; ne++;
+            e = e2;
         }
-        if (!needmask) return;
+        s_nent = ne;
     }
-    // a splitter is a 32-bit prefix followed by 31 ones (k_wx_sample): splitter < key <=> prefix < key >> 31 -- the search compares
-    // 32-bit words (half the LDS traffic and half the compare instructions of the 64-bit one)
-    unsigned int* spl_s = (unsigned int*)wx_smem;                          // [G][NB] splitter prefixes; FINE: [G][WX_TAB + 2], the tables
-    const int SPW = FINE ? WX_TAB + 2 : NB;
-    unsigned int* acc = spl_s + (size_t)G * SPW;                           // [G][NB F]: counts (0, 2) / running global offsets (1)
-    unsigned int* lh = acc + (size_t)G * NBF;                              // [NB] keys of the current (tile, segment) per bin
-    unsigned int* cst = lh + NB;                                           // [NB] their exclusive scan
-    unsigned long long* skey = (unsigned long long*)(((size_t)(cst + NB) + 7) & ~(size_t)7);   // [TR] staged keys (SCATTER)
-    unsigned int* sdst = (unsigned int*)(skey + TR);                       // [TR] their places in the bin
-    __shared__ unsigned int wsum[WXT / 64 + 1];
-    const size_t tile0 = (size_t)st * tps;
-    const double* Qj = model + ML.off_Q + j;
-    WX_STAMP_K(SCATTER ? 3 : 2, 0);
-    for (int grp = 0; grp * G < nsj; grp++) {
-        const int gn = (nsj - grp * G < G) ? nsj - grp * G : G;            // segments of this group: a1 = grp G + 1 .. grp G + gn
-        if (!FINE && ((needmask >> (grp * G)) & ((gn >= 32) ? 0xffffffffu : ((1u << gn) - 1u))) == 0) continue;      // (uniform)
-        if (FINE) {
-            for (int e = t; e < gn * SPW; e += WXT) spl_s[e] = tab[(size_t)(seg0 + grp * G) * SPW + e];
-            for (int e = t; e < gn * NBF; e += WXT) acc[e] = 0u;
-        } else
-            for (int e = t; e < gn * NB; e += WXT) {
-                const int gs = e / NB, b = e - gs * NB, seg = seg0 + grp * G + gs;
-                spl_s[e] = (b < NB - 1) ? (unsigned int)(spl[(size_t)seg * NB + b] >> 31) : 0xffffffffu;
-                acc[e] = SCATTER ? binbase[(size_t)seg * NB + b] + blockhist[((size_t)st * g.nseg_max + seg) * NB + b] : 0u;
-            }
-        __syncthreads();
-        if (grp == 0) WX_STAMP_K(SCATTER ? 3 : 2, 1);
-        for (int tt = 0; tt < tps; tt++) {
-            const size_t row_t = (tile0 + tt) * TR;
-            if (row_t >= nt) break;
-            // residuals of this thread's R rows at 1 .. as components (pred: the k-ascending fma chain of the oracle)
-            // All loads first, unconditionally (clamped rows and columns): with the loads inside the `k < as` branches of the chain
-            // every one waited for the one before -- R AM memory latencies in a row were 70-90 % of all three sweeps (in-kernel stamps).
-            double e[R][AM], estar[R], yv[R];
-            bool in[R];
+    __syncthreads();
+    const int nent = s_nent;
+    const ModelLayout ML = model_layout(M, P, A);
+    const size_t nrows = MODE == 2 ? kld : nt;                            // (MODE 2 also writes the padding rows nt .. kld - 1)
+    for (int tt = 0; tt < tpw; tt++) {
+        const size_t row_t = ((size_t)rr * tpw + tt) * TR;
+        if (row_t >= nrows) break;
+        double s[R][AM];
+        size_t ic[R];
+        bool in[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const size_t i = row_t + (size_t)r * WX_T + t;
+            in[r] = i < nt;
+            ic[r] = in[r] ? i : (nt ? nt - 1 : 0);
+#pragma unroll
+            for (int k = 0; k < AM; k++) s[r][k] = nt ? S[ic[r] + nt * (size_t)(k < A ? k : A - 1)] : 0.0;
+        }
+        // per (row, response): the loads of the NEXT response (its y, its loadings) are issued before the arithmetic of this one
+        const int lane = t & 63;
+        double ynext[R], qnext;
+        {
+            const int j0 = __builtin_amdgcn_readfirstlane(ej[0]);
+#pragma unroll
+            for (int r = 0; r < R; r++) ynext[r] = nt ? Y[row_test + ic[r] + ldy * (size_t)j0] : 0.0;
+            qnext = model[ML.off_Q + j0 + (size_t)P * (lane < A ? lane : A - 1)];
+        }
+        for (int ent = 0; ent < nent; ent++) {
+            const int j = __builtin_amdgcn_readfirstlane(ej[ent]);
+            const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane(em[ent]);
+            const int slot0 = __builtin_amdgcn_readfirstlane(es[ent]);
+            const int as = astar[j];
             const double sdy = model[ML.off_sd + M + j], muy = model[ML.off_mean + M + j];
+            // lane k holds q_jk (and, for a test (j, k + 1) of this group, its anchor): a step's operands come out of the lanes
+            // (v_readlane) -- as scalar loads / LDS reads inside the steps every one of them was waited for on the spot
+            const double qv = qnext;
+            const unsigned int below = mask & ((1u << (lane & 31)) - 1u);
+            const unsigned int kbv = (lane < 32 && ((mask >> lane) & 1u)) ? (unsigned int)kb_s[slot0 + __popc(below)] : 0u;
+            double zy[R], estar[R], pred[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const size_t i = row_t + (size_t)r * WXT + t;
-                in[r] = i < nt;
-                const size_t ic = in[r] ? i : nt - 1;
-                yv[r] = Y[row_test + ic + ldy * (size_t)j];
-#pragma unroll
-                for (int k = 0; k < AM; k++) e[r][k] = S[ic + nt * (size_t)(k < A ? k : A - 1)];
+                zy[r] = (sdy == 0.0) ? 0.0 : (ynext[r] - muy) / sdy;
+                pred[r] = 0.0;
             }
+            if (ent + 1 < nent) {
+                const int j2 = __builtin_amdgcn_readfirstlane(ej[ent + 1]);
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                estar[r] = 0.0;
-                const double zy = (sdy == 0.0) ? 0.0 : (yv[r] - muy) / sdy;        // (wx_zy)
-                double pred = 0.0;
-#pragma unroll
-                for (int k = 0; k < AM; k++)
-                    if (k < as) {
-                        pred = fma(e[r][k], Qj[(size_t)P * k], pred);
-                        e[r][k] = zy - pred;
-                        if (k == as - 1) estar[r] = fabs(zy - pred);
-                    }
+                for (int r = 0; r < R; r++) ynext[r] = nt ? Y[row_test + ic[r] + ldy * (size_t)j2] : 0.0;
+                qnext = model[ML.off_Q + j2 + (size_t)P * (lane < A ? lane : A - 1)];
             }
-            if (grp == 0 && tt == 0) WX_STAMP_K(SCATTER ? 3 : 2, 2);
+            const int qlo = __double2loint(qv), qhi = __double2hiint(qv);
 #pragma unroll
-            for (int a1 = 1; a1 < AM; a1++) {
-                if (a1 >= as || (a1 - 1) / G != grp) continue;            // (uniform over the work-group)
-                if (!FINE && !((needmask >> (a1 - 1)) & 1u)) continue;
-                const int gs = (a1 - 1) - grp * G;
-                const unsigned int* sp = spl_s + (size_t)gs * SPW;
-                if (SCATTER) { for (int b = t; b < NB; b += WXT) lh[b] = 0; __syncthreads(); }
-                unsigned long long key[R];
-                unsigned int k32[R];
-                int bin[R];
-                unsigned int rank[R];
-                bool nzr[R];
+            for (int k = 0; k < AM; k++)
+                if (k < as) {
+                    const double qk = __hiloint2double(__builtin_amdgcn_readlane(qhi, k), __builtin_amdgcn_readlane(qlo, k));
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const double d = in[r] ? estar[r] - fabs(e[r][a1 - 1]) : 0.0;
-                    nzr[r] = d != 0.0;
-                    const unsigned long long k63 = (unsigned long long)__double_as_longlong(fabs(d));
-                    k32[r] = (unsigned int)(k63 >> 31);
-                    key[r] = k63 | (d > 0.0 ? WX_SIGN : 0ull);
-                    bin[r] = 0;
+                    for (int r = 0; r < R; r++) pred[r] = fma(s[r][k], qk, pred[r]);
                 }
-                // bin = #{splitters < key}: NB is a power of two, so the search is log2(NB) steps for every row -- no data-dependent
-                // trip count, and the R chains of dependent LDS reads run interleaved (a `while (lo < hi)` per row ran them one
-                // after the other: 8 LDS round trips per key were most of this kernel)
-                if (FINE) {          // fine bin from the table: one LDS read and one LDS atomic per key, no dependent chain
-                    const unsigned int kmin = sp[WX_TAB], sh = sp[WX_TAB + 1];
-                    unsigned int* ac = acc + (size_t)gs * NBF;
 #pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (!nzr[r]) continue;
-                        unsigned int fine = 0;
-                        if (k32[r] >= kmin) {
-                            const unsigned int off = k32[r] - kmin, cell = off >> sh;
-                            if (cell >= (unsigned int)WX_TAB) fine = (unsigned int)NBF - 1u;
-                            else {
-                                const unsigned int e2 = sp[cell];
-                                fine = (e2 & 0xffffu) + (unsigned int)(((unsigned long long)(off & ((1u << sh) - 1u)) * (e2 >> 16)) >> sh);
-                                fine = fine < (unsigned int)NBF - 1u ? fine : (unsigned int)NBF - 1u;
+            for (int r = 0; r < R; r++) { estar[r] = fabs(zy[r] - pred[r]); pred[r] = 0.0; }
+            int slot = slot0;
+#pragma unroll
+            for (int k = 0; k < AM - 1; k++)
+                if (k + 1 < as) {                                         // (uniform)
+                    const double qk = __hiloint2double(__builtin_amdgcn_readlane(qhi, k), __builtin_amdgcn_readlane(qlo, k));
+#pragma unroll
+                    for (int r = 0; r < R; r++) pred[r] = fma(s[r][k], qk, pred[r]);
+                    if ((mask >> k) & 1u) {                               // (uniform) the test (j, a' = k + 1) is in this group
+                        const unsigned int kb = (unsigned int)__builtin_amdgcn_readlane((int)kbv, k);
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const double d = estar[r] - fabs(zy[r] - pred[r]);
+                            const unsigned long long k63 = (unsigned long long)__double_as_longlong(fabs(d));
+                            const bool key_ok = in[r] && d != 0.0;
+                            if (MODE == 2) {
+                                const size_t i = row_t + (size_t)r * WX_T + t;
+                                if (i < kld) keys[(size_t)(lo - act_lo + slot) * kld + i] = key_ok ? (k63 | (d > 0.0 ? WX_SIGN : 0ull)) : WX_NOKEY;
+                            } else if (key_ok) {
+                                const unsigned int k32 = (unsigned int)(k63 >> 31);
+                                const unsigned int bin = MODE == 0 ? wx_cell(k32, kb) : wx_fine(k32, kb, tab_s + (size_t)slot * WX_NC0);
+                                atomicAdd(&cnt[(size_t)slot * NBX + bin], d > 0.0 ? 65537u : 1u);
                             }
                         }
-                        atomicAdd(&ac[fine], 1u + ((key[r] & WX_SIGN) ? 65536u : 0u));
+                        slot++;
                     }
-                    continue;
                 }
-                for (int step = NB >> 1; step >= 1; step >>= 1) {
-#pragma unroll
-                    for (int r = 0; r < R; r++) bin[r] += (sp[bin[r] + step - 1] < k32[r]) ? step : 0;
-                }
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    rank[r] = 0;
-                    if (!nzr[r]) { bin[r] = -1; continue; }
-                    if (SCATTER) rank[r] = atomicAdd(&lh[bin[r]], 1u);
-                    else atomicAdd(&acc[(size_t)gs * NB + bin[r]], 1u);
-                }
-                if (SCATTER) {
-                    __syncthreads();
-                    const unsigned int total = wx_block_scan(lh, cst, NB, wsum);
-                    unsigned int* go = acc + (size_t)gs * NB;
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-                        if (bin[r] >= 0) {
-                            const unsigned int slot = cst[bin[r]] + rank[r];
-                            skey[slot] = key[r];
-                            sdst[slot] = go[bin[r]] + rank[r];
-                        }
-                    __syncthreads();
-                    unsigned long long* out = keys + (size_t)(seg0 + a1 - 1) * nt;
-                    for (unsigned int q = t; q < total; q += WXT) out[sdst[q]] = skey[q];
-                    for (int b = t; b < NB; b += WXT) go[b] += lh[b];
-                    __syncthreads();
-                }
-            }
-            if (grp == 0 && tt == 0) WX_STAMP_K(SCATTER ? 3 : 2, 3);
-            if (grp == 0 && tt == 0) WX_STAMP_K(SCATTER ? 3 : 2, 4);
         }
-        __syncthreads();
-        if (grp == 0) WX_STAMP_K(SCATTER ? 3 : 2, 5);
-        if (!SCATTER)
-            for (int e2 = t; e2 < gn * NBF; e2 += WXT) {
-                const int gs = e2 / NBF, b = e2 - gs * NBF, seg = seg0 + grp * G + gs;
-                blockhist[((size_t)st * g.nseg_max + seg) * NBF + b] = acc[e2];
-            }
-        __syncthreads();
     }
-    WX_STAMP_K(SCATTER ? 3 : 2, 6);
+    if (MODE != 2) {
+        __syncthreads();
+        unsigned int* dst = blockcnt + ((size_t)rr * act_n + (size_t)(lo - act_lo)) * NBX;
+        for (int e = t; e < ng * NBX; e += WX_T) dst[e] = cnt[e];
+    }
 }
 
-// does test `seg` (of a response whose tests start at seg_first) still need its exact rank sum?  v3: 0 rejected / 1 passed by the
+// the counters of a level's sweep work-groups added up: totals[slot][bin] = all keys | positive keys << 32 (the halves add up
+// separately -- also over the ranks of a row-sharded set, whose all-reduce takes these words -- while the set has fewer than 2^32
+// validation rows).  A work-group = 32 counters x 8 slices of the runs of tiles, the slices' sums combined through LDS: every
+// thread has RR / 8 independent loads (one work-group per test walking all RR runs was 440 us of latency at 112 tests x 488 runs)
+__global__ __launch_bounds__(256) void k_wx_totals(int NBX, int RR, int act_n, const unsigned int* __restrict__ blockcnt,
+                                                   unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long part[8][32];
+    const size_t ne = (size_t)act_n * NBX, e = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const int sl = threadIdx.x >> 5;
+    unsigned long long c = 0, p = 0;
+    if (e < ne) {
+        int rr = sl;
+        for (; rr + 56 < RR; rr += 64) {
+            unsigned int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = blockcnt[(size_t)(rr + 8 * u) * ne + e];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { c += v[u] & 0xffffu; p += v[u] >> 16; }
+        }
+        for (; rr < RR; rr += 8) { const unsigned int v = blockcnt[(size_t)rr * ne + e]; c += v & 0xffffu; p += v >> 16; }
+    }
+    part[sl][threadIdx.x & 31] = c | (p << 32);
+    __syncthreads();
+    if (sl == 0 && e < ne) {
+        unsigned long long tsum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) tsum += part[u][threadIdx.x];
+        totals[e] = tsum;
+    }
+}
+
+// does test `seg` (of a response whose tests start at seg_first) still need a closer look?  v3: 0 rejected / 1 passed by the
 // bounds, 2 undecided; a test behind a smaller a' that passed is never looked at (k_wx_decide stops there)
 __device__ __forceinline__ bool wx_need(const int* __restrict__ v3, int seg_first, int seg) {
     if (v3[seg] != 2) return false;
@@ -597,145 +462,224 @@ __device__ __forceinline__ bool wx_need(const int* __restrict__ v3, int seg_firs
 __device__ double normalcdf_poly(double z);
 __device__ __forceinline__ bool wx_passes(double x) { return 2.0 * (1.0 - normalcdf_poly(x)) > 0.1; }
 
-// BOUNDS on the signed rank sum from counts alone.  Fine bin b of a test holds c_b keys, p_b of them positive differences, B_b keys
+// BOUNDS on the signed rank sum from counts alone.  Bin b of a test holds c_b keys, p_b of them positive differences, B_b keys
 // lie below it: whatever the order inside the bin, its ranks are B_b + 1 .. B_b + c_b (average ranks of ties: a doubly stochastic
 // mix of those, which moves no subset sum beyond the extremes), so the positives' rank sum lies between the p_b lowest and the p_b
 // highest of them and   2 W_b in [4 p B + 2 p (p + 1), 4 p B + 4 p c - 2 p (p - 1)] - (2 c B + c (c + 1)).
-// Integers below 2^50, summed exactly.  The interval of |W| / sigma, widened by 1e-12 against the roundings of the division, is put
+// Integers, summed exactly.  The interval of |W| / sigma, widened by 1e-12 against the roundings of the division, is put
 // through the decision function of k_wx_decide at both ends: equal answers = THE answer (the function is monotone but for the last
-// bits next to its threshold); else the test stays undecided (2) and goes through the exact sweeps.  With ~3 sqrt(n) fine bins the
-// interval is ~0.3 sigma wide: a test is undecided when its statistic lies within that of the threshold.
-__global__ __launch_bounds__(1024) void k_wx_bounds(WxGeo g, const WxPlan* __restrict__ plan, const unsigned int* __restrict__ blockfine,
-                                                    unsigned long long* __restrict__ nz, int* __restrict__ v3,
-                                                    int* __restrict__ undecided) {
-    extern __shared__ unsigned int wxb_cp[];              // [NBF] packed (all keys, positive keys) of the test's fine bins
+// bits next to its threshold); else the test stays undecided (2).  With B bins of equal depth the interval is ~0.87 sqrt(m) / B
+// sigma wide.
+// One work-group per slot of the list; counts from totals (k_wx_totals; all-reduced over the ranks of a row-sharded set).  cl: the
+// all-keys counts of the slot (the next level's table / the exact step's bins are made from them).  The LAST work-group of a level
+// to finish (ticket) compacts the tests that are still needed into act_next, in test order, and tells the host how many.
+__global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const int* __restrict__ act, const int* __restrict__ nact_p,
+                                                    int act_lo, const unsigned long long* __restrict__ totals, unsigned long long* __restrict__ nz,
+                                                    int* __restrict__ v3, unsigned int* __restrict__ cl, size_t cl_ld, int cl_by_test,
+                                                    int* __restrict__ slotmap, unsigned int* __restrict__ ticket, unsigned int nblocks_level,
+                                                    const WxPlan* __restrict__ plan, const int* __restrict__ segbase,
+                                                    int* __restrict__ act_next, int* __restrict__ nact_next,
+                                                    const double* __restrict__ nv_ranks, size_t nv_stride, int Wr, int* __restrict__ pin_words,
+                                                    int force_undecided /* diagnostic: every test with keys stays undecided */) {
+    extern __shared__ unsigned int wxb_cp[];              // [NBX] packed (all keys, positive keys) of the test's bins
     __shared__ long long red[3][16];
-    __shared__ unsigned int wtot[16];
-    const int seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (seg >= plan->nseg) return;
-    const int NBF = g.NB * g.F;
-    const size_t stride = (size_t)g.nseg_max * NBF;
-    for (int b = t; b < NBF; b += 1024) {
-        const unsigned int* src = blockfine + (size_t)seg * NBF + b;
-        unsigned int c = 0, p = 0;
-        int st = 0;
-        for (; st + 8 <= g.STb; st += 8) {
-            unsigned int v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(st + u) * stride];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { c += v[u] & 0xffffu; p += v[u] >> 16; }
+    __shared__ unsigned long long wtot[16];
+    __shared__ int s_last;
+    const int e = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int end = act_lo + act_n;
+    { const int na = *nact_p; end = end < na ? end : na; }
+    if (act_lo + e < end) {
+        const int seg = act[act_lo + e];
+        for (int b = t; b < NBX; b += 1024) {
+            const unsigned long long v = totals[(size_t)e * NBX + b];
+            const unsigned int c = (unsigned int)v, p = (unsigned int)(v >> 32);
+            wxb_cp[2 * b] = c;
+            wxb_cp[2 * b + 1] = p;
+            if (cl) cl[(size_t)(cl_by_test ? seg : act_lo + e) * cl_ld + b] = c;
         }
-        for (; st < g.STb; st++) { const unsigned int v = src[(size_t)st * stride]; c += v & 0xffffu; p += v >> 16; }
-        wxb_cp[2 * b] = c;
-        wxb_cp[2 * b + 1] = p;
+        if (t == 0 && slotmap) slotmap[seg] = act_lo + e;
+        __syncthreads();
+        // thread t owns the consecutive bins [t per, (t + 1) per): keys below them by a work-group scan of the threads' totals
+        const int per = (NBX + 1023) / 1024, b0 = t * per;
+        unsigned long long loc = 0;
+        for (int i = 0; i < per; i++) if (b0 + i < NBX) loc += wxb_cp[2 * (b0 + i)];
+        unsigned long long inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = (unsigned long long)__shfl_up((long long)inc, o, 64); if (lane >= o) inc += u; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        unsigned long long below = inc - loc;
+        for (int w = 0; w < wave; w++) below += wtot[w];
+        long long lo2 = 0, hi2 = 0, m = (long long)loc;
+        for (int i = 0; i < per; i++)
+            if (b0 + i < NBX) {
+                const long long c = wxb_cp[2 * (b0 + i)], p = wxb_cp[2 * (b0 + i) + 1], B = (long long)below;
+                const long long all2 = 2 * c * B + c * (c + 1);
+                lo2 += 4 * p * B + 2 * p * (p + 1) - all2;
+                hi2 += 4 * p * B + 4 * p * c - 2 * p * (p - 1) - all2;
+                below += (unsigned long long)c;
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo2 += __shfl_xor(lo2, o, 64); hi2 += __shfl_xor(hi2, o, 64); m += __shfl_xor(m, o, 64); }
+        if (lane == 0) { red[0][wave] = lo2; red[1][wave] = hi2; red[2][wave] = m; }
+        __syncthreads();
+        if (t == 0) {
+            lo2 = hi2 = m = 0;
+            for (int w = 0; w < 16; w++) { lo2 += red[0][w]; hi2 += red[1][w]; m += red[2][w]; }
+            nz[seg] = (unsigned long long)m;
+            int v = 1;                                         // no non-zero difference: p = 1, the test passes (k_wx_decide)
+            if (m > 0) {
+                const double md = (double)m, sigma = sqrt(md * (md + 1.0) * (2.0 * md + 1.0) / 6.0);
+                const long long alo = lo2 < 0 ? -lo2 : lo2, ahi = hi2 < 0 ? -hi2 : hi2;
+                const long long mx2 = alo > ahi ? alo : ahi, mn2 = (lo2 <= 0 && hi2 >= 0) ? 0 : (alo < ahi ? alo : ahi);
+                const double x_lo = 0.5 * (double)mn2 / sigma * (1.0 - 1e-12), x_hi = 0.5 * (double)mx2 / sigma * (1.0 + 1e-12);
+                const bool p_lo = wx_passes(x_lo), p_hi = wx_passes(x_hi);
+                v = (p_lo == p_hi && !force_undecided) ? (p_lo ? 1 : 0) : 2;
+            }
+            v3[seg] = v;
+        }
     }
-    __syncthreads();
-    // thread t owns the consecutive fine bins [t per, (t + 1) per): keys below them by a work-group scan of the threads' totals
-    const int per = (NBF + 1023) / 1024, b0 = t * per;
-    unsigned int loc = 0;
-    for (int i = 0; i < per; i++) if (b0 + i < NBF) loc += wxb_cp[2 * (b0 + i)];
-    unsigned int inc = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    unsigned int below = inc - loc;
-    for (int w = 0; w < wave; w++) below += wtot[w];
-    long long lo2 = 0, hi2 = 0, m = loc;
-    for (int i = 0; i < per; i++)
-        if (b0 + i < NBF) {
-            const long long c = wxb_cp[2 * (b0 + i)], p = wxb_cp[2 * (b0 + i) + 1], B = below;
-            const long long all2 = 2 * c * B + c * (c + 1);
-            lo2 += 4 * p * B + 2 * p * (p + 1) - all2;
-            hi2 += 4 * p * B + 4 * p * c - 2 * p * (p - 1) - all2;
-            below += (unsigned int)c;
-        }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { lo2 += __shfl_xor(lo2, o, 64); hi2 += __shfl_xor(hi2, o, 64); m += __shfl_xor(m, o, 64); }
-    if (lane == 0) { red[0][wave] = lo2; red[1][wave] = hi2; red[2][wave] = m; }
+    // ---- the level's last work-group: the tests still needed, in test order ------------------------------------------------
     __syncthreads();
     if (t == 0) {
-        lo2 = hi2 = m = 0;
-        for (int w = 0; w < 16; w++) { lo2 += red[0][w]; hi2 += red[1][w]; m += red[2][w]; }
-        nz[seg] = (unsigned long long)m;
-        int v = 1;                                         // no non-zero difference: p = 1, the test passes (k_wx_decide)
-        if (m > 0) {
-            const double md = (double)m, sigma = sqrt(md * (md + 1.0) * (2.0 * md + 1.0) / 6.0);
-            const long long alo = lo2 < 0 ? -lo2 : lo2, ahi = hi2 < 0 ? -hi2 : hi2;
-            const long long mx2 = alo > ahi ? alo : ahi, mn2 = (lo2 <= 0 && hi2 >= 0) ? 0 : (alo < ahi ? alo : ahi);
-            const double x_lo = 0.5 * (double)mn2 / sigma * (1.0 - 1e-12), x_hi = 0.5 * (double)mx2 / sigma * (1.0 + 1e-12);
-            const bool p_lo = wx_passes(x_lo), p_hi = wx_passes(x_hi);
-            v = (p_lo == p_hi) ? (p_lo ? 1 : 0) : 2;
-        }
-        v3[seg] = v;
-        if (v == 2) atomicAdd(undecided, 1);
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1u) == nblocks_level - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int nseg = plan->nseg;
+    const int per = (nseg + 1023) / 1024, s0 = t * per;
+    const volatile int* v3v = v3;
+    int mine = 0;
+    for (int i = 0; i < per; i++) {
+        const int s = s0 + i;
+        if (s < nseg && wx_need((const int*)v3v, segbase[plan->seg_j[s]], s)) mine++;
+    }
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    __shared__ int wsum[16];
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int pos = inc - mine, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) pos += wsum[w]; total += wsum[w]; }
+    for (int i = 0; i < per; i++) {
+        const int s = s0 + i;
+        if (s < nseg && wx_need((const int*)v3v, segbase[plan->seg_j[s]], s)) act_next[pos++] = s;
+    }
+    if (t == 0) {
+        *nact_next = total;
+        long long vmax = 0;
+        if (nv_ranks) for (int r = 0; r < Wr; r++) { const long long v = (long long)nv_ranks[(size_t)r * nv_stride]; vmax = v > vmax ? v : vmax; }
+        pin_words[1] = (int)(vmax & 0x7fffffff);
+        pin_words[2] = (int)(vmax >> 31);
+        __threadfence_system();
+        pin_words[0] = total;                              // (the host spins on this word)
+        __threadfence_system();
     }
 }
 
-// per segment: blockhist[st][seg][b] -> the work-group's offset inside bin b (exclusive over st), hist[seg][b] = the bin's size,
-// binbase[seg][b] = keys in front of the bin, nz[seg] = non-zero differences of the test.  1024 threads = 256 bins x 4 quarters of
-// the work-groups: partial sums per quarter (independent loads, eight in flight), then the offsets in a second sweep
-__global__ __launch_bounds__(1024) void k_wx_offsets(WxGeo g, const WxPlan* __restrict__ plan, unsigned int* __restrict__ blockhist,
-                                                     unsigned int* __restrict__ hist, unsigned int* __restrict__ binbase,
-                                                     unsigned long long* __restrict__ nz, const int* __restrict__ v3,
-                                                     const int* __restrict__ segbase) {
-    __shared__ unsigned int tot[WX_NBMAX];
-    __shared__ unsigned int part[4][256];
-    const int seg = blockIdx.x, NB = g.NB;
-    if (seg >= plan->nseg) return;
-    if (!wx_need(v3, segbase[plan->seg_j[seg]], seg)) return;          // (uniform: settled by the bounds)
-    const int bl = threadIdx.x & 255, q = threadIdx.x >> 8;
-    const int per = (g.ST + 3) / 4, s0 = q * per, s1 = (s0 + per < g.ST) ? s0 + per : g.ST;
-    const size_t stride = (size_t)g.nseg_max * NB;
-    for (int b0 = 0; b0 < NB; b0 += 256) {
-        const int b = b0 + bl;
-        unsigned int sum = 0;
-        if (b < NB) {
-            const unsigned int* src = blockhist + (size_t)seg * NB + b;
-            int st = s0;
-            for (; st + 8 <= s1; st += 8) {
-                unsigned int v[8];
+// ===========================================================================================================================
+// the exact step: the tests whose statistic the last level leaves within its resolution of the threshold
+// ===========================================================================================================================
+// One work-group per undecided test (slot u of the batch): its bins are UNIONS OF THE LAST LEVEL'S FINE BINS -- fine bin f with
+// `cum` keys below it goes to bin cum / target, so a bin holds at most target keys plus one fine bin's -- and with the fine counts
+// all-reduced their sizes and the keys in front of them are known before a key is placed: binmap (fine bin -> bin), hist, binbase,
+// the cursors of the placing kernel (0), the test's table for that level again (tabx).
+__global__ __launch_bounds__(1024) void k_wx_xplan(int NBX, int nbcap, unsigned int target, const int* __restrict__ actx, const int* __restrict__ nx_p,
+                                                   int x_lo, const int* __restrict__ slotmap, const unsigned int* __restrict__ cl,
+                                                   const unsigned int* __restrict__ c0, unsigned int* __restrict__ tabx,
+                                                   unsigned short* __restrict__ binmap, unsigned int* __restrict__ hist,
+                                                   unsigned int* __restrict__ binbase, unsigned int* __restrict__ cursor) {
+    extern __shared__ unsigned int wxp_lds[];             // hist_s[nbcap], base_s[nbcap]
+    __shared__ unsigned int wtot[16];
+    const int u = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (x_lo + u >= *nx_p) return;
+    const int seg = actx[x_lo + u];
+    unsigned int* hist_s = wxp_lds;
+    unsigned int* base_s = hist_s + nbcap;
+    for (int b = t; b < nbcap; b += 1024) { hist_s[b] = 0u; base_s[b] = 0xffffffffu; }
+    if (wave == 0) wx_wave_table(c0 + (size_t)seg * WX_NC0, NBX, tabx + (size_t)u * WX_NC0);
+    const unsigned int* row = cl + (size_t)slotmap[seg] * NBX;
+    const int per = NBX / 1024, f0 = t * per;              // (NBX: a multiple of 1024)
+    unsigned int loc = 0;
+    for (int i = 0; i < per; i++) loc += row[f0 + i];
+    unsigned int inc = loc;
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = src[(size_t)(st + u) * stride];
-#pragma unroll
-                for (int u = 0; u < 8; u++) sum += v[u];
-            }
-            for (; st < s1; st++) sum += src[(size_t)st * stride];
-        }
-        part[q][bl] = sum;
-        __syncthreads();
-        if (b < NB) {
-            unsigned int run = 0;
-            for (int qq = 0; qq < q; qq++) run += part[qq][bl];
-            unsigned int* dst = blockhist + (size_t)seg * NB + b;
-            int st = s0;
-            for (; st + 8 <= s1; st += 8) {
-                unsigned int v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = dst[(size_t)(st + u) * stride];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { dst[(size_t)(st + u) * stride] = run; run += v[u]; }
-            }
-            for (; st < s1; st++) { const unsigned int v = dst[(size_t)st * stride]; dst[(size_t)st * stride] = run; run += v; }
-            if (q == 3) { tot[b] = run; hist[(size_t)seg * NB + b] = run; }
-        }
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    unsigned int cum = inc - loc;
+    for (int w = 0; w < wave; w++) cum += wtot[w];
+    for (int i = 0; i < per; i++) {
+        const unsigned int c = row[f0 + i];
+        unsigned int b = cum / target;
+        b = b < (unsigned int)nbcap - 1u ? b : (unsigned int)nbcap - 1u;
+        binmap[(size_t)u * NBX + f0 + i] = (unsigned short)b;
+        if (c) { atomicAdd(&hist_s[b], c); atomicMin(&base_s[b], cum); }
+        cum += c;
     }
-    unsigned int total = 0;
-    if (threadIdx.x < 64) {         // NB <= 2048 counters: one wave, NB / 64 per lane
-        const int perl = (NB + 63) / 64, i0 = threadIdx.x * perl;
-        unsigned int loc = 0;
-        for (int c = 0; c < perl; c++) if (i0 + c < NB) loc += tot[i0 + c];
-        unsigned int inc = loc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const unsigned int up = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += up; }
-        unsigned int run = inc - loc;
-        for (int c = 0; c < perl; c++)
-            if (i0 + c < NB) { const unsigned int v = tot[i0 + c]; binbase[(size_t)seg * NB + i0 + c] = run; run += v; }
-        total = __shfl(inc, 63, 64);
-        if (threadIdx.x == 0) nz[seg] = total;
+    __syncthreads();
+    for (int b = t; b < nbcap; b += 1024) {
+        hist[(size_t)u * nbcap + b] = hist_s[b];
+        binbase[(size_t)u * nbcap + b] = hist_s[b] ? base_s[b] : 0u;
+        cursor[(size_t)u * nbcap + b] = 0u;
     }
+}
+
+// the keys of the batch's tests (as the sweep wrote them, gathered over the ranks: keys_all[rank][slot][kld]) into their bins: a
+// work-group takes 16384 keys of one (rank, test), counts them per bin in LDS (a key's place among the work-group's keys of its bin
+// = the returned count), reserves the work-group's share of every bin it met with ONE global atomic on the bin's cursor, and writes
+// the keys there.  Which share a work-group gets depends on the order of arrival; the rank sums do not (k_wx_ranks counts smaller
+// and equal keys: exact half-integers whatever the order inside the bin).
+constexpr int WX_PK = 16;
+__global__ __launch_bounds__(1024) void k_wx_place(int NBX, int nbcap, const unsigned long long* __restrict__ keys_all, size_t kld, int XBn,
+                                                   const int* __restrict__ nx_p, int x_lo, const int* __restrict__ actx,
+                                                   const unsigned int* __restrict__ kbase, const unsigned int* __restrict__ tabx,
+                                                   const unsigned short* __restrict__ binmap, const unsigned int* __restrict__ binbase,
+                                                   unsigned int* __restrict__ cursor, unsigned long long* __restrict__ keysx, size_t xld) {
+    extern __shared__ unsigned int wxl_lds[];             // tab_s[WX_NC0], cntb[nbcap], baseb[nbcap], map_s[NBX] (16 bit)
+    const int u = blockIdx.y, q = blockIdx.z, t = threadIdx.x;
+    if (x_lo + u >= *nx_p) return;
+    const int seg = actx[x_lo + u];
+    unsigned int* tab_s = wxl_lds;
+    unsigned int* cntb = tab_s + WX_NC0;
+    unsigned int* baseb = cntb + nbcap;
+    unsigned short* map_s = (unsigned short*)(baseb + nbcap);
+    for (int c = t; c < WX_NC0; c += 1024) tab_s[c] = tabx[(size_t)u * WX_NC0 + c];
+    for (int b = t; b < nbcap; b += 1024) cntb[b] = 0u;
+    for (int f = t; f < NBX; f += 1024) map_s[f] = binmap[(size_t)u * NBX + f];
+    __syncthreads();
+    const unsigned int kb = kbase[seg];
+    const unsigned long long* src = keys_all + ((size_t)q * XBn + u) * kld;
+    const size_t i0 = (size_t)blockIdx.x * (1024 * WX_PK);
+    unsigned long long key[WX_PK];
+    int bin[WX_PK];
+    unsigned int lr[WX_PK];
+#pragma unroll
+    for (int v = 0; v < WX_PK; v++) {
+        const size_t i = i0 + (size_t)v * 1024 + t;
+        key[v] = i < kld ? src[i] : WX_NOKEY;
+    }
+#pragma unroll
+    for (int v = 0; v < WX_PK; v++) {
+        bin[v] = -1; lr[v] = 0;
+        if (key[v] != WX_NOKEY) {
+            bin[v] = (int)map_s[wx_fine((unsigned int)((key[v] & WX_MASK) >> 31), kb, tab_s)];
+            lr[v] = atomicAdd(&cntb[bin[v]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = t; b < nbcap; b += 1024) {
+        const unsigned int c = cntb[b];
+        if (c) baseb[b] = binbase[(size_t)u * nbcap + b] + atomicAdd(&cursor[(size_t)u * nbcap + b], c);
+    }
+    __syncthreads();
+    unsigned long long* out = keysx + (size_t)u * xld;
+#pragma unroll
+    for (int v = 0; v < WX_PK; v++)
+        if (bin[v] >= 0) out[baseb[bin[v]] + lr[v]] = key[v];
 }
 
 // bitonic sort of T SPT 64-bit keys, SPT per thread in registers (element t SPT + u): compare-exchanges inside a thread stay in
@@ -847,28 +791,30 @@ __device__ __forceinline__ double wx_bin_ranksum(const unsigned long long* __res
 // splitters (sort a sample, search it, count, place, walk) 70 000 - 112 000, this 25 000.  What linear sub-bins cannot take is a
 // bin whose keys are NOT spread over its range -- the first and the last bin of a test (a single tiny |d| stretches the range over
 // hundreds of binades), heavy ties: a sub-bin above WX_WALK keys sends the bin to k_wx_ranks_big, which sorts it.
+constexpr int WX_CAP = 16384;                    // keys one bin may hold (k_wx_ranks_big: the bin in 128 KB of LDS)
 constexpr int WX_CAP_S = 4096;                  // keys of a bin this kernel takes (16 per thread)
 constexpr int WX_NS = 1024;                     // linear sub-bins
 constexpr int WX_WALK = 48;                     // longest sub-bin it walks
-__global__ __launch_bounds__(256) void k_wx_ranks(WxGeo g, const WxPlan* __restrict__ plan, const unsigned long long* __restrict__ keys,
+// (round 5: a slot u of the exact step's batch = test actx[x_lo + u]; its placed keys at keys + u xld, its bins in hist / binbase [u][nbcap])
+__global__ __launch_bounds__(256) void k_wx_ranks(int nbcap, const int* __restrict__ actx, const int* __restrict__ nx_p, int x_lo,
+                                                  const unsigned long long* __restrict__ keys, size_t xld,
                                                   const unsigned int* __restrict__ hist, const unsigned int* __restrict__ binbase,
-                                                  double* __restrict__ W, unsigned int* __restrict__ big /* [0] count, then (seg, bin) pairs */,
-                                                  const int* __restrict__ v3, const int* __restrict__ segbase) {
+                                                  double* __restrict__ W, unsigned int* __restrict__ big /* [0] count, then (slot, bin) pairs */) {
     constexpr int T = 256, KPT = WX_CAP_S / T;
     __shared__ unsigned long long ks[WX_CAP_S + 1];
     __shared__ unsigned int cnt[WX_NS + 2], start[WX_NS + 2];
     __shared__ unsigned long long rmm[2 * T / 64];
     __shared__ double red[T / 64];
     __shared__ unsigned int s_max[T / 64];
-    const int seg = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    if (seg >= plan->nseg) return;
-    if (!wx_need(v3, segbase[plan->seg_j[seg]], seg)) return;
-    const unsigned int n = hist[(size_t)seg * g.NB + b];
+    const int u = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    if (x_lo + u >= *nx_p) return;
+    const int seg = actx[x_lo + u];
+    const unsigned int n = hist[(size_t)u * nbcap + b];
     if (n == 0) return;
-    auto to_big = [&]() { if (t == 0) { const unsigned int e = atomicAdd(&big[0], 1u); big[1 + 2 * e] = (unsigned int)seg; big[2 + 2 * e] = (unsigned int)b; } };
+    auto to_big = [&]() { if (t == 0) { const unsigned int e = atomicAdd(&big[0], 1u); big[1 + 2 * e] = (unsigned int)u; big[2 + 2 * e] = (unsigned int)b; } };
     if (n > (unsigned int)WX_CAP_S) { to_big(); return; }
-    const unsigned int base = binbase[(size_t)seg * g.NB + b];
-    const unsigned long long* src = keys + (size_t)seg * g.nt + base;
+    const unsigned int base = binbase[(size_t)u * nbcap + b];
+    const unsigned long long* src = keys + (size_t)u * xld + base;
     const int kpt = (int)((n + T - 1) / T);                                 // key slots in use (uniform over the work-group)
     WX_STAMP(0);
     unsigned long long k[KPT];
@@ -994,18 +940,20 @@ __global__ __launch_bounds__(256) void k_wx_ranks(WxGeo g, const WxPlan* __restr
 // the bins k_wx_ranks passes on (above WX_CAP_S keys: a sparse sample quantile; keys not spread over the bin's range: the ends of a
 // test, heavy ties): work-groups of 1024 threads with 128 KB of LDS walk the list and SORT each bin (wx_bin_ranksum); a bin above
 // WX_CAP keys raises the flag that sends the reduction to the sorted path
-__global__ __launch_bounds__(1024) void k_wx_ranks_big(WxGeo g, const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ hist,
+__global__ __launch_bounds__(1024) void k_wx_ranks_big(int nbcap, const int* __restrict__ actx, int x_lo, const unsigned long long* __restrict__ keys,
+                                                       size_t xld, const unsigned int* __restrict__ hist,
                                                        const unsigned int* __restrict__ binbase, double* __restrict__ W,
                                                        const unsigned int* __restrict__ big, int* __restrict__ fail) {
     extern __shared__ unsigned long long wx_big_ks[];                       // WX_CAP keys
     __shared__ double red[32];
     const unsigned int nbig = big[0];
     for (unsigned int e = blockIdx.x; e < nbig; e += gridDim.x) {
-        const unsigned int seg = big[1 + 2 * e], b = big[2 + 2 * e];
-        const unsigned int n = hist[(size_t)seg * g.NB + b];
+        const unsigned int u = big[1 + 2 * e], b = big[2 + 2 * e];
+        const int seg = actx[x_lo + (int)u];
+        const unsigned int n = hist[(size_t)u * nbcap + b];
         if (n > (unsigned int)WX_CAP) { if (threadIdx.x == 0) *fail = 1; continue; }    // (the host repeats the reduction on the sorted path)
-        const unsigned int base = binbase[(size_t)seg * g.NB + b];
-        const unsigned long long* src = keys + (size_t)seg * g.nt + base;
+        const unsigned int base = binbase[(size_t)u * nbcap + b];
+        const unsigned long long* src = keys + (size_t)u * xld + base;
         double tw;                                                           // (the network's length goes with the padded size)
         if (n <= 2048) tw = wx_bin_ranksum<1024, 2>(src, n, base, wx_big_ks, red);
         else if (n <= 4096) tw = wx_bin_ranksum<1024, 4>(src, n, base, wx_big_ks, red);
@@ -1063,7 +1011,6 @@ __global__ void k_wx_decide(double* __restrict__ model, int M, int P, int A, con
     if (threadIdx.x == 0) model[ML.off_hdr] = (double)s_ncomp;
 }
 
-// observed scores do not depend on ncomp (all A are stored), nothing else to refresh
 
 }  // namespace
 
@@ -1090,8 +1037,9 @@ static int launch_wilcoxon_sorted(abc_ctx* ctx, const double* X, const double* Y
     unsigned long long* val1 = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
     if (!plan || !seg_j || !seg_a || !astar || !nz || !W || !S || !key0 || !val0 || !key1 || !val1)
         ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu segments x %zu rows)", nseg_max, nt);
-    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar,
-                       (int)nseg_max, nz, W, (int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, ctx->stream, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar,
+                       (int)nseg_max, nz, W, (int*)nullptr, (int*)nullptr, (int*)nullptr, (unsigned int*)nullptr, (int*)nullptr, (int*)nullptr,
+                       (unsigned int*)nullptr, 1.0);
     // the number of segments actually needed lives on the device; size the grid for the maximum, idle blocks exit
     int nseg_host = 0;
     ABC_HIP(ctx, hipMemcpyAsync(&nseg_host, &plan->nseg, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1105,7 +1053,7 @@ static int launch_wilcoxon_sorted(abc_ctx* ctx, const double* X, const double* Y
         KC = 0;
     }
 #define LAUNCH_SC(KCV) hipLaunchKernelGGL(k_wx_scores<KCV>, dim3(rb), dim3(256), 0, ctx->stream, X, ldx, row_test, nt, \
-                                          (int)M, (int)P, (int)A, model, S)
+                                          (int)M, (int)P, (int)A, model, S, nt)
     switch (KC) {
         case 0: break;
         case 1: LAUNCH_SC(1); break;
@@ -1135,138 +1083,149 @@ static size_t wx_sorted_need(size_t nt, size_t P, size_t A) {
     return nt * A * 8 + 4 * seg * nt * 8 + 2 * 256 * ((seg * nt) / 1024 + 2) * 4 + seg * 32 + P * 8 + (2u << 20);
 }
 
-static bool wx_no_bounds() {            // A/B runs and tests (ABC_DIAG=1 ABC_WX_NOBOUNDS=1): every test through the exact sweeps
-    static const bool on = abc_diag_env("ABC_WX_NOBOUNDS") != nullptr;
-    return on;
-}
-// geometry of the binned path; false: the shape goes to the sorted path
-static bool wx_geometry(size_t nt, size_t P, size_t A, WxGeo* g, int* R_out) {
-    if (A > 32 || A < 2 || nt == 0 || P * (A - 1) > MAXSEG) return false;
-    int NB = 1;
-    if (nt > (size_t)WX_CAP / 2) while ((size_t)NB * 2048 < nt) NB *= 2;
-    if (NB > WX_NBMAX || nt / (size_t)NB > 3500) return false;
-    if (NB > 1 && nt < (size_t)(NB <= 256 ? 4096 : (NB <= 1024 ? 16384 : 32768))) return false;
-    const int R = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
-    const size_t TR = (size_t)WXT * R, tiles = (nt + TR - 1) / TR;
-    size_t tps = (tiles * P + 4095) / 4096;
-    if (tps < 1) tps = 1;
-    g->nt = nt;
-    g->NB = NB;
-    g->SAMP = NB <= 256 ? 4096 : (NB <= 1024 ? 16384 : 32768);      // >= 16 sampled rows per bin (k_wx_sample<SAMP / 1024>); NB > 1: nt > 4096
-    g->tps = (int)tps;
-    g->ST = (int)((tiles + tps - 1) / tps);
-    int G = (int)((96u << 10) / ((size_t)NB * 8));         // splitter prefixes (4 bytes) + counters (4) of a group's bins in <= 96 KB of LDS
-    if (G < 1) G = 1;
-    if (G > (int)A - 1) G = (int)A - 1;
-    g->G = G;
-    g->nseg_max = (int)(P * (A - 1));
-    // the bounds sweep: ~2.5 sqrt(nt) fine bins and up (an interval of <= 0.35 sigma), at most 8192; a work-group's rows below 2^16
-    g->F = 0; g->STb = 0; g->tpsb = 0; g->Gb = 0;
-    if (NB > 1 && !wx_no_bounds()) {
-        size_t nbf = (size_t)NB;
-        while (nbf < 8192 && (double)nbf < 2.5 * sqrt((double)nt)) nbf *= 2;
-        g->F = (int)(nbf / (size_t)NB);
-        size_t stb = (1024 + P - 1) / P;
-        if (stb > tiles) stb = tiles;
-        size_t tpsb = (tiles + stb - 1) / stb;
-        const size_t tmax = 61440 / TR;
-        if (tpsb > tmax) tpsb = tmax;
-        g->tpsb = (int)tpsb;
-        g->STb = (int)((tiles + tpsb - 1) / tpsb);
-        int Gb = (int)((72u << 10) / ((size_t)(WX_TAB + 2) * 4 + nbf * 4));
-        if (Gb < 1) Gb = 1;
-        if (Gb > (int)A - 1) Gb = (int)A - 1;
-        g->Gb = Gb;
-    }
-    *R_out = R;
-    return true;
-}
-static size_t wx_binned_need(size_t nt, size_t P, size_t A) {
-    WxGeo g;
-    int R;
-    if (!wx_geometry(nt, P, A, &g, &R)) return 0;
-    const size_t seg = P * (A - 1);
-    return nt * A * 8 + seg * nt * 8 + (size_t)g.ST * seg * g.NB * 4 + (size_t)g.STb * seg * g.NB * g.F * 4 + seg * g.NB * (8 + 4 + 4 + 8) +
-           seg * (40 + (size_t)(WX_TAB + 2) * 4) + P * 16 + (1u << 20);
-}
+
 static bool wx_force_sorted() {          // A/B runs and tests (ABC_DIAG=1 ABC_WX_SORTED=1): the sorted path only
     static const bool on = abc_diag_env("ABC_WX_SORTED") != nullptr;
     return on;
 }
-size_t abc_wx_need(size_t nt, size_t P, size_t A) {
-    const size_t b = wx_force_sorted() ? 0 : wx_binned_need(nt, P, A);
-    return b ? b : wx_sorted_need(nt, P, A);       // (a binned reduction that has to be repeated on the sorted path allocates its own arena)
+static bool wx_no_bounds() {             // A/B runs and tests (ABC_DIAG=1 ABC_WX_NOBOUNDS=1): every needed test through the exact step
+    static const bool on = abc_diag_env("ABC_WX_NOBOUNDS") != nullptr;
+    return on;
+}
+// the cascade takes sets of at least 16384 validation rows (over all ranks) and at most 32 components; the rest goes to the sorted path
+bool abc_wx_cascade_applies(size_t nv_total, size_t P, size_t A) {
+    return !wx_force_sorted() && A >= 2 && A <= 32 && nv_total >= 16384 && nv_total < ((size_t)1 << 31) && P * (A - 1) <= MAXSEG;
 }
 
-// mode 0: the counting sweep, 1: the placing sweep (blockhist: per-bin counts / offsets of the work-groups), 2: the bounds sweep
-// (blockhist: the fine-bin counters)
-template <int AM, int R>
-static void wx_launch_bins(abc_ctx* ctx, int mode, const WxGeo& g, const double* Y, size_t ldy, size_t row_test, size_t M, size_t P,
-                           size_t A, const double* model, const double* S, const WxPlan* plan, const int* segbase,
-                           const unsigned long long* spl, unsigned int* blockhist, const unsigned int* binbase, unsigned long long* keys,
-                           const int* v3, const unsigned int* tab) {
-    const int ST = mode == 2 ? g.STb : g.ST;
-    const dim3 grid = mode == 2 ? dim3((unsigned)(8 * ((ST + 7) / 8) * P), 1u) : dim3((unsigned)(8 * ((ST + 7) / 8)), (unsigned)P);
-    size_t lds = (size_t)g.G * g.NB * 8 + (size_t)g.NB * 8 + 8;
-    if (mode == 1) {
-        lds += (size_t)WXT * R * 12 + 16;
-        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_wx_bin<AM, R, 1>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
-                           plan, segbase, spl, blockhist, binbase, keys, v3, tab);
-    } else if (mode == 0) {
-        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_wx_bin<AM, R, 0>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
-                           plan, segbase, spl, blockhist, binbase, keys, v3, tab);
-    } else {
-        lds = (size_t)g.Gb * ((size_t)(WX_TAB + 2) * 4 + (size_t)g.NB * g.F * 4) + 64;
-        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_bin<AM, R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_wx_bin<AM, R, 2>), grid, dim3(WXT), lds, ctx->stream, Y, ldy, row_test, g, (int)M, (int)P, (int)A, model, S,
-                           plan, segbase, spl, blockhist, binbase, keys, v3, tab);
+namespace {
+struct WxLevel { int R, tiles, G, TG, RR, tpw, nslots; };   // rows per thread, tiles of 1024 R rows, tests per work-group, groups of tests,
+                                                            // runs of tiles, tiles per run, tests of this launch
+// A launch over `want` tests with NBX bins each: whole groups of G tests (a group's counters fill the LDS of a work-group), as many
+// tests as the counter buffer (bc_bytes) takes.  ONE work-group runs on a CU (LDS), so about 256 of them: R rows per thread as long
+// as (tiles x groups) still fills three quarters of the chip (more rows per thread = more loads in flight per latency), then
+// 256 / groups runs of tiles; a work-group's rows stay below 2^16 (its counters are 16-bit halves).
+WxLevel wx_level(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, size_t bc_bytes) {
+    WxLevel g;
+    g.G = (int)((size_t)WX_LDS / per_test_lds);
+    if (g.G < 1) g.G = 1;
+    if (g.G > want) g.G = want;
+    const int rmax = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
+    int ns = want;
+    for (int it = 0; it < 8; it++) {
+        g.nslots = ns;
+        g.TG = (ns + g.G - 1) / g.G;
+        g.R = rmax;
+        while (g.R > 1 && ((nt + (size_t)WX_T * g.R - 1) / ((size_t)WX_T * g.R)) * (size_t)g.TG < 192) g.R >>= 1;
+        g.tiles = (int)((nt + (size_t)WX_T * g.R - 1) / ((size_t)WX_T * g.R));
+        const int limit = 65535 / (WX_T * g.R);
+        int rr_target = 256 / g.TG;
+        if (rr_target < 1) rr_target = 1;
+        int tpw = (g.tiles + rr_target - 1) / rr_target;
+        if (tpw < 1) tpw = 1;
+        if (tpw > limit) tpw = limit;
+        g.tpw = tpw;
+        g.RR = (g.tiles + tpw - 1) / tpw;
+        if (g.RR < 1) g.RR = 1;
+        const size_t bytes = (size_t)g.RR * ns * NBX * 4;
+        if (bytes <= bc_bytes || ns <= g.G) break;
+        int fit = (int)(bc_bytes / ((size_t)g.RR * NBX * 4)) / g.G * g.G;
+        if (fit < g.G) fit = g.G;
+        if (fit >= ns) break;
+        ns = fit;
+    }
+    return g;
+}
+size_t wx_bc_bytes(size_t nv, size_t nseg_max) {           // the sweeps' counter buffer: [runs of tiles][tests of a launch][bins]
+    const size_t tiles = (nv + WX_T - 1) / WX_T;
+    size_t b = (tiles > 0 ? tiles : 1) * (nseg_max * 2048 * 4 > (size_t)8 * WX_NBFMAX * 4 ? nseg_max * 2048 * 4 : (size_t)8 * WX_NBFMAX * 4);
+    const size_t cap = (size_t)96 << 20;
+    return (b < cap ? b : cap) + (1u << 20);
+}
+// bins of a fine level over `nact` tests: the fewer tests are left, the finer (a test's counters live in LDS: 4 bytes a bin)
+int wx_pick_bins(int nact, size_t nvt) {
+    int nb = nact <= 8 ? 16384 : (nact <= 32 ? 8192 : (nact <= 96 ? 4096 : 2048));
+    while (nb > 1024 && (size_t)nb * 4 > nvt) nb >>= 1;                // (at least four keys to the bin)
+    return nb;
+}
+int wx_xb(size_t nvt) {                           // tests of one batch of the exact step
+    size_t xb = ((size_t)1 << 25) / (nvt ? nvt : 1);
+    return xb < 1 ? 1 : (xb > 8 ? 8 : (int)xb);
+}
+unsigned int wx_target(size_t nvt) { const size_t t = (nvt + 3499) / 3500; return (unsigned int)(t > 2048 ? t : 2048); }
+}  // namespace
+
+static size_t wx_cascade_need(size_t nv, size_t P, size_t A) {
+    if (!abc_wx_cascade_applies(nv, P, A)) return 0;
+    const size_t seg = P * (A - 1);
+    const int xb = wx_xb(nv);
+    const size_t nbcap = nv / wx_target(nv) + 2;
+    return nv * A * 8 + wx_bc_bytes(nv, seg) + seg * (2048 * 4 + 2048 * 8) + (size_t)40 * WX_NBFMAX * 12 + seg * WX_NC0 * (4 + 8) + seg * 64 + P * 16 +
+           (size_t)xb * (2 * nv * 8 + WX_NBFMAX * 2 + WX_NC0 * 4 + nbcap * 20) + (2u << 20);
+}
+size_t abc_wx_need(size_t nt, size_t P, size_t A) {
+    const size_t b = wx_cascade_need(nt, P, A);
+    return b ? b : wx_sorted_need(nt, P, A);       // (a cascade that has to be repeated on the sorted path allocates its own arena)
+}
+
+// the host's look at one word the device writes when it is done (pinned, preset to -1): a spin, with a glance at the stream
+// every few thousand turns so that a failed launch ends the wait
+static int wx_wait_word(abc_ctx* ctx, volatile int* w, int* out) {
+    for (unsigned long spins = 0;; spins++) {
+        const int v = *w;
+        if (v >= 0) { *out = v; return ABC_OK; }
+        if ((spins & 0x3fff) == 0x3fff) {
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) {
+                const int v2 = *w;
+                if (v2 >= 0) { *out = v2; return ABC_OK; }
+                ABC_FAIL(ctx, ABC_ERR_HIP, "wilcoxon: the stream went idle without the bounds kernel's word");
+            }
+            if (e != hipErrorNotReady) ABC_FAIL(ctx, ABC_ERR_HIP, "wilcoxon: %s", hipGetErrorString(e));
+        }
     }
 }
 
-// The binned path.  *fail_host = 1 when a bin outgrew LDS (the caller repeats the reduction on the sorted path).
-static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const double* X, const double* Y, size_t ldx, size_t ldy, size_t M,
-                                  size_t P, size_t A, size_t row_test, double* model, int* fail_host) {
-    const size_t nt = (size_t)g.nt, nseg_max = (size_t)g.nseg_max, NB = (size_t)g.NB;
-    WxPlan* plan = (WxPlan*)abc_ws_alloc(ctx, sizeof(WxPlan));
-    int* seg_j = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    int* seg_a = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    int* astar = (int*)abc_ws_alloc(ctx, P * sizeof(int));
-    int* segbase = (int*)abc_ws_alloc(ctx, P * sizeof(int));
-    int* fail = (int*)abc_ws_alloc(ctx, 2 * sizeof(int));
-    unsigned int* big = (unsigned int*)abc_ws_alloc(ctx, (1 + 2 * nseg_max * NB) * 4);       // bins above WX_CAP_S keys: count, (seg, bin) pairs
-    unsigned long long* nz = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * 8);
-    double* W = (double*)abc_ws_alloc(ctx, nseg_max * 8);
-    double* S = (double*)abc_ws_alloc(ctx, nt * A * 8);
-    unsigned long long* spl = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * NB * 8);
-    unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, nseg_max * NB * 4);
-    unsigned int* binbase = (unsigned int*)abc_ws_alloc(ctx, nseg_max * NB * 4);
-    unsigned int* blockhist = (unsigned int*)abc_ws_alloc(ctx, (size_t)g.ST * nseg_max * NB * 4);
-    unsigned int* blockfine = (unsigned int*)abc_ws_alloc(ctx, (size_t)g.STb * nseg_max * NB * g.F * 4 + 4);
-    int* v3 = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    unsigned int* tab = (unsigned int*)abc_ws_alloc(ctx, nseg_max * (size_t)(WX_TAB + 2) * 4);
-    unsigned long long* keys = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * nt * 8);
-    if (!blockfine || !v3 || !tab) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu segments x %zu rows)", nseg_max, nt);
-    if (!plan || !seg_j || !seg_a || !astar || !segbase || !fail || !big || !nz || !W || !S || !spl || !hist || !binbase || !blockhist || !keys)
-        ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu segments x %zu rows)", nseg_max, nt);
-    hipStream_t st = ctx->stream;
-#ifdef WX_STAMPS
-    static unsigned long long* stamp_dev = nullptr;
-    const size_t nslots = WX_STAMPS == 1 ? nseg_max * NB : (size_t)(8 * ((g.ST + 7) / 8)) * P;
-    const size_t nstamp = nslots * 16;
-    static size_t stamp_cap = 0;
-    if (stamp_cap < nstamp) { if (stamp_dev) (void)hipFree(stamp_dev); ABC_HIP(ctx, hipMalloc((void**)&stamp_dev, nstamp * 8)); stamp_cap = nstamp; }
-    ABC_HIP(ctx, hipMemsetAsync(stamp_dev, 0, nstamp * 8, st));
-    ABC_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(wx_stamp_buf), &stamp_dev, sizeof(stamp_dev), 0, hipMemcpyHostToDevice, st));
-#endif
-    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
-                       segbase, fail, v3);
-    ABC_HIP(ctx, hipMemsetAsync(big, 0, 4, st));
+template <int AM, int R>
+static void wx_launch_sweep(abc_ctx* ctx, int mode, const WxLevel& g, size_t lds, const double* Y, size_t ldy, size_t row_test, size_t nt, size_t M,
+                            size_t P, size_t A, const double* model, const double* S, const int* seg_j, const int* seg_a, const int* astar,
+                            const int* act, const int* nact_p, int act_lo, const unsigned int* kbase, const unsigned int* c0, int NBX,
+                            unsigned int* blockcnt, unsigned long long* keys, size_t kld) {
+    const dim3 grid((unsigned)(8 * ((g.RR + 7) / 8) * g.TG));
+#define WX_SW(MODEV)                                                                                                                      \
+    do {                                                                                                                                  \
+        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_sweep<AM, R, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_wx_sweep<AM, R, MODEV>), grid, dim3(WX_T), lds, ctx->stream, Y, ldy, row_test, nt, (int)M, (int)P, (int)A, model, S, \
+                           seg_j, seg_a, astar, act, nact_p, act_lo, g.nslots, g.G, g.TG, g.RR, g.tpw, kbase, c0, NBX, blockcnt, keys, kld);  \
+    } while (0)
+    if (mode == 0) WX_SW(0); else if (mode == 1) WX_SW(1); else WX_SW(2);
+#undef WX_SW
+}
+static void wx_sweep(abc_ctx* ctx, size_t A, int mode, const WxLevel& g, size_t lds, const double* Y, size_t ldy, size_t row_test,
+                     size_t nt, size_t M, size_t P, const double* model, const double* S, const int* seg_j, const int* seg_a, const int* astar,
+                     const int* act, const int* nact_p, int act_lo, const unsigned int* kbase, const unsigned int* c0, int NBX,
+                     unsigned int* blockcnt, unsigned long long* keys, size_t kld) {
+#define WX_GO(AMV, RV) wx_launch_sweep<AMV, RV>(ctx, mode, g, lds, Y, ldy, row_test, nt, M, P, A, model, S, seg_j, seg_a, astar, act, nact_p, act_lo, \
+                                                kbase, c0, NBX, blockcnt, keys, kld)
+    if (A <= 8) { if (g.R == 4) WX_GO(8, 4); else if (g.R == 2) WX_GO(8, 2); else WX_GO(8, 1); }
+    else if (A <= 16) { if (g.R == 2) WX_GO(16, 2); else WX_GO(16, 1); }
+    else WX_GO(32, 1);
+#undef WX_GO
+}
+
+// scores of the validation rows (S[i + nt k], all A components)
+static void wx_scores(abc_ctx* ctx, const double* X, size_t ldx, size_t row_test, size_t nt, size_t M, size_t P, size_t A, const double* model, double* S) {
+    // the projection's kernels where the shape is theirs (row pairs with 16-byte loads; 17..32 components on the fp64 matrix pipe: the
+    // vector kernel below took 605 us at 5e5 rows x 128 metrics x 32 components, k_project_mfma does twice the rows in 270), the
+    // vector kernel for what they leave (an odd last row, unaligned or narrow sets)
+    static const bool plain = abc_diag_env("ABC_WX_PLAIN_SCORES") != nullptr;
+    const size_t took = plain ? 0 : launch_project_scores(ctx, X + row_test, nt, ldx, M, P, A, model, S);
+    if (took >= nt) return;
+    const size_t nt_all = nt;
+    X += took; S += took; nt -= took;
     const unsigned rb = (unsigned)((nt + 255) / 256);
     int KC = 1;
     while (KC < (int)A) KC *= 2;
-#define LAUNCH_SC(KCV) hipLaunchKernelGGL(k_wx_scores<KCV>, dim3(rb), dim3(256), 0, st, X, ldx, row_test, nt, (int)M, (int)P, (int)A, model, S)
+#define LAUNCH_SC(KCV) hipLaunchKernelGGL(k_wx_scores<KCV>, dim3(rb), dim3(256), 0, ctx->stream, X, ldx, row_test, nt, (int)M, (int)P, (int)A, model, S, nt_all)
     switch (KC) {
         case 1: LAUNCH_SC(1); break;
         case 2: LAUNCH_SC(2); break;
@@ -1276,60 +1235,161 @@ static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const dou
         default: LAUNCH_SC(32); break;
     }
 #undef LAUNCH_SC
-    // (the number of tests lives on the device: every grid is sized for the maximum, idle work-groups leave at once)
-    if (g.NB > 1) {
-#define WX_SAMPLE(EPTV)                                                                                                              \
-    do {                                                                                                                             \
-        if ((size_t)g.SAMP * 4 > (48u << 10))                                                                                        \
-            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_sample<EPTV>, hipFuncAttributeMaxDynamicSharedMemorySize, g.SAMP * 4)); \
-        hipLaunchKernelGGL(k_wx_sample<EPTV>, dim3((unsigned)nseg_max), dim3(1024), (size_t)g.SAMP * 4, st, Y, ldy, row_test, g, (int)M, \
-                           (int)P, (int)A, (const double*)model, (const double*)S, (const WxPlan*)plan, spl, tab);                 \
-    } while (0)
-        if (g.SAMP == 4096) WX_SAMPLE(4);
-        else if (g.SAMP == 16384) WX_SAMPLE(16);
-        else WX_SAMPLE(32);
-#undef WX_SAMPLE
-    }
-#define WX_BINS(AMV, RV, MODE, BH) wx_launch_bins<AMV, RV>(ctx, MODE, g, Y, ldy, row_test, M, P, A, model, S, plan, segbase, spl, BH, binbase, keys, v3, tab)
-    // the bounds sweep first: it settles every test whose statistic is not next to the threshold (v3); the counting, placing and
-    // ranking launches behind it then only work on the undecided ones (their work-groups look at v3 and leave)
-    bool exact = true;                      // are the exact sweeps needed?
-    for (int pass = g.F ? -1 : 0; pass < 2; pass++) {
-        const int mode = pass < 0 ? 2 : pass;
-        unsigned int* bh = pass < 0 ? blockfine : blockhist;
-        if (R == 4) WX_BINS(8, 4, mode, bh);
-        else if (R == 2) WX_BINS(16, 2, mode, bh);
-        else WX_BINS(32, 1, mode, bh);
-        if (pass < 0) {
-            if ((size_t)NB * g.F * 8 > (48u << 10))
-                ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NB * g.F * 8)));
-            hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)nseg_max), dim3(1024), (size_t)NB * g.F * 8, st, g, (const WxPlan*)plan,
-                               (const unsigned int*)blockfine, nz, v3, fail + 1);
-            // the reduction's host visit, here rather than at its end: with every test settled (the usual case) nothing else is
-            // queued but the decision -- five launches of work-groups that would look at the verdicts and leave are 25 us
-            int und = 0;
-            ABC_HIP(ctx, hipMemcpyAsync(&und, fail + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-            ABC_HIP(ctx, hipStreamSynchronize(st));
-            if (und == 0) { exact = false; break; }
+}
+
+// The cascade.  *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
+static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* Y, size_t nt, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
+                                   size_t row_test, double* model, const abc_wx_shard* sh, int* fail_host) {
+    const int Wr = (sh && ctx->comm_kind) ? ctx->comm_world : 1;
+    const bool sharded = Wr > 1;
+    const size_t nvt = sh ? sh->nv_total : nt, nseg_max = P * (A - 1);
+    const size_t bc_bytes = wx_bc_bytes(nvt, nseg_max);
+    hipStream_t st = ctx->stream;
+    WxPlan* plan = (WxPlan*)abc_ws_alloc(ctx, sizeof(WxPlan));
+    int* seg_j = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    int* seg_a = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    int* astar = (int*)abc_ws_alloc(ctx, P * sizeof(int));
+    int* segbase = (int*)abc_ws_alloc(ctx, P * sizeof(int));
+    int* fail = (int*)abc_ws_alloc(ctx, 2 * sizeof(int));
+    unsigned long long* nz = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * 8);
+    double* W = (double*)abc_ws_alloc(ctx, nseg_max * 8);
+    int* v3 = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    unsigned int* kbase = (unsigned int*)abc_ws_alloc(ctx, nseg_max * 4);
+    int* actA = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    int* actB = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    int* nactv = (int*)abc_ws_alloc(ctx, 4 * sizeof(int));
+    unsigned int* tickets = (unsigned int*)abc_ws_alloc(ctx, 4 * sizeof(int));
+    int* slotmap = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+    unsigned char* passb = (unsigned char*)abc_ws_alloc(ctx, nseg_max);
+    double* S = (double*)abc_ws_alloc(ctx, (nt ? nt : 1) * A * 8);
+    unsigned int* c0 = (unsigned int*)abc_ws_alloc(ctx, nseg_max * WX_NC0 * 4);
+    unsigned int* blockcnt = (unsigned int*)abc_ws_alloc(ctx, bc_bytes);
+    if (!plan || !seg_j || !seg_a || !astar || !segbase || !fail || !nz || !W || !v3 || !kbase || !actA || !actB || !nactv || !tickets || !slotmap ||
+        !passb || !S || !c0 || !blockcnt)
+        ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu tests x %zu rows)", nseg_max, nt);
+    volatile int* pin = (volatile int*)(ctx->status_pin + 64);
+    const double* nv_ranks = sh ? sh->nv_ranks : nullptr;
+    const size_t nv_stride = sh ? sh->nv_stride : 0;
+
+    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
+                       segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt);
+    if (nt) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
+    ABC_HIP(ctx, hipGetLastError());
+
+    // one level over the tests act[0 .. nact_host) (nact on the device at nact_p): sweeps in batches, the counts (all-reduced over
+    // the ranks), bounds; the last bounds work-group leaves the tests still needed in act_out / nact_out and their number in the
+    // pinned word, which the host waits for
+    unsigned int* cl_fine = nullptr;
+    size_t cl_fine_ld = 0;
+    auto level = [&](int lvl, int mode, int NBX, const int* act, const int* nact_p, int nact_host, int* act_out, int* nact_out, unsigned int* cl,
+                     size_t cl_ld, int cl_by_test, int* left) -> int {
+        const size_t per_test = (size_t)NBX * 4 + (mode == 1 ? WX_NC0 * 4 : 0) + 6 * 4;
+        pin[0] = -1;
+        const size_t blds = (size_t)NBX * 8;
+        if (blds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+        for (int lo = 0; lo < nact_host;) {
+            const WxLevel g = wx_level(nt, A, nact_host - lo, NBX, per_test, bc_bytes);
+            const size_t lds = (size_t)g.G * per_test + 64, ne = (size_t)g.nslots * NBX;
+            unsigned long long* totals = (unsigned long long*)abc_ws_alloc(ctx, ne * 8);
+            if (!totals) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
+            if (nt) {
+                wx_sweep(ctx, A, mode, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act, nact_p, lo, kbase, c0, NBX, blockcnt, nullptr, 0);
+                hipLaunchKernelGGL(k_wx_totals, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, st, NBX, g.RR, g.nslots, (const unsigned int*)blockcnt, totals);
+            } else
+                ABC_HIP(ctx, hipMemsetAsync(totals, 0, ne * 8, st));
+            if (sharded) ABC_TRY(abc_comm_all_reduce(ctx, totals, ne, ABC_DT_I64));
+            hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)g.nslots), dim3(1024), blds, st, NBX, g.nslots, act, nact_p, lo, (const unsigned long long*)totals,
+                               nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const WxPlan*)plan, (const int*)segbase,
+                               act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0);
+            ABC_HIP(ctx, hipGetLastError());
+            lo += g.nslots;
         }
-        if (pass == 0)
-            hipLaunchKernelGGL(k_wx_offsets, dim3((unsigned)nseg_max), dim3(1024), 0, st, g, (const WxPlan*)plan, blockhist, hist, binbase, nz,
-                               (const int*)v3, (const int*)segbase);
+        return wx_wait_word(ctx, pin, left);
+    };
+
+    int left = 0;
+    int* act_cur = actB;
+    int* act_nxt = actA;
+    const int* cur_n_p = nactv + 1;         // the device word that holds the length of act_cur
+    int NBX_last = 0;
+    ABC_TRY(level(0, 0, WX_NC0, actA, nactv, (int)nseg_max, actB, nactv + 1, c0, WX_NC0, 1, &left));
+    // fine levels over what is left: at most two, the second only when few tests remain and finer bins are to be had
+    for (int f = 0; f < 2 && left > 0; f++) {
+        const int NBX = wx_pick_bins(left, nvt);
+        if (f == 1 && (NBX <= NBX_last || left > 32)) break;
+        cl_fine_ld = (size_t)NBX;
+        cl_fine = (unsigned int*)abc_ws_alloc(ctx, (size_t)left * NBX * 4);
+        if (!cl_fine) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%d tests x %d bins)", left, NBX);
+        const int nact_host = left;
+        ABC_TRY(level(1 + f, 1, NBX, act_cur, nactv + 1 + f, nact_host, act_nxt, nactv + 2 + f, cl_fine, cl_fine_ld, 0, &left));
+        int* tmp = act_cur; act_cur = act_nxt; act_nxt = tmp;
+        cur_n_p = nactv + 2 + f;
+        NBX_last = NBX;
     }
-#undef WX_BINS
+
+    // ---- the exact step -------------------------------------------------------------------------------------------------------
+    bool exact = left > 0;
     if (exact) {
-        hipLaunchKernelGGL(k_wx_ranks, dim3((unsigned)NB, (unsigned)nseg_max), dim3(256), 0, st, g, (const WxPlan*)plan,
-                           (const unsigned long long*)keys, (const unsigned int*)hist, (const unsigned int*)binbase, W, big, (const int*)v3,
-                           (const int*)segbase);
+        const int nx = left, XB = wx_xb(nvt) < nx ? wx_xb(nvt) : nx, NBX = NBX_last;
+        const unsigned int target = wx_target(nvt);
+        const int nbcap = (int)(nvt / target) + 2;
+        size_t vmax = nt;
+        if (sharded) vmax = (size_t)pin[1] | ((size_t)pin[2] << 31);
+        if (vmax < nt) ABC_FAIL(ctx, ABC_ERR_COMM, "wilcoxon: %zu validation rows on this rank, %zu at most on any", nt, vmax);
+        unsigned long long* keys_loc = (unsigned long long*)abc_ws_alloc(ctx, (size_t)XB * (vmax ? vmax : 1) * 8);
+        unsigned long long* keysx = (unsigned long long*)abc_ws_alloc(ctx, (size_t)XB * nvt * 8);
+        unsigned int* tabx = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * WX_NC0 * 4);
+        unsigned short* binmap = (unsigned short*)abc_ws_alloc(ctx, (size_t)XB * NBX * 2);
+        unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
+        unsigned int* binbase = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
+        unsigned int* cursor = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
+        unsigned int* big = (unsigned int*)abc_ws_alloc(ctx, (1 + 2 * (size_t)XB * nbcap) * 4);
+        const int* nxd = cur_n_p;
+        if (!keys_loc || !keysx || !tabx || !binmap || !hist || !binbase || !cursor || !big)
+            ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (the exact step: %d tests x %zu rows)", XB, nvt);
+        unsigned long long* keys_all = keys_loc;
+        if (sharded) {
+            ABC_TRY(abc_xbuf_reserve(ctx, (size_t)Wr * XB * vmax * 8 + 4096));
+            keys_all = (unsigned long long*)ctx->xbuf;
+        }
+        const int rkeys = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
+        const size_t plds = (size_t)2 * nbcap * 4;
+        const size_t llds = (size_t)WX_NC0 * 4 + (size_t)2 * nbcap * 4 + (size_t)NBX * 2 + 16;
+        if (plds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_xplan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+        if (llds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
         ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_ranks_big, hipFuncAttributeMaxDynamicSharedMemorySize, WX_CAP * 8));
-        hipLaunchKernelGGL(k_wx_ranks_big, dim3(256), dim3(1024), (size_t)WX_CAP * 8, st, g, (const unsigned long long*)keys, (const unsigned int*)hist,
-                           (const unsigned int*)binbase, W, (const unsigned int*)big, fail);
+        for (int x_lo = 0; x_lo < nx; x_lo += XB) {
+            const int xb = nx - x_lo < XB ? nx - x_lo : XB;
+            hipLaunchKernelGGL(k_wx_xplan, dim3((unsigned)xb), dim3(1024), plds, st, NBX, nbcap, target, (const int*)act_cur, nxd, x_lo,
+                               (const int*)slotmap, (const unsigned int*)cl_fine, (const unsigned int*)c0, tabx, binmap, hist, binbase, cursor);
+            if (vmax) {
+                WxLevel g;
+                g.R = rkeys; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
+                g.G = xb; g.TG = 1; g.RR = g.tiles; g.tpw = 1; g.nslots = xb;
+                const size_t lds = (size_t)xb * 6 * 4 + 64;
+                wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,
+                         keys_loc, vmax);
+                // (a batch shorter than XB leaves the tail of the block as it is: the placing kernel does not look at it)
+            }
+            if (sharded) ABC_TRY(abc_comm_all_gather(ctx, keys_loc, keys_all, (size_t)XB * vmax * 8));
+            ABC_HIP(ctx, hipMemsetAsync(big, 0, 4, st));
+            if (vmax)
+                hipLaunchKernelGGL(k_wx_place, dim3((unsigned)((vmax + 1024 * WX_PK - 1) / (1024 * WX_PK)), (unsigned)xb, (unsigned)Wr), dim3(1024), llds, st, NBX,
+                                   nbcap, (const unsigned long long*)keys_all, vmax, XB, nxd, x_lo, (const int*)act_cur,
+                                   (const unsigned int*)kbase, (const unsigned int*)tabx, (const unsigned short*)binmap, (const unsigned int*)binbase, cursor,
+                                   keysx, nvt);
+            hipLaunchKernelGGL(k_wx_ranks, dim3((unsigned)nbcap, (unsigned)xb), dim3(256), 0, st, nbcap, (const int*)act_cur, nxd, x_lo,
+                               (const unsigned long long*)keysx, nvt, (const unsigned int*)hist, (const unsigned int*)binbase, W, big);
+            hipLaunchKernelGGL(k_wx_ranks_big, dim3(256), dim3(1024), (size_t)WX_CAP * 8, st, nbcap, (const int*)act_cur, x_lo,
+                               (const unsigned long long*)keysx, nvt, (const unsigned int*)hist, (const unsigned int*)binbase, W, (const unsigned int*)big, fail);
+            ABC_HIP(ctx, hipGetLastError());
+        }
     }
-    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, (unsigned char*)hist, (const int*)v3);
+    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3);
     ABC_HIP(ctx, hipGetLastError());
     *fail_host = 0;
     if (exact) {
-        // did every bin of the exact sweeps fit?  (k_wx_decide has otherwise written a count from incomplete sums: the sorted path
+        // did every bin of the exact step fit?  (k_wx_decide has otherwise written a count from incomplete sums: the sorted path
         // overwrites it)
         ABC_HIP(ctx, hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, st));
         ABC_HIP(ctx, hipStreamSynchronize(st));
@@ -1341,57 +1401,35 @@ static int launch_wilcoxon_binned(abc_ctx* ctx, const WxGeo& g, int R, const dou
         ABC_HIP(ctx, hipMemcpy(hv.data(), v3, nseg_max * sizeof(int), hipMemcpyDeviceToHost));
         int cnt[3] = {0, 0, 0};
         for (int i = 0; i < hp.nseg; i++) cnt[hv[i] < 0 || hv[i] > 2 ? 2 : hv[i]]++;
-        fprintf(stderr, "WX_DEBUG: %d tests over %zu rows, %d bins x %d fine: bounds rejected %d, passed %d, undecided %d%s\n", hp.nseg, nt, g.NB,
-                g.F, cnt[0], cnt[1], cnt[2], *fail_host ? " (a bin outgrew LDS: repeat on the sorted path)" : "");
+        fprintf(stderr, "WX_DEBUG: %d tests over %zu rows (%zu here): rejected %d, passed %d, undecided %d by the bounds (exact step for %d tests, last level %d bins)%s\n",
+                hp.nseg, nvt, nt, cnt[0], cnt[1], cnt[2], left, NBX_last, *fail_host ? " (a bin outgrew LDS: repeat on the sorted path)" : "");
     }
-#ifdef WX_STAMPS
-    {
-        std::vector<unsigned long long> h(nstamp);
-        ABC_HIP(ctx, hipMemcpy(h.data(), stamp_dev, nstamp * 8, hipMemcpyDeviceToHost));
-        double ph[6] = {0, 0, 0, 0, 0, 0}, worst = 0;
-        size_t cntb = 0, worst_i = 0;
-        unsigned long long tmin = ~0ull, tmax = 0;
-        for (size_t i = 0; i < nslots; i++) {
-            const unsigned long long* q = &h[i * 16];
-            if (!q[0] || !q[6]) continue;
-            cntb++;
-            for (int p2 = 0; p2 < 6; p2++) ph[p2] += (double)(q[p2 + 1] - q[p2]);
-            if ((double)(q[6] - q[0]) > worst) { worst = (double)(q[6] - q[0]); worst_i = i; }
-            tmin = q[0] < tmin ? q[0] : tmin; tmax = q[6] > tmax ? q[6] : tmax;
-        }
-        fprintf(stderr, "WX_STAMPS kernel %d (1 k_wx_ranks: load, min/max, count, scan+place, walk, ranks; 2 / 3 k_wx_bin counting / placing: prologue, residuals of tile 0, its segments, -, later tiles, write-back): %zu work-groups, mean cycles %.0f %.0f %.0f %.0f %.0f %.0f; "
-                "longest work-group %.0f cycles (n %llu, %llu); first start to last end %.0f cycles\n", (int)WX_STAMPS, cntb, ph[0] / cntb,
-                ph[1] / cntb, ph[2] / cntb, ph[3] / cntb, ph[4] / cntb, ph[5] / cntb, worst, h[worst_i * 16 + 8], h[worst_i * 16 + 9],
-                (double)(tmax - tmin));
-    }
-#endif
     return ABC_OK;
 }
 
 int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
-                    size_t P, size_t A, size_t row_test, double* model) {
-    if (row_test >= n) return ABC_OK;                    // empty validation set: nothing to reduce
+                    size_t P, size_t A, size_t row_test, double* model, const abc_wx_shard* sh) {
+    const size_t nt = n > row_test ? n - row_test : 0;   // validation rows here
+    const size_t nvt = sh ? sh->nv_total : nt;           // ... and over all ranks
+    if (nvt == 0) return ABC_OK;                         // empty validation set: nothing to reduce
     if (A < 2 || P == 0) return ABC_OK;
     if (P * (A - 1) > MAXSEG)
         ABC_FAIL(ctx, ABC_ERR_UNSUPPORTED, "wilcoxon: P (A - 1) = %zu tests, more than %zu", P * (A - 1), MAXSEG);
     StageTimer tm(ctx, ST_PLS_MODEL);
-    const size_t nt = n - row_test;
-    WxGeo g;
-    int R = 0;
-    const bool binned = !wx_force_sorted() && wx_geometry(nt, P, A, &g, &R);
-    if (binned) {
-        // k_wx_decide needs the PRESS optima as the model fit left them: the binned pass rewrites them, so keep a copy for a repeat
+    if (abc_wx_cascade_applies(nvt, P, A)) {
+        // k_wx_decide needs the PRESS optima as the model fit left them: the cascade rewrites them, so keep a copy for a repeat
         const ModelLayout ML = model_layout(M, P, A);
         int failed = 0;
         double* per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!per_keep) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
         ABC_HIP(ctx, hipMemcpyAsync(per_keep, model + ML.off_per, P * 8, hipMemcpyDeviceToDevice, ctx->stream));
         ABC_HIP(ctx, hipMemcpyAsync(per_keep + P, model + ML.off_hdr, 8, hipMemcpyDeviceToDevice, ctx->stream));
-        ABC_TRY(launch_wilcoxon_binned(ctx, g, R, X, Y, ldx, ldy, M, P, A, row_test, model, &failed));
+        ABC_TRY(launch_wilcoxon_cascade(ctx, X, Y, nt, ldx, ldy, M, P, A, row_test, model, sh, &failed));
         static const bool force_fail = abc_diag_env("ABC_WX_FORCE_FAIL") != nullptr;   // tests: exercise the repeat
         if (!failed && !force_fail) return ABC_OK;
         ABC_HIP(ctx, hipMemcpyAsync(model + ML.off_per, per_keep, P * 8, hipMemcpyDeviceToDevice, ctx->stream));
         ABC_HIP(ctx, hipMemcpyAsync(model + ML.off_hdr, per_keep + P, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (sh) return ABC_INTERNAL_RETRY;       // (row shards: the caller gathers the validation rows and calls again without `sh`)
         // the sorted path needs four (key, value) buffers over all tests: an arena of its own for the duration of the repeat
         char* const ws = ctx->ws;
         const size_t ws_bytes = ctx->ws_bytes, ws_off = ctx->ws_off;
@@ -1406,5 +1444,6 @@ int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, si
         (void)hipFree(tmp);
         return rc;
     }
+    if (sh) return ABC_INTERNAL_RETRY;           // small sets: the caller gathers the rows
     return launch_wilcoxon_sorted(ctx, X, Y, n, ldx, ldy, M, P, A, row_test, model);
 }

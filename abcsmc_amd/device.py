@@ -40,7 +40,7 @@ def _ptr(t):
 class Generation:
     """Pre-allocated buffers + one call per generation (AbcSmc.cpp:634-664, 1041-1066, 490-518)."""
 
-    def __init__(self, N, M, P, K, Kp, Nnext, train_frac=0.5, max_comp=0, rule=_lib.RULE_MIN_PRESS,
+    def __init__(self, N, M, P, K, Kp, Nnext, train_frac=0.5, max_comp=0, rule=_lib.RULE_DEFAULT,
                  multivariate=True, device="cuda:0", ctx=None):
         self.device = torch.device(device)
         idx = self.device.index or 0

@@ -136,7 +136,11 @@ class HipBackend:
 
 
 class ShardedGeneration:
-    """One generation turn-over over `world` ranks; every rank holds n_local rows of the set."""
+    """One generation turn-over over `world` ranks; every rank holds n_local rows of the set.
+
+    The stage-level driver (torch.distributed collectives between C ABI stage calls): argmin-PRESS component rule only.  The
+    Wilcoxon rule -- the drop-in default -- needs its bounds cascade's counts exchanged between kernels of ONE stage; that lives
+    in the C++ driver (CabiShardedGeneration -> abc_generation_sharded_dev), which is also the fast one."""
 
     def __init__(self, backend, n_local, M, P, K, Kp, nnext_local, train_frac=0.5, max_comp=0,
                  rule=_lib.RULE_MIN_PRESS, multivariate=True, group=None):
@@ -149,6 +153,8 @@ class ShardedGeneration:
         self.nnext_local = nnext_local
         self.Nnext = nnext_local * self.world
         self.A = max_comp if max_comp > 0 else min(M, P)
+        if rule != _lib.RULE_MIN_PRESS:
+            raise ValueError("ShardedGeneration (stage-level driver) applies argmin PRESS only; use CabiShardedGeneration for the Wilcoxon rule")
         self.train_frac, self.rule, self.multivariate = train_frac, rule, multivariate
         be = backend
         self.k_local = min(K, n_local)
@@ -337,7 +343,7 @@ class CabiShardedGeneration:
     The context's communicator decides the world (Context.comm_info); without one it is a single-GPU generation."""
 
     def __init__(self, ctx, device, n_local, M, P, K, Kp, nnext_local, train_frac=0.5, max_comp=0,
-                 rule=_lib.RULE_MIN_PRESS, multivariate=True, row0=None, N_total=None, next0=None, Nnext_total=None):
+                 rule=_lib.RULE_DEFAULT, multivariate=True, row0=None, N_total=None, next0=None, Nnext_total=None):
         self.ctx, self.device = ctx, torch.device(device)
         _, world, rank = ctx.comm_info()
         self.world, self.rank = world, rank

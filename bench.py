@@ -99,9 +99,10 @@ def parse_args(argv=None):
                     help="--gpus N > 1 inside THIS process: abc_ctx_create_multi (ncclCommInitAll) and one host thread per GPU, each "
                          "driving abc_generation_sharded_dev on its device-resident shard; the fallback of a bare `--gpus N` when "
                          "torch.distributed.run is not available")
-    ap.add_argument("--rule", choices=["press", "wilcoxon"], default="press",
-                    help="PLS component rule of the timed generation (AbcUtil.cpp:447-449): press = argmin PRESS (default), "
-                         "wilcoxon = its Wilcoxon signed-rank reduction (SURVEY A.2); the other rule is timed in `extra`")
+    ap.add_argument("--rule", choices=["press", "wilcoxon"], default="wilcoxon",
+                    help="PLS component rule of the timed generation (AbcUtil.cpp:447-449): wilcoxon = argmin PRESS reduced by the "
+                         "Wilcoxon signed-rank test (SURVEY A.2; the default of the drop-in: C++ facade, shell, Python mirrors), "
+                         "press = plain argmin PRESS; the other rule is timed in `extra`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the timed region (sustained run, fp64 "
                     "kernel, INDEPENDENT noise, Wilcoxon rule, simple ranking, host-pointer call, log-normal alias build, scaling model)")
@@ -515,7 +516,7 @@ def run_rank(args, env):
     scaling_model = None
     if world == 1:
         rng0 = abcutil.rng(67890)
-        gen0 = device.Generation(N, M, P, K, 0, nn_loc, 0.5, A, multivariate=True, device=dev, ctx=ctx)
+        gen0 = device.Generation(N, M, P, K, 0, nn_loc, 0.5, A, rule=RULE, multivariate=True, device=dev, ctx=ctx)
         for _ in range(2):
             gen0.run(dX, dY, dobs, dpri, rng0)
         barrier()
@@ -617,10 +618,11 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t) / reps
 
+    this = _lib.RULE_WILCOXON if args.rule == "wilcoxon" else _lib.RULE_MIN_PRESS       # the rule of the timed region
     # (1) the fp64 vector kernel on the same pairs (--kde-mode fp64): what the split-operand kernel is an alternative to
     if Kp:
         rng = abcutil.rng(67890)
-        gen = device.Generation(N, M, P, K, Kp, N, 0.5, A, multivariate=True, device=dev, ctx=ctx)
+        gen = device.Generation(N, M, P, K, Kp, N, 0.5, A, rule=this, multivariate=True, device=dev, ctx=ctx)
         ctx.set_kde_mode(_lib.KDE_FP64)
         reps = 3 if K * Kp <= 2e10 else 1
         gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
@@ -638,7 +640,7 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
         out["kde_fp64_ms"] = round(st["k_kde"][0] / max(st["k_kde"][2], 1) - event_overhead_ms, 5)
         out["kde_fp64_step_ms"] = round(step_ms, 5)
         # (2) noise = INDEPENDENT, the reference's default (AbcSmc.cpp:419, AbcSmc.h:159)
-        geni = device.Generation(N, M, P, K, Kp, N, 0.5, A, multivariate=False, device=dev, ctx=ctx)
+        geni = device.Generation(N, M, P, K, Kp, N, 0.5, A, rule=this, multivariate=False, device=dev, ctx=ctx)
         out["independent_noise_step_ms"] = round(timed(lambda: geni.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)), 5)
     # (2b) the OTHER component rule (AbcUtil.cpp:447-449; SURVEY A.2: argmin PRESS reduced by a Wilcoxon signed-rank test): the whole
     # generation and the PLS ranking alone under it -- `wilcoxon_*` when the timed region ran argmin PRESS, `min_press_*` otherwise
@@ -682,14 +684,13 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
     out["ranking_simple_ms"] = round(timed(simple), 5)
     out["ranking_simple_particles_per_s"] = N / (out["ranking_simple_ms"] * 1e-3)
     # ... and the PLS ranking alone (no weights, no proposals), device resident
-    this = _lib.RULE_WILCOXON if args.rule == "wilcoxon" else _lib.RULE_MIN_PRESS
     genr = device.Generation(N, M, P, K, 0, 0, 0.5, A, rule=this, multivariate=True, device=dev, ctx=ctx)
     rngr = abcutil.rng(1)
     out["ranking_pls_ms"] = round(timed(lambda: genr.run(dX, dY, dobs, dpri, rngr)), 5)
     # (4) the drop-in call as the reference makes it (AbcUtil.h:149-153): host matrices in, host index vector out
     if N * (M + P) * 8 <= 2 << 30:
         X, Y, obs = dX.cpu().numpy().T, dY.cpu().numpy().T, dobs.cpu().numpy()
-        ms = timed(lambda: abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=K, max_comp=A, ctx=ctx), reps=3, warm=1)
+        ms = timed(lambda: abcutil.particle_ranking_PLS(X, Y, obs, 0.5, K=K, max_comp=A, rule=this, ctx=ctx), reps=3, warm=1)
         hbytes = 8.0 * N * (M + P)
         # PCIe time of the same bytes from pinned memory, measured here (the floor of any host-pointer call)
         pin = torch.empty(int(hbytes // 8), dtype=torch.float64).pin_memory()

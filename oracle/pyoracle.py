@@ -16,6 +16,7 @@ _LIB = None
 
 PRIOR_GAUSS, PRIOR_UNIF_INT, PRIOR_UNIF_REAL = 0, 1, 2
 RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
+RULE_DEFAULT = RULE_WILCOXON      # what the drop-in surface defaults to: the checker's default follows it
 
 
 class Prior(C.Structure):
@@ -180,7 +181,7 @@ def project_distance(X, mean, sd, R, a, obs_scores):
     return out
 
 
-def particle_ranking_pls(X, Y, obs, train_frac, max_comp=0, rule=RULE_MIN_PRESS, want="idx"):
+def particle_ranking_pls(X, Y, obs, train_frac, max_comp=0, rule=RULE_DEFAULT, want="idx"):
     """Returns dict(idx, dist, ncomp, R, Q, mean, sd, press)."""
     X, Y, obs = _f(X), _f(Y), _f(obs)
     N, M = X.shape; P = Y.shape[1]
@@ -316,7 +317,7 @@ def sample_mvn_predictive_priors(r, n, w, theta, priors, L, max_tries=0):
 
 
 def generation(X, Y, obs, priors, K, Nnext, r, theta_prev=None, w_prev=None, dv_prev=None,
-               train_frac=0.5, max_comp=0, rule=RULE_MIN_PRESS, multivariate=True,
+               train_frac=0.5, max_comp=0, rule=RULE_DEFAULT, multivariate=True,
                zero_dv_policy=0):
     X, Y, obs = _f(X), _f(Y), _f(obs)
     N, M = X.shape; P = Y.shape[1]

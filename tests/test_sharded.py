@@ -175,7 +175,7 @@ def test_sharded_world1_equals_fused(gpu_ctx):
     args = [device.colmajor(a, dev) for a in (X, Y, wl.observed())]
     pri = device.priors_to_device(_lib.make_priors(wl.prior_spec()), dev)
     prev = [device.colmajor(a, dev) for a in wl.previous_set(Kp)]
-    g1 = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, device=dev, ctx=gpu_ctx)
+    g1 = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=_lib.RULE_MIN_PRESS, device=dev, ctx=gpu_ctx)     # (the stage-level driver's rule)
     r1 = abcutil.rng(5)
     g1.run(*args, pri, r1, *prev)
     g2 = sharded.ShardedGeneration(sharded.HipBackend(dev, gpu_ctx), N, M, P, K, Kp, Nn, 0.5, A)
