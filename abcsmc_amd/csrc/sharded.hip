@@ -245,7 +245,12 @@ __global__ __launch_bounds__(256) void k_ls_unpack(const char* __restrict__ all,
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e == 0) {
         int bad = 0;
-        for (int q = 0; q < W; q++) if (R.hdr(all, q)[1] != 0ull || R.hdr(all, q)[0] != (unsigned long long)R.cap) bad = 1;
+        for (int q = 0; q < W; q++) {
+            // a full list, or -- a shard with fewer rows than the list is long -- ALL of the rank's rows (exhaustive: k_ls_check)
+            const unsigned long long cnt = R.hdr(all, q)[0], nloc = R.hdr(all, q)[2];
+            const bool whole = cnt == (unsigned long long)R.cap || (nloc <= (unsigned long long)R.cap && cnt == nloc);
+            if (R.hdr(all, q)[1] != 0ull || !whole) bad = 1;
+        }
         *fail = bad;
         if (fail_pin) *fail_pin = bad;
     }
@@ -264,7 +269,7 @@ __global__ void k_ls_check(const char* __restrict__ all, CandRec R, int W, const
     int bad = 0;
     for (int q = threadIdx.x; q < W; q += blockDim.x) {
         const bool exhaustive = R.hdr(all, q)[2] <= (unsigned long long)R.cap;
-        if (!exhaustive && !(R.dist(all, q)[R.cap - 1] > kth)) bad = 1;
+        if (!exhaustive && !(R.dist(all, q)[R.cap - 1] > kth)) bad = 1;       // (an exhaustive list: padded with +inf behind its rows)
     }
     if (__any(bad) && threadIdx.x == 0) { *fail = 1; if (fail_pin) *fail_pin = 1; }
 }
@@ -619,12 +624,19 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         if (!ds_fail) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         // this rank's ls_cap smallest, ascending (distance, global row), straight into its record; a bin selection that gives up
         // leaves a placeholder and says so in the record's header
-        ABC_TRY(launch_select_smallest(ctx, dist, n, ls_cap, row0, (uint64_t*)R.idx(rec_mine, 0), (double*)R.dist(rec_mine, 0), true));
-        const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
+        // (uneven shards: a rank with fewer rows than the list is long lists ALL of them, sorted, +inf behind -- its list is then
+        // exhaustive and the rule of k_ls_check holds for it whatever the K-th is; ADVICE round 4: such a rank used to fail the
+        // selection's K <= n check and took the communicator down with it)
+        const size_t ls_n = ls_cap < n ? ls_cap : n;
+        if (ls_n) ABC_TRY(launch_select_smallest(ctx, dist, n, ls_n, row0, (uint64_t*)R.idx(rec_mine, 0), (double*)R.dist(rec_mine, 0), true));
+        const bool bins_deferred = ls_n && ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
         ctx->sel_bins_ran = false;
-        hipLaunchKernelGGL(k_ls_header, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long*)R.hdr(rec_mine, 0), (unsigned long long)ls_cap,
+        if (ls_n < ls_cap)
+            hipLaunchKernelGGL(k_pad_tail, dim3((unsigned)((ls_cap - ls_n + 255) / 256)), dim3(256), 0, ctx->stream, (double*)R.dist(rec_mine, 0),
+                               (unsigned long long*)R.idx(rec_mine, 0), ls_n, ls_cap);
+        hipLaunchKernelGGL(k_ls_header, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long*)R.hdr(rec_mine, 0), (unsigned long long)ls_n,
                            (unsigned long long)n, bins_deferred ? (const int*)ctx->sel_fail_dev : (const int*)nullptr);
-        ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, (const uint64_t*)R.idx(rec_mine, 0), ls_cap, row0, (double*)R.rows(rec_mine, 0), ls_cap));
+        if (ls_n) ABC_TRY(launch_gather_rows(ctx, io->Y, n, n, P, (const uint64_t*)R.idx(rec_mine, 0), ls_n, row0, (double*)R.rows(rec_mine, 0), ls_cap));
         ABC_TRY(comm_all_gather(ctx, rec_mine, rec_all, R.rec_bytes));
         pfail_early = (int*)(ctx->status_pin + 40);
         *pfail_early = 0;

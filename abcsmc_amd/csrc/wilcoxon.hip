@@ -69,20 +69,49 @@ __global__ __launch_bounds__(256) void k_wx_plan(const double* __restrict__ mode
                                                  unsigned long long* __restrict__ nz, double* __restrict__ W, int* __restrict__ segbase,
                                                  int* __restrict__ fail, int* __restrict__ v3, unsigned int* __restrict__ kbase,
                                                  int* __restrict__ act, int* __restrict__ nact, unsigned int* __restrict__ tickets,
-                                                 double nv_total) {
+                                                 double nv_total, double* __restrict__ per_keep = nullptr) {
     __shared__ int s_ns;
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    if (per_keep) {           // the PRESS optima and the header as the fit left them (k_wx_decide rewrites them; a repeat starts from these)
+        const ModelLayout MLk = model_layout(M, P, A);
+        for (int j = threadIdx.x; j < P; j += blockDim.x) per_keep[j] = model[MLk.off_per + j];
+        if (threadIdx.x == 0) per_keep[P] = model[MLk.off_hdr];
+    }
     for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; if (v3) v3[s] = 2; if (act) act[s] = s; }
     const ModelLayout ML = model_layout(M, P, A);
     if (threadIdx.x == 0) {
         if (fail) { fail[0] = 0; fail[1] = 0; }
         if (tickets) { tickets[0] = 0; tickets[1] = 0; tickets[2] = 0; tickets[3] = 0; }
-        int ns = 0;
-        for (int j = 0; j < P; j++) {
-            const int as = (int)model[ML.off_per + j];
+        s_base = 0;
+    }
+    __syncthreads();
+    // a response per thread: its tests are the segments segbase[j] .. segbase[j] + a*_j - 2 (a scan of the counts over the work-group;
+    // one thread writing all of them in turn was 14 of this kernel's 22 us at 486 tests)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    for (int j0 = 0; j0 < P; j0 += (int)blockDim.x) {
+        const int j = j0 + (int)threadIdx.x;
+        const int as = j < P ? (int)model[ML.off_per + j] : 1;
+        const int cnt = as > 1 ? as - 1 : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int base = s_base + inc - cnt;
+        for (int w = 0; w < wave; w++) base += s_w[w];
+        if (j < P) {
             astar[j] = as;
-            if (segbase) segbase[j] = ns;            // the tests of response j are segments segbase[j] .. segbase[j] + as - 2
-            for (int a = 1; a < as && ns < nseg_max; a++) { seg_j[ns] = j; seg_a[ns] = a; ns++; }
+            if (segbase) segbase[j] = base < nseg_max ? base : nseg_max;
+            for (int a = 1; a < as; a++)
+                if (base + a - 1 < nseg_max) { seg_j[base + a - 1] = j; seg_a[base + a - 1] = a; }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) { int tot = s_base; for (int w = 0; w < nw; w++) tot += s_w[w]; s_base = tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int ns = s_base < nseg_max ? s_base : nseg_max;
         plan->nseg = ns;
         plan->pad_ = 0;
         plan->seg_j = seg_j;
@@ -298,35 +327,48 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
     const int lo = act_lo + tg * G;
     if (lo >= end) return;
     const int ng = (end - lo < G) ? end - lo : G, t = threadIdx.x;
-    unsigned int* cnt = wx_lds;                                           // [G][NBX]  (MODE 0 / 1)
-    unsigned int* tab_s = cnt + (MODE == 2 ? 0 : (size_t)G * NBX);        // [G][WX_NC0]  (MODE 1)
+    unsigned int* cnt = wx_lds;                                           // [G][NBX] + spare counters (NBX / 64)  (MODE 0 / 1)
+    unsigned int* tab_s = cnt + (MODE == 2 ? 0 : (size_t)G * NBX + (MODE == 0 ? NBX : 64));  // [G][WX_NC0]  (MODE 1)
     int* kb_s = (int*)(tab_s + (MODE == 1 ? (size_t)G * WX_NC0 : 0));     // [G] anchors
     int* sj = kb_s + G;                                                   // [G] response, [G] candidate of the group's tests
     int* sa = sj + G;
-    int* ej = sa + G;                                                     // entries: one per response present in the group
-    int* em = ej + G;                                                     //   mask of its candidates a' (bit a' - 1)
-    int* es = em + G;                                                     //   slot of its first test
+    // entries: one per response present in the group -- its index, the mask of its candidates a' (bit a' - 1), the slot of its first
+    // test, its optimum a*, and (two words each) the mean and the deviation of the response
+    int* ej = sa + G;
+    int* em = ej + G;
+    int* es = em + G;
+    int* eas = es + G;
+    double* emu = (double*)(((size_t)(eas + G) + 7) & ~(size_t)7);
+    double* esd = emu + G;
     __shared__ int s_nent;
+    __shared__ int s_wcnt[WX_T / 64];
+    const ModelLayout ML = model_layout(M, P, A);
     if (MODE != 2) for (int e = t; e < ng * NBX; e += WX_T) cnt[e] = 0u;
     if (t < ng) { const int s = act[lo + t]; kb_s[t] = (int)kbase[s]; sj[t] = seg_j[s]; sa[t] = seg_a[s]; }
     if (MODE == 1)
         for (int slot = t >> 6; slot < ng; slot += WX_T / 64) wx_wave_table(c0 + (size_t)act[lo + slot] * WX_NC0, NBX, tab_s + (size_t)slot * WX_NC0);
     __syncthreads();
-    if (t == 0) {
-        int ne = 0, e = 0;
-        while (e < ng) {
-            const int j = sj[e];
+    {   // the entries, in parallel: the thread of a response's FIRST test in the group collects the response's mask (<= 31 steps);
+        // its entry index = the starts in front of it (ballots; thread 0 walking the list alone was 7 us of a 60 us work-group)
+        const bool start = t < ng && (t == 0 || sj[t - 1] != sj[t]);
+        const unsigned long long bal = __ballot(start);
+        if ((t & 63) == 0) s_wcnt[t >> 6] = __popcll(bal);
+        __syncthreads();
+        if (start) {
+            int idx = __popcll(bal & ((1ull << (t & 63)) - 1ull));
+            for (int w = 0; w < (t >> 6); w++) idx += s_wcnt[w];
+            const int j = sj[t];
             unsigned int mask = 0;
-            int e2 = e;
-            while (e2 < ng && sj[e2] == j) { mask |= 1u << (sa[e2] - 1); e2++; }
-            ej[ne] = j; em[ne] = (int)mask; es[ne] = e; ne++;
-            e = e2;
+            for (int e2 = t; e2 < ng && sj[e2] == j; e2++) mask |= 1u << (sa[e2] - 1);
+            ej[idx] = j; em[idx] = (int)mask; es[idx] = t; eas[idx] = astar[j];
+            emu[idx] = model[ML.off_mean + M + j];
+            esd[idx] = model[ML.off_sd + M + j];
         }
-        s_nent = ne;
+        if (t == 0) { int ne = 0; for (int w = 0; w < WX_T / 64; w++) ne += s_wcnt[w]; s_nent = ne; }
     }
     __syncthreads();
     const int nent = s_nent;
-    const ModelLayout ML = model_layout(M, P, A);
+    const int lane = t & 63;
     const size_t nrows = MODE == 2 ? kld : nt;                            // (MODE 2 also writes the padding rows nt .. kld - 1)
     for (int tt = 0; tt < tpw; tt++) {
         const size_t row_t = ((size_t)rr * tpw + tt) * TR;
@@ -340,41 +382,41 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
             in[r] = i < nt;
             ic[r] = in[r] ? i : (nt ? nt - 1 : 0);
 #pragma unroll
-            for (int k = 0; k < AM; k++) s[r][k] = nt ? S[ic[r] + nt * (size_t)(k < A ? k : A - 1)] : 0.0;
+            for (int k = 0; k < AM; k++) s[r][k] = in[r] ? S[ic[r] + nt * (size_t)(k < A ? k : A - 1)] : 0.0;     // (rows past the end: zeros)
         }
-        // per (row, response): the loads of the NEXT response (its y, its loadings) are issued before the arithmetic of this one
-        const int lane = t & 63;
-        double ynext[R], qnext;
-        {
-            const int j0 = __builtin_amdgcn_readfirstlane(ej[0]);
+        // Everything a response needs -- its y, its loadings (lane k holds q_jk), its parameters, the anchors of its tests (lane k: the
+        // test a' = k + 1) -- is fetched while the arithmetic of the response BEFORE it runs; a step's operands then come out of the
+        // lanes (v_readlane).  As scalar loads / LDS reads inside the steps every one of them was waited for on the spot.
+        struct Ent { int j, mask, slot0, as; double mu, sd, q, y[R]; unsigned int kbv; };
+        auto fetch = [&](int e) -> Ent {
+            Ent n;
+            n.j = ej[e]; n.mask = em[e]; n.slot0 = es[e]; n.as = eas[e]; n.mu = emu[e]; n.sd = esd[e];
+            const int j = __builtin_amdgcn_readfirstlane(n.j);
 #pragma unroll
-            for (int r = 0; r < R; r++) ynext[r] = nt ? Y[row_test + ic[r] + ldy * (size_t)j0] : 0.0;
-            qnext = model[ML.off_Q + j0 + (size_t)P * (lane < A ? lane : A - 1)];
-        }
-        for (int ent = 0; ent < nent; ent++) {
-            const int j = __builtin_amdgcn_readfirstlane(ej[ent]);
-            const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane(em[ent]);
-            const int slot0 = __builtin_amdgcn_readfirstlane(es[ent]);
-            const int as = astar[j];
-            const double sdy = model[ML.off_sd + M + j], muy = model[ML.off_mean + M + j];
-            // lane k holds q_jk (and, for a test (j, k + 1) of this group, its anchor): a step's operands come out of the lanes
-            // (v_readlane) -- as scalar loads / LDS reads inside the steps every one of them was waited for on the spot
-            const double qv = qnext;
+            for (int r = 0; r < R; r++) n.y[r] = nt ? Y[row_test + ic[r] + ldy * (size_t)j] : 0.0;
+            n.q = model[ML.off_Q + j + (size_t)P * (lane < A ? lane : A - 1)];
+            const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane(n.mask);
             const unsigned int below = mask & ((1u << (lane & 31)) - 1u);
-            const unsigned int kbv = (lane < 32 && ((mask >> lane) & 1u)) ? (unsigned int)kb_s[slot0 + __popc(below)] : 0u;
+            n.kbv = (lane < 32 && ((mask >> lane) & 1u)) ? (unsigned int)kb_s[__builtin_amdgcn_readfirstlane(n.slot0) + __popc(below)] : 0u;
+            return n;
+        };
+        Ent nx = fetch(0);
+        for (int ent = 0; ent < nent; ent++) {
+            const Ent cu = nx;
+            if (ent + 1 < nent) nx = fetch(ent + 1);
+            const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane(cu.mask);
+            const int slot0 = __builtin_amdgcn_readfirstlane(cu.slot0);
+            const int as = __builtin_amdgcn_readfirstlane(cu.as);
+            const double muy = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cu.mu)), __builtin_amdgcn_readfirstlane(__double2loint(cu.mu)));
+            const double sdy = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cu.sd)), __builtin_amdgcn_readfirstlane(__double2loint(cu.sd)));
+            const unsigned int kbv = cu.kbv;
             double zy[R], estar[R], pred[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                zy[r] = (sdy == 0.0) ? 0.0 : (ynext[r] - muy) / sdy;
+                zy[r] = (sdy == 0.0 || !in[r]) ? 0.0 : (cu.y[r] - muy) / sdy;
                 pred[r] = 0.0;
             }
-            if (ent + 1 < nent) {
-                const int j2 = __builtin_amdgcn_readfirstlane(ej[ent + 1]);
-#pragma unroll
-                for (int r = 0; r < R; r++) ynext[r] = nt ? Y[row_test + ic[r] + ldy * (size_t)j2] : 0.0;
-                qnext = model[ML.off_Q + j2 + (size_t)P * (lane < A ? lane : A - 1)];
-            }
-            const int qlo = __double2loint(qv), qhi = __double2hiint(qv);
+            const int qlo = __double2loint(cu.q), qhi = __double2hiint(cu.q);
 #pragma unroll
             for (int k = 0; k < AM; k++)
                 if (k < as) {
@@ -385,31 +427,68 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
 #pragma unroll
             for (int r = 0; r < R; r++) { estar[r] = fabs(zy[r] - pred[r]); pred[r] = 0.0; }
             int slot = slot0;
+            if (MODE == 2) {
 #pragma unroll
-            for (int k = 0; k < AM - 1; k++)
-                if (k + 1 < as) {                                         // (uniform)
-                    const double qk = __hiloint2double(__builtin_amdgcn_readlane(qhi, k), __builtin_amdgcn_readlane(qlo, k));
+                for (int k = 0; k < AM - 1; k++)
+                    if (k + 1 < as) {                                     // (uniform)
+                        const double qk = __hiloint2double(__builtin_amdgcn_readlane(qhi, k), __builtin_amdgcn_readlane(qlo, k));
 #pragma unroll
-                    for (int r = 0; r < R; r++) pred[r] = fma(s[r][k], qk, pred[r]);
-                    if ((mask >> k) & 1u) {                               // (uniform) the test (j, a' = k + 1) is in this group
-                        const unsigned int kb = (unsigned int)__builtin_amdgcn_readlane((int)kbv, k);
+                        for (int r = 0; r < R; r++) pred[r] = fma(s[r][k], qk, pred[r]);
+                        if ((mask >> k) & 1u) {                           // (uniform) the test (j, a' = k + 1) is in this group
 #pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            const double d = estar[r] - fabs(zy[r] - pred[r]);
-                            const unsigned long long k63 = (unsigned long long)__double_as_longlong(fabs(d));
-                            const bool key_ok = in[r] && d != 0.0;
-                            if (MODE == 2) {
+                            for (int r = 0; r < R; r++) {
+                                const double d = estar[r] - fabs(zy[r] - pred[r]);
+                                const unsigned long long k63 = (unsigned long long)__double_as_longlong(fabs(d));
                                 const size_t i = row_t + (size_t)r * WX_T + t;
-                                if (i < kld) keys[(size_t)(lo - act_lo + slot) * kld + i] = key_ok ? (k63 | (d > 0.0 ? WX_SIGN : 0ull)) : WX_NOKEY;
-                            } else if (key_ok) {
-                                const unsigned int k32 = (unsigned int)(k63 >> 31);
-                                const unsigned int bin = MODE == 0 ? wx_cell(k32, kb) : wx_fine(k32, kb, tab_s + (size_t)slot * WX_NC0);
-                                atomicAdd(&cnt[(size_t)slot * NBX + bin], d > 0.0 ? 65537u : 1u);
+                                if (i < kld) keys[(size_t)(lo - act_lo + slot) * kld + i] = (in[r] && d != 0.0) ? (k63 | (d > 0.0 ? WX_SIGN : 0ull)) : WX_NOKEY;
                             }
+                            slot++;
                         }
-                        slot++;
+                    }
+            } else {
+                // Four candidates at a time without a uniform branch between them: a step that is not a test of this group (beyond a*,
+                // not in the list) still runs -- its keys go to a spare set of counters behind the group's.  Rows past the end carry
+                // zeros (d = 0: no key).  A block without any test only extends the prediction chain.  (The atomic stays under
+                // `d != 0`: adding 0 for the keyless lanes instead ran the kernel three times slower, 64 -> 193 us at 1e6 x 32 x 16 x 8
+                // with the same instruction and LDS-conflict counts -- measured, not understood.)
+                const unsigned int vmask = (as >= 2) ? (mask & (0xffffffffu >> (33 - as))) : 0u;        // tests a' = k + 1 < a*
+#pragma unroll
+                for (int k0 = 0; k0 < AM - 1; k0 += 4) {
+                    if (k0 + 1 >= as) continue;                           // (uniform) nothing of this response from here on
+                    if (((vmask >> k0) & 0xfu) != 0u) {                   // (uniform)
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = k0 + kk;
+                            if (k >= AM - 1) continue;                    // (compile time)
+                            const double qk = __hiloint2double(__builtin_amdgcn_readlane(qhi, k), __builtin_amdgcn_readlane(qlo, k));
+                            const bool valid = ((vmask >> k) & 1u) != 0u; // (uniform)
+                            const unsigned int kb = (unsigned int)__builtin_amdgcn_readlane((int)kbv, k);
+                            const int sl = valid ? slot : G;              // (slot G: the spare counters -- NBX of them at level 0, 64 at the
+                            unsigned int* cn = cnt + (size_t)sl * NBX;    //  fine levels, where the bin is cut to six bits; its table: any)
+                            const unsigned int* tb = tab_s + (size_t)(valid ? slot : 0) * WX_NC0;
+                            const unsigned int bmask = (MODE == 0 || valid) ? 0xffffffffu : 63u;
+#pragma unroll
+                            for (int r = 0; r < R; r++) {
+                                pred[r] = fma(s[r][k], qk, pred[r]);
+                                const double d = estar[r] - fabs(zy[r] - pred[r]);
+                                const unsigned int k32 = (unsigned int)((unsigned long long)__double_as_longlong(fabs(d)) >> 31);
+                                const unsigned int bin = MODE == 0 ? wx_cell(k32, kb) : (wx_fine(k32, kb, tb) & bmask);
+                                if (d != 0.0) atomicAdd(&cn[bin], d > 0.0 ? 65537u : 1u);
+                            }
+                            slot += valid ? 1 : 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = k0 + kk;
+                            if (k >= AM - 1) continue;
+                            const double qk = __hiloint2double(__builtin_amdgcn_readlane(qhi, k), __builtin_amdgcn_readlane(qlo, k));
+#pragma unroll
+                            for (int r = 0; r < R; r++) pred[r] = fma(s[r][k], qk, pred[r]);
+                        }
                     }
                 }
+            }
         }
     }
     if (MODE != 2) {
@@ -477,7 +556,7 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
                                                     int act_lo, const unsigned long long* __restrict__ totals, unsigned long long* __restrict__ nz,
                                                     int* __restrict__ v3, unsigned int* __restrict__ cl, size_t cl_ld, int cl_by_test,
                                                     int* __restrict__ slotmap, unsigned int* __restrict__ ticket, unsigned int nblocks_level,
-                                                    const WxPlan* __restrict__ plan, const int* __restrict__ segbase,
+                                                    const int* __restrict__ astar, int P, const int* __restrict__ segbase,
                                                     int* __restrict__ act_next, int* __restrict__ nact_next,
                                                     const double* __restrict__ nv_ranks, size_t nv_stride, int Wr, int* __restrict__ pin_words,
                                                     int force_undecided /* diagnostic: every test with keys stays undecided */) {
@@ -490,12 +569,20 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     { const int na = *nact_p; end = end < na ? end : na; }
     if (act_lo + e < end) {
         const int seg = act[act_lo + e];
-        for (int b = t; b < NBX; b += 1024) {
-            const unsigned long long v = totals[(size_t)e * NBX + b];
-            const unsigned int c = (unsigned int)v, p = (unsigned int)(v >> 32);
-            wxb_cp[2 * b] = c;
-            wxb_cp[2 * b + 1] = p;
-            if (cl) cl[(size_t)(cl_by_test ? seg : act_lo + e) * cl_ld + b] = c;
+        for (int b0 = 0; b0 < NBX; b0 += 8 * 1024) {           // (eight loads in flight: one per turn was 16 memory latencies at 16384 bins)
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int b = b0 + u * 1024 + t; v[u] = b < NBX ? totals[(size_t)e * NBX + b] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int b = b0 + u * 1024 + t;
+                if (b < NBX) {
+                    const unsigned int c = (unsigned int)v[u], p = (unsigned int)(v[u] >> 32);
+                    wxb_cp[2 * b] = c;
+                    wxb_cp[2 * b + 1] = p;
+                    if (cl) cl[(size_t)(cl_by_test ? seg : act_lo + e) * cl_ld + b] = c;
+                }
+            }
         }
         if (t == 0 && slotmap) slotmap[seg] = act_lo + e;
         __syncthreads();
@@ -548,35 +635,50 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    const int nseg = plan->nseg;
-    const int per = (nseg + 1023) / 1024, s0 = t * per;
-    const volatile int* v3v = v3;
-    int mine = 0;
-    for (int i = 0; i < per; i++) {
-        const int s = s0 + i;
-        if (s < nseg && wx_need((const int*)v3v, segbase[plan->seg_j[s]], s)) mine++;
-    }
-    int inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    // a response per thread: its verdicts (<= 31 independent loads), the tests still needed = the undecided ones in front of its
+    // first pass; their places by a scan over the responses (test order = response order).  (A thread per test that walked back to
+    // the response's first test was up to 31 dependent loads in a row: 15-20 us of every level.)
     __shared__ int wsum[16];
-    if (lane == 63) wsum[wave] = inc;
+    __shared__ int s_run;
+    if (t == 0) s_run = 0;
     __syncthreads();
-    int pos = inc - mine, total = 0;
-    for (int w = 0; w < 16; w++) { if (w < wave) pos += wsum[w]; total += wsum[w]; }
-    for (int i = 0; i < per; i++) {
-        const int s = s0 + i;
-        if (s < nseg && wx_need((const int*)v3v, segbase[plan->seg_j[s]], s)) act_next[pos++] = s;
+    const volatile int* v3v = v3;
+    for (int j0 = 0; j0 < P; j0 += 1024) {
+        const int j = j0 + t;
+        unsigned int need = 0;
+        int b0 = 0;
+        if (j < P) {
+            b0 = segbase[j];
+            const int n = astar[j] - 1;
+            unsigned int und = 0, pas = 0;
+#pragma unroll 8
+            for (int i = 0; i < n; i++) { const int v = v3v[b0 + i]; und |= (v == 2 ? 1u : 0u) << i; pas |= (v == 1 ? 1u : 0u) << i; }
+            need = pas ? (und & ((pas & (0u - pas)) - 1u)) : und;
+        }
+        const int mine = __popc(need);
+        int inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int pos = s_run + inc - mine;
+        for (int w = 0; w < wave; w++) pos += wsum[w];
+        while (need) { const int i = __ffs((int)need) - 1; need &= need - 1u; act_next[pos++] = b0 + i; }
+        __syncthreads();
+        if (t == 0) { int tot = s_run; for (int w = 0; w < 16; w++) tot += wsum[w]; s_run = tot; }
+        __syncthreads();
     }
+    const int total = s_run;
     if (t == 0) {
         *nact_next = total;
         long long vmax = 0;
         if (nv_ranks) for (int r = 0; r < Wr; r++) { const long long v = (long long)nv_ranks[(size_t)r * nv_stride]; vmax = v > vmax ? v : vmax; }
-        pin_words[1] = (int)(vmax & 0x7fffffff);
-        pin_words[2] = (int)(vmax >> 31);
-        __threadfence_system();
-        pin_words[0] = total;                              // (the host spins on this word)
-        __threadfence_system();
+        // (pinned, fine-grained host memory: the stores go straight through; a device-scope fence keeps their order.  A system-scope
+        // fence here writes the whole L2 back first -- the sweep's counters, the scores: 10-25 us of every level)
+        __hip_atomic_store(&pin_words[1], (int)(vmax & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pin_words[2], (int)(vmax >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence();
+        __hip_atomic_store(&pin_words[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the host spins on this word)
     }
 }
 
@@ -602,9 +704,10 @@ __global__ __launch_bounds__(1024) void k_wx_xplan(int NBX, int nbcap, unsigned 
     for (int b = t; b < nbcap; b += 1024) { hist_s[b] = 0u; base_s[b] = 0xffffffffu; }
     if (wave == 0) wx_wave_table(c0 + (size_t)seg * WX_NC0, NBX, tabx + (size_t)u * WX_NC0);
     const unsigned int* row = cl + (size_t)slotmap[seg] * NBX;
-    const int per = NBX / 1024, f0 = t * per;              // (NBX: a multiple of 1024)
-    unsigned int loc = 0;
-    for (int i = 0; i < per; i++) loc += row[f0 + i];
+    const int per = NBX / 1024, f0 = t * per;              // (NBX: a multiple of 1024, at most 16 of them)
+    unsigned int cf[WX_NBFMAX / 1024], loc = 0;
+#pragma unroll
+    for (int i = 0; i < WX_NBFMAX / 1024; i++) { cf[i] = i < per ? row[f0 + i] : 0u; loc += cf[i]; }
     unsigned int inc = loc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const unsigned int up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
@@ -612,8 +715,10 @@ __global__ __launch_bounds__(1024) void k_wx_xplan(int NBX, int nbcap, unsigned 
     __syncthreads();
     unsigned int cum = inc - loc;
     for (int w = 0; w < wave; w++) cum += wtot[w];
-    for (int i = 0; i < per; i++) {
-        const unsigned int c = row[f0 + i];
+#pragma unroll
+    for (int i = 0; i < WX_NBFMAX / 1024; i++) {
+        if (i >= per) break;
+        const unsigned int c = cf[i];
         unsigned int b = cum / target;
         b = b < (unsigned int)nbcap - 1u ? b : (unsigned int)nbcap - 1u;
         binmap[(size_t)u * NBX + f0 + i] = (unsigned short)b;
@@ -1106,7 +1211,7 @@ struct WxLevel { int R, tiles, G, TG, RR, tpw, nslots; };   // rows per thread, 
 // 256 / groups runs of tiles; a work-group's rows stay below 2^16 (its counters are 16-bit halves).
 WxLevel wx_level(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, size_t bc_bytes) {
     WxLevel g;
-    g.G = (int)((size_t)WX_LDS / per_test_lds);
+    g.G = (int)(((size_t)WX_LDS - 1024) / per_test_lds);          // (1 KB: the spare counters of the sweep)
     if (g.G < 1) g.G = 1;
     if (g.G > want) g.G = want;
     const int rmax = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
@@ -1239,7 +1344,7 @@ static void wx_scores(abc_ctx* ctx, const double* X, size_t ldx, size_t row_test
 
 // The cascade.  *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
 static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* Y, size_t nt, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
-                                   size_t row_test, double* model, const abc_wx_shard* sh, int* fail_host) {
+                                   size_t row_test, double* model, const abc_wx_shard* sh, int* fail_host, double* per_keep) {
     const int Wr = (sh && ctx->comm_kind) ? ctx->comm_world : 1;
     const bool sharded = Wr > 1;
     const size_t nvt = sh ? sh->nv_total : nt, nseg_max = P * (A - 1);
@@ -1272,7 +1377,7 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
     const size_t nv_stride = sh ? sh->nv_stride : 0;
 
     hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
-                       segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt);
+                       segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt, per_keep);
     if (nt) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
     ABC_HIP(ctx, hipGetLastError());
 
@@ -1283,13 +1388,13 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
     size_t cl_fine_ld = 0;
     auto level = [&](int lvl, int mode, int NBX, const int* act, const int* nact_p, int nact_host, int* act_out, int* nact_out, unsigned int* cl,
                      size_t cl_ld, int cl_by_test, int* left) -> int {
-        const size_t per_test = (size_t)NBX * 4 + (mode == 1 ? WX_NC0 * 4 : 0) + 6 * 4;
+        const size_t per_test = (size_t)NBX * 4 + (mode == 1 ? WX_NC0 * 4 : 0) + 7 * 4 + 16;
         pin[0] = -1;
         const size_t blds = (size_t)NBX * 8;
         if (blds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
         for (int lo = 0; lo < nact_host;) {
             const WxLevel g = wx_level(nt, A, nact_host - lo, NBX, per_test, bc_bytes);
-            const size_t lds = (size_t)g.G * per_test + 64, ne = (size_t)g.nslots * NBX;
+            const size_t lds = (size_t)g.G * per_test + (mode == 0 ? (size_t)NBX * 4 : 256) + 64, ne = (size_t)g.nslots * NBX;
             unsigned long long* totals = (unsigned long long*)abc_ws_alloc(ctx, ne * 8);
             if (!totals) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
             if (nt) {
@@ -1299,7 +1404,7 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
                 ABC_HIP(ctx, hipMemsetAsync(totals, 0, ne * 8, st));
             if (sharded) ABC_TRY(abc_comm_all_reduce(ctx, totals, ne, ABC_DT_I64));
             hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)g.nslots), dim3(1024), blds, st, NBX, g.nslots, act, nact_p, lo, (const unsigned long long*)totals,
-                               nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const WxPlan*)plan, (const int*)segbase,
+                               nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const int*)astar, (int)P, (const int*)segbase,
                                act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0);
             ABC_HIP(ctx, hipGetLastError());
             lo += g.nslots;
@@ -1366,7 +1471,7 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
                 WxLevel g;
                 g.R = rkeys; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
                 g.G = xb; g.TG = 1; g.RR = g.tiles; g.tpw = 1; g.nslots = xb;
-                const size_t lds = (size_t)xb * 6 * 4 + 64;
+                const size_t lds = (size_t)xb * (7 * 4 + 16) + 64;
                 wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,
                          keys_loc, vmax);
                 // (a batch shorter than XB leaves the tail of the block as it is: the placing kernel does not look at it)
@@ -1422,9 +1527,7 @@ int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, si
         int failed = 0;
         double* per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!per_keep) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
-        ABC_HIP(ctx, hipMemcpyAsync(per_keep, model + ML.off_per, P * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        ABC_HIP(ctx, hipMemcpyAsync(per_keep + P, model + ML.off_hdr, 8, hipMemcpyDeviceToDevice, ctx->stream));
-        ABC_TRY(launch_wilcoxon_cascade(ctx, X, Y, nt, ldx, ldy, M, P, A, row_test, model, sh, &failed));
+        ABC_TRY(launch_wilcoxon_cascade(ctx, X, Y, nt, ldx, ldy, M, P, A, row_test, model, sh, &failed, per_keep));     // (its plan kernel makes the copy)
         static const bool force_fail = abc_diag_env("ABC_WX_FORCE_FAIL") != nullptr;   // tests: exercise the repeat
         if (!failed && !force_fail) return ABC_OK;
         ABC_HIP(ctx, hipMemcpyAsync(model + ML.off_per, per_keep, P * 8, hipMemcpyDeviceToDevice, ctx->stream));

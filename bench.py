@@ -57,6 +57,7 @@ MFMA_SUSTAINED_TF = 1247.0    # same guide, 'DVFS give-back' (1): a bare bf16 MF
 FP64_VALU_PEAK_TF = 78.6      # same guide: fp64 vector peak
 ASSUMED_XGMI_COLLECTIVE_MS = 0.02   # scaling_model: a small RCCL collective over xGMI, ASSUMED (not measurable on one GPU)
 ASSUMED_EXCHANGE_KERNELS_MS = 0.03  # scaling_model: the kernels around the exchanges that a one-GPU run does not launch, ASSUMED
+ASSUMED_WILCOXON_REPLICATED_MS = 0.04   # scaling_model: per level of the Wilcoxon cascade, what does not shrink with the rows (totals, bounds, host look), from the kernel statistics of profiles/r05_*
 
 
 def pmc_traffic(kernel_prefix, config, world):
@@ -558,7 +559,8 @@ def run_rank(args, env):
                              "brackets is the clock the chip holds under sustained load relative to the timed region" % args.sustained_s}
         extra = extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, event_overhead_ms)
         scaling_model = scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, RULE,
-                                          ms_per_step, kde_ms * kde_launches, stage_ms, stage_launches, event_overhead_ms, step)
+                                          ms_per_step, kde_ms * kde_launches, stage_ms, stage_launches, event_overhead_ms, step,
+                                          min_press_step_ms=(extra or {}).get("min_press_rule_step_ms"))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -752,7 +754,7 @@ def predict_scaling(ms_per_step, kde_ms, sharded_ms, collectives, collective_ms,
 
 
 def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, rule, ms_per_step, kde_ms, stage_ms,
-                      stage_launches, event_overhead_ms, fused_step=None):
+                      stage_launches, event_overhead_ms, fused_step=None, min_press_step_ms=None):
     """The N = 1 line's PREDICTION of the strong-scaling curve, so that the first real multi-GPU run can be held against a
     stated number: stage times from this run + the latency of the sharded driver's collectives measured on a ONE-rank RCCL
     communicator (abc_comm_init_rank at world 1: every collective of the protocol is a real RCCL call on this GPU)."""
@@ -765,6 +767,17 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
     # collectives of one generation at world > 1 (the all-gathers of the ranks' statistics records, of their sorted
     # lists with their rows, and for weighted sets of the weight slices)
     coll_ms, ncoll, note, step1, measured = None, 3 if Kp else 2, None, None, 0
+    # ... and under the Wilcoxon rule the all-reduces of its bounds cascade (wilcoxon.hip): level 0 always, ONE fine level counted
+    # here (a second one and the all-gather of the undecided tests' keys only when statistics sit next to the threshold).  The rule's
+    # time = this step minus the argmin-PRESS step measured beside it; its sweeps and scores are row-proportional, what is not
+    # (plan, totals, bounds, the host's looks at the level counts) is ASSUMED_WILCOXON_REPLICATED_MS per level
+    wilcoxon_ms, wilcoxon_sharded_ms = None, 0.0
+    if rule == _lib.RULE_WILCOXON:
+        ncoll += 2
+        if min_press_step_ms is not None:
+            wilcoxon_ms = max(ms_per_step - min_press_step_ms, 0.0)
+            wilcoxon_sharded_ms = max(wilcoxon_ms - 2 * ASSUMED_WILCOXON_REPLICATED_MS, 0.0)
+            sharded_ms += wilcoxon_sharded_ms
     ratios = []
     c1 = None
     try:
@@ -829,6 +842,9 @@ def scaling_model_leg(args, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, 
                                           "replicated_ms": round(base - kde_ms - sharded_ms, 5),
                                           "collective_price_ms": round(price, 5),
                                           "collectives_per_step": ncoll,
+                                          "pls_component_rule": "wilcoxon" if rule == _lib.RULE_WILCOXON else "min_press",
+                                          "wilcoxon_rule_ms": None if wilcoxon_ms is None else round(wilcoxon_ms, 5),
+                                          "wilcoxon_row_sharded_ms": round(wilcoxon_sharded_ms, 5),
                                           "rccl_world1_collective_ms": None if coll_ms is None else round(coll_ms, 5),
                                           "rccl_world1_collectives_measured_per_step": measured,
                                           "sharded_driver_world1_step_ms": None if step1 is None else round(step1, 5),

@@ -3,7 +3,8 @@ argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, bo
 Python; "cabi" -> the same two ranks through abc_generation_sharded_dev with the gloo collectives handed in as callbacks;
 "rccl" -> abc_generation_sharded_dev over an in-library RCCL communicator, ONE GPU PER RANK (needs as many GPUs as ranks)),
 out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"], [rule = "press" | "wilcoxon" (cabi only)], [data = "plain" | "ties":
-the metric rows repeat 4 distinct ones, so the distances are massively tied]."""
+the metric rows repeat 4 distinct ones, so the distances are massively tied], [split = "even" | "uneven" (cabi / rccl only): the
+n_local * world rows dealt to the ranks in shares 2^(world-1-rank) -- two thirds / one third on two ranks, 4 : 2 : 1 on three]."""
 import json
 import os
 import sys
@@ -36,7 +37,16 @@ def main():
             X = np.asfortranarray(X4[np.arange(lo, hi) % 4])
         return X, Y
 
-    X, Y = rows(rank * n_loc, (rank + 1) * n_loc)
+    uneven = len(sys.argv) > 6 and sys.argv[6] == "uneven"
+    if uneven:
+        assert backend in ("cabi", "rccl")
+        shares = np.array([2.0 ** (world - 1 - r) for r in range(world)])
+        cuts = np.concatenate([[0], np.floor(N * np.cumsum(shares) / shares.sum() + 0.5).astype(int)])
+        cuts[-1] = N
+        row_lo, row_hi = int(cuts[rank]), int(cuts[rank + 1])
+    else:
+        row_lo, row_hi = rank * n_loc, (rank + 1) * n_loc
+    X, Y = rows(row_lo, row_hi)
     obs, spec = wl.observed(), wl.prior_spec()
     thp, wp, dvp = wl.previous_set(Kp) if Kp else (None, None, None)
     if backend == "numpy":
@@ -65,7 +75,8 @@ def main():
         else:
             sharded.attach_torch_distributed(ctx, dev)
             assert ctx.comm_info() == (_lib.COMM_CALLBACKS, world, rank)
-        gen = sharded.CabiShardedGeneration(ctx, dev, n_loc, M, P, K, Kp, nn_loc, 0.5, A, rule=rule, multivariate=True)
+        gen = sharded.CabiShardedGeneration(ctx, dev, row_hi - row_lo, M, P, K, Kp, nn_loc, 0.5, A, rule=rule, multivariate=True,
+                                            row0=row_lo, N_total=N, next0=rank * nn_loc, Nnext_total=nn_loc * world)
     else:
         gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
     rng = _lib.Rng()

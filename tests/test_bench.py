@@ -114,15 +114,18 @@ def test_single_process_route_on_one_gpu():
 
 @pytest.mark.gpu
 def test_n1_line_carries_both_component_rules_and_a_scaling_prediction():
-    """the default N = 1 run at the small configuration: `extra` times the Wilcoxon rule (whole generation and ranking alone),
-    `scaling_model` predicts 2 / 4 / 8 GPUs from the measured stages and the world-1 RCCL collective latency"""
+    """the default N = 1 run at the small configuration: the timed region runs the drop-in's default rule (Wilcoxon), `extra` times
+    the other one (argmin PRESS: whole generation and ranking alone), `scaling_model` predicts 2 / 4 / 8 GPUs from the measured
+    stages and the world-1 RCCL collective latency, with the rule's all-reduces counted"""
     p = _run(["--config", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained-s", "0.2"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     j = _json_lines(p.stdout)[0]
     ex = j["extra"]
-    assert ex["wilcoxon_rule_step_ms"] > 0 and ex["ranking_pls_wilcoxon_ms"] > 0 and ex["wilcoxon_rule_ncomp"] >= 1
+    assert j["config"]["pls_component_rule"] == "wilcoxon"
+    assert ex["min_press_rule_step_ms"] > 0 and ex["ranking_pls_min_press_ms"] > 0 and ex["min_press_rule_ncomp"] >= 1
     sm = j["scaling_model"]
-    assert set(sm["predicted"]) == {"2", "4", "8"} and sm["from"]["collectives_per_step"] in (2, 3)
+    assert set(sm["predicted"]) == {"2", "4", "8"} and sm["from"]["collectives_per_step"] in (4, 5)      # (3 + the cascade's two all-reduces)
+    assert sm["from"]["pls_component_rule"] == "wilcoxon" and sm["from"]["wilcoxon_rule_ms"] >= 0
     assert sm["from"]["rccl_world1_collective_ms"] is None or sm["from"]["rccl_world1_collective_ms"] >= 0
     # (at this small configuration the replicated chain and the collectives outweigh what sharding saves: the prediction may well be
     # SLOWER than one GPU -- it has to be self-consistent, not flattering)

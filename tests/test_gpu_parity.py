@@ -1200,7 +1200,7 @@ def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate, P):
 # ---------------------------------------------------------------------------------------------------
 # whole generation, device resident (AbcSmc.cpp:634-664, 1041-1066, 490-518)
 # ---------------------------------------------------------------------------------------------------
-def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=0):
+def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=1):      # (rule 1: the drop-in's default, _lib.RULE_DEFAULT = the Wilcoxon reduction)
     import torch
     from abcsmc_amd import abcutil, device, _lib
     wl, X, Y, obs = _wl(M, P, N)
@@ -1216,7 +1216,7 @@ def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=0):
     return wl, X, Y, obs, spec, prev, gen, r
 
 
-def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=0):
+def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=1):
     """_run_generation with the synthetic set generated ON the GPU (synthetic.Workload.rows_device: numpy takes minutes at
     1e7 rows) and downloaded for the oracle: both sides see the same bits"""
     import torch
@@ -1784,6 +1784,66 @@ def test_generation_config5_size_wilcoxon_rule(gpu_ctx, oracle):
     from abcsmc_amd import _lib
     _generation_size_properties(gpu_ctx, oracle, 1_000_000, 128, 16, 100_000, 100_000, 1_000_000, 32, KDE_TOL["auto"],
                                 device_inputs=True, rule=_lib.RULE_WILCOXON)
+
+
+def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
+    """BASELINE configs[3] at its STATED size under the drop-in's default rule: 1e7 particles x 64 metrics x 32 responses x 8
+    components = up to 224 tests over 5e6 validation rows, through the staged entry points on device-generated rows (the model under
+    argmin PRESS, then abc_pls_wilcoxon_dev).  The component count of EVERY response is compared with the oracle's reduction run on the
+    device's own model -- for 6 of the 32 responses: the oracle sorts 5e6 differences per (response, candidate) test, about a
+    second each, and the 224 tests of all responses would take four minutes; the responses are independent of each other in the
+    reduction (optimal_num_components works response by response), the six are spread over the columns."""
+    import torch
+    from abcsmc_amd import _lib, device, sharded, synthetic
+    lib = _lib.lib()
+    N, M, P, A = 10_000_000, 64, 32, 8
+    dev = "cuda:0"
+    wl = synthetic.Workload(M, P, 12345)
+    dX, dY = wl.rows_device(0, N, dev)
+    dobs = device.colmajor(wl.observed(), dev)
+    be = sharded.HipBackend(dev, gpu_ctx)
+    ntrain = N // 2
+    stats = be.zeros(be.stats_len(M, P))
+    L = be.model_len(M, P, A)
+    model = be.zeros(L + 8)
+    be.stats_shift(dX, dY, stats)
+    be.stats_accumulate(dX, dY, 0, ntrain, stats)
+    be.pls_model(stats, dobs, M, P, A, _lib.RULE_MIN_PRESS, model)
+    torch.cuda.synchronize()
+    m0 = model.cpu().numpy().copy()
+    gpu_ctx.check(lib.abc_pls_wilcoxon_dev(gpu_ctx.handle, dX.data_ptr(), dY.data_ptr(), N, N, N, M, P, A, ntrain, model.data_ptr()))
+    torch.cuda.synchronize()
+    m1 = model.cpu().numpy()
+    off_mean, off_sd = 4, 4 + M + P
+    off_R = off_sd + (M + P) + M + A
+    off_Q = off_R + M * A
+    off_per = L - P
+    per_press, per_wx = m0[off_per:L].astype(int), m1[off_per:L].astype(int)
+    mean, sd = m0[off_mean:off_mean + M + P], m0[off_sd:off_sd + M + P]
+    R = np.asfortranarray(m0[off_R:off_R + M * A].reshape(A, M).T)
+    Q = np.asfortranarray(m0[off_Q:off_Q + P * A].reshape(A, P).T)
+    assert int(m1[0]) == per_wx.max() and np.all(per_wx <= per_press) and np.all(per_wx >= 1)
+    cols = [0, 5, 11, 18, 26, 31]
+    Xv = dX[:, ntrain:].cpu().numpy().T                              # (N - ntrain, M) view of the download
+    Zx = np.asfortranarray((Xv - mean[:M]) / sd[:M])
+    del Xv
+    Yv = dY[cols][:, ntrain:].cpu().numpy().T
+    Zy = np.asfortranarray((Yv - mean[M:][cols]) / sd[M:][cols])
+    Qc = np.asfortranarray(Q[cols])
+    _, o_press = oracle.pls_optimal_components(Zx, Zy, R, Qc, oracle.RULE_MIN_PRESS)
+    _, o_wx = oracle.pls_optimal_components(Zx, Zy, R, Qc, oracle.RULE_WILCOXON)
+    assert np.array_equal(per_press[cols], o_press.astype(int)), (per_press[cols], o_press)
+    assert np.array_equal(per_wx[cols], o_wx.astype(int)), (per_wx[cols], o_wx, per_press[cols])
+    print("wilcoxon at configs[3] size: PRESS optima %s -> %s (responses %s against the oracle)" % (per_press.tolist(), per_wx.tolist(), cols))
+
+
+def test_generation_config4_full_size_wilcoxon_rule_properties(gpu_ctx, oracle):
+    """... and the whole generation at that size under the rule: the size-independent properties (selection = the oracle's ordering
+    of the device's own distances bit for bit, stratified weights against the oracle's formula, parents = the oracle's resampling of
+    the device's weights, support, factor) without the oracle's own model fit (test above: the reduction per response)"""
+    from abcsmc_amd import _lib
+    _generation_size_properties(gpu_ctx, oracle, 10_000_000, 64, 32, 1_000_000, 1_000_000, 10_000_000, 8, KDE_TOL["auto"],
+                                device_inputs=True, oracle_model=False, rule=_lib.RULE_WILCOXON)
 
 
 def test_generation_config3_size_properties(gpu_ctx, oracle):

@@ -18,16 +18,22 @@ SHAPES = {"small": "1500,12,5,4,500,300,1000", "wx": "2100,10,3,6,400,300,900", 
           # ... and for the resampling table to be built on the device (from 20000 entries) on every rank
           "huge": "120000,32,16,8,24000,1000,20000",
           # 40 parameters: each rank's row slice of the pair sums on the four-chunk split-operand kernel (33..64 parameters)
-          "p40": "1600,48,40,6,450,380,1100"}
+          "p40": "1600,48,40,6,450,380,1100",
+          # large enough for the Wilcoxon rule's bounds cascade over the shards (>= 16384 validation rows in all): 2 x 4e4 rows at
+          # configs[2]'s column shape, and the configs[3] / configs[4] column shapes (up to 224 / 496 tests)
+          "wxbig": "40000,32,16,8,2000,500,3000", "wxc4": "30000,64,32,8,1500,400,2000", "wxc5": "30000,128,16,32,1500,400,2000",
+          # three ranks, uneven shards (4 : 2 : 1): 15000 rows, the smallest shard shorter than the local-top list
+          "w3": "5000,64,32,8,6000,400,2000", "w3wx": "14000,64,32,8,3000,400,2000"}
 
 
-def _launch(backend, tmp_path, port, shape="small", rule="press", data="plain"):
-    out = str(tmp_path / ("sharded_%s_%s_%s_%s.json" % (backend, shape, rule, data)))
+def _launch(backend, tmp_path, port, shape="small", rule="press", data="plain", world=2, split="even", env_extra=None):
+    out = str(tmp_path / ("sharded_%s_%s_%s_%s_%d_%s.json" % (backend, shape, rule, data, world, split)))
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape], rule, data]
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[shape], rule, data, split]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     return json.load(open(out))
@@ -99,6 +105,46 @@ def test_sharded_world2_cabi_driver_wilcoxon_rule(tmp_path, shape, port):
     """the Wilcoxon component rule (AbcUtil.cpp:447-449) on two ranks: the validation rows of both shards are gathered and
     ranked together on every rank; component count, selection and everything downstream equal the single-process oracle's"""
     _check(_launch("cabi", tmp_path, port, shape, "wilcoxon"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,world,split,port", [("wxbig", 2, "even", 29651), ("wxc4", 2, "even", 29652), ("wxc5", 2, "even", 29653),
+                                                    ("wxbig", 2, "uneven", 29654), ("w3wx", 3, "uneven", 29655)])
+def test_sharded_cabi_driver_wilcoxon_cascade_over_the_shards(tmp_path, shape, world, split, port):
+    """the Wilcoxon rule on sets large enough for its bounds cascade (wilcoxon.hip, round 5): every rank sweeps ITS validation rows,
+    the counts of a level are all-reduced, verdicts are replicated, only the keys of the tests the bounds leave undecided are
+    all-gathered -- component count, selection and everything downstream equal the single-process oracle's; no rank gathers rows
+    (the exchange: the statistics records, the cascade's all-reduces and at most one key gather per batch of undecided tests, the
+    sorted lists, the weight slices); even and uneven shards, two and three ranks"""
+    res = _launch("cabi", tmp_path, port, shape, "wilcoxon", "plain", world, split)
+    _check(res)
+    calls = res["comm_calls"]
+    # all-reduces: the cascade's levels only (1..3); all-gathers: statistics, lists + rows, weight slices (+ the undecided tests' keys,
+    # in batches of eight) -- the row gather of rounds 1-4 took two more all-gathers and a count exchange
+    if split == "even":       # (shares of 2 : 1 and beyond: the largest shard holds more winners than its local-top list is long, the
+        #                       generation repeats with the radix protocol and its six all-reduces -- same results, checked above)
+        assert 1 <= calls["all_reduce"] <= 3, calls
+        assert 3 <= calls["all_gather"] <= 3 + 4, calls
+
+
+@pytest.mark.gpu
+def test_sharded_wilcoxon_cascade_equals_the_row_gather(tmp_path):
+    """... and the same generation with the validation rows gathered on every rank instead (ABC_WX_GATHER: the path of rounds 1-4,
+    still the fallback for small sets): the same outputs against the oracle, more collectives"""
+    res = _launch("cabi", tmp_path, 29656, "wxbig", "wilcoxon", "plain", 2, "even", {"ABC_DIAG": "1", "ABC_WX_GATHER": "1"})
+    _check(res)
+    assert res["comm_calls"]["all_reduce"] == 0 and res["comm_calls"]["all_gather"] >= 5, res["comm_calls"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,rule,port", [("w3", "press", 29657), ("big", "press", 29658)])
+def test_sharded_cabi_driver_uneven_shards(tmp_path, shape, rule, port):
+    """uneven shards: three ranks holding 4 : 2 : 1 of the rows at configs[3]'s column shape -- the smallest shard is
+    shorter than the local-top list, lists ALL its rows and is exhaustive; the largest holds more winners than its list is long,
+    the rule says so on every rank alike and the generation repeats with the radix protocol -- and two ranks at 2 : 1 where the
+    lists suffice; results = the single-process oracle's either way"""
+    world = 3 if shape == "w3" else 2
+    _check(_launch("cabi", tmp_path, port, shape, rule, "plain", world, "uneven"))
 
 
 @pytest.mark.gpu
