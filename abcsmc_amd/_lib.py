@@ -13,6 +13,7 @@ RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
 # best knowledge of upstream's optimal_num_components -- argmin PRESS reduced by the Wilcoxon signed-rank test
 RULE_DEFAULT = RULE_WILCOXON
 KDE_AUTO, KDE_FP64 = 0, 1
+GRAM_AUTO, GRAM_FP64 = 0, 1
 KDE_RAN_NONE, KDE_RAN_FP64, KDE_RAN_SPLIT = 0, 1, 2
 DT_F64, DT_I32, DT_I64 = 0, 1, 2
 COMM_ID_BYTES = 128
@@ -94,6 +95,7 @@ SIGNATURES = {
     "abc_ctx_set_stream": (_i, [_vp, _vp]),
     "abc_ctx_use_own_stream": (_i, [_vp]),
     "abc_ctx_set_kde_mode": (_i, [_vp, _i]),
+    "abc_ctx_set_gram_mode": (_i, [_vp, _i]),
     "abc_kde_last_kernel": (_i, [_vp, _vp]),
     "abc_ctx_set_noise_mode": (_i, [_vp, _i]),
     "abc_ctx_set_weight_kernel": (_i, [_vp, _i]),
@@ -289,6 +291,10 @@ class Context:
         F, A, on = np.empty(w.size), np.empty(w.size, dtype=np.uint64), C.c_int(0)
         self.check(lib().abc_alias_table(self._h, w.ctypes.data, w.size, F.ctypes.data, A.ctypes.data, C.byref(on)))
         return F, A, on.value
+
+    def set_gram_mode(self, mode):
+        """GRAM_AUTO (byte-limb statistics kernel for wide, large sets) or GRAM_FP64 (abc_ctx_set_gram_mode)"""
+        self.check(lib().abc_ctx_set_gram_mode(self._h, int(mode)))
 
     def set_kde_mode(self, mode):
         """KDE_AUTO (split-operand matrix-pipe kernel where it applies) or KDE_FP64 (abc_ctx_set_kde_mode)"""

@@ -63,6 +63,7 @@ struct abc_ctx {
     // optional per-stage timing with HIP events recorded on ctx->stream (abc_timing_*)
     int timing;            // 0 off, 1 every stage, 2 only the two kernel brackets bench.py's roofline needs (k_gram, k_kde)
     int kde_mode;  // ABC_KDE_AUTO / ABC_KDE_FP64
+    int gram_mode; // ABC_GRAM_AUTO / ABC_GRAM_FP64 (abc_ctx_set_gram_mode)
     int noise_mode;  // ABC_NOISE_DEVICE / ABC_NOISE_REFERENCE_STREAM
     int weight_kernel;  // ABC_WEIGHT_GAUSSIAN / ABC_WEIGHT_EPANECHNIKOV
     int alias_mode;     // ABC_ALIAS_DEVICE (default) / ABC_ALIAS_HOST
@@ -202,9 +203,11 @@ __host__ __device__ static inline ModelLayout model_layout(size_t M, size_t P, s
 // ---- stage launchers (each in its own .hip file) ---------------------------------------
 int launch_stats_shift(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
                        size_t M, size_t P, double* stats);
+// n_set (0: n): the rows of the WHOLE set these n are a shard of -- the choice between the i8 and the fp64 kernel of wide sets is
+// made from it, so that all ranks of a sharded generation and the unsharded run agree (abc_ctx_set_gram_mode)
 int launch_stats_accumulate(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx,
                             size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
-                            double* stats);
+                            double* stats, size_t n_set = 0);
 int launch_pls_model(abc_ctx*, const double* stats, const double* obs, size_t M, size_t P, size_t A,
                      int rule, double* model);
 int launch_simple_model(abc_ctx*, const double* stats, const double* obs, size_t M, size_t P,

@@ -1401,7 +1401,7 @@ int launch_stats_shift(abc_ctx* ctx, const double* X, const double* Y, size_t n,
 }
 
 int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
-                            size_t M, size_t P, uint64_t row0, uint64_t n_train_global, double* stats) {
+                            size_t M, size_t P, uint64_t row0, uint64_t n_train_global, double* stats, size_t n_set) {
     long long split = 0;
     if (n_train_global > row0) split = (long long)((n_train_global - row0) < n ? (n_train_global - row0) : n);
     const size_t C = (M + P + 15) / 16;
@@ -1430,11 +1430,11 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // that instantiation; it stays on the grouped path)
     // ... large sets on the byte-limb kernel on the i8 matrix pipe (k_gram_i8: sums and the diagonal exact, off-diagonal products
     // to ~1e-10 of sqrt(G_aa G_bb)); small ones, and all with ABC_GRAM_FP64 (A/B runs, tests), on the fp64 matrix pipe
-    static const bool gram_fp64 = abc_diag_env("ABC_GRAM_FP64") != nullptr;
+    const bool gram_fp64 = ctx->gram_mode == ABC_GRAM_FP64;      // (abc_ctx_set_gram_mode; ABC_DIAG=1 ABC_GRAM_FP64=1 presets it)
     // (LDS-DMA staging: 16-byte aligned columns, an even row count; from 200000 rows: the values are rounded to a 32-bit grid of
     // 10 .. 19 sigma, noise of 3e-9 sigma per value that averages out with the square root of the rows -- 1e-10 of sqrt(G_aa G_bb) at
     // 35000 rows per partition, which the 32nd loading of a 128-metric model amplifies to 2e-7; 4e-8 at 1e6 rows)
-    const bool i8_ok = !gram_fp64 && n >= 200000 && dma_ok;
+    const bool i8_ok = !gram_fp64 && (n_set ? n_set : n) >= 200000 && n >= 4096 && dma_ok;
 #define GRAM_WIDE_CASE(c, cy) if (C == c && CY == cy) return i8_ok ? run_gram_i8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats) \
                                                                     : run_gram_wide<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_WIDE_CASE(8, 0); GRAM_WIDE_CASE(8, 1); GRAM_WIDE_CASE(8, 2);

@@ -195,7 +195,11 @@ struct CandRec {
 // added up in rank order (the same bits on every rank).  The shifts are all near the column means, so the corrections are small
 // against G_r: nothing of the one-pass statistics' accuracy is lost.  Entries no rank has computed (the pure Y'Y blocks off their
 // diagonal, padding) stay zero.
-__global__ __launch_bounds__(256) void k_stats_merge(const double* __restrict__ all, int W, StatsLayout L, double* __restrict__ out) {
+// Which entries the ranks have computed follows from the BLOCK STRUCTURE (a 16-column block pair is skipped only when neither
+// block holds a metric column: the pure Y'Y blocks keep their diagonal alone), not from the values: a column that is constant
+// within every shard but differs between them has G_r = 0 and s_r = 0 on every rank, and its re-centring terms are all there is
+// (the values are still looked at for the blocks the structure does not vouch for).
+__global__ __launch_bounds__(256) void k_stats_merge(const double* __restrict__ all, int W, StatsLayout L, int M, double* __restrict__ out) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, C = L.C16;
     if (e < 2) {                                             // the counts
         double n = 0.0;
@@ -232,7 +236,9 @@ __global__ __launch_bounds__(256) void k_stats_merge(const double* __restrict__ 
         const double si = rec[L.off_sum[p] + i], sj = rec[L.off_sum[p] + j], nr = rec[L.off_n + p];
         acc += g + fma(di, sj, fma(si, dj, nr * di * dj));
     }
-    out[L.off_G[p] + ij] = (any || i == j) ? acc : 0.0;
+    const size_t CX = ((size_t)M + 15) / 16;                 // blocks with at least one metric column
+    const bool structural = i == j || i / 16 < CX || j / 16 < CX;
+    out[L.off_G[p] + ij] = (any || structural) ? acc : 0.0;
 }
 
 // header of a rank's list: [0] entries, [1] its selection gave up (placeholder entries), [2] the rank's rows
@@ -487,11 +493,12 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     // stream costs its critical path 6-7 us, the first packet of an idle queue nothing)
     ctx->side_early_waited = false;
     ctx->side_forked = false;
+    *(volatile unsigned*)(ctx->status_pin + 56) = 0u;          // (raised by a proposal kernel that gives up: read at the call's end)
     ABC_TRY(abc_side_fork(ctx));
     // Every rank takes its statistics about ITS OWN pilot shift (round 4: no broadcast of rank 0's in front of the pass over the
     // rows); the records are all-gathered and every rank re-centres them on rank 0's shift while it adds them up (k_stats_merge).
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
-    ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats));
+    ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats, N));
     // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream
     uint32_t* raw_early = nullptr;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));
@@ -507,7 +514,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         if (!stats_all) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
         ABC_TRY(comm_all_gather(ctx, stats, stats_all, SL.len * 8));
         const size_t ne = 2 * SL.C16 * SL.C16 + 3 * SL.C16 + 2;
-        hipLaunchKernelGGL(k_stats_merge, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)stats_all, W, SL, stats);
+        hipLaunchKernelGGL(k_stats_merge, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)stats_all, W, SL, (int)M, stats);
         ABC_HIP(ctx, hipGetLastError());
     }
     ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
@@ -868,6 +875,21 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
                                    cfg->multivariate ? L_used : dv, io->next, nullptr, cfg->Nnext_total, &prep_used));
             ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
+    }
+    // this rank's proposals the perturbation gave up on during THIS call (abc_generation_giveups; ADVICE round 4: the sharded driver
+    // left the count of the context's last fused generation standing): the pinned word a proposal kernel raises when it gives up
+    // tells whether the device counter has to be fetched at all
+    {
+        volatile unsigned* pgaveup = (volatile unsigned*)(ctx->status_pin + 56);
+        if (Nn && *pgaveup && ctx->giveups_dev) {
+            unsigned long long now = 0;
+            ABC_HIP(ctx, hipMemcpyAsync(&now, ctx->giveups_dev, sizeof(now), hipMemcpyDeviceToHost, ctx->stream));
+            ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->giveups_dev_known = now;
+        }
+        const unsigned long long gv = ctx->giveups_dev_known + ctx->giveups_host, before = ctx->giveups_seen;
+        ctx->giveups_seen = gv;
+        ctx->giveups_last_call = (Nn && gv > before) ? gv - before : 0ull;
     }
     if (spd) ABC_FAIL(ctx, ABC_ERR_NOT_SPD, "covariance of the selected particles is not positive definite");
     return ABC_OK;

@@ -198,6 +198,16 @@ class AbcSmc {
     void set_database_filename(std::string name) { db_path_ = name; }
     void set_retain_posterior_rank(const bool retain_rank) { keep_posterior_rank_ = retain_rank; }
     void set_filtering_type(const ABC::FILTER& ft) { ranking_kind_ = ft; }
+    // the PLS component rule of THIS object ("pls_component_rule" / "pls_max_components" of its configuration; -1: whatever
+    // ABC::set_component_rule / set_max_components say process-wide at the time of the ranking).  Kept per object: two AbcSmc
+    // objects with different configurations do not change each other's rule
+    void set_component_rule(int rule) {
+        if (rule != ABC_RULE_MIN_PRESS && rule != ABC_RULE_WILCOXON) { std::cerr << "Unknown PLS component rule. Aborting." << std::endl; exit(-210); }
+        component_rule_ = rule;
+    }
+    int component_rule() const { return component_rule_ < 0 ? ABC::component_rule() : component_rule_; }
+    void set_max_components(int a) { max_components_ = a < 0 ? 0 : a; }
+    int max_components() const { return max_components_ < 0 ? ABC::max_components_ref() : max_components_; }
     void set_noise_type(const ABC::NOISE& nt) { noise_kind_ = nt; }
     const ABC::Metric* add_next_metric(const ABC::Metric* m) {
         mets_.push_back(m);
@@ -253,6 +263,7 @@ class AbcSmc {
     Row observed_;
     bool keep_posterior_rank_ = false;
     ABC::FILTER ranking_kind_ = ABC::FILTER::PLS;
+    int component_rule_ = -1, max_components_ = -1;      // -1: the process-wide setting (ABC::component_rule(), default Wilcoxon)
     ABC::NOISE noise_kind_ = ABC::NOISE::INDEPENDENT;
     size_t n_sets_ = 0;
     std::vector<size_t> particles_per_set_, kept_per_set_;
@@ -506,11 +517,11 @@ inline bool AbcSmc::parse_config(const std::string& conf_filename) {          //
     // reduction as SURVEY A.2 describes it) and a cap on the number of components
     if (par.isMember("pls_component_rule")) {
         const std::string rule = par["pls_component_rule"].asString();
-        if (rule == "wilcoxon" || rule == "WILCOXON") ABC::set_component_rule(ABC_RULE_WILCOXON);
-        else if (rule == "min_press" || rule == "MIN_PRESS" || rule == "press") ABC::set_component_rule(ABC_RULE_MIN_PRESS);
+        if (rule == "wilcoxon" || rule == "WILCOXON") component_rule_ = ABC_RULE_WILCOXON;
+        else if (rule == "min_press" || rule == "MIN_PRESS" || rule == "press") component_rule_ = ABC_RULE_MIN_PRESS;
         else die(-210, "Unknown pls_component_rule specified: " + rule + ". Aborting.");
     }
-    if (par.isMember("pls_max_components")) ABC::set_max_components(par["pls_max_components"].asInt());
+    if (par.isMember("pls_max_components")) { max_components_ = par["pls_max_components"].asInt(); if (max_components_ < 0) max_components_ = 0; }
     return true;
 }
 
@@ -671,7 +682,7 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
             if (t > 0) prev_post = ABC::select_rows(set_params_[t - 1], kept_rows_[t - 1]);
             ABC::RankedSet rs = ABC::rank_and_weight(set_metrics_[t], set_params_[t], observed_, train_frac_, K,
                                                      pars_, t > 0 ? &prev_post : nullptr, t > 0 ? &set_weights_[t - 1] : nullptr,
-                                                     t > 0 ? &set_dv_[t - 1] : nullptr);
+                                                     t > 0 ? &set_dv_[t - 1] : nullptr, component_rule(), max_components());
             kept_rows_.push_back(rs.idx);
             AbcLog::filtering_report(this, t, rs.theta, ABC::select_rows(set_metrics_[t], kept_rows_[t]), *log_stream);
             _transaction(db, "recording posterior ranks", [&] {
@@ -685,7 +696,8 @@ inline bool AbcSmc::read_SMC_sets_from_database(sqdyn::Db& db, std::vector<std::
         } else {                                 // rank on the GPU, keep the best K, record the ranks
             switch (ranking_kind_) {
                 case ABC::FILTER::PLS:
-                    kept_rows_.push_back(ABC::particle_ranking_PLS(set_metrics_[t], set_params_[t], observed_, train_frac_));
+                    kept_rows_.push_back(ABC::particle_ranking_PLS(set_metrics_[t], set_params_[t], observed_, train_frac_, component_rule(),
+                                                                   max_components()));
                     break;
                 case ABC::FILTER::SIMPLE:
                     kept_rows_.push_back(ABC::particle_ranking_simple(set_metrics_[t], set_params_[t], observed_));

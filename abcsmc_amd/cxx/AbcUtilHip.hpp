@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -127,6 +128,18 @@ struct Parameter {
     virtual float_type get_sd() const { return std::nan(""); }
     virtual bool isPosterior() const { return false; }
     bool valid(float_type pval) const { return likelihood(pval) != 0.0; }
+    // Parameter.h:52-77 / Priors.h:19-43: recast(N(mu, sigma)) from the shared taus2 stream until it is valid, at most MAX_ATTEMPTS
+    // times; then the prior's mean, with the reference's message on stderr (host side: one value at a time, as upstream)
+    float_type noise(const RNG* rng, const float_type mu, const float_type sigma, const size_t MAX_ATTEMPTS = 1000) const {
+        size_t attempts = 1;
+        float_type dev = recast(ran_gaussian(rng, sigma) + mu);
+        while (!valid(dev) && (attempts++ < MAX_ATTEMPTS)) dev = recast(ran_gaussian(rng, sigma) + mu);
+        if (!valid(dev)) {
+            std::fprintf(stderr, "ERROR: failed to draw valid noise from prior %s - returning mean value.\n", get_name().c_str());
+            return get_mean();
+        }
+        return dev;
+    }
     size_t state_size() const { return state_size_; }
 
    private:
@@ -269,7 +282,8 @@ struct RankedSet {
 };
 inline RankedSet rank_and_weight(const Mat2D& X, const Mat2D& Y, const Row& obs, float_type training_fraction, size_t K,
                                  const std::vector<const Parameter*>& mpars, const Mat2D* prev_params = nullptr,
-                                 const Row* prev_weights = nullptr, const Row* prev_doubled_variance = nullptr) {
+                                 const Row* prev_weights = nullptr, const Row* prev_doubled_variance = nullptr,
+                                 int rule = -1 /* -1: component_rule() */, int max_components = -1 /* -1: the process-wide setting */) {
     if (!multi_device()) throw HipError(ABC_ERR_INVALID, "rank_and_weight: call use_devices() first");
     const size_t N = X.rows(), M = X.cols(), P = Y.cols();
     RankedSet out;
@@ -279,7 +293,8 @@ inline RankedSet rank_and_weight(const Mat2D& X, const Mat2D& Y, const Row& obs,
     abc_generation_cfg cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.N = N; cfg.M = M; cfg.P = P; cfg.K = K; cfg.Kp = prev_params ? prev_params->rows() : 0; cfg.Nnext = 0;
-    cfg.train_frac = training_fraction; cfg.max_comp = max_components_ref(); cfg.rule = component_rule(); cfg.multivariate = 0;
+    cfg.train_frac = training_fraction; cfg.max_comp = max_components < 0 ? max_components_ref() : max_components;
+    cfg.rule = rule < 0 ? component_rule() : rule; cfg.multivariate = 0;
     abc_generation_io io;
     memset(&io, 0, sizeof(io));
     io.X = X.data(); io.Y = Y.data(); io.obs = obs.data(); io.priors = pr.data();
@@ -296,15 +311,21 @@ inline RankedSet rank_and_weight(const Mat2D& X, const Mat2D& Y, const Row& obs,
 }
 
 // ---- AbcUtil.h:144-153 ----------------------------------------------------------------------------------
+// (rule / max_components: what an AbcSmc object was configured with -- the process-wide set_component_rule / set_max_components are
+// only the defaults of the four-argument form the reference has)
 inline std::vector<size_t> particle_ranking_PLS(const Mat2D& X_orig, const Mat2D& Y_orig, const Row& target_values,
-                                                const float_type training_fraction) {
+                                                const float_type training_fraction, int rule, int max_components) {
     if (!((0 < training_fraction) && (training_fraction <= 1))) throw HipError(ABC_ERR_INVALID, "training_fraction");
     const size_t N = X_orig.rows();
     std::vector<uint64_t> idx(N);
     check(abc_particle_ranking_pls(context(), X_orig.data(), Y_orig.data(), target_values.data(), N, X_orig.cols(),
-                                   Y_orig.cols(), training_fraction, max_components_ref(), component_rule(), N, idx.data(), nullptr,
+                                   Y_orig.cols(), training_fraction, max_components, rule, N, idx.data(), nullptr,
                                    nullptr, nullptr, nullptr, nullptr));
     return std::vector<size_t>(idx.begin(), idx.end());
+}
+inline std::vector<size_t> particle_ranking_PLS(const Mat2D& X_orig, const Mat2D& Y_orig, const Row& target_values,
+                                                const float_type training_fraction) {
+    return particle_ranking_PLS(X_orig, Y_orig, target_values, training_fraction, component_rule(), max_components_ref());
 }
 inline std::vector<size_t> particle_ranking_simple(const Mat2D& X_orig, const Mat2D& /* Y_orig */,
                                                    const Row& target_values) {
@@ -383,6 +404,40 @@ inline Mat2D sample_predictive_priors(const RNG* rng, const size_t num_samples, 
                                        doubled_variance.data(), out.data(), nullptr, seeds ? sd.data() : nullptr));
     if (seeds) seeds->assign(sd.begin(), sd.end());
     return out;
+}
+
+// ---- AbcUtil.h:80-91: the per-row samplers behind sample_predictive_priors / sample_mvn_predictive_priors ------------------------
+// The reference only calls them from those two (AbcUtil.cpp:386, 401); a drop-in header carries every declaration of
+// AbcUtil.h:78-172, so here they are, with the reference's semantics on the reference's stream: ONE row from the shared taus2
+// stream on the host (the device path draws whole sets: abc_sample_*).  Bit for bit the oracle's rows (tests/test_gpu_parity.py).
+// AbcUtil.cpp:145-158: per coordinate Parameter::noise (<= 1000 tries, then the prior's mean)
+inline Row gsl_ran_trunc_normal(const RNG* rng, const std::vector<const Parameter*> _model_pars, const Row& mu,
+                                const Row& sigma_squared) {
+    Row res(sigma_squared.size(), 0.0);
+    for (size_t parIdx = 0; parIdx < sigma_squared.size(); parIdx++)
+        res[parIdx] = _model_pars[parIdx]->noise(rng, mu[parIdx], std::sqrt(sigma_squared[parIdx]));
+    return res;
+}
+// AbcUtil.cpp:122-143: x = mu + L z (z iid N(0,1) in coordinate order: gsl_ran_multivariate_gaussian), every coordinate recast,
+// the whole draw again unless all are valid.  L: P x P, the lower triangle + diagonal of setup_mvn_sampler's factor.  The
+// reference retries without bound; here ABC_MVN_MAX_TRIES draws, then HipError (the device path falls back to the parent and
+// counts it, abc_perturb_giveups)
+constexpr size_t ABC_MVN_MAX_TRIES = 16384;
+inline Row gsl_ran_trunc_mv_normal(const RNG* rng, const std::vector<const Parameter*> _model_pars, const Row& mu, const Mat2D& L) {
+    const size_t npar = _model_pars.size();
+    Row par_values(npar, 0.0), z(npar, 0.0);
+    for (size_t tries = 0; tries < ABC_MVN_MAX_TRIES; tries++) {
+        bool success = true;
+        for (size_t i = 0; i < npar; i++) z[i] = ran_gaussian(rng, 1.0);                     // gsl_ran_ugaussian
+        for (size_t parIdx = 0; success && (parIdx < npar); parIdx++) {
+            double x = 0.0;                                                                  // dtrmv, lower, non-unit: row parIdx of L times z
+            for (size_t k = 0; k <= parIdx; k++) x += L(parIdx, k) * z[k];
+            par_values[parIdx] = _model_pars[parIdx]->recast(x + mu[parIdx]);
+            success = _model_pars[parIdx]->valid(par_values[parIdx]);
+        }
+        if (success) return par_values;
+    }
+    throw HipError(ABC_ERR_INVALID, "gsl_ran_trunc_mv_normal: no valid draw in 16384 tries");
 }
 
 // AbcUtil.cpp:320-324 (host helper kept for completeness; the device fuses it into the projection)

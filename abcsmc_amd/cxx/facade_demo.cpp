@@ -50,6 +50,23 @@ int main() {
         for (size_t i = 0; i < 12; i++) std::printf(" %zu", r_wx[i]);
         std::printf("\n");
         if (dflt != ABC_RULE_WILCOXON || !rejected) return 3;
+        // AbcUtil.h:80-91: the per-row samplers on the reference's own stream (one uniform of the resampling draw in front, as
+        // sample_predictive_priors / sample_mvn_predictive_priors consume it for a one-row posterior)
+        DiscreteUniformPrior q0("a", "a", 1, 1000);
+        ContinuousUniformPrior q1("b", "b", -2.0, 3.0);
+        GaussianPrior q2("c", "c", 5.0, 10.0);
+        std::vector<const Parameter*> qp = {&q0, &q1, &q2};
+        const Row mu = {500.2, 2.9, 4.0}, s2 = {2500.0, 4.0, 1.5};
+        RNG r1(777);
+        (void)rng_get(&r1);
+        const Row tn = gsl_ran_trunc_normal(&r1, qp, mu, s2);
+        std::printf("trunc_normal: %.17g %.17g %.17g state %lu\n", tn[0], tn[1], tn[2], rng_get(&r1));
+        Mat2D Lq(3, 3);
+        Lq(0, 0) = 40.0; Lq(1, 0) = 0.7; Lq(1, 1) = 1.9; Lq(2, 0) = -0.3; Lq(2, 1) = 0.4; Lq(2, 2) = 1.1;
+        RNG r2(778);
+        (void)rng_get(&r2);
+        const Row tm = gsl_ran_trunc_mv_normal(&r2, qp, mu, Lq);
+        std::printf("trunc_mv_normal: %.17g %.17g %.17g state %lu\n", tm[0], tm[1], tm[2], rng_get(&r2));
     } catch (const HipError& e) {
         std::printf("HipError %d: %s\n", e.code, e.what());
         return 1;

@@ -62,7 +62,7 @@ int main(int argc, char* argv[]) {
     }
     AbcSmc* abc = new AbcSmc();
     abc->parse_config(argv[1]);
-    if (component_rule >= 0) ABC::set_component_rule(component_rule);          // (the command line overrides the configuration)
+    if (component_rule >= 0) abc->set_component_rule(component_rule);          // (the command line overrides the configuration; per object)
     try {
         if (!devices.empty()) ABC::use_devices(devices);
         if (reference_stream && process_db) ABC::set_reference_stream(true);

@@ -86,6 +86,21 @@ int  abc_version(void);
  * ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
+/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets -- 113..160 columns (metrics + parameters).
+ * ABC_GRAM_AUTO (default): from 200 000 rows IN THE WHOLE SET (the sharded generation decides from N_total, so that every rank and
+ * the unsharded run of the same set take the same kernel) the byte-limb kernel on the i8 matrix pipe: every value rounded to a 32-bit
+ * fixed-point grid of 10..19 sigma per column; column sums, row counts and the Gram DIAGONAL are exact, an off-diagonal product
+ * carries ~4e-11 (typical) .. 2e-9 (worst seen: a point-mass column) of sqrt(G_aa G_bb), which the high loadings of a 128-metric,
+ * 32-component model amplify to 2e-7 .. 4e-6 relative (still inside the 1e-6 of BASELINE.json for the 8 components the distance
+ * uses at configs[4]; the selection is the oracle's up to near-ties).  Rows outside a column's grid ("far" rows) are summed in fp64
+ * by a serial side kernel: sets with heavy tails in many rows should use ABC_GRAM_FP64.  Below the row threshold, for narrower or
+ * wider sets, for unaligned / odd-length columns: fp64 kernels regardless.
+ * ABC_GRAM_FP64: the fp64 kernels always (k_gram_wide: products on the fp64 matrix pipe, ~1e-15 of sqrt(G_aa G_bb)); 1.5x the time of
+ * the i8 kernel at 1e6 rows x 144 columns.  With it the sharded generation's statistics equal the unsharded ones to rounding of the
+ * order of summation (distances within 1e-12); under ABC_GRAM_AUTO the two differ by the fixed-point noise above (each rank rounds
+ * on its own grid), selection indices still agree up to near-ties. */
+enum { ABC_GRAM_AUTO = 0, ABC_GRAM_FP64 = 1 };
+int  abc_ctx_set_gram_mode(abc_ctx* ctx, int mode);
 /* Which of the two kernels produced the pair sums of the most recent weight call on this context (synchronises). */
 enum { ABC_KDE_RAN_NONE = 0, ABC_KDE_RAN_FP64 = 1, ABC_KDE_RAN_SPLIT = 2 };
 int  abc_kde_last_kernel(abc_ctx* ctx, int* which);
@@ -123,7 +138,9 @@ int  abc_alias_table(abc_ctx* ctx, const double* w, size_t K, double* F, uint64_
  * AbcUtil.cpp:132) plus independent-noise coordinates that fell back to the prior mean after 1000 tries (the reference prints
  * an error line per fallback, Priors.h:27-29).  Synchronises. */
 int  abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset);
-/* ... and how many of them the most recent abc_generation_dev call on this context added (0 after a clean generation; the value the host already holds at the call's end: no synchronisation). */
+/* ... and how many of them the most recent abc_generation_dev / abc_generation_sharded_dev call on this context added (the sharded
+ * call: those of THIS rank's slice of the proposals; 0 after a clean generation; the value the host already holds at the call's
+ * end: no synchronisation). */
 int  abc_generation_giveups(const abc_ctx* ctx, uint64_t* count);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
@@ -347,7 +364,9 @@ int abc_ctx_create_multi(const int* devices, int ndev, abc_ctx** out);
  * n_local); idx / dist / theta / w / dv / L are replicated outputs (global row numbers in idx); next / parent / seeds
  * hold this rank's nnext_local proposals (leading dimension nnext_local).  rng: the same state on every rank; advanced by
  * the 2 Nnext_total draws of the whole generation.  Results equal abc_generation_dev on the unsharded set bit for bit
- * (indices, parents, seeds) and to rounding of the reduction order (statistics -> model -> distances within 1e-12). */
+ * (indices, parents, seeds) and to rounding of the reduction order (statistics -> model -> distances within 1e-12) -- for sets of
+ * 113..160 columns and 200 000 rows or more under ABC_GRAM_FP64 only (abc_ctx_set_gram_mode: the default byte-limb statistics
+ * kernel rounds every rank's values on the rank's own grid; indices then agree up to near-ties, distances to ~1e-7). */
 typedef struct {
     size_t n_local, row0, N_total;        /* this rank's rows of the current set                      */
     size_t M, P;

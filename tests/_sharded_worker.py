@@ -3,7 +3,7 @@ argv: backend ("numpy" -> CPU tensors + gloo; "hip" -> cuda:0 tensors + gloo, bo
 Python; "cabi" -> the same two ranks through abc_generation_sharded_dev with the gloo collectives handed in as callbacks;
 "rccl" -> abc_generation_sharded_dev over an in-library RCCL communicator, ONE GPU PER RANK (needs as many GPUs as ranks)),
 out_json, [shape = "n_local,M,P,A,K,Kp,nnext_local"], [rule = "press" | "wilcoxon" (cabi only)], [data = "plain" | "ties":
-the metric rows repeat 4 distinct ones, so the distances are massively tied], [split = "even" | "uneven" (cabi / rccl only): the
+the metric rows repeat 4 distinct ones, so the distances are massively tied | "blocked": metric 1 takes one value per shard], [split = "even" | "uneven" (cabi / rccl only): the
 n_local * world rows dealt to the ranks in shares 2^(world-1-rank) -- two thirds / one third on two ranks, 4 : 2 : 1 on three]."""
 import json
 import os
@@ -30,11 +30,15 @@ def main():
     wl = synthetic.Workload(M, P, 777)
     ties = len(sys.argv) > 5 and sys.argv[5] == "ties"
 
+    blocked = len(sys.argv) > 5 and sys.argv[5] == "blocked"
+
     def rows(lo, hi):
         X, Y = wl.rows(lo, hi)
         if ties:
             X4, _ = wl.rows(0, 4)
             X = np.asfortranarray(X4[np.arange(lo, hi) % 4])
+        if blocked:        # a metric that is constant WITHIN every (even) shard and differs between them: its Gram entries and sums are
+            X[:, 1] = 3.0 + 2.0 * (np.arange(lo, hi) // n_loc)           # zero on every rank, its re-centring terms are all there is
         return X, Y
 
     uneven = len(sys.argv) > 6 and sys.argv[6] == "uneven"

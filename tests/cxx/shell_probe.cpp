@@ -36,7 +36,7 @@ static int describe_mode(const char* cfg) {
     std::cout << "iterations " << abc.get_smc_iterations() << "\n";
     std::cout << "noise " << (abc.noise_type() == ABC::NOISE::MULTIVARIATE ? "MULTIVARIATE" : "INDEPENDENT") << "\n";
     std::cout << "filtering " << (abc.filtering_type() == ABC::FILTER::PLS ? "PLS" : "SIMPLE") << "\n";
-    std::cout << "component_rule " << (ABC::component_rule() == ABC_RULE_WILCOXON ? "wilcoxon" : "min_press") << "\n";
+    std::cout << "component_rule " << (abc.component_rule() == ABC_RULE_WILCOXON ? "wilcoxon" : "min_press") << "\n";
     std::cout << "set_sizes";
     for (size_t t = 0; t < abc.get_smc_iterations(); t++) std::cout << " " << abc.get_smc_size_at(t);
     std::cout << "\npred_prior_sizes";

@@ -1456,6 +1456,22 @@ def test_cxx_facade_demo(gpu_ctx, tmp_path):
     lines = {ln.split(":")[0]: [int(v) for v in ln.split(":")[1].split()] for ln in out.stdout.splitlines() if ln.startswith(("press:", "wilcoxon:"))}
     assert lines["press"] == [int(v) for v in O.particle_ranking_pls(X, Y, obs, 0.5, rule=O.RULE_MIN_PRESS)["idx"][:12]]
     assert lines["wilcoxon"] == [int(v) for v in O.particle_ranking_pls(X, Y, obs, 0.5, rule=O.RULE_WILCOXON)["idx"][:12]]
+    # ABC::gsl_ran_trunc_normal / gsl_ran_trunc_mv_normal (AbcUtil.h:80-91), one row each on the shared taus2 stream: the oracle's
+    # sample_predictive_priors / sample_mvn_predictive_priors of a one-row posterior, bit for bit, and the same stream position after
+    from abcsmc_amd import _lib
+    spec = [(_lib.PRIOR_UNIF_INT, 1, 1000), (_lib.PRIOR_UNIF_REAL, -2.0, 3.0), (_lib.PRIOR_GAUSS, 5.0, 10.0)]
+    mu, s2 = np.array([[500.2, 2.9, 4.0]]), np.array([2500.0, 4.0, 1.5])
+    r1 = O.rng(777)
+    want = O.sample_predictive_priors(r1, 1, np.array([1.0]), np.asfortranarray(mu), O.make_priors(spec), s2)
+    got = [ln for ln in out.stdout.splitlines() if ln.startswith("trunc_normal:")][0].split()
+    assert [float(v) for v in got[1:4]] == [float(v) for v in np.asarray(want[0]).ravel()], (got, want)
+    assert int(got[5]) == O.rng_get(r1)
+    L = np.asfortranarray(np.array([[40.0, 0, 0], [0.7, 1.9, 0], [-0.3, 0.4, 1.1]]))
+    r2 = O.rng(778)
+    want = O.sample_mvn_predictive_priors(r2, 1, np.array([1.0]), np.asfortranarray(mu), O.make_priors(spec), L)
+    got = [ln for ln in out.stdout.splitlines() if ln.startswith("trunc_mv_normal:")][0].split()
+    assert [float(v) for v in got[1:4]] == [float(v) for v in np.asarray(want[0]).ravel()], (got, want)
+    assert int(got[5]) == O.rng_get(r2)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1559,6 +1575,38 @@ def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
         assert np.allclose(G[part][:M, :C], G[part][:C, :M].T)                                       # symmetric where both halves exist
     print("wide Gram %s N=%d: worst off-diagonal error %.2e of sqrt(G_aa G_bb) (%s)" % (kind, N, worst, where))
     assert worst <= 5e-10, worst
+
+
+def test_gram_mode_is_a_public_setting(gpu_ctx):
+    """abc_ctx_set_gram_mode (the precision of the wide sets' statistics was an internal switch): ABC_GRAM_FP64 sends
+    a set the byte-limb kernel would take to the fp64 matrix pipe -- off-diagonal products to 1e-13 of sqrt(G_aa G_bb) instead of
+    ~1e-10 --, ABC_GRAM_AUTO brings the i8 kernel back (a different, less exact record), an unknown mode is refused"""
+    from abcsmc_amd import _lib
+    N, M, P = 200_000, 128, 16
+    wl, X, Y, obs = _wl(M, P, N, 21)
+    X, Y = np.asfortranarray(X), np.asfortranarray(Y)
+    ntrain, C = N // 2, M + P
+    Z = np.hstack([X, Y])
+
+    def worst():
+        shift, sums, G = _stats_record(gpu_ctx, X, Y, ntrain)
+        w = 0.0
+        for part, (a, b) in enumerate(((0, ntrain), (ntrain, N))):
+            V = Z[a:b] - shift[:C]
+            ref = V.T @ V
+            scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300
+            w = max(w, float((np.abs(G[part][:M, :C] - ref[:M, :C]) / scale[:M, :C]).max()))
+        return w
+    try:
+        gpu_ctx.set_gram_mode(_lib.GRAM_FP64)
+        e64 = worst()
+        gpu_ctx.set_gram_mode(_lib.GRAM_AUTO)
+        e8 = worst()
+    finally:
+        gpu_ctx.set_gram_mode(_lib.GRAM_AUTO)
+    print("wide Gram, 144 columns x 2e5 rows: worst off-diagonal error %.2e (ABC_GRAM_FP64), %.2e (ABC_GRAM_AUTO: i8 limbs)" % (e64, e8))
+    assert e64 <= 1e-13 and 1e-13 < e8 <= 5e-10, (e64, e8)
+    assert _lib.lib().abc_ctx_set_gram_mode(gpu_ctx.handle, 7) == _lib.lib().abc_ctx_set_gram_mode(None, 0) != 0
 
 
 def _wilcoxon_per_response(gpu_ctx, oracle, X, Y, obs, A, f=0.5):

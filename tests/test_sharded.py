@@ -128,6 +128,14 @@ def test_sharded_cabi_driver_wilcoxon_cascade_over_the_shards(tmp_path, shape, w
 
 
 @pytest.mark.gpu
+def test_sharded_statistics_merge_of_a_column_constant_within_every_shard(tmp_path):
+    """a metric that takes one value per shard (sorted or blocked data): every rank's centred sums and products of that column are
+    exactly zero, the merged record's entries for it consist of the re-centring terms alone -- the merge takes which entries exist
+    from the block structure, not from the values"""
+    _check(_launch("cabi", tmp_path, 29659, "small", "press", "blocked"))
+
+
+@pytest.mark.gpu
 def test_sharded_wilcoxon_cascade_equals_the_row_gather(tmp_path):
     """... and the same generation with the validation rows gathered on every rank instead (ABC_WX_GATHER: the path of rounds 1-4,
     still the fallback for small sets): the same outputs against the oracle, more collectives"""
