@@ -533,8 +533,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (fork_late) ABC_TRY(abc_side_fork(ctx));
     if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
     else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
-    if (!simple && cfg->rule == ABC_RULE_WILCOXON)
-        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, forked behind the Gram
     // kernel (which wants the whole memory system) and running beside the reduce / model fit that leave the chip empty
     uint32_t* raw_early = nullptr;
@@ -560,6 +558,12 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     if (seeds_late) ABC_TRY(abc_rng_seeds_early(ctx, rng, 0, Nn, io->seeds, Nn));
     ctx->side_forked = false;
+    // The Wilcoxon reduction of the component count goes BEHIND the side stream's launches in host order (round 5): the host looks
+    // at the cascade's level counts between its launches, and whatever it has not queued by then waits for those looks -- queued
+    // in front (rounds 1-4), the previous set's prologue and the taus2 streams started only after the reduction and the host's
+    // ~90 us of enqueueing them showed as a bubble in front of the projection (rocprofv3 timeline, profiles/r05_timeline_*)
+    if (!simple && cfg->rule == ABC_RULE_WILCOXON)
+        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/io->w != nullptr));

@@ -559,7 +559,8 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
                                                     const int* __restrict__ astar, int P, const int* __restrict__ segbase,
                                                     int* __restrict__ act_next, int* __restrict__ nact_next,
                                                     const double* __restrict__ nv_ranks, size_t nv_stride, int Wr, int* __restrict__ pin_words,
-                                                    int force_undecided /* diagnostic: every test with keys stays undecided */) {
+                                                    int force_undecided /* diagnostic: every test with keys stays undecided */,
+                                                    double* __restrict__ model, int M, int A) {
     extern __shared__ unsigned int wxb_cp[];              // [NBX] packed (all keys, positive keys) of the test's bins
     __shared__ long long red[3][16];
     __shared__ unsigned long long wtot[16];
@@ -569,6 +570,11 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     { const int na = *nact_p; end = end < na ? end : na; }
     if (act_lo + e < end) {
         const int seg = act[act_lo + e];
+        // (all, positive) of bin b as one 8-byte word at cp[b + b / per]: a thread owns `per` consecutive bins, and the pad word per
+        // thread keeps the lanes of a wave on different banks (unpadded, lane t read word 2 per t: all on ONE bank at per = 16 --
+        // 1.5 us per turn of the loops below, 25 of this kernel's 40 us at 16384 bins)
+        unsigned long long* cp = (unsigned long long*)wxb_cp;
+        const int per = (NBX + 1023) / 1024, b0t = t * per;
         for (int b0 = 0; b0 < NBX; b0 += 8 * 1024) {           // (eight loads in flight: one per turn was 16 memory latencies at 16384 bins)
             unsigned long long v[8];
 #pragma unroll
@@ -577,19 +583,16 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
             for (int u = 0; u < 8; u++) {
                 const int b = b0 + u * 1024 + t;
                 if (b < NBX) {
-                    const unsigned int c = (unsigned int)v[u], p = (unsigned int)(v[u] >> 32);
-                    wxb_cp[2 * b] = c;
-                    wxb_cp[2 * b + 1] = p;
-                    if (cl) cl[(size_t)(cl_by_test ? seg : act_lo + e) * cl_ld + b] = c;
+                    cp[b + b / per] = v[u];
+                    if (cl) cl[(size_t)(cl_by_test ? seg : act_lo + e) * cl_ld + b] = (unsigned int)v[u];
                 }
             }
         }
         if (t == 0 && slotmap) slotmap[seg] = act_lo + e;
         __syncthreads();
         // thread t owns the consecutive bins [t per, (t + 1) per): keys below them by a work-group scan of the threads' totals
-        const int per = (NBX + 1023) / 1024, b0 = t * per;
         unsigned long long loc = 0;
-        for (int i = 0; i < per; i++) if (b0 + i < NBX) loc += wxb_cp[2 * (b0 + i)];
+        for (int i = 0; i < per; i++) if (b0t + i < NBX) loc += (unsigned int)cp[b0t + i + t];
         unsigned long long inc = loc;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = (unsigned long long)__shfl_up((long long)inc, o, 64); if (lane >= o) inc += u; }
@@ -599,8 +602,9 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
         for (int w = 0; w < wave; w++) below += wtot[w];
         long long lo2 = 0, hi2 = 0, m = (long long)loc;
         for (int i = 0; i < per; i++)
-            if (b0 + i < NBX) {
-                const long long c = wxb_cp[2 * (b0 + i)], p = wxb_cp[2 * (b0 + i) + 1], B = (long long)below;
+            if (b0t + i < NBX) {
+                const unsigned long long w = cp[b0t + i + t];
+                const long long c = (long long)(unsigned int)w, p = (long long)(w >> 32), B = (long long)below;
                 const long long all2 = 2 * c * B + c * (c + 1);
                 lo2 += 4 * p * B + 2 * p * (p + 1) - all2;
                 hi2 += 4 * p * B + 4 * p * c - 2 * p * (p - 1) - all2;
@@ -669,6 +673,25 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
         __syncthreads();
     }
     const int total = s_run;
+    // Nothing left: every test is settled by its bounds, and the component counts follow from the verdicts alone -- written here
+    // (k_wx_decide's rule: per response the first candidate that passes, else the PRESS optimum; the largest over the responses),
+    // and the host, which sees `0`, does not launch that kernel: its launch behind the host's look was 20 us of the critical path
+    if (total == 0 && model) {
+        __shared__ int s_nc;
+        if (t == 0) s_nc = 1;
+        __syncthreads();
+        const ModelLayout ML = model_layout(M, P, A);
+        for (int j = t; j < P; j += 1024) {
+            const int b0 = segbase[j], as = astar[j];
+            int best = as;
+            for (int i = 0; i + 1 < as; i++)
+                if (v3v[b0 + i] == 1) { best = i + 1; break; }
+            model[ML.off_per + j] = (double)best;
+            atomicMax(&s_nc, best);
+        }
+        __syncthreads();
+        if (t == 0) model[ML.off_hdr] = (double)s_nc;
+    }
     if (t == 0) {
         *nact_next = total;
         long long vmax = 0;
@@ -715,6 +738,9 @@ __global__ __launch_bounds__(1024) void k_wx_xplan(int NBX, int nbcap, unsigned 
     __syncthreads();
     unsigned int cum = inc - loc;
     for (int w = 0; w < wave; w++) cum += wtot[w];
+    // (a thread's consecutive fine bins mostly share a bin: their counts are added up in registers and go to LDS once per bin -- one
+    // atomic per fine bin had four to sixty-four lanes of a wave on the same counter)
+    unsigned int run_b = 0xffffffffu, run_c = 0, run_base = 0;
 #pragma unroll
     for (int i = 0; i < WX_NBFMAX / 1024; i++) {
         if (i >= per) break;
@@ -722,9 +748,16 @@ __global__ __launch_bounds__(1024) void k_wx_xplan(int NBX, int nbcap, unsigned 
         unsigned int b = cum / target;
         b = b < (unsigned int)nbcap - 1u ? b : (unsigned int)nbcap - 1u;
         binmap[(size_t)u * NBX + f0 + i] = (unsigned short)b;
-        if (c) { atomicAdd(&hist_s[b], c); atomicMin(&base_s[b], cum); }
+        if (c) {
+            if (b != run_b) {
+                if (run_c) { atomicAdd(&hist_s[run_b], run_c); atomicMin(&base_s[run_b], run_base); }
+                run_b = b; run_c = 0; run_base = cum;
+            }
+            run_c += c;
+        }
         cum += c;
     }
+    if (run_c) { atomicAdd(&hist_s[run_b], run_c); atomicMin(&base_s[run_b], run_base); }
     __syncthreads();
     for (int b = t; b < nbcap; b += 1024) {
         hist[(size_t)u * nbcap + b] = hist_s[b];
@@ -1390,7 +1423,7 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
                      size_t cl_ld, int cl_by_test, int* left) -> int {
         const size_t per_test = (size_t)NBX * 4 + (mode == 1 ? WX_NC0 * 4 : 0) + 7 * 4 + 16;
         pin[0] = -1;
-        const size_t blds = (size_t)NBX * 8;
+        const size_t blds = ((size_t)NBX + 1024) * 8;
         if (blds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
         for (int lo = 0; lo < nact_host;) {
             const WxLevel g = wx_level(nt, A, nact_host - lo, NBX, per_test, bc_bytes);
@@ -1405,7 +1438,7 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
             if (sharded) ABC_TRY(abc_comm_all_reduce(ctx, totals, ne, ABC_DT_I64));
             hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)g.nslots), dim3(1024), blds, st, NBX, g.nslots, act, nact_p, lo, (const unsigned long long*)totals,
                                nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const int*)astar, (int)P, (const int*)segbase,
-                               act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0);
+                               act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0, model, (int)M, (int)A);
             ABC_HIP(ctx, hipGetLastError());
             lo += g.nslots;
         }
@@ -1490,7 +1523,8 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
             ABC_HIP(ctx, hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3);
+    if (exact)          // (else: the last bounds kernel has written the component counts itself)
+        hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3);
     ABC_HIP(ctx, hipGetLastError());
     *fail_host = 0;
     if (exact) {

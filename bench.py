@@ -65,7 +65,7 @@ def pmc_traffic(kernel_prefix, config, world):
     written by scripts/summarize_profiles.py); only for the exact single-GPU configuration profiled, else None"""
     if world != 1:
         return None
-    for name in ("r04_pmc_hbm_traffic.json", "history/r03_pmc_hbm_traffic.json"):
+    for name in ("r05_pmc_hbm_traffic.json", "history/r04_pmc_hbm_traffic.json", "history/r03_pmc_hbm_traffic.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(prof):
             continue

@@ -23,11 +23,16 @@ for c in 2 3 5; do
 done
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_c4" -o runc --output-format csv -- \
     python3 "$ROOT/bench.py" --config 4 --steps 3 --warmup 1 --no-cpu-baseline --no-extra) > "$OUT/prof_c4.log" 2>&1
-# the same generations under the Wilcoxon component rule (the k_wx_* kernels; configs[2] and configs[4])
+# (round 5: the timed region runs the drop-in's default rule, the Wilcoxon reduction -- the k_wx_* kernels are in prof_c*)
+# the same generations under plain argmin PRESS (configs[2] and configs[4])
 for c in 3 5; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_w$c" -o runc --output-format csv -- \
-      python3 "$ROOT/bench.py" --config $c --rule wilcoxon --steps 5 --warmup 2 --no-cpu-baseline --no-extra) > "$OUT/prof_w$c.log" 2>&1
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_p$c" -o runc --output-format csv -- \
+      python3 "$ROOT/bench.py" --config $c --rule press --steps 5 --warmup 2 --no-cpu-baseline --no-extra) > "$OUT/prof_p$c.log" 2>&1
 done
+# how the cascade settled the tests at the three column shapes (ABC_WX_DEBUG; not under the profiler: the report synchronises)
+for shape in "1000000 32 16 8" "1000000 128 16 32" "10000000 64 32 8"; do
+  ABC_DIAG=1 ABC_WX_DEBUG=1 python3 scripts/wx_time.py $shape 3 dbg 2>&1 | grep -E "WX_DEBUG|ranking" | sort | uniq -c | sort -rn | head -3
+done > "$OUT/wx_debug.txt" 2>&1
 # the kernel timeline of one generation (configs[2], weighted and first set)
 for m in full set0; do
   (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/trace_$m" -o t --output-format csv -- python3 "$ROOT/scripts/trace_step.py" 3 $m 5) > "$OUT/trace_$m.log" 2>&1

@@ -210,47 +210,51 @@ for c, sfx in ((4, ''), (5, ''), (5, 'f')):
     if ents:
         roof.setdefault("config%d" % c, {})["roofline_mfma" + ("_fp64gram" if sfx else "")] = ents
 
-# ---- the Wilcoxon rule's kernels: algorithmic bytes and achieved GB/s --------------------------------
+# ---- the Wilcoxon rule's kernels: the cascade of round 5 (the timed region's default rule: prof_c*) ---------------------------------
 for c in cfgs:
-    dw = G + '%s_w%d' % (sp, c)
-    if not os.path.isdir(dw):
-        continue
-    shutil.copy(find(dw, 'kernel_stats.csv'), 'profiles/%s_kernel_stats_config%d_wilcoxon.csv' % (tag, c))
+    dp = G + '%s_p%d' % (sp, c)
+    if os.path.isdir(dp):
+        shutil.copy(find(dp, 'kernel_stats.csv'), 'profiles/%s_kernel_stats_config%d_press.csv' % (tag, c))
     b = bench(c)
-    ex, cfgd = b.get("extra", {}), b["config"]
-    if "wilcoxon_tests" not in ex:
+    ex, cfgd = b.get("extra") or {}, b["config"]
+    if cfgd.get("pls_component_rule") != "wilcoxon":
         continue
-    T, nv, M, P, A = ex["wilcoxon_tests"], ex["wilcoxon_validation_rows"], cfgd["metrics"], cfgd["params"], cfgd["pls_components"]
-    stw = {short(r['Name']): (int(r['Calls']), float(r['AverageNs'])) for r in csv.DictReader(open(find(dw, 'kernel_stats.csv')))}
+    stw = stats(c)
+    if not any(k.startswith('k_wx_decide') for k in stw):
+        continue
+    nv, M, P, A = cfgd["particles_per_gpu"] - int(round(cfgd["particles_per_gpu"] * cfgd["train_fraction"])), cfgd["metrics"], cfgd["params"], cfgd["pls_components"]
+    T = ex.get("wilcoxon_tests")
     gens = max(v[0] for k, v in stw.items() if k.startswith('k_wx_decide'))
-    # (the bounds sweep settles most tests: the counting / placing / ranking launches behind it only work on the undecided ones, so
-    # no byte count is attached to them; the bounds sweep reads scores and responses once and is bound by its per-key work: keys/s)
-    alg = {'k_wx_scores': 8.0 * nv * (M + A), 'k_wx_bin<.., 2>': 8.0 * nv * (A + P)}
     rows, tot_ns = [], 0.0
     for k, (calls, ns) in sorted(stw.items()):
         if not k.startswith('k_wx_'):
             continue
         per_gen = calls / gens
-        tot_ns += ns * per_gen
-        key = k.split('<')[0]
-        if key == 'k_wx_bin':
-            key = 'k_wx_bin<.., %s>' % k.rstrip('>').split(',')[-1].strip()
-        a = alg.get(key)
+        tot_ns += ns * calls / gens
+        a, kps = None, None
+        if k.startswith('k_wx_sweep') and k.rstrip('>').endswith(', 0'):          # level 0: every test's keys once
+            a = 8.0 * nv * (A + P)
+            kps = round(T * nv / (ns * 1e-9), -6) if T else None
         rows.append({"kernel": k, "launches_per_generation": per_gen, "avg_us": round(ns / 1e3, 2), "algorithmic_bytes": a,
-                     "achieved_GBs": round(a / ns, 1) if a else None, "frac_of_hbm_peak": round(a / ns / HBM_PEAK, 4) if a else None,
-                     "keys_per_s": round(T * nv / (ns * 1e-9), -6) if key == 'k_wx_bin<.., 2>' else None})
+                     "achieved_GBs": round(a / ns, 1) if a else None, "frac_of_hbm_peak": round(a / ns / HBM_PEAK, 4) if a else None, "keys_per_s": kps})
+    # the scores of the validation rows come from the projection's kernels (half the rows of the projection proper): their launches with the
+    # shorter duration
     total_alg = 8.0 * nv * (M + A) + 8.0 * nv * (A + P)
     roof.setdefault("config%d" % c, {})["wilcoxon_rule"] = {
-        "tests": T, "validation_rows": nv, "kernels": rows, "kernel_us_per_generation": round(tot_ns / 1e3, 1),
-        "algorithmic_bytes_per_generation": total_alg, "achieved_GBs": round(total_alg / tot_ns, 1), "frac_of_hbm_peak": round(total_alg / tot_ns / HBM_PEAK, 4),
-        "bench": {k: v for k, v in ex.items() if 'wilcoxon' in k or k == 'ranking_pls_ms'},
+        "tests": T, "validation_rows": nv, "kernels": rows, "k_wx_kernel_us_per_generation": round(tot_ns / 1e3, 1),
+        "algorithmic_bytes_per_generation": total_alg,
+        "rule_ms": round(b["ms_per_step"] - ex["min_press_rule_step_ms"], 4) if "min_press_rule_step_ms" in ex else None,
+        "bench": {k: v for k, v in ex.items() if 'wilcoxon' in k or 'min_press' in k or k == 'ranking_pls_ms'},
         "note": "algorithmic bytes: the validation rows' metrics read once for the scores (8 nv (M + A) with the scores' write), scores and responses "
-                "read once by the bounds sweep (8 nv (A + P)); the exact sweeps behind it (a key written once and read once per undecided test) "
-                "carry no byte count: how many tests stay undecided is data"}
+                "read once by the level-0 sweep (8 nv (A + P)); the fine levels and the exact step only touch the tests level 0 leaves undecided "
+                "(how many: data; gpurun wx_debug.txt / profiles/%s_wx_debug.txt).  rule_ms = the timed step minus the argmin-PRESS step of the same run "
+                "(kernels + the host's looks at the level counts)" % tag}
     with open('profiles/%s_wilcoxon_kernels_config%d.csv' % (tag, c), 'w') as f:
         f.write("kernel,launches_per_generation,avg_us,algorithmic_bytes,achieved_GBs,frac_of_hbm_peak,keys_per_s\n")
         for r in rows:
             f.write('"%s",%g,%.2f,%s,%s,%s,%s\n' % (r["kernel"], r["launches_per_generation"], r["avg_us"], r["algorithmic_bytes"], r["achieved_GBs"], r["frac_of_hbm_peak"], r["keys_per_s"]))
+if os.path.exists(G + 'wx_debug.txt'):
+    shutil.copy(G + 'wx_debug.txt', 'profiles/%s_wx_debug.txt' % tag)
 json.dump(roof, open('profiles/%s_roofline.json' % tag, 'w'), indent=1)
 for c in cfgs:
     e = roof["config%d" % c]

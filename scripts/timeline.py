@@ -1,7 +1,8 @@
 """Timeline of the last complete generation in a rocprofv3 kernel trace (CSV): per-kernel start offset, duration and the gap
 to the previous kernel's end (negative: it overlaps work on another stream).
     python scripts/timeline.py <..._kernel_trace.csv>
-A generation has exactly one projection kernel (k_project_dist* / k_simple_dist); it starts at the k_pilot_shift before it."""
+A generation has exactly one model fit (k_pls_fit*; k_simple_dist for FILTER::SIMPLE) -- the projection kernels also run for the
+Wilcoxon rule's scores since round 5 --; it starts at the k_pilot_shift before it."""
 import csv
 import sys
 
@@ -14,7 +15,7 @@ def short(n):
     return n.split("(")[0][:44]
 
 
-marks = [i for i, r in enumerate(rows) if "k_project_dist" in r["Kernel_Name"] or "k_simple_dist" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_pls_fit" in r["Kernel_Name"] or "k_simple_dist" in r["Kernel_Name"]]
 if len(marks) < 2:
     sys.exit("fewer than two generations in the trace")
 

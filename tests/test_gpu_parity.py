@@ -1834,6 +1834,27 @@ def test_generation_config5_size_wilcoxon_rule(gpu_ctx, oracle):
                                 device_inputs=True, rule=_lib.RULE_WILCOXON)
 
 
+def test_generation_config2_size_against_the_full_oracle(gpu_ctx, oracle):
+    """BASELINE configs[1] (1e5 particles x 16 parameters x 32 metrics, 8 components; K = K' = 1e4) against the COMPLETE oracle
+    generation under the drop-in's default rule -- at this size the oracle's O(K K' P) weight stage is affordable (1.6e9 density
+    evaluations, ~20 s on one core), so nothing is sampled: component count, all K selection indices and all N_next parents bit for
+    bit, every weight to 1e-6 relative, doubled variances, posterior rows"""
+    from abcsmc_amd import device
+    N, M, P, K, Kp, Nn, A = 100_000, 32, 16, 10_000, 10_000, 100_000, 8
+    wl, X, Y, obs, spec, prev, gen, r = _run_generation(N, M, P, K, Kp, Nn, A, True)
+    o = oracle.rng(67890)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A, multivariate=True)
+    assert gen.ncomp.value == ref["ncomp"]
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    w = gen.w.cpu().numpy()
+    werr = float(np.max(np.abs(w - ref["w"]) / ref["w"]))
+    print("configs[1] against the full oracle: ncomp %d, largest relative weight error %.2e over all %d weights" % (ref["ncomp"], werr, K))
+    assert werr <= RTOL, werr
+    assert np.allclose(gen.dv.cpu().numpy(), ref["dv"], rtol=1e-9)
+    assert np.array_equal(device.to_numpy(gen.theta), Y[ref["idx"].astype(int)])
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+
+
 def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
     """BASELINE configs[3] at its STATED size under the drop-in's default rule: 1e7 particles x 64 metrics x 32 responses x 8
     components = up to 224 tests over 5e6 validation rows, through the staged entry points on device-generated rows (the model under
