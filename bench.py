@@ -498,17 +498,26 @@ def run_rank(args, env):
                     "achieved_event_bracket": round(gram_bytes / (gram_bracket_ms * 1e-3) / 1e9, 1) if gram_bracket_ms > 0 else 0.0}
 
     # ---- all streaming stages together = the step without the pair-sum kernel ------------------------------
-    def alg_bytes(kp):
+    # Under the Wilcoxon rule the reference's path reads the validation rows once more ("an extra pass over the test rows":
+    # per-observation residuals of every candidate count): + 8 N_v (M + P) bytes, N_v = the rows behind the training fraction.  The
+    # scores this implementation writes and re-reads between its kernels are NOT algorithmic bytes.
+    nv_loc = (n_loc - int(round(n_loc * 0.5))) if RULE == _lib.RULE_WILCOXON else 0
+
+    def alg_bytes(kp, rule_pass=True):
         nn, k = nn_loc, K
         return (8.0 * n_loc * (M + P) + 8.0 * n_loc * M + 8.0 * n_loc + 16.0 * n_loc + 16.0 * k * P + nn * (16.0 * P + 8.0)
-                + 8.0 * kp * P + 8.0 * (k + kp))
+                + 8.0 * kp * P + 8.0 * (k + kp) + (8.0 * nv_loc * (M + P) if rule_pass else 0.0))
     stream_ms = ms_per_step - kde_ms * kde_launches
     stream_gbs = alg_bytes(Kp) / (stream_ms * 1e-3) / 1e9
     roofline_streaming = {"bound": "hbm", "algorithmic_bytes_per_step": alg_bytes(Kp), "bytes_per_particle": round(alg_bytes(Kp) / n_loc, 1),
                           "ms": round(stream_ms, 5), "achieved": round(stream_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(stream_gbs / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes_without_the_rules_pass": alg_bytes(Kp, False),
+                          "frac_without_the_rules_pass": round(alg_bytes(Kp, False) / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "SURVEY 8(d): B_alg / (wall time of a step minus the pair-sum kernel), per GPU; host work "
-                                  "(alias table) and launch gaps included"}
+                                  "(alias table) and launch gaps included.  Under the Wilcoxon component rule B_alg carries the rule's "
+                                  "pass over the validation rows, 8 N_v (M + P) bytes (SURVEY A.2); frac_without_the_rules_pass holds the "
+                                  "same time against SURVEY 8(d)'s formula as written (argmin PRESS from sufficient statistics)"}
 
     # set 0 (uniform weights, AbcUtil.cpp:539-545) has no O(K K') stage: reported separately, outside the timed region
     set0 = None
