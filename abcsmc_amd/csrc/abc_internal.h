@@ -54,6 +54,8 @@ struct abc_ctx {
     // side stream of the fused drivers: the two taus2 streams of a generation (draws, seeds) depend on the rng state alone and
     // run there from the first launch on, beside the ranking chain (abc_rng_streams_early); ev_fork / ev_side order them
     hipStream_t side;
+    hipStream_t wx_stream;             // the Wilcoxon reduction of a fused generation, beside the ranking that speculates on its outcome
+    hipEvent_t ev_wx_fork, ev_wx_done;
     hipEvent_t ev_fork, ev_side, ev_prev;
     hipEvent_t ev_theta, ev_moments;   // the posterior's moments on the side stream: start (rows gathered) and end
     bool side_forked;      // ev_fork of the current generation is recorded (abc_side_fork); cleared when the generation ends
@@ -264,8 +266,14 @@ struct abc_wx_shard {
     size_t nv_stride;
 };
 bool abc_wx_cascade_applies(size_t nv_total, size_t P, size_t A);
+// dec / changed_host (the fused generation's SPECULATIVE run, api.hip): with dec != NULL the cascade leaves the model record as the
+// fit wrote it and puts its decision into dec (P per-response counts, then the largest); *changed_host = 0: the largest count is
+// the fit's (everything ranked with it stands), 1: it differs (launch_wilcoxon_commit, rank again), 2: the reduction took a path
+// that rewrote the model record itself (small sets, the sorted-path repeat): rank again.
 int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
-                    size_t A, size_t row_test, double* model, const abc_wx_shard* sh = nullptr);
+                    size_t A, size_t row_test, double* model, const abc_wx_shard* sh = nullptr, double* dec = nullptr,
+                    int* changed_host = nullptr);
+int launch_wilcoxon_commit(abc_ctx*, double* model, size_t M, size_t P, size_t A, const double* dec, int with_hdr);
 // collectives on the context's stream and the exchange buffer (sharded.hip)
 int abc_comm_all_reduce(abc_ctx* ctx, void* buf, size_t count, int dtype);
 int abc_comm_all_gather(abc_ctx* ctx, const void* send, void* recv, size_t bytes);

@@ -108,6 +108,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_theta) { (void)hipEventDestroy(ctx->ev_theta); (void)hipEventDestroy(ctx->ev_moments); }
+    if (ctx->wx_stream) { (void)hipStreamSynchronize(ctx->wx_stream); (void)hipStreamDestroy(ctx->wx_stream); (void)hipEventDestroy(ctx->ev_wx_fork); (void)hipEventDestroy(ctx->ev_wx_done); }
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_side); if (ctx->ev_prev) (void)hipEventDestroy(ctx->ev_prev); }
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -562,7 +563,29 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // at the cascade's level counts between its launches, and whatever it has not queued by then waits for those looks -- queued
     // in front (rounds 1-4), the previous set's prologue and the taus2 streams started only after the reduction and the host's
     // ~90 us of enqueueing them showed as a bubble in front of the projection (rocprofv3 timeline, profiles/r05_timeline_*)
-    if (!simple && cfg->rule == ABC_RULE_WILCOXON)
+    // SPECULATION (round 5, second half): the ranking does not wait for the reduction.  The reduction can only LOWER the component
+    // count of a response, and the count the distances use is the largest over the responses -- unchanged unless every response
+    // that holds the maximum is reduced.  So projection, selection and gather are queued at once on the counts the fit wrote, the
+    // cascade runs beside them on a stream of its own (it reads the model record, its decision goes to a buffer of its own), and
+    // when the host has its result -- the ranking's kernels are long done by then -- either nothing has changed (the usual case:
+    // the per-response counts are committed, the generation goes on) or the decision is committed and the three stages run again.
+    // Whole generations on sets the cascade takes only (ranking-only calls and small sets: in stream order, as before).
+    static const int wx_inline = abc_diag_env("ABC_WX_INLINE") ? 1 : 0;                  // A/B switch for measurements
+    const bool wx_rule = !simple && cfg->rule == ABC_RULE_WILCOXON;
+    const size_t nvalid = N > (size_t)ntrain ? N - (size_t)ntrain : 0;
+    const bool wx_spec = wx_rule && io->w && K && !wx_inline && abc_wx_cascade_applies(nvalid, P, A);
+    double* wx_dec = nullptr;
+    if (wx_spec) {
+        if (!ctx->wx_stream) {
+            ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_fork, abc_xstream_event_flags()));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_done, abc_xstream_event_flags()));
+        }
+        wx_dec = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
+        if (!wx_dec) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
+        ABC_HIP(ctx, hipEventRecord(ctx->ev_wx_fork, ctx->stream));                     // (behind the model fit)
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, ctx->ev_wx_fork, 0));
+    } else if (wx_rule)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
@@ -589,7 +612,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     hdr_pin[0] = 0.0; *spd_pin = 0;
     bool status_early = false;
     static const int status_late = abc_diag_env("ABC_STATUS_KERNEL") ? 1 : 0;           // A/B switch for measurements
-    const bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
+    bool bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
     // The main stream needs what the side stream queued early (the previous set's tiles, the taus2 outputs) only behind the
     // gather, and those kernels ended long ago: the wait goes IN FRONT of the gather, where the event is certain to have fired
     // (a wait that still has to be resolved between the gather and the new set's tiles cost ~12 us of the critical path there)
@@ -612,6 +635,36 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const bool theta_ev_bound = moments_side_planned && !ev_marker;
     ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
                                theta_ev_bound ? ctx->ev_theta : nullptr));
+    if (wx_spec) {
+        // the reduction itself, on its own stream, while the ranking queued above runs (the host's looks at the cascade's level
+        // counts happen here, beside GPU work that does not depend on them)
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->wx_stream;
+        int changed = 2;
+        int rc = launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, nullptr, wx_dec, &changed);
+        if (rc == ABC_OK && hipEventRecord(ctx->ev_wx_done, ctx->wx_stream) != hipSuccess) rc = ABC_ERR_HIP;
+        ctx->stream = main_stream;
+        if (rc == ABC_INTERNAL_RETRY) {          // a bin of its exact step outgrew LDS (massive ties): once more in stream order, on the sorted path
+            ABC_HIP(ctx, hipStreamSynchronize(ctx->wx_stream));
+            ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            rc = launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model);
+            changed = 2;
+        }
+        if (rc != ABC_OK) { if (!ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "generation: the component rule's reduction failed"); return rc; }
+        if (changed != 2) {
+            ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wx_done, 0));
+            ABC_TRY(launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, changed == 1));
+        }
+        if (changed) {                           // the largest count moved: the ranking once more, with it
+            ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            *pfail_early = 0;
+            ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, P, A, model, 0, dist));
+            ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/true));
+            bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
+            ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
+                                       theta_ev_bound ? ctx->ev_theta : nullptr));
+        }
+    }
     // A failed bin selection (degenerate distances) leaves placeholder winners: everything downstream of it is repeated with
     // the radix select.  Weighted generations learn of it at the host's wait for the weights (launch_resample's abort flag),
     // before the alias table, the draws and the proposals of the placeholder are queued; set 0 has no host wait before its

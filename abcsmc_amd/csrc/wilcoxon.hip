@@ -560,7 +560,8 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
                                                     int* __restrict__ act_next, int* __restrict__ nact_next,
                                                     const double* __restrict__ nv_ranks, size_t nv_stride, int Wr, int* __restrict__ pin_words,
                                                     int force_undecided /* diagnostic: every test with keys stays undecided */,
-                                                    double* __restrict__ model, int M, int A) {
+                                                    double* __restrict__ model, int M, int A, double* __restrict__ dec,
+                                                    const double* __restrict__ per_keep) {
     extern __shared__ unsigned int wxb_cp[];              // [NBX] packed (all keys, positive keys) of the test's bins
     __shared__ long long red[3][16];
     __shared__ unsigned long long wtot[16];
@@ -676,21 +677,28 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     // Nothing left: every test is settled by its bounds, and the component counts follow from the verdicts alone -- written here
     // (k_wx_decide's rule: per response the first candidate that passes, else the PRESS optimum; the largest over the responses),
     // and the host, which sees `0`, does not launch that kernel: its launch behind the host's look was 20 us of the critical path
+    // (dec != NULL -- the fused generation's speculative run, api.hip: the counts go to dec[0 .. P - 1], the largest to dec[P], and the
+    // model record keeps what the fit wrote; pin_words[3] / [4]: the final count, and whether it differs from the fit's)
+    __shared__ int s_nc;
+    if (t == 0) s_nc = 1;
+    __syncthreads();
     if (total == 0 && model) {
-        __shared__ int s_nc;
-        if (t == 0) s_nc = 1;
-        __syncthreads();
         const ModelLayout ML = model_layout(M, P, A);
+        double* per_out = dec ? dec : model + ML.off_per;
         for (int j = t; j < P; j += 1024) {
             const int b0 = segbase[j], as = astar[j];
             int best = as;
             for (int i = 0; i + 1 < as; i++)
                 if (v3v[b0 + i] == 1) { best = i + 1; break; }
-            model[ML.off_per + j] = (double)best;
+            per_out[j] = (double)best;
             atomicMax(&s_nc, best);
         }
         __syncthreads();
-        if (t == 0) model[ML.off_hdr] = (double)s_nc;
+        if (t == 0) {
+            if (dec) dec[P] = (double)s_nc; else model[ML.off_hdr] = (double)s_nc;
+            __hip_atomic_store(&pin_words[3], s_nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&pin_words[4], (per_keep && s_nc != (int)per_keep[P]) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (t == 0) {
         *nact_next = total;
@@ -1113,7 +1121,8 @@ __device__ double normalcdf_poly(double z) {        // [PLS] normalcdf, Abramowi
 // responses (single-threaded it was 50 us of square roots and divisions in a row at 112 tests)
 __global__ void k_wx_decide(double* __restrict__ model, int M, int P, int A, const WxPlan* __restrict__ plan,
                             const unsigned long long* __restrict__ nz, const double* __restrict__ W, unsigned char* __restrict__ pass,
-                            const int* __restrict__ v3) {
+                            const int* __restrict__ v3, double* __restrict__ dec = nullptr, const double* __restrict__ per_keep = nullptr,
+                            int* __restrict__ pin_words = nullptr) {
     const int nseg = plan->nseg;
     auto verdict = [&](int s) -> bool {
         if (v3 && v3[s] != 2) return v3[s] == 1;           // settled by the bounds (k_wx_bounds): the exact sum was never taken
@@ -1142,11 +1151,24 @@ __global__ void k_wx_decide(double* __restrict__ model, int M, int P, int A, con
             if (s >= nseg) break;
             if (pass ? pass[s] != 0 : verdict(s)) { best = a; break; }
         }
-        model[ML.off_per + j] = (double)best;
+        if (dec) dec[j] = (double)best; else model[ML.off_per + j] = (double)best;
         atomicMax(&s_ncomp, best);
     }
     __syncthreads();
-    if (threadIdx.x == 0) model[ML.off_hdr] = (double)s_ncomp;
+    if (threadIdx.x == 0) {
+        if (dec) dec[P] = (double)s_ncomp; else model[ML.off_hdr] = (double)s_ncomp;
+        if (pin_words) {
+            __hip_atomic_store(&pin_words[3], s_ncomp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&pin_words[4], (per_keep && s_ncomp != (int)per_keep[P]) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// the speculative run's decision (dec: P counts, then the largest) into the model record
+__global__ void k_wx_commit(double* __restrict__ model, int M, int P, int A, const double* __restrict__ dec, int with_hdr) {
+    const ModelLayout ML = model_layout(M, P, A);
+    for (int j = threadIdx.x; j < P; j += blockDim.x) model[ML.off_per + j] = dec[j];
+    if (threadIdx.x == 0 && with_hdr) model[ML.off_hdr] = dec[P];
 }
 
 
@@ -1377,7 +1399,8 @@ static void wx_scores(abc_ctx* ctx, const double* X, size_t ldx, size_t row_test
 
 // The cascade.  *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
 static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* Y, size_t nt, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
-                                   size_t row_test, double* model, const abc_wx_shard* sh, int* fail_host, double* per_keep) {
+                                   size_t row_test, double* model, const abc_wx_shard* sh, int* fail_host, double* per_keep, double* dec,
+                                   int* changed_host) {
     const int Wr = (sh && ctx->comm_kind) ? ctx->comm_world : 1;
     const bool sharded = Wr > 1;
     const size_t nvt = sh ? sh->nv_total : nt, nseg_max = P * (A - 1);
@@ -1438,7 +1461,8 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
             if (sharded) ABC_TRY(abc_comm_all_reduce(ctx, totals, ne, ABC_DT_I64));
             hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)g.nslots), dim3(1024), blds, st, NBX, g.nslots, act, nact_p, lo, (const unsigned long long*)totals,
                                nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const int*)astar, (int)P, (const int*)segbase,
-                               act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0, model, (int)M, (int)A);
+                               act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0, model, (int)M, (int)A, dec,
+                               (const double*)per_keep);
             ABC_HIP(ctx, hipGetLastError());
             lo += g.nslots;
         }
@@ -1524,7 +1548,8 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
         }
     }
     if (exact)          // (else: the last bounds kernel has written the component counts itself)
-        hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3);
+        hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3, dec,
+                           (const double*)per_keep, (int*)pin);
     ABC_HIP(ctx, hipGetLastError());
     *fail_host = 0;
     if (exact) {
@@ -1533,6 +1558,7 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
         ABC_HIP(ctx, hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, st));
         ABC_HIP(ctx, hipStreamSynchronize(st));
     }
+    if (changed_host) *changed_host = pin[4];          // (visible: written in front of the word the last wait / the synchronisation saw)
     if (abc_diag_env("ABC_WX_DEBUG")) {          // (diagnostic: how the tests were settled)
         std::vector<int> hv(nseg_max);
         WxPlan hp;
@@ -1547,7 +1573,8 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
 }
 
 int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
-                    size_t P, size_t A, size_t row_test, double* model, const abc_wx_shard* sh) {
+                    size_t P, size_t A, size_t row_test, double* model, const abc_wx_shard* sh, double* dec, int* changed_host) {
+    if (changed_host) *changed_host = 2;                 // (2: the model record itself was rewritten -- any path but the cascade's own end)
     const size_t nt = n > row_test ? n - row_test : 0;   // validation rows here
     const size_t nvt = sh ? sh->nv_total : nt;           // ... and over all ranks
     if (nvt == 0) return ABC_OK;                         // empty validation set: nothing to reduce
@@ -1561,9 +1588,11 @@ int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, si
         int failed = 0;
         double* per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!per_keep) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
-        ABC_TRY(launch_wilcoxon_cascade(ctx, X, Y, nt, ldx, ldy, M, P, A, row_test, model, sh, &failed, per_keep));     // (its plan kernel makes the copy)
+        int changed = 2;
+        ABC_TRY(launch_wilcoxon_cascade(ctx, X, Y, nt, ldx, ldy, M, P, A, row_test, model, sh, &failed, per_keep, dec, &changed));     // (its plan kernel makes the copy)
         static const bool force_fail = abc_diag_env("ABC_WX_FORCE_FAIL") != nullptr;   // tests: exercise the repeat
-        if (!failed && !force_fail) return ABC_OK;
+        if (!failed && !force_fail) { if (changed_host && dec) *changed_host = changed; return ABC_OK; }
+        if (dec) return ABC_INTERNAL_RETRY;      // (a speculative run: the model record is as the fit left it; the caller runs the reduction again, by itself)
         ABC_HIP(ctx, hipMemcpyAsync(model + ML.off_per, per_keep, P * 8, hipMemcpyDeviceToDevice, ctx->stream));
         ABC_HIP(ctx, hipMemcpyAsync(model + ML.off_hdr, per_keep + P, 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (sh) return ABC_INTERNAL_RETRY;       // (row shards: the caller gathers the validation rows and calls again without `sh`)
@@ -1583,4 +1612,11 @@ int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, si
     }
     if (sh) return ABC_INTERNAL_RETRY;           // small sets: the caller gathers the rows
     return launch_wilcoxon_sorted(ctx, X, Y, n, ldx, ldy, M, P, A, row_test, model);
+}
+
+// the decision of a speculative run (launch_wilcoxon with dec) into the model record, on the context's stream
+int launch_wilcoxon_commit(abc_ctx* ctx, double* model, size_t M, size_t P, size_t A, const double* dec, int with_hdr) {
+    hipLaunchKernelGGL(k_wx_commit, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, dec, with_hdr);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
 }

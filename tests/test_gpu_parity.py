@@ -1855,6 +1855,39 @@ def test_generation_config2_size_against_the_full_oracle(gpu_ctx, oracle):
     assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
 
 
+@pytest.mark.parametrize("M,P,A,noise,Kp", [(20, 5, 10, 2.0, 500), (16, 3, 8, 1.5, 0), (16, 6, 8, 0.0, 500)])
+def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, noise, Kp):
+    """Whole generations on sets the Wilcoxon cascade takes run the ranking BESIDE the reduction, on the component count the fit wrote
+    (api.hip, round 5): with noisy responses the reduction lowers the largest count and projection, selection and gather run once
+    more with it; with clean ones it stands.  Either way every output equals the oracle's generation under the rule -- weighted and
+    first set -- and the count equals the oracle's, which in the noisy cases is below the argmin-PRESS count (checked: the
+    speculation is wrong there and has to be repaired)."""
+    from abcsmc_amd import _lib, abcutil, device, synthetic
+    N, K, Nn = 60_000, 2_000, 5_000
+    wl = synthetic.Workload(M, P, 4713 if M == 20 else 4711)
+    X, Y = wl.rows(0, N)
+    if noise:
+        Y = np.asfortranarray(Y + np.random.default_rng(7).normal(size=Y.shape) * Y.std(0) * noise)
+    obs, spec = wl.observed(), wl.prior_spec()
+    prev = wl.previous_set(Kp) if Kp else (None, None, None)
+    dev = "cuda:0"
+    gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=_lib.RULE_WILCOXON, multivariate=True, device=dev, ctx=gpu_ctx)
+    r = abcutil.rng(67890)
+    dprev = [device.colmajor(a, dev) for a in prev] if Kp else []
+    gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
+    o = oracle.rng(67890)
+    ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A, rule=oracle.RULE_WILCOXON, multivariate=True)
+    press = oracle.particle_ranking_pls(X, Y, obs, 0.5, A, rule=oracle.RULE_MIN_PRESS)["ncomp"]
+    print("speculation: argmin PRESS keeps %d components, the Wilcoxon rule %d (noise %.1f)" % (press, ref["ncomp"], noise))
+    if noise:
+        assert ref["ncomp"] < press            # (the case the test is for: the count the ranking speculated on is wrong)
+    assert gen.ncomp.value == ref["ncomp"]
+    assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
+    assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
+    assert np.array_equal(device.to_numpy(gen.theta), Y[ref["idx"].astype(int)])
+    assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
+
+
 def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
     """BASELINE configs[3] at its STATED size under the drop-in's default rule: 1e7 particles x 64 metrics x 32 responses x 8
     components = up to 224 tests over 5e6 validation rows, through the staged entry points on device-generated rows (the model under
