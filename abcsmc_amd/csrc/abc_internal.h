@@ -272,8 +272,16 @@ bool abc_wx_cascade_applies(size_t nv_total, size_t P, size_t A);
 // that rewrote the model record itself (small sets, the sorted-path repeat): rank again.
 int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
                     size_t A, size_t row_test, double* model, const abc_wx_shard* sh = nullptr, double* dec = nullptr,
-                    int* changed_host = nullptr);
+                    int* changed_host = nullptr, int stop_at_max = 0);
+// stop_at_max (the generations: their caller only uses the LARGEST per-response count, AbcUtil.cpp:449): the cascade ends as soon as
+// that is certain; the per-response counts it leaves are then upper ends for the responses it did not finish
 int launch_wilcoxon_commit(abc_ctx*, double* model, size_t M, size_t P, size_t A, const double* dec, int with_hdr);
+// the cascade in two halves, for a caller with work to queue between them (the fused generation: api.hip)
+struct abc_wx_run;
+int launch_wilcoxon_begin(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
+                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out);
+int launch_wilcoxon_finish(abc_ctx*, abc_wx_run* run, int* changed_host);
+void launch_wilcoxon_abandon(abc_ctx*, abc_wx_run* run, hipStream_t its_stream);
 // collectives on the context's stream and the exchange buffer (sharded.hip)
 int abc_comm_all_reduce(abc_ctx* ctx, void* buf, size_t count, int dtype);
 int abc_comm_all_gather(abc_ctx* ctx, const void* send, void* recv, size_t bytes);

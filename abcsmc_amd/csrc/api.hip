@@ -575,6 +575,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const size_t nvalid = N > (size_t)ntrain ? N - (size_t)ntrain : 0;
     const bool wx_spec = wx_rule && io->w && K && !wx_inline && abc_wx_cascade_applies(nvalid, P, A);
     double* wx_dec = nullptr;
+    abc_wx_run* wx_run = nullptr;
+    struct WxGuard {          // an error return between the cascade's halves: its kernels still write into this call's arena
+        abc_ctx* c; abc_wx_run** r;
+        ~WxGuard() { if (*r) { launch_wilcoxon_abandon(c, *r, c->wx_stream); *r = nullptr; } }
+    } wx_guard = {ctx, &wx_run};
     if (wx_spec) {
         if (!ctx->wx_stream) {
             ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
@@ -585,6 +590,13 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         if (!wx_dec) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
         ABC_HIP(ctx, hipEventRecord(ctx->ev_wx_fork, ctx->stream));                     // (behind the model fit)
         ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, ctx->ev_wx_fork, 0));
+        // its first half -- plan, scores, the level-0 sweep and bounds -- is queued BEFORE the ranking (the host needs ~60 us to queue
+        // the ranking's eight launches: the cascade started that much late behind them, rocprofv3 timeline)
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->wx_stream;
+        const int rcb = launch_wilcoxon_begin(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, wx_dec, /*stop_at_max=*/1, &wx_run);
+        ctx->stream = main_stream;
+        ABC_TRY(rcb);
     } else if (wx_rule)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
@@ -641,7 +653,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->wx_stream;
         int changed = 2;
-        int rc = launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, nullptr, wx_dec, &changed);
+        int rc = launch_wilcoxon_finish(ctx, wx_run, &changed);
+        wx_run = nullptr;
         if (rc == ABC_OK && hipEventRecord(ctx->ev_wx_done, ctx->wx_stream) != hipSuccess) rc = ABC_ERR_HIP;
         ctx->stream = main_stream;
         if (rc == ABC_INTERNAL_RETRY) {          // a bin of its exact step outgrew LDS (massive ties): once more in stream order, on the sorted path
@@ -697,6 +710,27 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     } else {
         ABC_TRY(launch_doubled_variance(ctx, theta, K, P, dv));
     }
+    bool w_on_host = false;
+    if (Kp == 0 || !io->theta_prev) {
+        if (!filled_early) ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
+    } else {
+        if (wprev.ready && !ctx->side_early_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
+        const double* sumsq = nullptr;       // the normalisation's sum of squares comes out of the weight stage's last kernel
+        ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
+                                   io->w, &wprev, &sumsq));
+        // (with proposals to draw the host builds the alias table of these weights next: the normalisation kernel stores them
+        // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
+        double* mirror = nullptr;
+        const bool alias_on_device = ctx->alias_mode == ABC_ALIAS_DEVICE && K >= ABC_ALIAS_DEV_MIN_K && K <= ABC_ALIAS_DEV_MAX_K;
+        if (Nn && !alias_on_device) {          // (the device build reads the weights where they are)
+            ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
+            mirror = (double*)ctx->pin;
+        }
+        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror, sumsq));           // AbcUtil.cpp:583
+        w_on_host = mirror != nullptr;
+    }
+    // (queued BEHIND the weight stage's launches since round 5: with the ranking speculating beside the Wilcoxon cascade the host
+    // arrives here late, and the side stream's four launches in front of them delayed the pair sums by their enqueue time)
     // The posterior's moments and what follows from them (doubled variance, proposal factor, the perturbation's row-major copy
     // and padded factor) need the gathered rows only: with the resampling table built on the device nothing waits for the host
     // any more, so they run on the SIDE stream from here on, beside the weight stage, and are long done when the proposals need
@@ -728,25 +762,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_HIP(ctx, hipEventRecord(ctx->ev_moments, ctx->side));
         theta_stats = st;
         moments_on_side = true;
-    }
-    bool w_on_host = false;
-    if (Kp == 0 || !io->theta_prev) {
-        if (!filled_early) ABC_TRY(launch_fill(ctx, io->w, K, 1.0 / (double)K));                 // AbcUtil.cpp:543-544
-    } else {
-        if (wprev.ready && !ctx->side_early_waited) ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prev, 0));
-        const double* sumsq = nullptr;       // the normalisation's sum of squares comes out of the weight stage's last kernel
-        ABC_TRY(launch_weights_raw(ctx, io->priors, theta, K, P, 0, K, io->theta_prev, Kp, io->w_prev, io->dv_prev,
-                                   io->w, &wprev, &sumsq));
-        // (with proposals to draw the host builds the alias table of these weights next: the normalisation kernel stores them
-        // into the pinned scratch as it writes them -- launch_resample then has nothing to copy)
-        double* mirror = nullptr;
-        const bool alias_on_device = ctx->alias_mode == ABC_ALIAS_DEVICE && K >= ABC_ALIAS_DEV_MIN_K && K <= ABC_ALIAS_DEV_MAX_K;
-        if (Nn && !alias_on_device) {          // (the device build reads the weights where they are)
-            ABC_TRY(abc_pin_reserve(ctx, abc_alias_pin_bytes(K)));
-            mirror = (double*)ctx->pin;
-        }
-        ABC_TRY(launch_normalize_l2(ctx, io->w, K, mirror, sumsq));           // AbcUtil.cpp:583
-        w_on_host = mirror != nullptr;
     }
     int spd = 0;
     bool have_spd = false;

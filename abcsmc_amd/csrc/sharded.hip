@@ -532,7 +532,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
         if (NvT && abc_wx_cascade_applies(NvT, P, A) && !ctx->wx_gather_rows) {
             const abc_wx_shard sh = {NvT, stats_all + SL.off_n + 1, SL.len};
-            wx_rc = launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, wx_v0, model, &sh);
+            wx_rc = launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, wx_v0, model, &sh, nullptr, nullptr, /*stop_at_max=*/1);
             if (wx_rc != ABC_OK && wx_rc != ABC_INTERNAL_RETRY) return wx_rc;
         }
     }

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
                                                     const double* __restrict__ nv_ranks, size_t nv_stride, int Wr, int* __restrict__ pin_words,
                                                     int force_undecided /* diagnostic: every test with keys stays undecided */,
                                                     double* __restrict__ model, int M, int A, double* __restrict__ dec,
-                                                    const double* __restrict__ per_keep) {
+                                                    const double* __restrict__ per_keep, int stop_at_max) {
     extern __shared__ unsigned int wxb_cp[];              // [NBX] packed (all keys, positive keys) of the test's bins
     __shared__ long long red[3][16];
     __shared__ unsigned long long wtot[16];
@@ -643,22 +643,34 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     // a response per thread: its verdicts (<= 31 independent loads), the tests still needed = the undecided ones in front of its
     // first pass; their places by a scan over the responses (test order = response order).  (A thread per test that walked back to
     // the response's first test was up to 31 dependent loads in a row: 15-20 us of every level.)
+    // Beside them, per response, the RANGE its final count can still take: the first passing candidate in front of any undecided one
+    // is the count; an undecided candidate u in front of every pass leaves [u, first pass behind it (or a*)].  The caller of the
+    // fused generations only uses the LARGEST count over the responses (AbcUtil.cpp:449: `.maxCoeff()`), so with stop_at_max the
+    // cascade ends as soon as the ranges' lower and upper ends have the same maximum -- at 1e6 x 32 x 16 x 8 after level 0, with one
+    // test of 112 still open: its response cannot exceed the 8 components fifteen others keep for certain.
     __shared__ int wsum[16];
-    __shared__ int s_run;
-    if (t == 0) s_run = 0;
+    __shared__ int s_run, s_lo, s_hi;
+    if (t == 0) { s_run = 0; s_lo = 1; s_hi = 1; }
     __syncthreads();
     const volatile int* v3v = v3;
+    const ModelLayout MLd = model_layout(M, P, A);
+    double* per_out = model ? (dec ? dec : model + MLd.off_per) : nullptr;
     for (int j0 = 0; j0 < P; j0 += 1024) {
         const int j = j0 + t;
         unsigned int need = 0;
         int b0 = 0;
         if (j < P) {
             b0 = segbase[j];
-            const int n = astar[j] - 1;
+            const int as = astar[j], n = as - 1;
             unsigned int und = 0, pas = 0;
 #pragma unroll 8
             for (int i = 0; i < n; i++) { const int v = v3v[b0 + i]; und |= (v == 2 ? 1u : 0u) << i; pas |= (v == 1 ? 1u : 0u) << i; }
             need = pas ? (und & ((pas & (0u - pas)) - 1u)) : und;
+            const int fp = pas ? __ffs((int)pas) : n + 1, fu = need ? __ffs((int)need) : n + 1;      // 1-based candidates; n + 1: none (the count stays a*)
+            const int hi = fp, lo = fu < fp ? fu : fp;
+            atomicMax(&s_lo, lo);
+            atomicMax(&s_hi, hi);
+            if (per_out) per_out[j] = (double)hi;            // (exact once nothing of the response is open; an upper end until then)
         }
         const int mine = __popc(need);
         int inc = mine;
@@ -673,32 +685,18 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
         if (t == 0) { int tot = s_run; for (int w = 0; w < 16; w++) tot += wsum[w]; s_run = tot; }
         __syncthreads();
     }
-    const int total = s_run;
-    // Nothing left: every test is settled by its bounds, and the component counts follow from the verdicts alone -- written here
-    // (k_wx_decide's rule: per response the first candidate that passes, else the PRESS optimum; the largest over the responses),
-    // and the host, which sees `0`, does not launch that kernel: its launch behind the host's look was 20 us of the critical path
-    // (dec != NULL -- the fused generation's speculative run, api.hip: the counts go to dec[0 .. P - 1], the largest to dec[P], and the
-    // model record keeps what the fit wrote; pin_words[3] / [4]: the final count, and whether it differs from the fit's)
-    __shared__ int s_nc;
-    if (t == 0) s_nc = 1;
-    __syncthreads();
-    if (total == 0 && model) {
-        const ModelLayout ML = model_layout(M, P, A);
-        double* per_out = dec ? dec : model + ML.off_per;
-        for (int j = t; j < P; j += 1024) {
-            const int b0 = segbase[j], as = astar[j];
-            int best = as;
-            for (int i = 0; i + 1 < as; i++)
-                if (v3v[b0 + i] == 1) { best = i + 1; break; }
-            per_out[j] = (double)best;
-            atomicMax(&s_nc, best);
-        }
-        __syncthreads();
-        if (t == 0) {
-            if (dec) dec[P] = (double)s_nc; else model[ML.off_hdr] = (double)s_nc;
-            __hip_atomic_store(&pin_words[3], s_nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&pin_words[4], (per_keep && s_nc != (int)per_keep[P]) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    // Decided -- nothing left, or (stop_at_max) the largest count is certain: the counts are written here (k_wx_decide's rule: per
+    // response the first candidate that passes, else the PRESS optimum; the largest over the responses) and the host, which is told
+    // `0 left`, neither queues another level nor launches k_wx_decide (its launch behind the host's look was 20 us of the critical path).
+    // dec != NULL -- the fused generation's speculative run, api.hip: the counts go to dec[0 .. P - 1], the largest to dec[P], and the
+    // model record keeps what the fit wrote; pin_words[3] / [4]: the final count, and whether it differs from the fit's
+    const bool decided = s_run == 0 || (stop_at_max && s_lo == s_hi);
+    const int total = decided ? 0 : s_run;
+    if (decided && model && t == 0) {
+        const int nc = s_hi;
+        if (dec) dec[P] = (double)nc; else model[MLd.off_hdr] = (double)nc;
+        __hip_atomic_store(&pin_words[3], nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pin_words[4], (per_keep && nc != (int)per_keep[P]) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (t == 0) {
         *nact_next = total;
@@ -1397,53 +1395,24 @@ static void wx_scores(abc_ctx* ctx, const double* X, size_t ldx, size_t row_test
 #undef LAUNCH_SC
 }
 
-// The cascade.  *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
-static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* Y, size_t nt, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
-                                   size_t row_test, double* model, const abc_wx_shard* sh, int* fail_host, double* per_keep, double* dec,
-                                   int* changed_host) {
-    const int Wr = (sh && ctx->comm_kind) ? ctx->comm_world : 1;
-    const bool sharded = Wr > 1;
-    const size_t nvt = sh ? sh->nv_total : nt, nseg_max = P * (A - 1);
-    const size_t bc_bytes = wx_bc_bytes(nvt, nseg_max);
-    hipStream_t st = ctx->stream;
-    WxPlan* plan = (WxPlan*)abc_ws_alloc(ctx, sizeof(WxPlan));
-    int* seg_j = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    int* seg_a = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    int* astar = (int*)abc_ws_alloc(ctx, P * sizeof(int));
-    int* segbase = (int*)abc_ws_alloc(ctx, P * sizeof(int));
-    int* fail = (int*)abc_ws_alloc(ctx, 2 * sizeof(int));
-    unsigned long long* nz = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * 8);
-    double* W = (double*)abc_ws_alloc(ctx, nseg_max * 8);
-    int* v3 = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    unsigned int* kbase = (unsigned int*)abc_ws_alloc(ctx, nseg_max * 4);
-    int* actA = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    int* actB = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    int* nactv = (int*)abc_ws_alloc(ctx, 4 * sizeof(int));
-    unsigned int* tickets = (unsigned int*)abc_ws_alloc(ctx, 4 * sizeof(int));
-    int* slotmap = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-    unsigned char* passb = (unsigned char*)abc_ws_alloc(ctx, nseg_max);
-    double* S = (double*)abc_ws_alloc(ctx, (nt ? nt : 1) * A * 8);
-    unsigned int* c0 = (unsigned int*)abc_ws_alloc(ctx, nseg_max * WX_NC0 * 4);
-    unsigned int* blockcnt = (unsigned int*)abc_ws_alloc(ctx, bc_bytes);
-    if (!plan || !seg_j || !seg_a || !astar || !segbase || !fail || !nz || !W || !v3 || !kbase || !actA || !actB || !nactv || !tickets || !slotmap ||
-        !passb || !S || !c0 || !blockcnt)
-        ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu tests x %zu rows)", nseg_max, nt);
-    volatile int* pin = (volatile int*)(ctx->status_pin + 64);
-    const double* nv_ranks = sh ? sh->nv_ranks : nullptr;
-    const size_t nv_stride = sh ? sh->nv_stride : 0;
-
-    hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
-                       segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt, per_keep);
-    if (nt) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
-    ABC_HIP(ctx, hipGetLastError());
+// The cascade, in two halves: begin() queues everything up to level 0's bounds and returns; finish() waits for the host's first
+// look and goes on from there.  (The fused generation queues its ranking between the two: api.hip.)
+// *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
+struct abc_wx_run {
+    abc_ctx* ctx; const double* X; const double* Y; size_t nt, ldx, ldy, M, P, A, row_test; double* model; abc_wx_shard shv; bool has_sh;
+    double* per_keep; double* dec; int stop_at_max;
+    int Wr; bool sharded; size_t nvt, nseg_max, bc_bytes;
+    WxPlan* plan; int *seg_j, *seg_a, *astar, *segbase, *fail; unsigned long long* nz; double* W; int* v3; unsigned int* kbase;
+    int *actA, *actB, *nactv; unsigned int* tickets; int* slotmap; unsigned char* passb; double* S; unsigned int *c0, *blockcnt;
+    volatile int* pin; const double* nv_ranks; size_t nv_stride;
+    unsigned int* cl_fine; size_t cl_fine_ld;
 
     // one level over the tests act[0 .. nact_host) (nact on the device at nact_p): sweeps in batches, the counts (all-reduced over
     // the ranks), bounds; the last bounds work-group leaves the tests still needed in act_out / nact_out and their number in the
-    // pinned word, which the host waits for
-    unsigned int* cl_fine = nullptr;
-    size_t cl_fine_ld = 0;
-    auto level = [&](int lvl, int mode, int NBX, const int* act, const int* nact_p, int nact_host, int* act_out, int* nact_out, unsigned int* cl,
-                     size_t cl_ld, int cl_by_test, int* left) -> int {
+    // pinned word, which level_wait reads
+    int level_queue(int lvl, int mode, int NBX, const int* act, const int* nact_p, int nact_host, int* act_out, int* nact_out, unsigned int* cl,
+                    size_t cl_ld, int cl_by_test) {
+        hipStream_t st = ctx->stream;
         const size_t per_test = (size_t)NBX * 4 + (mode == 1 ? WX_NC0 * 4 : 0) + 7 * 4 + 16;
         pin[0] = -1;
         const size_t blds = ((size_t)NBX + 1024) * 8;
@@ -1462,118 +1431,163 @@ static int launch_wilcoxon_cascade(abc_ctx* ctx, const double* X, const double* 
             hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)g.nslots), dim3(1024), blds, st, NBX, g.nslots, act, nact_p, lo, (const unsigned long long*)totals,
                                nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const int*)astar, (int)P, (const int*)segbase,
                                act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0, model, (int)M, (int)A, dec,
-                               (const double*)per_keep);
+                               (const double*)per_keep, stop_at_max);
             ABC_HIP(ctx, hipGetLastError());
             lo += g.nslots;
         }
-        return wx_wait_word(ctx, pin, left);
-    };
+        return ABC_OK;
+    }
+    int level_wait(int* left) { return wx_wait_word(ctx, pin, left); }
 
-    int left = 0;
-    int* act_cur = actB;
-    int* act_nxt = actA;
-    const int* cur_n_p = nactv + 1;         // the device word that holds the length of act_cur
-    int NBX_last = 0;
-    ABC_TRY(level(0, 0, WX_NC0, actA, nactv, (int)nseg_max, actB, nactv + 1, c0, WX_NC0, 1, &left));
-    // fine levels over what is left: at most two, the second only when few tests remain and finer bins are to be had
-    for (int f = 0; f < 2 && left > 0; f++) {
-        const int NBX = wx_pick_bins(left, nvt);
-        if (f == 1 && (NBX <= NBX_last || left > 32)) break;
-        cl_fine_ld = (size_t)NBX;
-        cl_fine = (unsigned int*)abc_ws_alloc(ctx, (size_t)left * NBX * 4);
-        if (!cl_fine) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%d tests x %d bins)", left, NBX);
-        const int nact_host = left;
-        ABC_TRY(level(1 + f, 1, NBX, act_cur, nactv + 1 + f, nact_host, act_nxt, nactv + 2 + f, cl_fine, cl_fine_ld, 0, &left));
-        int* tmp = act_cur; act_cur = act_nxt; act_nxt = tmp;
-        cur_n_p = nactv + 2 + f;
-        NBX_last = NBX;
+    int begin() {
+        Wr = (has_sh && ctx->comm_kind) ? ctx->comm_world : 1;
+        sharded = Wr > 1;
+        nvt = has_sh ? shv.nv_total : nt;
+        nseg_max = P * (A - 1);
+        bc_bytes = wx_bc_bytes(nvt, nseg_max);
+        hipStream_t st = ctx->stream;
+        plan = (WxPlan*)abc_ws_alloc(ctx, sizeof(WxPlan));
+        seg_j = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        seg_a = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        astar = (int*)abc_ws_alloc(ctx, P * sizeof(int));
+        segbase = (int*)abc_ws_alloc(ctx, P * sizeof(int));
+        fail = (int*)abc_ws_alloc(ctx, 2 * sizeof(int));
+        nz = (unsigned long long*)abc_ws_alloc(ctx, nseg_max * 8);
+        W = (double*)abc_ws_alloc(ctx, nseg_max * 8);
+        v3 = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        kbase = (unsigned int*)abc_ws_alloc(ctx, nseg_max * 4);
+        actA = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        actB = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        nactv = (int*)abc_ws_alloc(ctx, 4 * sizeof(int));
+        tickets = (unsigned int*)abc_ws_alloc(ctx, 4 * sizeof(int));
+        slotmap = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        passb = (unsigned char*)abc_ws_alloc(ctx, nseg_max);
+        S = (double*)abc_ws_alloc(ctx, (nt ? nt : 1) * A * 8);
+        c0 = (unsigned int*)abc_ws_alloc(ctx, nseg_max * WX_NC0 * 4);
+        blockcnt = (unsigned int*)abc_ws_alloc(ctx, bc_bytes);
+        if (!plan || !seg_j || !seg_a || !astar || !segbase || !fail || !nz || !W || !v3 || !kbase || !actA || !actB || !nactv || !tickets || !slotmap ||
+            !passb || !S || !c0 || !blockcnt)
+            ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu tests x %zu rows)", nseg_max, nt);
+        pin = (volatile int*)(ctx->status_pin + 64);
+        nv_ranks = has_sh ? shv.nv_ranks : nullptr;
+        nv_stride = has_sh ? shv.nv_stride : 0;
+        cl_fine = nullptr;
+        cl_fine_ld = 0;
+        hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
+                           segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt, per_keep);
+        if (nt) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
+        ABC_HIP(ctx, hipGetLastError());
+        return level_queue(0, 0, WX_NC0, actA, nactv, (int)nseg_max, actB, nactv + 1, c0, WX_NC0, 1);
     }
 
-    // ---- the exact step -------------------------------------------------------------------------------------------------------
-    bool exact = left > 0;
-    if (exact) {
-        const int nx = left, XB = wx_xb(nvt) < nx ? wx_xb(nvt) : nx, NBX = NBX_last;
-        const unsigned int target = wx_target(nvt);
-        const int nbcap = (int)(nvt / target) + 2;
-        size_t vmax = nt;
-        if (sharded) vmax = (size_t)pin[1] | ((size_t)pin[2] << 31);
-        if (vmax < nt) ABC_FAIL(ctx, ABC_ERR_COMM, "wilcoxon: %zu validation rows on this rank, %zu at most on any", nt, vmax);
-        unsigned long long* keys_loc = (unsigned long long*)abc_ws_alloc(ctx, (size_t)XB * (vmax ? vmax : 1) * 8);
-        unsigned long long* keysx = (unsigned long long*)abc_ws_alloc(ctx, (size_t)XB * nvt * 8);
-        unsigned int* tabx = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * WX_NC0 * 4);
-        unsigned short* binmap = (unsigned short*)abc_ws_alloc(ctx, (size_t)XB * NBX * 2);
-        unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
-        unsigned int* binbase = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
-        unsigned int* cursor = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
-        unsigned int* big = (unsigned int*)abc_ws_alloc(ctx, (1 + 2 * (size_t)XB * nbcap) * 4);
-        const int* nxd = cur_n_p;
-        if (!keys_loc || !keysx || !tabx || !binmap || !hist || !binbase || !cursor || !big)
-            ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (the exact step: %d tests x %zu rows)", XB, nvt);
-        unsigned long long* keys_all = keys_loc;
-        if (sharded) {
-            ABC_TRY(abc_xbuf_reserve(ctx, (size_t)Wr * XB * vmax * 8 + 4096));
-            keys_all = (unsigned long long*)ctx->xbuf;
+    int finish(int* fail_host, int* changed_host) {
+        hipStream_t st = ctx->stream;
+        int left = 0;
+        int* act_cur = actB;
+        int* act_nxt = actA;
+        const int* cur_n_p = nactv + 1;         // the device word that holds the length of act_cur
+        int NBX_last = 0;
+        ABC_TRY(level_wait(&left));
+        // fine levels over what is left: at most two, the second only when few tests remain and finer bins are to be had
+        for (int f = 0; f < 2 && left > 0; f++) {
+            const int NBX = wx_pick_bins(left, nvt);
+            if (f == 1 && (NBX <= NBX_last || left > 32)) break;
+            cl_fine_ld = (size_t)NBX;
+            cl_fine = (unsigned int*)abc_ws_alloc(ctx, (size_t)left * NBX * 4);
+            if (!cl_fine) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%d tests x %d bins)", left, NBX);
+            const int nact_host = left;
+            ABC_TRY(level_queue(1 + f, 1, NBX, act_cur, nactv + 1 + f, nact_host, act_nxt, nactv + 2 + f, cl_fine, cl_fine_ld, 0));
+            ABC_TRY(level_wait(&left));
+            int* tmp = act_cur; act_cur = act_nxt; act_nxt = tmp;
+            cur_n_p = nactv + 2 + f;
+            NBX_last = NBX;
         }
-        const int rkeys = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
-        const size_t plds = (size_t)2 * nbcap * 4;
-        const size_t llds = (size_t)WX_NC0 * 4 + (size_t)2 * nbcap * 4 + (size_t)NBX * 2 + 16;
-        if (plds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_xplan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-        if (llds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
-        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_ranks_big, hipFuncAttributeMaxDynamicSharedMemorySize, WX_CAP * 8));
-        for (int x_lo = 0; x_lo < nx; x_lo += XB) {
-            const int xb = nx - x_lo < XB ? nx - x_lo : XB;
-            hipLaunchKernelGGL(k_wx_xplan, dim3((unsigned)xb), dim3(1024), plds, st, NBX, nbcap, target, (const int*)act_cur, nxd, x_lo,
-                               (const int*)slotmap, (const unsigned int*)cl_fine, (const unsigned int*)c0, tabx, binmap, hist, binbase, cursor);
-            if (vmax) {
-                WxLevel g;
-                g.R = rkeys; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
-                g.G = xb; g.TG = 1; g.RR = g.tiles; g.tpw = 1; g.nslots = xb;
-                const size_t lds = (size_t)xb * (7 * 4 + 16) + 64;
-                wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,
-                         keys_loc, vmax);
-                // (a batch shorter than XB leaves the tail of the block as it is: the placing kernel does not look at it)
+        // ---- the exact step -------------------------------------------------------------------------------------------------------
+        bool exact = left > 0;
+        if (exact) {
+            const int nx = left, XB = wx_xb(nvt) < nx ? wx_xb(nvt) : nx, NBX = NBX_last;
+            const unsigned int target = wx_target(nvt);
+            const int nbcap = (int)(nvt / target) + 2;
+            size_t vmax = nt;
+            if (sharded) vmax = (size_t)pin[1] | ((size_t)pin[2] << 31);
+            if (vmax < nt) ABC_FAIL(ctx, ABC_ERR_COMM, "wilcoxon: %zu validation rows on this rank, %zu at most on any", nt, vmax);
+            unsigned long long* keys_loc = (unsigned long long*)abc_ws_alloc(ctx, (size_t)XB * (vmax ? vmax : 1) * 8);
+            unsigned long long* keysx = (unsigned long long*)abc_ws_alloc(ctx, (size_t)XB * nvt * 8);
+            unsigned int* tabx = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * WX_NC0 * 4);
+            unsigned short* binmap = (unsigned short*)abc_ws_alloc(ctx, (size_t)XB * NBX * 2);
+            unsigned int* hist = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
+            unsigned int* binbase = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
+            unsigned int* cursor = (unsigned int*)abc_ws_alloc(ctx, (size_t)XB * nbcap * 4);
+            unsigned int* big = (unsigned int*)abc_ws_alloc(ctx, (1 + 2 * (size_t)XB * nbcap) * 4);
+            const int* nxd = cur_n_p;
+            if (!keys_loc || !keysx || !tabx || !binmap || !hist || !binbase || !cursor || !big)
+                ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (the exact step: %d tests x %zu rows)", XB, nvt);
+            unsigned long long* keys_all = keys_loc;
+            if (sharded) {
+                ABC_TRY(abc_xbuf_reserve(ctx, (size_t)Wr * XB * vmax * 8 + 4096));
+                keys_all = (unsigned long long*)ctx->xbuf;
             }
-            if (sharded) ABC_TRY(abc_comm_all_gather(ctx, keys_loc, keys_all, (size_t)XB * vmax * 8));
-            ABC_HIP(ctx, hipMemsetAsync(big, 0, 4, st));
-            if (vmax)
-                hipLaunchKernelGGL(k_wx_place, dim3((unsigned)((vmax + 1024 * WX_PK - 1) / (1024 * WX_PK)), (unsigned)xb, (unsigned)Wr), dim3(1024), llds, st, NBX,
-                                   nbcap, (const unsigned long long*)keys_all, vmax, XB, nxd, x_lo, (const int*)act_cur,
-                                   (const unsigned int*)kbase, (const unsigned int*)tabx, (const unsigned short*)binmap, (const unsigned int*)binbase, cursor,
-                                   keysx, nvt);
-            hipLaunchKernelGGL(k_wx_ranks, dim3((unsigned)nbcap, (unsigned)xb), dim3(256), 0, st, nbcap, (const int*)act_cur, nxd, x_lo,
-                               (const unsigned long long*)keysx, nvt, (const unsigned int*)hist, (const unsigned int*)binbase, W, big);
-            hipLaunchKernelGGL(k_wx_ranks_big, dim3(256), dim3(1024), (size_t)WX_CAP * 8, st, nbcap, (const int*)act_cur, x_lo,
-                               (const unsigned long long*)keysx, nvt, (const unsigned int*)hist, (const unsigned int*)binbase, W, (const unsigned int*)big, fail);
-            ABC_HIP(ctx, hipGetLastError());
+            const int rkeys = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
+            const size_t plds = (size_t)2 * nbcap * 4;
+            const size_t llds = (size_t)WX_NC0 * 4 + (size_t)2 * nbcap * 4 + (size_t)NBX * 2 + 16;
+            if (plds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_xplan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+            if (llds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+            ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_ranks_big, hipFuncAttributeMaxDynamicSharedMemorySize, WX_CAP * 8));
+            for (int x_lo = 0; x_lo < nx; x_lo += XB) {
+                const int xb = nx - x_lo < XB ? nx - x_lo : XB;
+                hipLaunchKernelGGL(k_wx_xplan, dim3((unsigned)xb), dim3(1024), plds, st, NBX, nbcap, target, (const int*)act_cur, nxd, x_lo,
+                                   (const int*)slotmap, (const unsigned int*)cl_fine, (const unsigned int*)c0, tabx, binmap, hist, binbase, cursor);
+                if (vmax) {
+                    WxLevel g;
+                    g.R = rkeys; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
+                    g.G = xb; g.TG = 1; g.RR = g.tiles; g.tpw = 1; g.nslots = xb;
+                    const size_t lds = (size_t)xb * (7 * 4 + 16) + 64;
+                    wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,
+                             keys_loc, vmax);
+                    // (a batch shorter than XB leaves the tail of the block as it is: the placing kernel does not look at it)
+                }
+                if (sharded) ABC_TRY(abc_comm_all_gather(ctx, keys_loc, keys_all, (size_t)XB * vmax * 8));
+                ABC_HIP(ctx, hipMemsetAsync(big, 0, 4, st));
+                if (vmax)
+                    hipLaunchKernelGGL(k_wx_place, dim3((unsigned)((vmax + 1024 * WX_PK - 1) / (1024 * WX_PK)), (unsigned)xb, (unsigned)Wr), dim3(1024), llds, st, NBX,
+                                       nbcap, (const unsigned long long*)keys_all, vmax, XB, nxd, x_lo, (const int*)act_cur,
+                                       (const unsigned int*)kbase, (const unsigned int*)tabx, (const unsigned short*)binmap, (const unsigned int*)binbase, cursor,
+                                       keysx, nvt);
+                hipLaunchKernelGGL(k_wx_ranks, dim3((unsigned)nbcap, (unsigned)xb), dim3(256), 0, st, nbcap, (const int*)act_cur, nxd, x_lo,
+                                   (const unsigned long long*)keysx, nvt, (const unsigned int*)hist, (const unsigned int*)binbase, W, big);
+                hipLaunchKernelGGL(k_wx_ranks_big, dim3(256), dim3(1024), (size_t)WX_CAP * 8, st, nbcap, (const int*)act_cur, x_lo,
+                                   (const unsigned long long*)keysx, nvt, (const unsigned int*)hist, (const unsigned int*)binbase, W, (const unsigned int*)big, fail);
+                ABC_HIP(ctx, hipGetLastError());
+            }
         }
+        if (exact)          // (else: the last bounds kernel has written the component counts itself)
+            hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3, dec,
+                               (const double*)per_keep, (int*)pin);
+        ABC_HIP(ctx, hipGetLastError());
+        *fail_host = 0;
+        if (exact) {
+            // did every bin of the exact step fit?  (k_wx_decide has otherwise written a count from incomplete sums: the sorted path
+            // overwrites it)
+            ABC_HIP(ctx, hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, st));
+            ABC_HIP(ctx, hipStreamSynchronize(st));
+        }
+        if (changed_host) *changed_host = pin[4];          // (visible: written in front of the word the last wait / the synchronisation saw)
+        if (abc_diag_env("ABC_WX_DEBUG")) {          // (diagnostic: how the tests were settled)
+            std::vector<int> hv(nseg_max);
+            WxPlan hp;
+            ABC_HIP(ctx, hipMemcpy(&hp, plan, sizeof(WxPlan), hipMemcpyDeviceToHost));
+            ABC_HIP(ctx, hipMemcpy(hv.data(), v3, nseg_max * sizeof(int), hipMemcpyDeviceToHost));
+            int cnt[3] = {0, 0, 0};
+            for (int i = 0; i < hp.nseg; i++) cnt[hv[i] < 0 || hv[i] > 2 ? 2 : hv[i]]++;
+            fprintf(stderr, "WX_DEBUG: %d tests over %zu rows (%zu here): rejected %d, passed %d, undecided %d by the bounds (exact step for %d tests, last level %d bins)%s\n",
+                    hp.nseg, nvt, nt, cnt[0], cnt[1], cnt[2], left, NBX_last, *fail_host ? " (a bin outgrew LDS: repeat on the sorted path)" : "");
+        }
+        return ABC_OK;
     }
-    if (exact)          // (else: the last bounds kernel has written the component counts itself)
-        hipLaunchKernelGGL(k_wx_decide, dim3(1), dim3(1024), 0, st, model, (int)M, (int)P, (int)A, plan, nz, W, passb, (const int*)v3, dec,
-                           (const double*)per_keep, (int*)pin);
-    ABC_HIP(ctx, hipGetLastError());
-    *fail_host = 0;
-    if (exact) {
-        // did every bin of the exact step fit?  (k_wx_decide has otherwise written a count from incomplete sums: the sorted path
-        // overwrites it)
-        ABC_HIP(ctx, hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, st));
-        ABC_HIP(ctx, hipStreamSynchronize(st));
-    }
-    if (changed_host) *changed_host = pin[4];          // (visible: written in front of the word the last wait / the synchronisation saw)
-    if (abc_diag_env("ABC_WX_DEBUG")) {          // (diagnostic: how the tests were settled)
-        std::vector<int> hv(nseg_max);
-        WxPlan hp;
-        ABC_HIP(ctx, hipMemcpy(&hp, plan, sizeof(WxPlan), hipMemcpyDeviceToHost));
-        ABC_HIP(ctx, hipMemcpy(hv.data(), v3, nseg_max * sizeof(int), hipMemcpyDeviceToHost));
-        int cnt[3] = {0, 0, 0};
-        for (int i = 0; i < hp.nseg; i++) cnt[hv[i] < 0 || hv[i] > 2 ? 2 : hv[i]]++;
-        fprintf(stderr, "WX_DEBUG: %d tests over %zu rows (%zu here): rejected %d, passed %d, undecided %d by the bounds (exact step for %d tests, last level %d bins)%s\n",
-                hp.nseg, nvt, nt, cnt[0], cnt[1], cnt[2], left, NBX_last, *fail_host ? " (a bin outgrew LDS: repeat on the sorted path)" : "");
-    }
-    return ABC_OK;
-}
+};
 
 int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M,
-                    size_t P, size_t A, size_t row_test, double* model, const abc_wx_shard* sh, double* dec, int* changed_host) {
+                    size_t P, size_t A, size_t row_test, double* model, const abc_wx_shard* sh, double* dec, int* changed_host, int stop_at_max) {
     if (changed_host) *changed_host = 2;                 // (2: the model record itself was rewritten -- any path but the cascade's own end)
     const size_t nt = n > row_test ? n - row_test : 0;   // validation rows here
     const size_t nvt = sh ? sh->nv_total : nt;           // ... and over all ranks
@@ -1589,7 +1603,13 @@ int launch_wilcoxon(abc_ctx* ctx, const double* X, const double* Y, size_t n, si
         double* per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!per_keep) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
         int changed = 2;
-        ABC_TRY(launch_wilcoxon_cascade(ctx, X, Y, nt, ldx, ldy, M, P, A, row_test, model, sh, &failed, per_keep, dec, &changed));     // (its plan kernel makes the copy)
+        abc_wx_run run;
+        memset((void*)&run, 0, sizeof(run));
+        run.ctx = ctx; run.X = X; run.Y = Y; run.nt = nt; run.ldx = ldx; run.ldy = ldy; run.M = M; run.P = P; run.A = A; run.row_test = row_test;
+        run.model = model; run.has_sh = sh != nullptr; if (sh) run.shv = *sh;
+        run.per_keep = per_keep; run.dec = dec; run.stop_at_max = stop_at_max;
+        ABC_TRY(run.begin());                                   // (its plan kernel makes the copy of the PRESS optima)
+        ABC_TRY(run.finish(&failed, &changed));
         static const bool force_fail = abc_diag_env("ABC_WX_FORCE_FAIL") != nullptr;   // tests: exercise the repeat
         if (!failed && !force_fail) { if (changed_host && dec) *changed_host = changed; return ABC_OK; }
         if (dec) return ABC_INTERNAL_RETRY;      // (a speculative run: the model record is as the fit left it; the caller runs the reduction again, by itself)
@@ -1619,4 +1639,44 @@ int launch_wilcoxon_commit(abc_ctx* ctx, double* model, size_t M, size_t P, size
     hipLaunchKernelGGL(k_wx_commit, dim3(1), dim3(256), 0, ctx->stream, model, (int)M, (int)P, (int)A, dec, with_hdr);
     ABC_HIP(ctx, hipGetLastError());
     return ABC_OK;
+}
+
+// The two halves for a caller that has work to queue between them (the fused generation's speculative ranking, api.hip): begin
+// queues the cascade up to level 0's bounds on the context's stream and returns at once; finish waits for the host's looks, runs
+// what is left, and says whether the largest count differs from the fit's (*changed_host: 0 / 1).  The decision goes to dec (P
+// counts, then the largest); the model record stays as the fit wrote it.  ABC_INTERNAL_RETRY from finish: a bin of the exact step
+// outgrew LDS -- the caller runs launch_wilcoxon in stream order instead.
+int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
+                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out) {
+    *out = nullptr;
+    const size_t nt = n > row_test ? n - row_test : 0;
+    if (!abc_wx_cascade_applies(nt, P, A) || !dec) ABC_FAIL(ctx, ABC_ERR_INVALID, "wilcoxon: not a set for the two-halves cascade");
+    abc_wx_run* run = new (std::nothrow) abc_wx_run;
+    if (!run) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: host memory");
+    memset((void*)run, 0, sizeof(*run));
+    run->ctx = ctx; run->X = X; run->Y = Y; run->nt = nt; run->ldx = ldx; run->ldy = ldy; run->M = M; run->P = P; run->A = A; run->row_test = row_test;
+    run->model = model; run->has_sh = false; run->dec = dec; run->stop_at_max = stop_at_max;
+    run->per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
+    int rc = run->per_keep ? ABC_OK : ABC_ERR_NOMEM;
+    if (rc == ABC_OK) rc = run->begin();
+    if (rc != ABC_OK) { delete run; if (rc == ABC_ERR_NOMEM && !ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "wilcoxon: workspace exhausted"); return rc; }
+    *out = run;
+    return ABC_OK;
+}
+int launch_wilcoxon_finish(abc_ctx* ctx, abc_wx_run* run, int* changed_host) {
+    int failed = 0, changed = 0;
+    const int rc = run->finish(&failed, &changed);
+    delete run;
+    ABC_TRY(rc);
+    static const bool force_fail = abc_diag_env("ABC_WX_FORCE_FAIL") != nullptr;   // tests: exercise the repeat
+    if (failed || force_fail) return ABC_INTERNAL_RETRY;
+    if (changed_host) *changed_host = changed;
+    return ABC_OK;
+}
+// a begun cascade that will not be finished (an error between the halves): wait for what it queued, release the handle
+void launch_wilcoxon_abandon(abc_ctx* ctx, abc_wx_run* run, hipStream_t its_stream) {
+    if (!run) return;
+    (void)hipStreamSynchronize(its_stream);
+    delete run;
+    (void)ctx;
 }
