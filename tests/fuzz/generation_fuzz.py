@@ -43,9 +43,11 @@ for case in range(cases):
         Nn = int(g.choice([5000, 100000, 270000]))
         A = int(g.integers(1, min(M, 10) + 1))
     sd = int(g.integers(1, 1 << 30))
-    wilcoxon = bool(g.integers(0, 4) == 0) and P <= 40
+    wilcoxon = bool(g.integers(0, 2) == 0) and P <= 40      # (round 5: half the cases -- the rule is the drop-in's default)
+    ynoise = float(g.choice([0.0, 0.0, 1.0, 2.5])) if wilcoxon else 0.0      # noisy responses: the reduction lowers the largest count and the
+    #                                                                          fused generation's speculation on the fit's count has to be repaired
     dups = bool(g.integers(0, 5) == 0)                    # duplicated rows: exact distance ties, broken by the row index
-    tag = dict(case=case, N=N, M=M, P=P, K=K, Kp=Kp, Nn=Nn, A=A, multivariate=mv, train_frac=tf, seed=sd, wilcoxon=wilcoxon, dups=dups)
+    tag = dict(case=case, N=N, M=M, P=P, K=K, Kp=Kp, Nn=Nn, A=A, multivariate=mv, train_frac=tf, seed=sd, wilcoxon=wilcoxon, dups=dups, ynoise=ynoise)
     try:
         wl = synthetic.Workload(M, P, sd)
         dX, dY = wl.rows_device(0, N, dev)
@@ -55,6 +57,9 @@ for case in range(cases):
             dst = torch.randint(0, N, (N // 20,), generator=gd).to(dev)
             dX[:, dst] = dX[:, src]
             dY[:, dst[::2]] = dY[:, src[::2]]             # (half of them whole-row copies)
+        if ynoise:
+            gn = torch.Generator(device=dev).manual_seed(sd)
+            dY += torch.randn(dY.shape, generator=gn, device=dev, dtype=torch.float64) * dY.std(dim=1, keepdim=True) * ynoise
         obs, spec = wl.observed(), wl.prior_spec()
         rule = _lib.RULE_WILCOXON if wilcoxon else _lib.RULE_MIN_PRESS
         dprev = wl.previous_set_device(Kp, dev) if Kp else ()
@@ -120,6 +125,8 @@ for case in range(cases):
                     problems.append("proposal outside the support of parameter %d" % p)
                 if k == 1 and (np.any(nxt[:, p] != np.round(nxt[:, p])) or nxt[:, p].min() < a or nxt[:, p].max() > b):
                     problems.append("integer parameter %d off its grid / range" % p)
+        if wilcoxon:
+            tag["ncomp_press"] = int(oracle.particle_ranking_pls(X, Y, obs, tf, A, rule=oracle.RULE_MIN_PRESS)["ncomp"])
         tag.update(ncomp=int(ref["ncomp"]), same_selection=bool(same_sel), weight_err=werr, problems=problems)
     except Exception as e:        # noqa: BLE001 -- a crash of one case is a finding, the sweep goes on
         tag.update(problems=["exception: %r" % (e,)])

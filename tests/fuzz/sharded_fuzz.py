@@ -25,22 +25,26 @@ for case in range(cases):
     M = int(g.integers(max(3, P // 2), 66))
     big = case % 4 == 3
     n_loc = int(g.integers(4200, 9000)) if big else int(g.integers(500, 2500))
+    cascade = case % 4 == 1        # (round 5) sets whose validation rows take the Wilcoxon rule's bounds cascade over the shards: >= 16384 of them
+    if cascade:
+        n_loc = int(g.integers(18000, 40000))
     N = n_loc * world
     K = int(g.integers(max(40, 2 * P + 8), N // 5))
     Kp = 0 if case % 5 == 4 else int(g.integers(max(40, 2 * P + 8), 900))
     nn_loc = int(g.integers(200, 3000))
     A = int(g.integers(1, min(M, 10) + 1))
-    rule = "wilcoxon" if (case % 6 == 1 and P <= 40) else "press"
+    rule = "wilcoxon" if ((case % 6 == 1 or cascade) and P <= 40) else "press"
+    split = "uneven" if case % 5 == 3 else "even"      # (round 5) shards of 2 : 1 (4 : 2 : 1 on three ranks)
     data = "ties" if case % 7 == 5 else "plain"
     if data == "ties":
         A = min(A, 3)        # (four distinct metric rows: beyond their rank the PRESS values are rounding noise and so is the count that minimises them)
     shape = "%d,%d,%d,%d,%d,%d,%d" % (n_loc, M, P, A, K, Kp, nn_loc)
-    tag = dict(case=case, world=world, shape=shape, rule=rule, data=data)
+    tag = dict(case=case, world=world, shape=shape, rule=rule, data=data, split=split)
     res_path = os.path.join(tmp, "c%d.json" % case)
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + case % 200), os.path.join(ROOT, "tests", "_sharded_worker.py"), "cabi", res_path, shape, rule, data]
+           "--master-port", str(29700 + case % 200), os.path.join(ROOT, "tests", "_sharded_worker.py"), "cabi", res_path, shape, rule, data, split]
     problems = []
     try:
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

@@ -1,5 +1,5 @@
 """The Wilcoxon component rule (wilcoxon.hip) against the CPU oracle on sets LARGE ENOUGH for its binned path and its bounds sweep
-(more than 8192 validation rows; tests/fuzz/ranking_fuzz.py stays below that and only sees the one-bin case): random row counts
+(16384 validation rows and more: the bounds cascade of round 5; tests/fuzz/ranking_fuzz.py stays below that and only sees the sorted path): random row counts
 (20 000 .. 600 000), 4..48 metrics, 1..12 responses, 2..32 components, training fractions 0.3..0.7, and responses whose noise is
 drawn so that the tests of a case are a MIX of decisive ones (settled by the bounds) and ones with statistics next to the threshold
 (undecided: the exact sweeps); tie structures: duplicated validation rows, validation rows drawn from few distinct rows (tie groups
@@ -35,7 +35,7 @@ g = np.random.default_rng(seed0)
 
 rows, fails = [], []
 for case in range(cases):
-    N = int(g.choice([20_000, 33_000, 70_000, 150_000, 300_000, 600_000])) + int(g.integers(0, 999))
+    N = int(g.choice([36_000, 45_000, 70_000, 150_000, 300_000, 600_000])) + int(g.integers(0, 999))
     M = int(g.integers(4, 49))
     P = int(g.integers(1, 13))
     A = int(g.choice([2, 3, 5, 8, 8, 12, 16, 24, 32]))
@@ -78,10 +78,10 @@ for case in range(cases):
                 os.close(keep)
             cap.seek(0)
             said = cap.read().decode(errors="replace")
-        m = re.search(r"(\d+) bins x (\d+) fine: bounds rejected (\d+), passed (\d+), undecided (\d+)(.*)", said)
+        m = re.search(r"rejected (\d+), passed (\d+), undecided (\d+) by the bounds \(exact step for (\d+) tests, last level (\d+) bins\)(.*)", said)
         if m:
-            tag.update(bins=int(m.group(1)), fine=int(m.group(2)), bounds_rejected=int(m.group(3)), bounds_passed=int(m.group(4)),
-                       undecided=int(m.group(5)), sorted_repeat="repeat" in m.group(6))
+            tag.update(bounds_rejected=int(m.group(1)), bounds_passed=int(m.group(2)), undecided=int(m.group(3)), exact_tests=int(m.group(4)),
+                       last_level_bins=int(m.group(5)), sorted_repeat="repeat" in m.group(6))
         problems = []
         if not np.array_equal(per_press, o_press):
             problems.append("PRESS optima %s vs the oracle's %s" % (per_press.tolist(), o_press.tolist()))
@@ -96,7 +96,7 @@ for case in range(cases):
     if tag["problems"]:
         fails.append(tag)
     print(("FAIL " if tag["problems"] else "ok   ") + json.dumps(tag), flush=True)
-tot = {k: sum(r.get(k, 0) for r in rows) for k in ("tests", "bounds_rejected", "bounds_passed", "undecided")}
+tot = {k: sum(r.get(k, 0) for r in rows) for k in ("tests", "bounds_rejected", "bounds_passed", "undecided", "exact_tests")}
 tot["cases_repeated_on_the_sorted_path"] = sum(1 for r in rows if r.get("sorted_repeat"))
 json.dump({"cases": len(rows), "failed": len(fails), "totals": tot, "failures": fails, "rows": rows}, open(out, "w"), indent=0)
 print("totals", json.dumps(tot))
