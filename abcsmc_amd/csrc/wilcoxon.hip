@@ -309,16 +309,17 @@ __device__ __forceinline__ void wx_wave_table(const unsigned int* __restrict__ c
 //   (all keys in the low, positive differences in the high half of a 32-bit counter: a work-group's rows stay below 2^16)
 //   MODE 2: the key itself (sign of d in bit 63) to keys[slot][row] -- the exact step.
 // The work-groups of one run of tiles (one per group of tests) follow each other on ONE XCD (blockIdx % 8), so the scores come
-// from HBM once and from that XCD's L2 for the other groups.
-template <int AM, int R, int MODE>
-__global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y, size_t ldy, size_t row_test, size_t nt, int M, int P, int A,
+// from HBM once and from that XCD's L2 for the other groups.  TT threads: 1024 (four waves per SIMD, <= 128 registers), or 768 with two
+// rows per thread at 17..32 components (three waves per SIMD, <= 170 registers: the 2 x 32 scores of a thread's rows alone are 128).
+template <int AM, int R, int MODE, int TT>
+__global__ __launch_bounds__(TT) void k_wx_sweep(const double* __restrict__ Y, size_t ldy, size_t row_test, size_t nt, int M, int P, int A,
                                                    const double* __restrict__ model, const double* __restrict__ S,
                                                    const int* __restrict__ seg_j, const int* __restrict__ seg_a, const int* __restrict__ astar,
                                                    const int* __restrict__ act, const int* __restrict__ nact_p, int act_lo, int act_n, int G,
                                                    int TG, int RR, int tpw, const unsigned int* __restrict__ kbase,
                                                    const unsigned int* __restrict__ c0, int NBX, unsigned int* __restrict__ blockcnt,
                                                    unsigned long long* __restrict__ keys, size_t kld) {
-    constexpr int TR = WX_T * R;
+    constexpr int TR = TT * R;
     extern __shared__ unsigned int wx_lds[];
     const int q = (int)(blockIdx.x >> 3), rr = (q / TG) * 8 + (int)(blockIdx.x & 7), tg = q % TG;
     if (rr >= RR) return;
@@ -341,12 +342,12 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
     double* emu = (double*)(((size_t)(eas + G) + 7) & ~(size_t)7);
     double* esd = emu + G;
     __shared__ int s_nent;
-    __shared__ int s_wcnt[WX_T / 64];
+    __shared__ int s_wcnt[TT / 64];
     const ModelLayout ML = model_layout(M, P, A);
-    if (MODE != 2) for (int e = t; e < ng * NBX; e += WX_T) cnt[e] = 0u;
+    if (MODE != 2) for (int e = t; e < ng * NBX; e += TT) cnt[e] = 0u;
     if (t < ng) { const int s = act[lo + t]; kb_s[t] = (int)kbase[s]; sj[t] = seg_j[s]; sa[t] = seg_a[s]; }
     if (MODE == 1)
-        for (int slot = t >> 6; slot < ng; slot += WX_T / 64) wx_wave_table(c0 + (size_t)act[lo + slot] * WX_NC0, NBX, tab_s + (size_t)slot * WX_NC0);
+        for (int slot = t >> 6; slot < ng; slot += TT / 64) wx_wave_table(c0 + (size_t)act[lo + slot] * WX_NC0, NBX, tab_s + (size_t)slot * WX_NC0);
     __syncthreads();
     {   // the entries, in parallel: the thread of a response's FIRST test in the group collects the response's mask (<= 31 steps);
         // its entry index = the starts in front of it (ballots; thread 0 walking the list alone was 7 us of a 60 us work-group)
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
             emu[idx] = model[ML.off_mean + M + j];
             esd[idx] = model[ML.off_sd + M + j];
         }
-        if (t == 0) { int ne = 0; for (int w = 0; w < WX_T / 64; w++) ne += s_wcnt[w]; s_nent = ne; }
+        if (t == 0) { int ne = 0; for (int w = 0; w < TT / 64; w++) ne += s_wcnt[w]; s_nent = ne; }
     }
     __syncthreads();
     const int nent = s_nent;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
         bool in[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const size_t i = row_t + (size_t)r * WX_T + t;
+            const size_t i = row_t + (size_t)r * TT + t;
             in[r] = i < nt;
             ic[r] = in[r] ? i : (nt ? nt - 1 : 0);
 #pragma unroll
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
                             for (int r = 0; r < R; r++) {
                                 const double d = estar[r] - fabs(zy[r] - pred[r]);
                                 const unsigned long long k63 = (unsigned long long)__double_as_longlong(fabs(d));
-                                const size_t i = row_t + (size_t)r * WX_T + t;
+                                const size_t i = row_t + (size_t)r * TT + t;
                                 if (i < kld) keys[(size_t)(lo - act_lo + slot) * kld + i] = (in[r] && d != 0.0) ? (k63 | (d > 0.0 ? WX_SIGN : 0ull)) : WX_NOKEY;
                             }
                             slot++;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(WX_T) void k_wx_sweep(const double* __restrict__ Y,
     if (MODE != 2) {
         __syncthreads();
         unsigned int* dst = blockcnt + ((size_t)rr * act_n + (size_t)(lo - act_lo)) * NBX;
-        for (int e = t; e < ng * NBX; e += WX_T) dst[e] = cnt[e];
+        for (int e = t; e < ng * NBX; e += TT) dst[e] = cnt[e];
     }
 }
 
@@ -1256,7 +1257,7 @@ bool abc_wx_cascade_applies(size_t nv_total, size_t P, size_t A) {
 }
 
 namespace {
-struct WxLevel { int R, tiles, G, TG, RR, tpw, nslots; };   // rows per thread, tiles of 1024 R rows, tests per work-group, groups of tests,
+struct WxLevel { int R, tiles, G, TG, RR, tpw, nslots, TT; };   // rows per thread, tiles of TT R rows, tests per work-group, groups of tests,
                                                             // runs of tiles, tiles per run, tests of this launch
 // A launch over `want` tests with NBX bins each: whole groups of G tests (a group's counters fill the LDS of a work-group), as many
 // tests as the counter buffer (bc_bytes) takes.  ONE work-group runs on a CU (LDS), so about 256 of them: R rows per thread as long
@@ -1267,15 +1268,18 @@ WxLevel wx_level(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, si
     g.G = (int)(((size_t)WX_LDS - 1024) / per_test_lds);          // (1 KB: the spare counters of the sweep)
     if (g.G < 1) g.G = 1;
     if (g.G > want) g.G = want;
-    const int rmax = A <= 8 ? 4 : (A <= 16 ? 2 : 1);
+    static const bool t768 = abc_diag_env("ABC_WX_T768") != nullptr;          // A/B switch: 17..32 components on 768 threads x 2 rows
+    const int rmax = A <= 8 ? 4 : (A <= 16 ? 2 : (t768 ? 2 : 1));
     int ns = want;
     for (int it = 0; it < 8; it++) {
         g.nslots = ns;
         g.TG = (ns + g.G - 1) / g.G;
         g.R = rmax;
-        while (g.R > 1 && ((nt + (size_t)WX_T * g.R - 1) / ((size_t)WX_T * g.R)) * (size_t)g.TG < 192) g.R >>= 1;
-        g.tiles = (int)((nt + (size_t)WX_T * g.R - 1) / ((size_t)WX_T * g.R));
-        const int limit = 65535 / (WX_T * g.R);
+        auto threads = [&](int R) { return (A > 16 && R == 2) ? 768 : WX_T; };
+        while (g.R > 1 && ((nt + (size_t)threads(g.R) * g.R - 1) / ((size_t)threads(g.R) * g.R)) * (size_t)g.TG < 192) g.R >>= 1;
+        g.TT = threads(g.R);
+        g.tiles = (int)((nt + (size_t)g.TT * g.R - 1) / ((size_t)g.TT * g.R));
+        const int limit = 65535 / (g.TT * g.R);
         int rr_target = 256 / g.TG;
         if (rr_target < 1) rr_target = 1;
         int tpw = (g.tiles + rr_target - 1) / rr_target;
@@ -1343,7 +1347,7 @@ static int wx_wait_word(abc_ctx* ctx, volatile int* w, int* out) {
     }
 }
 
-template <int AM, int R>
+template <int AM, int R, int TT>
 static void wx_launch_sweep(abc_ctx* ctx, int mode, const WxLevel& g, size_t lds, const double* Y, size_t ldy, size_t row_test, size_t nt, size_t M,
                             size_t P, size_t A, const double* model, const double* S, const int* seg_j, const int* seg_a, const int* astar,
                             const int* act, const int* nact_p, int act_lo, const unsigned int* kbase, const unsigned int* c0, int NBX,
@@ -1351,8 +1355,8 @@ static void wx_launch_sweep(abc_ctx* ctx, int mode, const WxLevel& g, size_t lds
     const dim3 grid((unsigned)(8 * ((g.RR + 7) / 8) * g.TG));
 #define WX_SW(MODEV)                                                                                                                      \
     do {                                                                                                                                  \
-        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_sweep<AM, R, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_wx_sweep<AM, R, MODEV>), grid, dim3(WX_T), lds, ctx->stream, Y, ldy, row_test, nt, (int)M, (int)P, (int)A, model, S, \
+        if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_sweep<AM, R, MODEV, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_wx_sweep<AM, R, MODEV, TT>), grid, dim3(TT), lds, ctx->stream, Y, ldy, row_test, nt, (int)M, (int)P, (int)A, model, S, \
                            seg_j, seg_a, astar, act, nact_p, act_lo, g.nslots, g.G, g.TG, g.RR, g.tpw, kbase, c0, NBX, blockcnt, keys, kld);  \
     } while (0)
     if (mode == 0) WX_SW(0); else if (mode == 1) WX_SW(1); else WX_SW(2);
@@ -1362,11 +1366,12 @@ static void wx_sweep(abc_ctx* ctx, size_t A, int mode, const WxLevel& g, size_t 
                      size_t nt, size_t M, size_t P, const double* model, const double* S, const int* seg_j, const int* seg_a, const int* astar,
                      const int* act, const int* nact_p, int act_lo, const unsigned int* kbase, const unsigned int* c0, int NBX,
                      unsigned int* blockcnt, unsigned long long* keys, size_t kld) {
-#define WX_GO(AMV, RV) wx_launch_sweep<AMV, RV>(ctx, mode, g, lds, Y, ldy, row_test, nt, M, P, A, model, S, seg_j, seg_a, astar, act, nact_p, act_lo, \
-                                                kbase, c0, NBX, blockcnt, keys, kld)
-    if (A <= 8) { if (g.R == 4) WX_GO(8, 4); else if (g.R == 2) WX_GO(8, 2); else WX_GO(8, 1); }
-    else if (A <= 16) { if (g.R == 2) WX_GO(16, 2); else WX_GO(16, 1); }
-    else WX_GO(32, 1);
+#define WX_GO(AMV, RV, TV) wx_launch_sweep<AMV, RV, TV>(ctx, mode, g, lds, Y, ldy, row_test, nt, M, P, A, model, S, seg_j, seg_a, astar, act, nact_p, act_lo, \
+                                                    kbase, c0, NBX, blockcnt, keys, kld)
+    if (A <= 8) { if (g.R == 4) WX_GO(8, 4, 1024); else if (g.R == 2) WX_GO(8, 2, 1024); else WX_GO(8, 1, 1024); }
+    else if (A <= 16) { if (g.R == 2) WX_GO(16, 2, 1024); else WX_GO(16, 1, 1024); }
+    else if (g.R == 2) WX_GO(32, 2, 768);
+    else WX_GO(32, 1, 1024);
 #undef WX_GO
 }
 
@@ -1539,7 +1544,7 @@ struct abc_wx_run {
                                    (const int*)slotmap, (const unsigned int*)cl_fine, (const unsigned int*)c0, tabx, binmap, hist, binbase, cursor);
                 if (vmax) {
                     WxLevel g;
-                    g.R = rkeys; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
+                    g.R = rkeys; g.TT = WX_T; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
                     g.G = xb; g.TG = 1; g.RR = g.tiles; g.tpw = 1; g.nslots = xb;
                     const size_t lds = (size_t)xb * (7 * 4 + 16) + 64;
                     wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,

@@ -67,6 +67,7 @@ for case in range(cases):
         prev = tuple((dprev[0].cpu().numpy().T, dprev[1].cpu().numpy(), dprev[2].cpu().numpy())) if Kp else ()
         gen = device.Generation(N, M, P, K, Kp, Nn, tf, A, rule=rule, multivariate=mv, device=dev)
         r = abcutil.rng(sd)
+        gen.ctx.perturb_giveups(reset=True)
         gen.run(dX, dY, device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
         torch.cuda.synchronize()
         o = oracle.rng(sd)
@@ -116,13 +117,17 @@ for case in range(cases):
         if not np.array_equal(gen.seeds.cpu().numpy().astype(np.uint64)[:Nn], np.array([oracle.rng_get(o2) for _ in range(Nn)], dtype=np.uint64)):
             problems.append("seeds differ")
         nxt = device.to_numpy(gen.next)
+        giveups = int(gen.ctx.perturb_giveups(reset=True))    # noisy responses can leave the winners outside the priors' support: the reference's
+        tag["giveups"] = giveups                              # rejection loop would never end there, the device gives up and SAYS so (abcsmc_hip.h:22)
         if nxt.shape != (Nn, P) or not np.isfinite(nxt).all():
             problems.append("proposals not finite")
         else:
             for p in range(P):
                 k, a, b = spec[p]
                 if k == 2 and (nxt[:, p].min() < a or nxt[:, p].max() > b):
-                    problems.append("proposal outside the support of parameter %d" % p)
+                    nout = int(((nxt[:, p] < a) | (nxt[:, p] > b)).sum())
+                    if nout > giveups:
+                        problems.append("proposal outside the support of parameter %d in %d rows, %d give-ups reported" % (p, nout, giveups))
                 if k == 1 and (np.any(nxt[:, p] != np.round(nxt[:, p])) or nxt[:, p].min() < a or nxt[:, p].max() > b):
                     problems.append("integer parameter %d off its grid / range" % p)
         if wilcoxon:
