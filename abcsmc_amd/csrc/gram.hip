@@ -716,19 +716,21 @@ struct GramI8 {
     static constexpr int NBLK = C * (C + 1) / 2 - CY * (CY + 1) / 2;
     static constexpr int PSZ = NBLK * 256 + 2 * C16;             // the partial record of k_gram
     static constexpr int NT = 512, NW = 8, TRW = 32;             // a tile = one 32-row step of the i8 MFMA
-    static constexpr int NI = CB;                                // columns per thread and tile in the conversion (column 32 i + t / 16, row pair t % 16)
+    static constexpr int NR = (C32 + 63) / 64;                   // conversion rounds per tile: a thread takes (column 64 r + t / 8, rows 4 (t % 8) .. + 3)
     static constexpr int NDMA = C32 * 16 * 16 / 1024;            // LDS-DMA instructions per tile (1 KB each: 4 columns x 16 row pairs)
     static constexpr int DPW = (NDMA + NW - 1) / NW;             // ... per wave
-    static constexpr int RAW = C32 * 256;                        // bytes of a raw tile in LDS: [column][32 rows] doubles
+    static constexpr int RAW = C32 * 256;                        // bytes of a raw tile in LDS: [column][16 row pairs, the even ones first] doubles
+    static constexpr int NRAW = 3;                               // raw tiles: the one being converted and two in flight
     static constexpr int CS = 48;                                // bytes of a (byte plane, column) in LDS: 32 rows + 16 (b128 reads conflict-free)
     static constexpr int PLANE = C32 * CS;
     static constexpr bool skip_last = (2 * (CB - 1) >= C - CY);  // the last diagonal tile holds Y'Y / padding only
     static constexpr int NTILE = CB * (CB + 1) / 2 - (skip_last ? 1 : 0);
     static constexpr int TPW = (NTILE + NW - 1) / NW;            // tiles per wave
-    // two raw tiles (LDS-DMA targets), one set of byte planes, the running column sums and sums of squares of every (column, row
-    // pair), (shift, magic, limit) per column, two sets of far flags (32 rows + any)
-    static constexpr int SUMS = C32 * 16 * 8;
-    static constexpr int LDS_B = 2 * RAW + 4 * PLANE + 2 * SUMS + C32 * 24 + 2 * 48;
+    // three raw tiles (LDS-DMA targets), one set of byte planes, two sets of far flags (32 rows + any); the running column sums and
+    // sums of squares live in registers (a thread's (column, four rows) slots are the same in every tile) and pass through the raw
+    // tiles' space once, at the end
+    static constexpr int LDS_B = NRAW * RAW + 4 * PLANE + C32 * 16 + 2 * 48;
+    static_assert(2 * C32 * 8 * 8 <= RAW, "the final sums fit a raw tile");
     static constexpr int FLUSH = 512;                            // tiles (32-row steps) between two flushes of the i32 accumulators
 };
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -774,14 +776,18 @@ __global__ __launch_bounds__(1024) void k_pilot_scale(const double* __restrict__
 }
 
 // Staging by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without a register round trip), TWO raw tiles in flight behind the one
-// being multiplied (80 KB per CU: HBM at 6 TB/s with ~2.5 us of latency wants ~60 KB per CU in flight).  What was measured on the way
+// being converted (120 KB of raw tiles per CU: HBM at 6 TB/s with ~2.5 us of latency wants ~60 KB per CU in flight).  What was measured on the way
 // (1e6 rows x 144 columns): the next tile prefetched in registers, one tile ahead -- 336 us, the kernel ran at the latency of its
 // loads (41 KB in flight per CU), and the ~250 registers a thread then needs spill, each scratch reload being a vmcnt wait that also
 // waits for the prefetch; three converter waves feeding five multiplier waves (roles as separate code paths) -- 450 us with one tile
-// ahead, 930 us with two (the compiler spilled the converters' second tile).  The running column sums live in LDS for the same
-// reason (every (column, row pair) slot has one owner: plain read-add-write, a fixed order): with them in registers the conversion
-// spilled accumulators around itself.  Per tile: wait for the own DMAs of tile i, barrier, convert it (raw -> byte planes, column
-// sums and squares in fp64, far flags), barrier, refill its raw slot with tile i + 2, the MFMAs of tile i.
+// ahead, 930 us with two (the compiler spilled the converters' second tile).  Round 4's conversion took a (column, row PAIR) per
+// thread and step, five columns one after the other with the per-column constants and the running sums re-read from LDS each time
+// and eight 2-byte plane stores per four values: twelve LDS instructions per step, 417 us.  Round 5: a thread converts FOUR rows of
+// a column (the DMA lanes fetch the even row pairs into the first half of a column's 256 bytes and the odd ones into the second,
+// so a thread's two 16-byte reads are 16-byte strided across the lanes: conflict-free), the 4 x 4 byte transpose is eight
+// v_perm_b32, every plane store one ds_write_b32; shift and binade of the thread's (at most three) columns and its sums stay in
+// registers, the rounds are unrolled so their LDS latencies overlap.  Per tile: wait for the own DMAs of tile i, barrier, convert
+// it (raw -> byte planes, column sums and squares in fp64, far flags), barrier, refill its raw slot with tile i + 3, the MFMAs of tile i.
 template <int C, int CY>
 __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M,
                                                  int P, long long n, long long split, const double* __restrict__ shift,
@@ -791,12 +797,10 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
                                                  long long tmax) {
     using D = GramI8<C, CY>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
-    unsigned char* raw0 = lds8;                                               // [2][C32][32 rows] doubles
-    unsigned char* planes = lds8 + 2 * D::RAW;                                // [4][C32][CS]
-    double* lsum = reinterpret_cast<double*>(lds8 + 2 * D::RAW + 4 * D::PLANE);             // [C32][16] column sums per row pair
-    double* lsq = lsum + D::C32 * 16;                                                       // [C32][16] sums of squares
-    double* colc = lsq + D::C32 * 16;                                                       // [C32][3]: shift, magic, range limit
-    unsigned char* rowfar0 = reinterpret_cast<unsigned char*>(colc + D::C32 * 3);           // [2][48]: 32 row flags + the any-flag word
+    unsigned char* raw0 = lds8;                                               // [3][C32][16 row pairs: 0, 2, .. 14, 1, 3, .. 15] doubles
+    unsigned char* planes = lds8 + D::NRAW * D::RAW;                          // [4][C32][CS]
+    double* colc = reinterpret_cast<double*>(planes + 4 * D::PLANE);          // [C32][2]: shift, binade
+    unsigned char* rowfar0 = reinterpret_cast<unsigned char*>(colc + 2 * D::C32);           // [2][48]: 32 row flags + the any-flag word
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
@@ -811,16 +815,18 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
         for (int i2 = 0; i2 < bi; i2++) b += C - i2;
         return b + (bj - bi);
     };
-    // per-column constants: shift, magic = 1.5 2^(21 + e) (v + magic has q = rint(v 2^(31 - e)) in its low word), and the range
-    // limit (1 - 2^-6) 2^e (so that the balanced bytes of q never carry out of the top one)
+    // conversion: thread -> (column 64 r + t / 8, rows 4 (t % 8) .. + 3) in round r.  Per-column constants: shift, magic = 1.5 2^(21 + e)
+    // (v + magic has q = rint(v 2^(31 - e)) in its low word), and the range limit (1 - 2^-6) 2^e (so that the balanced bytes of q
+    // never carry out of the top one): the two from the binade e by integer arithmetic on the exponent field
+    const int cq = t >> 3, qd = t & 7;
+    double ssum[D::NR], ssq[D::NR];
+#pragma unroll
+    for (int r = 0; r < D::NR; r++) { ssum[r] = 0.0; ssq[r] = 0.0; }
     for (int c = t; c < D::C32; c += D::NT) {
         const bool real = c < M + P;
-        const int e = real ? escale[c] : 0;
-        colc[3 * c] = real ? shift[c] : 0.0;
-        colc[3 * c + 1] = ldexp(1.5, 21 + e);
-        colc[3 * c + 2] = ldexp(0.984375, e);
+        colc[2 * c] = real ? shift[c] : 0.0;
+        reinterpret_cast<int*>(colc + 2 * c + 1)[0] = real ? escale[c] : 0;
     }
-    for (int e2 = t; e2 < 2 * D::C32 * 16; e2 += D::NT) lsum[e2] = 0.0;     // (lsum and lsq are adjacent)
     if (t < 24) reinterpret_cast<unsigned int*>(rowfar0)[t] = 0u;            // both sets of far flags
     for (int e2 = t; e2 < D::NBLK * 256; e2 += D::NT) out[e2] = 0.0;       // the flushes ADD into the record
     // this wave's tiles: the b-th (I, J >= I) super-block pair in row-major order, b = wave + 8 k
@@ -840,11 +846,13 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
         for (int o = 0; o < 5; o++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[k][o][r] = 0;
-    // LDS-DMA: instruction d of a tile moves columns 4 d .. 4 d + 3 (lane = 16 (column & 3) + row pair); wave w issues d = w, w + 8, ...
-    auto stage = [&](long long k) {                                             // the k-th tile of this work-group -> raw slot k & 1
-        const long long r = t0 + (g + k * G) * D::TRW + 2 * (lane & 15);
+    // LDS-DMA: instruction d of a tile moves columns 4 d .. 4 d + 3; lane = 16 (column & 3) + p fetches row pair 2 p (p < 8) resp.
+    // 2 (p - 8) + 1: rows 4 q .. 4 q + 3 of a column sit at its bytes 16 q and 128 + 16 q.  Wave w issues d = w, w + 8, ...
+    const int dma_rp = ((lane & 7) << 1) | ((lane >> 3) & 1);
+    auto stage = [&](long long k) {                                             // the k-th tile of this work-group -> raw slot k % 3
+        const long long r = t0 + (g + k * G) * D::TRW + 2 * dma_rp;
         const long long rr = r > rmax ? rmax : r;                               // (a legal address for rows past the end: masked later)
-        unsigned char* dst = raw0 + (size_t)(k & 1) * D::RAW;
+        unsigned char* dst = raw0 + (size_t)(k % D::NRAW) * D::RAW;
 #pragma unroll
         for (int j = 0; j < D::DPW; j++) {
             const int d = wave + D::NW * j, c = 4 * d + (lane >> 4);
@@ -854,35 +862,54 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
             }
         }
     };
-    // conversion: thread -> (column 32 i + t / 16, row pair t % 16)
-    const int cq = t >> 4, rp = t & 15;
-    auto convert = [&](long long k) {                                           // raw slot k & 1 -> the byte planes, far flags k & 1
-        const unsigned char* raw = raw0 + (size_t)(k & 1) * D::RAW;
+    auto convert = [&](long long k) {                                           // raw slot k % 3 -> the byte planes, far flags k & 1
+        const unsigned char* raw = raw0 + (size_t)(k % D::NRAW) * D::RAW;
         unsigned char* rowfar = rowfar0 + (int)(k & 1) * 48;
-        const long long r = t0 + (g + k * G) * D::TRW + 2 * rp;
-        const bool oka = (r >= r_begin) && (r < r_end), okb = (r + 1 >= r_begin) && (r + 1 < r_end);
-        bool farx = false, fary = false;
-#pragma unroll 1
-        for (int i = 0; i < D::NI; i++) {                                      // (one column after the other: the accumulators leave few registers)
-            const int c = 32 * i + cq;
-            const d2 v = *reinterpret_cast<const d2*>(raw + (size_t)c * 256 + 16 * rp);
-            const double sh = colc[3 * c], magic = colc[3 * c + 1], lim = colc[3 * c + 2];
-            const bool real = c < M + P;
-            const double zx = (real && oka) ? v.x - sh : 0.0, zy = (real && okb) ? v.y - sh : 0.0;   // (rows outside the partition: 0)
-            lsum[c * 16 + rp] += zx + zy;                                      // (this thread's slot: no other thread touches it)
-            lsq[c * 16 + rp] = fma(zy, zy, fma(zx, zx, lsq[c * 16 + rp]));
-            farx = farx || !(fabs(zx) <= lim);                                 // (NaN: not in range)
-            fary = fary || !(fabs(zy) <= lim);
-            const unsigned int qx = (unsigned int)__double_as_longlong(zx + magic), qy = (unsigned int)__double_as_longlong(zy + magic);
-            const unsigned int bx = (qx + 0x80808080u) ^ 0x80808080u, by = (qy + 0x80808080u) ^ 0x80808080u;
-            unsigned char* dst = planes + (size_t)c * D::CS + 2 * rp;
+        const long long r = t0 + (g + k * G) * D::TRW + 4 * qd;
+        bool ok[4], far[4] = {false, false, false, false};
 #pragma unroll
-            for (int b = 0; b < 4; b++)
-                *reinterpret_cast<unsigned short*>(dst + (size_t)b * D::PLANE) = (unsigned short)(((bx >> (8 * b)) & 0xffu) | (((by >> (8 * b)) & 0xffu) << 8));
+        for (int j = 0; j < 4; j++) ok[j] = (r + j >= r_begin) && (r + j < r_end);
+        d2 va[D::NR], vb[D::NR];
+#pragma unroll
+        for (int i = 0; i < D::NR; i++) {
+            const int c = 64 * i + cq;
+            if (c < D::C32) {                                                  // (wave-uniform: 64 i + t / 8 with C32 a multiple of 32)
+                va[i] = *reinterpret_cast<const d2*>(raw + (size_t)c * 256 + 16 * qd);
+                vb[i] = *reinterpret_cast<const d2*>(raw + (size_t)c * 256 + 128 + 16 * qd);
+            }
         }
-        if (farx) rowfar[2 * rp] = 1;
-        if (fary) rowfar[2 * rp + 1] = 1;
-        if (farx || fary) rowfar[32] = 1;
+#pragma unroll
+        for (int i = 0; i < D::NR; i++) {
+            const int c = 64 * i + cq;
+            if (c >= D::C32) continue;
+            const bool real = c < M + P;
+            const double sh = colc[2 * c];
+            const int e = reinterpret_cast<const int*>(colc + 2 * c + 1)[0];
+            const double magic = __hiloint2double((int)(0x3ff80000u + ((unsigned)(21 + e) << 20)), 0);       // 1.5 2^(21 + e)
+            const double lim = __hiloint2double((int)(0x3fef8000u + ((unsigned)e << 20)), 0);                // 0.984375 2^e
+            double z[4] = {va[i].x - sh, va[i].y - sh, vb[i].x - sh, vb[i].y - sh};
+            unsigned int bq[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                z[j] = (real && ok[j]) ? z[j] : 0.0;                           // (rows outside the partition, padding columns: 0)
+                far[j] = far[j] || !(fabs(z[j]) <= lim);                       // (NaN: not in range)
+                const unsigned int q = (unsigned int)__double_as_longlong(z[j] + magic);
+                bq[j] = (q + 0x80808080u) ^ 0x80808080u;
+            }
+            ssum[i] += (z[0] + z[1]) + (z[2] + z[3]);
+            ssq[i] = fma(z[3], z[3], fma(z[2], z[2], fma(z[1], z[1], fma(z[0], z[0], ssq[i]))));
+            // 4 x 4 byte transpose: plane b gets byte b of the four rows' words (v_perm_b32: selector bytes 0-3 = the second operand)
+            const unsigned int l01 = __builtin_amdgcn_perm(bq[1], bq[0], 0x05010400u), h01 = __builtin_amdgcn_perm(bq[1], bq[0], 0x07030602u);
+            const unsigned int l23 = __builtin_amdgcn_perm(bq[3], bq[2], 0x05010400u), h23 = __builtin_amdgcn_perm(bq[3], bq[2], 0x07030602u);
+            unsigned char* dst = planes + (size_t)c * D::CS + 4 * qd;
+            *reinterpret_cast<unsigned int*>(dst) = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+            *reinterpret_cast<unsigned int*>(dst + (size_t)D::PLANE) = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+            *reinterpret_cast<unsigned int*>(dst + (size_t)2 * D::PLANE) = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+            *reinterpret_cast<unsigned int*>(dst + (size_t)3 * D::PLANE) = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (far[j]) rowfar[4 * qd + j] = 1;
+        if (far[0] || far[1] || far[2] || far[3]) rowfar[32] = 1;
     };
     // flush of the i32 accumulators into this work-group's partial record (fp64): tile (I, J), order o = b + b' - 3 carries weight
     // 2^(8 o) 2^(e_a + e_b - 62 + 24); a 32 x 32 tile is up to four 16 x 16 blocks of the record, stored in the f64 MFMA's C layout
@@ -915,21 +942,24 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
     __syncthreads();
     if (nmine > 0) stage(0);
     if (nmine > 1) stage(1);
+    if (nmine > 2) stage(2);
     // (two loops: the accumulators are flushed between runs of FLUSH tiles -- the flush stays out of the inner loop's register budget)
     for (long long i0 = 0; i0 < nmine; i0 += D::FLUSH) {
         const long long i1 = (i0 + D::FLUSH < nmine) ? i0 + D::FLUSH : nmine;
 #pragma unroll 1
         for (long long i = i0; i < i1; i++) {
-            // (1) the own DMAs of tile i have landed (those of tile i + 1 may stay in flight), then everybody's
-            if (i + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::DPW) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (1) the own DMAs of tile i have landed (those of tiles i + 1 and i + 2 may stay in flight), then everybody's
+            if (i + 2 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D::DPW) : "memory");
+            else if (i + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                                   // (also: every wave is done with the MFMAs of tile i - 1)
             // (2) tile i -> bytes
             unsigned char* rowfar = rowfar0 + (int)(i & 1) * 48;
             const long long tile = g + i * G, row0 = t0 + tile * D::TRW;
             convert(i);
             __syncthreads();                                                   // the planes are complete, tile i's raw slot is free
-            // (3) refill the slot with tile i + 2; far rows; the byte products of tile i
-            if (i + 2 < nmine) stage(i + 2);
+            // (3) refill the slot with tile i + 3; far rows; the byte products of tile i
+            if (i + 3 < nmine) stage(i + 3);
             if (wave == 0) {                                                   // tile i's far rows as a mask (always written: no memset)
                 const unsigned long long m = __ballot(lane < 32 && rowfar[lane & 31] != 0 && row0 + lane >= r_begin && row0 + lane < r_end);
                 if (lane == 0) {
@@ -973,12 +1003,20 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     flush();
-    // column sums / sums of squares (16 slots per column) and the exact diagonal
+    // column sums / sums of squares (eight slots per column, through the raw tiles' space, added in a fixed order) and the exact diagonal
+    double* lsum = reinterpret_cast<double*>(raw0);                                          // [C32][8], then the same of the squares
+    double* lsq = lsum + D::C32 * 8;
+#pragma unroll
+    for (int r = 0; r < D::NR; r++) {
+        const int c = 64 * r + cq;
+        if (c < D::C32) { lsum[c * 8 + qd] = ssum[r]; lsq[c * 8 + qd] = ssq[r]; }
+    }
+    __syncthreads();
     if (t < D::C16) {
         for (int half = 0; half < 2; half++) {
             const double* src = half ? lsq : lsum;
             double sacc = 0.0;
-            for (int l = 0; l < 16; l++) sacc += src[t * 16 + l];
+            for (int l = 0; l < 8; l++) sacc += src[t * 8 + l];
             out[D::NBLK * 256 + half * D::C16 + t] = sacc;
             if (half == 1 && (t >> 4) < C - CY) {                              // the diagonal element of block (t / 16, t / 16)
                 const int rr = t & 15;
