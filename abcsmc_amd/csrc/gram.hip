@@ -717,20 +717,23 @@ struct GramI8 {
     static constexpr int PSZ = NBLK * 256 + 2 * C16;             // the partial record of k_gram
     static constexpr int NT = 512, NW = 8, TRW = 32;             // a tile = one 32-row step of the i8 MFMA
     static constexpr int NR = (C32 + 63) / 64;                   // conversion rounds per tile: a thread takes (column 64 r + t / 8, rows 4 (t % 8) .. + 3)
-    static constexpr int NDMA = C32 * 16 * 16 / 1024;            // LDS-DMA instructions per tile (1 KB each: 4 columns x 16 row pairs)
-    static constexpr int DPW = (NDMA + NW - 1) / NW;             // ... per wave
-    static constexpr int RAW = C32 * 256;                        // bytes of a raw tile in LDS: [column][16 row pairs, the even ones first] doubles
-    static constexpr int NRAW = 3;                               // raw tiles: the one being converted and two in flight
-    static constexpr int CS = 48;                                // bytes of a (byte plane, column) in LDS: 32 rows + 16 (b128 reads conflict-free)
+    static constexpr int DPW = (C32 / 4 + NW - 1) / NW;          // LDS-DMA instructions (1 KB each: 4 columns x 16 row pairs) per wave and tile, at most
+    static constexpr int CS = 32;                                // bytes of a (byte plane, column) in LDS: 32 rows, the two 16-byte halves swapped
+    //                                                              in columns 4..7 mod 8 (b128 operand reads and the conversion's b32 stores conflict-free)
     static constexpr int PLANE = C32 * CS;
     static constexpr bool skip_last = (2 * (CB - 1) >= C - CY);  // the last diagonal tile holds Y'Y / padding only
     static constexpr int NTILE = CB * (CB + 1) / 2 - (skip_last ? 1 : 0);
     static constexpr int TPW = (NTILE + NW - 1) / NW;            // tiles per wave
-    // three raw tiles (LDS-DMA targets), one set of byte planes, two sets of far flags (32 rows + any); the running column sums and
-    // sums of squares live in registers (a thread's (column, four rows) slots are the same in every tile) and pass through the raw
-    // tiles' space once, at the end
-    static constexpr int LDS_B = NRAW * RAW + 4 * PLANE + C32 * 16 + 2 * 48;
-    static_assert(2 * C32 * 8 * 8 <= RAW, "the final sums fit a raw tile");
+    // two or three raw tiles (LDS-DMA targets: the real columns only, [column][16 row pairs]), TWO sets of byte planes, a 16-byte
+    // record per column (shift, high words of magic and limit), three sets of far flags (32 rows + any); the running column sums
+    // and sums of squares live in registers (a thread's (column, four rows) slots are the same in every tile) and pass through
+    // the raw tiles' space once, at the end
+    static constexpr int FIXED_B = 8 * PLANE + C32 * 16 + 3 * 48 + 256;         // (+ 256 zero bytes: the "raw column" of the padding columns)
+    static constexpr int LDS_MAX = 160 * 1024;
+    static int raw_bytes(int cols) { return ((cols + 3) / 4) * 1024; }
+    static int raw_tiles(int cols) { return FIXED_B + 3 * raw_bytes(cols) <= LDS_MAX ? 3 : 2; }          // (two: 157..160 columns)
+    static int lds_bytes(int cols) { return FIXED_B + raw_tiles(cols) * raw_bytes(cols); }
+    static_assert(2 * C32 * 8 * 8 <= 2 * ((C16 - 15 + 3) / 4) * 1024, "the final sums fit the raw tiles");
     static constexpr int FLUSH = 512;                            // tiles (32-row steps) between two flushes of the i32 accumulators
 };
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -775,39 +778,48 @@ __global__ __launch_bounds__(1024) void k_pilot_scale(const double* __restrict__
     }
 }
 
-// Staging by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without a register round trip), TWO raw tiles in flight behind the one
-// being converted (120 KB of raw tiles per CU: HBM at 6 TB/s with ~2.5 us of latency wants ~60 KB per CU in flight).  What was measured on the way
+// Staging by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without a register round trip), two raw tiles in flight behind the one
+// being converted (HBM at 6 TB/s with ~2.5 us of latency wants ~60 KB per CU in flight).  What was measured on the way
 // (1e6 rows x 144 columns): the next tile prefetched in registers, one tile ahead -- 336 us, the kernel ran at the latency of its
 // loads (41 KB in flight per CU), and the ~250 registers a thread then needs spill, each scratch reload being a vmcnt wait that also
 // waits for the prefetch; three converter waves feeding five multiplier waves (roles as separate code paths) -- 450 us with one tile
 // ahead, 930 us with two (the compiler spilled the converters' second tile).  Round 4's conversion took a (column, row PAIR) per
 // thread and step, five columns one after the other with the per-column constants and the running sums re-read from LDS each time
-// and eight 2-byte plane stores per four values: twelve LDS instructions per step, 417 us.  Round 5: a thread converts FOUR rows of
-// a column (the DMA lanes fetch the even row pairs into the first half of a column's 256 bytes and the odd ones into the second,
-// so a thread's two 16-byte reads are 16-byte strided across the lanes: conflict-free), the 4 x 4 byte transpose is eight
-// v_perm_b32, every plane store one ds_write_b32; shift and binade of the thread's (at most three) columns and its sums stay in
-// registers, the rounds are unrolled so their LDS latencies overlap.  Per tile: wait for the own DMAs of tile i, barrier, convert
-// it (raw -> byte planes, column sums and squares in fp64, far flags), barrier, refill its raw slot with tile i + 3, the MFMAs of tile i.
+// and eight 2-byte plane stores per four values: twelve LDS instructions per step, 417 us.  Round 5, first: a thread converts FOUR
+// rows of a column (the DMA lanes fetch the even row pairs into the first half of a column's 256 bytes and the odd ones into the
+// second, so a thread's two 16-byte reads are 16-byte strided across the lanes: conflict-free), the 4 x 4 byte transpose is eight
+// v_perm_b32, every plane store one ds_write_b32; the sums stay in registers: 360 us -- and the phases taken out one at a time
+// (ABC_GRAM_ABL) said why: the refills alone 222 us (5.2 TB/s, what this access pattern gets), conversion + products WITHOUT
+// refills 290 us, i.e. ~5000 cycles per tile of which the byte products own 1664 (four tile pairs x 13 MFMAs x 32 cycles on the
+// busier SIMDs) and the conversion ~2500 (two waves of ~260 vector instructions per SIMD), one after the other between barriers.
+// Round 5, second: the two run TOGETHER.  Two sets of byte planes; in the step of tile i the four waves 0..3 (one per SIMD) multiply
+// tile i and then convert tile i + 1 into the other set, the waves 4..7 do the same in the opposite order -- a SIMD's two waves
+// keep its matrix pipe and its vector pipe busy at the same time -- and ONE barrier per tile separates the steps.
+// Per step: wait for the own DMAs of tile i + 1, barrier, refill tile i's raw slot with tile i + 3, tile i's far rows, the MFMAs
+// of tile i / the conversion of tile i + 1 (raw -> byte planes, column sums and squares in fp64, far flags).
 template <int C, int CY>
 __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, const double* __restrict__ Y, size_t ldx, size_t ldy, int M,
                                                  int P, long long n, long long split, const double* __restrict__ shift,
                                                  const int* __restrict__ escale, double* __restrict__ partial,
                                                  unsigned long long* __restrict__ far_mask /* [2][tmax]: far rows of every 32-row tile */,
                                                  unsigned long long* __restrict__ far_sum /* [2][(tmax + 63) / 64]: tiles with any; then one word: any at all */,
-                                                 long long tmax) {
+                                                 long long tmax, int nraw /* raw tiles in LDS: 3, or 2 */,
+                                                 int abl /* diagnostic (ABC_GRAM_ABL): 1 no conversion, 2 no products, 4 no refills */) {
     using D = GramI8<C, CY>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
-    unsigned char* raw0 = lds8;                                               // [3][C32][16 row pairs: 0, 2, .. 14, 1, 3, .. 15] doubles
-    unsigned char* planes = lds8 + D::NRAW * D::RAW;                          // [4][C32][CS]
-    double* colc = reinterpret_cast<double*>(planes + 4 * D::PLANE);          // [C32][2]: shift, binade
-    unsigned char* rowfar0 = reinterpret_cast<unsigned char*>(colc + 2 * D::C32);           // [2][48]: 32 row flags + the any-flag word
+    const int ncols = M + P, ndma = (ncols + 3) / 4, rawb = ndma * 1024;
+    unsigned char* planes0 = lds8;                                            // [2][4][C32][CS]
+    double* colc = reinterpret_cast<double*>(lds8 + 8 * D::PLANE);            // [C32][2]: shift; high words of magic and limit
+    unsigned char* rowfar0 = reinterpret_cast<unsigned char*>(colc + 2 * D::C32);           // [3][48]: 32 row flags + the any-flag word
+    unsigned char* zero256 = rowfar0 + 3 * 48;                                // what the conversion reads for a padding column
+    unsigned char* raw0 = zero256 + 256;                                      // [nraw][ncols up to 4][16 row pairs: 0, 2, .. 14, 1, 3, .. 15] doubles
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int part = blockIdx.y, G = gridDim.x, g = blockIdx.x;
     const long long r_begin = part ? split : 0, r_end = part ? n : split;
     const long long t0 = r_begin & ~1LL;
     const long long ntiles = (r_end > r_begin) ? (r_end - t0 + D::TRW - 1) / D::TRW : 0;
-    const long long nmine = (ntiles > g) ? (ntiles - g + G - 1) / G : 0;      // this work-group's tiles: g, g + G, ...
+    const int nmine = (ntiles > g) ? (int)((ntiles - g + G - 1) / G) : 0;     // this work-group's tiles: g, g + G, ...  (tmax < 2^31)
     const long long rmax = (n - 2) & ~1LL;                                    // last in-bounds 16-B row pair (n is even on this path)
     double* out = partial + ((size_t)part * (G + 1) + g) * D::PSZ;           // (record G of a partition: k_gram_far's)
     auto blk_index = [&](int bi, int bj) -> int {                               // (bi, bj >= bi, bi < C - CY) enumeration of k_gram
@@ -817,17 +829,20 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
     };
     // conversion: thread -> (column 64 r + t / 8, rows 4 (t % 8) .. + 3) in round r.  Per-column constants: shift, magic = 1.5 2^(21 + e)
     // (v + magic has q = rint(v 2^(31 - e)) in its low word), and the range limit (1 - 2^-6) 2^e (so that the balanced bytes of q
-    // never carry out of the top one): the two from the binade e by integer arithmetic on the exponent field
+    // never carry out of the top one): the two from the binade e by integer arithmetic on the exponent field (their low words are 0)
     const int cq = t >> 3, qd = t & 7;
     double ssum[D::NR], ssq[D::NR];
 #pragma unroll
     for (int r = 0; r < D::NR; r++) { ssum[r] = 0.0; ssq[r] = 0.0; }
     for (int c = t; c < D::C32; c += D::NT) {
-        const bool real = c < M + P;
+        const bool real = c < ncols;
+        const int e = real ? escale[c] : 0;
         colc[2 * c] = real ? shift[c] : 0.0;
-        reinterpret_cast<int*>(colc + 2 * c + 1)[0] = real ? escale[c] : 0;
+        reinterpret_cast<int*>(colc + 2 * c + 1)[0] = (int)(0x3ff80000u + ((unsigned)(21 + e) << 20));      // 1.5 2^(21 + e)
+        reinterpret_cast<int*>(colc + 2 * c + 1)[1] = (int)(0x3fef8000u + ((unsigned)e << 20));             // 0.984375 2^e
     }
-    if (t < 24) reinterpret_cast<unsigned int*>(rowfar0)[t] = 0u;            // both sets of far flags
+    for (int e2 = t; e2 < 8 * D::PLANE / 16; e2 += D::NT) reinterpret_cast<v4i*>(planes0)[e2] = v4i{0, 0, 0, 0};   // (the padding columns' bytes stay 0)
+    if (t < 36 + 64) reinterpret_cast<unsigned int*>(rowfar0)[t] = 0u;       // the three sets of far flags, the zero column
     for (int e2 = t; e2 < D::NBLK * 256; e2 += D::NT) out[e2] = 0.0;       // the flushes ADD into the record
     // this wave's tiles: the b-th (I, J >= I) super-block pair in row-major order, b = wave + 8 k
     int wI[D::TPW], wJ[D::TPW];
@@ -847,69 +862,108 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[k][o][r] = 0;
     // LDS-DMA: instruction d of a tile moves columns 4 d .. 4 d + 3; lane = 16 (column & 3) + p fetches row pair 2 p (p < 8) resp.
-    // 2 (p - 8) + 1: rows 4 q .. 4 q + 3 of a column sit at its bytes 16 q and 128 + 16 q.  Wave w issues d = w, w + 8, ...
+    // 2 (p - 8) + 1: rows 4 q .. 4 q + 3 of a column sit at its bytes 16 q and 128 + 16 q.  Wave w issues d = w, w + 8, ... < ndma:
+    // my_dma instructions per tile (the counted waits below go by it)
     const int dma_rp = ((lane & 7) << 1) | ((lane >> 3) & 1);
-    auto stage = [&](long long k) {                                             // the k-th tile of this work-group -> raw slot k % 3
-        const long long r = t0 + (g + k * G) * D::TRW + 2 * dma_rp;
+    const int my_dma = (ndma > wave) ? (ndma - wave + D::NW - 1) / D::NW : 0;
+    // (the slots and flag sets of the tiles are counted along by the loop: k % nraw with nraw a run-time number is a division
+    // sequence, and the first version of this loop spent a third of a step in such scalar arithmetic)
+    auto stage = [&](int k, int slot) {                                         // the k-th tile of this work-group -> raw slot k % nraw
+        const long long r = t0 + ((long long)g + (long long)k * G) * D::TRW + 2 * dma_rp;
         const long long rr = r > rmax ? rmax : r;                               // (a legal address for rows past the end: masked later)
-        unsigned char* dst = raw0 + (size_t)(k % D::NRAW) * D::RAW;
+        unsigned char* dst = raw0 + slot * rawb;
 #pragma unroll
         for (int j = 0; j < D::DPW; j++) {
             const int d = wave + D::NW * j, c = 4 * d + (lane >> 4);
-            if (d < D::NDMA) {
-                const double* p = (c < M) ? X + (size_t)c * ldx : (c < M + P) ? Y + (size_t)(c - M) * ldy : X;
+            if (d < ndma) {
+                const double* p = (c < M) ? X + (size_t)c * ldx : Y + (size_t)((c < ncols ? c : M) - M) * ldy;    // (a column past the last: fetched, never read)
                 dma16(p + rr, reinterpret_cast<double*>(dst + (size_t)d * 1024));
             }
         }
     };
-    auto convert = [&](long long k) {                                           // raw slot k % 3 -> the byte planes, far flags k & 1
-        const unsigned char* raw = raw0 + (size_t)(k % D::NRAW) * D::RAW;
-        unsigned char* rowfar = rowfar0 + (int)(k & 1) * 48;
-        const long long r = t0 + (g + k * G) * D::TRW + 4 * qd;
-        bool ok[4], far[4] = {false, false, false, false};
-#pragma unroll
-        for (int j = 0; j < 4; j++) ok[j] = (r + j >= r_begin) && (r + j < r_end);
-        d2 va[D::NR], vb[D::NR];
+    // at most `tiles` of this wave's staged tiles still in flight (the immediates: my_dma is 3, 4 or 5 for 113 .. 160 columns)
+    auto wait_in_flight = [&](int tiles) {
+        const int nout = tiles * my_dma;
+        if (nout == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nout == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (nout == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (nout == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (nout == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (nout == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nout == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto convert = [&](int k, int slot, int fset) {                             // raw slot k % nraw -> byte planes k & 1, far flags k % 3
+        const unsigned char* raw = raw0 + slot * rawb;
+        unsigned char* planes = planes0 + (k & 1) * 4 * D::PLANE;
+        unsigned char* rowfar = rowfar0 + fset * 48;
+        const long long tile = (long long)g + (long long)k * G, r = t0 + tile * D::TRW + 4 * qd;
+        const bool edge = tile == 0 || tile == ntiles - 1;                      // (uniform) only a partition's first and last tile hold rows outside it
+        bool far[4] = {false, false, false, false};
+        // (straight-line code over the rounds: a padding column reads zeros against a zero shift and stores zero bytes like any other,
+        // so the rounds' LDS reads can all be in flight before the first value is needed -- with a branch around each round a wave
+        // paid the LDS latency three times per tile)
 #pragma unroll
         for (int i = 0; i < D::NR; i++) {
+            if (64 * i + 8 * wave >= D::C32) continue;                         // (scalar: the last round of a 160-column set has 32 columns)
             const int c = 64 * i + cq;
-            if (c < D::C32) {                                                  // (wave-uniform: 64 i + t / 8 with C32 a multiple of 32)
-                va[i] = *reinterpret_cast<const d2*>(raw + (size_t)c * 256 + 16 * qd);
-                vb[i] = *reinterpret_cast<const d2*>(raw + (size_t)c * 256 + 128 + 16 * qd);
+            {
+                const unsigned char* src = (c < ncols) ? raw + c * 256 : zero256;
+                const d2 va = *reinterpret_cast<const d2*>(src + 16 * qd);
+                const d2 vb = *reinterpret_cast<const d2*>(src + 128 + 16 * qd);
+                const v4i cc = *reinterpret_cast<const v4i*>(colc + 2 * c);
+                const double sh = __hiloint2double(cc[1], cc[0]), magic = __hiloint2double(cc[2], 0), lim = __hiloint2double(cc[3], 0);
+                double z[4] = {va.x - sh, va.y - sh, vb.x - sh, vb.y - sh};
+                if (edge) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) z[j] = (r + j >= r_begin && r + j < r_end) ? z[j] : 0.0;      // (rows outside the partition: 0)
+                }
+                unsigned int bq[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    far[j] = far[j] || !(fabs(z[j]) <= lim);                   // (NaN: not in range)
+                    const unsigned int q = (unsigned int)__double_as_longlong(z[j] + magic);
+                    bq[j] = (q + 0x80808080u) ^ 0x80808080u;
+                }
+                ssum[i] += (z[0] + z[1]) + (z[2] + z[3]);
+                ssq[i] = fma(z[3], z[3], fma(z[2], z[2], fma(z[1], z[1], fma(z[0], z[0], ssq[i]))));
+                // 4 x 4 byte transpose: plane b gets byte b of the four rows' words (v_perm_b32: selector bytes 0-3 = the second operand)
+                const unsigned int l01 = __builtin_amdgcn_perm(bq[1], bq[0], 0x05010400u), h01 = __builtin_amdgcn_perm(bq[1], bq[0], 0x07030602u);
+                const unsigned int l23 = __builtin_amdgcn_perm(bq[3], bq[2], 0x05010400u), h23 = __builtin_amdgcn_perm(bq[3], bq[2], 0x07030602u);
+                unsigned char* dst = planes + (size_t)c * D::CS + 16 * ((qd >> 2) ^ ((c >> 2) & 1)) + 4 * (qd & 3);
+                *reinterpret_cast<unsigned int*>(dst) = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+                *reinterpret_cast<unsigned int*>(dst + (size_t)D::PLANE) = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+                *reinterpret_cast<unsigned int*>(dst + (size_t)2 * D::PLANE) = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+                *reinterpret_cast<unsigned int*>(dst + (size_t)3 * D::PLANE) = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
             }
         }
+        if (far[0] || far[1] || far[2] || far[3]) {
 #pragma unroll
-        for (int i = 0; i < D::NR; i++) {
-            const int c = 64 * i + cq;
-            if (c >= D::C32) continue;
-            const bool real = c < M + P;
-            const double sh = colc[2 * c];
-            const int e = reinterpret_cast<const int*>(colc + 2 * c + 1)[0];
-            const double magic = __hiloint2double((int)(0x3ff80000u + ((unsigned)(21 + e) << 20)), 0);       // 1.5 2^(21 + e)
-            const double lim = __hiloint2double((int)(0x3fef8000u + ((unsigned)e << 20)), 0);                // 0.984375 2^e
-            double z[4] = {va[i].x - sh, va[i].y - sh, vb[i].x - sh, vb[i].y - sh};
-            unsigned int bq[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                z[j] = (real && ok[j]) ? z[j] : 0.0;                           // (rows outside the partition, padding columns: 0)
-                far[j] = far[j] || !(fabs(z[j]) <= lim);                       // (NaN: not in range)
-                const unsigned int q = (unsigned int)__double_as_longlong(z[j] + magic);
-                bq[j] = (q + 0x80808080u) ^ 0x80808080u;
-            }
-            ssum[i] += (z[0] + z[1]) + (z[2] + z[3]);
-            ssq[i] = fma(z[3], z[3], fma(z[2], z[2], fma(z[1], z[1], fma(z[0], z[0], ssq[i]))));
-            // 4 x 4 byte transpose: plane b gets byte b of the four rows' words (v_perm_b32: selector bytes 0-3 = the second operand)
-            const unsigned int l01 = __builtin_amdgcn_perm(bq[1], bq[0], 0x05010400u), h01 = __builtin_amdgcn_perm(bq[1], bq[0], 0x07030602u);
-            const unsigned int l23 = __builtin_amdgcn_perm(bq[3], bq[2], 0x05010400u), h23 = __builtin_amdgcn_perm(bq[3], bq[2], 0x07030602u);
-            unsigned char* dst = planes + (size_t)c * D::CS + 4 * qd;
-            *reinterpret_cast<unsigned int*>(dst) = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
-            *reinterpret_cast<unsigned int*>(dst + (size_t)D::PLANE) = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
-            *reinterpret_cast<unsigned int*>(dst + (size_t)2 * D::PLANE) = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
-            *reinterpret_cast<unsigned int*>(dst + (size_t)3 * D::PLANE) = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+            for (int j = 0; j < 4; j++) if (far[j]) rowfar[4 * qd + j] = 1;
+            rowfar[32] = 1;
         }
+    };
+    // the byte products of a tile from plane set `buf`: lane -> column 32 I + lane % 32, rows 16 (lane / 32) .. + 15 of every plane
+    auto products = [&](int buf) {
+        const unsigned char* planes = planes0 + (size_t)buf * 4 * D::PLANE;
+        const int hoff = 16 * ((lane >> 5) ^ ((lane >> 2) & 1));
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (far[j]) rowfar[4 * qd + j] = 1;
-        if (far[0] || far[1] || far[2] || far[3]) rowfar[32] = 1;
+        for (int k = 0; k < D::TPW; k++) {
+            if (wI[k] < 0) continue;                                           // (wave-uniform)
+            v4i fa[4];
+            const unsigned char* pa = planes + (size_t)(32 * wI[k] + (lane & 31)) * D::CS + hoff;
+            const unsigned char* pb = planes + (size_t)(32 * wJ[k] + (lane & 31)) * D::CS + hoff;
+#pragma unroll
+            for (int b = 0; b < 4; b++) fa[b] = *reinterpret_cast<const v4i*>(pa + (size_t)b * D::PLANE);
+            // order o = b + b' - 2: (2,0)(1,1)(0,2) | (3,0)(2,1)(1,2)(0,3) | (3,1)(2,2)(1,3) | (3,2)(2,3) | (3,3)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; b2++) {
+                const v4i fb = *reinterpret_cast<const v4i*>(pb + (size_t)b2 * D::PLANE);
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (b + b2 >= 2) acc[k][b + b2 - 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[b], fb, acc[k][b + b2 - 2], 0, 0, 0);
+            }
+        }
     };
     // flush of the i32 accumulators into this work-group's partial record (fp64): tile (I, J), order o = b + b' - 3 carries weight
     // 2^(8 o) 2^(e_a + e_b - 62 + 24); a 32 x 32 tile is up to four 16 x 16 blocks of the record, stored in the f64 MFMA's C layout
@@ -919,11 +973,11 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
             if (wI[k] < 0) continue;
             const int I = wI[k], J = wJ[k];
             const int ncol = 32 * J + (lane & 31);                            // this lane's column of the tile
-            const int eb = (ncol < M + P) ? escale[ncol] : 0;
+            const int eb = (ncol < ncols) ? escale[ncol] : 0;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int mrow = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int ea = (mrow < M + P) ? escale[mrow] : 0;
+                const int ea = (mrow < ncols) ? escale[mrow] : 0;
                 const double val = ldexp(((double)acc[k][4][r] * 4294967296.0 + (double)acc[k][3][r] * 16777216.0) +
                                          ((double)acc[k][2][r] * 65536.0 + ((double)acc[k][1][r] * 256.0 + (double)acc[k][0][r])), ea + eb - 62 + 16);
                 const int bi = mrow >> 4, bj = ncol >> 4;
@@ -940,27 +994,40 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the record's loads and stores out of the DMA count)
     };
     __syncthreads();
-    if (nmine > 0) stage(0);
-    if (nmine > 1) stage(1);
-    if (nmine > 2) stage(2);
+    const int npre = nmine < nraw ? nmine : nraw;
+    for (int k = 0; k < npre; k++) stage(k, k);
+    if (nmine > 0) {                                                           // tile 0 -> plane set 0
+        wait_in_flight(npre - 1);
+        __syncthreads();
+        if (!(abl & 1)) convert(0, 0, 0);
+    }
+    int slot_i = 0, fset_i = 0;                                                // i % nraw, i % 3
     // (two loops: the accumulators are flushed between runs of FLUSH tiles -- the flush stays out of the inner loop's register budget)
-    for (long long i0 = 0; i0 < nmine; i0 += D::FLUSH) {
-        const long long i1 = (i0 + D::FLUSH < nmine) ? i0 + D::FLUSH : nmine;
+    for (int i0 = 0; i0 < nmine; i0 += D::FLUSH) {
+        const int i1 = (i0 + D::FLUSH < nmine) ? i0 + D::FLUSH : nmine;
 #pragma unroll 1
-        for (long long i = i0; i < i1; i++) {
-            // (1) the own DMAs of tile i have landed (those of tiles i + 1 and i + 2 may stay in flight), then everybody's
-            if (i + 2 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D::DPW) : "memory");
-            else if (i + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::DPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                                   // (also: every wave is done with the MFMAs of tile i - 1)
-            // (2) tile i -> bytes
-            unsigned char* rowfar = rowfar0 + (int)(i & 1) * 48;
-            const long long tile = g + i * G, row0 = t0 + tile * D::TRW;
-            convert(i);
-            __syncthreads();                                                   // the planes are complete, tile i's raw slot is free
-            // (3) refill the slot with tile i + 3; far rows; the byte products of tile i
-            if (i + 3 < nmine) stage(i + 3);
-            if (wave == 0) {                                                   // tile i's far rows as a mask (always written: no memset)
+        for (int i = i0; i < i1; i++) {
+            const int slot_n = (slot_i + 1 == nraw) ? 0 : slot_i + 1, fset_n = (fset_i == 2) ? 0 : fset_i + 1;     // tile i + 1's
+            // (1) the own DMAs of tile i + 1 have landed (the staged tiles behind it may stay in flight), then everybody's; the barrier
+            //     also says: tile i's planes and far flags are complete, every wave is done with the MFMAs of tile i - 1 (the other
+            //     plane set is free) and with tile i's raw slot
+            if (nraw == 3 && i + 2 < nmine) {                                   // (the steady state, without the general case's chain of compares)
+                if (my_dma == D::DPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::DPW) : "memory");
+                else if (my_dma == D::DPW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D::DPW - 1) : "memory");
+                else wait_in_flight(1);
+            } else {
+                const int last = (i + nraw - 1 < nmine - 1) ? i + nraw - 1 : nmine - 1;     // last tile staged so far
+                wait_in_flight(last > i + 1 ? last - (i + 1) : 0);
+            }
+            __syncthreads();
+            const unsigned char any_far = rowfar0[fset_i * 48 + 32];           // (read here, needed behind the refill)
+            // (2) tile i's far rows; refill tile i's raw slot with tile i + nraw.  (In this order: the mask's store counts in vmcnt like the
+            //     DMAs, and issued BEHIND the refill it made wave 0's next counted wait -- "all but the newest tile's" -- wait for one
+            //     DMA of the tile just requested, a full memory latency in every step with seven waves waiting at the barrier: rounds 4's
+            //     order, and most of what kept that kernel from overlapping its refills with its arithmetic)
+            unsigned char* rowfar = rowfar0 + fset_i * 48;
+            const long long tile = (long long)g + (long long)i * G, row0 = t0 + tile * D::TRW;
+            if (wave == D::NW - 1) {                                           // tile i's far rows as a mask (always written: no memset); the wave with the least else to do
                 const unsigned long long m = __ballot(lane < 32 && rowfar[lane & 31] != 0 && row0 + lane >= r_begin && row0 + lane < r_end);
                 if (lane == 0) {
                     far_mask[(size_t)part * tmax + tile] = m;
@@ -969,34 +1036,25 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
                         far_sum[(size_t)2 * ((tmax + 63) / 64)] = 1ull;        // (k_gram_far's way out when nothing is far)
                     }
                 }
-                // the other set of flags, for tile i + 1: its readers (tile i - 1) passed this iteration's first barrier, its writers
-                // have to pass the next iteration's
-                if (lane < 12) reinterpret_cast<unsigned int*>(rowfar0 + (int)((i + 1) & 1) * 48)[lane] = 0u;
+                // the set of flags tile i + 2 will use: its last readers (tile i - 1) passed this step's barrier, its writers (the
+                // conversion of tile i + 2, next step) have to pass the next one
+                if (lane < 12) reinterpret_cast<unsigned int*>(rowfar0 + ((fset_n == 2) ? 0 : fset_n + 1) * 48)[lane] = 0u;
             }
-            if (rowfar[32]) {                                                  // (uniform) rare: zero the far rows' bytes
+            if (i + nraw < nmine && !(abl & 4)) stage(i + nraw, slot_i);
+            if (any_far) {                                                     // (uniform) rare: zero the far rows' bytes
+                unsigned char* planes = planes0 + (i & 1) * 4 * D::PLANE;
                 for (int e2 = t; e2 < 4 * D::C32 * 32; e2 += D::NT) {
                     const int r = e2 & 31, c = (e2 >> 5) % D::C32, b = e2 / (32 * D::C32);
-                    if (rowfar[r]) planes[(size_t)b * D::PLANE + (size_t)c * D::CS + r] = 0;
+                    if (rowfar[r]) planes[(size_t)b * D::PLANE + (size_t)c * D::CS + 16 * ((r >> 4) ^ ((c >> 2) & 1)) + (r & 15)] = 0;
                 }
                 __syncthreads();
             }
-#pragma unroll
-            for (int k = 0; k < D::TPW; k++) {
-                if (wI[k] < 0) continue;                                       // (wave-uniform)
-                v4i fa[4];
-                const unsigned char* pa = planes + (size_t)(32 * wI[k] + (lane & 31)) * D::CS + 16 * (lane >> 5);
-                const unsigned char* pb = planes + (size_t)(32 * wJ[k] + (lane & 31)) * D::CS + 16 * (lane >> 5);
-#pragma unroll
-                for (int b = 0; b < 4; b++) fa[b] = *reinterpret_cast<const v4i*>(pa + (size_t)b * D::PLANE);
-                // order o = b + b' - 2: (2,0)(1,1)(0,2) | (3,0)(2,1)(1,2)(0,3) | (3,1)(2,2)(1,3) | (3,2)(2,3) | (3,3)
-#pragma unroll
-                for (int b2 = 0; b2 < 4; b2++) {
-                    const v4i fb = *reinterpret_cast<const v4i*>(pb + (size_t)b2 * D::PLANE);
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (b + b2 >= 2) acc[k][b + b2 - 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[b], fb, acc[k][b + b2 - 2], 0, 0, 0);
-                }
-            }
+            // (3) the byte products of tile i and the conversion of tile i + 1, in opposite orders on the two waves of a SIMD
+            const bool conv = i + 1 < nmine && !(abl & 1);
+            if (conv && wave >= 4) convert(i + 1, slot_n, fset_n);
+            if (!(abl & 2)) products(i & 1);                                   // (one call site: the accumulators stay in their registers)
+            if (conv && wave < 4) convert(i + 1, slot_n, fset_n);
+            slot_i = slot_n; fset_i = fset_n;
         }
         if (i1 < nmine) flush();                                               // (rare: more than FLUSH tiles in this work-group)
     }
@@ -1319,14 +1377,16 @@ int run_gram_i8(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t
     unsigned long long* far_mask = (unsigned long long*)abc_ws_alloc(ctx, (size_t)2 * tmax * 8);
     unsigned long long* far_sum = (unsigned long long*)abc_ws_alloc(ctx, (2 * sumw + 1) * 8);
     if (!partial || !escale || !far_mask || !far_sum) ABC_FAIL(ctx, ABC_ERR_NOMEM, "gram: workspace exhausted (%zu B)", pbytes);
-    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_i8<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D::LDS_B));
+    const int lds_b = D::lds_bytes((int)(M + P)), nraw = D::raw_tiles((int)(M + P));
+    ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_i8<C, CY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+    static const int abl = abc_diag_env("ABC_GRAM_ABL") ? atoi(abc_diag_env("ABC_GRAM_ABL")) : 0;      // (phases left out: timings only)
     {
         StageTimer tm(ctx, ctx->in_mvn ? -1 : ST_GRAM);
         hipLaunchKernelGGL(k_pilot_scale, dim3((unsigned)D::C16), dim3(1024), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P, (long long)n,
                            (const double*)(stats + L.off_shift), escale);
         ABC_HIP(ctx, hipMemsetAsync(far_sum, 0, (2 * sumw + 1) * 8, ctx->stream));
-        hipLaunchKernelGGL((k_gram_i8<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), (size_t)D::LDS_B, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
-                           (long long)n, split, (const double*)(stats + L.off_shift), (const int*)escale, partial, far_mask, far_sum, tmax);
+        hipLaunchKernelGGL((k_gram_i8<C, CY>), dim3((unsigned)G, 2), dim3(D::NT), (size_t)lds_b, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
+                           (long long)n, split, (const double*)(stats + L.off_shift), (const int*)escale, partial, far_mask, far_sum, tmax, nraw, abl);
         hipLaunchKernelGGL((k_gram_far<C, CY>), dim3((unsigned)(D::NBLK + 1), 2), dim3(256), 0, ctx->stream, X, Y, ldx, ldy, (int)M, (int)P,
                            (long long)n, split, (const double*)(stats + L.off_shift), partial, (int)G, (const unsigned long long*)far_mask,
                            (const unsigned long long*)far_sum, tmax);
