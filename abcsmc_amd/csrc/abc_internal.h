@@ -55,7 +55,7 @@ struct abc_ctx {
     // run there from the first launch on, beside the ranking chain (abc_rng_streams_early); ev_fork / ev_side order them
     hipStream_t side;
     hipStream_t wx_stream;             // the Wilcoxon reduction of a fused generation, beside the ranking that speculates on its outcome
-    hipEvent_t ev_wx_fork, ev_wx_done;
+    hipEvent_t ev_wx_fork, ev_wx_done, ev_wx_scores;
     hipEvent_t ev_fork, ev_side, ev_prev;
     hipEvent_t ev_theta, ev_moments;   // the posterior's moments on the side stream: start (rows gathered) and end
     bool side_forked;      // ev_fork of the current generation is recorded (abc_side_fork); cleared when the generation ends
@@ -82,6 +82,7 @@ struct abc_ctx {
     int* sel_fail_dev;       // device: the sampled-range bin selection gave up (select.hip); read by abc_select_check
     bool sel_bins_ran;       // the last launch_select_smallest took the bin path and has not been checked yet
     bool sel_force_radix;    // set by a caller that repeats its work after a failed bin selection
+    bool wx_force_inline;    // set by a generation that repeats itself after its speculation on the component count failed: the Wilcoxon reduction in stream order
     bool wx_gather_rows;     // diagnostic (ABC_DIAG=1 ABC_WX_GATHER=1, set at context creation): the sharded generation's Wilcoxon rule by
                              // gathering the validation rows on every rank (rounds 1-4) instead of the sharded cascade
     bool in_mvn;   // the covariance pass reuses k_gram: keep it out of the k_gram stage timer
@@ -218,6 +219,10 @@ int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, siz
                             size_t A, const double* model, int simple, double* dist);
 // scores of n rows (all A components) by the projection kernels: S[i + n k]; returns the rows taken (an even count, 0: not their shape)
 size_t launch_project_scores(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model, double* S);
+// the ranking's projection and the validation scores (rows from row_test on: S[i - row_test + sld k]) in one pass over X;
+// 0: queued, 1: not a shape for it, nothing queued
+int launch_project_distance_scores(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model,
+                                   double* dist, double* S, size_t sld, size_t row_test);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out, bool defer_check = false);
 int abc_select_check(abc_ctx* ctx, int* failed);
@@ -278,8 +283,13 @@ int launch_wilcoxon(abc_ctx*, const double* X, const double* Y, size_t n, size_t
 int launch_wilcoxon_commit(abc_ctx*, double* model, size_t M, size_t P, size_t A, const double* dec, int with_hdr);
 // the cascade in two halves, for a caller with work to queue between them (the fused generation: api.hip)
 struct abc_wx_run;
+// scores: the caller has a pass over X of its own to queue (the ranking's projection) and lets it write the validation scores
+// too: fn(arg, S, sld) queues that pass, makes the context's (= the cascade's) stream wait for it and returns 0 -- or returns 1
+// without queueing anything, and the cascade scores the rows itself
+struct abc_wx_scores_hook { int (*fn)(void* arg, double* S, size_t sld); void* arg; };
 int launch_wilcoxon_begin(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
-                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out);
+                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out,
+                          const abc_wx_scores_hook* scores = nullptr);
 int launch_wilcoxon_finish(abc_ctx*, abc_wx_run* run, int* changed_host);
 void launch_wilcoxon_abandon(abc_ctx*, abc_wx_run* run, hipStream_t its_stream);
 // collectives on the context's stream and the exchange buffer (sharded.hip)

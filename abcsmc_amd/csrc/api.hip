@@ -108,7 +108,7 @@ extern "C" void abc_ctx_destroy(abc_ctx* ctx) {
     if (ctx->xbuf) (void)hipFree(ctx->xbuf);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_theta) { (void)hipEventDestroy(ctx->ev_theta); (void)hipEventDestroy(ctx->ev_moments); }
-    if (ctx->wx_stream) { (void)hipStreamSynchronize(ctx->wx_stream); (void)hipStreamDestroy(ctx->wx_stream); (void)hipEventDestroy(ctx->ev_wx_fork); (void)hipEventDestroy(ctx->ev_wx_done); }
+    if (ctx->wx_stream) { (void)hipStreamSynchronize(ctx->wx_stream); (void)hipStreamDestroy(ctx->wx_stream); (void)hipEventDestroy(ctx->ev_wx_fork); (void)hipEventDestroy(ctx->ev_wx_done); (void)hipEventDestroy(ctx->ev_wx_scores); }
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_side); if (ctx->ev_prev) (void)hipEventDestroy(ctx->ev_prev); }
     for (int i = 0; i < 256; i++) if (ctx->ev[i].a) { (void)hipEventDestroy(ctx->ev[i].a); (void)hipEventDestroy(ctx->ev[i].b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -573,18 +573,20 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     static const int wx_inline = abc_diag_env("ABC_WX_INLINE") ? 1 : 0;                  // A/B switch for measurements
     const bool wx_rule = !simple && cfg->rule == ABC_RULE_WILCOXON;
     const size_t nvalid = N > (size_t)ntrain ? N - (size_t)ntrain : 0;
-    const bool wx_spec = wx_rule && io->w && K && !wx_inline && abc_wx_cascade_applies(nvalid, P, A);
+    const bool wx_spec = wx_rule && io->w && K && !wx_inline && !ctx->wx_force_inline && abc_wx_cascade_applies(nvalid, P, A);
     double* wx_dec = nullptr;
     abc_wx_run* wx_run = nullptr;
     struct WxGuard {          // an error return between the cascade's halves: its kernels still write into this call's arena
         abc_ctx* c; abc_wx_run** r;
         ~WxGuard() { if (*r) { launch_wilcoxon_abandon(c, *r, c->wx_stream); *r = nullptr; } }
     } wx_guard = {ctx, &wx_run};
+    bool projected = false;                              // the ranking's projection queued by the cascade's first half (below)
     if (wx_spec) {
         if (!ctx->wx_stream) {
             ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
             ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_fork, abc_xstream_event_flags()));
             ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_done, abc_xstream_event_flags()));
+            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_scores, abc_xstream_event_flags()));
         }
         wx_dec = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!wx_dec) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
@@ -592,14 +594,34 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, ctx->ev_wx_fork, 0));
         // its first half -- plan, scores, the level-0 sweep and bounds -- is queued BEFORE the ranking (the host needs ~60 us to queue
         // the ranking's eight launches: the cascade started that much late behind them, rocprofv3 timeline)
+        // ONE pass over X for both: the ranking's projection (main stream) also writes the validation rows' scores, all A
+        // components, and the cascade's sweeps wait for it -- as two launches the validation half of X was read twice and the
+        // second pass (51 us at configs[2]) ran beside the selection's kernels
         hipStream_t main_stream = ctx->stream;
+        struct ScoresArg { abc_ctx* ctx; hipStream_t main; const double* X; size_t N, M, P, A, ntrain; const double* model; double* dist; }
+            sarg = {ctx, main_stream, io->X, N, M, P, A, (size_t)ntrain, model, dist};
+        abc_wx_scores_hook hook = {
+            [](void* a, double* S, size_t sld) -> int {
+                ScoresArg* q = (ScoresArg*)a;
+                abc_ctx* c = q->ctx;
+                hipStream_t wx = c->stream;
+                c->stream = q->main;
+                int rc = launch_project_distance_scores(c, q->X, q->N, q->N, q->M, q->P, q->A, q->model, q->dist, S, sld, q->ntrain);
+                if (rc == 0 && hipEventRecord(c->ev_wx_scores, q->main) != hipSuccess) rc = ABC_ERR_HIP;
+                c->stream = wx;
+                if (rc == 0 && hipStreamWaitEvent(wx, c->ev_wx_scores, 0) != hipSuccess) rc = ABC_ERR_HIP;
+                if (rc == 0) q->dist = nullptr;          // (taken)
+                return rc;
+            },
+            &sarg};
         ctx->stream = ctx->wx_stream;
-        const int rcb = launch_wilcoxon_begin(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, wx_dec, /*stop_at_max=*/1, &wx_run);
+        const int rcb = launch_wilcoxon_begin(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, wx_dec, /*stop_at_max=*/1, &wx_run, &hook);
         ctx->stream = main_stream;
         ABC_TRY(rcb);
+        projected = sarg.dist == nullptr;
     } else if (wx_rule)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
-    ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
+    if (!projected) ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/io->w != nullptr));
     if (!simple && ncomp_host && !io->w) {
@@ -647,7 +669,14 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const bool theta_ev_bound = moments_side_planned && !ev_marker;
     ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
                                theta_ev_bound ? ctx->ev_theta : nullptr));
-    if (wx_spec) {
+    // Where the cascade's second half goes.  A generation with pair sums to compute (a previous set) DEFERS it: the weight stage
+    // needs the gathered rows, not the component counts, so it is queued first and the host's looks at the cascade's levels -- and
+    // the levels themselves -- happen beside the pair sums; if the largest count then turns out to have moved, everything queued on
+    // the fit's count is thrown away and the generation runs once more with the reduction in stream order.  A set without pair sums
+    // has nothing to hide the cascade behind: the second half follows the gather, and a moved count repeats the ranking only.
+    static const int wx_finish_early = abc_diag_env("ABC_WX_FINISH_EARLY") ? 1 : 0;     // A/B switch for measurements
+    const bool wx_defer = wx_spec && weighted && !wx_finish_early;
+    if (wx_spec && !wx_defer) {
         // the reduction itself, on its own stream, while the ranking queued above runs (the host's looks at the cascade's level
         // counts happen here, beside GPU work that does not depend on them)
         hipStream_t main_stream = ctx->stream;
@@ -682,19 +711,24 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // the radix select.  Weighted generations learn of it at the host's wait for the weights (launch_resample's abort flag),
     // before the alias table, the draws and the proposals of the placeholder are queued; set 0 has no host wait before its
     // end and finds out there.  Either way the proposals' give-up counter is put back to its snapshot.
-    auto repeat_with_radix = [&]() -> int {
+    auto repeat_generation = [&](bool radix, bool wx_in_order) -> int {
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->side) ABC_HIP(ctx, hipStreamSynchronize(ctx->side));
+        if (ctx->wx_stream) ABC_HIP(ctx, hipStreamSynchronize(ctx->wx_stream));
         if (ctx->giveups_dev)
             ABC_HIP(ctx, hipMemcpyAsync(ctx->giveups_dev, ctx->giveups_dev + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
         ctx->sel_bins_ran = false;
         ctx->ws_off = ws_entry;
         if (rng) *rng = rng_entry;
-        ctx->sel_force_radix = true;
+        const bool radix0 = ctx->sel_force_radix, inline0 = ctx->wx_force_inline;      // (a repeat inside a repeat keeps the outer one's reason)
+        ctx->sel_force_radix = radix0 || radix;
+        ctx->wx_force_inline = inline0 || wx_in_order;
         const int rc = generation_core(ctx, cfg, io, rng, ncomp_host, simple, model_out);
-        ctx->sel_force_radix = false;
+        ctx->sel_force_radix = radix0;
+        ctx->wx_force_inline = inline0;
         return rc;
     };
+    auto repeat_with_radix = [&]() -> int { return repeat_generation(true, false); };
     double* dv = io->dv ? io->dv : (double*)abc_ws_alloc(ctx, P * 8);
     double* theta_stats = nullptr;        // moments of the posterior: shared by dv and the MVN factor
     // Weighted generations with proposals: the kernel density of the weights uses the PREVIOUS set's variance, so the new set's
@@ -762,6 +796,21 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ABC_HIP(ctx, hipEventRecord(ctx->ev_moments, ctx->side));
         theta_stats = st;
         moments_on_side = true;
+    }
+    if (wx_defer) {
+        // the cascade's second half (see above): the weight stage and the posterior's moments are queued, the pair sums run
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->wx_stream;
+        int changed = 2;
+        int rc = launch_wilcoxon_finish(ctx, wx_run, &changed);
+        wx_run = nullptr;
+        if (rc == ABC_OK && hipEventRecord(ctx->ev_wx_done, ctx->wx_stream) != hipSuccess) rc = ABC_ERR_HIP;
+        ctx->stream = main_stream;
+        // the largest count moved (or a bin of the exact step outgrew LDS: massive ties): what was queued ranked on the wrong count
+        if (rc == ABC_INTERNAL_RETRY || (rc == ABC_OK && changed)) return repeat_generation(false, true);
+        if (rc != ABC_OK) { if (!ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "generation: the component rule's reduction failed"); return rc; }
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wx_done, 0));
+        ABC_TRY(launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, 0));
     }
     int spd = 0;
     bool have_spd = false;

@@ -64,18 +64,22 @@ __global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restr
                                                            const double* __restrict__ mean, const double* __restrict__ sd,
                                                            const double* __restrict__ model, size_t off_R, size_t off_oscore,
                                                            double* __restrict__ dist, double* __restrict__ Sout = nullptr, size_t sld = 0,
-                                                           int nc_force = 0) {
-    // Sout (round 5, the Wilcoxon reduction's validation scores): instead of the distance, the first nc_force scores of every row
-    // go to Sout[row + sld k] -- the same fma chains, hence the bits the distances are made of
+                                                           int nc_force = 0, size_t row_split = 0) {
+    // Sout (round 5, the Wilcoxon reduction's validation scores): the first nc_force scores of every row from row_split (an even
+    // number) on go to Sout[row - row_split + sld k] -- the same fma chains, hence the bits the distances are made of.  Without
+    // dist that is all (the rule's own pass); with dist the launch is the ranking's projection AND the rule's: all nc_force
+    // components are scored, the distance takes the first model[0] of them (a term beyond those is fma(0, 0, d) = d whether its
+    // score is a padding zero or switched off here: the same bits as the distance-only launch)
     extern __shared__ double Rl[];                                       // M*KC + KC
     double* const opad = Rl + (size_t)M * KC;
+    const int ncomp_dist = dist ? (int)model[0] : 0;
     {   // the zero-padded loadings and observed scores straight from the model (what k_pad_model writes for the other kernels)
-        const int ncomp = Sout ? nc_force : (int)model[0];
+        const int ncomp = Sout ? nc_force : ncomp_dist;
         for (int e = threadIdx.x; e < M * KC; e += 256) {
             const int m = e / KC, k = e % KC;
             Rl[e] = (k < ncomp) ? model[off_R + m + (size_t)M * k] : 0.0;
         }
-        if (threadIdx.x < KC) opad[threadIdx.x] = (threadIdx.x < ncomp) ? model[off_oscore + threadIdx.x] : 0.0;
+        if (threadIdx.x < KC) opad[threadIdx.x] = (threadIdx.x < ncomp_dist) ? model[off_oscore + threadIdx.x] : 0.0;
     }
     __syncthreads();
     constexpr int PF = 4, H = KC / 4;                                    // H: 16-byte reads per half row of loadings
@@ -142,15 +146,18 @@ __global__ __launch_bounds__(256) void k_project_dist2_lds(const double* __restr
             chunk(xb, m0 + PF);
         }
         if (Sout) {
+            if (2 * i >= row_split) {
 #pragma unroll
-            for (int k = 0; k < KC; k++)
-                if (k < nc_force) *reinterpret_cast<d2*>(Sout + 2 * i + sld * (size_t)k) = (d2){s0[k], s1[k]};
-            continue;
+                for (int k = 0; k < KC; k++)
+                    if (k < nc_force) *reinterpret_cast<d2*>(Sout + (2 * i - row_split) + sld * (size_t)k) = (d2){s0[k], s1[k]};
+            }
+            if (!dist) continue;
         }
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll
         for (int k = 0; k < KC; k++) {
-            const double t0 = s0[k] - opad[k], t1 = s1[k] - opad[k];
+            const bool on = !Sout || k < ncomp_dist;                             // (uniform; without Sout the padding zeros do it)
+            const double t0 = on ? s0[k] - opad[k] : 0.0, t1 = on ? s1[k] - opad[k] : 0.0;
             d0 = fma(t0, t0, d0);
             d1 = fma(t1, t1, d1);
         }
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__
                                                       const double* __restrict__ mean, const double* __restrict__ sd,
                                                       const double* __restrict__ model, size_t off_R, size_t off_oscore,
                                                       double* __restrict__ dist, int lds_main /* doubles in front of the observed scores */,
-                                                      double* __restrict__ Sout = nullptr, size_t sld = 0, int nc_force = 0) {
+                                                      double* __restrict__ Sout = nullptr, size_t sld = 0, int nc_force = 0,
+                                                      size_t row_split = 0) {
     constexpr int KC = 16 * KT, SROW = KC + 1, PF = 8;
     extern __shared__ double lds[];
     const int M4 = (M + 3) & ~3;
@@ -185,13 +193,14 @@ __global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__
     double* const sg = mu + M4;                          // M4 (0: the metric takes no part -- zero variance or padding)
     double* const op = lds + lds_main;                   // KC observed scores, behind everything the epilogue overlays
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
-    const int ncomp = Sout ? nc_force : (int)model[0];          // (Sout: the scores themselves, as k_project_dist2_lds)
+    const int ncomp_dist = dist ? (int)model[0] : 0;
+    const int ncomp = Sout ? nc_force : ncomp_dist;             // (Sout, row_split, Sout beside dist: as k_project_dist2_lds)
     for (int e = t; e < M4 * KC; e += 256) {
         const int m = e / KC, k = e % KC;
         Rl[e] = (m < M && k < ncomp) ? model[off_R + m + (size_t)M * k] : 0.0;
     }
     for (int m = t; m < M4; m += 256) { mu[m] = (m < M) ? mean[m] : 0.0; sg[m] = (m < M) ? sd[m] : 0.0; }
-    if (t < KC) op[t] = (t < ncomp) ? model[off_oscore + t] : 0.0;
+    if (t < KC) op[t] = (t < ncomp_dist) ? model[off_oscore + t] : 0.0;
     __syncthreads();
     const size_t base = ((size_t)blockIdx.x * 4 + wave) * 64;
     const double* xr[2];
@@ -251,14 +260,14 @@ __global__ __launch_bounds__(256) void k_project_mfma(const double* __restrict__
     __syncthreads();
     if (Sout) {
         const size_t p = base + lane;
-        if (p < n)
-            for (int k = 0; k < nc_force; k++) Sout[p + sld * (size_t)k] = stage[(size_t)lane * SROW + k];
-        return;
+        if (p < n && p >= row_split)
+            for (int k = 0; k < nc_force; k++) Sout[(p - row_split) + sld * (size_t)k] = stage[(size_t)lane * SROW + k];
+        if (!dist) return;
     }
     double d2v = 0.0;
 #pragma unroll 8
     for (int k = 0; k < KC; k++) {
-        const double tt = stage[(size_t)lane * SROW + k] - op[k];
+        const double tt = (!Sout || k < ncomp_dist) ? stage[(size_t)lane * SROW + k] - op[k] : 0.0;
         d2v = fma(tt, tt, d2v);
     }
     const size_t p = base + lane;
@@ -505,4 +514,46 @@ size_t launch_project_scores(abc_ctx* ctx, const double* X, size_t n, size_t ldx
         hipLaunchKernelGGL(k_project_dist2_lds<16>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
                            model + ML.off_sd, model, ML.off_R, ML.off_oscore, (double*)nullptr, S, n, (int)A);
     return 2 * npairs;
+}
+
+// The ranking's projection AND the Wilcoxon reduction's validation scores in ONE pass over X (round 5: as two launches the
+// validation half of X was read twice, and the second read competed with the selection for the chip): dist as
+// launch_project_distance, S[i - row_test + sld k] = score k (all A components) of the rows from row_test on.
+// 0: done; 1: not a shape for it (nothing queued: the caller launches the two separately).
+int launch_project_distance_scores(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model,
+                                   double* dist, double* S, size_t sld, size_t row_test) {
+    static const bool off = abc_diag_env("ABC_PROJECT_SEPARATE") != nullptr;              // A/B switch for measurements
+    const ModelLayout ML = model_layout(M, P, A);
+    int KC = 1;
+    while (KC < (int)A) KC *= 2;
+    const bool vec_ok = (ldx % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)dist & 15) == 0) && (((uintptr_t)S & 15) == 0) &&
+                        n >= 2 && !(n & 1) && !(row_test & 1) && !(sld & 1) && row_test < n;
+    if (off || !vec_ok || (KC != 8 && KC != 16 && KC != 32)) return 1;
+    StageTimer tm(ctx, ST_PROJECT);
+    const size_t npairs = n / 2;
+    if (KC == 32) {
+        const size_t M4 = (M + 3) & ~(size_t)3;
+        const size_t mfma_main = (M4 * KC + 2 * M4 > (size_t)4 * 64 * (KC + 1)) ? M4 * KC + 2 * M4 : (size_t)4 * 64 * (KC + 1);
+        const size_t lb = (mfma_main + KC) * sizeof(double);
+        static const bool valu_only = abc_diag_env("ABC_PROJECT_VALU") != nullptr;
+        if (lb > 150 * 1024 || valu_only) return 1;
+        const unsigned gb = (unsigned)((n + 255) / 256);
+        ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_project_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+        hipLaunchKernelGGL(k_project_mfma<2>, dim3(gb), dim3(256), lb, ctx->stream, X, n, ldx, (int)M, model + ML.off_mean, model + ML.off_sd,
+                           model, ML.off_R, ML.off_oscore, dist, (int)mfma_main, S, sld, (int)A, row_test);
+        ABC_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    if ((M * KC + KC) * sizeof(double) > 64 * 1024) return 1;
+    size_t pblocks = (npairs + 255) / 256;
+    if (pblocks > 1024) pblocks = 1024;
+    const int lb = (int)((M * KC + KC) * sizeof(double));
+    if (KC == 8)
+        hipLaunchKernelGGL(k_project_dist2_lds<8>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
+                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, S, sld, (int)A, row_test);
+    else
+        hipLaunchKernelGGL(k_project_dist2_lds<16>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
+                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, S, sld, (int)A, row_test);
+    ABC_HIP(ctx, hipGetLastError());
+    return 0;
 }

@@ -1405,7 +1405,7 @@ static void wx_scores(abc_ctx* ctx, const double* X, size_t ldx, size_t row_test
 // *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
 struct abc_wx_run {
     abc_ctx* ctx; const double* X; const double* Y; size_t nt, ldx, ldy, M, P, A, row_test; double* model; abc_wx_shard shv; bool has_sh;
-    double* per_keep; double* dec; int stop_at_max;
+    double* per_keep; double* dec; int stop_at_max; const abc_wx_scores_hook* scores_hook;
     int Wr; bool sharded; size_t nvt, nseg_max, bc_bytes;
     WxPlan* plan; int *seg_j, *seg_a, *astar, *segbase, *fail; unsigned long long* nz; double* W; int* v3; unsigned int* kbase;
     int *actA, *actB, *nactv; unsigned int* tickets; int* slotmap; unsigned char* passb; double* S; unsigned int *c0, *blockcnt;
@@ -1480,7 +1480,12 @@ struct abc_wx_run {
         cl_fine_ld = 0;
         hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
                            segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt, per_keep);
-        if (nt) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
+        if (nt) {
+            int hooked = 1;                              // (1: the caller has no pass of its own for these rows)
+            if (scores_hook) hooked = scores_hook->fn(scores_hook->arg, S, nt);
+            if (hooked < 0) return hooked;
+            if (hooked) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
+        }
         ABC_HIP(ctx, hipGetLastError());
         return level_queue(0, 0, WX_NC0, actA, nactv, (int)nseg_max, actB, nactv + 1, c0, WX_NC0, 1);
     }
@@ -1652,7 +1657,7 @@ int launch_wilcoxon_commit(abc_ctx* ctx, double* model, size_t M, size_t P, size
 // counts, then the largest); the model record stays as the fit wrote it.  ABC_INTERNAL_RETRY from finish: a bin of the exact step
 // outgrew LDS -- the caller runs launch_wilcoxon in stream order instead.
 int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
-                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out) {
+                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out, const abc_wx_scores_hook* scores) {
     *out = nullptr;
     const size_t nt = n > row_test ? n - row_test : 0;
     if (!abc_wx_cascade_applies(nt, P, A) || !dec) ABC_FAIL(ctx, ABC_ERR_INVALID, "wilcoxon: not a set for the two-halves cascade");
@@ -1660,10 +1665,11 @@ int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t
     if (!run) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: host memory");
     memset((void*)run, 0, sizeof(*run));
     run->ctx = ctx; run->X = X; run->Y = Y; run->nt = nt; run->ldx = ldx; run->ldy = ldy; run->M = M; run->P = P; run->A = A; run->row_test = row_test;
-    run->model = model; run->has_sh = false; run->dec = dec; run->stop_at_max = stop_at_max;
+    run->model = model; run->has_sh = false; run->dec = dec; run->stop_at_max = stop_at_max; run->scores_hook = scores;
     run->per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
     int rc = run->per_keep ? ABC_OK : ABC_ERR_NOMEM;
     if (rc == ABC_OK) rc = run->begin();
+    run->scores_hook = nullptr;                          // (the caller's: not kept beyond this call)
     if (rc != ABC_OK) { delete run; if (rc == ABC_ERR_NOMEM && !ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "wilcoxon: workspace exhausted"); return rc; }
     *out = run;
     return ABC_OK;
