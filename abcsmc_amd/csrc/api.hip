@@ -583,6 +583,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     bool projected = false;                              // the ranking's projection queued by the cascade's first half (below)
     if (wx_spec) {
         if (!ctx->wx_stream) {
+            // (a stream of the device's highest priority was tried for it: the step got 0.02-0.03 ms longer at configs[2] and [4])
             ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
             ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_fork, abc_xstream_event_flags()));
             ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_done, abc_xstream_event_flags()));
@@ -676,6 +677,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // has nothing to hide the cascade behind: the second half follows the gather, and a moved count repeats the ranking only.
     static const int wx_finish_early = abc_diag_env("ABC_WX_FINISH_EARLY") ? 1 : 0;     // A/B switch for measurements
     const bool wx_defer = wx_spec && weighted && !wx_finish_early;
+    bool wx_tail_pending = false;
     if (wx_spec && !wx_defer) {
         // the reduction itself, on its own stream, while the ranking queued above runs (the host's looks at the cascade's level
         // counts happen here, beside GPU work that does not depend on them)
@@ -797,21 +799,6 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         theta_stats = st;
         moments_on_side = true;
     }
-    if (wx_defer) {
-        // the cascade's second half (see above): the weight stage and the posterior's moments are queued, the pair sums run
-        hipStream_t main_stream = ctx->stream;
-        ctx->stream = ctx->wx_stream;
-        int changed = 2;
-        int rc = launch_wilcoxon_finish(ctx, wx_run, &changed);
-        wx_run = nullptr;
-        if (rc == ABC_OK && hipEventRecord(ctx->ev_wx_done, ctx->wx_stream) != hipSuccess) rc = ABC_ERR_HIP;
-        ctx->stream = main_stream;
-        // the largest count moved (or a bin of the exact step outgrew LDS: massive ties): what was queued ranked on the wrong count
-        if (rc == ABC_INTERNAL_RETRY || (rc == ABC_OK && changed)) return repeat_generation(false, true);
-        if (rc != ABC_OK) { if (!ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "generation: the component rule's reduction failed"); return rc; }
-        ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wx_done, 0));
-        ABC_TRY(launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, 0));
-    }
     int spd = 0;
     bool have_spd = false;
     int alias_deferred = 0;
@@ -895,6 +882,31 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             taus2_jump(rng, 2 * (uint64_t)Nn);   // Nnext resampling draws + Nnext seeds
         }
     }
+    if (wx_defer) {
+        // the cascade's second half (see above): EVERYTHING of this generation is queued by now, the pair sums run.  (Queued in
+        // front of the resampling stage, first version, the host's waits for the cascade's levels -- whose kernels get hardly any
+        // CU while the pair sums' work-groups hold them all -- kept the resampling table from being queued in time: 0.34 ms of
+        // idle main stream behind the weights at configs[4], rocprofv3 timeline)
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->wx_stream;
+        int changed = 2;
+        int rc = launch_wilcoxon_finish(ctx, wx_run, &changed);
+        wx_run = nullptr;
+        if (rc == ABC_OK && hipEventRecord(ctx->ev_wx_done, ctx->wx_stream) != hipSuccess) rc = ABC_ERR_HIP;
+        ctx->stream = main_stream;
+        // the largest count moved (or a bin of the exact step outgrew LDS: massive ties): what was queued ranked on the wrong count
+        if (rc == ABC_INTERNAL_RETRY || (rc == ABC_OK && changed)) return repeat_generation(false, true);
+        if (rc != ABC_OK) { if (!ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "generation: the component rule's reduction failed"); return rc; }
+        // the per-response counts into the model record, on the cascade's own stream: nothing this generation still queues reads
+        // them (the largest count, which everything used, is the fit's), and on the main stream the launch sat between the
+        // normalised weights and the resampling table -- 16 us of the critical path (rocprofv3 timeline).  The host waits for that
+        // stream at the generation's end.
+        ctx->stream = ctx->wx_stream;
+        rc = launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, 0);
+        ctx->stream = main_stream;
+        ABC_TRY(rc);
+        wx_tail_pending = true;
+    }
     {
         // status words into the pinned block: [0..31] model header (component count), [32] Cholesky status, [36] selection flag
         double* hdr = (double*)ctx->status_pin;
@@ -915,6 +927,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         }
         ctx->side_early_waited = false;
         ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (wx_tail_pending) ABC_HIP(ctx, hipStreamSynchronize(ctx->wx_stream));
         if (status_early) {
             // header and Cholesky status came from k_post_tail, the selection's flag from the gather (bins_deferred), the proposals'
             // give-up counter is read only when a proposal kernel raised the flag word
