@@ -616,7 +616,10 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             },
             &sarg};
         ctx->stream = ctx->wx_stream;
-        const int rcb = launch_wilcoxon_begin(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, wx_dec, /*stop_at_max=*/1, &wx_run, &hook);
+        // (level 0's sweep is held back until the selection and the gather are queued: the sweep cannot start before the projection
+        // has ended anyway, and queued in front of them its three launches kept the selection from the main stream for ~65 us)
+        const int rcb = launch_wilcoxon_begin(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model, wx_dec, /*stop_at_max=*/1, &wx_run, &hook,
+                                              /*hold_level0=*/1);
         ctx->stream = main_stream;
         ABC_TRY(rcb);
         projected = sarg.dist == nullptr;
@@ -670,6 +673,13 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     const bool theta_ev_bound = moments_side_planned && !ev_marker;
     ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
                                theta_ev_bound ? ctx->ev_theta : nullptr));
+    if (wx_run) {                                        // level 0 of the cascade, behind the ranking's launches in host order
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->wx_stream;
+        const int rc0 = launch_wilcoxon_level0(ctx, wx_run);
+        ctx->stream = main_stream;
+        ABC_TRY(rc0);
+    }
     // Where the cascade's second half goes.  A generation with pair sums to compute (a previous set) DEFERS it: the weight stage
     // needs the gathered rows, not the component counts, so it is queued first and the host's looks at the cascade's levels -- and
     // the levels themselves -- happen beside the pair sums; if the largest count then turns out to have moved, everything queued on

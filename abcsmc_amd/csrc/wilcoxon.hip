@@ -1405,7 +1405,7 @@ static void wx_scores(abc_ctx* ctx, const double* X, size_t ldx, size_t row_test
 // *fail_host = 1 when a bin of the exact step outgrew LDS (the caller repeats the reduction on the sorted path).
 struct abc_wx_run {
     abc_ctx* ctx; const double* X; const double* Y; size_t nt, ldx, ldy, M, P, A, row_test; double* model; abc_wx_shard shv; bool has_sh;
-    double* per_keep; double* dec; int stop_at_max; const abc_wx_scores_hook* scores_hook;
+    double* per_keep; double* dec; int stop_at_max; const abc_wx_scores_hook* scores_hook; bool hold_level0, level0_queued;
     int Wr; bool sharded; size_t nvt, nseg_max, bc_bytes;
     WxPlan* plan; int *seg_j, *seg_a, *astar, *segbase, *fail; unsigned long long* nz; double* W; int* v3; unsigned int* kbase;
     int *actA, *actB, *nactv; unsigned int* tickets; int* slotmap; unsigned char* passb; double* S; unsigned int *c0, *blockcnt;
@@ -1487,10 +1487,18 @@ struct abc_wx_run {
             if (hooked) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
         }
         ABC_HIP(ctx, hipGetLastError());
+        level0_queued = false;
+        return hold_level0 ? ABC_OK : level0();
+    }
+    // level 0 (sweep, totals, bounds): part of begin(), or queued by the caller once its own launches are out (hold_level0)
+    int level0() {
+        if (level0_queued) return ABC_OK;
+        level0_queued = true;
         return level_queue(0, 0, WX_NC0, actA, nactv, (int)nseg_max, actB, nactv + 1, c0, WX_NC0, 1);
     }
 
     int finish(int* fail_host, int* changed_host) {
+        ABC_TRY(level0());
         hipStream_t st = ctx->stream;
         int left = 0;
         int* act_cur = actB;
@@ -1657,7 +1665,8 @@ int launch_wilcoxon_commit(abc_ctx* ctx, double* model, size_t M, size_t P, size
 // counts, then the largest); the model record stays as the fit wrote it.  ABC_INTERNAL_RETRY from finish: a bin of the exact step
 // outgrew LDS -- the caller runs launch_wilcoxon in stream order instead.
 int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
-                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out, const abc_wx_scores_hook* scores) {
+                          size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out, const abc_wx_scores_hook* scores,
+                          int hold_level0) {
     *out = nullptr;
     const size_t nt = n > row_test ? n - row_test : 0;
     if (!abc_wx_cascade_applies(nt, P, A) || !dec) ABC_FAIL(ctx, ABC_ERR_INVALID, "wilcoxon: not a set for the two-halves cascade");
@@ -1665,7 +1674,7 @@ int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t
     if (!run) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: host memory");
     memset((void*)run, 0, sizeof(*run));
     run->ctx = ctx; run->X = X; run->Y = Y; run->nt = nt; run->ldx = ldx; run->ldy = ldy; run->M = M; run->P = P; run->A = A; run->row_test = row_test;
-    run->model = model; run->has_sh = false; run->dec = dec; run->stop_at_max = stop_at_max; run->scores_hook = scores;
+    run->model = model; run->has_sh = false; run->dec = dec; run->stop_at_max = stop_at_max; run->scores_hook = scores; run->hold_level0 = hold_level0 != 0;
     run->per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
     int rc = run->per_keep ? ABC_OK : ABC_ERR_NOMEM;
     if (rc == ABC_OK) rc = run->begin();
@@ -1674,6 +1683,7 @@ int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t
     *out = run;
     return ABC_OK;
 }
+int launch_wilcoxon_level0(abc_ctx* ctx, abc_wx_run* run) { (void)ctx; return run->level0(); }
 int launch_wilcoxon_finish(abc_ctx* ctx, abc_wx_run* run, int* changed_host) {
     int failed = 0, changed = 0;
     const int rc = run->finish(&failed, &changed);
