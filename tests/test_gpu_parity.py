@@ -1531,9 +1531,11 @@ def _stats_record(gpu_ctx, X, Y, ntrain):
 
 
 @pytest.mark.parametrize("N,M,P,kind", [(200_000, 128, 16, "plain"), (400_000, 120, 8, "plain"), (231_073, 140, 20, "plain"),
-                                        (240_000, 128, 16, "spikes"), (240_000, 128, 16, "heavy"), (220_000, 113, 16, "constant")])
+                                        (240_000, 128, 16, "spikes"), (240_000, 128, 16, "heavy"), (220_000, 113, 16, "constant"),
+                                        (200_000, 144, 16, "plain"), (210_000, 112, 16, "spikes")])
 def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
-    """k_gram_i8 (round 4): the Gram of 113..160 columns (from 200000 rows) from four signed bytes per value on v_mfma_i32_32x32x32_i8.
+    """k_gram_i8 (round 4; round 5: four rows per thread in the conversion, two sets of byte planes, one barrier per tile -- 160 columns
+    leave LDS for two raw tiles instead of three, 128 columns are two whole conversion rounds): the Gram of 113..160 columns (from 200000 rows) from four signed bytes per value on v_mfma_i32_32x32x32_i8.
     Against numpy on the same shifted data: column sums and the diagonal (fp64 on the vector pipe) to rounding, the off-diagonal
     products -- exact integer arithmetic on values rounded to a 32-bit grid of 4 x a robust sample range, byte pairs below 2^-32 of the
     top pair dropped -- to 5e-10 of sqrt(G_aa G_bb) (it falls with the square root of the rows); with values far outside the sampled
@@ -1855,13 +1857,18 @@ def test_generation_config2_size_against_the_full_oracle(gpu_ctx, oracle):
     assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
 
 
-@pytest.mark.parametrize("M,P,A,noise,Kp", [(20, 5, 10, 2.0, 500), (16, 3, 8, 1.5, 0), (16, 6, 8, 0.0, 500)])
+@pytest.mark.parametrize("M,P,A,noise,Kp", [(20, 5, 10, 2.0, 500), (16, 3, 8, 1.5, 0), (16, 6, 8, 0.0, 500), (40, 4, 20, 1.0, 500),
+                                            (40, 4, 20, 2.0, 0)])
 def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, noise, Kp):
     """Whole generations on sets the Wilcoxon cascade takes run the ranking BESIDE the reduction, on the component count the fit wrote
-    (api.hip, round 5): with noisy responses the reduction lowers the largest count and projection, selection and gather run once
-    more with it; with clean ones it stands.  Either way every output equals the oracle's generation under the rule -- weighted and
-    first set -- and the count equals the oracle's, which in the noisy cases is below the argmin-PRESS count (checked: the
-    speculation is wrong there and has to be repaired)."""
+    (api.hip, round 5): the ranking's projection scores all A components in its one pass over X (the validation rows' scores go to
+    the cascade) and takes the distance over the fit's count.  With noisy responses the reduction lowers the largest count: a first
+    set repeats projection, selection and gather with it; a weighted generation, which has queued its weight stage and its proposals
+    on the fit's count by the time it looks at the cascade, throws them away and runs once more with the reduction in stream order.
+    With clean responses the count stands.  Either way every output equals the oracle's generation under the rule -- the parents too,
+    so the repeat starts from the generator's state at entry -- and the count equals the oracle's, which in the noisy cases is below
+    the argmin-PRESS count (checked: the speculation is wrong there and has to be repaired).  8 / 10 components: the vector
+    projection kernels; 20: the fp64 matrix-pipe one."""
     from abcsmc_amd import _lib, abcutil, device, synthetic
     N, K, Nn = 60_000, 2_000, 5_000
     wl = synthetic.Workload(M, P, 4713 if M == 20 else 4711)
