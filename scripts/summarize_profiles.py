@@ -52,7 +52,7 @@ def bench(cfg):
 cfgs = [c for c in (2, 3, 4, 5) if os.path.exists(G + 'bench_c%d.json' % c)]
 for c in cfgs:
     shutil.copy(find(G + '%s_c%d' % (sp, c), 'kernel_stats.csv'), 'profiles/%s_kernel_stats_config%d.csv' % (tag, c))
-    shutil.copy(G + 'bench_c%d.json' % c, 'profiles/%s_bench_config%d.json' % (tag, c))
+    open('profiles/%s_bench_config%d.json' % (tag, c), 'w').write(open(G + 'bench_c%d.json' % c).read().strip().splitlines()[-1] + '\n')   # (the JSON line: librccl prints a banner in front of it)
 
 # ---- HBM traffic per kernel -------------------------------------------------------------------------------------------------
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `python3 bench.py --config N --steps 2 "
@@ -220,11 +220,11 @@ for c in cfgs:
     if cfgd.get("pls_component_rule") != "wilcoxon":
         continue
     stw = stats(c)
-    if not any(k.startswith('k_wx_decide') for k in stw):
+    if not any(k.startswith('k_wx_plan') for k in stw):
         continue
     nv, M, P, A = cfgd["particles_per_gpu"] - int(round(cfgd["particles_per_gpu"] * cfgd["train_fraction"])), cfgd["metrics"], cfgd["params"], cfgd["pls_components"]
     T = ex.get("wilcoxon_tests")
-    gens = max(v[0] for k, v in stw.items() if k.startswith('k_wx_decide'))
+    gens = max(v[0] for k, v in stw.items() if k.startswith('k_wx_plan'))        # (one per generation; the cascade may end before k_wx_decide)
     rows, tot_ns = [], 0.0
     for k, (calls, ns) in sorted(stw.items()):
         if not k.startswith('k_wx_'):
@@ -232,7 +232,8 @@ for c in cfgs:
         per_gen = calls / gens
         tot_ns += ns * calls / gens
         a, kps = None, None
-        if k.startswith('k_wx_sweep') and k.rstrip('>').endswith(', 0'):          # level 0: every test's keys once
+        targs = [x.strip() for x in k[k.index('<') + 1:k.rindex('>')].split(',')] if '<' in k else []
+        if k.startswith('k_wx_sweep') and len(targs) >= 3 and targs[2] == '0':          # level 0 (MODE = 0): every test's keys once
             a = 8.0 * nv * (A + P)
             kps = round(T * nv / (ns * 1e-9), -6) if T else None
         rows.append({"kernel": k, "launches_per_generation": per_gen, "avg_us": round(ns / 1e3, 2), "algorithmic_bytes": a,
