@@ -583,7 +583,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     bool projected = false;                              // the ranking's projection queued by the cascade's first half (below)
     if (wx_spec) {
         if (!ctx->wx_stream) {
-            // (a stream of the device's highest priority was tried for it: the step got 0.02-0.03 ms longer at configs[2] and [4])
+            // (stream priorities were tried for it, highest and lowest: no effect on any config beyond the runs' spread)
             ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
             ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_fork, abc_xstream_event_flags()));
             ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_done, abc_xstream_event_flags()));
