@@ -675,6 +675,21 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                                theta_ev_bound ? ctx->ev_theta : nullptr));
     if (wx_run) {                                        // level 0 of the cascade, behind the ranking's launches in host order
         hipStream_t main_stream = ctx->stream;
+        // ... and, where its sweep is short enough to fit beside the resampling table and the proposals at the generation's end, behind
+        // the gather ON THE DEVICE too: a level sweep fills every CU with a 1024-thread work-group, the selection's kernels beside it
+        // waited for CUs (configs[3]: the 80 MB histogram pass took 1.4 ms beside a 1.4 ms sweep), and once the pair sums run the
+        // sweep gets no CU until they end -- so a held-back sweep runs behind the pair sums.  Estimates: ~1e9 keys per ms at up to
+        // 8 components (0.8e9 to 16, 0.5e9 to 32); the proposals ~16 P bytes per row at 4 TB/s behind ~0.15 ms of table build.
+        // configs[3]: 359.9 -> 358.8 ms (everything but the pair sums 8.4 -> 7.1 ms), configs[2]: the same within the runs' spread,
+        // configs[4] (a 0.5 ms sweep against 0.2 ms of proposals: not held back; forced, 3.71 -> 3.90 ms)
+        static const int l0_force = abc_diag_env("ABC_WX_L0_AFTER_GATHER") ? atoi(abc_diag_env("ABC_WX_L0_AFTER_GATHER")) : -1;   // A/B switch: 0 / 1
+        const double sweep_ms = (double)nvalid * (double)(P * (A - 1)) / (A <= 8 ? 1.0e9 : (A <= 16 ? 0.8e9 : 0.5e9));
+        const double tail_ms = 0.15 + (double)Nn * (double)P * 16.0 / 4.0e9;
+        const bool l0_after = l0_force >= 0 ? l0_force != 0 : sweep_ms <= tail_ms;
+        if (l0_after && wx_spec && weighted) {
+            if (!theta_ev_bound) ABC_HIP(ctx, hipEventRecord(ctx->ev_wx_scores, ctx->stream));
+            ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, theta_ev_bound ? ctx->ev_theta : ctx->ev_wx_scores, 0));
+        }
         ctx->stream = ctx->wx_stream;
         const int rc0 = launch_wilcoxon_level0(ctx, wx_run);
         ctx->stream = main_stream;
