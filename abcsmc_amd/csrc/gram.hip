@@ -1515,6 +1515,12 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // wave-private staging in 8-row chunks (two waves per SIMD keep the fp64 matrix pipe busy: 0.36 -> 0.29 ms on the configs[3]
     // shard against the four-wave, 16-row-chunk variant, which stays for the column-pointer-table mode of the grouped path).
     // (6, 0) needs 172 KB for its epilogue and stays on the VGPR-staged kernel.
+    // (81..96 columns of a LARGE set on the byte-limb kernel: an experiment behind a switch)
+    static const bool i8_96 = abc_diag_env("ABC_GRAM_I8_96") != nullptr;
+    if (i8_96 && C == 6 && dma_ok && ctx->gram_mode != ABC_GRAM_FP64 && (n_set ? n_set : n) >= 2000000) {
+        if (CY == 2) return run_gram_i8<6, 2>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
+        if (CY == 1) return run_gram_i8<6, 1>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
+    }
 #define GRAM_DMA4_CASE(c, cy) if (C == c && CY == cy && dma_ok) return run_gram_dma8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     GRAM_DMA4_CASE(4, 0); GRAM_DMA4_CASE(4, 1); GRAM_DMA4_CASE(4, 2); GRAM_DMA4_CASE(5, 0); GRAM_DMA4_CASE(5, 1); GRAM_DMA4_CASE(5, 2);
     GRAM_DMA4_CASE(6, 1); GRAM_DMA4_CASE(6, 2);
