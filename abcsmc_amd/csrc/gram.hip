@@ -843,7 +843,8 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
     }
     for (int e2 = t; e2 < 8 * D::PLANE / 16; e2 += D::NT) reinterpret_cast<v4i*>(planes0)[e2] = v4i{0, 0, 0, 0};   // (the padding columns' bytes stay 0)
     if (t < 36 + 64) reinterpret_cast<unsigned int*>(rowfar0)[t] = 0u;       // the three sets of far flags, the zero column
-    for (int e2 = t; e2 < D::NBLK * 256; e2 += D::NT) out[e2] = 0.0;       // the flushes ADD into the record
+    // (the record is not zeroed: every element of it has one owner -- a lane of the wave that holds its tile pair, or the diagonal's
+    // thread at the end -- whose FIRST flush stores and whose later ones add)
     // this wave's tiles: the b-th (I, J >= I) super-block pair in row-major order, b = wave + 8 k
     int wI[D::TPW], wJ[D::TPW];
 #pragma unroll
@@ -967,6 +968,7 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
     };
     // flush of the i32 accumulators into this work-group's partial record (fp64): tile (I, J), order o = b + b' - 3 carries weight
     // 2^(8 o) 2^(e_a + e_b - 62 + 24); a 32 x 32 tile is up to four 16 x 16 blocks of the record, stored in the f64 MFMA's C layout
+    bool flushed = false;
     auto flush = [&]() {
 #pragma unroll
         for (int k = 0; k < D::TPW; k++) {
@@ -984,13 +986,15 @@ __global__ __launch_bounds__(512) void k_gram_i8(const double* __restrict__ X, c
                 if (bi > bj || bi >= C - CY || bj >= C || mrow == ncol) continue;   // lower triangle, pure Y'Y / padding, the diagonal
                 // C/D layout of v_mfma_f64_16x16x4_f64: element (row, col) of a block sits at lane' = 16 (row & 3) + col, register row >> 2
                 const int rr = mrow & 15, cc = ncol & 15;
-                out[(size_t)blk_index(bi, bj) * 256 + (rr >> 2) * 64 + 16 * (rr & 3) + cc] += val;     // (one owner per element)
+                double* po = out + (size_t)blk_index(bi, bj) * 256 + (rr >> 2) * 64 + 16 * (rr & 3) + cc;     // (one owner per element)
+                *po = flushed ? *po + val : val;
             }
 #pragma unroll
             for (int o = 0; o < 5; o++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[k][o][r] = 0;
         }
+        flushed = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the record's loads and stores out of the DMA count)
     };
     __syncthreads();
@@ -1515,9 +1519,11 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // wave-private staging in 8-row chunks (two waves per SIMD keep the fp64 matrix pipe busy: 0.36 -> 0.29 ms on the configs[3]
     // shard against the four-wave, 16-row-chunk variant, which stays for the column-pointer-table mode of the grouped path).
     // (6, 0) needs 172 KB for its epilogue and stays on the VGPR-staged kernel.
-    // (81..96 columns of a LARGE set on the byte-limb kernel: an experiment behind a switch)
-    static const bool i8_96 = abc_diag_env("ABC_GRAM_I8_96") != nullptr;
-    if (i8_96 && C == 6 && dma_ok && ctx->gram_mode != ABC_GRAM_FP64 && (n_set ? n_set : n) >= 2000000) {
+    // 81..96 columns of a LARGE set (configs[3]: 64 metrics + 32 parameters, 1e7 rows) go through the byte-limb kernel of the wide
+    // sets (k_gram_i8, below): 1.59 ms against k_gram_dma8's 1.99 at 1e7 rows x 96 columns (0.60 against 0.48 of HBM: the fp64
+    // matrix pipe is 0.62 busy there), the same statistics to the byte products' error (section 4).  From 2e6 rows: where it was measured.
+    static const bool dma8_96 = abc_diag_env("ABC_GRAM_DMA8_96") != nullptr;              // A/B switch: the fp64 kernel as before
+    if (!dma8_96 && C == 6 && dma_ok && ctx->gram_mode != ABC_GRAM_FP64 && (n_set ? n_set : n) >= 2000000 && n >= 4096) {
         if (CY == 2) return run_gram_i8<6, 2>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
         if (CY == 1) return run_gram_i8<6, 1>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
     }

@@ -1532,10 +1532,11 @@ def _stats_record(gpu_ctx, X, Y, ntrain):
 
 @pytest.mark.parametrize("N,M,P,kind", [(200_000, 128, 16, "plain"), (400_000, 120, 8, "plain"), (231_073, 140, 20, "plain"),
                                         (240_000, 128, 16, "spikes"), (240_000, 128, 16, "heavy"), (220_000, 113, 16, "constant"),
-                                        (200_000, 144, 16, "plain"), (210_000, 112, 16, "spikes")])
+                                        (200_000, 144, 16, "plain"), (210_000, 112, 16, "spikes"), (2_000_000, 64, 32, "heavy")])
 def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
     """k_gram_i8 (round 4; round 5: four rows per thread in the conversion, two sets of byte planes, one barrier per tile -- 160 columns
-    leave LDS for two raw tiles instead of three, 128 columns are two whole conversion rounds): the Gram of 113..160 columns (from 200000 rows) from four signed bytes per value on v_mfma_i32_32x32x32_i8.
+    leave LDS for two raw tiles instead of three, 128 columns are two whole conversion rounds; 81..96 columns take it from 2e6 rows -- the
+    configs[3] column shape): the Gram of 113..160 columns (from 200000 rows) from four signed bytes per value on v_mfma_i32_32x32x32_i8.
     Against numpy on the same shifted data: column sums and the diagonal (fp64 on the vector pipe) to rounding, the off-diagonal
     products -- exact integer arithmetic on values rounded to a 32-bit grid of 4 x a robust sample range, byte pairs below 2^-32 of the
     top pair dropped -- to 5e-10 of sqrt(G_aa G_bb) (it falls with the square root of the rows); with values far outside the sampled
