@@ -212,7 +212,7 @@ int launch_stats_accumulate(abc_ctx*, const double* X, const double* Y, size_t n
                             size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
                             double* stats, size_t n_set = 0);
 int launch_pls_model(abc_ctx*, const double* stats, const double* obs, size_t M, size_t P, size_t A,
-                     int rule, double* model);
+                     int rule, double* model, hipEvent_t done = nullptr);
 int launch_simple_model(abc_ctx*, const double* stats, const double* obs, size_t M, size_t P,
                         double* model);
 int launch_project_distance(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P,
@@ -222,7 +222,7 @@ size_t launch_project_scores(abc_ctx*, const double* X, size_t n, size_t ldx, si
 // the ranking's projection and the validation scores (rows from row_test on: S[i - row_test + sld k]) in one pass over X;
 // 0: queued, 1: not a shape for it, nothing queued
 int launch_project_distance_scores(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model,
-                                   double* dist, double* S, size_t sld, size_t row_test);
+                                   double* dist, double* S, size_t sld, size_t row_test, hipEvent_t done);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out, bool defer_check = false);
 int abc_select_check(abc_ctx* ctx, int* failed);

@@ -532,8 +532,20 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, Yp, N, N, N, M, Pstat, 0, ntrain, stats));
     if (fork_late) ABC_TRY(abc_side_fork(ctx));
+    // (the cascade's stream is forked behind the fit: where the generation will speculate -- the condition is restated below --
+    // the fork's event rides on the fit kernel's completion signal)
+    static const int wx_inline = abc_diag_env("ABC_WX_INLINE") ? 1 : 0;                  // A/B switch for measurements
+    const bool wx_spec = !simple && cfg->rule == ABC_RULE_WILCOXON && io->w && K && !wx_inline && !ctx->wx_force_inline &&
+                         abc_wx_cascade_applies(N > (size_t)ntrain ? N - (size_t)ntrain : 0, P, A);
+    if (wx_spec && !ctx->wx_stream) {
+        // (stream priorities were tried for it, highest and lowest: no effect on any config beyond the runs' spread)
+        ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_fork, abc_xstream_event_flags()));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_done, abc_xstream_event_flags()));
+        ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_scores, abc_xstream_event_flags()));
+    }
     if (simple) ABC_TRY(launch_simple_model(ctx, stats, io->obs, M, Pstat, model));
-    else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
+    else ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model, wx_spec ? ctx->ev_wx_fork : nullptr));
     // the taus2 streams of the proposals (draws, seeds) need the rng state only: on the side stream, forked behind the Gram
     // kernel (which wants the whole memory system) and running beside the reduce / model fit that leave the chip empty
     uint32_t* raw_early = nullptr;
@@ -570,10 +582,8 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // when the host has its result -- the ranking's kernels are long done by then -- either nothing has changed (the usual case:
     // the per-response counts are committed, the generation goes on) or the decision is committed and the three stages run again.
     // Whole generations on sets the cascade takes only (ranking-only calls and small sets: in stream order, as before).
-    static const int wx_inline = abc_diag_env("ABC_WX_INLINE") ? 1 : 0;                  // A/B switch for measurements
     const bool wx_rule = !simple && cfg->rule == ABC_RULE_WILCOXON;
     const size_t nvalid = N > (size_t)ntrain ? N - (size_t)ntrain : 0;
-    const bool wx_spec = wx_rule && io->w && K && !wx_inline && !ctx->wx_force_inline && abc_wx_cascade_applies(nvalid, P, A);
     double* wx_dec = nullptr;
     abc_wx_run* wx_run = nullptr;
     struct WxGuard {          // an error return between the cascade's halves: its kernels still write into this call's arena
@@ -582,17 +592,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     } wx_guard = {ctx, &wx_run};
     bool projected = false;                              // the ranking's projection queued by the cascade's first half (below)
     if (wx_spec) {
-        if (!ctx->wx_stream) {
-            // (stream priorities were tried for it, highest and lowest: no effect on any config beyond the runs' spread)
-            ABC_HIP(ctx, hipStreamCreateWithFlags(&ctx->wx_stream, hipStreamNonBlocking));
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_fork, abc_xstream_event_flags()));
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_done, abc_xstream_event_flags()));
-            ABC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_wx_scores, abc_xstream_event_flags()));
-        }
         wx_dec = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!wx_dec) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
-        ABC_HIP(ctx, hipEventRecord(ctx->ev_wx_fork, ctx->stream));                     // (behind the model fit)
-        ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, ctx->ev_wx_fork, 0));
+        ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, ctx->ev_wx_fork, 0));           // (the fit's completion: launch_pls_model above)
         // its first half -- plan, scores, the level-0 sweep and bounds -- is queued BEFORE the ranking (the host needs ~60 us to queue
         // the ranking's eight launches: the cascade started that much late behind them, rocprofv3 timeline)
         // ONE pass over X for both: the ranking's projection (main stream) also writes the validation rows' scores, all A
@@ -607,8 +609,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
                 abc_ctx* c = q->ctx;
                 hipStream_t wx = c->stream;
                 c->stream = q->main;
-                int rc = launch_project_distance_scores(c, q->X, q->N, q->N, q->M, q->P, q->A, q->model, q->dist, S, sld, q->ntrain);
-                if (rc == 0 && hipEventRecord(c->ev_wx_scores, q->main) != hipSuccess) rc = ABC_ERR_HIP;
+                int rc = launch_project_distance_scores(c, q->X, q->N, q->N, q->M, q->P, q->A, q->model, q->dist, S, sld, q->ntrain, c->ev_wx_scores);
                 c->stream = wx;
                 if (rc == 0 && hipStreamWaitEvent(wx, c->ev_wx_scores, 0) != hipSuccess) rc = ABC_ERR_HIP;
                 if (rc == 0) q->dist = nullptr;          // (taken)

@@ -8,6 +8,7 @@
 // (no inter-wave barriers): XY and the P x P eigen work matrices live in LDS, XX stays in L2.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
 #include "abc_internal.h"
 
 namespace {
@@ -1251,8 +1252,10 @@ static double g_pls_stamps[64];
 #endif
 
 static int zstats_lds(abc_ctx* ctx, size_t M, size_t P, size_t* bytes);
+// done (optional): an event behind the fit -- bound to the fit kernel's own completion signal where that kernel is the 16-lane
+// one (a hipEventRecord is one more packet in front of the projection: ~7 us of the critical path), recorded otherwise
 int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_t M, size_t P, size_t A, int rule,
-                     double* model) {
+                     double* model, hipEvent_t done) {
     if (A < 1 || A > M) ABC_FAIL(ctx, ABC_ERR_INVALID, "pls: components A=%zu must be in [1, M=%zu]", A, M);
     StageTimer tm(ctx, ST_PLS_MODEL);
     const ZLayout Z = z_layout(M, P);
@@ -1299,8 +1302,8 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
         const int lb = (int)(lds16_d * sizeof(double));
 #define FIT16_LAUNCH(NW_, NB_) do { \
             ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_pls_fit16<NW_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lb)); \
-            hipLaunchKernelGGL((k_pls_fit16<NW_, NB_>), dim3(1), dim3(64 * NW_), lb, ctx->stream, (const double*)zwork, obs, (int)M, \
-                               (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork); } while (0)
+            hipExtLaunchKernelGGL((k_pls_fit16<NW_, NB_>), dim3(1), dim3(64 * NW_), lb, ctx->stream, nullptr, done, 0, (const double*)zwork, obs, (int)M, \
+                                  (int)P, (int)A, model, scratch, xx_in_lds, stats_in, zwork); done = nullptr; } while (0)
         if (M > 64) { if (nb16 == 1) FIT16_LAUNCH(8, 1); else FIT16_LAUNCH(8, 2); }
         else { if (nb16 == 1) FIT16_LAUNCH(4, 1); else FIT16_LAUNCH(4, 2); }
 #undef FIT16_LAUNCH
@@ -1313,6 +1316,7 @@ int launch_pls_model(abc_ctx* ctx, const double* stats, const double* obs, size_
 #undef PLS_LAUNCH_NB
 #undef PLS_LAUNCH
     ABC_HIP(ctx, hipGetLastError());
+    if (done) ABC_HIP(ctx, hipEventRecord(done, ctx->stream));          // (the other fit kernels: a record behind them)
 #ifdef PLS_STAMPS
     ABC_HIP(ctx, hipMemcpyAsync(g_pls_stamps, scratch + A * M + A * A + 2 * P * A, 64 * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));

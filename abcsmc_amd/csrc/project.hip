@@ -10,6 +10,7 @@
 // d2 = fma(s_k - o_k, s_k - o_k, d2) for k ascending; dist = sqrt(d2).  HBM-bound: 8*M B/particle.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
 #include "abc_internal.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -520,8 +521,10 @@ size_t launch_project_scores(abc_ctx* ctx, const double* X, size_t n, size_t ldx
 // validation half of X was read twice, and the second read competed with the selection for the chip): dist as
 // launch_project_distance, S[i - row_test + sld k] = score k (all A components) of the rows from row_test on.
 // 0: done; 1: not a shape for it (nothing queued: the caller launches the two separately).
+// done: an event bound to the kernel's own completion signal (as launch_gather_rows' -- a hipEventRecord behind the launch is one more
+// packet the selection's first kernel would wait for: ~7 us of the critical path)
 int launch_project_distance_scores(abc_ctx* ctx, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model,
-                                   double* dist, double* S, size_t sld, size_t row_test) {
+                                   double* dist, double* S, size_t sld, size_t row_test, hipEvent_t done) {
     static const bool off = abc_diag_env("ABC_PROJECT_SEPARATE") != nullptr;              // A/B switch for measurements
     const ModelLayout ML = model_layout(M, P, A);
     int KC = 1;
@@ -539,8 +542,8 @@ int launch_project_distance_scores(abc_ctx* ctx, const double* X, size_t n, size
         if (lb > 150 * 1024 || valu_only) return 1;
         const unsigned gb = (unsigned)((n + 255) / 256);
         ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_project_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-        hipLaunchKernelGGL(k_project_mfma<2>, dim3(gb), dim3(256), lb, ctx->stream, X, n, ldx, (int)M, model + ML.off_mean, model + ML.off_sd,
-                           model, ML.off_R, ML.off_oscore, dist, (int)mfma_main, S, sld, (int)A, row_test);
+        hipExtLaunchKernelGGL(k_project_mfma<2>, dim3(gb), dim3(256), lb, ctx->stream, nullptr, done, 0, X, n, ldx, (int)M, model + ML.off_mean,
+                              model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, (int)mfma_main, S, sld, (int)A, row_test);
         ABC_HIP(ctx, hipGetLastError());
         return 0;
     }
@@ -549,11 +552,11 @@ int launch_project_distance_scores(abc_ctx* ctx, const double* X, size_t n, size
     if (pblocks > 1024) pblocks = 1024;
     const int lb = (int)((M * KC + KC) * sizeof(double));
     if (KC == 8)
-        hipLaunchKernelGGL(k_project_dist2_lds<8>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
-                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, S, sld, (int)A, row_test);
+        hipExtLaunchKernelGGL(k_project_dist2_lds<8>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, nullptr, done, 0, X, npairs, ldx, (int)M,
+                              model + ML.off_mean, model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, S, sld, (int)A, row_test);
     else
-        hipLaunchKernelGGL(k_project_dist2_lds<16>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, X, npairs, ldx, (int)M, model + ML.off_mean,
-                           model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, S, sld, (int)A, row_test);
+        hipExtLaunchKernelGGL(k_project_dist2_lds<16>, dim3((unsigned)pblocks), dim3(256), lb, ctx->stream, nullptr, done, 0, X, npairs, ldx, (int)M,
+                              model + ML.off_mean, model + ML.off_sd, model, ML.off_R, ML.off_oscore, dist, S, sld, (int)A, row_test);
     ABC_HIP(ctx, hipGetLastError());
     return 0;
 }
