@@ -215,10 +215,17 @@ __global__ __launch_bounds__(1024) void k_bs_sample(const double* __restrict__ d
     for (int i = t; i < nbins + 1; i += 1024) hist[i] = 0;
     const size_t stride = n / BS_S;
     unsigned long long mn = ~0ull;
-    for (int i = t; i < BS_S; i += 1024) {
-        const unsigned long long k = key_of(dist[(size_t)i * stride + stride / 2]);
-        sk[i] = k;
-        mn = k < mn ? k : mn;
+    {   // (the thread's samples are fetched TOGETHER: one at a time each was a trip to HBM / L2 of its own on an otherwise empty chip)
+        static_assert(BS_S % 1024 == 0 && BS_S / 1024 <= 8, "samples per thread");
+        double dv[BS_S / 1024];
+#pragma unroll
+        for (int j = 0; j < BS_S / 1024; j++) dv[j] = dist[(size_t)(t + 1024 * j) * stride + stride / 2];
+#pragma unroll
+        for (int j = 0; j < BS_S / 1024; j++) {
+            const unsigned long long k = key_of(dv[j]);
+            sk[t + 1024 * j] = k;
+            mn = k < mn ? k : mn;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const unsigned long long v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
