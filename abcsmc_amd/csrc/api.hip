@@ -696,13 +696,14 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ctx->stream = main_stream;
         ABC_TRY(rc0);
     }
-    // Where the cascade's second half goes.  A generation with pair sums to compute (a previous set) DEFERS it: the weight stage
-    // needs the gathered rows, not the component counts, so it is queued first and the host's looks at the cascade's levels -- and
-    // the levels themselves -- happen beside the pair sums; if the largest count then turns out to have moved, everything queued on
-    // the fit's count is thrown away and the generation runs once more with the reduction in stream order.  A set without pair sums
-    // has nothing to hide the cascade behind: the second half follows the gather, and a moved count repeats the ranking only.
+    // Where the cascade's second half goes: BEHIND everything else the generation queues.  The weight stage and the proposals need
+    // the gathered rows, not the component counts, so they are queued first and the host's looks at the cascade's levels -- and
+    // the levels themselves -- happen beside the pair sums (a first set: beside the selection, the gather and the proposals); if the
+    // largest count then turns out to have moved, everything queued on the fit's count is thrown away and the generation runs once
+    // more with the reduction in stream order.  (ABC_WX_FINISH_EARLY: the second half right behind the gather, a moved count
+    // repeats the ranking only -- the round's first form, kept for A/B runs.)
     static const int wx_finish_early = abc_diag_env("ABC_WX_FINISH_EARLY") ? 1 : 0;     // A/B switch for measurements
-    const bool wx_defer = wx_spec && weighted && !wx_finish_early;
+    const bool wx_defer = wx_spec && !wx_finish_early;
     bool wx_tail_pending = false;
     if (wx_spec && !wx_defer) {
         // the reduction itself, on its own stream, while the ranking queued above runs (the host's looks at the cascade's level

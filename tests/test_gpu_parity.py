@@ -1896,6 +1896,24 @@ def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, 
     assert np.array_equal(gen.parent.cpu().numpy().astype(np.uint64), ref["parent"])
 
 
+def test_generation_repeats_itself_when_the_cascade_gives_up(gpu_ctx):
+    """the cascade's second half reports failure (ABC_WX_FORCE_FAIL: as if a bin of its exact step had outgrown LDS) when the
+    generation has already queued its weight stage and its proposals on the fit's count: everything is thrown away and the
+    generation runs once more with the reduction in stream order (which, forced to fail again, repeats itself on the sorted path).
+    The speculation test's weighted and first-set cases in a process of their own (the switch is read once): every output the
+    oracle's, parents included"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ABC_DIAG="1", ABC_WX_FORCE_FAIL="1")
+    ids = ["tests/test_gpu_parity.py::test_generation_speculates_on_the_component_count[%s]" % i for i in ("20-5-10-2.0-500", "16-3-8-1.5-0", "16-6-8-0.0-500")]
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + ids, capture_output=True, text=True,
+                       timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "3 passed" in p.stdout, p.stdout[-500:]
+
+
 def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
     """BASELINE configs[3] at its STATED size under the drop-in's default rule: 1e7 particles x 64 metrics x 32 responses x 8
     components = up to 224 tests over 5e6 validation rows, through the staged entry points on device-generated rows (the model under
