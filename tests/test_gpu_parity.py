@@ -1863,9 +1863,9 @@ def test_generation_config2_size_against_the_full_oracle(gpu_ctx, oracle):
 def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, noise, Kp):
     """Whole generations on sets the Wilcoxon cascade takes run the ranking BESIDE the reduction, on the component count the fit wrote
     (api.hip, round 5): the ranking's projection scores all A components in its one pass over X (the validation rows' scores go to
-    the cascade) and takes the distance over the fit's count.  With noisy responses the reduction lowers the largest count: a first
-    set repeats projection, selection and gather with it; a weighted generation, which has queued its weight stage and its proposals
-    on the fit's count by the time it looks at the cascade, throws them away and runs once more with the reduction in stream order.
+    the cascade) and takes the distance over the fit's count.  With noisy responses the reduction lowers the largest count: the generation,
+    which has queued everything up to its proposals on the fit's count by the time it looks at the cascade, throws that away and
+    runs once more with the reduction in stream order.
     With clean responses the count stands.  Either way every output equals the oracle's generation under the rule -- the parents too,
     so the repeat starts from the generator's state at entry -- and the count equals the oracle's, which in the noisy cases is below
     the argmin-PRESS count (checked: the speculation is wrong there and has to be repaired).  8 / 10 components: the vector
