@@ -1547,6 +1547,11 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     const bool i8_ok = !gram_fp64 && (n_set ? n_set : n) >= 200000 && n >= 4096 && dma_ok;
 #define GRAM_WIDE_CASE(c, cy) if (C == c && CY == cy) return i8_ok ? run_gram_i8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats) \
                                                                     : run_gram_wide<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+    // (7 blocks, 97..112 columns: the byte-limb kernel where it applies -- round 5; the fp64 one-launch kernel spills at that width, so
+    // small sets of it stay on the grouped path below, which reads every column twice)
+#define GRAM_I8_ONLY_CASE(c, cy) if (C == c && CY == cy && i8_ok) return run_gram_i8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
+    GRAM_I8_ONLY_CASE(7, 0); GRAM_I8_ONLY_CASE(7, 1); GRAM_I8_ONLY_CASE(7, 2);
+#undef GRAM_I8_ONLY_CASE
     GRAM_WIDE_CASE(8, 0); GRAM_WIDE_CASE(8, 1); GRAM_WIDE_CASE(8, 2);
     GRAM_WIDE_CASE(9, 0); GRAM_WIDE_CASE(9, 1); GRAM_WIDE_CASE(9, 2); GRAM_WIDE_CASE(10, 0); GRAM_WIDE_CASE(10, 1); GRAM_WIDE_CASE(10, 2);
 #undef GRAM_WIDE_CASE

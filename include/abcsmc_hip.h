@@ -86,8 +86,8 @@ int  abc_version(void);
  * ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
-/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets -- 113..160 columns (metrics + parameters),
- * and, from 2 000 000 rows, 81..96 columns (round 5).
+/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets -- 97..160 columns (metrics + parameters; 97..112
+ * since round 5), and, from 2 000 000 rows, 81..96 columns (round 5).
  * ABC_GRAM_AUTO (default): from 200 000 rows (81..96 columns: 2 000 000) IN THE WHOLE SET (the sharded generation decides from N_total, so that every rank and
  * the unsharded run of the same set take the same kernel) the byte-limb kernel on the i8 matrix pipe: every value rounded to a 32-bit
  * fixed-point grid of 10..19 sigma per column; column sums, row counts and the Gram DIAGONAL are exact, an off-diagonal product
