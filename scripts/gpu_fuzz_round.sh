@@ -7,7 +7,7 @@ PART=${1:-abc}
 mkdir -p $OUT
 if [[ $PART == *a* ]]; then
 python3 tests/fuzz/wilcoxon_fuzz.py $OUT/r05_wilcoxon_fuzz.json 100 505 > $OUT/fuzz_wilcoxon.log 2>&1; tail -2 $OUT/fuzz_wilcoxon.log
-python3 tests/fuzz/wide_gram_fuzz.py $OUT/r05_wide_gram_fuzz.json 30 506 > $OUT/fuzz_wide_gram.log 2>&1; tail -1 $OUT/fuzz_wide_gram.log
+python3 tests/fuzz/wide_gram_fuzz.py $OUT/r05_wide_gram_fuzz.json 40 506 > $OUT/fuzz_wide_gram.log 2>&1; tail -1 $OUT/fuzz_wide_gram.log
 python3 tests/fuzz/ranking_fuzz.py $OUT/r05_ranking_fuzz.json 150 507 > $OUT/fuzz_ranking.log 2>&1; tail -1 $OUT/fuzz_ranking.log
 fi
 if [[ $PART == *b* ]]; then
