@@ -686,7 +686,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         static const int l0_force = abc_diag_env("ABC_WX_L0_AFTER_GATHER") ? atoi(abc_diag_env("ABC_WX_L0_AFTER_GATHER")) : -1;   // A/B switch: 0 / 1
         const double sweep_ms = (double)nvalid * (double)(P * (A - 1)) / (A <= 8 ? 1.0e9 : (A <= 16 ? 0.8e9 : 0.5e9));
         const double tail_ms = 0.15 + (double)Nn * (double)P * 16.0 / 4.0e9;
-        const bool l0_after = l0_force >= 0 ? l0_force != 0 : sweep_ms <= tail_ms;
+        // ... and only where there are pair sums to speak of (~4.8e9 pairs per ms): the cascade is a chain of short dependent steps
+        // (sweep, totals, bounds, the host's look), and started behind the gather it outlasts a generation whose weight stage is
+        // over in 0.04 ms (configs[1], K = K' = 1e4: 0.336 -> 0.361 ms held)
+        const double pairs_ms = (double)K * (double)Kp / 4.8e9;
+        const bool l0_after = l0_force >= 0 ? l0_force != 0 : (sweep_ms <= tail_ms && pairs_ms >= 0.25);
         if (l0_after && wx_spec && weighted) {
             if (!theta_ev_bound) ABC_HIP(ctx, hipEventRecord(ctx->ev_wx_scores, ctx->stream));
             ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, theta_ev_bound ? ctx->ev_theta : ctx->ev_wx_scores, 0));
