@@ -101,6 +101,7 @@ SIGNATURES = {
     "abc_ctx_set_weight_kernel": (_i, [_vp, _i]),
     "abc_perturb_giveups": (_i, [_vp, _vp, _i]),
     "abc_generation_giveups": (_i, [_vp, _vp]),
+    "abc_generation_repeats": (_i, [_vp, _vp, _vp, _i]),
     "abc_ctx_set_alias_mode": (_i, [_vp, _i]),
     "abc_alias_stats": (_i, [_vp, _vp, _vp, _i]),
     "abc_alias_table": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
@@ -211,6 +212,19 @@ class Context:
         """non-zero status: AbcError (the ABI has no positive status)"""
         if rc:
             raise AbcError(rc, lib().abc_last_error(self._h).decode())
+
+    def generation_repeats(self, reset=False):
+        """(ranking repeats, generation repeats) since the context was created / the last reset: what the speculation on the
+        component count has cost (abc_generation_repeats)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.check(lib().abc_generation_repeats(self._h, C.byref(a), C.byref(b), int(reset)))
+        return a.value, b.value
+
+    def generation_giveups(self):
+        """proposals the most recent generation call gave up on (abc_generation_giveups); no synchronisation"""
+        n = C.c_uint64(0)
+        lib().abc_generation_giveups(self._h, C.byref(n))
+        return n.value
 
     def warn_generation_giveups(self):
         """after abc_generation_dev: a Python warning when the perturbation gave up on proposals during that call (they are

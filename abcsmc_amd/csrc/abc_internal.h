@@ -82,6 +82,7 @@ struct abc_ctx {
     int* sel_fail_dev;       // device: the sampled-range bin selection gave up (select.hip); read by abc_select_check
     bool sel_bins_ran;       // the last launch_select_smallest took the bin path and has not been checked yet
     bool sel_force_radix;    // set by a caller that repeats its work after a failed bin selection
+    unsigned long long wx_moved_counts, generation_repeats;      // abc_generation_repeats
     bool wx_force_inline;    // set by a generation that repeats itself after its speculation on the component count failed: the Wilcoxon reduction in stream order
     bool wx_gather_rows;     // diagnostic (ABC_DIAG=1 ABC_WX_GATHER=1, set at context creation): the sharded generation's Wilcoxon rule by
                              // gathering the validation rows on every rank (rounds 1-4) instead of the sharded cascade
@@ -223,6 +224,9 @@ size_t launch_project_scores(abc_ctx*, const double* X, size_t n, size_t ldx, si
 // 0: queued, 1: not a shape for it, nothing queued
 int launch_project_distance_scores(abc_ctx*, const double* X, size_t n, size_t ldx, size_t M, size_t P, size_t A, const double* model,
                                    double* dist, double* S, size_t sld, size_t row_test, hipEvent_t done);
+// the distances again from the scores of all rows that pass has left (S[i + sld k], row_test = 0): a repeat of the ranking on a
+// lowered component count (model[0]) without a second pass over X
+int launch_distance_from_scores(abc_ctx*, const double* S, size_t n, size_t sld, size_t M, size_t P, size_t A, const double* model, double* dist);
 int launch_select_smallest(abc_ctx*, const double* dist, size_t n, size_t K, uint64_t idx_base,
                            uint64_t* idx, double* dist_out, bool defer_check = false);
 int abc_select_check(abc_ctx* ctx, int* failed);
@@ -284,9 +288,11 @@ int launch_wilcoxon_commit(abc_ctx*, double* model, size_t M, size_t P, size_t A
 // the cascade in two halves, for a caller with work to queue between them (the fused generation: api.hip)
 struct abc_wx_run;
 // scores: the caller has a pass over X of its own to queue (the ranking's projection) and lets it write the validation scores
-// too: fn(arg, S, sld) queues that pass, makes the context's (= the cascade's) stream wait for it and returns 0 -- or returns 1
-// without queueing anything, and the cascade scores the rows itself
-struct abc_wx_scores_hook { int (*fn)(void* arg, double* S, size_t sld); void* arg; };
+// too: fn(arg, &S, &sld) queues that pass, makes the context's (= the cascade's) stream wait for it, says where the validation rows'
+// scores are (S[i + sld k], row i of the validation rows: the caller's own buffer -- round 6: the generation keeps the scores of ALL
+// rows, so that a moved count repeats the distances from them instead of from X) and returns 0 -- or returns 1 without queueing
+// anything, and the cascade scores the rows itself into a buffer of its own
+struct abc_wx_scores_hook { int (*fn)(void* arg, double** S, size_t* sld); void* arg; };
 int launch_wilcoxon_begin(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
                           size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out,
                           const abc_wx_scores_hook* scores = nullptr, int hold_level0 = 0);

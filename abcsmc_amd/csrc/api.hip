@@ -198,6 +198,14 @@ extern "C" int abc_generation_giveups(const abc_ctx* ctx, uint64_t* count) {
     return ABC_OK;
 }
 
+extern "C" int abc_generation_repeats(const abc_ctx* ctx, uint64_t* ranking_repeats, uint64_t* generation_repeats, int reset) {
+    if (!ctx) return ABC_ERR_INVALID;
+    if (ranking_repeats) *ranking_repeats = (uint64_t)ctx->wx_moved_counts;
+    if (generation_repeats) *generation_repeats = (uint64_t)ctx->generation_repeats;
+    if (reset) { abc_ctx* c = const_cast<abc_ctx*>(ctx); c->wx_moved_counts = 0; c->generation_repeats = 0; }
+    return ABC_OK;
+}
+
 extern "C" int abc_kde_last_kernel(abc_ctx* ctx, int* which) {
     if (!ctx || !which) return ABC_ERR_INVALID;
     *which = ABC_KDE_RAN_NONE;
@@ -584,6 +592,13 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // Whole generations on sets the cascade takes only (ranking-only calls and small sets: in stream order, as before).
     const bool wx_rule = !simple && cfg->rule == ABC_RULE_WILCOXON;
     const size_t nvalid = N > (size_t)ntrain ? N - (size_t)ntrain : 0;
+    // ROUND 6: the host LOOKS at the reduction in front of the weight stage again (round 5's first form), because the look has become
+    // cheap: the cascade takes the LARGEST COUNT FIRST (wilcoxon.hip, k_wx_plan) -- level 0 over the tests of two to four responses
+    // that hold it instead of all P (A - 1) --, so its verdict is there before the selection and the gather beside it have ended, and
+    // a moved count costs the cascade's second half and the three ranking stages once more instead of the whole generation
+    // (round 5's default queued everything up to the proposals on the fit's count first and repeated the generation: ABC_WX_DEFER,
+    // kept for A/B runs).
+    static const int wx_defer_env = abc_diag_env("ABC_WX_DEFER") ? 1 : 0;
     double* wx_dec = nullptr;
     abc_wx_run* wx_run = nullptr;
     struct WxGuard {          // an error return between the cascade's halves: its kernels still write into this call's arena
@@ -591,6 +606,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ~WxGuard() { if (*r) { launch_wilcoxon_abandon(c, *r, c->wx_stream); *r = nullptr; } }
     } wx_guard = {ctx, &wx_run};
     bool projected = false;                              // the ranking's projection queued by the cascade's first half (below)
+    const double* scores_all = nullptr;                  // ... which has then left the scores of all rows (N x A, leading dimension N)
     if (wx_spec) {
         wx_dec = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
         if (!wx_dec) ABC_FAIL(ctx, ABC_ERR_NOMEM, "generation: workspace exhausted");
@@ -601,18 +617,34 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // components, and the cascade's sweeps wait for it -- as two launches the validation half of X was read twice and the
         // second pass (51 us at configs[2]) ran beside the selection's kernels
         hipStream_t main_stream = ctx->stream;
-        struct ScoresArg { abc_ctx* ctx; hipStream_t main; const double* X; size_t N, M, P, A, ntrain; const double* model; double* dist; }
-            sarg = {ctx, main_stream, io->X, N, M, P, A, (size_t)ntrain, model, dist};
+        // (round 6: the pass leaves the scores of EVERY row, not only the validation half -- N x A doubles of this call's arena: should
+        // the reduction lower the largest count, the distances are taken again from them, N x count x 8 bytes instead of X once more)
+        static const int scores_valid_only = abc_diag_env("ABC_SCORES_VALID_ONLY") ? 1 : 0;      // A/B switch: round 5's half
+        struct ScoresArg { abc_ctx* ctx; hipStream_t main; const double* X; size_t N, M, P, A, ntrain; const double* model; double* dist; double* S_all; }
+            sarg = {ctx, main_stream, io->X, N, M, P, A, (size_t)ntrain, model, dist, nullptr};
+        if (!scores_valid_only && !(N & 1)) sarg.S_all = (double*)abc_ws_alloc(ctx, N * A * 8);
         abc_wx_scores_hook hook = {
-            [](void* a, double* S, size_t sld) -> int {
+            [](void* a, double** S, size_t* sld) -> int {
                 ScoresArg* q = (ScoresArg*)a;
                 abc_ctx* c = q->ctx;
                 hipStream_t wx = c->stream;
+                double* S_half = nullptr;
+                if (!q->S_all) {
+                    S_half = (double*)abc_ws_alloc(c, (q->N - q->ntrain) * q->A * 8);
+                    if (!S_half) { snprintf(c->err, sizeof(c->err), "generation: workspace exhausted"); return ABC_ERR_NOMEM; }
+                }
                 c->stream = q->main;
-                int rc = launch_project_distance_scores(c, q->X, q->N, q->N, q->M, q->P, q->A, q->model, q->dist, S, sld, q->ntrain, c->ev_wx_scores);
+                int rc = q->S_all ? launch_project_distance_scores(c, q->X, q->N, q->N, q->M, q->P, q->A, q->model, q->dist, q->S_all, q->N, 0, c->ev_wx_scores)
+                                  : launch_project_distance_scores(c, q->X, q->N, q->N, q->M, q->P, q->A, q->model, q->dist, S_half, q->N - q->ntrain, q->ntrain,
+                                                                   c->ev_wx_scores);
                 c->stream = wx;
                 if (rc == 0 && hipStreamWaitEvent(wx, c->ev_wx_scores, 0) != hipSuccess) rc = ABC_ERR_HIP;
-                if (rc == 0) q->dist = nullptr;          // (taken)
+                if (rc == 0) {
+                    q->dist = nullptr;          // (taken)
+                    *S = q->S_all ? q->S_all + q->ntrain : S_half;
+                    *sld = q->S_all ? q->N : q->N - q->ntrain;
+                } else if (rc == 1)
+                    q->S_all = nullptr;         // (not a shape for the fused pass: no scores of all rows either)
                 return rc;
             },
             &sarg};
@@ -624,6 +656,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ctx->stream = main_stream;
         ABC_TRY(rcb);
         projected = sarg.dist == nullptr;
+        scores_all = projected ? sarg.S_all : nullptr;
     } else if (wx_rule)
         ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, N, N, N, M, P, A, (size_t)ntrain, model));
     if (!projected) ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
@@ -690,7 +723,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         // (sweep, totals, bounds, the host's look), and started behind the gather it outlasts a generation whose weight stage is
         // over in 0.04 ms (configs[1], K = K' = 1e4: 0.336 -> 0.361 ms held)
         const double pairs_ms = (double)K * (double)Kp / 4.8e9;
-        const bool l0_after = l0_force >= 0 ? l0_force != 0 : (sweep_ms <= tail_ms && pairs_ms >= 0.25);
+        const bool l0_after = (l0_force >= 0 ? l0_force != 0 : (sweep_ms <= tail_ms && pairs_ms >= 0.25)) && wx_defer_env;
         if (l0_after && wx_spec && weighted) {
             if (!theta_ev_bound) ABC_HIP(ctx, hipEventRecord(ctx->ev_wx_scores, ctx->stream));
             ABC_HIP(ctx, hipStreamWaitEvent(ctx->wx_stream, theta_ev_bound ? ctx->ev_theta : ctx->ev_wx_scores, 0));
@@ -706,8 +739,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // largest count then turns out to have moved, everything queued on the fit's count is thrown away and the generation runs once
     // more with the reduction in stream order.  (ABC_WX_FINISH_EARLY: the second half right behind the gather, a moved count
     // repeats the ranking only -- the round's first form, kept for A/B runs.)
-    static const int wx_finish_early = abc_diag_env("ABC_WX_FINISH_EARLY") ? 1 : 0;     // A/B switch for measurements
-    const bool wx_defer = wx_spec && !wx_finish_early;
+    const bool wx_defer = wx_spec && wx_defer_env;
     bool wx_tail_pending = false;
     if (wx_spec && !wx_defer) {
         // the reduction itself, on its own stream, while the ranking queued above runs (the host's looks at the cascade's level
@@ -726,14 +758,24 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
             changed = 2;
         }
         if (rc != ABC_OK) { if (!ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "generation: the component rule's reduction failed"); return rc; }
-        if (changed != 2) {
+        if (changed == 1) {                      // the counts AND the header, in front of the ranking's second run
             ABC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wx_done, 0));
-            ABC_TRY(launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, changed == 1));
+            ABC_TRY(launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, 1));
+        } else if (changed == 0) {
+            // the per-response counts into the model record on the cascade's own stream: nothing this generation still queues reads
+            // them (the largest count, which everything used, is the fit's); the host waits for that stream at the generation's end
+            ctx->stream = ctx->wx_stream;
+            const int rcc = launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, 0);
+            ctx->stream = main_stream;
+            ABC_TRY(rcc);
+            wx_tail_pending = true;
         }
         if (changed) {                           // the largest count moved: the ranking once more, with it
+            ctx->wx_moved_counts++;
             ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             *pfail_early = 0;
-            ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, P, A, model, 0, dist));
+            if (scores_all) ABC_TRY(launch_distance_from_scores(ctx, scores_all, N, N, M, P, A, model, dist));
+            else ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, P, A, model, 0, dist));
             ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/true));
             bins_deferred = ctx->sel_bins_ran && ctx->sel_fail_dev && !ctx->sel_force_radix;
             ABC_TRY(launch_gather_rows(ctx, io->Y, N, N, P, io->idx, K, 0, theta, K, bins_deferred ? ctx->sel_fail_dev : nullptr, pfail_early,
@@ -753,6 +795,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ctx->sel_bins_ran = false;
         ctx->ws_off = ws_entry;
         if (rng) *rng = rng_entry;
+        ctx->generation_repeats++;
         const bool radix0 = ctx->sel_force_radix, inline0 = ctx->wx_force_inline;      // (a repeat inside a repeat keeps the outer one's reason)
         ctx->sel_force_radix = radix0 || radix;
         ctx->wx_force_inline = inline0 || wx_in_order;
@@ -1019,7 +1062,7 @@ extern "C" int abc_generation_dev(abc_ctx* ctx, const abc_generation_cfg* cfg, c
     if (!cfg || !io || !io->X || !io->obs || !io->idx) ABC_FAIL(ctx, ABC_ERR_INVALID, "generation: null argument");
     const size_t A = default_A(cfg->M, cfg->P, cfg->max_comp);
     size_t need = abc_ws_need(cfg->N, cfg->M, cfg->P, A, cfg->K, cfg->Kp, cfg->Nnext);
-    if (cfg->rule == ABC_RULE_WILCOXON) need += abc_wx_need(cfg->N, cfg->P, A);
+    if (cfg->rule == ABC_RULE_WILCOXON) need += abc_wx_need(cfg->N, cfg->P, A) + cfg->N * A * 8 + 4096;      // (+ the scores of all rows)
     ABC_TRY(abc_ws_reserve(ctx, need));
     return generation_core(ctx, cfg, io, rng, ncomp_host, 0);
 }

@@ -560,3 +560,39 @@ int launch_project_distance_scores(abc_ctx* ctx, const double* X, size_t n, size
     ABC_HIP(ctx, hipGetLastError());
     return 0;
 }
+
+// The distances once more from the scores the ranking's projection has left for EVERY row (round 6: a generation whose component
+// count the Wilcoxon reduction lowered repeats its ranking -- the scores do not depend on the count, only how many of them the
+// distance takes): dist[i] = sqrt(sum_{k < model[0]} (S[i + sld k] - obs_score[k])^2), the projection kernels' own fma chain in
+// component order, hence their bits.  N x ncomp x 8 bytes instead of a second pass over X.
+__global__ __launch_bounds__(256) void k_dist_from_scores(const double* __restrict__ S, size_t n, size_t sld, const double* __restrict__ model,
+                                                          size_t off_oscore, double* __restrict__ dist) {
+    const int nc = (int)model[0];
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; 2 * i < n; i += stride) {
+        if (2 * i + 1 < n) {
+            double d0 = 0.0, d1 = 0.0;
+            for (int k = 0; k < nc; k++) {
+                const d2 v = *reinterpret_cast<const d2*>(S + 2 * i + sld * (size_t)k);
+                const double o = model[off_oscore + k], t0 = v.x - o, t1 = v.y - o;
+                d0 = fma(t0, t0, d0);
+                d1 = fma(t1, t1, d1);
+            }
+            *reinterpret_cast<d2*>(dist + 2 * i) = (d2){sqrt(d0), sqrt(d1)};
+        } else {
+            double d0 = 0.0;
+            for (int k = 0; k < nc; k++) { const double t0 = S[2 * i + sld * (size_t)k] - model[off_oscore + k]; d0 = fma(t0, t0, d0); }
+            dist[2 * i] = sqrt(d0);
+        }
+    }
+}
+// (S, dist 16-byte aligned, sld even: launch_project_distance_scores' own conditions, under which the scores exist)
+int launch_distance_from_scores(abc_ctx* ctx, const double* S, size_t n, size_t sld, size_t M, size_t P, size_t A, const double* model, double* dist) {
+    const ModelLayout ML = model_layout(M, P, A);
+    StageTimer tm(ctx, ST_PROJECT);
+    size_t blocks = (n / 2 + 256) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_dist_from_scores, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, S, n, sld, model, ML.off_oscore, dist);
+    ABC_HIP(ctx, hipGetLastError());
+    return ABC_OK;
+}

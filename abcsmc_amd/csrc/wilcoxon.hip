@@ -34,6 +34,9 @@
 // The SORTED path of rounds 1-3 (one stable LSD radix sort of all (key, test) pairs) stays for small sets, for more than
 // 32 components and as the fallback when a bin of the exact step outgrows LDS (massive ties).
 #include "abc_internal.h"
+#include <chrono>
+#include <sched.h>
+#include <time.h>
 #include <vector>
 
 #pragma clang diagnostic ignored "-Wpass-failed"
@@ -56,6 +59,8 @@ constexpr int WX_NC0 = 192;                      // cells of level 0: 12 binades
 constexpr int WX_CSH = 17;                       // a cell = 2^17 key prefixes (prefix = the leading 32 of the 63 key bits: 2^21 to the binade)
 constexpr int WX_LDS = 144 << 10;                // LDS of a sweep work-group's counters and tables
 constexpr int WX_NBFMAX = 16384;                 // most fine bins of a level (start and span of a cell travel in 16 bits each)
+constexpr int WX_FIRST_MAX = 8;                  // most responses whose tests go first (the largest count first: k_wx_plan)
+constexpr int WX_NWORDS = 12;                    // ticket / list-length words of a run (levels of both halves)
 constexpr unsigned long long WX_SIGN = 1ull << 63;
 constexpr unsigned long long WX_MASK = ~WX_SIGN;
 constexpr unsigned long long WX_NOKEY = ~0ull;   // a row without a key (zero difference, padding)
@@ -69,8 +74,12 @@ __global__ __launch_bounds__(256) void k_wx_plan(const double* __restrict__ mode
                                                  unsigned long long* __restrict__ nz, double* __restrict__ W, int* __restrict__ segbase,
                                                  int* __restrict__ fail, int* __restrict__ v3, unsigned int* __restrict__ kbase,
                                                  int* __restrict__ act, int* __restrict__ nact, unsigned int* __restrict__ tickets,
-                                                 double nv_total, double* __restrict__ per_keep = nullptr) {
+                                                 double nv_total, double* __restrict__ per_keep = nullptr, int first_r = 0,
+                                                 int* __restrict__ act_rest = nullptr, unsigned char* __restrict__ in_first = nullptr) {
     __shared__ int s_ns;
+    __shared__ double s_score[1024];
+    __shared__ int s_pick[WX_FIRST_MAX];
+    __shared__ int s_npick, s_fitmax;
     __shared__ int s_w[16];
     __shared__ int s_base;
     if (per_keep) {           // the PRESS optima and the header as the fit left them (k_wx_decide rewrites them; a repeat starts from these)
@@ -79,11 +88,14 @@ __global__ __launch_bounds__(256) void k_wx_plan(const double* __restrict__ mode
         if (threadIdx.x == 0) per_keep[P] = model[MLk.off_hdr];
     }
     for (int s = threadIdx.x; s < nseg_max; s += blockDim.x) { nz[s] = 0; W[s] = 0.0; if (v3) v3[s] = 2; if (act) act[s] = s; }
+    if (in_first) for (int j = threadIdx.x; j < P; j += blockDim.x) in_first[j] = 0;
     const ModelLayout ML = model_layout(M, P, A);
     if (threadIdx.x == 0) {
         if (fail) { fail[0] = 0; fail[1] = 0; }
-        if (tickets) { tickets[0] = 0; tickets[1] = 0; tickets[2] = 0; tickets[3] = 0; }
+        if (tickets) for (int i = 0; i < WX_NWORDS; i++) tickets[i] = 0;
         s_base = 0;
+        s_npick = 0;
+        s_fitmax = 1;
     }
     __syncthreads();
     // a response per thread: its tests are the segments segbase[j] .. segbase[j] + a*_j - 2 (a scan of the counts over the work-group;
@@ -123,6 +135,71 @@ __global__ __launch_bounds__(256) void k_wx_plan(const double* __restrict__ mode
     __syncthreads();
     if (!kbase) return;
     const int ns = s_ns;
+    // THE LARGEST COUNT FIRST (round 6; first_r > 0: a caller that only uses the largest per-response count, AbcUtil.cpp:449).  That
+    // count stays the fit's as soon as ONE response that holds it keeps it, i.e. has all its tests rejected -- so the cascade starts
+    // with the tests of the first_r responses most likely to: among the responses whose PRESS optimum is the largest, those whose
+    // closest competitor lies furthest above the optimum in relative PRESS (a heuristic that only orders the work: whatever it
+    // picks, the verdicts are the tests' own).  act = their tests (response order), act_rest = all the others (test order),
+    // in_first[j] = 1 for the picked responses; nact[0] / nact[4] = the two lengths.  Nothing to pick from (one component, more
+    // than 1024 responses, no more holders than picks would leave anything over): act = every test, as before.
+    if (first_r > 0 && act_rest && in_first && P <= 1024 && ns > 0) {
+        const int t = threadIdx.x;
+        for (int j = t; j < P; j += blockDim.x) atomicMax(&s_fitmax, astar[j]);
+        __syncthreads();
+        const int fitmax = s_fitmax;
+        for (int j = t; j < P; j += blockDim.x) {
+            double sc = -1.0;
+            const int as = astar[j];
+            if (as == fitmax && as > 1) {
+                const double best = model[ML.off_press + (as - 1) + (size_t)A * j];
+                double dmin = 1e300;
+                for (int a = 1; a < as; a++) { const double d = model[ML.off_press + (a - 1) + (size_t)A * j] - best; dmin = d < dmin ? d : dmin; }
+                sc = best > 0.0 ? dmin / best : (dmin > 0.0 ? 1e300 : 0.0);
+                if (!(sc >= 0.0)) sc = 0.0;                      // (NaN, a negative difference: still a holder, picked last)
+            }
+            s_score[j] = sc;
+        }
+        __syncthreads();
+        if (t < 64) {                                            // wave 0: first_r rounds of (largest score, lowest response)
+            const int want = first_r < WX_FIRST_MAX ? first_r : WX_FIRST_MAX;
+            for (int r = 0; r < want; r++) {
+                double bs = -1.0;
+                int bj = 1 << 30;
+                for (int j = t; j < P; j += 64) { const double sc = s_score[j]; if (sc > bs) { bs = sc; bj = j; } }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const double os = __shfl_xor(bs, o, 64);
+                    const int oj = __shfl_xor(bj, o, 64);
+                    if (os > bs || (os == bs && oj < bj)) { bs = os; bj = oj; }
+                }
+                if (bs < 0.0) break;                             // (uniform: no holder left)
+                if (t == 0) { s_pick[s_npick++] = bj; s_score[bj] = -2.0; }
+                __builtin_amdgcn_wave_barrier();                 // (one wave: its LDS accesses execute in program order)
+            }
+        }
+        __syncthreads();
+        const int np = s_npick;
+        if (np > 0 && np < P) {
+            for (int i = t; i < np; i += blockDim.x) in_first[s_pick[i]] = 1;
+            __syncthreads();
+            for (int j = t; j < P; j += blockDim.x) {
+                const int as = astar[j], cnt = as > 1 ? as - 1 : 0, b0 = segbase[j];
+                int pa = 0, mine = 0;                            // picked tests in front of response j
+                for (int i = 0; i < np; i++) { const int pj = s_pick[i]; if (pj < j) pa += astar[pj] - 1; if (pj == j) mine = 1; }
+                for (int a = 0; a < cnt; a++)
+                    if (b0 + a < ns) { if (mine) act[pa + a] = b0 + a; else act_rest[b0 - pa + a] = b0 + a; }
+            }
+            if (t == 0) {
+                int na = 0;
+                for (int i = 0; i < np; i++) na += astar[s_pick[i]] - 1;
+                nact[0] = na;
+                nact[4] = ns - na;
+            }
+        } else if (t == 0)
+            nact[4] = 0;
+    } else if (nact && threadIdx.x == 0 && act_rest)
+        nact[4] = 0;
+    __syncthreads();
     for (int s = threadIdx.x; s < ns; s += blockDim.x) {
         const int j = seg_j[s], a1 = seg_a[s], as = astar[j];
         double var = 0.0;
@@ -313,7 +390,7 @@ __device__ __forceinline__ void wx_wave_table(const unsigned int* __restrict__ c
 // rows per thread at 17..32 components (three waves per SIMD, <= 170 registers: the 2 x 32 scores of a thread's rows alone are 128).
 template <int AM, int R, int MODE, int TT>
 __global__ __launch_bounds__(TT) void k_wx_sweep(const double* __restrict__ Y, size_t ldy, size_t row_test, size_t nt, int M, int P, int A,
-                                                   const double* __restrict__ model, const double* __restrict__ S,
+                                                   const double* __restrict__ model, const double* __restrict__ S, size_t sld,
                                                    const int* __restrict__ seg_j, const int* __restrict__ seg_a, const int* __restrict__ astar,
                                                    const int* __restrict__ act, const int* __restrict__ nact_p, int act_lo, int act_n, int G,
                                                    int TG, int RR, int tpw, const unsigned int* __restrict__ kbase,
@@ -383,7 +460,7 @@ __global__ __launch_bounds__(TT) void k_wx_sweep(const double* __restrict__ Y, s
             in[r] = i < nt;
             ic[r] = in[r] ? i : (nt ? nt - 1 : 0);
 #pragma unroll
-            for (int k = 0; k < AM; k++) s[r][k] = in[r] ? S[ic[r] + nt * (size_t)(k < A ? k : A - 1)] : 0.0;     // (rows past the end: zeros)
+            for (int k = 0; k < AM; k++) s[r][k] = in[r] ? S[ic[r] + sld * (size_t)(k < A ? k : A - 1)] : 0.0;     // (rows past the end: zeros)
         }
         // Everything a response needs -- its y, its loadings (lane k holds q_jk), its parameters, the anchors of its tests (lane k: the
         // test a' = k + 1) -- is fetched while the arithmetic of the response BEFORE it runs; a step's operands then come out of the
@@ -562,7 +639,9 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
                                                     const double* __restrict__ nv_ranks, size_t nv_stride, int Wr, int* __restrict__ pin_words,
                                                     int force_undecided /* diagnostic: every test with keys stays undecided */,
                                                     double* __restrict__ model, int M, int A, double* __restrict__ dec,
-                                                    const double* __restrict__ per_keep, int stop_at_max) {
+                                                    const double* __restrict__ per_keep, int stop_at_max,
+                                                    const unsigned char* __restrict__ in_first /* the first half: the picked responses only */,
+                                                    const int* __restrict__ nrest_p /* ... and the number of tests outside it */) {
     extern __shared__ unsigned int wxb_cp[];              // [NBX] packed (all keys, positive keys) of the test's bins
     __shared__ long long red[3][16];
     __shared__ unsigned long long wtot[16];
@@ -669,6 +748,9 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
             need = pas ? (und & ((pas & (0u - pas)) - 1u)) : und;
             const int fp = pas ? __ffs((int)pas) : n + 1, fu = need ? __ffs((int)need) : n + 1;      // 1-based candidates; n + 1: none (the count stays a*)
             const int hi = fp, lo = fu < fp ? fu : fp;
+            // (the first half -- the largest count first, k_wx_plan: only a picked response that can still keep its optimum has tests
+            // worth another level; the others' ranges enter the decision as they are, untested = [1, a*])
+            if (in_first && (!in_first[j] || pas)) need = 0;
             atomicMax(&s_lo, lo);
             atomicMax(&s_hi, hi);
             if (per_out) per_out[j] = (double)hi;            // (exact once nothing of the response is open; an upper end until then)
@@ -691,7 +773,9 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     // `0 left`, neither queues another level nor launches k_wx_decide (its launch behind the host's look was 20 us of the critical path).
     // dec != NULL -- the fused generation's speculative run, api.hip: the counts go to dec[0 .. P - 1], the largest to dec[P], and the
     // model record keeps what the fit wrote; pin_words[3] / [4]: the final count, and whether it differs from the fit's
-    const bool decided = s_run == 0 || (stop_at_max && s_lo == s_hi);
+    // (first half: nothing left to look at is NOT a decision -- the picked responses were all reduced or stay within the last level's
+    // resolution of the threshold: the host goes on with the other responses' tests)
+    const bool decided = in_first ? (s_lo == s_hi) : (s_run == 0 || (stop_at_max && s_lo == s_hi));
     const int total = decided ? 0 : s_run;
     if (decided && model && t == 0) {
         const int nc = s_hi;
@@ -707,6 +791,8 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
         // fence here writes the whole L2 back first -- the sweep's counters, the scores: 10-25 us of every level)
         __hip_atomic_store(&pin_words[1], (int)(vmax & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pin_words[2], (int)(vmax >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pin_words[5], decided ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (nrest_p) __hip_atomic_store(&pin_words[6], *nrest_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence();
         __hip_atomic_store(&pin_words[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the host spins on this word)
     }
@@ -1263,14 +1349,26 @@ struct WxLevel { int R, tiles, G, TG, RR, tpw, nslots, TT; };   // rows per thre
 // tests as the counter buffer (bc_bytes) takes.  ONE work-group runs on a CU (LDS), so about 256 of them: R rows per thread as long
 // as (tiles x groups) still fills three quarters of the chip (more rows per thread = more loads in flight per latency), then
 // 256 / groups runs of tiles; a work-group's rows stay below 2^16 (its counters are 16-bit halves).
-WxLevel wx_level(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, size_t bc_bytes) {
+WxLevel wx_level_one(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, size_t bc_bytes, int fixed_slots);
+// ... and the tests of a batch from the validation rows of ALL ranks (nvt), so that every rank of a row-sharded set cuts a level into
+// the same batches -- a batch is one all-reduce of nslots x NBX counts, and ranks with different row counts (the validation rows are the
+// global tail: leading ranks have none) would otherwise issue different numbers of collectives of different sizes;
+// the geometry over the rank's own rows then takes that many tests as given.
+WxLevel wx_level(size_t nt, size_t nvt, bool sharded, size_t A, int want, int NBX, size_t per_test_lds, size_t bc_bytes) {
+    if (!sharded) return wx_level_one(nt, A, want, NBX, per_test_lds, bc_bytes, 0);
+    const WxLevel all = wx_level_one(nvt > nt ? nvt : nt, A, want, NBX, per_test_lds, bc_bytes, -1);
+    return wx_level_one(nt, A, want, NBX, per_test_lds, bc_bytes, all.nslots);
+}
+// fixed_slots > 0: that many tests, whatever the buffer; -1: the tests of a batch for ANY rank's share of the rows (a rank with fewer
+// rows may cut them into MORE runs of tiles than the whole set would be: the buffer is sized for the most runs a geometry can have)
+WxLevel wx_level_one(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, size_t bc_bytes, int fixed_slots) {
     WxLevel g;
     g.G = (int)(((size_t)WX_LDS - 1024) / per_test_lds);          // (1 KB: the spare counters of the sweep)
     if (g.G < 1) g.G = 1;
     if (g.G > want) g.G = want;
     static const bool t768 = abc_diag_env("ABC_WX_T768") != nullptr;          // A/B switch: 17..32 components on 768 threads x 2 rows
     const int rmax = A <= 8 ? 4 : (A <= 16 ? 2 : (t768 ? 2 : 1));
-    int ns = want;
+    int ns = fixed_slots > 0 ? fixed_slots : want;
     for (int it = 0; it < 8; it++) {
         g.nslots = ns;
         g.TG = (ns + g.G - 1) / g.G;
@@ -1288,9 +1386,15 @@ WxLevel wx_level(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, si
         g.tpw = tpw;
         g.RR = (g.tiles + tpw - 1) / tpw;
         if (g.RR < 1) g.RR = 1;
-        const size_t bytes = (size_t)g.RR * ns * NBX * 4;
+        const int rr_bytes = (fixed_slots < 0 && g.RR < rr_target) ? rr_target : g.RR;
+        const size_t bytes = (size_t)rr_bytes * ns * NBX * 4;
+        if (fixed_slots > 0) {
+            // (cannot happen by the sizing above; if it did, fewer and longer runs of tiles -- never a different batch)
+            while ((size_t)g.RR * ns * NBX * 4 > bc_bytes && g.RR > 1 && g.tpw < limit) { g.tpw++; g.RR = (g.tiles + g.tpw - 1) / g.tpw; }
+            break;
+        }
         if (bytes <= bc_bytes || ns <= g.G) break;
-        int fit = (int)(bc_bytes / ((size_t)g.RR * NBX * 4)) / g.G * g.G;
+        int fit = (int)(bc_bytes / ((size_t)rr_bytes * NBX * 4)) / g.G * g.G;
         if (fit < g.G) fit = g.G;
         if (fit >= ns) break;
         ns = fit;
@@ -1300,7 +1404,9 @@ WxLevel wx_level(size_t nt, size_t A, int want, int NBX, size_t per_test_lds, si
 size_t wx_bc_bytes(size_t nv, size_t nseg_max) {           // the sweeps' counter buffer: [runs of tiles][tests of a launch][bins]
     const size_t tiles = (nv + WX_T - 1) / WX_T;
     size_t b = (tiles > 0 ? tiles : 1) * (nseg_max * 2048 * 4 > (size_t)8 * WX_NBFMAX * 4 ? nseg_max * 2048 * 4 : (size_t)8 * WX_NBFMAX * 4);
-    const size_t cap = (size_t)96 << 20;
+    size_t cap = (size_t)96 << 20;
+    static const char* cap_env = abc_diag_env("ABC_WX_BC_CAP_KB");          // tests: a small buffer, so that a level takes several batches
+    if (cap_env && atol(cap_env) > 0) cap = (size_t)atol(cap_env) << 10;
     return (b < cap ? b : cap) + (1u << 20);
 }
 // bins of a fine level over `nact` tests: the fewer tests are left, the finer (a test's counters live in LDS: 4 bytes a bin)
@@ -1322,7 +1428,10 @@ static size_t wx_cascade_need(size_t nv, size_t P, size_t A) {
     const int xb = wx_xb(nv);
     const size_t nbcap = nv / wx_target(nv) + 2;
     return nv * A * 8 + wx_bc_bytes(nv, seg) + seg * (2048 * 4 + 2048 * 8) + (size_t)40 * WX_NBFMAX * 12 + seg * WX_NC0 * (4 + 8) + seg * 64 + P * 16 +
-           (size_t)xb * (2 * nv * 8 + WX_NBFMAX * 2 + WX_NC0 * 4 + nbcap * 20) + (2u << 20);
+           (size_t)xb * (2 * nv * 8 + WX_NBFMAX * 2 + WX_NC0 * 4 + nbcap * 20) + (2u << 20) +
+           // (the largest count first: the picked responses' own level 0 and fine levels, <= 124 tests -- 96 x 4096 and 32 x 16384 bins of
+           // counts and totals at most --, the second list of tests, the picks)
+           ((size_t)24 << 20) + seg * 4 + P + 64;
 }
 size_t abc_wx_need(size_t nt, size_t P, size_t A) {
     const size_t b = wx_cascade_need(nt, P, A);
@@ -1332,10 +1441,24 @@ size_t abc_wx_need(size_t nt, size_t P, size_t A) {
 // the host's look at one word the device writes when it is done (pinned, preset to -1): a spin, with a glance at the stream
 // every few thousand turns so that a failed launch ends the wait
 static int wx_wait_word(abc_ctx* ctx, volatile int* w, int* out) {
+    // the first 2 ms a plain spin (the word is usually tens of microseconds away and the generation's critical path waits for it);
+    // then the core is given up between looks (sched_yield, from 50 ms on 50 us naps: other ranks' enqueue threads may share it),
+    // and a wait beyond ABC_WX_WAIT_S seconds (default 600) fails the call instead of spinning on a wedged stream for ever
+    static const double limit_s = abc_diag_env("ABC_WX_WAIT_S") ? atof(abc_diag_env("ABC_WX_WAIT_S")) : 600.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    double waited = 0.0;
     for (unsigned long spins = 0;; spins++) {
         const int v = *w;
         if (v >= 0) { *out = v; return ABC_OK; }
-        if ((spins & 0x3fff) == 0x3fff) {
+        if ((spins & 0x3ff) == 0x3ff) {
+            waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > limit_s) ABC_FAIL(ctx, ABC_ERR_HIP, "wilcoxon: no word from the bounds kernel after %.0f s", waited);
+        }
+        if (waited > 2e-3) {
+            if (waited > 50e-3) { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
+            else sched_yield();
+        }
+        if ((spins & 0x3fff) == 0x3fff || (waited > 2e-3 && (spins & 0xff) == 0xff)) {
             const hipError_t e = hipStreamQuery(ctx->stream);
             if (e == hipSuccess) {
                 const int v2 = *w;
@@ -1349,24 +1472,24 @@ static int wx_wait_word(abc_ctx* ctx, volatile int* w, int* out) {
 
 template <int AM, int R, int TT>
 static void wx_launch_sweep(abc_ctx* ctx, int mode, const WxLevel& g, size_t lds, const double* Y, size_t ldy, size_t row_test, size_t nt, size_t M,
-                            size_t P, size_t A, const double* model, const double* S, const int* seg_j, const int* seg_a, const int* astar,
+                            size_t P, size_t A, const double* model, const double* S, size_t sld, const int* seg_j, const int* seg_a, const int* astar,
                             const int* act, const int* nact_p, int act_lo, const unsigned int* kbase, const unsigned int* c0, int NBX,
                             unsigned int* blockcnt, unsigned long long* keys, size_t kld) {
     const dim3 grid((unsigned)(8 * ((g.RR + 7) / 8) * g.TG));
 #define WX_SW(MODEV)                                                                                                                      \
     do {                                                                                                                                  \
         if (lds > (48u << 10)) (void)hipFuncSetAttribute((const void*)k_wx_sweep<AM, R, MODEV, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_wx_sweep<AM, R, MODEV, TT>), grid, dim3(TT), lds, ctx->stream, Y, ldy, row_test, nt, (int)M, (int)P, (int)A, model, S, \
+        hipLaunchKernelGGL((k_wx_sweep<AM, R, MODEV, TT>), grid, dim3(TT), lds, ctx->stream, Y, ldy, row_test, nt, (int)M, (int)P, (int)A, model, S, sld, \
                            seg_j, seg_a, astar, act, nact_p, act_lo, g.nslots, g.G, g.TG, g.RR, g.tpw, kbase, c0, NBX, blockcnt, keys, kld);  \
     } while (0)
     if (mode == 0) WX_SW(0); else if (mode == 1) WX_SW(1); else WX_SW(2);
 #undef WX_SW
 }
 static void wx_sweep(abc_ctx* ctx, size_t A, int mode, const WxLevel& g, size_t lds, const double* Y, size_t ldy, size_t row_test,
-                     size_t nt, size_t M, size_t P, const double* model, const double* S, const int* seg_j, const int* seg_a, const int* astar,
+                     size_t nt, size_t M, size_t P, const double* model, const double* S, size_t sld, const int* seg_j, const int* seg_a, const int* astar,
                      const int* act, const int* nact_p, int act_lo, const unsigned int* kbase, const unsigned int* c0, int NBX,
                      unsigned int* blockcnt, unsigned long long* keys, size_t kld) {
-#define WX_GO(AMV, RV, TV) wx_launch_sweep<AMV, RV, TV>(ctx, mode, g, lds, Y, ldy, row_test, nt, M, P, A, model, S, seg_j, seg_a, astar, act, nact_p, act_lo, \
+#define WX_GO(AMV, RV, TV) wx_launch_sweep<AMV, RV, TV>(ctx, mode, g, lds, Y, ldy, row_test, nt, M, P, A, model, S, sld, seg_j, seg_a, astar, act, nact_p, act_lo, \
                                                     kbase, c0, NBX, blockcnt, keys, kld)
     if (A <= 8) { if (g.R == 4) WX_GO(8, 4, 1024); else if (g.R == 2) WX_GO(8, 2, 1024); else WX_GO(8, 1, 1024); }
     else if (A <= 16) { if (g.R == 2) WX_GO(16, 2, 1024); else WX_GO(16, 1, 1024); }
@@ -1408,27 +1531,32 @@ struct abc_wx_run {
     double* per_keep; double* dec; int stop_at_max; const abc_wx_scores_hook* scores_hook; bool hold_level0, level0_queued;
     int Wr; bool sharded; size_t nvt, nseg_max, bc_bytes;
     WxPlan* plan; int *seg_j, *seg_a, *astar, *segbase, *fail; unsigned long long* nz; double* W; int* v3; unsigned int* kbase;
-    int *actA, *actB, *nactv; unsigned int* tickets; int* slotmap; unsigned char* passb; double* S; unsigned int *c0, *blockcnt;
+    int *actA, *actB, *nactv; unsigned int* tickets; int* slotmap; unsigned char* passb; double* S; size_t S_ld; unsigned int *c0, *blockcnt;
     volatile int* pin; const double* nv_ranks; size_t nv_stride;
     unsigned int* cl_fine; size_t cl_fine_ld;
+    // the largest count first (k_wx_plan): the tests of first_r picked responses (actA, at most first_bound of them), then -- only
+    // if none of those responses keeps its optimum -- the rest (act_rest)
+    int first_r, first_bound; int* act_rest; unsigned char* in_first; bool looked0; int left0; bool decided0;
 
     // one level over the tests act[0 .. nact_host) (nact on the device at nact_p): sweeps in batches, the counts (all-reduced over
     // the ranks), bounds; the last bounds work-group leaves the tests still needed in act_out / nact_out and their number in the
     // pinned word, which level_wait reads
     int level_queue(int lvl, int mode, int NBX, const int* act, const int* nact_p, int nact_host, int* act_out, int* nact_out, unsigned int* cl,
-                    size_t cl_ld, int cl_by_test) {
+                    size_t cl_ld, int cl_by_test, bool first_half) {
         hipStream_t st = ctx->stream;
         const size_t per_test = (size_t)NBX * 4 + (mode == 1 ? WX_NC0 * 4 : 0) + 7 * 4 + 16;
         pin[0] = -1;
         const size_t blds = ((size_t)NBX + 1024) * 8;
         if (blds > (48u << 10)) ABC_HIP(ctx, hipFuncSetAttribute((const void*)k_wx_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
         for (int lo = 0; lo < nact_host;) {
-            const WxLevel g = wx_level(nt, A, nact_host - lo, NBX, per_test, bc_bytes);
+            const WxLevel g = wx_level(nt, nvt, sharded, A, nact_host - lo, NBX, per_test, bc_bytes);
+            if ((size_t)g.RR * g.nslots * NBX * 4 > bc_bytes && sharded)
+                ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: %d runs x %d tests x %d bins do not fit the counter buffer", g.RR, g.nslots, NBX);
             const size_t lds = (size_t)g.G * per_test + (mode == 0 ? (size_t)NBX * 4 : 256) + 64, ne = (size_t)g.nslots * NBX;
             unsigned long long* totals = (unsigned long long*)abc_ws_alloc(ctx, ne * 8);
             if (!totals) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted");
             if (nt) {
-                wx_sweep(ctx, A, mode, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act, nact_p, lo, kbase, c0, NBX, blockcnt, nullptr, 0);
+                wx_sweep(ctx, A, mode, g, lds, Y, ldy, row_test, nt, M, P, model, S, S_ld, seg_j, seg_a, astar, act, nact_p, lo, kbase, c0, NBX, blockcnt, nullptr, 0);
                 hipLaunchKernelGGL(k_wx_totals, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, st, NBX, g.RR, g.nslots, (const unsigned int*)blockcnt, totals);
             } else
                 ABC_HIP(ctx, hipMemsetAsync(totals, 0, ne * 8, st));
@@ -1436,13 +1564,18 @@ struct abc_wx_run {
             hipLaunchKernelGGL(k_wx_bounds, dim3((unsigned)g.nslots), dim3(1024), blds, st, NBX, g.nslots, act, nact_p, lo, (const unsigned long long*)totals,
                                nz, v3, cl, cl_ld, cl_by_test, slotmap, tickets + lvl, (unsigned int)nact_host, (const int*)astar, (int)P, (const int*)segbase,
                                act_out, nact_out, nv_ranks, nv_stride, Wr, (int*)pin, wx_no_bounds() ? 1 : 0, model, (int)M, (int)A, dec,
-                               (const double*)per_keep, stop_at_max);
+                               (const double*)per_keep, stop_at_max, first_half ? (const unsigned char*)in_first : (const unsigned char*)nullptr,
+                               first_half ? (const int*)(nactv + 4) : (const int*)nullptr);
             ABC_HIP(ctx, hipGetLastError());
             lo += g.nslots;
         }
         return ABC_OK;
     }
-    int level_wait(int* left) { return wx_wait_word(ctx, pin, left); }
+    int level_wait(int* left, bool* decided) {
+        ABC_TRY(wx_wait_word(ctx, pin, left));
+        *decided = pin[5] != 0;                 // (written in front of the word the wait saw)
+        return ABC_OK;
+    }
 
     int begin() {
         Wr = (has_sh && ctx->comm_kind) ? ctx->comm_world : 1;
@@ -1463,15 +1596,29 @@ struct abc_wx_run {
         kbase = (unsigned int*)abc_ws_alloc(ctx, nseg_max * 4);
         actA = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
         actB = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
-        nactv = (int*)abc_ws_alloc(ctx, 4 * sizeof(int));
-        tickets = (unsigned int*)abc_ws_alloc(ctx, 4 * sizeof(int));
+        nactv = (int*)abc_ws_alloc(ctx, WX_NWORDS * sizeof(int));
+        tickets = (unsigned int*)abc_ws_alloc(ctx, WX_NWORDS * sizeof(int));
+        // the largest count first: where the caller only uses the largest per-response count and there are more responses than picks
+        static const char* first_env = abc_diag_env("ABC_WX_FIRST");            // A/B switch and tests: 0 = every test at level 0, as round 5
+        first_r = 0;
+        if (stop_at_max && P <= 1024 && A >= 2) {
+            first_r = 32 / (int)(A - 1);
+            first_r = first_r < 2 ? 2 : (first_r > 4 ? 4 : first_r);
+            if (first_env) first_r = atoi(first_env) < WX_FIRST_MAX ? atoi(first_env) : WX_FIRST_MAX;
+            if ((size_t)first_r >= P) first_r = 0;
+        }
+        first_bound = first_r ? first_r * (int)(A - 1) : (int)nseg_max;
+        act_rest = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
+        in_first = (unsigned char*)abc_ws_alloc(ctx, P ? P : 1);
+        looked0 = false; left0 = 0; decided0 = false;
         slotmap = (int*)abc_ws_alloc(ctx, nseg_max * sizeof(int));
         passb = (unsigned char*)abc_ws_alloc(ctx, nseg_max);
-        S = (double*)abc_ws_alloc(ctx, (nt ? nt : 1) * A * 8);
+        S = nullptr;
+        S_ld = nt;
         c0 = (unsigned int*)abc_ws_alloc(ctx, nseg_max * WX_NC0 * 4);
         blockcnt = (unsigned int*)abc_ws_alloc(ctx, bc_bytes);
         if (!plan || !seg_j || !seg_a || !astar || !segbase || !fail || !nz || !W || !v3 || !kbase || !actA || !actB || !nactv || !tickets || !slotmap ||
-            !passb || !S || !c0 || !blockcnt)
+            !passb || !c0 || !blockcnt || !act_rest || !in_first)
             ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu tests x %zu rows)", nseg_max, nt);
         pin = (volatile int*)(ctx->status_pin + 64);
         nv_ranks = has_sh ? shv.nv_ranks : nullptr;
@@ -1479,12 +1626,17 @@ struct abc_wx_run {
         cl_fine = nullptr;
         cl_fine_ld = 0;
         hipLaunchKernelGGL(k_wx_plan, dim3(1), dim3(256), 0, st, (const double*)model, (int)M, (int)P, (int)A, plan, seg_j, seg_a, astar, (int)nseg_max, nz, W,
-                           segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt, per_keep);
+                           segbase, fail, v3, kbase, actA, nactv, tickets, (double)nvt, per_keep, first_r, act_rest, in_first);
         if (nt) {
             int hooked = 1;                              // (1: the caller has no pass of its own for these rows)
-            if (scores_hook) hooked = scores_hook->fn(scores_hook->arg, S, nt);
+            if (scores_hook) hooked = scores_hook->fn(scores_hook->arg, &S, &S_ld);      // (0: it has queued the pass and says where the scores go)
             if (hooked < 0) return hooked;
-            if (hooked) wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
+            if (hooked) {
+                S = (double*)abc_ws_alloc(ctx, nt * A * 8);
+                S_ld = nt;
+                if (!S) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%zu x %zu scores)", nt, A);
+                wx_scores(ctx, X, ldx, row_test, nt, M, P, A, model, S);
+            }
         }
         ABC_HIP(ctx, hipGetLastError());
         level0_queued = false;
@@ -1494,34 +1646,69 @@ struct abc_wx_run {
     int level0() {
         if (level0_queued) return ABC_OK;
         level0_queued = true;
-        return level_queue(0, 0, WX_NC0, actA, nactv, (int)nseg_max, actB, nactv + 1, c0, WX_NC0, 1);
+        return level_queue(0, 0, WX_NC0, actA, nactv, first_bound, actB, nactv + 1, c0, WX_NC0, 1, first_r > 0);
+    }
+    // the host's first look (level 0 of the picked responses, or of everything): how many tests still want a closer look, and whether
+    // the counts (the largest count) are settled already -- the fused generation calls it in front of its weight stage (api.hip)
+    int look0(int* left, bool* decided) {
+        if (!looked0) {
+            ABC_TRY(level0());
+            ABC_TRY(level_wait(&left0, &decided0));
+            looked0 = true;
+        }
+        *left = left0; *decided = decided0;
+        return ABC_OK;
     }
 
     int finish(int* fail_host, int* changed_host) {
-        ABC_TRY(level0());
         hipStream_t st = ctx->stream;
         int left = 0;
+        bool decided = false;
         int* act_cur = actB;
         int* act_nxt = actA;
         const int* cur_n_p = nactv + 1;         // the device word that holds the length of act_cur
         int NBX_last = 0;
-        ABC_TRY(level_wait(&left));
-        // fine levels over what is left: at most two, the second only when few tests remain and finer bins are to be had
-        for (int f = 0; f < 2 && left > 0; f++) {
-            const int NBX = wx_pick_bins(left, nvt);
-            if (f == 1 && (NBX <= NBX_last || left > 32)) break;
-            cl_fine_ld = (size_t)NBX;
-            cl_fine = (unsigned int*)abc_ws_alloc(ctx, (size_t)left * NBX * 4);
-            if (!cl_fine) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%d tests x %d bins)", left, NBX);
-            const int nact_host = left;
-            ABC_TRY(level_queue(1 + f, 1, NBX, act_cur, nactv + 1 + f, nact_host, act_nxt, nactv + 2 + f, cl_fine, cl_fine_ld, 0));
-            ABC_TRY(level_wait(&left));
-            int* tmp = act_cur; act_cur = act_nxt; act_nxt = tmp;
-            cur_n_p = nactv + 2 + f;
-            NBX_last = NBX;
-        }
+        ABC_TRY(look0(&left, &decided));
+        // fine levels over what is left: at most two, the second only when few tests remain and finer bins are to be had.  word0: the
+        // first of the half's ticket / length words (a level reads its list's length at word0 + 1 + f, leaves the next at + 2 + f)
+        auto fine_levels = [&](int word0, bool first_half) -> int {
+            for (int f = 0; f < 2 && !decided && left > 0; f++) {
+                const int NBX = wx_pick_bins(left, nvt);
+                if (f == 1 && (NBX <= NBX_last || left > 32)) break;
+                cl_fine_ld = (size_t)NBX;
+                cl_fine = (unsigned int*)abc_ws_alloc(ctx, (size_t)left * NBX * 4);
+                if (!cl_fine) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: workspace exhausted (%d tests x %d bins)", left, NBX);
+                const int nact_host = left;
+                ABC_TRY(level_queue(word0 + 1 + f, 1, NBX, act_cur, nactv + word0 + 1 + f, nact_host, act_nxt, nactv + word0 + 2 + f, cl_fine, cl_fine_ld, 0,
+                                    first_half));
+                ABC_TRY(level_wait(&left, &decided));
+                int* tmp = act_cur; act_cur = act_nxt; act_nxt = tmp;
+                cur_n_p = nactv + word0 + 2 + f;
+                NBX_last = NBX;
+            }
+            return ABC_OK;
+        };
+        if (first_r > 0) {
+            // the first half: the picked responses' tests through the fine levels; then, unless one of them keeps the largest count,
+            // level 0 of ALL THE OTHER tests -- from there on as if level 0 had taken every test at once (the picked responses' verdicts
+            // stand; those of their tests that are still open join the others' in the fine levels and the exact step)
+            ABC_TRY(fine_levels(0, true));
+            if (!decided) {
+                // (the host sizes the launch for the tests there are -- pin[6], left by the first half's bounds kernels; sized for all
+                // P (A - 1) that a set could have, two thirds of the work-groups of a 77-test level found nothing to do and the rest
+                // had a third of the chip: 216 us at 1e6 x 128 x 16 x 32.  A level without tests still runs its decision.)
+                int n_rest = pin[6];
+                if (n_rest < 1) n_rest = 1;
+                if (n_rest > (int)nseg_max) n_rest = (int)nseg_max;
+                ABC_TRY(level_queue(4, 0, WX_NC0, act_rest, nactv + 4, n_rest, actB, nactv + 5, c0, WX_NC0, 1, false));
+                ABC_TRY(level_wait(&left, &decided));
+                act_cur = actB; act_nxt = actA; cur_n_p = nactv + 5; NBX_last = 0;
+                ABC_TRY(fine_levels(4, false));
+            }
+        } else
+            ABC_TRY(fine_levels(0, false));
         // ---- the exact step -------------------------------------------------------------------------------------------------------
-        bool exact = left > 0;
+        bool exact = !decided && left > 0;
         if (exact) {
             const int nx = left, XB = wx_xb(nvt) < nx ? wx_xb(nvt) : nx, NBX = NBX_last;
             const unsigned int target = wx_target(nvt);
@@ -1560,7 +1747,7 @@ struct abc_wx_run {
                     g.R = rkeys; g.TT = WX_T; g.tiles = (int)((vmax + (size_t)WX_T * rkeys - 1) / ((size_t)WX_T * rkeys));
                     g.G = xb; g.TG = 1; g.RR = g.tiles; g.tpw = 1; g.nslots = xb;
                     const size_t lds = (size_t)xb * (7 * 4 + 16) + 64;
-                    wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,
+                    wx_sweep(ctx, A, 2, g, lds, Y, ldy, row_test, nt, M, P, model, S, S_ld, seg_j, seg_a, astar, act_cur, nxd, x_lo, kbase, c0, NBX, nullptr,
                              keys_loc, vmax);
                     // (a batch shorter than XB leaves the tail of the block as it is: the placing kernel does not look at it)
                 }

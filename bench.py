@@ -721,6 +721,13 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
         out["host_entry_pcie_floor_ms"] = round(pcie, 4)
         out["host_entry_over_pcie_floor"] = round(ms / pcie, 3)
         del pin, dst
+    # (4b) WHAT A WRONG GUESS OF THE COMPONENT COUNT COSTS.  The timed region's synthetic responses never make
+    # the Wilcoxon reduction lower the LARGEST per-response count, so its speculation (ranking on the fit's count beside the reduction)
+    # is always right there.  Here the same workload with noise added to the responses until the rule's count falls below argmin
+    # PRESS's: the step under the rule on that data, the argmin-PRESS step on the SAME data (the difference is the rule plus the
+    # repair), how often the ranking / the whole generation was repeated per step (abc_generation_repeats), and the same for a first set.
+    if args.rule == "wilcoxon":
+        out["moved_count"] = moved_count_legs(ctx, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, timed)
     # (5) the resampling table (gsl_ran_discrete_preproc): device build (default; HIP-event bracket of its ten launches) and the
     # host's sequential build it replaces (host ms; the GPU idles behind it, plus two PCIe hops), on log-normal weights
     g = np.random.default_rng(5)
@@ -744,6 +751,94 @@ def extra_legs(args, ctx, wl, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp
     builds, fallbacks = ctx.alias_stats(reset=True)           # over the WHOLE run: warm-up, timed region, sustained leg, these legs
     out["alias_device_builds"], out["alias_device_fallbacks"] = builds, fallbacks
     return out
+
+
+def moved_count_data(ctx, dX, dY, dobs, N, M, P, K, Kp, A, dev):
+    """A set that needs FEWER components than argmin PRESS keeps (for extra["moved_count"] and scripts/trace_step.py).  The centred
+    metrics are projected onto a random r-dimensional subspace (r = 3, 2 in turn) and independent noise of half each column's factor
+    share is put back on it (after z-scoring the same in every column: the best predictor of the factors then lies in their own r
+    directions); the responses are random combinations of those r factors + N(0, 1) x their standard deviation.  r components carry
+    everything the metrics know about the responses, the PRESS values beyond them are flat, argmin PRESS lands somewhere on the
+    plateau -- the largest over the responses near its end -- and the Wilcoxon rule takes the surplus back.  (Lower-rank RESPONSES
+    over the workload's own metrics do not move the count at 5e5 validation rows: with eight latent factors in the metrics every
+    one of eight components is significant.)  Priors, previous set and its variances are taken from THAT data the way
+    synthetic.Workload takes them from its own (uniform [mu - 6 sd, mu + 6 sd] / Gaussian(mu, 3 sd); K' rows shrunk halfway to the
+    mean), so the proposals' acceptance is as in the timed region.
+    Returns None when the rule's largest count stays argmin PRESS's at every r, else (r, dXn, dYn, dprin, prev)."""
+    import torch
+    from abcsmc_amd import _lib, abcutil, device
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    rng = abcutil.rng(67890)
+    gw = device.Generation(N, M, P, K, 0, 0, 0.5, A, rule=_lib.RULE_WILCOXON, multivariate=True, device=dev, ctx=ctx)
+    gp = device.Generation(N, M, P, K, 0, 0, 0.5, A, rule=_lib.RULE_MIN_PRESS, multivariate=True, device=dev, ctx=ctx)
+    mux, sdx = dX.mean(dim=1, keepdim=True), dX.std(dim=1, keepdim=True)
+    muy, sdy = dY.mean(dim=1, keepdim=True), dY.std(dim=1, keepdim=True)
+    f64 = dY.dtype
+    dpri0 = device.priors_to_device(_lib.make_priors([(_lib.PRIOR_GAUSS, 0.0, 1.0)] * P), dev)
+    for r in (3, 2):
+        Bx = torch.linalg.qr(torch.randn((M, r), generator=g, device=dev, dtype=f64))[0]
+        Z = Bx.T @ ((dX - mux) / sdx)                            # r x N factors of the z-scored metrics
+        Z = Z / Z.std(dim=1, keepdim=True)
+        rown = Bx.norm(dim=1, keepdim=True)
+        dXn = Bx @ Z
+        for j in range(M):                                       # (column by column: no second M x N temporary)
+            dXn[j] += 0.5 * rown[j, 0] * torch.randn((N,), generator=g, device=dev, dtype=f64)
+        dXn = (mux + sdx / (rown * 1.25 ** 0.5) * dXn).contiguous()
+        Wy = torch.randn((P, r), generator=g, device=dev, dtype=f64) / r ** 0.5
+        dYn = (muy + sdy * (Wy @ Z + torch.randn((P, N), generator=g, device=dev, dtype=f64))).contiguous()
+        del Z
+        gw.run(dXn, dYn, dobs, dpri0, rng)                       # (ranking only: the priors are not looked at)
+        gp.run(dXn, dYn, dobs, dpri0, rng)
+        torch.cuda.synchronize()
+        if gw.ncomp.value < gp.ncomp.value:
+            mun, sdn = dYn.mean(dim=1).cpu().numpy(), dYn.std(dim=1).cpu().numpy()
+            spec = [(_lib.PRIOR_UNIF_REAL, mun[j] - 6 * sdn[j], mun[j] + 6 * sdn[j]) if j % 2 == 0 else (_lib.PRIOR_GAUSS, mun[j], 3 * sdn[j])
+                    for j in range(P)]
+            dprin = device.priors_to_device(_lib.make_priors(spec), dev)
+            prev = ()
+            if Kp:
+                rows = torch.randint(0, N, (Kp,), generator=g, device=dev)
+                mn = dYn.mean(dim=1, keepdim=True)
+                th = (mn + 0.5 * (dYn[:, rows] - mn)).contiguous()
+                prev = (th, torch.full((Kp,), 1.0 / Kp, dtype=f64, device=dev), 2.0 * th.var(dim=1, unbiased=True))
+            return r, dXn, dYn, dprin, prev
+        dXn = dYn = None
+    return None
+
+
+def moved_count_legs(ctx, dX, dY, dobs, dpri, dtp, dwp, ddvp, N, M, P, K, Kp, A, dev, timed):
+    """extra["moved_count"]: see the caller and moved_count_data."""
+    from abcsmc_amd import _lib, abcutil, device
+    data = moved_count_data(ctx, dX, dY, dobs, N, M, P, K, Kp, A, dev)
+    if data is None:
+        return {"found": False}
+    r, dXn, dYn, dprin, prev = data
+    res = {"found": True, "factor_rank": r}
+    rng = abcutil.rng(67890)
+    gw = device.Generation(N, M, P, K, Kp, N, 0.5, A, rule=_lib.RULE_WILCOXON, multivariate=True, device=dev, ctx=ctx)
+    gp = device.Generation(N, M, P, K, Kp, N, 0.5, A, rule=_lib.RULE_MIN_PRESS, multivariate=True, device=dev, ctx=ctx)
+    gw0 = device.Generation(N, M, P, K, 0, N, 0.5, A, rule=_lib.RULE_WILCOXON, multivariate=True, device=dev, ctx=ctx)
+    gp0 = device.Generation(N, M, P, K, 0, N, 0.5, A, rule=_lib.RULE_MIN_PRESS, multivariate=True, device=dev, ctx=ctx)
+
+    def leg(gen_w, gen_p, args_prev):
+        ctx.generation_repeats(reset=True)
+        reps = 5 if K * max(Kp, 1) <= 2e10 else 2
+        ms_w = timed(lambda: gen_w.run(dXn, dYn, dobs, dprin, rng, *args_prev), reps=reps, warm=2)
+        rr, gr = ctx.generation_repeats(reset=True)
+        ms_p = timed(lambda: gen_p.run(dXn, dYn, dobs, dprin, rng, *args_prev), reps=reps, warm=2)
+        return {"moved_count_step_ms": round(ms_w, 5), "moved_count_ncomp": int(gen_w.ncomp.value), "fit_ncomp": int(gen_p.ncomp.value),
+                "min_press_step_ms_same_data": round(ms_p, 5), "rule_and_repair_ms": round(ms_w - ms_p, 5),
+                "ranking_repeats_per_step": rr / (reps + 2), "generation_repeats_per_step": gr / (reps + 2),
+                "proposal_giveups_last_step": ctx.generation_giveups()}
+    res.update(leg(gw, gp, prev))
+    res["first_set"] = leg(gw0, gp0, ())
+    res["note"] = ("metrics = factor_rank factors of the workload's + noise (half the factors' share per column), responses = combinations "
+                   "of those factors + N(0,1) x their standard deviation: argmin PRESS keeps components "
+                   "that only fit noise and the Wilcoxon rule takes them back, i.e. the ranking that ran beside the reduction on the "
+                   "fit's count is repeated (ranking_repeats_per_step 1) -- the case the timed region's clean responses never reach; "
+                   "rule_and_repair_ms = this step minus the argmin-PRESS step on the same data")
+    return res
 
 
 def predict_scaling(ms_per_step, kde_ms, sharded_ms, collectives, collective_ms, gpus=(2, 4, 8)):

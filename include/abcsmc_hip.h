@@ -143,6 +143,13 @@ int  abc_perturb_giveups(abc_ctx* ctx, uint64_t* count, int reset);
  * call: those of THIS rank's slice of the proposals; 0 after a clean generation; the value the host already holds at the call's
  * end: no synchronisation). */
 int  abc_generation_giveups(const abc_ctx* ctx, uint64_t* count);
+/* What the speculation on the component count cost since the context was created (or the last reset).  A whole generation under
+ * ABC_RULE_WILCOXON ranks on the count the fit wrote while the reduction of AbcUtil.cpp:447-449 runs beside it;
+ * when the reduction lowers the LARGEST per-response count -- the one the distances use, AbcUtil.cpp:449 -- the projection, the
+ * selection and the gather run once more with it (*ranking_repeats), and when the reduction itself gives up on its fast path, or a
+ * degenerate selection has to be redone by radix select, the generation starts over (*generation_repeats).  Both 0 on clean
+ * responses; neither changes a result.  No synchronisation. */
+int  abc_generation_repeats(const abc_ctx* ctx, uint64_t* ranking_repeats, uint64_t* generation_repeats, int reset);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
  * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]

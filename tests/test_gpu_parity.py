@@ -1862,10 +1862,11 @@ def test_generation_config2_size_against_the_full_oracle(gpu_ctx, oracle):
                                             (40, 4, 20, 2.0, 0)])
 def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, noise, Kp):
     """Whole generations on sets the Wilcoxon cascade takes run the ranking BESIDE the reduction, on the component count the fit wrote
-    (api.hip, round 5): the ranking's projection scores all A components in its one pass over X (the validation rows' scores go to
-    the cascade) and takes the distance over the fit's count.  With noisy responses the reduction lowers the largest count: the generation,
-    which has queued everything up to its proposals on the fit's count by the time it looks at the cascade, throws that away and
-    runs once more with the reduction in stream order.
+    (api.hip, round 5): the ranking's projection scores all A components in its one pass over X (every row's scores are kept, the
+    validation rows' go to the cascade) and takes the distance over the fit's count.  The host looks at the cascade -- which takes the
+    tests of a few responses that hold the largest count first (round 6) -- in front of the weight stage.  With noisy responses the
+    reduction lowers the largest count: the distances are taken again from the kept scores, selection and gather run once more
+    (round 5's default had queued everything up to the proposals by then and repeated the whole generation: ABC_WX_DEFER).
     With clean responses the count stands.  Either way every output equals the oracle's generation under the rule -- the parents too,
     so the repeat starts from the generator's state at entry -- and the count equals the oracle's, which in the noisy cases is below
     the argmin-PRESS count (checked: the speculation is wrong there and has to be repaired).  8 / 10 components: the vector
@@ -1882,13 +1883,22 @@ def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, 
     gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=_lib.RULE_WILCOXON, multivariate=True, device=dev, ctx=gpu_ctx)
     r = abcutil.rng(67890)
     dprev = [device.colmajor(a, dev) for a in prev] if Kp else []
+    gpu_ctx.generation_repeats(reset=True)
     gen.run(device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
+    ranking_repeats, generation_repeats = gpu_ctx.generation_repeats(reset=True)
     o = oracle.rng(67890)
     ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=0.5, max_comp=A, rule=oracle.RULE_WILCOXON, multivariate=True)
     press = oracle.particle_ranking_pls(X, Y, obs, 0.5, A, rule=oracle.RULE_MIN_PRESS)["ncomp"]
-    print("speculation: argmin PRESS keeps %d components, the Wilcoxon rule %d (noise %.1f)" % (press, ref["ncomp"], noise))
+    print("speculation: argmin PRESS keeps %d components, the Wilcoxon rule %d (noise %.1f); ranking repeated %d times, generation %d times"
+          % (press, ref["ncomp"], noise, ranking_repeats, generation_repeats))
     if noise:
         assert ref["ncomp"] < press            # (the case the test is for: the count the ranking speculated on is wrong)
+    # what the repair cost (abc_generation_repeats): a moved count = the three ranking stages ONCE more, a count that stands = nothing;
+    # the generation itself is never repeated (round 5's default did that).  Under the diagnostic switches that force the cascade to
+    # fail or defer its look the counts are those switches' own.
+    import os
+    if not any(os.environ.get(k) for k in ("ABC_WX_FORCE_FAIL", "ABC_WX_DEFER", "ABC_WX_INLINE")):
+        assert (ranking_repeats, generation_repeats) == ((1, 0) if ref["ncomp"] < press else (0, 0))
     assert gen.ncomp.value == ref["ncomp"]
     assert np.array_equal(gen.idx.cpu().numpy().astype(np.uint64), ref["idx"])
     assert np.allclose(gen.w.cpu().numpy(), ref["w"], rtol=RTOL)
@@ -1897,9 +1907,9 @@ def test_generation_speculates_on_the_component_count(gpu_ctx, oracle, M, P, A, 
 
 
 def test_generation_repeats_itself_when_the_cascade_gives_up(gpu_ctx):
-    """the cascade's second half reports failure (ABC_WX_FORCE_FAIL: as if a bin of its exact step had outgrown LDS) when the
-    generation has already queued its weight stage and its proposals on the fit's count: everything is thrown away and the
-    generation runs once more with the reduction in stream order (which, forced to fail again, repeats itself on the sorted path).
+    """the cascade reports failure (ABC_WX_FORCE_FAIL: as if a bin of its exact step had outgrown LDS) when the generation looks at
+    it in front of its weight stage: the reduction runs once more in stream order (which, forced to fail again, repeats itself on
+    the sorted path), and the ranking with it.
     The speculation test's weighted and first-set cases in a process of their own (the switch is read once): every output the
     oracle's, parents included"""
     import os
@@ -1912,6 +1922,13 @@ def test_generation_repeats_itself_when_the_cascade_gives_up(gpu_ctx):
                        timeout=900, env=env, cwd=root)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "3 passed" in p.stdout, p.stdout[-500:]
+    # ... and round 5's default, kept behind a switch: everything up to the proposals queued on the fit's count, the look at the
+    # cascade behind them, a moved count repeating the whole generation -- one weighted case with noisy responses
+    env = dict(os.environ, ABC_DIAG="1", ABC_WX_DEFER="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", ids[0]], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "1 passed" in p.stdout, p.stdout[-500:]
 
 
 def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
