@@ -13,7 +13,7 @@ RULE_MIN_PRESS, RULE_WILCOXON = 0, 1
 # best knowledge of upstream's optimal_num_components -- argmin PRESS reduced by the Wilcoxon signed-rank test
 RULE_DEFAULT = RULE_WILCOXON
 KDE_AUTO, KDE_FP64 = 0, 1
-GRAM_AUTO, GRAM_FP64 = 0, 1
+GRAM_AUTO, GRAM_FP64, GRAM_I8 = 0, 1, 2
 KDE_RAN_NONE, KDE_RAN_FP64, KDE_RAN_SPLIT = 0, 1, 2
 DT_F64, DT_I32, DT_I64 = 0, 1, 2
 COMM_ID_BYTES = 128
@@ -307,7 +307,8 @@ class Context:
         return F, A, on.value
 
     def set_gram_mode(self, mode):
-        """GRAM_AUTO (byte-limb statistics kernel for wide, large sets) or GRAM_FP64 (abc_ctx_set_gram_mode)"""
+        """GRAM_AUTO (byte-limb statistics kernel for wide sets whose partitions hold >= 400 000 rows), GRAM_FP64, or GRAM_I8 (the
+        byte-limb kernel from 200 000 rows: A/B runs, its own tests) -- abc_ctx_set_gram_mode"""
         self.check(lib().abc_ctx_set_gram_mode(self._h, int(mode)))
 
     def set_kde_mode(self, mode):

@@ -85,7 +85,7 @@ extern "C" int abc_ctx_create(int device, abc_ctx** out) {
     if (hipHostMalloc((void**)&ctx->status_pin, 128, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ABC_ERR_HIP; }
     ctx->stream = ctx->own_stream;
     ctx->wx_gather_rows = abc_diag_env("ABC_WX_GATHER") != nullptr;
-    ctx->gram_mode = abc_diag_env("ABC_GRAM_FP64") ? ABC_GRAM_FP64 : ABC_GRAM_AUTO;      // (the diagnostic switch of round 4: the initial mode)
+    ctx->gram_mode = abc_diag_env("ABC_GRAM_FP64") ? ABC_GRAM_FP64 : (abc_diag_env("ABC_GRAM_I8") ? ABC_GRAM_I8 : ABC_GRAM_AUTO);      // (the diagnostic switch of round 4: the initial mode)
     *out = ctx;
     return ABC_OK;
 }
@@ -140,7 +140,7 @@ extern "C" int abc_ctx_set_kde_mode(abc_ctx* ctx, int mode) {
 
 extern "C" int abc_ctx_set_gram_mode(abc_ctx* ctx, int mode) {
     if (!ctx) return ABC_ERR_INVALID;
-    if (mode != ABC_GRAM_AUTO && mode != ABC_GRAM_FP64) ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_gram_mode: unknown mode %d", mode);
+    if (mode != ABC_GRAM_AUTO && mode != ABC_GRAM_FP64 && mode != ABC_GRAM_I8) ABC_FAIL(ctx, ABC_ERR_INVALID, "abc_ctx_set_gram_mode: unknown mode %d", mode);
     ctx->gram_mode = mode;
     return ABC_OK;
 }

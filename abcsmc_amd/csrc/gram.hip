@@ -1523,7 +1523,19 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // sets (k_gram_i8, below): 1.59 ms against k_gram_dma8's 1.99 at 1e7 rows x 96 columns (0.60 against 0.48 of HBM: the fp64
     // matrix pipe is 0.62 busy there), the same statistics to the byte products' error (section 4).  From 2e6 rows: where it was measured.
     static const bool dma8_96 = abc_diag_env("ABC_GRAM_DMA8_96") != nullptr;              // A/B switch: the fp64 kernel as before
-    if (!dma8_96 && C == 6 && dma_ok && ctx->gram_mode != ABC_GRAM_FP64 && (n_set ? n_set : n) >= 2000000 && n >= 4096) {
+    // WHERE THE BYTE-LIMB KERNEL IS THE DEFAULT (round 6).  Its noise -- every value rounded to a 32-bit grid -- is harmless at the
+    // Gram's own scale (4e-11 of sqrt(G_aa G_bb)) but not always at the LOADINGS: a component that fits noise works on cross
+    // products sqrt(rows) below that scale, with close eigenvalues, and tests/fuzz/wide_model_fuzz.py found a used loading column
+    // 4.3e-6 off the oracle's (fp64 kernels: 4e-10) at 66 000 training rows x 29 responses x 30 components -- BASELINE.json allows
+    // 1e-6.  The error falls faster than 1 / rows: 60 fuzzed sets whose partitions hold 450 000 rows and more stay within 7.7e-8
+    // (profiles/r06_wide_model_fuzz_big.json).  So ABC_GRAM_AUTO takes the kernel only where EVERY non-empty partition of the
+    // WHOLE set (training / validation rows: n_train_global, n_set) has at least 400 000 rows -- configs[4] (5e5 + 5e5), configs[3]
+    // (5e6 + 5e6) -- and the fp64 kernels below that; ABC_GRAM_I8 is round 5's rule (200 000 rows in the whole set) for A/B runs and tests.
+    const size_t rows_set = n_set ? n_set : n;
+    const size_t ntr_set = n_train_global < rows_set ? (size_t)n_train_global : rows_set, nte_set = rows_set - ntr_set;
+    const size_t part_min = (ntr_set && nte_set) ? (ntr_set < nte_set ? ntr_set : nte_set) : (ntr_set ? ntr_set : nte_set);
+    const bool i8_rows = ctx->gram_mode == ABC_GRAM_I8 ? rows_set >= 200000 : (ctx->gram_mode == ABC_GRAM_AUTO && part_min >= 400000);
+    if (!dma8_96 && C == 6 && dma_ok && i8_rows && rows_set >= 2000000 && n >= 4096) {
         if (CY == 2) return run_gram_i8<6, 2>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
         if (CY == 1) return run_gram_i8<6, 1>(ctx, X, Y, n, ldx, ldy, M, P, split, stats);
     }
@@ -1544,7 +1556,9 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // (LDS-DMA staging: 16-byte aligned columns, an even row count; from 200000 rows: the values are rounded to a 32-bit grid of
     // 10 .. 19 sigma, noise of 3e-9 sigma per value that averages out with the square root of the rows -- 1e-10 of sqrt(G_aa G_bb) at
     // 35000 rows per partition, which the 32nd loading of a 128-metric model amplifies to 2e-7; 4e-8 at 1e6 rows)
-    const bool i8_ok = !gram_fp64 && (n_set ? n_set : n) >= 200000 && n >= 4096 && dma_ok;
+    // (a rank whose shard the kernel cannot take -- an odd row count, columns that are not 16-byte aligned, fewer than 4096 rows --
+    // runs the fp64 kernel on ITS rows: the decision above is the same on every rank, this one is about what can run)
+    const bool i8_ok = !gram_fp64 && i8_rows && n >= 4096 && dma_ok;
 #define GRAM_WIDE_CASE(c, cy) if (C == c && CY == cy) return i8_ok ? run_gram_i8<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats) \
                                                                     : run_gram_wide<c, cy>(ctx, X, Y, n, ldx, ldy, M, P, split, stats)
     // (7 blocks, 97..112 columns: the byte-limb kernel where it applies -- round 5; the fp64 one-launch kernel spills at that width, so

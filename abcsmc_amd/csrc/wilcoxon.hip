@@ -738,7 +738,7 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
     for (int j0 = 0; j0 < P; j0 += 1024) {
         const int j = j0 + t;
         unsigned int need = 0;
-        int b0 = 0;
+        int b0 = 0, my_hi = 0;
         if (j < P) {
             b0 = segbase[j];
             const int as = astar[j], n = as - 1;
@@ -754,6 +754,19 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
             atomicMax(&s_lo, lo);
             atomicMax(&s_hi, hi);
             if (per_out) per_out[j] = (double)hi;            // (exact once nothing of the response is open; an upper end until then)
+            my_hi = hi;
+        }
+        // (round 6) a caller that only uses the LARGEST count does not need the open tests of a response whose count can no longer
+        // exceed what another response keeps for certain (hi_j <= max_j lo_j): with noisy responses most responses have a passing
+        // candidate low down, and their open tests in front of it were most of the next level's work.  (One response per thread:
+        // up to 1024 responses, where the maximum is known here; beyond, every response keeps its tests.)
+        // Their verdict becomes 3 = "left open, not needed": neither passed nor open to the levels after this one and to k_wx_decide,
+        // so the response's count stays the upper end its first pass gives (as every count a stop_at_max run leaves behind).
+        if (stop_at_max && P <= 1024) {
+            __syncthreads();
+            if (j < P && my_hi <= s_lo) {
+                while (need) { const int i = __ffs((int)need) - 1; need &= need - 1u; v3[b0 + i] = 3; }
+            }
         }
         const int mine = __popc(need);
         int inc = mine;
@@ -1409,11 +1422,34 @@ size_t wx_bc_bytes(size_t nv, size_t nseg_max) {           // the sweeps' counte
     if (cap_env && atol(cap_env) > 0) cap = (size_t)atol(cap_env) << 10;
     return (b < cap ? b : cap) + (1u << 20);
 }
-// bins of a fine level over `nact` tests: the fewer tests are left, the finer (a test's counters live in LDS: 4 bytes a bin)
+// bins of a fine level over `nact` tests.  A sweep work-group keeps the counters of G(bins) tests in LDS and every group of tests is
+// one more pass over the validation rows' scores (8 A bytes a row, from L2 / HBM: at 32 components the passes ARE the sweep's time --
+// 85 us for ten tests in three groups at 8192 bins, 293 us for 60 tests in eight groups at 4096; rocprofv3, round 6).  So the bins
+// are chosen by what a level is expected to cost: its passes, plus ~1.5 passes for every test it is expected to leave open (the exact
+// step's key pass, placing and ranking; or the next level's share) -- the resolution of B equi-depth bins is ~0.87 sqrt(m) / B
+// sigma, and a test that reaches a fine level has its statistic near the threshold, where |W| / sigma has density ~0.2: about
+// 126 / B sqrt(m / 5e5) of them stay open.  Rounds 4-5 took 16384 / 8192 / 4096 / 2048 bins by the number of tests alone.
 int wx_pick_bins(int nact, size_t nvt) {
-    int nb = nact <= 8 ? 16384 : (nact <= 32 ? 8192 : (nact <= 96 ? 4096 : 2048));
-    while (nb > 1024 && (size_t)nb * 4 > nvt) nb >>= 1;                // (at least four keys to the bin)
-    return nb;
+    static const char* fixed = abc_diag_env("ABC_WX_BINS_BY_COUNT");          // A/B switch: the rule of rounds 4-5
+    if (fixed) {
+        int nb = nact <= 8 ? 16384 : (nact <= 32 ? 8192 : (nact <= 96 ? 4096 : 2048));
+        while (nb > 1024 && (size_t)nb * 4 > nvt) nb >>= 1;                // (at least four keys to the bin)
+        return nb;
+    }
+    const double open_per_bin = 126.0 * sqrt((double)nvt / 5.0e5);
+    int best = 1024;
+    double best_cost = 1e300;
+    for (int nb = 16384; nb >= 1024; nb >>= 1) {
+        if (nb > 1024 && (size_t)nb * 4 > nvt) continue;                     // (at least four keys to the bin)
+        int G = (int)(((size_t)WX_LDS - 1024) / ((size_t)nb * 4 + WX_NC0 * 4 + 7 * 4 + 16));
+        if (G < 1) G = 1;
+        const double passes = (double)((nact + G - 1) / G);
+        double open = open_per_bin / nb;
+        if (open > 1.0) open = 1.0;
+        const double cost = passes + 1.5 * open * nact;
+        if (cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
 }
 int wx_xb(size_t nvt) {                           // tests of one batch of the exact step
     size_t xb = ((size_t)1 << 25) / (nvt ? nvt : 1);

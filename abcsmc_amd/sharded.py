@@ -143,7 +143,7 @@ class ShardedGeneration:
     in the C++ driver (CabiShardedGeneration -> abc_generation_sharded_dev), which is also the fast one."""
 
     def __init__(self, backend, n_local, M, P, K, Kp, nnext_local, train_frac=0.5, max_comp=0,
-                 rule=_lib.RULE_MIN_PRESS, multivariate=True, group=None):
+                 rule=None, multivariate=True, group=None):
         self.be = backend
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -153,8 +153,11 @@ class ShardedGeneration:
         self.nnext_local = nnext_local
         self.Nnext = nnext_local * self.world
         self.A = max_comp if max_comp > 0 else min(M, P)
+        # (no default: everything else without a rule argument applies the Wilcoxon rule -- a silent argmin PRESS here would give
+        # other component counts and selections than device.Generation / CabiShardedGeneration on the same set)
         if rule != _lib.RULE_MIN_PRESS:
-            raise ValueError("ShardedGeneration (stage-level driver) applies argmin PRESS only; use CabiShardedGeneration for the Wilcoxon rule")
+            raise ValueError("ShardedGeneration (stage-level driver) applies argmin PRESS only: pass rule=RULE_MIN_PRESS to say so, "
+                             "or use CabiShardedGeneration for the Wilcoxon rule (the default everywhere else)")
         self.train_frac, self.rule, self.multivariate = train_frac, rule, multivariate
         be = backend
         self.k_local = min(K, n_local)

@@ -86,21 +86,31 @@ int  abc_version(void);
  * ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
-/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets -- 97..160 columns (metrics + parameters; 97..112
- * since round 5), and, from 2 000 000 rows, 81..96 columns (round 5).
- * ABC_GRAM_AUTO (default): from 200 000 rows (81..96 columns: 2 000 000) IN THE WHOLE SET (the sharded generation decides from N_total, so that every rank and
- * the unsharded run of the same set take the same kernel) the byte-limb kernel on the i8 matrix pipe: every value rounded to a 32-bit
- * fixed-point grid of 10..19 sigma per column; column sums, row counts and the Gram DIAGONAL are exact, an off-diagonal product
- * carries ~4e-11 (typical) .. 2e-9 (worst seen: a point-mass column) of sqrt(G_aa G_bb), which the high loadings of a 128-metric,
- * 32-component model amplify to 2e-7 .. 4e-6 relative (still inside the 1e-6 of BASELINE.json for the 8 components the distance
- * uses at configs[4]; the selection is the oracle's up to near-ties).  Rows outside a column's grid ("far" rows) are summed in fp64
- * by a serial side kernel: sets with heavy tails in many rows should use ABC_GRAM_FP64.  Below the row threshold, for narrower or
- * wider sets, for unaligned / odd-length columns: fp64 kernels regardless.
- * ABC_GRAM_FP64: the fp64 kernels always (k_gram_wide: products on the fp64 matrix pipe, ~1e-15 of sqrt(G_aa G_bb)); 1.5x the time of
- * the i8 kernel at 1e6 rows x 144 columns.  With it the sharded generation's statistics equal the unsharded ones to rounding of the
- * order of summation (distances within 1e-12); under ABC_GRAM_AUTO the two differ by the fixed-point noise above (each rank rounds
- * on its own grid), selection indices still agree up to near-ties. */
-enum { ABC_GRAM_AUTO = 0, ABC_GRAM_FP64 = 1 };
+/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets: 97..160 columns (metrics + parameters), and
+ * 81..96 columns with 1..32 parameters from 2 000 000 rows.
+ * The byte-limb kernel (csrc/gram.hip: k_gram_i8, the i8 matrix pipe) rounds every value to a 32-bit fixed-point grid per column.
+ * Row counts, column sums and the Gram DIAGONAL stay exact; an off-diagonal entry obeys ONE error model (tests/_gram_model.py, the
+ * bound the fixed tests and tests/fuzz/wide_gram_fuzz.py assert per entry):
+ *     |G_ab - exact| <= 2^-32 (4 range_a range_b sqrt(rows) + range_a |S_b| + range_b |S_a|),
+ * range_c = the column's grid (4 x a robust size of |x - shift| among 4096 sampled rows, rounded up to a power of two: 10 .. 19
+ * sigma for Gaussian-like columns), S_c = the partition's sum of x - shift_c: 2e-10 of sqrt(G_aa G_bb) at 2e5 rows for Gaussian-like
+ * columns (measured: 0.06 .. 0.1 of the bound), 1.5e-9 beside a column whose mass sits in one value.  That noise is harmless at the
+ * Gram's scale but is AMPLIFIED in the loadings of components that fit noise (cross products sqrt(rows) below that scale, close
+ * eigenvalues): tests/fuzz/wide_model_fuzz.py holds every USED loading column against the oracle's fit and found 4.3e-6 (fp64
+ * kernels: 4e-10) at 66 000 training rows x 29 responses x 30 components, against the 1e-6 of BASELINE.json; with 450 000 rows and
+ * more in each partition the worst of 60 fuzzed sets is 7.7e-8 (profiles/r06_wide_model_fuzz*.json).  Hence:
+ * ABC_GRAM_AUTO (default): the byte-limb kernel only where EVERY non-empty partition (training rows, validation rows) OF THE WHOLE
+ *   SET has at least 400 000 rows -- the sharded generation decides from N_total and the training fraction, so every rank and the
+ *   unsharded run of the same set take the same kernel; a rank whose own shard the kernel cannot take (odd row count, columns not
+ *   16-byte aligned, fewer than 4096 rows) accumulates ITS rows in fp64 --, the fp64 kernels everywhere else.  Rows outside a
+ *   column's grid ("far" rows) are summed in fp64 by a serial side kernel: sets with heavy tails in many rows should use ABC_GRAM_FP64.
+ * ABC_GRAM_FP64: the fp64 kernels always (products on the fp64 matrix pipe, ~1e-15 of sqrt(G_aa G_bb)); 1.5x the time of the i8
+ *   kernel at 1e6 rows x 144 columns.  With it the sharded generation's statistics equal the unsharded ones to rounding of the order
+ *   of summation (distances within 1e-12); under the byte-limb kernel the two differ by the fixed-point noise above (each rank
+ *   rounds on its own grid), selection indices still agree up to near-ties.
+ * ABC_GRAM_I8: the byte-limb kernel from 200 000 rows in the whole set (round 5's default; A/B runs, the kernel's own tests): Gram
+ *   entries within the model above, loadings NOT held to 1e-6. */
+enum { ABC_GRAM_AUTO = 0, ABC_GRAM_FP64 = 1, ABC_GRAM_I8 = 2 };
 int  abc_ctx_set_gram_mode(abc_ctx* ctx, int mode);
 /* Which of the two kernels produced the pair sums of the most recent weight call on this context (synchronises). */
 enum { ABC_KDE_RAN_NONE = 0, ABC_KDE_RAN_FP64 = 1, ABC_KDE_RAN_SPLIT = 2 };
@@ -372,9 +382,10 @@ int abc_ctx_create_multi(const int* devices, int ndev, abc_ctx** out);
  * n_local); idx / dist / theta / w / dv / L are replicated outputs (global row numbers in idx); next / parent / seeds
  * hold this rank's nnext_local proposals (leading dimension nnext_local).  rng: the same state on every rank; advanced by
  * the 2 Nnext_total draws of the whole generation.  Results equal abc_generation_dev on the unsharded set bit for bit
- * (indices, parents, seeds) and to rounding of the reduction order (statistics -> model -> distances within 1e-12) -- for sets of
- * 113..160 columns and 200 000 rows or more under ABC_GRAM_FP64 only (abc_ctx_set_gram_mode: the default byte-limb statistics
- * kernel rounds every rank's values on the rank's own grid; indices then agree up to near-ties, distances to ~1e-7). */
+ * (indices, parents, seeds) and to rounding of the reduction order (statistics -> model -> distances within 1e-12) -- for the wide
+ * sets that take the byte-limb statistics kernel (abc_ctx_set_gram_mode: 97..160 columns, or 81..96 with parameters from 2 000 000
+ * rows, and 400 000 rows in every partition of the whole set) under ABC_GRAM_FP64 only: that kernel rounds every rank's values on
+ * the rank's own grid; indices then agree up to near-ties, distances to ~1e-7. */
 typedef struct {
     size_t n_local, row0, N_total;        /* this rank's rows of the current set                      */
     size_t M, P;

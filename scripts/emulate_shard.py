@@ -49,7 +49,7 @@ dtp, dwp, ddvp = device.colmajor(th_prev, dev), device.colmajor(w_prev, dev), de
 rng = abcutil.rng(67890)
 ctx = _lib.default_context(0)
 # train_frac / W: the train/validation boundary falls inside this rank's rows, as it does on one GPU
-gen = sharded.ShardedGeneration(sharded.HipBackend(dev, ctx), n_loc, M, P, K, Kp, n_loc, 0.5 / W, A, multivariate=True)
+gen = sharded.ShardedGeneration(sharded.HipBackend(dev, ctx), n_loc, M, P, K, Kp, n_loc, 0.5 / W, A, rule=_lib.RULE_MIN_PRESS, multivariate=True)
 for _ in range(2):
     gen.run(dX, dY, dobs, dpri, rng, dtp, dwp, ddvp)
 torch.cuda.synchronize()

@@ -1,21 +1,27 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the randomised differential tests against the oracle on the final build of a round
-#   gpurun --timeout 1200 -- 'bash scripts/gpu_fuzz_round.sh [part]'        part a: wilcoxon + wide gram + ranking; b: generations (+ large); c: sharded, weights, resample
+#   gpurun --timeout 1200 -- 'bash scripts/gpu_fuzz_round.sh [part] [round tag]'
+#   part a: wilcoxon + wide gram + wide model; b: generations (+ large); c: sharded, weights, resample, ranking
 set -u
 OUT=gpurun_out
 PART=${1:-abc}
+R=${2:-r06}
 mkdir -p $OUT
+run() { # script, out name, cases, seed, [env]
+  timeout -k 10 ${T:-900} python3 tests/fuzz/$1 $OUT/${R}_$2.json $3 $4 > $OUT/fuzz_$2.log 2>&1; tail -1 $OUT/fuzz_$2.log
+}
 if [[ $PART == *a* ]]; then
-python3 tests/fuzz/wilcoxon_fuzz.py $OUT/r05_wilcoxon_fuzz.json 100 505 > $OUT/fuzz_wilcoxon.log 2>&1; tail -2 $OUT/fuzz_wilcoxon.log
-python3 tests/fuzz/wide_gram_fuzz.py $OUT/r05_wide_gram_fuzz.json 40 506 > $OUT/fuzz_wide_gram.log 2>&1; tail -1 $OUT/fuzz_wide_gram.log
-python3 tests/fuzz/ranking_fuzz.py $OUT/r05_ranking_fuzz.json 150 507 > $OUT/fuzz_ranking.log 2>&1; tail -1 $OUT/fuzz_ranking.log
+run wilcoxon_fuzz.py wilcoxon_fuzz 100 605
+run wide_gram_fuzz.py wide_gram_fuzz 40 606
+run wide_model_fuzz.py wide_model_fuzz 60 607
 fi
 if [[ $PART == *b* ]]; then
-python3 tests/fuzz/generation_fuzz.py $OUT/r05_generation_fuzz.json 200 508 > $OUT/fuzz_generation.log 2>&1; tail -1 $OUT/fuzz_generation.log
-FUZZ_LARGE=1 python3 tests/fuzz/generation_fuzz.py $OUT/r05_generation_fuzz_large.json 40 509 > $OUT/fuzz_generation_large.log 2>&1; tail -1 $OUT/fuzz_generation_large.log
+run generation_fuzz.py generation_fuzz 200 608
+FUZZ_LARGE=1 run generation_fuzz.py generation_fuzz_large 40 609
 fi
 if [[ $PART == *c* ]]; then
-python3 tests/fuzz/sharded_fuzz.py $OUT/r05_sharded_fuzz.json 24 510 > $OUT/fuzz_sharded.log 2>&1; tail -1 $OUT/fuzz_sharded.log
-python3 tests/fuzz/weights_fuzz.py $OUT/r05_weights_fuzz.json 200 511 > $OUT/fuzz_weights.log 2>&1; tail -1 $OUT/fuzz_weights.log
-python3 tests/fuzz/resample_fuzz.py $OUT/r05_resample_fuzz.json 150 512 > $OUT/fuzz_resample.log 2>&1; tail -1 $OUT/fuzz_resample.log
+run sharded_fuzz.py sharded_fuzz 24 610
+run weights_fuzz.py weights_fuzz 200 611
+run resample_fuzz.py resample_fuzz 150 612
+run ranking_fuzz.py ranking_fuzz 150 613
 fi

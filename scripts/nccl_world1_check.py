@@ -50,7 +50,7 @@ dX, dY, dobs = device.colmajor(X, dev), device.colmajor(Y, dev), device.colmajor
 dpri = device.priors_to_device(_lib.make_priors(wl.prior_spec()), dev)
 prev = [device.colmajor(a, dev) for a in wl.previous_set(Kp)]
 ctx = _lib.default_context(0)
-sg = sharded.ShardedGeneration(sharded.HipBackend(dev, ctx), N, M, P, K, Kp, N, 0.5, A, multivariate=True)
+sg = sharded.ShardedGeneration(sharded.HipBackend(dev, ctx), N, M, P, K, Kp, N, 0.5, A, rule=_lib.RULE_MIN_PRESS, multivariate=True)
 sg.run(dX, dY, dobs, dpri, abcutil.rng(67890), *prev)
 fg = device.Generation(N, M, P, K, Kp, N, 0.5, A, multivariate=True, device=dev, ctx=ctx)
 fg.run(dX, dY, dobs, dpri, abcutil.rng(67890), *prev)

@@ -87,7 +87,7 @@ def main():
         gen = sharded.CabiShardedGeneration(ctx, dev, row_hi - row_lo, M, P, K, Kp, nn_loc, 0.5, A, rule=rule, multivariate=True,
                                             row0=row_lo, N_total=N, next0=rank * nn_loc, Nnext_total=nn_loc * world)
     else:
-        gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, multivariate=True)
+        gen = sharded.ShardedGeneration(be, n_loc, M, P, K, Kp, nn_loc, 0.5, A, rule=_lib.RULE_MIN_PRESS, multivariate=True)
     rng = _lib.Rng()
     _lib.lib().abc_rng_set(__import__("ctypes").byref(rng), 4242)
     gen.run(cm(X), cm(Y), cm(obs), priors, rng, cm(thp), cm(wp), cm(dvp))

@@ -1216,18 +1216,32 @@ def _run_generation(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=1):   
     return wl, X, Y, obs, spec, prev, gen, r
 
 
+_DEVICE_SET = {}
+
+
+def _device_set(N, M, P):
+    """the synthetic set of seed 12345 generated on the GPU and its download, kept for the NEXT test that asks for the same shape
+    (round 6: the three tests at configs[3]'s stated size each generated and downloaded the same 7.7 GB; one entry is kept)"""
+    from abcsmc_amd import synthetic
+    key = (N, M, P)
+    if key not in _DEVICE_SET:
+        _DEVICE_SET.clear()
+        wl = synthetic.Workload(M, P, 12345)
+        dX, dY = wl.rows_device(0, N, "cuda:0")
+        _DEVICE_SET[key] = (wl, dX, dY, dX.cpu().numpy().T, dY.cpu().numpy().T)     # (N, c) column-major views of the downloads
+    return _DEVICE_SET[key]
+
+
 def _run_generation_device_inputs(N, M, P, K, Kp, Nn, A, multivariate, seed=67890, rule=1):
     """_run_generation with the synthetic set generated ON the GPU (synthetic.Workload.rows_device: numpy takes minutes at
     1e7 rows) and downloaded for the oracle: both sides see the same bits"""
     import torch
     from abcsmc_amd import abcutil, device, synthetic, _lib
     dev = "cuda:0"
-    wl = synthetic.Workload(M, P, 12345)
-    dX, dY = wl.rows_device(0, N, dev)
+    wl, dX, dY, X, Y = _device_set(N, M, P)
     obs = wl.observed()
     spec = wl.prior_spec()
     dprev = wl.previous_set_device(Kp, dev)
-    X, Y = dX.cpu().numpy().T, dY.cpu().numpy().T                  # (N, c) column-major views of the downloads
     prev = (dprev[0].cpu().numpy().T, dprev[1].cpu().numpy(), dprev[2].cpu().numpy())
     gen = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=rule, multivariate=multivariate, device=dev)
     r = abcutil.rng(seed)
@@ -1542,6 +1556,8 @@ def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
     top pair dropped -- to 5e-10 of sqrt(G_aa G_bb) (it falls with the square root of the rows); with values far outside the sampled
     range (their rows go through k_gram_far in fp64), heavy tails, a column of tiny variance and a constant one; an odd row count
     (no 16-byte row pairs for the LDS-DMA staging) stays on the fp64 matrix pipe"""
+    from abcsmc_amd import _lib
+    gpu_ctx.set_gram_mode(_lib.GRAM_I8)        # (round 6: ABC_GRAM_AUTO takes this kernel from 400 000 rows per partition only)
     wl, X, Y, obs = _wl(M, P, N, 21)
     rng = np.random.default_rng(3)
     if kind == "spikes":                      # a handful of values hundreds of times beyond anything the 4096 sampled rows hold
@@ -1556,10 +1572,14 @@ def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
         X[:, 9] = -1.0                       # ... and one that is constant throughout
     X, Y = np.asfortranarray(X), np.asfortranarray(Y)
     ntrain = N // 2
-    shift, sums, G = _stats_record(gpu_ctx, X, Y, ntrain)
+    try:
+        shift, sums, G = _stats_record(gpu_ctx, X, Y, ntrain)
+    finally:
+        gpu_ctx.set_gram_mode(_lib.GRAM_AUTO)
     Z = np.hstack([X, Y])
     C = M + P
-    worst, where = 0.0, ""
+    worst, where, worst_vs_model = 0.0, "", 0.0
+    from _gram_model import gram_error_bound
     for part, (a, b) in enumerate(((0, ntrain), (ntrain, N))):
         V = Z[a:b] - shift[:C]
         ref = V.T @ V
@@ -1570,20 +1590,26 @@ def test_wide_gram_on_the_i8_matrix_pipe(gpu_ctx, N, M, P, kind):
         assert np.allclose(np.diag(G[part])[M:C], np.diag(ref)[M:C], rtol=1e-12)                     # Y'Y diagonal
         blockXX = np.abs(G[part][:M, :M] - ref[:M, :M]) / scale[:M, :M]
         blockXY = np.abs(G[part][:M, M:C] - ref[:M, M:C]) / scale[:M, M:C]
+        # the kernel's error model, per entry (tests/_gram_model.py: 4 x 2^-32 range_a range_b sqrt(rows), range_c as k_pilot_scale
+        # takes it) -- the ONE contract of the header, the fuzzer and this test; an odd row count stays on the fp64 kernel
+        ratio = np.abs(G[part][:M, :C] - ref[:M, :C]) / ((gram_error_bound(Z, shift[:C], a, b)[:M, :C] if N % 2 == 0 else 1e-13 * scale[:M, :C]) + 1e-300)
+        np.fill_diagonal(ratio[:, :M], 0.0)
+        worst_vs_model = max(worst_vs_model, float(ratio.max()))
         if max(blockXX.max(), blockXY.max()) > worst:
             worst = max(blockXX.max(), blockXY.max())
             full = np.abs(G[part][:M, :C] - ref[:M, :C]) / scale[:M, :C]
             wa, wb = np.unravel_index(np.argmax(full), full.shape)
             where = "partition %d, columns (%d, %d): %.17g against %.17g" % (part, wa, wb, G[part][wa, wb], ref[wa, wb])
         assert np.allclose(G[part][:M, :C], G[part][:C, :M].T)                                       # symmetric where both halves exist
-    print("wide Gram %s N=%d: worst off-diagonal error %.2e of sqrt(G_aa G_bb) (%s)" % (kind, N, worst, where))
-    assert worst <= 5e-10, worst
+    print("wide Gram %s N=%d: worst off-diagonal error %.2e of sqrt(G_aa G_bb) (%s) = %.2f x the error model's bound" % (kind, N, worst, where, worst_vs_model))
+    assert worst_vs_model <= 1.0, (worst_vs_model, worst)
 
 
 def test_gram_mode_is_a_public_setting(gpu_ctx):
     """abc_ctx_set_gram_mode (the precision of the wide sets' statistics was an internal switch): ABC_GRAM_FP64 sends
     a set the byte-limb kernel would take to the fp64 matrix pipe -- off-diagonal products to 1e-13 of sqrt(G_aa G_bb) instead of
-    ~1e-10 --, ABC_GRAM_AUTO brings the i8 kernel back (a different, less exact record), an unknown mode is refused"""
+    ~1e-10 --, ABC_GRAM_I8 brings the byte-limb kernel back (a different, less exact record), ABC_GRAM_AUTO takes it only where every
+    partition holds 400 000 rows (round 6: the loadings-level contract, tests/fuzz/wide_model_fuzz.py), an unknown mode is refused"""
     from abcsmc_amd import _lib
     N, M, P = 200_000, 128, 16
     wl, X, Y, obs = _wl(M, P, N, 21)
@@ -1603,12 +1629,15 @@ def test_gram_mode_is_a_public_setting(gpu_ctx):
     try:
         gpu_ctx.set_gram_mode(_lib.GRAM_FP64)
         e64 = worst()
-        gpu_ctx.set_gram_mode(_lib.GRAM_AUTO)
+        gpu_ctx.set_gram_mode(_lib.GRAM_I8)
         e8 = worst()
+        gpu_ctx.set_gram_mode(_lib.GRAM_AUTO)         # (round 6: 1e5 rows per partition are fewer than the 400 000 the default asks for)
+        eauto = worst()
     finally:
         gpu_ctx.set_gram_mode(_lib.GRAM_AUTO)
-    print("wide Gram, 144 columns x 2e5 rows: worst off-diagonal error %.2e (ABC_GRAM_FP64), %.2e (ABC_GRAM_AUTO: i8 limbs)" % (e64, e8))
-    assert e64 <= 1e-13 and 1e-13 < e8 <= 5e-10, (e64, e8)
+    print("wide Gram, 144 columns x 2e5 rows: worst off-diagonal error %.2e (ABC_GRAM_FP64), %.2e (ABC_GRAM_I8: byte limbs), %.2e (ABC_GRAM_AUTO)"
+          % (e64, e8, eauto))
+    assert e64 <= 1e-13 and 1e-13 < e8 <= 5e-10 and eauto <= 1e-13, (e64, e8, eauto)
     assert _lib.lib().abc_ctx_set_gram_mode(gpu_ctx.handle, 7) == _lib.lib().abc_ctx_set_gram_mode(None, 0) != 0
 
 
@@ -1935,16 +1964,15 @@ def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
     """BASELINE configs[3] at its STATED size under the drop-in's default rule: 1e7 particles x 64 metrics x 32 responses x 8
     components = up to 224 tests over 5e6 validation rows, through the staged entry points on device-generated rows (the model under
     argmin PRESS, then abc_pls_wilcoxon_dev).  The component count of EVERY response is compared with the oracle's reduction run on the
-    device's own model -- for 6 of the 32 responses: the oracle sorts 5e6 differences per (response, candidate) test, about a
+    device's own model -- for 3 of the 32 responses: the oracle sorts 5e6 differences per (response, candidate) test, about a
     second each, and the 224 tests of all responses would take four minutes; the responses are independent of each other in the
-    reduction (optimal_num_components works response by response), the six are spread over the columns."""
+    reduction (optimal_num_components works response by response), the three are spread over the columns."""
     import torch
     from abcsmc_amd import _lib, device, sharded, synthetic
     lib = _lib.lib()
     N, M, P, A = 10_000_000, 64, 32, 8
     dev = "cuda:0"
-    wl = synthetic.Workload(M, P, 12345)
-    dX, dY = wl.rows_device(0, N, dev)
+    wl, dX, dY, _, _ = _device_set(N, M, P)
     dobs = device.colmajor(wl.observed(), dev)
     be = sharded.HipBackend(dev, gpu_ctx)
     ntrain = N // 2
@@ -1968,7 +1996,7 @@ def test_wilcoxon_reduction_at_config4_stated_size(gpu_ctx, oracle):
     R = np.asfortranarray(m0[off_R:off_R + M * A].reshape(A, M).T)
     Q = np.asfortranarray(m0[off_Q:off_Q + P * A].reshape(A, P).T)
     assert int(m1[0]) == per_wx.max() and np.all(per_wx <= per_press) and np.all(per_wx >= 1)
-    cols = [0, 5, 11, 18, 26, 31]
+    cols = [0, 11, 26]                                               # (round 6: three responses instead of six -- ~1 s of sorting per test)
     Xv = dX[:, ntrain:].cpu().numpy().T                              # (N - ntrain, M) view of the download
     Zx = np.asfortranarray((Xv - mean[:M]) / sd[:M])
     del Xv

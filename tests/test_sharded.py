@@ -250,7 +250,7 @@ def test_sharded_world1_equals_fused(gpu_ctx):
     g1 = device.Generation(N, M, P, K, Kp, Nn, 0.5, A, rule=_lib.RULE_MIN_PRESS, device=dev, ctx=gpu_ctx)     # (the stage-level driver's rule)
     r1 = abcutil.rng(5)
     g1.run(*args, pri, r1, *prev)
-    g2 = sharded.ShardedGeneration(sharded.HipBackend(dev, gpu_ctx), N, M, P, K, Kp, Nn, 0.5, A)
+    g2 = sharded.ShardedGeneration(sharded.HipBackend(dev, gpu_ctx), N, M, P, K, Kp, Nn, 0.5, A, rule=_lib.RULE_MIN_PRESS)
     r2 = abcutil.rng(5)
     g2.run(*args, pri, r2, *prev)
     torch.cuda.synchronize()
