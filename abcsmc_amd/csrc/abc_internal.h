@@ -295,7 +295,8 @@ struct abc_wx_run;
 struct abc_wx_scores_hook { int (*fn)(void* arg, double** S, size_t* sld); void* arg; };
 int launch_wilcoxon_begin(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
                           size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out,
-                          const abc_wx_scores_hook* scores = nullptr, int hold_level0 = 0);
+                          const abc_wx_scores_hook* scores = nullptr, int hold_level0 = 0, const abc_wx_shard* sh = nullptr);
+// sh: the rows are a shard of a row-sharded set (the counts of every level are all-reduced over the context's communicator)
 // hold_level0: begin stops in front of level 0's sweep; the caller queues it (on the cascade's stream) once its own launches are out
 int launch_wilcoxon_level0(abc_ctx*, abc_wx_run* run);
 int launch_wilcoxon_finish(abc_ctx*, abc_wx_run* run, int* changed_host);

@@ -471,6 +471,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
         need += 2 * abc_wx_need(NvT, P, A) + (2u << 20);  // (the cascade over the shards and, should its exact step give up, the
                                                           // reduction once more on the gathered rows; those live in the exchange buffer)
+        need += n * A * 8 + 4096;                         // (the scores of all of this rank's rows: the projection's, read by the cascade)
     }
     ABC_TRY(abc_ws_reserve(ctx, need));
     const StatsLayout SL = stats_layout(M, P);
@@ -518,22 +519,53 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
         ABC_HIP(ctx, hipGetLastError());
     }
     ABC_TRY(launch_pls_model(ctx, stats, io->obs, M, P, A, cfg->rule, model));
-    if (cfg->rule == ABC_RULE_WILCOXON && W == 1)
-        ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, (size_t)ntrain, model));
     // The rank sums rank the paired differences of ALL validation rows (global rows >= ntrain, AbcUtil.cpp:438-446) together.
     // Round 5: nothing of the rows travels.  The reduction is a cascade of bounds on the rank sums from per-bin counts, and counts
     // are additive over rows: every rank sweeps ITS validation rows, the counts of a level are all-reduced (192 cells x 8 bytes a
     // test, then the fine bins of the tests still undecided), bounds and verdicts are computed from the same numbers on every
     // rank -- the (replicated) model stays identical everywhere without a broadcast; only the keys of the tests the bounds leave
     // undecided (8 bytes a validation row each) are all-gathered for their exact rank sums (wilcoxon.hip).
+    // Round 6: ONE pass over this rank's rows for the ranking's projection AND the cascade's scores, as in the single-GPU driver -- the
+    // projection runs first, on the count the fit wrote, and leaves the scores of all its rows; the cascade (the largest count first:
+    // the caller only uses that one) reads the validation rows' scores from there, and should it lower the count, the distances are
+    // taken again from the scores (k_dist_from_scores), not from X.  All on the main stream: the cascade's all-reduces and the
+    // selection's all-gathers share one communicator, whose collectives every rank must issue in one order.
     int wx_rc = ABC_INTERNAL_RETRY;
+    bool projected = false;
     const size_t wx_v0 = (ntrain > row0) ? (size_t)((ntrain - row0) < n ? (ntrain - row0) : n) : 0;
-    if (cfg->rule == ABC_RULE_WILCOXON && W > 1) {
+    if (cfg->rule == ABC_RULE_WILCOXON) {
         const size_t NvT = N > ntrain ? N - (size_t)ntrain : 0;
         if (NvT && abc_wx_cascade_applies(NvT, P, A) && !ctx->wx_gather_rows) {
-            const abc_wx_shard sh = {NvT, stats_all + SL.off_n + 1, SL.len};
-            wx_rc = launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, wx_v0, model, &sh, nullptr, nullptr, /*stop_at_max=*/1);
+            const abc_wx_shard sh = {NvT, W > 1 ? stats_all + SL.off_n + 1 : nullptr, SL.len};
+            double* wx_dec = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
+            if (!wx_dec) ABC_FAIL(ctx, ABC_ERR_NOMEM, "sharded generation: workspace exhausted");
+            struct ScoresArg { abc_ctx* ctx; const double* X; size_t n, M, P, A, v0; const double* model; double* dist; double* S_all; }
+                sarg = {ctx, io->X, n, M, P, A, wx_v0, model, dist, nullptr};
+            if (!(n & 1)) sarg.S_all = (double*)abc_ws_alloc(ctx, n * A * 8);
+            abc_wx_scores_hook hook = {
+                [](void* a, double** S, size_t* sld) -> int {
+                    ScoresArg* q = (ScoresArg*)a;
+                    if (!q->S_all) return 1;
+                    const int rc = launch_project_distance_scores(q->ctx, q->X, q->n, q->n, q->M, q->P, q->A, q->model, q->dist, q->S_all, q->n, 0, nullptr);
+                    if (rc == 0) { *S = q->S_all + q->v0; *sld = q->n; q->dist = nullptr; }
+                    else if (rc == 1) q->S_all = nullptr;
+                    return rc;
+                },
+                &sarg};
+            abc_wx_run* run = nullptr;
+            wx_rc = launch_wilcoxon_begin(ctx, io->X, io->Y, n, n, n, M, P, A, wx_v0, model, wx_dec, /*stop_at_max=*/1, &run, &hook, 0, W > 1 ? &sh : nullptr);
+            int changed = 2;
+            if (wx_rc == ABC_OK) wx_rc = launch_wilcoxon_finish(ctx, run, &changed);
             if (wx_rc != ABC_OK && wx_rc != ABC_INTERNAL_RETRY) return wx_rc;
+            if (wx_rc == ABC_OK) {
+                ABC_TRY(launch_wilcoxon_commit(ctx, model, M, P, A, wx_dec, changed ? 1 : 0));
+                projected = sarg.dist == nullptr;
+                if (projected && changed) ABC_TRY(launch_distance_from_scores(ctx, sarg.S_all, n, n, M, P, A, model, dist));
+            }
+        }
+        if (wx_rc == ABC_INTERNAL_RETRY && W == 1) {       // small sets, more than 32 components, the cascade's own give-up: in stream order
+            ABC_TRY(launch_wilcoxon(ctx, io->X, io->Y, n, n, n, M, P, A, (size_t)ntrain, model));
+            wx_rc = ABC_OK;
         }
     }
     if (cfg->rule == ABC_RULE_WILCOXON && W > 1 && wx_rc == ABC_INTERNAL_RETRY) {
@@ -584,7 +616,7 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
             ABC_TRY(launch_wilcoxon(ctx, Xv, Yv, Nv, Nv, Nv, M, P, A, 0, model));
         }
     }
-    ABC_TRY(launch_project_distance(ctx, io->X, n, n, M, P, A, model, 0, dist));
+    if (!projected) ABC_TRY(launch_project_distance(ctx, io->X, n, n, M, P, A, model, 0, dist));
     // first set: uniform weights, their alias table is built by the host while the GPU ranks
     const bool uniform_w = (Kp == 0 || !io->theta_prev);
     if (uniform_w && Nn) ABC_TRY(abc_uniform_alias(ctx, K));

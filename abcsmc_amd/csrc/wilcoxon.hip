@@ -1889,15 +1889,16 @@ int launch_wilcoxon_commit(abc_ctx* ctx, double* model, size_t M, size_t P, size
 // outgrew LDS -- the caller runs launch_wilcoxon in stream order instead.
 int launch_wilcoxon_begin(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P, size_t A,
                           size_t row_test, double* model, double* dec, int stop_at_max, abc_wx_run** out, const abc_wx_scores_hook* scores,
-                          int hold_level0) {
+                          int hold_level0, const abc_wx_shard* sh) {
     *out = nullptr;
     const size_t nt = n > row_test ? n - row_test : 0;
-    if (!abc_wx_cascade_applies(nt, P, A) || !dec) ABC_FAIL(ctx, ABC_ERR_INVALID, "wilcoxon: not a set for the two-halves cascade");
+    if (!abc_wx_cascade_applies(sh ? sh->nv_total : nt, P, A) || !dec) ABC_FAIL(ctx, ABC_ERR_INVALID, "wilcoxon: not a set for the two-halves cascade");
     abc_wx_run* run = new (std::nothrow) abc_wx_run;
     if (!run) ABC_FAIL(ctx, ABC_ERR_NOMEM, "wilcoxon: host memory");
     memset((void*)run, 0, sizeof(*run));
     run->ctx = ctx; run->X = X; run->Y = Y; run->nt = nt; run->ldx = ldx; run->ldy = ldy; run->M = M; run->P = P; run->A = A; run->row_test = row_test;
-    run->model = model; run->has_sh = false; run->dec = dec; run->stop_at_max = stop_at_max; run->scores_hook = scores; run->hold_level0 = hold_level0 != 0;
+    run->model = model; run->has_sh = sh != nullptr; if (sh) run->shv = *sh;
+    run->dec = dec; run->stop_at_max = stop_at_max; run->scores_hook = scores; run->hold_level0 = hold_level0 != 0;
     run->per_keep = (double*)abc_ws_alloc(ctx, (P + 1) * 8);
     int rc = run->per_keep ? ABC_OK : ABC_ERR_NOMEM;
     if (rc == ABC_OK) rc = run->begin();
