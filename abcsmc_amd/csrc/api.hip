@@ -772,7 +772,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         }
         if (changed) {                           // the largest count moved: the ranking once more, with it
             ctx->wx_moved_counts++;
-            ABC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            // (the second selection's give-up flag goes to a word of its own in the pinned block: the first gather may still be
+            // running -- resetting ITS word would need a wait for the stream here, ~15 us of idle GPU in front of the repeat)
+            pfail_early = (int*)(ctx->status_pin + 96);
             *pfail_early = 0;
             if (scores_all) ABC_TRY(launch_distance_from_scores(ctx, scores_all, N, N, M, P, A, model, dist));
             else ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, P, A, model, 0, dist));

@@ -805,7 +805,10 @@ __global__ __launch_bounds__(1024) void k_wx_bounds(int NBX, int act_n, const in
         __hip_atomic_store(&pin_words[1], (int)(vmax & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pin_words[2], (int)(vmax >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pin_words[5], decided ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (nrest_p) __hip_atomic_store(&pin_words[6], *nrest_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (nrest_p) {
+            __hip_atomic_store(&pin_words[6], *nrest_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&pin_words[7], *nact_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (the tests of this level's list)
+        }
         __threadfence();
         __hip_atomic_store(&pin_words[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the host spins on this word)
     }
@@ -1705,6 +1708,8 @@ struct abc_wx_run {
         const int* cur_n_p = nactv + 1;         // the device word that holds the length of act_cur
         int NBX_last = 0;
         ABC_TRY(look0(&left, &decided));
+        static const bool dbg_levels = abc_diag_env("ABC_WX_DEBUG") != nullptr;
+        if (dbg_levels) fprintf(stderr, "WX_LEVELS: level 0 (%s) leaves %d tests, decided %d\n", first_r > 0 ? "picked responses" : "all tests", left, (int)decided);
         // fine levels over what is left: at most two, the second only when few tests remain and finer bins are to be had.  word0: the
         // first of the half's ticket / length words (a level reads its list's length at word0 + 1 + f, leaves the next at + 2 + f)
         auto fine_levels = [&](int word0, bool first_half) -> int {
@@ -1718,6 +1723,7 @@ struct abc_wx_run {
                 ABC_TRY(level_queue(word0 + 1 + f, 1, NBX, act_cur, nactv + word0 + 1 + f, nact_host, act_nxt, nactv + word0 + 2 + f, cl_fine, cl_fine_ld, 0,
                                     first_half));
                 ABC_TRY(level_wait(&left, &decided));
+                if (dbg_levels) fprintf(stderr, "WX_LEVELS: fine level (%s, %d tests, %d bins) leaves %d, decided %d\n", first_half ? "first half" : "all", nact_host, NBX, left, (int)decided);
                 int* tmp = act_cur; act_cur = act_nxt; act_nxt = tmp;
                 cur_n_p = nactv + word0 + 2 + f;
                 NBX_last = NBX;
@@ -1728,6 +1734,10 @@ struct abc_wx_run {
             // the first half: the picked responses' tests through the fine levels; then, unless one of them keeps the largest count,
             // level 0 of ALL THE OTHER tests -- from there on as if level 0 had taken every test at once (the picked responses' verdicts
             // stand; those of their tests that are still open join the others' in the fine levels and the exact step)
+            // (tried, round 6: no fine level of their own when more than a third of the picked tests are still open after level 0 -- 15 of
+            // 28, 16 of 26, 20 of 28 on sets whose count moves, 9 of 62 and none on the clean ones.  Slower, not faster: +0.42 against
+            // +0.36 ms for a moved count at configs[2], same box -- the verdicts of that level let the level over the other responses drop
+            // most of their tests, 4 of 83 left instead of 50)
             ABC_TRY(fine_levels(0, true));
             if (!decided) {
                 // (the host sizes the launch for the tests there are -- pin[6], left by the first half's bounds kernels; sized for all
@@ -1738,6 +1748,7 @@ struct abc_wx_run {
                 if (n_rest > (int)nseg_max) n_rest = (int)nseg_max;
                 ABC_TRY(level_queue(4, 0, WX_NC0, act_rest, nactv + 4, n_rest, actB, nactv + 5, c0, WX_NC0, 1, false));
                 ABC_TRY(level_wait(&left, &decided));
+                if (dbg_levels) fprintf(stderr, "WX_LEVELS: level 0 of the other %d tests leaves %d, decided %d\n", n_rest, left, (int)decided);
                 act_cur = actB; act_nxt = actA; cur_n_p = nactv + 5; NBX_last = 0;
                 ABC_TRY(fine_levels(4, false));
             }

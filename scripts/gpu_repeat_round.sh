@@ -9,8 +9,12 @@ R=${1:-60}
 run() { echo "== $*"; env "$@" python3 scripts/repeat_check.py $R 2>&1 | grep -E "^ok|^FAIL|shapes"; }
 run A=1
 run AMD_SERIALIZE_KERNEL=3
-run ABC_WX_FINISH_EARLY=1
+# round 6's switches: round 5's deferred look, every test at level 0 (no "largest count first"), only the validation rows' scores
+# kept, the fine levels' bins by the number of tests, the scores in a pass of their own, the reduction in stream order
+run ABC_WX_DEFER=1
+run ABC_WX_FIRST=0
+run ABC_WX_FIRST=8
+run ABC_SCORES_VALID_ONLY=1
+run ABC_WX_BINS_BY_COUNT=1
 run ABC_PROJECT_SEPARATE=1
-run ABC_WX_L0_AFTER_GATHER=0
-run ABC_WX_L0_AFTER_GATHER=1
 run ABC_WX_INLINE=1
