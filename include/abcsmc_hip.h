@@ -86,8 +86,8 @@ int  abc_version(void);
  * ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
-/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets: 97..160 columns (metrics + parameters), and
- * 81..96 columns with 1..32 parameters from 2 000 000 rows.
+/* Which kernel takes the sufficient statistics (column sums, Gram blocks) of WIDE sets: 97..160 columns (metrics + parameters), and,
+ * from 2 000 000 rows, 81..96 columns whose last one or two 16-column blocks hold parameters only (80 + 16, 64 + 32: configs[3]).
  * The byte-limb kernel (csrc/gram.hip: k_gram_i8, the i8 matrix pipe) rounds every value to a 32-bit fixed-point grid per column.
  * Row counts, column sums and the Gram DIAGONAL stay exact; an off-diagonal entry obeys ONE error model (tests/_gram_model.py, the
  * bound the fixed tests and tests/fuzz/wide_gram_fuzz.py assert per entry):

@@ -15,7 +15,7 @@ if [[ $PART == *a* ]]; then
 # (configs 4 / 5 = BASELINE configs[3] / configs[4] at their STATED totals on this one GPU: 1e7 / 1e6 particles)
 python3 bench.py > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
 python3 bench.py --config 2 --no-cpu-baseline > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
-python3 bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --sustained-s 1.0 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 bench.py --config 5 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
 for c in 2 3 5; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_c$c" -o runc --output-format csv -- \
@@ -33,11 +33,15 @@ done
 for shape in "1000000 32 16 8" "1000000 128 16 32" "10000000 64 32 8"; do
   ABC_DIAG=1 ABC_WX_DEBUG=1 python3 scripts/wx_time.py $shape 3 dbg 2>&1 | grep -E "WX_DEBUG|ranking" | sort | uniq -c | sort -rn | head -3
 done > "$OUT/wx_debug.txt" 2>&1
-# the kernel timeline of one generation (configs[2], weighted and first set)
-for m in full set0; do
-  (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/trace_$m" -o t --output-format csv -- python3 "$ROOT/scripts/trace_step.py" 3 $m 5) > "$OUT/trace_$m.log" 2>&1
-  python3 scripts/timeline.py $(find "$OUT/trace_$m" -name "*kernel_trace.csv" | head -1) > "$OUT/timeline_$m.txt"
+# the kernel timeline of one generation: configs[2] weighted, first set, and with a component count the rule lowers (weighted and
+# first set: bench.moved_count_data); configs[4] and configs[3] weighted and moved
+for cm in "3 full" "3 set0" "3 moved" "3 moved0" "5 full" "5 moved" "4 full"; do
+  set -- $cm; c=$1; m=$2
+  (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/trace_${c}_$m" -o t --output-format csv -- python3 "$ROOT/scripts/trace_step.py" $c $m 5) > "$OUT/trace_${c}_$m.log" 2>&1
+  python3 scripts/timeline.py $(find "$OUT/trace_${c}_$m" -name "*kernel_trace.csv" | head -1) > "$OUT/timeline_${c}_$m.txt"
 done
+# how the cascade went, level by level (not under the profiler)
+bash scripts/gpu_r6_levels.sh > "$OUT/wx_levels.txt" 2>&1
 fi
 if [[ $PART == *b* ]]; then
 for c in 2 3; do
