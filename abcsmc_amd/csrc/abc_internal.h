@@ -209,6 +209,8 @@ int launch_stats_shift(abc_ctx*, const double* X, const double* Y, size_t n, siz
                        size_t M, size_t P, double* stats);
 // n_set (0: n): the rows of the WHOLE set these n are a shard of -- the choice between the i8 and the fp64 kernel of wide sets is
 // made from it, so that all ranks of a sharded generation and the unsharded run agree (abc_ctx_set_gram_mode)
+bool abc_gram_takes_i8(const abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
+                       uint64_t n_train_global, size_t n_set);     // the byte-limb statistics kernel for this set? (gram.hip)
 int launch_stats_accumulate(abc_ctx*, const double* X, const double* Y, size_t n, size_t ldx,
                             size_t ldy, size_t M, size_t P, uint64_t row0, uint64_t n_train_global,
                             double* stats, size_t n_set = 0);

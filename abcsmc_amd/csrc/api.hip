@@ -534,7 +534,13 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // it is forked at the call's START -- the record is the first packet of an idle queue, processed while the host prepares the
     // first launch -- and runs beside the Gram kernel; forked behind that kernel (rounds 2 and 3) the record sat between the
     // reduce and the fit and cost the critical path ~6 us (rocprofv3 timeline).  Its launches still follow the fit's.
-    static const int fork_late = abc_diag_env("ABC_FORK_LATE") ? 1 : 0;
+    // ... except beside the BYTE-LIMB statistics kernel of wide sets (round 6): that one keeps a 512-thread work-group with 150-160 KB
+    // of LDS on every CU, and every side-stream kernel resident beside it takes CUs away from it for as long as it runs -- the
+    // previous set's prologue alone is 0.74 ms there at configs[3] (0.2 ms on an idle chip): 2.34 ms for the statistics pass against
+    // 1.6 stand-alone.  Forked behind it the side stream's work runs beside the model fit and the projection instead: everything
+    // but the pair sums 6.80 -> 6.57 ms at configs[3], 1.408 -> 1.387 at configs[4].
+    static const int fork_late_env = abc_diag_env("ABC_FORK_LATE") ? 1 : (abc_diag_env("ABC_FORK_EARLY") ? -1 : 0);     // A/B switches
+    const int fork_late = fork_late_env > 0 || (fork_late_env == 0 && !simple && abc_gram_takes_i8(ctx, io->X, Yp, N, N, N, M, Pstat, ntrain, N));
     ctx->side_forked = false;
     if (!fork_late) ABC_TRY(abc_side_fork(ctx));
     ABC_TRY(launch_stats_shift(ctx, io->X, Yp, N, N, N, M, Pstat, stats));
@@ -662,6 +668,9 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (!projected) ABC_TRY(launch_project_distance(ctx, io->X, N, N, M, simple ? Pstat : P, A, model, simple, dist));
     if (K == 0) return ABC_OK;
     ABC_TRY(launch_select_smallest(ctx, dist, N, K, 0, io->idx, io->dist, /*defer_check=*/io->w != nullptr));
+    // (tried, round 6: level 0 of the cascade held BEHIND the selection where the gather is long enough to hide it -- at configs[3] the
+    // sweep beside the selection's histogram pass stretches that from 45 to 164 us, and the 0.6 ms gather behind it has room for the
+    // sweep: everything but the pair sums 6.60 -> 6.69 ms, the gather loses more than the histogram gains.  Not kept.)
     if (!simple && ncomp_host && !io->w) {
         double hdr[4];
         ABC_HIP(ctx, hipMemcpyAsync(hdr, model, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));

@@ -1502,6 +1502,23 @@ int launch_stats_shift(abc_ctx* ctx, const double* X, const double* Y, size_t n,
     return ABC_OK;
 }
 
+// Will launch_stats_accumulate take the byte-limb kernel for this set?  (The same conditions as below, for a caller that arranges its
+// streams around that kernel: one 512-thread work-group per CU with 150-160 KB of LDS -- anything resident beside it costs it CUs.)
+bool abc_gram_takes_i8(const abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy, size_t M, size_t P,
+                       uint64_t n_train_global, size_t n_set) {
+    const size_t C = (M + P + 15) / 16;
+    size_t CY = C - (M + 15) / 16;
+    if (CY > 2) CY = 2;
+    const bool dma_ok = (ldx % 2 == 0) && (ldy % 2 == 0) && (n % 2 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)Y & 15) == 0) && n >= 2;
+    const size_t rows_set = n_set ? n_set : n;
+    const size_t ntr_set = n_train_global < rows_set ? (size_t)n_train_global : rows_set, nte_set = rows_set - ntr_set;
+    const size_t part_min = (ntr_set && nte_set) ? (ntr_set < nte_set ? ntr_set : nte_set) : (ntr_set ? ntr_set : nte_set);
+    const bool i8_rows = ctx->gram_mode == ABC_GRAM_I8 ? rows_set >= 200000 : (ctx->gram_mode == ABC_GRAM_AUTO && part_min >= 400000);
+    if (!i8_rows || !dma_ok || n < 4096) return false;
+    if (C == 6) return rows_set >= 2000000 && CY >= 1 && !abc_diag_env("ABC_GRAM_DMA8_96");
+    return C >= 7 && C <= 10;
+}
+
 int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size_t n, size_t ldx, size_t ldy,
                             size_t M, size_t P, uint64_t row0, uint64_t n_train_global, double* stats, size_t n_set) {
     long long split = 0;
