@@ -581,6 +581,10 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     if (early) ABC_TRY(abc_rng_streams_early(ctx, rng, 0, Nn, seeds_late ? nullptr : io->seeds, Nn, &raw_early, parent_early, K));
     abc_wprev wprev;
     memset(&wprev, 0, sizeof(wprev));
+    // (tried, round 6: the ranking's launches in front of the prologue's in this thread's order -- under rocprofv3 the selection's launches
+    // arrive late behind the prologue's ten, 38 us of idle main stream; unprofiled the host is fast enough and the step is 11 us LONGER
+    // that way, 0.609 against 0.597 ms outside the pair sums at configs[2]: the prologue then runs beside the selection instead of
+    // beside the model fit's empty chip)
     if (weighted)
         ABC_TRY(abc_weights_prev_early(ctx, P, K, io->theta_prev, Kp, io->w_prev, io->dv_prev, &wprev));
     if (seeds_late) ABC_TRY(abc_rng_seeds_early(ctx, rng, 0, Nn, io->seeds, Nn));

@@ -495,11 +495,14 @@ static int sharded_core(abc_ctx* ctx, const abc_sharded_cfg* cfg, const abc_gene
     ctx->side_early_waited = false;
     ctx->side_forked = false;
     *(volatile unsigned*)(ctx->status_pin + 56) = 0u;          // (raised by a proposal kernel that gives up: read at the call's end)
-    ABC_TRY(abc_side_fork(ctx));
+    // (... except beside the byte-limb statistics kernel of wide sets, which wants every CU to itself: forked behind it, api.hip)
+    const bool fork_late = abc_gram_takes_i8(ctx, io->X, io->Y, n, n, n, M, P, ntrain, N);
+    if (!fork_late) ABC_TRY(abc_side_fork(ctx));
     // Every rank takes its statistics about ITS OWN pilot shift (round 4: no broadcast of rank 0's in front of the pass over the
     // rows); the records are all-gathered and every rank re-centres them on rank 0's shift while it adds them up (k_stats_merge).
     ABC_TRY(launch_stats_shift(ctx, io->X, io->Y, n, n, n, M, P, stats));
     ABC_TRY(launch_stats_accumulate(ctx, io->X, io->Y, n, n, n, M, P, row0, ntrain, stats, N));
+    if (fork_late) ABC_TRY(abc_side_fork(ctx));
     // the taus2 streams of this rank's proposals (draws, seeds) need the rng state only: on the side stream
     uint32_t* raw_early = nullptr;
     if (Nn) ABC_TRY(abc_rng_streams_early(ctx, rng, cfg->next0, Nn, io->seeds, cfg->Nnext_total, &raw_early));

@@ -13,7 +13,7 @@ run() { # script, out name, cases, seed, [env]
 if [[ $PART == *a* ]]; then
 run wilcoxon_fuzz.py wilcoxon_fuzz 100 605
 run wide_gram_fuzz.py wide_gram_fuzz 40 606
-run wide_model_fuzz.py wide_model_fuzz 60 607
+FUZZ_BIG=1 run wide_model_fuzz.py wide_model_fuzz_big 40 607      # (the default's own regime: >= 450 000 rows in every partition)
 fi
 if [[ $PART == *b* ]]; then
 run generation_fuzz.py generation_fuzz 200 608
