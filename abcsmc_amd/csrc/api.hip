@@ -746,12 +746,11 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
         ctx->stream = main_stream;
         ABC_TRY(rc0);
     }
-    // Where the cascade's second half goes: BEHIND everything else the generation queues.  The weight stage and the proposals need
-    // the gathered rows, not the component counts, so they are queued first and the host's looks at the cascade's levels -- and
-    // the levels themselves -- happen beside the pair sums (a first set: beside the selection, the gather and the proposals); if the
-    // largest count then turns out to have moved, everything queued on the fit's count is thrown away and the generation runs once
-    // more with the reduction in stream order.  (ABC_WX_FINISH_EARLY: the second half right behind the gather, a moved count
-    // repeats the ranking only -- the round's first form, kept for A/B runs.)
+    // Where the host looks at the cascade: HERE, in front of the weight stage (round 6; round 5's first form).  The verdict of the
+    // cascade's first half -- the tests of a few responses that hold the largest count -- is there by the time the gather ends; a count
+    // that stands costs nothing, a count that moved costs the cascade's second half and the ranking once more (distances from the
+    // kept scores, selection, gather).  ABC_WX_DEFER: round 5's default -- the weight stage and the proposals queued first on the
+    // fit's count, the looks beside the pair sums, a moved count throwing the generation away (kept for A/B runs).
     const bool wx_defer = wx_spec && wx_defer_env;
     bool wx_tail_pending = false;
     if (wx_spec && !wx_defer) {

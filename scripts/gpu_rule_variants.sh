@@ -15,8 +15,8 @@ import json; d=json.loads(open('gpurun_out/variant.json').read()); print('%-34s 
 for r in $(seq 1 $REPS); do
   run "press" press A=1
   run "wilcoxon" wilcoxon A=1
-  run "wilcoxon, finish early" wilcoxon ABC_WX_FINISH_EARLY=1
+  run "wilcoxon, look deferred (round 5)" wilcoxon ABC_WX_DEFER=1
   run "wilcoxon, scores separate" wilcoxon ABC_PROJECT_SEPARATE=1
-  run "wilcoxon, early + separate" wilcoxon ABC_WX_FINISH_EARLY=1 ABC_PROJECT_SEPARATE=1
+  run "wilcoxon, all tests at level 0" wilcoxon ABC_WX_FIRST=0
   run "wilcoxon, in stream order" wilcoxon ABC_WX_INLINE=1
 done
