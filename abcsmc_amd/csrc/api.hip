@@ -592,7 +592,7 @@ static int generation_core(abc_ctx* ctx, const abc_generation_cfg* cfg, const ab
     // The Wilcoxon reduction of the component count goes BEHIND the side stream's launches in host order (round 5): the host looks
     // at the cascade's level counts between its launches, and whatever it has not queued by then waits for those looks -- queued
     // in front (rounds 1-4), the previous set's prologue and the taus2 streams started only after the reduction and the host's
-    // ~90 us of enqueueing them showed as a bubble in front of the projection (rocprofv3 timeline, profiles/r05_timeline_*)
+    // ~90 us of enqueueing them showed as a bubble in front of the projection (rocprofv3 timeline, profiles/history/r05_timeline_*)
     // SPECULATION (round 5, second half): the ranking does not wait for the reduction.  The reduction can only LOWER the component
     // count of a response, and the count the distances use is the largest over the responses -- unchanged unless every response
     // that holds the maximum is reduced.  So projection, selection and gather are queued at once on the counts the fit wrote, the

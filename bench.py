@@ -56,8 +56,8 @@ MFMA_F16_PEAK_TF = 2500.0     # same guide: dense f16 / bf16 MFMA peak (v_mfma_f
 MFMA_SUSTAINED_TF = 1247.0    # same guide, 'DVFS give-back' (1): a bare bf16 MFMA loop on RANDOM operands (the chip holds 1.90-1.95 GHz)
 FP64_VALU_PEAK_TF = 78.6      # same guide: fp64 vector peak
 ASSUMED_XGMI_COLLECTIVE_MS = 0.02   # scaling_model: a small RCCL collective over xGMI, ASSUMED (not measurable on one GPU)
-ASSUMED_EXCHANGE_KERNELS_MS = 0.03  # scaling_model: the kernels around the exchanges that a one-GPU run does not launch, ASSUMED
-ASSUMED_WILCOXON_REPLICATED_MS = 0.04   # scaling_model: per level of the Wilcoxon cascade, what does not shrink with the rows (totals, bounds, host look), from the kernel statistics of profiles/r05_*
+ASSUMED_EXCHANGE_KERNELS_MS = 0.03  # scaling_model: the kernels around the exchanges that a one-GPU run does not launch (list header, unpack, merge, check, placement, slice unpadding: six launches of ~5 us, the floor of a dependent launch in every timeline under profiles/) -- not measurable at world 1
+ASSUMED_WILCOXON_REPLICATED_MS = 0.045  # scaling_model: per level of the Wilcoxon cascade, what does not shrink with the rows: k_wx_totals 7-10 us + k_wx_bounds 17-24 us + the host's look and the next launch 11-13 us (profiles/r06_timeline_config3_weighted.txt, r06_timeline_config5_weighted.txt)
 
 
 def pmc_traffic(kernel_prefix, config, world):
@@ -65,7 +65,7 @@ def pmc_traffic(kernel_prefix, config, world):
     written by scripts/summarize_profiles.py); only for the exact single-GPU configuration profiled, else None"""
     if world != 1:
         return None
-    for name in ("r05_pmc_hbm_traffic.json", "history/r04_pmc_hbm_traffic.json", "history/r03_pmc_hbm_traffic.json"):
+    for name in ("r06_pmc_hbm_traffic.json", "history/r05_pmc_hbm_traffic.json", "history/r04_pmc_hbm_traffic.json", "history/r03_pmc_hbm_traffic.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(prof):
             continue
