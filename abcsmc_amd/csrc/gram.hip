@@ -1544,7 +1544,7 @@ int launch_stats_accumulate(abc_ctx* ctx, const double* X, const double* Y, size
     // Gram's own scale (4e-11 of sqrt(G_aa G_bb)) but not always at the LOADINGS: a component that fits noise works on cross
     // products sqrt(rows) below that scale, with close eigenvalues, and tests/fuzz/wide_model_fuzz.py found a used loading column
     // 4.3e-6 off the oracle's (fp64 kernels: 4e-10) at 66 000 training rows x 29 responses x 30 components -- BASELINE.json allows
-    // 1e-6.  The error falls faster than 1 / rows: 60 fuzzed sets whose partitions hold 450 000 rows and more stay within 7.7e-8
+    // 1e-6.  The error falls faster than 1 / rows: 64 fuzzed sets whose partitions hold 450 000 rows and more stay within 2.6e-7
     // (profiles/r06_wide_model_fuzz_big.json).  So ABC_GRAM_AUTO takes the kernel only where EVERY non-empty partition of the
     // WHOLE set (training / validation rows: n_train_global, n_set) has at least 400 000 rows -- configs[4] (5e5 + 5e5), configs[3]
     // (5e6 + 5e6) -- and the fp64 kernels below that; ABC_GRAM_I8 is round 5's rule (200 000 rows in the whole set) for A/B runs and tests.

@@ -98,7 +98,7 @@ int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
  * Gram's scale but is AMPLIFIED in the loadings of components that fit noise (cross products sqrt(rows) below that scale, close
  * eigenvalues): tests/fuzz/wide_model_fuzz.py holds every USED loading column against the oracle's fit and found 4.3e-6 (fp64
  * kernels: 4e-10) at 66 000 training rows x 29 responses x 30 components, against the 1e-6 of BASELINE.json; with 450 000 rows and
- * more in each partition the worst of 60 fuzzed sets is 7.7e-8 (profiles/r06_wide_model_fuzz*.json).  Hence:
+ * more in each partition the worst of 64 fuzzed sets is 2.6e-7 (profiles/r06_wide_model_fuzz*.json).  Hence:
  * ABC_GRAM_AUTO (default): the byte-limb kernel only where EVERY non-empty partition (training rows, validation rows) OF THE WHOLE
  *   SET has at least 400 000 rows -- the sharded generation decides from N_total and the training fraction, so every rank and the
  *   unsharded run of the same set take the same kernel; a rank whose own shard the kernel cannot take (odd row count, columns not

@@ -23,6 +23,7 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 2026
 dev = "cuda:0"
 g = np.random.default_rng(seed0)
+LARGE = bool(os.environ.get("FUZZ_LARGE"))
 rows, fails = [], []
 for case in range(cases):
     P = int(g.integers(1, 41)) if case % 4 else int(g.choice([1, 2, 4, 5, 8, 13, 14, 16, 17, 29, 30, 32, 33, 48, 61, 62, 64]))
@@ -34,7 +35,7 @@ for case in range(cases):
     A = int(g.integers(1, min(M, 12) + 1))
     mv = bool(g.integers(0, 2))
     tf = float(g.choice([0.5, 0.5, 0.3, 0.8]))
-    if os.environ.get("FUZZ_LARGE"):        # sizes at which the other code paths run: sorts beyond 2^18 keys, the radix select (2 K > N), the device alias build
+    if LARGE:        # sizes at which the other code paths run: sorts beyond 2^18 keys, the radix select (2 K > N), the device alias build
         P = int(g.choice([3, 8, 12, 16, 20, 32, 40]))
         M = int(g.integers(max(4, P // 2), 40))
         N = int(g.choice([70000, 150000, 270000, 400000]))
@@ -46,8 +47,9 @@ for case in range(cases):
     wilcoxon = bool(g.integers(0, 2) == 0) and P <= 40      # (round 5: half the cases -- the rule is the drop-in's default)
     ynoise = float(g.choice([0.0, 0.0, 1.0, 2.5])) if wilcoxon else 0.0      # noisy responses: the reduction lowers the largest count and the
     #                                                                          fused generation's speculation on the fit's count has to be repaired
+    lowrank = wilcoxon and LARGE and bool(g.integers(0, 2) == 0)        # (large runs: half of the rule's cases get a count that moves)
     dups = bool(g.integers(0, 5) == 0)                    # duplicated rows: exact distance ties, broken by the row index
-    tag = dict(case=case, N=N, M=M, P=P, K=K, Kp=Kp, Nn=Nn, A=A, multivariate=mv, train_frac=tf, seed=sd, wilcoxon=wilcoxon, dups=dups, ynoise=ynoise)
+    tag = dict(case=case, N=N, M=M, P=P, K=K, Kp=Kp, Nn=Nn, A=A, multivariate=mv, train_frac=tf, seed=sd, wilcoxon=wilcoxon, dups=dups, ynoise=ynoise, lowrank=lowrank)
     try:
         wl = synthetic.Workload(M, P, sd)
         dX, dY = wl.rows_device(0, N, dev)
@@ -60,6 +62,22 @@ for case in range(cases):
         if ynoise:
             gn = torch.Generator(device=dev).manual_seed(sd)
             dY += torch.randn(dY.shape, generator=gn, device=dev, dtype=torch.float64) * dY.std(dim=1, keepdim=True) * ynoise
+        if lowrank:
+            # (round 6) metrics rebuilt from r factors + noise, responses = combinations of those factors + noise (bench.moved_count_data):
+            # the components beyond r fit noise, argmin PRESS lands on the plateau and the rule takes the surplus back -- at the sizes
+            # where the cascade runs BESIDE the ranking, i.e. the speculation on the fit's count has to be repaired
+            gn = torch.Generator(device=dev).manual_seed(sd + 1)
+            rr = int(g.integers(1, 4))
+            mux, sdx = dX.mean(dim=1, keepdim=True), dX.std(dim=1, keepdim=True)
+            muy, sdy = dY.mean(dim=1, keepdim=True), dY.std(dim=1, keepdim=True)
+            Bx = torch.linalg.qr(torch.randn((M, rr), generator=gn, device=dev, dtype=torch.float64))[0]
+            Z = Bx.T @ ((dX - mux) / sdx)
+            Z = Z / Z.std(dim=1, keepdim=True)
+            rown = Bx.norm(dim=1, keepdim=True)
+            dX = (mux + sdx / (rown * 1.25 ** 0.5) * (Bx @ Z + 0.5 * rown * torch.randn(dX.shape, generator=gn, device=dev, dtype=torch.float64))).contiguous()
+            Wy = torch.randn((P, rr), generator=gn, device=dev, dtype=torch.float64) / rr ** 0.5
+            dY = (muy + sdy * (Wy @ Z + torch.randn(dY.shape, generator=gn, device=dev, dtype=torch.float64))).contiguous()
+            del Z
         obs, spec = wl.observed(), wl.prior_spec()
         rule = _lib.RULE_WILCOXON if wilcoxon else _lib.RULE_MIN_PRESS
         dprev = wl.previous_set_device(Kp, dev) if Kp else ()
@@ -68,7 +86,9 @@ for case in range(cases):
         gen = device.Generation(N, M, P, K, Kp, Nn, tf, A, rule=rule, multivariate=mv, device=dev)
         r = abcutil.rng(sd)
         gen.ctx.perturb_giveups(reset=True)
+        gen.ctx.generation_repeats(reset=True)
         gen.run(dX, dY, device.colmajor(obs, dev), device.priors_to_device(_lib.make_priors(spec), dev), r, *dprev)
+        tag["ranking_repeats"], tag["generation_repeats"] = gen.ctx.generation_repeats(reset=True)
         torch.cuda.synchronize()
         o = oracle.rng(sd)
         ref = oracle.generation(X, Y, obs, oracle.make_priors(spec), K, Nn, o, *prev, train_frac=tf, max_comp=A, rule=(oracle.RULE_WILCOXON if wilcoxon else oracle.RULE_MIN_PRESS), multivariate=mv)
@@ -139,5 +159,9 @@ for case in range(cases):
     if tag["problems"]:
         fails.append(tag)
     print(("FAIL " if tag["problems"] else "ok   ") + json.dumps(tag), flush=True)
-json.dump({"cases": len(rows), "failed": len(fails), "failures": fails, "rows": rows}, open(out, "w"), indent=1)
+json.dump({"cases": len(rows), "failed": len(fails),
+           "cases_whose_count_the_rule_lowered": len([r for r in rows if r.get("ncomp_press", 0) > r.get("ncomp", 0)]),
+           "cases_that_repeated_their_ranking": len([r for r in rows if r.get("ranking_repeats")]),
+           "cases_that_repeated_themselves": len([r for r in rows if r.get("generation_repeats")]),
+           "failures": fails, "rows": rows}, open(out, "w"), indent=1)
 print("%d cases, %d with problems" % (len(rows), len(fails)))

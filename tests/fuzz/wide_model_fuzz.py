@@ -18,7 +18,7 @@ FUZZ_BIG=1 draws sets of 0.9 .. 1.2e6 rows (450 000 and more in each partition: 
 WHAT THE RUNS SAID (round 6): at 2e5 .. 5e5 rows (60 000 .. 350 000 a partition) the byte-limb kernel put loading columns 19 and 20 of a
 30-component model 4.3e-6 off the oracle's (fp64 kernels: 4e-10) in one of 60 sets (profiles/r06_wide_model_fuzz_i8_small_sets.json:
 round 5's default, FUZZ_I8=1 today) -- ABC_GRAM_AUTO therefore takes the kernel only from 400 000 rows in every partition, where
-the worst of the fuzzed sets is 7.7e-8 (profiles/r06_wide_model_fuzz_big.json).
+the worst of 64 fuzzed sets is 2.6e-7 (profiles/r06_wide_model_fuzz_big.json: 40 of them; a point-mass column beside 28 responses).
     python tests/fuzz/wide_model_fuzz.py [out.json] [cases] [seed]"""
 import json
 import os
