@@ -24,6 +24,7 @@ seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 2026
 dev = "cuda:0"
 g = np.random.default_rng(seed0)
 LARGE = bool(os.environ.get("FUZZ_LARGE"))
+ONLY = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None
 rows, fails = [], []
 for case in range(cases):
     P = int(g.integers(1, 41)) if case % 4 else int(g.choice([1, 2, 4, 5, 8, 13, 14, 16, 17, 29, 30, 32, 33, 48, 61, 62, 64]))
@@ -50,6 +51,10 @@ for case in range(cases):
     lowrank = wilcoxon and LARGE and bool(g.integers(0, 2) == 0)        # (large runs: half of the rule's cases get a count that moves)
     dups = bool(g.integers(0, 5) == 0)                    # duplicated rows: exact distance ties, broken by the row index
     tag = dict(case=case, N=N, M=M, P=P, K=K, Kp=Kp, Nn=Nn, A=A, multivariate=mv, train_frac=tf, seed=sd, wilcoxon=wilcoxon, dups=dups, ynoise=ynoise, lowrank=lowrank)
+    if ONLY is not None and case != ONLY:      # (FUZZ_ONLY=<case>: replay one case; the others only advance the generator)
+        if lowrank:
+            g.integers(1, 4)
+        continue
     try:
         wl = synthetic.Workload(M, P, sd)
         dX, dY = wl.rows_device(0, N, dev)
@@ -110,12 +115,24 @@ for case in range(cases):
                 if worst > 1e-10:
                     problems.append("selection order differs beyond near-ties (%.2e)" % worst)
         w = gen.w.cpu().numpy()
+        if np.isnan(ref["w"]).any():
+            # The REFERENCE's own pathology, not a difference: a selected particle outside a prior's support (numerator 0) whose kernel
+            # sum underflows to exactly 0 in the product of P pdf factors (AbcUtil.cpp:572-580) is 0 / 0 = NaN there, and Eigen's
+            # normalize() then leaves the whole vector unnormalised (squaredNorm > 0 is false for NaN: the oracle does the same).  Here the
+            # sum of one exponential per pair is tiny but not 0, the weight is 0 and the rest is normalised.  Compared: the oracle's raw
+            # weights with those rows at 0, normalised the same way.  (Seen with 40 parameters and responses 2.5 sd noisier than the priors
+            # were made for: 29 of 162 000 rows.)
+            tag["reference_nan_weights"] = int(np.isnan(ref["w"]).sum())
+            rw = np.where(np.isnan(ref["w"]), 0.0, ref["w"])
+            ref["w"] = rw / np.linalg.norm(rw)
         tol = 1e-12 if not Kp else (1e-9 if (P < 5 or P > 64) else 8e-7 if P > 32 else 5.5e-7 if P > 16 else 5e-7)
         werr = None
         if same_sel:
             ok = ref["w"] > 0
             if not np.array_equal(w == 0, ref["w"] == 0):
-                problems.append("zero pattern of the weights differs")
+                dz = np.nonzero((w == 0) != (ref["w"] == 0))[0]
+                problems.append("zero pattern of the weights differs at %d of %d rows (first %s: device %s, oracle %s)"
+                                % (dz.size, w.size, dz[:4].tolist(), w[dz[:4]].tolist(), ref["w"][dz[:4]].tolist()))
             elif ok.any():
                 werr = float(np.max(np.abs(w - ref["w"])[ok] / ref["w"][ok]))
                 if werr > tol:
