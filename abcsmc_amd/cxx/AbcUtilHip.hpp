@@ -238,6 +238,14 @@ inline uint64_t perturb_giveups(bool reset = false) {
     check(abc_perturb_giveups(context(), &n, reset ? 1 : 0));
     return n;
 }
+// What the speculation on the component count has cost this context (abc_generation_repeats): whole generations under the Wilcoxon
+// rule rank on the count the fit wrote while the reduction runs beside them; .first = how often the reduction lowered the largest
+// count and the ranking was repeated, .second = how often a generation started over (degenerate selection, a cascade that gave up)
+inline std::pair<uint64_t, uint64_t> generation_repeats(bool reset = false) {
+    uint64_t r = 0, g = 0;
+    check(abc_generation_repeats(context(), &r, &g, reset ? 1 : 0));
+    return {r, g};
+}
 // How many PLS components particle_ranking_PLS keeps (AbcUtil.cpp:447-449: `PLS::optimal_num_components(em).maxCoeff()`; the PLS
 // library is not in the reference tree).  SURVEY A.2, the only specification of it at hand, describes upstream as: per response
 // the component count of least PRESS, REDUCED to the smallest count whose validation errors a two-sided Wilcoxon signed-rank
