@@ -875,7 +875,8 @@ def rccl_world1_latency(dev, messages, reps=20):
     os.unlink(store.name)
     try:
         torch.cuda.set_device(torch.device(dev))
-        dist.init_process_group("nccl", init_method="file://" + store.name, world_size=1, rank=0)
+        import datetime
+        dist.init_process_group("nccl", init_method="file://" + store.name, world_size=1, rank=0, timeout=datetime.timedelta(seconds=60))
         for name, nbytes in messages.items():
             n = max(int(nbytes) // 8, 1)
             a = torch.zeros(n, dtype=torch.float64, device=dev)
