@@ -198,11 +198,11 @@ extern "C" int abc_generation_giveups(const abc_ctx* ctx, uint64_t* count) {
     return ABC_OK;
 }
 
-extern "C" int abc_generation_repeats(const abc_ctx* ctx, uint64_t* ranking_repeats, uint64_t* generation_repeats, int reset) {
+extern "C" int abc_generation_repeats(abc_ctx* ctx, uint64_t* ranking_repeats, uint64_t* generation_repeats, int reset) {
     if (!ctx) return ABC_ERR_INVALID;
     if (ranking_repeats) *ranking_repeats = (uint64_t)ctx->wx_moved_counts;
     if (generation_repeats) *generation_repeats = (uint64_t)ctx->generation_repeats;
-    if (reset) { abc_ctx* c = const_cast<abc_ctx*>(ctx); c->wx_moved_counts = 0; c->generation_repeats = 0; }
+    if (reset) { ctx->wx_moved_counts = 0; ctx->generation_repeats = 0; }
     return ABC_OK;
 }
 

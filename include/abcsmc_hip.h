@@ -159,7 +159,7 @@ int  abc_generation_giveups(const abc_ctx* ctx, uint64_t* count);
  * selection and the gather run once more with it (*ranking_repeats), and when the reduction itself gives up on its fast path, or a
  * degenerate selection has to be redone by radix select, the generation starts over (*generation_repeats).  Both 0 on clean
  * responses; neither changes a result.  No synchronisation. */
-int  abc_generation_repeats(const abc_ctx* ctx, uint64_t* ranking_repeats, uint64_t* generation_repeats, int reset);
+int  abc_generation_repeats(abc_ctx* ctx, uint64_t* ranking_repeats, uint64_t* generation_repeats, int reset);
 /* Optional per-stage timing: HIP events recorded on the context's stream around each stage
  * (and around the k_gram / k_kde kernels alone).  abc_timing_read synchronises, then returns the
  * number of stages; names[i] is a static string, ms[i] the accumulated device time, host_ms[i]

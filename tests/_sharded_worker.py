@@ -20,20 +20,36 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    """argv as in the module's docstring; an optional 7th argument holds FURTHER cases for the same ranks, a JSON list of
+    [shape, rule, data, split] (round 6: one launch of the ranks for several cases -- starting them is 3-4 s of every test): the
+    output file then holds {"cases": [result, ...]} in the order given, else the one result"""
     backend, out_path = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
+    first = [sys.argv[3] if len(sys.argv) > 3 else "1500,12,5,4,500,300,1000", sys.argv[4] if len(sys.argv) > 4 else "press",
+             sys.argv[5] if len(sys.argv) > 5 else "plain", sys.argv[6] if len(sys.argv) > 6 else "even"]
+    more = json.loads(sys.argv[7]) if len(sys.argv) > 7 else []
+    results = [run_case(backend, *c) for c in [first] + more]
+    if dist.get_rank() == 0:
+        with open(out_path, "w") as f:
+            json.dump(results[0] if not more else {"cases": results}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_case(backend, shape_s, rule_s, data_s, split_s):
     rank, world = dist.get_rank(), dist.get_world_size()
     from abcsmc_amd import _lib, sharded, synthetic
     from oracle import pyoracle as O
-    n_loc, M, P, A, K, Kp, nn_loc = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1500,12,5,4,500,300,1000").split(","))
+    n_loc, M, P, A, K, Kp, nn_loc = (int(v) for v in shape_s.split(","))
     N = n_loc * world
-    rule = _lib.RULE_WILCOXON if (len(sys.argv) > 4 and sys.argv[4] == "wilcoxon") else _lib.RULE_MIN_PRESS
+    rule = _lib.RULE_WILCOXON if rule_s == "wilcoxon" else _lib.RULE_MIN_PRESS
     wl = synthetic.Workload(M, P, 777)
-    ties = len(sys.argv) > 5 and sys.argv[5] == "ties"
+    ties = data_s == "ties"
 
-    blocked = len(sys.argv) > 5 and sys.argv[5] == "blocked"
-    noisy = len(sys.argv) > 5 and sys.argv[5] == "noisy"
+    blocked = data_s == "blocked"
+    noisy = data_s == "noisy"
     noise_all = np.random.default_rng(7).normal(size=(N, P)) if noisy else None
+    ctx = None
 
     def rows(lo, hi):
         X, Y = wl.rows(lo, hi)
@@ -46,7 +62,7 @@ def main():
             Y = np.asfortranarray(Y + 1.5 * wl.sd_y * noise_all[lo:hi])
         return X, Y
 
-    uneven = len(sys.argv) > 6 and sys.argv[6] == "uneven"
+    uneven = split_s == "uneven"
     if uneven:
         assert backend in ("cabi", "rccl")
         shares = np.array([2.0 ** (world - 1 - r) for r in range(world)])
@@ -127,10 +143,16 @@ def main():
             "next_finite": bool(torch.isfinite(gen.next).all().item()),
             "comm_calls": getattr(ctx, "comm_calls", None) if backend == "cabi" else None,
         }
-        with open(out_path, "w") as f:
-            json.dump(res, f)
     dist.barrier()
-    dist.destroy_process_group()
+    del gen
+    if ctx is not None:          # (this case's context: its arena and communicator go before the next case starts)
+        try:
+            ctx.close()
+        except Exception:        # noqa: BLE001
+            pass
+    if dev != "cpu":
+        torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

@@ -39,6 +39,24 @@ def _launch(backend, tmp_path, port, shape="small", rule="press", data="plain", 
     return json.load(open(out))
 
 
+def _launch_many(backend, tmp_path, port, cases, world=2, env_extra=None):
+    """several cases -- (shape, rule, data, split) -- on ONE launch of the ranks (round 6: starting them is 3-4 s of every test);
+    returns their results in order"""
+    import json as _json
+    out = str(tmp_path / ("sharded_many_%s_%d_%d.json" % (backend, world, port)))
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(env_extra or {})
+    first, more = cases[0], [[SHAPES[c[0]], c[1], c[2], c[3]] for c in cases[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), backend, out, SHAPES[first[0]], first[1], first[2], first[3]] + ([_json.dumps(more)] if more else [])
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.load(open(out))
+    return res["cases"] if more else [res]
+
+
 def _check(res):
     assert res["ncomp"][0] == res["ncomp"][1]
     assert res["idx_equal"] and res["theta_equal"]
@@ -52,38 +70,51 @@ def test_sharded_world2_gloo_cpu(tmp_path, shape, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,port", [("small", 29612), ("config4", 29614), ("config5", 29615)])
-def test_sharded_world2_gloo_hip(tmp_path, shape, port):
-    _check(_launch("hip", tmp_path, port, shape))
+def test_sharded_world2_gloo_hip(tmp_path):
+    """(the three shapes small / config4 / config5 on one launch of the two ranks)"""
+    shapes = ("small", "config4", "config5")
+    for shape, res in zip(shapes, _launch_many("hip", tmp_path, 29612, [(sh, "press", "plain", "even") for sh in shapes])):
+        try:
+            _check(res)
+        except AssertionError as e:
+            raise AssertionError("shape %s: %s" % (shape, res)) from e
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,port", [("small", 29616), ("config4", 29617), ("config5", 29618), ("p40", 29619)])
-def test_sharded_world2_cabi_driver(tmp_path, shape, port):
+def test_sharded_world2_cabi_driver(tmp_path):
     """abc_generation_sharded_dev (the C++ driver behind the C ABI) on two ranks sharing cuda:0, its collectives forwarded to
-    gloo through abc_comm_init_callbacks: the same checks against the single-process oracle as the Python driver"""
-    _check(_launch("cabi", tmp_path, port, shape))
+    gloo through abc_comm_init_callbacks: the same checks against the single-process oracle as the Python driver -- the shapes
+    small / config4 / config5 / p40 on one launch of the two ranks"""
+    shapes = ("small", "config4", "config5", "p40")
+    for shape, res in zip(shapes, _launch_many("cabi", tmp_path, 29616, [(sh, "press", "plain", "even") for sh in shapes])):
+        try:
+            _check(res)
+        except AssertionError as e:
+            raise AssertionError("shape %s: %s" % (shape, res)) from e
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,data,port", [("big", "plain", 29631), ("big0", "plain", 29632), ("big", "ties", 29633), ("big0", "ties", 29634),
-                                             ("huge", "plain", 29635), ("huge", "ties", 29636)])
-def test_sharded_world2_cabi_driver_local_top_selection(tmp_path, shape, data, port):
+@pytest.mark.parametrize("data,port", [("plain", 29631), ("ties", 29633)])
+def test_sharded_world2_cabi_driver_local_top_selection(tmp_path, data, port):
     """sets large enough for the C++ driver's local-top selection (every rank's K / W + 8 sigma smallest distances, sorted, with
     their rows in ONE all-gather; the merge of the W runs on every rank; the rule that no rank may hold an unlisted key at or below
     the K-th): weighted and first-set generations against the single-process oracle; with massively tied distances the rule
     fails, every rank takes the same decision and the generation repeats itself with the radix protocol (weighted: at the host's
     wait for the weights; set 0: at its end) -- same results"""
-    res = _launch("cabi", tmp_path, port, shape, "press", data)
-    _check(res)
-    calls = res["comm_calls"]
-    total = sum(calls.values())
-    if data == "plain":
-        # the all-gather of the ranks' statistics records (each about its own pilot shift), the all-gather of the ranks' sorted lists
-        # with their rows, and (weighted generations) the all-gather of the raw weight slices: 3 collectives, 2 in the first set
-        assert {k: v for k, v in calls.items() if v} == {"all_gather": 2 if shape == "big0" else 3}, calls
-    else:
-        assert total > 10 and calls["all_reduce"] >= 6, calls           # ... + the whole radix protocol of the repeat
+    shapes = ("big", "big0", "huge")                      # (one launch of the two ranks for the three shapes: round 6)
+    for shape, res in zip(shapes, _launch_many("cabi", tmp_path, port, [(sh, "press", data, "even") for sh in shapes])):
+        try:
+            _check(res)
+        except AssertionError as e:
+            raise AssertionError("shape %s: %s" % (shape, res)) from e
+        calls = res["comm_calls"]
+        total = sum(calls.values())
+        if data == "plain":
+            # the all-gather of the ranks' statistics records (each about its own pilot shift), the all-gather of the ranks' sorted
+            # lists with their rows, and (weighted generations) the all-gather of the raw weight slices: 3 collectives, 2 in the first set
+            assert {k: v for k, v in calls.items() if v} == {"all_gather": 2 if shape == "big0" else 3}, (shape, calls)
+        else:
+            assert total > 10 and calls["all_reduce"] >= 6, (shape, calls)           # ... + the whole radix protocol of the repeat
 
 
 @pytest.mark.gpu
@@ -100,33 +131,41 @@ def test_sharded_world2_rccl_two_gpus(tmp_path, shape, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,port", [("small", 29621), ("wx", 29622)])
-def test_sharded_world2_cabi_driver_wilcoxon_rule(tmp_path, shape, port):
+def test_sharded_world2_cabi_driver_wilcoxon_rule(tmp_path):
     """the Wilcoxon component rule (AbcUtil.cpp:447-449) on two ranks: the validation rows of both shards are gathered and
-    ranked together on every rank; component count, selection and everything downstream equal the single-process oracle's"""
-    _check(_launch("cabi", tmp_path, port, shape, "wilcoxon"))
+    ranked together on every rank; component count, selection and everything downstream equal the single-process oracle's
+    (shapes small / wx on one launch of the ranks)"""
+    for shape, res in zip(("small", "wx"), _launch_many("cabi", tmp_path, 29621, [("small", "wilcoxon", "plain", "even"), ("wx", "wilcoxon", "plain", "even")])):
+        try:
+            _check(res)
+        except AssertionError as e:
+            raise AssertionError("shape %s: %s" % (shape, res)) from e
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,world,split,port", [("wxbig", 2, "even", 29651), ("wxc4", 2, "even", 29652), ("wxc5", 2, "even", 29653),
-                                                    ("wxbig", 2, "uneven", 29654), ("w3wx", 3, "uneven", 29655)])
-def test_sharded_cabi_driver_wilcoxon_cascade_over_the_shards(tmp_path, shape, world, split, port):
+@pytest.mark.parametrize("world,cases,port", [(2, (("wxbig", "even"), ("wxc4", "even"), ("wxc5", "even"), ("wxbig", "uneven")), 29651),
+                                              (3, (("w3wx", "uneven"),), 29655)])
+def test_sharded_cabi_driver_wilcoxon_cascade_over_the_shards(tmp_path, world, cases, port):
     """the Wilcoxon rule on sets large enough for its bounds cascade (wilcoxon.hip, round 5): every rank sweeps ITS validation rows,
     the counts of a level are all-reduced, verdicts are replicated, only the keys of the tests the bounds leave undecided are
     all-gathered -- component count, selection and everything downstream equal the single-process oracle's; no rank gathers rows
     (the exchange: the statistics records, the cascade's all-reduces and at most one key gather per batch of undecided tests, the
     sorted lists, the weight slices); even and uneven shards, two and three ranks"""
-    res = _launch("cabi", tmp_path, port, shape, "wilcoxon", "plain", world, split)
-    _check(res)
-    calls = res["comm_calls"]
-    # all-reduces: the cascade's levels only (1..3); all-gathers: statistics, lists + rows, weight slices (+ the undecided tests' keys,
-    # in batches of eight) -- the row gather of rounds 1-4 took two more all-gathers and a count exchange
-    if split == "even":       # (shares of 2 : 1 and beyond: the largest shard holds more winners than its local-top list is long, the
-        #                       generation repeats with the radix protocol and its six all-reduces -- same results, checked above)
-        # (round 6: the largest count first -- one all-reduce when a picked response keeps its optimum at level 0; at most two fine
-        # levels for them, level 0 of the others, two fine levels)
-        assert 1 <= calls["all_reduce"] <= 6, calls
-        assert 3 <= calls["all_gather"] <= 3 + 4, calls
+    results = _launch_many("cabi", tmp_path, port, [(sh, "wilcoxon", "plain", sp) for sh, sp in cases], world)     # (one launch of the ranks)
+    for (shape, split), res in zip(cases, results):
+        try:
+            _check(res)
+        except AssertionError as e:
+            raise AssertionError("shape %s, %s shards: %s" % (shape, split, res)) from e
+        calls = res["comm_calls"]
+        # all-reduces: the cascade's levels only; all-gathers: statistics, lists + rows, weight slices (+ the undecided tests' keys,
+        # in batches of eight) -- the row gather of rounds 1-4 took two more all-gathers and a count exchange
+        if split == "even":   # (shares of 2 : 1 and beyond: the largest shard holds more winners than its local-top list is long, the
+            #                   generation repeats with the radix protocol and its six all-reduces -- same results, checked above)
+            # (round 6: the largest count first -- one all-reduce when a picked response keeps its optimum at level 0; at most two
+            # fine levels for them, level 0 of the others, two fine levels)
+            assert 1 <= calls["all_reduce"] <= 6, (shape, calls)
+            assert 3 <= calls["all_gather"] <= 3 + 4, (shape, calls)
 
 
 @pytest.mark.gpu
