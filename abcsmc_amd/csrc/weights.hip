@@ -444,7 +444,9 @@ __device__ __forceinline__ unsigned f16_of_int(int n, int s) {
 // also the tile layout: the lane's four 16-byte limb operands go straight to [half][row][8 x 16 bit].  Row quantities (norm,
 // far flags) are combined across the row's lanes in fixed order.  Same outputs as the two kernels: the scaled fp64 row-major
 // copy (+ hb for the previous set), the limb tiles, far flags / list, ha_int / ha_frac.
-template <int NCH>
+// (NST < NCH -- 33..48 parameters, round 6: the lanes are dealt out as for four chunks, three are stored; the fourth chunk's
+// parameters do not exist, its limbs would be zeros that the pair sums' matrix steps multiply for nothing)
+template <int NCH, int NST = NCH>
 __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, size_t rows, size_t ld, int P, int PP, size_t rows_pad,
                                                WConst* __restrict__ wc, const double* __restrict__ w, int is_prev,
                                                double* __restrict__ out, double* __restrict__ hb,
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
     const int c = g >> 1, h = g & 1;
     unsigned pk[KS_NL][4];
     unsigned top_pc[3] = {0u, 0u, 0u}, low_pc[3] = {0u, 0u, 0u};
-    const bool fold_lane = fold && g == G - 1;                        // the lane that holds K-slots 8..15 of its row's LAST chunk
+    const bool fold_lane = fold && g == 2 * NST - 1;                  // the lane that holds K-slots 8..15 of its row's LAST (stored) chunk
     if (fold_lane && is_prev) ks_pieces_f16(valid ? 0.5 * nrow + lw : KS_HB_ZERO, KS_XUNIT_INV, top_pc, low_pc);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -545,11 +547,12 @@ __global__ __launch_bounds__(256) void k_wrows(const double* __restrict__ in, si
     }
 #pragma unroll
     for (int k = 0; k < KS_NL; k++)
-        *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + r32) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+        if (NST == NCH || c < NST)
+            *(uint4*)(tb + (size_t)(c * KS_NL + k) * 512 + (h * 32 + r32) * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
     if (g == 0) {
         if (is_prev && !fold) {
             unsigned pc[6];
-            unsigned short* ob = tb + (size_t)(NCH * KS_NL) * 512;
+            unsigned short* ob = tb + (size_t)(NST * KS_NL) * 512;
             const double hbv = valid ? 0.5 * nrow + lw : KS_HB_ZERO;
             ks_pieces(hbv, KS_XUNIT_INV, pc);
             if (topf) topf[spos] = (float)(rint(hbv * KS_XUNIT_INV) / KS_XUNIT_INV);     // (the top ks_pieces splits off)
@@ -702,8 +705,9 @@ __host__ __device__ constexpr int kz_nsteps() { return kz_fold<NCH>() ? 1 + 6 * 
 // step S of a batch: 0 norm top; 1..NCH h0.h0'; [vector: n]; NCH+1: -n; NCH+2: norm low; then 5 products per chunk
 // (folded: 0..NCH-1 h0.h0', the last chunk's with the norm top; [vector: n]; NCH: -n; then 5 products per chunk, the last chunk's
 // (h0 2^-11).(r2' 2^11) with the norm low)
-template <int NCH, int S>
-__device__ __forceinline__ void kz_mfma(const uint4* A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
+// (AT: the previous tile's operands -- a register array (uint4*) or, in k_kde_split_lds, KsLdsOps: the same indices into a tile staged in LDS)
+template <int NCH, int S, typename AT>
+__device__ __forceinline__ void kz_mfma(const AT A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
     const f32x16 Z0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (kz_fold<NCH>()) {
         constexpr int C = kz_nch<NCH>();
@@ -756,16 +760,16 @@ __device__ __forceinline__ void kz_mfma(const uint4* A, const uint4* B, const ui
                                                    __builtin_bit_cast(f16x8, B[c * KS_NL + KS_LB[l]]), Z, 0, 0, 0);
     }
 }
-template <int NCH, int S0, int S1>
-__device__ __forceinline__ void kz_mfma_range(const uint4* A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
+template <int NCH, int S0, int S1, typename AT>
+__device__ __forceinline__ void kz_mfma_range(const AT A, const uint4* B, const uint4 (&NB)[2], const uint4& BN, f32x16& Z) {
     if constexpr (S0 < S1) {
         kz_mfma<NCH, S0>(A, B, NB, BN, Z);
         kz_mfma_range<NCH, S0 + 1, S1>(A, B, NB, BN, Z);
     }
 }
 // n = floor(max of the lane's 16 values) and the B operand that subtracts it (see above); |n| < 2048: two bf16 pieces
-template <int V>
-__device__ __forceinline__ void kz_reference(const f32x16& Z, const uint4* A, const uint4& NB0, unsigned lane, int& n, uint4& BN) {
+template <int V, typename AT>
+__device__ __forceinline__ void kz_reference(const f32x16& Z, const AT A, const uint4& NB0, unsigned lane, int& n, uint4& BN) {
     // The first read of the freshly written accumulator is an instruction the compiler knows (it places the wait states a VALU
     // read of an MFMA result needs; it does not look inside inline assembly): ONE v_max_f32 of Z[0] with itself (fmaxf of two
     // accumulator values is three instructions: each input is quieted first); the v_max3_f32 tree follows.
@@ -798,8 +802,8 @@ __device__ __forceinline__ void kz_reference(const f32x16& Z, const uint4* A, co
 // One step of a wave: the vector work of the finished batch (Zc, reference nc) interleaved with the whole chain of the next one
 // (An x Bn -> Zn, reference nn).  Eight slots of two exponentials; the next batch's exact part goes first, its reference is taken
 // in slot 3 (its two MFMAs have ~100 cycles behind them by then), the rest of the chain follows.
-template <int NCH, int R>
-__device__ __forceinline__ void kz_slots(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
+template <int NCH, int R, typename AT>
+__device__ __forceinline__ void kz_slots(const AT An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
                                          const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
     if constexpr (R < 8) {
         constexpr int NS = kz_nsteps<NCH>(), NA = kz_nexact<NCH>();   // NA exact steps, then the reference, then NS - NA more
@@ -838,8 +842,8 @@ __device__ __forceinline__ void kz_slots(const uint4* An, const uint4* Bn, const
 // instruction stream of a wave is what fills the matrix pipe -- a wave issues in order, so vector work placed behind a run of
 // dependent MFMAs does not overlap with them; here at most ceil(steps / slots) MFMAs stand between two exponentials.  The exact
 // steps go first (one per slot), the reference one slot behind them, the remaining steps evenly over the slots that are left.
-template <int NCH, int RO, int R>
-__device__ __forceinline__ void kz_fine(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
+template <int NCH, int RO, int R, typename AT>
+__device__ __forceinline__ void kz_fine(const AT An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
                                         const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
     if constexpr (R < 16) {
         constexpr int NS = kz_nsteps<NCH>(), NA = kz_nexact<NCH>(), R0 = NA + RO, M = NS - NA, L = 16 - R0;
@@ -869,8 +873,8 @@ __device__ __forceinline__ void kz_fine(const uint4* An, const uint4* Bn, const 
         kz_fine<NCH, RO, R + 1>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
     }
 }
-template <int NCH, int FINE>
-__device__ __forceinline__ void kz_step(const uint4* An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
+template <int NCH, int FINE, typename AT>
+__device__ __forceinline__ void kz_step(const AT An, const uint4* Bn, const uint4 (&NB)[2], f32x16& Zn, int& nn, unsigned lane,
                                         const f32x16& Zc, int nc, int hsub, double& s, KsRef& q, uint4& BN) {
     if constexpr (FINE > 0) kz_fine<NCH, FINE, 0>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
     else kz_slots<NCH, 0>(An, Bn, NB, Zn, nn, lane, Zc, nc, hsub, s, q, BN);
@@ -966,6 +970,111 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
     }
     {
         const double v0 = acc0 + __shfl_xor(acc0, 32, 64);          // the two halves hold different previous rows
+        const double v1 = acc1 + __shfl_xor(acc1, 32, 64);
+        const size_t i0 = (it0 + 0) * 32 + (lane & 31), i1 = (it0 + 1) * 32 + (lane & 31);
+        if (lane < 32 && i0 < kn) part[(size_t)sl * kn + i0] = v0;
+        if (lane < 32 && i1 < kn) part[(size_t)sl * kn + i1] = v1;
+    }
+}
+
+// 33..64 parameters with the previous tiles STAGED IN LDS (round 6).  k_kde_split keeps two operand sets of the previous tiles in
+// registers (2 x 17 x 4) beside the two resident column sets (2 x 64): 354 registers, one wave per SIMD, the compiler parks operands
+// in accumulation registers -- its MFMA costs 25 % more time than at 32 parameters.  Here a work-group's four waves share ONE copy of
+// the tile in LDS (they all walk the same tiles), double-buffered; an MFMA's A operand is a ds_read_b128 in front of it, and the
+// kernel fits two waves per SIMD, so one wave's LDS latency and vector work sit under the other's MFMAs.  The chain, its order and
+// every operand are k_kde_split's: the sums are bit-identical.  One barrier per tile: the buffer written in pass t (behind the first
+// step) was last read in the first step of pass t - 1, which every wave has left when any wave is past pass t - 1's barrier.
+struct KsLdsOps {
+    const uint4* p;                                              // the tile's base in LDS + lane
+    __device__ __forceinline__ const uint4& operator[](int i) const { return p[i * 64]; }
+};
+#ifndef KDE_LDS_F4
+#define KDE_LDS_F4 0
+#endif
+#ifndef KDE_LDS_W3
+#define KDE_LDS_W3 3
+#endif
+template <int NCH, int WPS, int FINE>
+__global__ __launch_bounds__(256, WPS) void k_kde_split_lds(const uint4* __restrict__ at, size_t kn,
+                                                          const uint4* __restrict__ bt, unsigned nbt,
+                                                          const WConst* __restrict__ wc, const int* __restrict__ ha_int,
+                                                          double* __restrict__ part, const uint2* __restrict__ tmin) {
+    if (!ks_split_on(wc)) return;                             // the fp64 kernel's turn
+    constexpr int OPA = kz_nch<NCH>() * KS_NL, OPB = OPA + (kz_fold<NCH>() ? 0 : 1);
+    constexpr int OPT = kz_topn<NCH>() ? 1 : 0;
+    constexpr int TILE = (OPB + OPT) * 64, NR = OPA / 4;      // NR rounds of 256 words: the limb operands
+    __shared__ uint4 sA[2 * TILE];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
+    const unsigned slices = gridDim.y, sl = blockIdx.y;
+    const unsigned t0 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * sl / slices));
+    const unsigned t1 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)nbt * (sl + 1) / slices));
+    uint4 B0[OPA], B1[OPA];
+#pragma unroll
+    for (int q = 0; q < OPA; q++) {
+        B0[q] = at[((it0 + 0) * OPA + q) * 64 + lane];
+        B1[q] = at[((it0 + 1) * OPA + q) * 64 + lane];
+    }
+    uint4 NB[2];
+    NB[0] = (lane < 32) ? make_uint4(KS_MONE | (KS_MONE << 16), KS_MONE, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    NB[1] = (lane < 32) ? make_uint4(0u, KS_MONE << 16, KS_MONE | (KS_MONE << 16), 0u) : make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (kz_fold<NCH>()) {
+        const bool mine = (lane < 32) == (((lane & 31u) & 4u) == 0u);
+        NB[0] = make_uint4(0u, 0u, 0u, mine ? (KS_MONE | (KS_MONE << 16)) : 0u);
+    }
+    const int hs0 = ha_int[(it0 + 0) * 32 + (lane & 31)], hs1 = ha_int[(it0 + 1) * 32 + (lane & 31)];
+    double acc0 = 0.0, acc1 = 0.0;
+    if (t0 < t1) {                                              // (uniform over the work-group: the barriers below are too)
+        uint4 r[NR], r4 = make_uint4(0u, 0u, 0u, 0u);
+        uint2 ti = make_uint2(0u, 0u);
+        // a tile is OPB x 64 consecutive 16-byte words; 256 threads fetch it in rounds and write it where it came from
+        // (the limb operands are NR whole rounds of the work-group; the norm operand -- plain and KS_TOPN variants -- is wave 0's extra word)
+        static_assert(OPA * 64 == NR * 256, "a tile's limb operands are whole rounds of the work-group");
+#define KZ_TILE_FETCH(T)                                                                                            \
+        {                                                                                                           \
+            const uint4* src = bt + (size_t)(T) * (OPB * 64) + threadIdx.x;                                         \
+            _Pragma("unroll") for (int j = 0; j < NR; j++) r[j] = src[256 * j];                                     \
+            if constexpr (OPB > OPA) { if (threadIdx.x < 64) r4 = src[256 * NR]; }                                  \
+            if constexpr (OPT) { if (threadIdx.x < 64) ti = tmin[(T)]; }                                            \
+        }
+#define KZ_TILE_STORE(BUF)                                                                                          \
+        {                                                                                                           \
+            uint4* dst = sA + (BUF) * TILE + threadIdx.x;                                                           \
+            _Pragma("unroll") for (int j = 0; j < NR; j++) dst[256 * j] = r[j];                                     \
+            if constexpr (OPB > OPA) { if (threadIdx.x < 64) dst[256 * NR] = r4; }                                  \
+            if constexpr (OPT) { if (threadIdx.x < 64) dst[OPB * 64] = make_uint4(ti.x, ti.y, 0u, 0u); }            \
+        }
+        KZ_TILE_FETCH(t0)
+        KZ_TILE_STORE(0)
+        __syncthreads();
+        f32x16 Z0, Z1;
+        int n0 = 0, n1 = 0;
+        uint4 BN = make_uint4(0u, 0u, 0u, 0u);
+        unsigned cur = 0;
+        {   // (t0, columns 0): the whole chain up front
+            constexpr int NA = kz_nexact<NCH>();
+            const KsLdsOps A{sA + lane};
+            kz_mfma_range<NCH, 0, NA>(A, B0, NB, BN, Z0);
+            kz_reference<NCH>(Z0, A, NB[0], lane, n0, BN);
+            kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
+        }
+        for (unsigned t = t0; t < t1; t++) {
+            const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass stages its own tile once more (no branch); unused
+            KZ_TILE_FETCH(tn)
+            __builtin_amdgcn_sched_barrier(0);
+            const KsLdsOps A{sA + cur * TILE + lane}, An{sA + (cur ^ 1u) * TILE + lane};
+            KsRef q;
+            kz_step<NCH, FINE>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
+            KZ_TILE_STORE(cur ^ 1u)
+            __syncthreads();
+            kz_step<NCH, FINE>(An, B0, NB, Z0, n0, lane, Z1, n1, hs1, acc1, q, BN);     // matrix: (t+1, columns 0); vector: (t, columns 1)
+            cur ^= 1u;
+        }
+#undef KZ_TILE_FETCH
+#undef KZ_TILE_STORE
+    }
+    {
+        const double v0 = acc0 + __shfl_xor(acc0, 32, 64);
         const double v1 = acc1 + __shfl_xor(acc1, 32, 64);
         const size_t i0 = (it0 + 0) * 32 + (lane & 31), i1 = (it0 + 1) * 32 + (lane & 31);
         if (lane < 32 && i0 < kn) part[(size_t)sl * kn + i0] = v0;
@@ -1266,11 +1375,20 @@ static bool ks_topn_on(size_t P, bool split, bool fold, size_t pairs) {
     return (double)pairs >= minp;
 }
 
-// up to 13 / 17..29 / 33..61 parameters: the variants of the split kernel with two MFMAs fewer (norm pieces in the spare K-slots: KS_FOLD)
+// 33..64 parameters: the previous tiles staged in LDS (k_kde_split_lds; ABC_KDE_LDS=0 under ABC_DIAG: the register-resident kernel of
+// rounds 3-5), and with it three stored chunks instead of four at 33..48 parameters (ABC_KDE_CHUNKS3=0: four)
+static bool ks_lds_on() {
+    static const bool on = [] { const char* e = abc_diag_env("ABC_KDE_LDS"); return !e || atoi(e) != 0; }();
+    return on;
+}
+static int ks_chunks(size_t P) {
+    static const bool three = [] { const char* e = abc_diag_env("ABC_KDE_CHUNKS3"); return !e || atoi(e) != 0; }();
+    return (P <= 16) ? 1 : (P <= 32) ? 2 : (P <= 48 && three && ks_lds_on()) ? 3 : 4;
+}
+// up to 13 / 17..29 / 33..45 / 49..61 parameters: the variants of the split kernel with two MFMAs fewer (norm pieces in the spare K-slots: KS_FOLD)
 static bool ks_fold_on(size_t P, bool split) {
     static const bool off = abc_diag_env("ABC_KDE_NOFOLD") != nullptr;              // A/B switch for measurements
-    const size_t nch = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
-    return split && P + 3 <= 16 * nch && !off;                                // three spare K-slots in the last chunk
+    return split && P + 3 <= (size_t)16 * ks_chunks(P) && !off;               // three spare K-slots in the last chunk
 }
 
 int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* theta_prev, size_t Kp, const double* w_prev,
@@ -1282,7 +1400,7 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
     int PP = 2;
     while (PP < (int)P) PP *= 2;
     if (P > 64) PP = (int)((P + 63) / 64 * 64);
-    const int NCH = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
+    const int NCH = ks_chunks(P);                                   // (3: dealt out as four, three stored)
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
     const bool split = (PP >= 8 && P <= 64 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32;
@@ -1334,6 +1452,9 @@ int launch_weights_prev(abc_ctx* ctx, size_t P, size_t kn_max, const double* the
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((rbp / 16 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
                                w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0, (const unsigned*)rank, topf);
+        else if (NCH == 3)
+            hipLaunchKernelGGL((k_wrows<4, 3>), dim3((unsigned)((rbp / 8 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
+                               w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0, (const unsigned*)rank, topf);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((rbp / 8 + 3) / 4)), dim3(256), 0, s, theta_prev, Kp, Kp, (int)P, PP, rbp, wc,
                                w_prev, 1, b, hb, bt, opb, (unsigned char*)nullptr, far_list, (int*)nullptr, (double*)nullptr, fold ? 1 : 0, (const unsigned*)rank, topf);
@@ -1371,7 +1492,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
     if (slices > 1024) slices = 1024;
     // split-operand kernel: 5 <= P <= 64 parameters (padded width 8, 16, 32 or 64: one, two or four 16-parameter chunks; below
     // that the fp64 body is as short), unless the caller asked for fp64
-    const int NCH = (P <= 16) ? 1 : (P <= 32) ? 2 : 4;
+    const int NCH = ks_chunks(P);
     const bool epan = ctx->weight_kernel == ABC_WEIGHT_EPANECHNIKOV;
     const bool split = (PP >= 8 && P <= 64 && ctx->kde_mode != ABC_KDE_FP64 && !epan);
     const size_t nbt = (Kp + 31) / 32, nat = rb * 8;
@@ -1424,6 +1545,9 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         else if (NCH == 2)
             hipLaunchKernelGGL(k_wrows<2>, dim3((unsigned)((ra / 16 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
                                wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0, (const unsigned*)nullptr, (float*)nullptr);
+        else if (NCH == 3)
+            hipLaunchKernelGGL((k_wrows<4, 3>), dim3((unsigned)((ra / 8 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
+                               wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0, (const unsigned*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL(k_wrows<4>, dim3((unsigned)((ra / 8 + 3) / 4)), dim3(256), 0, ctx->stream, theta + k0, kn, K, (int)P, PP, ra,
                                wc, (const double*)nullptr, 0, a, (double*)nullptr, at, opa, far_flag, far_list, ha_int, ha_frac, fold ? 1 : 0, (const unsigned*)nullptr, (float*)nullptr);
@@ -1452,6 +1576,7 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
 #undef LAUNCH_EPAN
     } else {
         StageTimer tk(ctx, ST_KDE);
+        const bool kde_lds = ks_lds_on();
         if (split) {
             // three waves per SIMD at 16 parameters (129 VGPRs; four, with two spills: no faster), two at 32 (192)
             // ... one at 64 (more than 256 registers: the two resident column operand sets alone are 128)
@@ -1466,6 +1591,12 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             else if (fold && NCH == 2)      // (17..29: thirteen instead of fifteen)
                 hipLaunchKernelGGL((k_kde_split<KS_FOLD + 2, 2, false, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (fold && NCH == 3)      // (33..45: three chunks, nineteen MFMAs per 1024 pairs; previous tiles in LDS, two waves per SIMD)
+                hipLaunchKernelGGL((k_kde_split_lds<KS_FOLD + 3, KDE_LDS_W3, KDE_LDS_F4>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (fold && kde_lds)       // (49..61 with the previous tiles in LDS: twenty-five)
+                hipLaunchKernelGGL((k_kde_split_lds<KS_FOLD + 4, 2, KDE_LDS_F4>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (fold)                  // (33..61: twenty-five instead of twenty-seven)
                 hipLaunchKernelGGL((k_kde_split<KS_FOLD + 4, 1, true, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
@@ -1475,6 +1606,12 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
             else if (prev->tmin && NCH == 2)      // (30..32: fourteen instead of fifteen)
                 hipLaunchKernelGGL((k_kde_split<KS_TOPN + 2, 2, false, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (prev->tmin && NCH == 3)      // (46..48: twenty)
+                hipLaunchKernelGGL((k_kde_split_lds<KS_TOPN + 3, KDE_LDS_W3, KDE_LDS_F4>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (prev->tmin && kde_lds)       // (62..64: twenty-six)
+                hipLaunchKernelGGL((k_kde_split_lds<KS_TOPN + 4, 2, KDE_LDS_F4>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (prev->tmin)                  // (62..64: twenty-six instead of twenty-seven)
                 hipLaunchKernelGGL((k_kde_split<KS_TOPN + 4, 1, true, 0>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
@@ -1483,6 +1620,12 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else if (NCH == 2)
                 hipLaunchKernelGGL((k_kde_split<2, 2>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (NCH == 3)
+                hipLaunchKernelGGL((k_kde_split_lds<3, KDE_LDS_W3, KDE_LDS_F4>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
+                                   (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
+            else if (kde_lds)
+                hipLaunchKernelGGL((k_kde_split_lds<4, 2, KDE_LDS_F4>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,
                                    (const uint4*)at, kn, (const uint4*)bt, (unsigned)nbt, wc, (const int*)ha_int, part, (const uint2*)prev->tmin);
             else
                 hipLaunchKernelGGL((k_kde_split<4, 1>), dim3((unsigned)rb, (unsigned)slices), dim3(256), 0, ctx->stream,

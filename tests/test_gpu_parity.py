@@ -399,7 +399,7 @@ def _weights_case(P, K, Kp, seed):
 #   fp64 vector kernel                      1e-9  (measured ~1e-12)
 #   split-operand matrix-pipe kernel (auto)  2.5e-7 (<= 2e-8 absolute in the base-2 exponent of a term; north star: 1e-6)
 #   ... at 17..32 parameters (two chunks)    3e-7 } (the limb products left out, h1.r2' + r2.h1', grow with sqrt(P))
-#   ... at 33..64 parameters (four chunks)   7e-7 }
+#   ... at 33..64 parameters (three / four chunks)   7e-7 }
 # Largest error over ~15 000 weights per parameter count, every count from 5 to 64, far rows, zero and sixty-binade weights
 # (tests/fuzz/kde_accuracy_sweep.py -> profiles/history/r03_kde_accuracy.json): 2.15e-7 up to 16 parameters, 2.43e-7 at 17..32, 4.1e-7 at 33..64;
 # over 980 whole generations at random shapes (tests/fuzz/generation_fuzz.py -> profiles/history/r03_generation_fuzz.json): 3.1e-7 / 3.1e-7 / 5.2e-7.
@@ -431,7 +431,9 @@ class _kde_mode:
                                     (9, 513, 31), (20, 65, 1000), (13, 1, 40), (33, 130, 97), (64, 257, 300), (57, 64, 1030),
                                     (70, 90, 80),
                                     # either side of the parameter counts up to which the norm pieces ride in spare K-slots (13, 29, 61)
-                                    (13, 200, 333), (14, 200, 333), (29, 150, 260), (30, 150, 260), (61, 100, 140), (62, 100, 140)])
+                                    (13, 200, 333), (14, 200, 333), (29, 150, 260), (30, 150, 260), (61, 100, 140), (62, 100, 140),
+                                    # ... and of the three-chunk kernels of round 6 (33..45 folded, 46..48 not, 49 four chunks again)
+                                    (45, 100, 140), (46, 100, 140), (49, 100, 140)])
 def test_weight_predictive_prior(gpu_ctx, oracle, P, K, Kp, mode):
     from abcsmc_amd import abcutil, _lib
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 77 + P)
@@ -538,11 +540,12 @@ def test_weight_split_kernel_with_tiles_in_the_order_of_the_norm_tops(gpu_ctx, o
     assert np.max(np.abs(w - w_plain)[ok] / ref[ok]) < 2 * _kde_tol("auto", P)
 
 
-@pytest.mark.parametrize("P,K,Kp", [(40, 2100, 3000), (64, 1500, 4100)])
+@pytest.mark.parametrize("P,K,Kp", [(40, 2100, 3000), (64, 1500, 4100), (47, 1100, 2100)])
 def test_weight_split_kernel_accuracy_at_33_to_64_parameters(gpu_ctx, oracle, P, K, Kp):
-    """33..64 parameters: four 16-parameter chunks per pair (27 matrix instructions per 1024 pairs, one wave per SIMD, the two
-    operand sets of the previous tiles trading places), many tiles and column slices, an odd and an even number of previous
-    tiles per slice; against the oracle and the fp64 kernel, with previous weights of exactly 0 and one far row on each side"""
+    """33..64 parameters: three (up to 48 parameters, round 6) or four 16-parameter chunks per pair (19-21 / 25-27 matrix instructions
+    per 1024 pairs), the previous tiles staged in LDS and shared by a work-group's waves, many tiles and column slices, an odd and
+    an even number of previous tiles per slice; against the oracle and the fp64 kernel, with previous weights of exactly 0 and one
+    far row on each side"""
     from abcsmc_amd import abcutil, _lib
     wl, th, tp, wp, dv = _weights_case(P, K, Kp, 1000 + P)
     wp = wp.copy()
@@ -563,6 +566,35 @@ def test_weight_split_kernel_accuracy_at_33_to_64_parameters(gpu_ctx, oracle, P,
     print("P = %d split kernel: max rel err %.2e (rms %.2e); fp64 kernel: %.2e" % (P, err.max(), np.sqrt((err ** 2).mean()), err64.max()))
     assert ok.sum() >= K - 1 and err64.max() < 1e-9 and err.max() < _kde_tol("auto", P)
     assert np.array_equal(w == 0, ref == 0)
+
+
+def test_weight_split_kernel_staging_does_not_change_the_sums():
+    """33..64 parameters since round 6: the previous tiles are staged in LDS (k_kde_split_lds, two or three waves per SIMD) instead
+    of being held in registers (k_kde_split, one wave per SIMD), and up to 48 parameters three chunks are stored and multiplied
+    instead of four.  The staging changes where an operand comes from, not one matrix step: at 49..64 parameters the weights are the
+    register kernel's BIT FOR BIT, and so are the four-chunk LDS kernel's at 33..48; the three-chunk kernels (the fourth chunk's
+    products were exact zeros; the norm pieces ride in another chunk's spare slots up to 45 parameters, and 46..48 lose the folded
+    variant) agree with them far inside the kernel's error budget.  One process per setting: the switches are read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    counts = ["33", "40", "45", "46", "48", "49", "57", "61", "62", "64"]
+
+    def run(**env):
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "_kde_worker.py")] + counts, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, ABC_DIAG="1", **env), cwd=root)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        rows = [l.split() for l in p.stdout.splitlines() if l.startswith("KDE ")]
+        assert [r[1] for r in rows] == counts
+        return {int(r[1]): (r[2], float(r[3])) for r in rows}
+    built, four, regs = run(), run(ABC_KDE_CHUNKS3="0"), run(ABC_KDE_LDS="0")
+    for P in (int(c) for c in counts):
+        assert four[P][0] == regs[P][0], P                                  # LDS staging alone: the same bits
+        if P > 48:
+            assert built[P][0] == regs[P][0], P
+        else:
+            assert abs(built[P][1] / regs[P][1] - 1.0) < 1e-7, (P, built[P][1], regs[P][1])
 
 
 @pytest.mark.parametrize("P", [16, 11])
