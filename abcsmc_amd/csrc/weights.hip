@@ -1579,7 +1579,9 @@ int launch_weights_raw(abc_ctx* ctx, const abc_prior* priors, const double* thet
         const bool kde_lds = ks_lds_on();
         if (split) {
             // three waves per SIMD at 16 parameters (129 VGPRs; four, with two spills: no faster), two at 32 (192)
-            // ... one at 64 (more than 256 registers: the two resident column operand sets alone are 128)
+            // ... one at 64 on this kernel (more than 256 registers: the two resident column operand sets alone are 128) -- which is
+            // why 33..64 parameters go to k_kde_split_lds since round 6: the previous tiles in LDS, two waves per SIMD at four chunks
+            // (194-205 registers), three at three chunks (up to 48 parameters; 163-168): 7.2-7.9 -> 4.2-6.3 ms per 1e10 pairs
             // (16 parameters: the sixteen-slot interleave, reference one slot behind the exact steps: 2.244 -> 2.220 ms per 1e10 pairs,
             // and ON TOP of it the operand sets trading places instead of being copied: -> 2.13-2.17 ms (without the finer interleave
             // the same loop was 2 % slower than the copying one, rounds 2 and 3); at 32 parameters either change and both together are

@@ -82,7 +82,9 @@ int  abc_version(void);
  * max relative on such a partial sum; error budget of a weight that one term dominates (all of it at its worst): 5e-7 up to 16 parameters, 5.5e-7 at 17..32, 8e-7 at 33..64; the fixed-seed tests hold 2.5e-7 / 3e-7 / 7e-7 (largest
  * error over ~15 000 weights per parameter count, every count from 5 to 64: 2.2e-7 / 2.4e-7 / 4.1e-7, profiles/history/r03_kde_accuracy.json; in 980 whole generations at random shapes 3.1e-7 / 3.1e-7 / 5.2e-7, profiles/history/r03_generation_fuzz.json),
  * budget 1e-6; rows it cannot represent exactly are summed in fp64, sets it cannot take fall back by themselves); P < 5 and
- * 64 < P run the fp64 kernel (at 64 parameters it is 8 times slower: 63.5 against 8.0 ms per 1e10 pairs).
+ * 64 < P run the fp64 kernel (at 64 parameters it is 10 times slower: 63.5 against 6.35 ms per 1e10 pairs; round 6: above 32
+ * parameters the previous tiles are staged in LDS -- the same matrix steps on the same operands, the same sums -- and 33..48
+ * parameters take three 16-parameter chunks instead of four).
  * ABC_KDE_FP64: always the fp64 vector kernel (<= 1e-12 relative). */
 enum { ABC_KDE_AUTO = 0, ABC_KDE_FP64 = 1 };
 int  abc_ctx_set_kde_mode(abc_ctx* ctx, int mode);
