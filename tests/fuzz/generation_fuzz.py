@@ -27,7 +27,7 @@ LARGE = bool(os.environ.get("FUZZ_LARGE"))
 ONLY = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None
 rows, fails = [], []
 for case in range(cases):
-    P = int(g.integers(1, 41)) if case % 4 else int(g.choice([1, 2, 4, 5, 8, 13, 14, 16, 17, 29, 30, 32, 33, 48, 61, 62, 64]))
+    P = int(g.integers(1, 41)) if case % 4 else int(g.choice([1, 2, 4, 5, 8, 13, 14, 16, 17, 29, 30, 32, 33, 45, 46, 48, 49, 61, 62, 64]))
     M = int(g.integers(max(2, P // 2), 70))
     N = int(g.integers(600, 6000))
     K = int(g.integers(max(40, 2 * P + 8), max(50, N // 4)))
