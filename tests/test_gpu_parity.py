@@ -505,7 +505,8 @@ def test_weight_split_kernel_accuracy_and_zero_weights(gpu_ctx, oracle, P):
     assert np.max(np.abs(w2 - w) / w) < KDE_TOL["auto"]
 
 
-@pytest.mark.parametrize("P,K,Kp,heavy", [(16, 2500, 6000, False), (14, 1300, 4000, True), (32, 1500, 5000, False), (64, 700, 3000, True)])
+@pytest.mark.parametrize("P,K,Kp,heavy", [(16, 2500, 6000, False), (14, 1300, 4000, True), (32, 1500, 5000, False), (64, 700, 3000, True),
+                                          (48, 900, 3100, True), (46, 700, 2000, False)])      # (three chunks, round 6)
 def test_weight_split_kernel_with_tiles_in_the_order_of_the_norm_tops(gpu_ctx, oracle, monkeypatch, P, K, Kp, heavy):
     """full 16-parameter chunks and enough pairs: the previous set's tiles are filled in the order of the rows' norm tops and the
     kernel subtracts top and batch reference in one MFMA step (KS_TOPN; forced here at a test's size).  Against the oracle and the fp64
