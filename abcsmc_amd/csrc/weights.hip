@@ -984,6 +984,10 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
 // kernel fits two waves per SIMD, so one wave's LDS latency and vector work sit under the other's MFMAs.  The chain, its order and
 // every operand are k_kde_split's: the sums are bit-identical.  One barrier per tile: the buffer written in pass t (behind the first
 // step) was last read in the first step of pass t - 1, which every wave has left when any wave is past pass t - 1's barrier.
+// Three chunks (33..48 parameters; k_wrows<4, 3>): 163-168 registers, THREE waves per SIMD (KDE_LDS_W3; two: + 3 %).  Measured per
+// 1e10 pairs: 64 parameters 7.82 -> 6.35 ms, 48: 7.21 -> 4.92, 33: 7.17 -> 4.16 (profiles/r06_kde_by_parameters.txt); the same
+// staging at 16 / 32 parameters, where the register kernel already holds three / two waves, is 12 % / 6 % slower and is not built;
+// the sixteen-slot interleave (KDE_LDS_F4 = 1) costs 2 % here.
 struct KsLdsOps {
     const uint4* p;                                              // the tile's base in LDS + lane
     __device__ __forceinline__ const uint4& operator[](int i) const { return p[i * 64]; }
