@@ -251,9 +251,18 @@ __global__ __launch_bounds__(256) void k_theta_rows(const double* __restrict__ t
 // of x (a quarter of the FMAs).  sL: the padded factor (k_theta_rows), wave-uniform addresses: in k_perturb it lives in
 // global memory and arrives through the scalar cache as SGPR operands of the FMAs (from LDS every FMA needed its own
 // broadcast read: 192 LDS instructions per attempt at 16 parameters).
+template <int PP, int A0>
+__device__ __forceinline__ void mv_cols4(const double* __restrict__ l, const double (&z)[4], double (&x)[PP]) {
+#pragma unroll
+    for (int a = A0; a < PP; a++) {
+        x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
+        x[a] = fma(l[2 * PP + a], z[2], x[a]); x[a] = fma(l[3 * PP + a], z[3], x[a]);
+    }
+}
 template <int PP>
 __device__ __forceinline__ void mv_noise(const double* __restrict__ sL, unsigned long long gi, unsigned attempt, uint32_t k0,
-                                         uint32_t k1, double (&x)[PP]) {
+                                         uint32_t k1, double (&x)[PP], int P) {
+    const int nq = (P + 3) / 4;                                  // column quads that hold anything
 #pragma unroll
     for (int a = 0; a < PP; a++) x[a] = 0.0;
     if constexpr (PP < 4) {
@@ -265,26 +274,24 @@ __device__ __forceinline__ void mv_noise(const double* __restrict__ sL, unsigned
 #pragma unroll
             for (int a = 0; a < PP; a++) x[a] = fma(sL[PP * b + a], z[b], x[a]);
     } else {
-        // columns 4 qd .. 4 qd + 3 of L per Philox block; L is lower triangular, so the blocks of its right half only touch
-        // the lower half of x
+        // columns 4 qd .. 4 qd + 3 of L per Philox block.  L is lower triangular: a column block only touches the rows from its own
+        // first row on -- taken in FOUR row groups from 17 parameters (round 6; two until then, and still at up to 16, where four
+        // cost a wave per SIMD in registers: 5/8 instead of 3/4 of the square's FMAs), the left-out products are exact zeros -- and the padded columns (from P on) hold nothing: their blocks are not drawn
 #pragma unroll 1
-        for (int qd = 0; qd < PP / 4; qd++) {
+        for (int qd = 0; qd < nq; qd++) {
             U4 c; c.x = (uint32_t)gi; c.y = (uint32_t)(gi >> 32); c.z = attempt; c.w = (uint32_t)qd;
             double z[4];
             normal4(philox(c, k0, k1), z);
             const double* l = sL + PP * (4 * qd);
-            if (qd < (PP / 4 + 1) / 2) {
-#pragma unroll
-                for (int a = 0; a < PP; a++) {
-                    x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
-                    x[a] = fma(l[2 * PP + a], z[2], x[a]); x[a] = fma(l[3 * PP + a], z[3], x[a]);
-                }
+            if constexpr (PP >= 32) {
+                const int g = (4 * qd) / (PP / 4);                   // (wave-uniform)
+                if (g == 0) mv_cols4<PP, 0>(l, z, x);
+                else if (g == 1) mv_cols4<PP, PP / 4>(l, z, x);
+                else if (g == 2) mv_cols4<PP, PP / 2>(l, z, x);
+                else mv_cols4<PP, 3 * (PP / 4)>(l, z, x);
             } else {
-#pragma unroll
-                for (int a = PP / 2; a < PP; a++) {
-                    x[a] = fma(l[a], z[0], x[a]); x[a] = fma(l[PP + a], z[1], x[a]);
-                    x[a] = fma(l[2 * PP + a], z[2], x[a]); x[a] = fma(l[3 * PP + a], z[3], x[a]);
-                }
+                if (qd < (PP / 4 + 1) / 2) mv_cols4<PP, 0>(l, z, x);
+                else mv_cols4<PP, PP / 2>(l, z, x);
             }
         }
     }
@@ -327,11 +334,12 @@ __global__ __launch_bounds__(256, (MV && PP <= 16) ? 3 : (PP <= 16 ? 2 : 1)) voi
     if (MV) {
         // AbcUtil.cpp:132-139: draw the whole vector x = mu + L z, accept iff every coordinate is valid
         for (unsigned attempt = 0; attempt < MVN_MAX_TRIES; attempt++) {
-            mv_noise<PP>(L_or_dv, gi, attempt, k0, k1, x);
+            mv_noise<PP>(L_or_dv, gi, attempt, k0, k1, x, P);
             bool ok = true;
             asm volatile("" ::: "memory");      // the prior table is re-read from LDS here (hoisted out of the loop it costs 96 VGPRs)
 #pragma unroll
             for (int a = 0; a < PP; a += 2) {
+                if (PP > 32 && a >= P) continue;      // (33..64 parameters share the 64-wide kernel: nothing to add, test or store from P on)
                 const double2 m = *reinterpret_cast<const double2*>(mrow + a);
                 x[a] = recast_valid(sp[a], sinv[a], x[a] + m.x, ok);
                 x[a + 1] = recast_valid(sp[a + 1], sinv[a + 1], x[a + 1] + m.y, ok);
@@ -368,9 +376,11 @@ __global__ __launch_bounds__(256, (MV && PP <= 16) ? 3 : (PP <= 16 ? 2 : 1)) voi
     }
 }
 
-// 32 < P <= 64: same draws and acceptance rule as k_perturb, but only the accumulators x[PP] live in registers;
-// the parent row is re-read (one cached line per 16 coordinates) and accepted coordinates are stored as they are
-// produced -- a rejected attempt is simply overwritten by the next one.
+// 32 < P <= 64, INDEPENDENT noise (multivariate noise runs on k_perturb<64> since round 6: this kernel's multivariate branch kept the
+// factor in LDS -- one broadcast read per FMA, the full 64 x 64 square, 255 registers, one wave per SIMD -- and took 1.1-2.5 ms for
+// 1e6 proposals at 40-64 parameters where k_perturb<64> takes 0.39-1.05; the draws, their order and the acceptance rule are the same,
+// the proposals bit-identical): same draws and acceptance rule as k_perturb; the parent row is re-read (one cached line per 16
+// coordinates) and accepted coordinates are stored as they are produced -- a rejected attempt is simply overwritten by the next one.
 template <int PP, bool MV>
 __global__ __launch_bounds__(256) void k_perturb_stream(abc_rng key, const double* __restrict__ theta, size_t K, int P,
                                                         const abc_prior* __restrict__ priors,
@@ -857,14 +867,14 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
     if (!rows) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
     const double* Lpad = (prep && prep->rows) ? prep->Lpad : nullptr;
     if (!(prep && prep->rows)) {
-        const bool need_lp = multivariate && (PP <= 32 || PP > 64);
+        const bool need_lp = multivariate != 0;
         double* lp = need_lp ? (double*)abc_ws_alloc(ctx, (size_t)PP * PP * sizeof(double)) : nullptr;
         if (need_lp && !lp) ABC_FAIL(ctx, ABC_ERR_NOMEM, "perturb: workspace exhausted");
         ABC_TRY(launch_theta_rows(ctx, theta, K, P, PP, rows, lp ? L_or_dv : nullptr, lp));
         Lpad = lp;
     }
     theta = rows;
-    if (multivariate && (PP <= 32 || PP > 64) && !Lpad) ABC_FAIL(ctx, ABC_ERR_INVALID, "perturb: the padded factor was not prepared");
+    if (multivariate && !Lpad) ABC_FAIL(ctx, ABC_ERR_INVALID, "perturb: the padded factor was not prepared");
     if (PP > 64) {
         const size_t lds = P * sizeof(abc_prior);
         if (multivariate)
@@ -894,19 +904,16 @@ int launch_perturb(abc_ctx* ctx, const abc_rng* rng, const double* theta, size_t
         case 8: LAUNCH_PT(8); break;
         case 16: LAUNCH_PT(16); break;
         case 32: LAUNCH_PT(32); break;
-        default: {
-            if (multivariate) {
-                const size_t lds = (64 * 64) * sizeof(double) + 64 * sizeof(abc_prior);
-                hipLaunchKernelGGL((k_perturb_stream<64, true>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
-                                   (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,
-                                   ctx->giveups_dev);
+        default:                               // 33..64 parameters
+            if (multivariate) {                // (until round 6: k_perturb_stream, the factor in LDS, one read per FMA, one wave per SIMD)
+                LAUNCH_PT(64);
             } else {
                 const size_t lds = 64 * sizeof(double) + 64 * sizeof(abc_prior);
                 hipLaunchKernelGGL((k_perturb_stream<64, false>), dim3(blocks), dim3(256), lds, ctx->stream, *rng, theta, K,
                                    (int)P, priors, (const unsigned long long*)parent, (unsigned long long)i0, n, L_or_dv, out,
                                    ctx->giveups_dev);
             }
-        } break;
+            break;
     }
 #undef LAUNCH_PT
     ABC_HIP(ctx, hipGetLastError());

@@ -1189,10 +1189,11 @@ def test_generation_reports_giveups_through_a_count_not_a_status(gpu_ctx):
     assert gpu_ctx.perturb_giveups(reset=True) == Nn
 
 
-@pytest.mark.parametrize("multivariate,P", [(True, 48), (False, 48), (True, 150), (False, 150)])
+@pytest.mark.parametrize("multivariate,P", [(True, 48), (False, 48), (True, 150), (False, 150), (True, 64), (True, 47)])
 def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate, P):
-    """33..64 parameters take the streaming perturb kernel, more than 64 the chunked one (the reference's loops have no size
-    limit): same parents, same support rules, same spread"""
+    """33..64 parameters: multivariate noise on the 64-wide instance of the proposal kernel (round 6; the factor through the scalar
+    cache, the padded columns not drawn), independent noise on the streaming kernel; more than 64 the chunked one (the reference's
+    loops have no size limit): same parents, same support rules, same spread"""
     from abcsmc_amd import abcutil, _lib
     rng = np.random.default_rng(23)
     K, n = 500, 30000
@@ -1228,6 +1229,7 @@ def test_samplers_wide_parameter_sets(gpu_ctx, oracle, multivariate, P):
     if multivariate:      # the proposal keeps the posterior's correlations
         dg, do = out - th[parent.astype(int)], oout - th[opar.astype(int)]
         assert np.allclose(np.corrcoef(dg[:, [0, 3, 6, 45]].T), np.corrcoef(do[:, [0, 3, 6, 45]].T), atol=0.04)
+        assert np.allclose(np.corrcoef(dg[:, [1, P - 2, P - 1]].T), np.corrcoef(do[:, [1, P - 2, P - 1]].T), atol=0.04)     # (the last columns of the factor)
 
 
 # ---------------------------------------------------------------------------------------------------
