@@ -988,9 +988,14 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
 // 1e10 pairs: 64 parameters 7.82 -> 6.35 ms, 48: 7.21 -> 4.92, 33: 7.17 -> 4.16 (profiles/r06_kde_by_parameters.txt); the same
 // staging at 16 / 32 parameters, where the register kernel already holds three / two waves, is 12 % / 6 % slower and is not built;
 // the sixteen-slot interleave (KDE_LDS_F4 = 1) costs 2 % here.
+// (INFO: the index of the tile's info word -- KS_TOPN: its smallest top and the mask -- or -1.  That word is wave-uniform and is
+// needed at the head of a chain, in front of a branch: it travels in scalar registers, fetched from the info array itself, instead of
+// through LDS like the operands -- the chain then starts without a wait on LDS)
+template <int INFO>
 struct KsLdsOps {
     const uint4* p;                                              // the tile's base in LDS + lane
-    __device__ __forceinline__ const uint4& operator[](int i) const { return p[i * 64]; }
+    uint4 info;
+    __device__ __forceinline__ const uint4& operator[](int i) const { return (INFO >= 0 && i == INFO) ? info : p[i * 64]; }
 };
 #ifndef KDE_LDS_F4
 #define KDE_LDS_F4 0
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split_lds(const uint4* __restr
     if (!ks_split_on(wc)) return;                             // the fp64 kernel's turn
     constexpr int OPA = kz_nch<NCH>() * KS_NL, OPB = OPA + (kz_fold<NCH>() ? 0 : 1);
     constexpr int OPT = kz_topn<NCH>() ? 1 : 0;
-    constexpr int TILE = (OPB + OPT) * 64, NR = OPA / 4;      // NR rounds of 256 words: the limb operands
+    constexpr int TILE = OPB * 64, NR = OPA / 4;      // NR rounds of 256 words: the limb operands
     __shared__ uint4 sA[2 * TILE];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t it0 = ((size_t)blockIdx.x * 4 + wv) * 2;
@@ -1030,7 +1035,6 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split_lds(const uint4* __restr
     double acc0 = 0.0, acc1 = 0.0;
     if (t0 < t1) {                                              // (uniform over the work-group: the barriers below are too)
         uint4 r[NR], r4 = make_uint4(0u, 0u, 0u, 0u);
-        uint2 ti = make_uint2(0u, 0u);
         // a tile is OPB x 64 consecutive 16-byte words; 256 threads fetch it in rounds and write it where it came from
         // (the limb operands are NR whole rounds of the work-group; the norm operand -- plain and KS_TOPN variants -- is wave 0's extra word)
         static_assert(OPA * 64 == NR * 256, "a tile's limb operands are whole rounds of the work-group");
@@ -1039,14 +1043,12 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split_lds(const uint4* __restr
             const uint4* src = bt + (size_t)(T) * (OPB * 64) + threadIdx.x;                                         \
             _Pragma("unroll") for (int j = 0; j < NR; j++) r[j] = src[256 * j];                                     \
             if constexpr (OPB > OPA) { if (threadIdx.x < 64) r4 = src[256 * NR]; }                                  \
-            if constexpr (OPT) { if (threadIdx.x < 64) ti = tmin[(T)]; }                                            \
         }
 #define KZ_TILE_STORE(BUF)                                                                                          \
         {                                                                                                           \
             uint4* dst = sA + (BUF) * TILE + threadIdx.x;                                                           \
             _Pragma("unroll") for (int j = 0; j < NR; j++) dst[256 * j] = r[j];                                     \
             if constexpr (OPB > OPA) { if (threadIdx.x < 64) dst[256 * NR] = r4; }                                  \
-            if constexpr (OPT) { if (threadIdx.x < 64) dst[OPB * 64] = make_uint4(ti.x, ti.y, 0u, 0u); }            \
         }
         KZ_TILE_FETCH(t0)
         KZ_TILE_STORE(0)
@@ -1057,7 +1059,8 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split_lds(const uint4* __restr
         unsigned cur = 0;
         {   // (t0, columns 0): the whole chain up front
             constexpr int NA = kz_nexact<NCH>();
-            const KsLdsOps A{sA + lane};
+            KsLdsOps<OPT ? OPB : -1> A{sA + lane, make_uint4(0u, 0u, 0u, 0u)};
+            if constexpr (OPT) { const uint2 ti = tmin[t0]; A.info = make_uint4(ti.x, ti.y, 0u, 0u); }
             kz_mfma_range<NCH, 0, NA>(A, B0, NB, BN, Z0);
             kz_reference<NCH>(Z0, A, NB[0], lane, n0, BN);
             kz_mfma_range<NCH, NA, kz_nsteps<NCH>()>(A, B0, NB, BN, Z0);
@@ -1066,7 +1069,12 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split_lds(const uint4* __restr
             const unsigned tn = (t + 1 < t1) ? t + 1 : t;      // the last pass stages its own tile once more (no branch); unused
             KZ_TILE_FETCH(tn)
             __builtin_amdgcn_sched_barrier(0);
-            const KsLdsOps A{sA + cur * TILE + lane}, An{sA + (cur ^ 1u) * TILE + lane};
+            KsLdsOps<OPT ? OPB : -1> A{sA + cur * TILE + lane, make_uint4(0u, 0u, 0u, 0u)}, An{sA + (cur ^ 1u) * TILE + lane, make_uint4(0u, 0u, 0u, 0u)};
+            if constexpr (OPT) {
+                const uint2 ti = tmin[t], tj = tmin[tn];       // (wave-uniform addresses: scalar loads)
+                A.info = make_uint4(ti.x, ti.y, 0u, 0u);
+                An.info = make_uint4(tj.x, tj.y, 0u, 0u);
+            }
             KsRef q;
             kz_step<NCH, FINE>(A, B1, NB, Z1, n1, lane, Z0, n0, hs0, acc0, q, BN);      // matrix: (t, columns 1); vector: (t, columns 0)
             KZ_TILE_STORE(cur ^ 1u)
