@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256, WPS) void k_kde_split(const uint4* __restrict_
 // step) was last read in the first step of pass t - 1, which every wave has left when any wave is past pass t - 1's barrier.
 // Three chunks (33..48 parameters; k_wrows<4, 3>): 163-168 registers, THREE waves per SIMD (KDE_LDS_W3; two: + 3 %).  Measured per
 // 1e10 pairs: 64 parameters 7.82 -> 6.35 ms, 48: 7.21 -> 4.92, 33: 7.17 -> 4.16 (profiles/r06_kde_by_parameters.txt); the same
-// staging at 16 / 32 parameters, where the register kernel already holds three / two waves, is 12 % / 6 % slower and is not built;
+// staging at 16 / 32 parameters, where the register kernel already holds three / two waves, is 7-12 % / 3.5-6 % slower and is not built;
 // the sixteen-slot interleave (KDE_LDS_F4 = 1) costs 2 % here.
 // (INFO: the index of the tile's info word -- KS_TOPN: its smallest top and the mask -- or -1.  That word is wave-uniform and is
 // needed at the head of a chain, in front of a branch: it travels in scalar registers, fetched from the info array itself, instead of
